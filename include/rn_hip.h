@@ -1,0 +1,253 @@
+/*
+ * rn_hip.h -- C ABI of librn_hip.so: the MI355X (gfx950) kernels behind the RetinaNet hot path.
+ *
+ * The reference (vshmyhlo/retinanet-tensorflow) has no FFI seam: its model/loss code calls
+ * TensorFlow kernels directly.  This library is the drop-in for exactly those kernels; every
+ * entry point cites the reference call site(s) whose TF op it replaces.  The Python host side
+ * (retinanet-tensorflow_amd/) binds it with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void*.
+ *   - all tensors are dense fp32, NHWC activations, HWIO conv kernels, [kh,kw,C] depthwise.
+ *   - the caller owns every buffer (including workspaces); the library never allocates device
+ *     memory, never synchronises and keeps no pointer after a call returns: every call only
+ *     enqueues work on `stream` (hipGraph-capturable).
+ *   - return value: 0 (RN_OK) or a negative rn_status; rn_last_error() has the text.
+ *   - "segments": several independent problems that share one weight / one parameter set are
+ *     passed as an array and run in ONE launch (the shared heads over P3..P7,
+ *     reference retinanet.py:283-291).
+ */
+#ifndef RN_HIP_H
+#define RN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rn_stream_t;
+
+enum rn_status {
+  RN_OK = 0,
+  RN_EINVAL = -1,       /* bad argument */
+  RN_EUNSUPPORTED = -2, /* shape outside what the kernels cover */
+  RN_EHIP = -3,         /* HIP runtime error at launch */
+  RN_EWORKSPACE = -4    /* workspace too small */
+};
+
+enum rn_act { RN_ACT_NONE = 0, RN_ACT_RELU = 1, RN_ACT_ELU = 2, RN_ACT_RELU6 = 3, RN_ACT_SIGMOID = 4 };
+enum rn_loss_mode { RN_LOSS_BCE_DICE = 0, RN_LOSS_FOCAL = 1 };
+enum rn_opt { RN_OPT_MOMENTUM = 0, RN_OPT_RMSPROP = 1, RN_OPT_ADAM = 2 };
+
+#define RN_MAX_SEG 16
+
+int rn_version(void);
+const char* rn_last_error(void);
+
+/* TF 'SAME' padding rule: out = ceil(n/s); before = max((out-1)s+k-n,0)/2. */
+void rn_same_pad(int n, int k, int s, int* out, int* pad_before);
+
+/* ------------------------------------------------------------------ dense convolution
+ * Replaces tf.layers.Conv2D (Conv2D / Conv2DBackpropInput / Conv2DBackpropFilter kernels):
+ * retinanet.py:39-46,55-62,87-94,100-106,127-145,170-201; mobilenet_v2.py:57-59,75-77,
+ * 112-114,179-181; resnet.py:32-49,67-69,147-149; densenet.py:37,61-70,137,168.
+ * padding='same' always (the reference never uses 'valid'); implicit GEMM on
+ * v_mfma_f32_32x32x2_f32, fp32 in / fp32 accumulate.
+ */
+typedef struct rn_conv_seg {
+  const float* x;    /* fwd,wgrad: input  [n,h,w,cin]                       */
+  const float* wgt;  /* fwd,dgrad: kernel [kh,kw,cin,cout]                  */
+  const float* bias; /* fwd: [cout] or NULL                                 */
+  float* y;          /* fwd: output [n,oh,ow,cout]                          */
+  const float* dy;   /* dgrad,wgrad: grad of output [n,oh,ow,cout]          */
+  float* dx;         /* dgrad: grad of input [n,h,w,cin]                    */
+  int32_t n, h, w;   /* input batch / height / width                        */
+  int32_t cout;      /* may differ per segment in fwd/dgrad                 */
+} rn_conv_seg;
+
+typedef struct rn_conv_geom {
+  int32_t kh, kw, stride, cin;
+} rn_conv_geom;
+
+int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream);
+int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream);
+/* dw[kh,kw,cin,cout] = sum over all segments (they share the kernel: shared heads);
+ * split-K partial slabs go to `workspace`, reduced in fixed order (bitwise reproducible).
+ * If accumulate != 0 the result is added to dw instead of overwriting it. */
+size_t rn_conv2d_wgrad_workspace(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g);
+int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, int accumulate,
+                    void* workspace, size_t workspace_bytes, rn_stream_t stream);
+
+/* dbias[cout] = sum over all segments / pixels of dy (the out_conv biases, retinanet.py:46-53). */
+size_t rn_conv2d_bias_grad_workspace(int cout);
+int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dbias, void* workspace,
+                        size_t workspace_bytes, rn_stream_t stream);
+
+/* ------------------------------------------------------------------ depthwise 3x3
+ * Replaces tf.nn.depthwise_conv2d (DepthwiseConv2dNative + its two backprops),
+ * mobilenet_v2.py:35-36.  Kernel [kh,kw,C] (channel multiplier 1), padding SAME.
+ */
+int rn_depthwise_fwd(const float* x, const float* wgt, float* y, int n, int h, int w, int c, int k, int stride,
+                     rn_stream_t stream);
+int rn_depthwise_dgrad(const float* dy, const float* wgt, float* dx, int n, int h, int w, int c, int k,
+                       int stride, rn_stream_t stream);
+size_t rn_depthwise_wgrad_workspace(int n, int h, int w, int c, int k, int stride);
+int rn_depthwise_wgrad(const float* x, const float* dy, float* dw, int n, int h, int w, int c, int k, int stride,
+                       void* workspace, size_t workspace_bytes, rn_stream_t stream);
+
+/* ------------------------------------------------------------------ GroupNorm (+act, +dropout, +residual)
+ * Replaces normalization.py:20-35 (reshape + tf.nn.moments + affine), the activation that
+ * follows it in every reference Sequential (tf.nn.elu train.py:214 / tf.nn.relu resnet.py:85),
+ * tf.layers.Dropout (mobilenet_v2.py:62,71,79) and the residual add (mobilenet_v2.py:91-92).
+ *   y = dropout(act((x-mean_g)*rstd_g*gamma_c+beta_c)) + residual
+ * Segments share gamma/beta (heads: one layer applied to P3..P7).
+ * mean / rstd ([n, groups] per segment) are outputs of fwd and inputs of bwd.
+ */
+typedef struct rn_gn_seg {
+  const float* x;        /* [n, hw, c] conv output                         */
+  float* y;              /* fwd out                                         */
+  const float* residual; /* fwd: optional, same shape as y, or NULL         */
+  const float* dy;       /* bwd in                                          */
+  float* dx;             /* bwd out                                         */
+  float* mean;           /* [n, groups]                                     */
+  float* rstd;           /* [n, groups]                                     */
+  int32_t n, hw;
+} rn_gn_seg;
+
+typedef struct rn_gn_params {
+  int32_t c, groups, act;
+  float eps;
+  float drop_rate;    /* 0 => no dropout                                    */
+  uint64_t drop_seed; /* counter-based mask: keep iff hash(seed, elem) >= rate            */
+  const uint64_t* drop_seed_dev; /* optional DEVICE counter added to drop_seed (so a replayed
+                                    hipGraph draws a fresh mask every step); may be NULL    */
+} rn_gn_params;
+
+size_t rn_group_norm_workspace(const rn_gn_seg* segs, int nseg, const rn_gn_params* p);
+int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, const float* gamma,
+                      const float* beta, void* workspace, size_t workspace_bytes, rn_stream_t stream);
+/* dgamma/dbeta [c] are OVERWRITTEN with the sum over all segments. */
+int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, const float* gamma,
+                      const float* beta, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                      rn_stream_t stream);
+
+/* ------------------------------------------------------------------ small elementwise ops
+ * activation alone (retinanet.py:180-181 `activation` before the P7 conv) */
+int rn_act_fwd(const float* x, float* y, int64_t count, int act, rn_stream_t stream);
+int rn_act_bwd(const float* x, const float* dy, float* dx, int64_t count, int act, rn_stream_t stream);
+/* y = lateral + nearest_resize(top -> lateral size, align_corners=True); retinanet.py:153-157
+ * (ResizeNearestNeighbor) and its gradient w.r.t. top (sum over the children). */
+int rn_upsample_add_fwd(const float* lateral, const float* top, float* y, int n, int h, int w, int th, int tw, int c,
+                        rn_stream_t stream);
+int rn_upsample_add_bwd_top(const float* dy, float* dtop, int n, int h, int w, int th, int tw, int c,
+                            rn_stream_t stream);
+
+/* ------------------------------------------------------------------ loss
+ * Replaces utils.process_labels_and_logits/postprocess_and_mask (utils.py:240-284; the
+ * boolean_mask compaction becomes a 0/1 row weight, result-identical) and losses.loss
+ * (losses.py:155-175): class loss = BCE+dice (live, :124-139) or focal (:6-15,:119-122),
+ * regression loss = Huber(delta 1) over fg rows / (4*#fg) (:144-152).
+ * Segment = one pyramid level, rows = n*h*w*anchors.
+ */
+typedef struct rn_loss_seg {
+  const float* cls_logit; /* [rows, C]                                      */
+  const float* cls_label; /* [rows, C] one-hot / zeros                      */
+  const float* reg_pred;  /* [rows, 4]                                      */
+  const float* reg_label; /* [rows, 4]                                      */
+  const uint8_t* trainable; /* [rows] 0/1                                   */
+  float* d_cls_logit;     /* bwd out [rows, C]                              */
+  float* d_reg_pred;      /* bwd out [rows, 4]                              */
+  int64_t rows;
+} rn_loss_seg;
+
+/* stats layout (float32, device): [0]=class_loss [1]=regr_loss [2]=M (trainable rows)
+ * [3]=#fg [4]=sum bce [5]=sum focal [6]=sum huber [7]=reserved, then per class c:
+ * [8+3c]=I_c=sum l*sigmoid, [9+3c]=L_c=sum l, [10+3c]=P_c=sum sigmoid. */
+#define RN_LOSS_STATS_HEADER 8
+size_t rn_loss_workspace(const rn_loss_seg* segs, int nseg, int num_classes);
+int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, float* stats, void* workspace,
+                size_t workspace_bytes, rn_stream_t stream);
+/* d(g_cls*class_loss + g_reg*regr_loss)/d(logits); g_* are device scalars (upstream grads). */
+int rn_loss_bwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, const float* stats,
+                const float* g_cls, const float* g_reg, rn_stream_t stream);
+
+/* ------------------------------------------------------------------ anchor assignment
+ * Replaces dataset.level_labels / build_labels (dataset.py:43-142) for a batch of images:
+ * IoU of every anchor with every object -> arg-max/max -> one-hot class (zero where IoU<0.5),
+ * log-space regression target of the arg-max object, trainable = IoU<0.4 || IoU>=0.5.
+ * boxes [nimg, max_obj, 4] normalised corners, class_ids [nimg, max_obj], num_obj [nimg] (>=1).
+ * anchor_sizes [A,2] already divided by the image size (levels.py:38-44, dataset.py:53).
+ */
+int rn_anchor_assign(const float* boxes, const int32_t* class_ids, const int32_t* num_obj, int nimg, int max_obj,
+                     const float* anchor_sizes, int num_anchors, int grid_h, int grid_w, int num_classes,
+                     float* cls_out, float* reg_out, uint8_t* trainable_out, int32_t* argmax_out,
+                     rn_stream_t stream);
+
+/* ------------------------------------------------------------------ decode + NMS
+ * rn_decode_boxes: utils.regression_postprocess (utils.py:108-117): exp, anchor scale, add
+ *   cell centre, centre->corner.  reg [n,h,w,A,4] -> boxes [n,h,w,A,4].
+ * rn_detect_*: utils.boxes_decode + merge_boxes_decoded + nms_classwise (utils.py:183-227,
+ *   tf.image.non_max_suppression max 1000 / IoU>0.5) for a whole batch in one pass.
+ */
+int rn_decode_boxes(const float* reg, const float* anchor_sizes, float* boxes, int n, int h, int w, int num_anchors,
+                    rn_stream_t stream);
+
+typedef struct rn_det_level {
+  const float* prob;  /* [n, rows_per_image, C] class probabilities (post-sigmoid) */
+  const float* boxes; /* [n, rows_per_image, 4] decoded corner boxes               */
+  int64_t rows_per_image;
+} rn_det_level;
+
+typedef struct rn_det_params {
+  int32_t n, num_classes, max_per_class; /* 1000 = utils.NMS_MAX_OUTPUT_SIZE          */
+  float score_threshold, iou_threshold;  /* 0.5 / 0.5                                  */
+  int64_t max_candidates;                /* capacity of the candidate buffers          */
+} rn_det_params;
+
+size_t rn_detect_workspace(const rn_det_level* levels, int nlevels, const rn_det_params* p);
+/* outputs (device): out_boxes [max_candidates,4], out_scores, out_class (int32), out_image (int32),
+ * out_anchor (int64 flat index of the row inside its image, levels concatenated P3..P7):
+ * survivors in (image, class, score-desc, index-asc) order; counts[0]=#candidates,
+ * counts[1]=#survivors, counts[2..2+n) survivors per image. */
+int rn_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, float* out_boxes, float* out_scores,
+              int32_t* out_class, int32_t* out_image, int64_t* out_anchor, int64_t* counts, void* workspace,
+              size_t workspace_bytes, rn_stream_t stream);
+
+/* utils.boxes_decode alone (utils.py:183-195) for a batch: candidates (max prob > threshold) in
+ * row-major anchor order, no sort / NMS.  Same outputs as rn_detect; counts[0]=counts[1]=#candidates. */
+int rn_boxes_decode(const rn_det_level* levels, int nlevels, const rn_det_params* p, float* out_boxes,
+                    float* out_scores, int32_t* out_class, int32_t* out_image, int64_t* out_anchor, int64_t* counts,
+                    void* workspace, size_t workspace_bytes, rn_stream_t stream);
+/* utils.nms_classwise / utils.nms (utils.py:198-220) on already decoded boxes: K = *count_dev
+ * (device scalar) rows of boxes/scores/class_ids/image_ids; p->max_candidates >= K is the buffer
+ * capacity.  Output order (image, class, score desc, index asc); out_index = row of the input. */
+size_t rn_nms_classwise_workspace(const rn_det_params* p);
+int rn_nms_classwise(const float* boxes, const float* scores, const int32_t* class_ids, const int32_t* image_ids,
+                     const int64_t* count_dev, const rn_det_params* p, float* out_boxes, float* out_scores,
+                     int32_t* out_class, int32_t* out_image, int64_t* out_index, int64_t* counts, void* workspace,
+                     size_t workspace_bytes, rn_stream_t stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * Replaces tf.train.{Momentum,RMSProp,Adam}Optimizer.apply + the L2 regulariser gradient
+ * + tf.clip_by_global_norm (train.py:111-134,221) on ONE flat fp32 parameter arena.
+ * The arena is cut into blocks of RN_OPT_BLOCK elements; wd_per_block[b] is the L2 scale of
+ * the parameter that owns block b (0 for gamma/beta/bias and padding).
+ *   g' = grad*grad_scale*clip_scale + wd*w      (grad_scale = 1/world_size)
+ */
+#define RN_OPT_BLOCK 1024
+size_t rn_optimizer_workspace(int64_t count);
+/* out[0] = sum(grad^2)*grad_scale^2 (global norm squared), out[1] = sum_b wd_b * 0.5*sum(w^2) */
+int rn_grad_norm_l2reg(const float* w, const float* grad, const float* wd_per_block, int64_t count,
+                       float grad_scale, float* out2, void* workspace, size_t workspace_bytes, rn_stream_t stream);
+/* clip_norm <= 0 disables clipping; norm_sq is the device scalar from rn_grad_norm_l2reg.
+ * step is 1-based (Adam bias correction). state1/state2: momentum-acc | rms,mom | m,v. */
+int rn_optimizer_step(int kind, float* w, const float* grad, float* state1, float* state2,
+                      const float* wd_per_block, int64_t count, float lr, float grad_scale, float clip_norm,
+                      const float* norm_sq, int64_t step, rn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RN_HIP_H */

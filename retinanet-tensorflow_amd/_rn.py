@@ -1,0 +1,189 @@
+"""ctypes binding of librn_hip.so (C ABI: include/rn_hip.h).
+
+PyTorch-ROCm tensors are only the device-memory / stream / autograd carrier: every call
+below hands raw device pointers and the current HIP stream to a hand-written gfx950
+kernel.  There is no CPU or eager-PyTorch fallback -- a missing library, or a tensor that is
+not a contiguous fp32 device tensor, raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librn_hip.so")
+
+MAX_SEG = 16
+ACT = {None: 0, "none": 0, "linear": 0, "relu": 1, "elu": 2, "relu6": 3, "sigmoid": 4}
+LOSS_MODE = {"bce_dice": 0, "focal": 1}
+OPT = {"momentum": 0, "rmsprop": 1, "adam": 2}
+OPT_BLOCK = 1024
+LOSS_STATS_HEADER = 8
+
+
+class RnError(RuntimeError):
+    pass
+
+
+class ConvSeg(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("wgt", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
+                ("dy", C.c_void_p), ("dx", C.c_void_p),
+                ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cout", C.c_int32)]
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("cin", C.c_int32)]
+
+
+class GnSeg(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("residual", C.c_void_p), ("dy", C.c_void_p),
+                ("dx", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("n", C.c_int32), ("hw", C.c_int32)]
+
+
+class GnParams(C.Structure):
+    _fields_ = [("c", C.c_int32), ("groups", C.c_int32), ("act", C.c_int32), ("eps", C.c_float),
+                ("drop_rate", C.c_float), ("drop_seed", C.c_uint64), ("drop_seed_dev", C.c_void_p)]
+
+
+class LossSeg(C.Structure):
+    _fields_ = [("cls_logit", C.c_void_p), ("cls_label", C.c_void_p), ("reg_pred", C.c_void_p),
+                ("reg_label", C.c_void_p), ("trainable", C.c_void_p), ("d_cls_logit", C.c_void_p),
+                ("d_reg_pred", C.c_void_p), ("rows", C.c_int64)]
+
+
+class DetLevel(C.Structure):
+    _fields_ = [("prob", C.c_void_p), ("boxes", C.c_void_p), ("rows_per_image", C.c_int64)]
+
+
+class DetParams(C.Structure):
+    _fields_ = [("n", C.c_int32), ("num_classes", C.c_int32), ("max_per_class", C.c_int32),
+                ("score_threshold", C.c_float), ("iou_threshold", C.c_float), ("max_candidates", C.c_int64)]
+
+
+_lib = None
+
+# every symbol include/rn_hip.h declares (tests/test_abi.py checks the .so exports them all)
+SYMBOLS = [
+    "rn_version", "rn_last_error", "rn_same_pad",
+    "rn_conv2d_fwd", "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad",
+    "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad",
+    "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad",
+    "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
+    "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
+    "rn_loss_workspace", "rn_loss_fwd", "rn_loss_bwd",
+    "rn_anchor_assign", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
+    "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
+    "rn_optimizer_workspace", "rn_grad_norm_l2reg", "rn_optimizer_step",
+]
+
+
+def lib():
+    """Load librn_hip.so (built by `make -C retinanet-tensorflow_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RnError("librn_hip.so not found at %s: build it with "
+                          "`make -C retinanet-tensorflow_amd/csrc` (there is no fallback path)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.rn_last_error.restype = C.c_char_p
+        for name in ("rn_conv2d_wgrad_workspace", "rn_depthwise_wgrad_workspace", "rn_group_norm_workspace",
+                     "rn_loss_workspace", "rn_detect_workspace", "rn_optimizer_workspace",
+                     "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace"):
+            getattr(L, name).restype = C.c_size_t
+        L.rn_optimizer_workspace.argtypes = [C.c_int64]
+        L.rn_depthwise_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_depthwise_dgrad.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_depthwise_wgrad_workspace.argtypes = [C.c_int] * 6
+        L.rn_depthwise_wgrad.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rn_conv2d_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rn_conv2d_dgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rn_conv2d_wgrad_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rn_conv2d_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]
+        L.rn_conv2d_bias_grad_workspace.argtypes = [C.c_int]
+        L.rn_conv2d_bias_grad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                          C.c_void_p]
+        L.rn_group_norm_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rn_group_norm_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_void_p]
+        L.rn_group_norm_bwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rn_act_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.rn_act_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.rn_upsample_add_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_upsample_add_bwd_top.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_loss_workspace.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.rn_loss_fwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                  C.c_void_p]
+        L.rn_loss_bwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]
+        L.rn_anchor_assign.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 4 + \
+                                      [C.c_void_p] * 4 + [C.c_void_p]
+        L.rn_decode_boxes.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
+        L.rn_detect_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rn_detect.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 6 + [C.c_void_p, C.c_size_t,
+                                                                                     C.c_void_p]
+        L.rn_boxes_decode.argtypes = L.rn_detect.argtypes
+        L.rn_nms_classwise_workspace.argtypes = [C.c_void_p]
+        L.rn_nms_classwise.argtypes = [C.c_void_p] * 5 + [C.c_void_p] + [C.c_void_p] * 6 + [C.c_void_p, C.c_size_t,
+                                                                                        C.c_void_p]
+        L.rn_grad_norm_l2reg.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
+                                                             C.c_size_t, C.c_void_p]
+        L.rn_optimizer_step.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int64, C.c_float, C.c_float,
+                                                                       C.c_float, C.c_void_p, C.c_int64,
+                                                                       C.c_void_p]
+        L.rn_same_pad.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.rn_same_pad.restype = None
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RnError("%s failed (status %d): %s" % (what, status, lib().rn_last_error().decode()))
+
+
+def same_pad(n, k, s):
+    """TF SAME rule -> (out, pad_before); host-side mirror of rn_same_pad."""
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return out, total // 2
+
+
+def ptr(t):
+    """Raw device pointer of a contiguous fp32/u8/int tensor on the GPU (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RnError("rn_hip kernels need device tensors (got a CPU tensor): there is no CPU fallback")
+    if not t.is_contiguous():
+        raise RnError("rn_hip kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def f32(t):
+    if t.dtype != torch.float32:
+        raise RnError("rn_hip kernels are fp32 (got %s)" % t.dtype)
+    return ptr(t)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# one scratch arena per device, reused by every op (ops are stream-ordered); grown on demand
+_workspaces = {}
+WORKSPACE_MIN_BYTES = 256 << 20
+
+
+def workspace(nbytes, device):
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RnError("workspace must be sized before graph capture (need %d bytes)" % nbytes)
+        size = max(int(nbytes), WORKSPACE_MIN_BYTES)
+        ws = torch.empty(size, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws

@@ -1,0 +1,122 @@
+// Anchor assignment on the device (dataset.level_labels / build_labels, dataset.py:43-142).
+// Compiled with -ffp-contract=off: every float32 operation is rounded separately, in the
+// reference's order, so the class maps, trainable masks and arg-max indices are bit-identical
+// to the CPU oracle (BASELINE north_star: "bit-exact for anchor assignment").
+//
+// One thread per anchor (image, cell, anchor).  The [.., C] one-hot rows dominate the bytes
+// (C floats per anchor), so a wave writes the rows of its 64 anchors cooperatively: lane l
+// stores class l (and l+64..) of anchor i for i = 0..63 -- contiguous 4-B stores.
+#include "rn_common.h"
+
+namespace {
+constexpr int T = 256;
+
+struct AssignArgs {
+  const float* boxes; const int32_t* class_ids; const int32_t* num_obj;
+  int nimg, max_obj;
+  const float* anchor_sizes; int A, H, W, C;
+  float* cls_out; float* reg_out; uint8_t* tr_out; int32_t* arg_out;
+};
+
+// cell centre i of `size` cells: tf.linspace(cell/2, 1-cell/2, size)[i] in float32
+// (dataset.py:16-25; [TF-sem] value = start + step*i, step = (stop-start)/(size-1))
+__device__ __forceinline__ float cell_center(int i, int size) {
+  const float cell = (float)(1.0 / (double)size);
+  const float start = cell / 2.0f;
+  if (size == 1) return start;
+  const float stop = 1.0f - start;
+  const float step = (stop - start) / (float)(size - 1);
+  const float t = step * (float)i;
+  return start + t;
+}
+
+__global__ __launch_bounds__(T) void assign_kernel(const AssignArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t per_img = (int64_t)a.H * a.W * a.A;
+  const int64_t total = per_img * a.nimg;
+  const int64_t nwave_iters = (total + 63) / 64;
+  const int64_t wave0 = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * T) >> 6;
+  for (int64_t wi = wave0; wi < nwave_iters; wi += nwaves) {
+    const int64_t r = wi * 64 + lane;
+    const bool active = r < total;
+    int cls = -1;
+    bool bg = true;
+    if (active) {
+      const int img = (int)(r / per_img);
+      int64_t q = r - (int64_t)img * per_img;
+      const int an = (int)(q % a.A); q /= a.A;
+      const int x_ = (int)(q % a.W);
+      const int y_ = (int)(q / a.W);
+      const float ay = cell_center(y_, a.H), ax = cell_center(x_, a.W);
+      const float ah = a.anchor_sizes[an * 2], aw = a.anchor_sizes[an * 2 + 1];
+      // from_center_box(anchor) (dataset.py:35-39)
+      const float hh = ah / 2.0f, hw = aw / 2.0f;
+      const float a0 = ay - hh, a1 = ax - hw, a2 = ay + hh, a3 = ax + hw;
+      const float area_a = (a2 - a0) * (a3 - a1);
+      const int no = a.num_obj[img];
+      float best = 0.f;
+      int best_i = 0;
+      float bcy = 0.f, bcx = 0.f, bsh = 1.f, bsw = 1.f;
+      for (int o = 0; o < no; ++o) {
+        const float* tb = a.boxes + ((size_t)img * a.max_obj + o) * 4;
+        // to_center_box (dataset.py:28-32) then from_center_box
+        const float sh = tb[2] - tb[0], sw = tb[3] - tb[1];
+        const float cy = tb[0] + sh / 2.0f, cx = tb[1] + sw / 2.0f;
+        const float th = sh / 2.0f, tw = sw / 2.0f;
+        const float b0 = cy - th, b1 = cx - tw, b2 = cy + th, b3 = cx + tw;
+        // utils.iou (utils.py:62-97)
+        const float yt = fmaxf(a0, b0), xl = fmaxf(a1, b1), yb = fminf(a2, b2), xr = fminf(a3, b3);
+        const bool invalid = (yb < yt) || (xr < xl);
+        const float inter = (yb - yt) * (xr - xl);
+        const float area_b = (b2 - b0) * (b3 - b1);
+        const float den = (area_a + area_b) - inter;
+        float v = inter / den;
+        if (invalid) v = 0.f;
+        if (o == 0 || v > best) {  // arg-max keeps the FIRST maximum
+          best = v; best_i = o; bcy = cy; bcx = cx; bsh = sh; bsw = sw;
+        }
+      }
+      bg = best < 0.5f;                                   // dataset.py:83
+      const bool trainable = (best < 0.4f) || (best >= 0.5f);  // dataset.py:87
+      cls = a.class_ids[(size_t)img * a.max_obj + best_i];
+      // regression target of the arg-max object, NOT zeroed on background (dataset.py:105-121)
+      float4 rg;
+      rg.x = (bcy - ay) / ah;
+      rg.y = (bcx - ax) / aw;
+      rg.z = logf(bsh / ah);
+      rg.w = logf(bsw / aw);
+      *reinterpret_cast<float4*>(a.reg_out + (size_t)r * 4) = rg;
+      a.tr_out[r] = trainable ? 1 : 0;
+      if (a.arg_out) a.arg_out[r] = best_i;
+    }
+    const int hot = (active && !bg && cls >= 0 && cls < a.C) ? cls : -1;
+    // cooperative one-hot rows
+    const int64_t rbase = wi * 64;
+    const int nrow = (int)((total - rbase) < 64 ? (total - rbase) : 64);
+    for (int i = 0; i < nrow; ++i) {
+      const int h = __shfl(hot, i, 64);
+      float* row = a.cls_out + (size_t)(rbase + i) * a.C;
+      for (int c = lane; c < a.C; c += 64) row[c] = (c == h) ? 1.f : 0.f;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int rn_anchor_assign(const float* boxes, const int32_t* class_ids, const int32_t* num_obj, int nimg,
+                                int max_obj, const float* anchor_sizes, int num_anchors, int grid_h, int grid_w,
+                                int num_classes, float* cls_out, float* reg_out, uint8_t* trainable_out,
+                                int32_t* argmax_out, rn_stream_t stream) {
+  RN_CHECK_ARG(boxes && class_ids && num_obj && anchor_sizes && cls_out && reg_out && trainable_out,
+               "anchor_assign: null pointer");
+  RN_CHECK_ARG(nimg >= 1 && max_obj >= 1 && num_anchors >= 1 && grid_h >= 1 && grid_w >= 1 && num_classes >= 1,
+               "anchor_assign: bad shape");
+  AssignArgs a = {boxes, class_ids, num_obj, nimg, max_obj, anchor_sizes, num_anchors, grid_h, grid_w, num_classes,
+                  cls_out, reg_out, trainable_out, argmax_out};
+  const int64_t total = (int64_t)nimg * grid_h * grid_w * num_anchors;
+  int64_t blocks = (total + T - 1) / T;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(assign_kernel, dim3((unsigned)blocks), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}

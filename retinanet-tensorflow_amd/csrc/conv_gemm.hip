@@ -1,0 +1,720 @@
+// Dense NHWC convolution as implicit GEMM on the gfx950 fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, bit-exact fmaf chain).
+//
+//   fwd   : Y[m=(n,oh,ow)][co]      = sum_k A[m][k=(kh,kw,ci)] * W[k][co]      (+bias)
+//   dgrad : dX[m=(n,ih,iw)][ci]     = sum_k dY_gather[m][k=(kh,kw,co)] * W[(kh,kw)][ci][co]
+//   wgrad : dW[m'=(kh,kw,ci)][co]   = sum_{p=(n,oh,ow)} X_gather[p][m'] * dY[p][co]   (split over p)
+//
+// One launch covers up to RN_MAX_SEG independent problems ("segments") -- the shared
+// class/box heads applied to P3..P7 (reference retinanet.py:283-291) are ONE launch per layer,
+// and for wgrad the pyramid levels are simply more reduction length for the shared kernel.
+//
+// Tiling: BMxBN block tile, BK=32, WMxWN waves (64 lanes) each owning TMxTN 32x32 MFMA tiles.
+// Global -> register prefetch of tile t+1 overlaps the MFMAs of tile t (an f32 MFMA occupies
+// its SIMD for 64 cycles, so one prefetch stage covers HBM/L2 latency); operands are staged in
+// LDS, k-contiguous tiles padded to 36 floats so the ds_read_b128 fragments are conflict-free.
+// Tile ids are remapped so neighbouring tiles (which share the activation rows / the weight
+// panel) run on the same XCD and hit its L2.
+#include "rn_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;   // K-tile
+constexpr int LDK = 36;  // row stride (floats) of k-contiguous LDS tiles: 144 B, 16-B aligned,
+                         // rows r and r+1 are 4 banks apart => b128 fragment reads conflict-free
+
+struct SegDev {
+  const float* a;     // fwd: x     dgrad: dy    wgrad: x
+  const float* b;     // fwd: w     dgrad: w     wgrad: dy
+  const float* bias;  // fwd only
+  float* out;         // fwd: y     dgrad: dx    wgrad: unused
+  int n, h, w, oh, ow, cout, pad_t, pad_l;
+  int m;              // fwd: n*oh*ow   dgrad: n*h*w   wgrad: n*oh*ow (reduction length)
+  int tiles_n;        // fwd/dgrad: tiles along N
+  int start;          // fwd/dgrad: first tile id; wgrad: first split id
+  int chunk;          // wgrad: reduction rows per split (multiple of BK)
+};
+
+struct ConvArgs {
+  SegDev seg[RN_MAX_SEG];
+  int nseg;
+  int kh, kw, stride, cin;
+  int ktotal;    // fwd: kh*kw*cin   dgrad: kh*kw*cout(seg)  (recomputed per seg)   wgrad: kh*kw*cin
+  int tiles_mn;  // wgrad: output tiles per split
+  int tiles_n;   // wgrad
+  int cout;      // wgrad (all segments share it)
+  float* slab;   // wgrad: [nsplit][ktotal][cout]
+};
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+  typedef float4 type;
+  static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <>
+struct Vec<1> {
+  typedef float type;
+  static __device__ __forceinline__ float zero() { return 0.f; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// MFMA over one staged K-tile.  A fragment: lane l supplies A[row l&31][k-slot l>>5]; we let
+// lane-half h own the 4 consecutive k = 8*kg + 4*h .. +3 of each 8-wide k-group, so an
+// MK-layout fragment is ONE ds_read_b128.  B uses the same k per half, so the sum is complete.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_NK>
+__device__ __forceinline__ void mma_ktile(const float* __restrict__ As, const float* __restrict__ Bs,
+                                          f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int wm, int wn, int lane) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int kg = 0; kg < BK / 8; ++kg) {
+    const int k0 = kg * 8 + half * 4;
+    float a[TM][4], b[TN][4];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = wm * (BM / WM) + tm * 32 + l31;
+      if (A_KM) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[tm][j] = As[(k0 + j) * BM + row];
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(&As[row * LDK + k0]);
+        a[tm][0] = v.x; a[tm][1] = v.y; a[tm][2] = v.z; a[tm][3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = wn * (BN / WN) + tn * 32 + l31;
+      if (B_NK) {
+        const float4 v = *reinterpret_cast<const float4*>(&Bs[col * LDK + k0]);
+        b[tn][0] = v.x; b[tn][1] = v.y; b[tn][2] = v.z; b[tn][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[tn][j] = Bs[(k0 + j) * BN + col];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][j], b[tn][j], acc[tm][tn], 0, 0, 0);
+  }
+}
+
+// C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ out,
+                                           const float* __restrict__ bias, int m0, int n0, int mmax, int nmax,
+                                           int ldc, int wm, int wn, int lane) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + wn * (BN / WN) + tn * 32 + l31;
+    if (col >= nmax) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int rbase = m0 + wm * (BM / WM) + tm * 32 + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row < mmax) out[(size_t)row * ldc + col] = acc[tm][tn][r] + bv;
+      }
+    }
+  }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+}
+
+__device__ __forceinline__ int find_seg(const ConvArgs& args, int id) {
+  int s = 0;
+  while (s + 1 < args.nseg && id >= args.seg[s + 1].start) ++s;
+  return s;
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <int BM, int BN, int WM, int WN, int VEC>
+__global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs args) {
+  constexpr int T = WM * WN * 64;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int KQ = BK / VEC, A_RPP = T / KQ, A_PASS = BM / A_RPP;
+  constexpr int NQ = BN / VEC, B_RPP = T / NQ, B_PASS = BK / B_RPP;
+  static_assert(A_PASS >= 1 && B_PASS >= 1 && BM % A_RPP == 0 && BK % B_RPP == 0, "tile/threads mismatch");
+  typedef typename Vec<VEC>::type vec_t;
+  __shared__ __attribute__((aligned(16))) float smem[BM * LDK + BK * BN];
+  float* As = smem;
+  float* Bs = smem + BM * LDK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  const int s = find_seg(args, bid);
+  const SegDev& sg = args.seg[s];
+  const int local = bid - sg.start;
+  const int tile_n = local % sg.tiles_n, tile_m = local / sg.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int H = sg.h, W = sg.w, OW = sg.ow, OHW = sg.oh * sg.ow, M = sg.m, cout = sg.cout;
+  const int cin = args.cin, kw = args.kw, stride = args.stride;
+  const int ktotal = args.kh * args.kw * cin;
+  const float* __restrict__ xa = sg.a;
+  const float* __restrict__ wb = sg.b;
+
+  // per-thread im2col row bookkeeping (rows fixed for the whole K loop)
+  const int kq = tid % KQ;
+  int ih0[A_PASS], iw0[A_PASS], nb[A_PASS];
+#pragma unroll
+  for (int i = 0; i < A_PASS; ++i) {
+    const int m = m0 + tid / KQ + i * A_RPP;
+    if (m < M) {
+      const int n_ = m / OHW, rem = m - n_ * OHW;
+      const int oh_ = rem / OW, ow_ = rem - oh_ * OW;
+      ih0[i] = oh_ * stride - sg.pad_t;
+      iw0[i] = ow_ * stride - sg.pad_l;
+      nb[i] = n_ * H;
+    } else {
+      ih0[i] = -0x40000000; iw0[i] = 0; nb[i] = 0;
+    }
+  }
+  const int nq = tid % NQ;
+  const int bcol = n0 + nq * VEC;
+  const bool bcol_ok = bcol < cout;
+
+  vec_t ra[A_PASS], rb[B_PASS];
+  auto load_tiles = [&](int kt) {
+    const int k = kt * BK + kq * VEC;
+    const bool kok = k < ktotal;
+    const int tap = k / cin, ci = k - tap * cin;
+    const int khh = tap / kw, kww = tap - khh * kw;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      const int ih = ih0[i] + khh, iw = iw0[i] + kww;
+      const bool ok = kok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      ra[i] = Vec<VEC>::zero();
+      if (ok) ra[i] = *reinterpret_cast<const vec_t*>(xa + ((size_t)(nb[i] + ih) * W + iw) * cin + ci);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j) {
+      const int kk = kt * BK + tid / NQ + j * B_RPP;
+      rb[j] = Vec<VEC>::zero();
+      if (bcol_ok && kk < ktotal) rb[j] = *reinterpret_cast<const vec_t*>(wb + (size_t)kk * cout + bcol);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i)
+      *reinterpret_cast<vec_t*>(&As[(tid / KQ + i * A_RPP) * LDK + kq * VEC]) = ra[i];
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j)
+      *reinterpret_cast<vec_t*>(&Bs[(tid / NQ + j * B_RPP) * BN + nq * VEC]) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  const int nk = (ktotal + BK - 1) / BK;
+  load_tiles(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tiles();
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    mma_ktile<BM, BN, WM, WN, false, false>(As, Bs, acc, wm, wn, lane);
+    __syncthreads();
+  }
+  store_tile<BM, BN, WM, WN>(acc, sg.out, sg.bias, m0, n0, M, cout, cout, wm, wn, lane);
+}
+
+// =============================================================================================
+// dgrad: rows = input pixels, K = (kh,kw,co), N = ci.  W tile is read "NK" (ci rows, co contiguous).
+// =============================================================================================
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs args) {
+  constexpr int T = WM * WN * 64;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int KQ = BK / 4, RPP = T / KQ, A_PASS = BM / RPP, B_PASS = BN / RPP;
+  static_assert(A_PASS >= 1 && B_PASS >= 1, "tile/threads mismatch");
+  __shared__ __attribute__((aligned(16))) float smem[BM * LDK + BN * LDK];
+  float* As = smem;
+  float* Bs = smem + BM * LDK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  const int s = find_seg(args, bid);
+  const SegDev& sg = args.seg[s];
+  const int local = bid - sg.start;
+  const int tile_n = local % sg.tiles_n, tile_m = local / sg.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int W = sg.w, OH = sg.oh, OW = sg.ow, HW = sg.h * sg.w, M = sg.m, cout = sg.cout;
+  const int cin = args.cin, kw = args.kw, stride = args.stride;
+  const int ktotal = args.kh * args.kw * cout;
+  const float* __restrict__ dy = sg.a;
+  const float* __restrict__ wb = sg.b;
+
+  const int kq = tid % KQ, r0 = tid / KQ;
+  int ihp[A_PASS], iwp[A_PASS], nb[A_PASS];
+#pragma unroll
+  for (int i = 0; i < A_PASS; ++i) {
+    const int m = m0 + r0 + i * RPP;
+    if (m < M) {
+      const int n_ = m / HW, rem = m - n_ * HW;
+      const int ih = rem / W, iw = rem - ih * W;
+      ihp[i] = ih + sg.pad_t;
+      iwp[i] = iw + sg.pad_l;
+      nb[i] = n_ * OH;
+    } else {
+      ihp[i] = -0x40000000; iwp[i] = 0; nb[i] = 0;
+    }
+  }
+
+  float4 ra[A_PASS], rb[B_PASS];
+  auto load_tiles = [&](int kt) {
+    const int k = kt * BK + kq * 4;
+    const bool kok = k < ktotal;
+    const int tap = k / cout, co = k - tap * cout;
+    const int khh = tap / kw, kww = tap - khh * kw;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      const int ohs = ihp[i] - khh, ows = iwp[i] - kww;
+      int oh_, ow_;
+      bool ok = kok && ohs >= 0 && ows >= 0;
+      if (stride == 1) {
+        oh_ = ohs; ow_ = ows;
+      } else {
+        oh_ = ohs / stride; ow_ = ows / stride;
+        ok = ok && (oh_ * stride == ohs) && (ow_ * stride == ows);
+      }
+      ok = ok && oh_ < OH && ow_ < OW;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) ra[i] = *reinterpret_cast<const float4*>(dy + ((size_t)(nb[i] + oh_) * OW + ow_) * cout + co);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j) {
+      const int ci = n0 + r0 + j * RPP;
+      rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kok && ci < cin) rb[j] = *reinterpret_cast<const float4*>(wb + ((size_t)tap * cin + ci) * cout + co);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<float4*>(&As[(r0 + i * RPP) * LDK + kq * 4]) = ra[i];
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j) *reinterpret_cast<float4*>(&Bs[(r0 + j * RPP) * LDK + kq * 4]) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  const int nk = (ktotal + BK - 1) / BK;
+  load_tiles(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tiles();
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    mma_ktile<BM, BN, WM, WN, false, true>(As, Bs, acc, wm, wn, lane);
+    __syncthreads();
+  }
+  store_tile<BM, BN, WM, WN>(acc, sg.out, nullptr, m0, n0, M, cin, cin, wm, wn, lane);
+}
+
+// =============================================================================================
+// wgrad: rows m' = (kh,kw,ci), cols = co, reduction over output pixels p, split over blocks.
+// A tile is "KM" (pixel rows, m' contiguous = ci contiguous in x), B tile is dY rows.
+// =============================================================================================
+template <int BM, int BN, int WM, int WN, int VEC>
+__global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs args) {
+  constexpr int T = WM * WN * 64;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int MQ = BM / VEC, A_RPP = T / MQ, A_PASS = BK / A_RPP;
+  constexpr int NQ = BN / VEC, B_RPP = T / NQ, B_PASS = BK / B_RPP;
+  static_assert(A_PASS >= 1 && B_PASS >= 1 && BK % A_RPP == 0 && BK % B_RPP == 0, "tile/threads mismatch");
+  typedef typename Vec<VEC>::type vec_t;
+  __shared__ __attribute__((aligned(16))) float smem[BK * BM + BK * BN];
+  float* As = smem;
+  float* Bs = smem + BK * BM;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid / args.tiles_mn, t = bid - split * args.tiles_mn;
+  const int tile_n = t % args.tiles_n, tile_m = t / args.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int s = find_seg(args, split);
+  const SegDev& sg = args.seg[s];
+  const int p0 = (split - sg.start) * sg.chunk;
+  const int p1 = min(p0 + sg.chunk, sg.m);
+  const int H = sg.h, W = sg.w, OW = sg.ow, OHW = sg.oh * sg.ow;
+  const int cin = args.cin, cout = args.cout, kw = args.kw, stride = args.stride;
+  const int ktotal = args.ktotal;
+  const float* __restrict__ xa = sg.a;
+  const float* __restrict__ dy = sg.b;
+  const bool pointwise = (args.kh == 1 && args.kw == 1 && stride == 1);
+
+  // this thread's m' (fixed): tap and channel
+  const int mq = tid % MQ;
+  const int mrow = m0 + mq * VEC;
+  const bool mok = mrow < ktotal;
+  const int tap = mrow / cin, ci = mrow - tap * cin;
+  const int khh = tap / kw - sg.pad_t, kww = tap % kw - sg.pad_l;
+  const int nq = tid % NQ;
+  const int bcol = n0 + nq * VEC;
+  const bool bok = bcol < cout;
+
+  vec_t ra[A_PASS], rb[B_PASS];
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < A_PASS; ++j) {
+      const int p = p0 + kt * BK + tid / MQ + j * A_RPP;
+      ra[j] = Vec<VEC>::zero();
+      if (mok && p < p1) {
+        if (pointwise) {
+          ra[j] = *reinterpret_cast<const vec_t*>(xa + (size_t)p * cin + ci);
+        } else {
+          const int n_ = p / OHW, rem = p - n_ * OHW;
+          const int oh_ = rem / OW, ow_ = rem - oh_ * OW;
+          const int ih = oh_ * stride + khh, iw = ow_ * stride + kww;
+          if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+            ra[j] = *reinterpret_cast<const vec_t*>(xa + ((size_t)(n_ * H + ih) * W + iw) * cin + ci);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j) {
+      const int p = p0 + kt * BK + tid / NQ + j * B_RPP;
+      rb[j] = Vec<VEC>::zero();
+      if (bok && p < p1) rb[j] = *reinterpret_cast<const vec_t*>(dy + (size_t)p * cout + bcol);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int j = 0; j < A_PASS; ++j)
+      *reinterpret_cast<vec_t*>(&As[(tid / MQ + j * A_RPP) * BM + mq * VEC]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j)
+      *reinterpret_cast<vec_t*>(&Bs[(tid / NQ + j * B_RPP) * BN + nq * VEC]) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  const int nk = (p1 - p0 + BK - 1) / BK;
+  if (nk > 0) load_tiles(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tiles();
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    mma_ktile<BM, BN, WM, WN, true, false>(As, Bs, acc, wm, wn, lane);
+    __syncthreads();
+  }
+  float* out = args.slab + (size_t)split * ktotal * cout;
+  store_tile<BM, BN, WM, WN>(acc, out, nullptr, m0, n0, ktotal, cout, cout, wm, wn, lane);
+}
+
+// dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i], fixed order => bitwise reproducible
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t count, int nsplit,
+                                   int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float v = accumulate ? dw[i] : 0.f;
+  for (int s = 0; s < nsplit; ++s) v += slab[(size_t)s * count + i];
+  dw[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: tile-shape choice and launch
+// ---------------------------------------------------------------------------------------------
+struct TileCfg {
+  int bm, bn;
+  double penalty;
+};
+const TileCfg kCfgs[] = {{128, 128, 1.00}, {128, 64, 1.06}, {64, 64, 1.12}, {128, 32, 1.20}};
+constexpr int kNumCfg = 4;
+
+// pick the tile shape with the least padded work, corrected for chip fill (256 CUs)
+template <typename F>
+int choose_cfg(F dims, int nseg) {
+  int best = 0;
+  double best_cost = 1e300;
+  for (int c = 0; c < kNumCfg; ++c) {
+    double work = 0;
+    long tiles = 0;
+    for (int s = 0; s < nseg; ++s) {
+      long m, n;
+      dims(s, &m, &n);
+      long tm = (m + kCfgs[c].bm - 1) / kCfgs[c].bm, tn = (n + kCfgs[c].bn - 1) / kCfgs[c].bn;
+      tiles += tm * tn;
+      work += (double)tm * kCfgs[c].bm * tn * kCfgs[c].bn;
+    }
+    double fill = 1.0;
+    if (tiles < 1024) {  // few tiles: count whole "rounds" of 256 CUs
+      long rounds = (tiles + 255) / 256;
+      fill = (double)(rounds * 256) / (double)tiles;
+      if (fill > 4.0) fill = 4.0;
+    }
+    double cost = work * kCfgs[c].penalty * fill;
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+int validate_geom(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
+  RN_CHECK_ARG(segs && g, "conv: null argument");
+  RN_CHECK_ARG(nseg >= 1 && nseg <= RN_MAX_SEG, "conv: nseg %d outside [1,%d]", nseg, RN_MAX_SEG);
+  RN_CHECK_ARG(g->kh >= 1 && g->kw >= 1 && g->stride >= 1 && g->cin >= 1, "conv: bad geometry");
+  for (int s = 0; s < nseg; ++s)
+    RN_CHECK_ARG(segs[s].n >= 1 && segs[s].h >= 1 && segs[s].w >= 1 && segs[s].cout >= 1, "conv: bad segment %d", s);
+  return RN_OK;
+}
+
+}  // namespace
+
+extern "C" void rn_same_pad(int n, int k, int s, int* out, int* pad_before) { rn::same_pad(n, k, s, out, pad_before); }
+
+extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream) {
+  if (int e = validate_geom(segs, nseg, g)) return e;
+  ConvArgs a = {};
+  a.nseg = nseg; a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.cin = g->cin;
+  bool vec = (g->cin % 4 == 0);
+  for (int s = 0; s < nseg; ++s) {
+    RN_CHECK_ARG(segs[s].x && segs[s].wgt && segs[s].y, "conv fwd: null pointer in segment %d", s);
+    SegDev& d = a.seg[s];
+    d.a = segs[s].x; d.b = segs[s].wgt; d.bias = segs[s].bias; d.out = segs[s].y;
+    d.n = segs[s].n; d.h = segs[s].h; d.w = segs[s].w; d.cout = segs[s].cout;
+    rn::same_pad(d.h, g->kh, g->stride, &d.oh, &d.pad_t);
+    rn::same_pad(d.w, g->kw, g->stride, &d.ow, &d.pad_l);
+    d.m = d.n * d.oh * d.ow;
+    vec = vec && (d.cout % 4 == 0);
+  }
+  const int c = choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m; *n = a.seg[s].cout; }, nseg);
+  int tiles = 0;
+  for (int s = 0; s < nseg; ++s) {
+    SegDev& d = a.seg[s];
+    d.tiles_n = rn::ceil_div(d.cout, kCfgs[c].bn);
+    d.start = tiles;
+    tiles += rn::ceil_div(d.m, kCfgs[c].bm) * d.tiles_n;
+  }
+  hipStream_t st = (hipStream_t)stream;
+#define RN_FWD(BM_, BN_, WM_, WN_)                                                                   \
+  do {                                                                                               \
+    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 4>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+    else hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 1>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a);     \
+  } while (0)
+  switch (c) {
+    case 0: RN_FWD(128, 128, 2, 2); break;
+    case 1: RN_FWD(128, 64, 2, 2); break;
+    case 2: RN_FWD(64, 64, 2, 2); break;
+    default: RN_FWD(128, 32, 4, 1); break;
+  }
+#undef RN_FWD
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream) {
+  if (int e = validate_geom(segs, nseg, g)) return e;
+  ConvArgs a = {};
+  a.nseg = nseg; a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.cin = g->cin;
+  for (int s = 0; s < nseg; ++s) {
+    RN_CHECK_ARG(segs[s].dy && segs[s].wgt && segs[s].dx, "conv dgrad: null pointer in segment %d", s);
+    RN_UNSUPPORTED(segs[s].cout % 4 != 0, "conv dgrad: cout %d not a multiple of 4", segs[s].cout);
+    SegDev& d = a.seg[s];
+    d.a = segs[s].dy; d.b = segs[s].wgt; d.bias = nullptr; d.out = segs[s].dx;
+    d.n = segs[s].n; d.h = segs[s].h; d.w = segs[s].w; d.cout = segs[s].cout;
+    rn::same_pad(d.h, g->kh, g->stride, &d.oh, &d.pad_t);
+    rn::same_pad(d.w, g->kw, g->stride, &d.ow, &d.pad_l);
+    d.m = d.n * d.h * d.w;
+  }
+  const int cin = g->cin;
+  const int c = choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m; *n = cin; }, nseg);
+  int tiles = 0;
+  for (int s = 0; s < nseg; ++s) {
+    SegDev& d = a.seg[s];
+    d.tiles_n = rn::ceil_div(cin, kCfgs[c].bn);
+    d.start = tiles;
+    tiles += rn::ceil_div(d.m, kCfgs[c].bm) * d.tiles_n;
+  }
+  hipStream_t st = (hipStream_t)stream;
+#define RN_DG(BM_, BN_, WM_, WN_) \
+  hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a)
+  switch (c) {
+    case 0: RN_DG(128, 128, 2, 2); break;
+    case 1: RN_DG(128, 64, 2, 2); break;
+    case 2: RN_DG(64, 64, 2, 2); break;
+    default: RN_DG(128, 32, 4, 1); break;
+  }
+#undef RN_DG
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+namespace {
+struct WgradPlan {
+  int cfg, tiles_m, tiles_n, nsplit, ktotal, cout;
+  int chunk[RN_MAX_SEG], start[RN_MAX_SEG], pixels[RN_MAX_SEG], oh[RN_MAX_SEG], ow[RN_MAX_SEG], pt[RN_MAX_SEG],
+      pl[RN_MAX_SEG];
+};
+
+int plan_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, WgradPlan* p) {
+  p->ktotal = g->kh * g->kw * g->cin;
+  p->cout = segs[0].cout;
+  long total_pixels = 0;
+  for (int s = 0; s < nseg; ++s) {
+    RN_CHECK_ARG(segs[s].cout == p->cout, "conv wgrad: segments must share cout (one kernel tensor)");
+    rn::same_pad(segs[s].h, g->kh, g->stride, &p->oh[s], &p->pt[s]);
+    rn::same_pad(segs[s].w, g->kw, g->stride, &p->ow[s], &p->pl[s]);
+    p->pixels[s] = segs[s].n * p->oh[s] * p->ow[s];
+    total_pixels += p->pixels[s];
+  }
+  const long kt = p->ktotal, co = p->cout;
+  p->cfg = choose_cfg([&](int, long* m, long* n) { *m = kt; *n = co; }, 1);
+  // wgrad output tiles are few: the fill comes from splitting the reduction, so prefer the
+  // shape with the least padding only.
+  {
+    double best = 1e300;
+    for (int c = 0; c < kNumCfg; ++c) {
+      double w = (double)rn::ceil_div((int)kt, kCfgs[c].bm) * kCfgs[c].bm * rn::ceil_div((int)co, kCfgs[c].bn) *
+                 kCfgs[c].bn * kCfgs[c].penalty;
+      if (w < best) { best = w; p->cfg = c; }
+    }
+  }
+  p->tiles_m = rn::ceil_div(p->ktotal, kCfgs[p->cfg].bm);
+  p->tiles_n = rn::ceil_div(p->cout, kCfgs[p->cfg].bn);
+  const int tiles_mn = p->tiles_m * p->tiles_n;
+  // aim for ~1536 blocks (6 per CU); each split reduces >= 64 pixels
+  long want_splits = (1536 + tiles_mn - 1) / tiles_mn;
+  long chunk = (total_pixels + want_splits - 1) / want_splits;
+  chunk = (chunk + BK - 1) / BK * BK;
+  if (chunk < 2 * BK) chunk = 2 * BK;
+  int nsplit = 0;
+  for (int s = 0; s < nseg; ++s) {
+    p->chunk[s] = (int)chunk;
+    p->start[s] = nsplit;
+    nsplit += rn::ceil_div(p->pixels[s], (int)chunk);
+  }
+  p->nsplit = nsplit;
+  return RN_OK;
+}
+}  // namespace
+
+extern "C" size_t rn_conv2d_wgrad_workspace(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
+  if (validate_geom(segs, nseg, g)) return 0;
+  WgradPlan p;
+  if (plan_wgrad(segs, nseg, g, &p)) return 0;
+  return (size_t)p.nsplit * p.ktotal * p.cout * sizeof(float);
+}
+
+extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, int accumulate,
+                               void* workspace, size_t workspace_bytes, rn_stream_t stream) {
+  if (int e = validate_geom(segs, nseg, g)) return e;
+  RN_CHECK_ARG(dw && workspace, "conv wgrad: null dw/workspace");
+  WgradPlan p;
+  if (int e = plan_wgrad(segs, nseg, g, &p)) return e;
+  const size_t need = (size_t)p.nsplit * p.ktotal * p.cout * sizeof(float);
+  if (workspace_bytes < need) {
+    rn::set_error("conv wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+    return RN_EWORKSPACE;
+  }
+  ConvArgs a = {};
+  a.nseg = nseg; a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.cin = g->cin;
+  a.ktotal = p.ktotal; a.cout = p.cout; a.tiles_n = p.tiles_n; a.tiles_mn = p.tiles_m * p.tiles_n;
+  a.slab = (float*)workspace;
+  for (int s = 0; s < nseg; ++s) {
+    RN_CHECK_ARG(segs[s].x && segs[s].dy, "conv wgrad: null pointer in segment %d", s);
+    SegDev& d = a.seg[s];
+    d.a = segs[s].x; d.b = segs[s].dy; d.n = segs[s].n; d.h = segs[s].h; d.w = segs[s].w; d.cout = p.cout;
+    d.oh = p.oh[s]; d.ow = p.ow[s]; d.pad_t = p.pt[s]; d.pad_l = p.pl[s];
+    d.m = p.pixels[s]; d.start = p.start[s]; d.chunk = p.chunk[s];
+  }
+  const bool vec = (g->cin % 4 == 0) && (p.cout % 4 == 0);
+  const int blocks = p.nsplit * a.tiles_mn;
+  hipStream_t st = (hipStream_t)stream;
+#define RN_WG(BM_, BN_, WM_, WN_)                                                                    \
+  do {                                                                                               \
+    if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, WM_, WN_, 4>), dim3(blocks), dim3(WM_* WN_ * 64), 0, st, a); \
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, WM_, WN_, 1>), dim3(blocks), dim3(WM_* WN_ * 64), 0, st, a);     \
+  } while (0)
+  switch (p.cfg) {
+    case 0: RN_WG(128, 128, 2, 2); break;
+    case 1: RN_WG(128, 64, 2, 2); break;
+    case 2: RN_WG(64, 64, 2, 2); break;
+    default: RN_WG(128, 32, 4, 1); break;
+  }
+#undef RN_WG
+  RN_LAUNCH_CHECK();
+  const int64_t count = (int64_t)p.ktotal * p.cout;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rn::ceil_div64(count, 256)), dim3(256), 0, st,
+                     (const float*)workspace, dw, count, p.nsplit, accumulate);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bias gradient: column sums of dy over every pixel of every segment (two fixed-order stages)
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int BG_BLOCKS = 256;
+struct BiasArgs {
+  const float* dy[RN_MAX_SEG];
+  int rows[RN_MAX_SEG];
+  int nseg, cout;
+  float* partial;  // [BG_BLOCKS][cout]
+};
+__global__ __launch_bounds__(256) void bias_partial_kernel(const BiasArgs a) {
+  // thread owns column c = tid % cout (cout <= 256 fast path, else loops), rows strided
+  for (int c0 = 0; c0 < a.cout; c0 += 256) {
+    const int c = c0 + threadIdx.x;
+    float acc = 0.f;
+    if (c < a.cout) {
+      for (int s = 0; s < a.nseg; ++s) {
+        const float* p = a.dy[s];
+        for (int r = blockIdx.x; r < a.rows[s]; r += gridDim.x) acc += p[(size_t)r * a.cout + c];
+      }
+      a.partial[(size_t)blockIdx.x * a.cout + c] = acc;
+    }
+  }
+}
+__global__ void bias_final_kernel(const float* __restrict__ partial, float* __restrict__ dbias, int cout, int nb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cout) return;
+  double v = 0.0;
+  for (int b = 0; b < nb; ++b) v += (double)partial[(size_t)b * cout + c];
+  dbias[c] = (float)v;
+}
+}  // namespace
+
+extern "C" size_t rn_conv2d_bias_grad_workspace(int cout) { return (size_t)BG_BLOCKS * (size_t)(cout > 0 ? cout : 0) * sizeof(float); }
+
+extern "C" int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dbias, void* workspace,
+                                   size_t workspace_bytes, rn_stream_t stream) {
+  if (int e = validate_geom(segs, nseg, g)) return e;
+  RN_CHECK_ARG(dbias && workspace, "bias grad: null pointer");
+  BiasArgs a = {};
+  a.nseg = nseg; a.cout = segs[0].cout; a.partial = (float*)workspace;
+  for (int s = 0; s < nseg; ++s) {
+    RN_CHECK_ARG(segs[s].dy && segs[s].cout == a.cout, "bias grad: bad segment %d", s);
+    int oh, ow, pt, pl;
+    rn::same_pad(segs[s].h, g->kh, g->stride, &oh, &pt);
+    rn::same_pad(segs[s].w, g->kw, g->stride, &ow, &pl);
+    a.dy[s] = segs[s].dy; a.rows[s] = segs[s].n * oh * ow;
+  }
+  if (workspace_bytes < rn_conv2d_bias_grad_workspace(a.cout)) { rn::set_error("bias grad: workspace too small"); return RN_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bias_partial_kernel, dim3(BG_BLOCKS), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bias_final_kernel, dim3(rn::ceil_div(a.cout, 256)), dim3(256), 0, st, (const float*)workspace, dbias,
+                     a.cout, BG_BLOCKS);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}

@@ -1,0 +1,475 @@
+// Anchor decode, candidate extraction and batched class-wise greedy NMS.
+// (utils.regression_postprocess utils.py:108-117; boxes_decode :183-195; merge_boxes_decoded
+//  :223-227; nms_classwise / nms :198-220 = tf.image.non_max_suppression(max 1000, IoU>0.5).)
+// Compiled with -ffp-contract=off: the IoU / threshold arithmetic is float32 op-for-op the
+// oracle's, so the kept indices are bit-identical (north_star: "bit-exact ... NMS indices").
+//
+// Pipeline for a whole batch, no host round trip:
+//   1. scan   : one wave per anchor row: max / first-arg-max over the C class probabilities
+//               (coalesced row reads, HBM-bound: this is where the bytes are), per-wave counts
+//   2. offsets: exclusive scan of the per-wave counts (order-preserving compaction)
+//   3. emit   : candidates (box, score, class, image, anchor) + 64-bit key
+//               (image*C+class) << 32 | ~score_bits   in anchor order
+//   4. sort   : stable LSD radix sort of (key, index) pairs (rocPRIM device primitive)
+//               => segments (image, class), score descending, ties by lower anchor index
+//   5. nms    : one wave per (image, class) segment, exact greedy semantics: 64 candidates at
+//               a time are tested against the kept list (LDS) in parallel, then resolved in
+//               order with wave ballots; stops at max_per_class
+//   6. gather : kept boxes of all segments, (image, class)-major = the reference's output order
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "rn_common.h"
+
+namespace {
+
+constexpr int T = 256;
+constexpr int MAXL = 8;
+
+struct DetLevel { const float* prob; const float* boxes; int64_t rows; int64_t row_off; int wave_off; };
+struct DetArgs {
+  DetLevel lv[MAXL];
+  int nlv, n, C, max_keep;
+  float score_thr, iou_thr;
+  int64_t cap;            // candidate capacity
+  int64_t rows_per_image; // sum over levels
+  int waves_per_image;
+  // workspace
+  float* row_score; int32_t* row_class; int32_t* wave_count; int32_t* wave_off;
+  uint64_t* keys_in; uint64_t* keys_out; uint32_t* vals_in; uint32_t* vals_out;
+  float* cand_box; float* cand_score; int32_t* cand_class; int32_t* cand_image; int64_t* cand_anchor;
+  int32_t* seg_start; int32_t* seg_keep; int32_t* seg_off; int32_t* keep_idx;
+  // outputs
+  float* out_boxes; float* out_scores; int32_t* out_class; int32_t* out_image; int64_t* out_anchor; int64_t* counts;
+};
+
+__device__ __forceinline__ void locate_wave(const DetArgs& a, int64_t wid, int* img, int* lvl, int64_t* row0) {
+  *img = (int)(wid / a.waves_per_image);
+  const int w = (int)(wid - (int64_t)(*img) * a.waves_per_image);
+  int l = 0;
+  while (l + 1 < a.nlv && w >= a.lv[l + 1].wave_off) ++l;
+  *lvl = l;
+  *row0 = (int64_t)(w - a.lv[l].wave_off) * 64;
+}
+
+// ---- 1. scan: lane i of a wave ends up holding (max prob, arg-max) of row row0+i
+__global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
+  const int64_t nw = (int64_t)a.n * a.waves_per_image;
+  if (wid >= nw) return;
+  int img, l; int64_t row0;
+  locate_wave(a, wid, &img, &l, &row0);
+  const DetLevel& lv = a.lv[l];
+  const int nrow = (int)((lv.rows - row0) < 64 ? (lv.rows - row0) : 64);
+  const float* base = lv.prob + ((size_t)img * lv.rows + row0) * a.C;
+  float my_s = 0.f; int my_c = 0;
+  for (int i = 0; i < nrow; ++i) {
+    const float* row = base + (size_t)i * a.C;
+    float best = -1e30f; int bi = 0x7fffffff;
+    for (int c = lane; c < a.C; c += 64) {
+      const float v = row[c];
+      if (v > best) { best = v; bi = c; }   // ascending c per lane: keeps the lowest index on ties
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == i) { my_s = best; my_c = bi; }
+  }
+  const bool flag = lane < nrow && my_s > a.score_thr;
+  const int64_t g = (int64_t)img * a.rows_per_image + lv.row_off + row0 + lane;
+  if (lane < nrow) { a.row_score[g] = my_s; a.row_class[g] = my_c; }
+  const unsigned long long m = __ballot(flag);
+  if (lane == 0) a.wave_count[wid] = __popcll(m);
+}
+
+// ---- 2. exclusive scan of wave counts (single block; n_waves is at most a few 10^4)
+__global__ void det_offsets_kernel(const DetArgs a) {
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  const int64_t nw = (int64_t)a.n * a.waves_per_image;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nw; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int v = i < nw ? a.wave_count[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nw) a.wave_off[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.counts[0] = carry;
+}
+
+// ---- 3. emit candidates in anchor order; pad the key array with sentinels
+__global__ __launch_bounds__(T) void det_emit_kernel(const DetArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
+  const int64_t nw = (int64_t)a.n * a.waves_per_image;
+  if (wid >= nw) return;
+  int img, l; int64_t row0;
+  locate_wave(a, wid, &img, &l, &row0);
+  const DetLevel& lv = a.lv[l];
+  const int nrow = (int)((lv.rows - row0) < 64 ? (lv.rows - row0) : 64);
+  const int64_t in_img = lv.row_off + row0 + lane;
+  const int64_t g = (int64_t)img * a.rows_per_image + in_img;
+  float s = 0.f; int c = 0;
+  if (lane < nrow) { s = a.row_score[g]; c = a.row_class[g]; }
+  const bool flag = lane < nrow && s > a.score_thr;
+  const unsigned long long m = __ballot(flag);
+  if (!flag) return;
+  const int64_t pos = (int64_t)a.wave_off[wid] + __popcll(m & ((1ull << lane) - 1ull));
+  if (pos >= a.cap) return;  // overflow is reported through counts[0] > capacity
+  const float4 b = *reinterpret_cast<const float4*>(lv.boxes + ((size_t)img * lv.rows + row0 + lane) * 4);
+  *reinterpret_cast<float4*>(a.cand_box + pos * 4) = b;
+  a.cand_score[pos] = s; a.cand_class[pos] = c; a.cand_image[pos] = img; a.cand_anchor[pos] = in_img;
+  const uint32_t sb = __float_as_uint(s);  // s > 0: bit pattern is monotone in the value
+  a.keys_in[pos] = ((uint64_t)(uint32_t)(img * a.C + c) << 32) | (uint64_t)(0xFFFFFFFFu - sb);
+  a.vals_in[pos] = (uint32_t)pos;
+}
+
+__global__ void det_pad_kernel(const DetArgs a) {
+  const int64_t ncand = a.counts[0] < a.cap ? a.counts[0] : a.cap;
+  for (int64_t i = ncand + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.cap; i += (int64_t)gridDim.x * blockDim.x) {
+    a.keys_in[i] = ~0ull;
+    a.vals_in[i] = 0xFFFFFFFFu;
+  }
+}
+
+// ---- segment starts: first sorted position whose segment id >= k, for k in [0, n*C]
+__global__ void det_segments_kernel(const DetArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nseg = a.n * a.C;
+  if (k > nseg) return;
+  const int64_t ncand = a.counts[0] < a.cap ? a.counts[0] : a.cap;
+  int64_t lo = 0, hi = ncand;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((uint32_t)(a.keys_out[mid] >> 32) < (uint32_t)k) lo = mid + 1; else hi = mid;
+  }
+  a.seg_start[k] = (int)lo;
+}
+
+// [TF-sem] IoU of TF's NonMaxSuppression kernel (corner normalisation, area<=0 -> 0, clamped extents)
+struct NBox { float ymin, xmin, ymax, xmax, area; };
+__device__ __forceinline__ NBox norm_box(const float4 b) {
+  NBox r;
+  r.ymin = fminf(b.x, b.z); r.ymax = fmaxf(b.x, b.z);
+  r.xmin = fminf(b.y, b.w); r.xmax = fmaxf(b.y, b.w);
+  r.area = (r.ymax - r.ymin) * (r.xmax - r.xmin);
+  return r;
+}
+__device__ __forceinline__ bool suppresses(const NBox& i, const NBox& j, float thr) {
+  if (i.area <= 0.f || j.area <= 0.f) return false;
+  const float iy = fmaxf(fminf(i.ymax, j.ymax) - fmaxf(i.ymin, j.ymin), 0.f);
+  const float ix = fmaxf(fminf(i.xmax, j.xmax) - fmaxf(i.xmin, j.xmin), 0.f);
+  const float inter = iy * ix;
+  const float v = inter / ((i.area + j.area) - inter);
+  return v > thr;
+}
+
+// ---- 5. one wave per (image, class) segment
+constexpr int KEEP_LDS = 1024;
+__global__ __launch_bounds__(64) void det_nms_kernel(const DetArgs a) {
+  __shared__ NBox kept[KEEP_LDS];
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const int s0 = a.seg_start[k], s1 = a.seg_start[k + 1];
+  int nk = 0;
+  int* keep_out = a.keep_idx + (size_t)k * a.max_keep;
+  for (int base = s0; base < s1 && nk < a.max_keep; base += 64) {
+    const int idx = base + lane;
+    const bool have = idx < s1;
+    uint32_t cand = 0;
+    NBox me = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (have) {
+      cand = a.vals_out[idx];
+      me = norm_box(*reinterpret_cast<const float4*>(a.cand_box + (size_t)cand * 4));
+    }
+    bool alive = have;
+    for (int j = 0; j < nk && alive; ++j) alive = !suppresses(kept[j], me, a.iou_thr);
+    // resolve the 64 candidates in order
+    unsigned long long live = __ballot(alive);
+    while (live != 0ull && nk < a.max_keep) {
+      const int i = __ffsll((long long)live) - 1;
+      NBox bi;
+      bi.ymin = __shfl(me.ymin, i, 64); bi.xmin = __shfl(me.xmin, i, 64);
+      bi.ymax = __shfl(me.ymax, i, 64); bi.xmax = __shfl(me.xmax, i, 64); bi.area = __shfl(me.area, i, 64);
+      if (lane == i) { kept[nk] = me; keep_out[nk] = (int)cand; alive = false; }
+      if (alive && lane > i && suppresses(bi, me, a.iou_thr)) alive = false;
+      ++nk;
+      __syncthreads();
+      live = __ballot(alive);
+    }
+  }
+  if (lane == 0) a.seg_keep[k] = nk;
+}
+
+// ---- exclusive scan of kept counts per segment + per-image totals (single block)
+__global__ void det_keep_offsets_kernel(const DetArgs a) {
+  if (threadIdx.x != 0) return;
+  int run = 0;
+  for (int img = 0; img < a.n; ++img) {
+    int tot = 0;
+    for (int c = 0; c < a.C; ++c) {
+      const int k = img * a.C + c;
+      a.seg_off[k] = run;
+      run += a.seg_keep[k];
+      tot += a.seg_keep[k];
+    }
+    a.counts[2 + img] = tot;
+  }
+  a.counts[1] = run;
+}
+
+__global__ void det_gather_kernel(const DetArgs a) {
+  const int k = blockIdx.x;
+  const int nk = a.seg_keep[k], off = a.seg_off[k];
+  const int* keep = a.keep_idx + (size_t)k * a.max_keep;
+  for (int i = threadIdx.x; i < nk; i += blockDim.x) {
+    const int c = keep[i];
+    const int64_t o = (int64_t)off + i;
+    *reinterpret_cast<float4*>(a.out_boxes + o * 4) = *reinterpret_cast<const float4*>(a.cand_box + (size_t)c * 4);
+    a.out_scores[o] = a.cand_score[c]; a.out_class[o] = a.cand_class[c]; a.out_image[o] = a.cand_image[c];
+    a.out_anchor[o] = a.cand_anchor[c];
+  }
+}
+
+// ---- anchor decode (utils.py:108-117)
+__device__ __forceinline__ float cell_center(int i, int size) {
+  const float cell = (float)(1.0 / (double)size);
+  const float start = cell / 2.0f;
+  if (size == 1) return start;
+  const float stop = 1.0f - start;
+  const float step = (stop - start) / (float)(size - 1);
+  const float t = step * (float)i;
+  return start + t;
+}
+
+__global__ void decode_kernel(const float* __restrict__ reg, const float* __restrict__ anchors, float* __restrict__ out,
+                              int n, int h, int w, int A) {
+  const int64_t total = (int64_t)n * h * w * A;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t q = i;
+    const int an = (int)(q % A); q /= A;
+    const int x_ = (int)(q % w); q /= w;
+    const int y_ = (int)(q % h);
+    const float4 r = *reinterpret_cast<const float4*>(reg + i * 4);
+    const float ah = anchors[an * 2], aw = anchors[an * 2 + 1];
+    const float sy = r.x * ah, sx = r.y * aw;
+    const float bh = expf(r.z) * ah, bw = expf(r.w) * aw;
+    const float cy = sy + cell_center(y_, h), cx = sx + cell_center(x_, w);
+    const float hh = bh / 2.0f, hw = bw / 2.0f;
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(cy - hh, cx - hw, cy + hh, cx + hw);
+  }
+}
+
+struct WsLayout { size_t off[20]; size_t total; size_t sort_bytes; };
+
+int plan(const rn_det_level* levels, int nlevels, const rn_det_params* p, DetArgs* a, WsLayout* L) {
+  RN_CHECK_ARG(levels && p && nlevels >= 1 && nlevels <= MAXL, "detect: bad levels");
+  RN_CHECK_ARG(p->n >= 1 && p->num_classes >= 1 && p->max_per_class >= 1 && p->max_candidates >= 1, "detect: bad params");
+  RN_UNSUPPORTED(p->max_per_class > KEEP_LDS, "detect: max_per_class %d > %d", p->max_per_class, KEEP_LDS);
+  RN_UNSUPPORTED((int64_t)p->n * p->num_classes >= (1ll << 31) || p->max_candidates >= (1ll << 31), "detect: too large");
+  a->nlv = nlevels; a->n = p->n; a->C = p->num_classes; a->max_keep = p->max_per_class;
+  a->score_thr = p->score_threshold; a->iou_thr = p->iou_threshold; a->cap = p->max_candidates;
+  int64_t rows = 0; int waves = 0;
+  for (int l = 0; l < nlevels; ++l) {
+    RN_CHECK_ARG(levels[l].rows_per_image >= 1, "detect: empty level %d", l);
+    a->lv[l].prob = levels[l].prob; a->lv[l].boxes = levels[l].boxes; a->lv[l].rows = levels[l].rows_per_image;
+    a->lv[l].row_off = rows; a->lv[l].wave_off = waves;
+    rows += levels[l].rows_per_image;
+    waves += (int)((levels[l].rows_per_image + 63) / 64);
+  }
+  a->rows_per_image = rows; a->waves_per_image = waves;
+  const int64_t nrows = rows * p->n, nw = (int64_t)waves * p->n, cap = p->max_candidates;
+  const int64_t nseg = (int64_t)p->n * p->num_classes;
+  size_t sort_bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                            (uint32_t*)nullptr, (size_t)cap, 0, 64, (hipStream_t)0);
+  L->sort_bytes = sort_bytes;
+  const size_t sizes[18] = {
+      (size_t)nrows * 4, (size_t)nrows * 4, (size_t)nw * 4, (size_t)nw * 4,            // row_score,row_class,wave_count,wave_off
+      (size_t)cap * 8, (size_t)cap * 8, (size_t)cap * 4, (size_t)cap * 4,              // keys in/out, vals in/out
+      (size_t)cap * 16, (size_t)cap * 4, (size_t)cap * 4, (size_t)cap * 4, (size_t)cap * 8,  // cand box,score,class,image,anchor
+      (size_t)(nseg + 1) * 4, (size_t)nseg * 4, (size_t)nseg * 4, (size_t)nseg * p->max_per_class * 4,  // seg_*, keep_idx
+      sort_bytes};
+  size_t o = 0;
+  for (int i = 0; i < 18; ++i) { L->off[i] = o; o += rn::align_up(sizes[i], 256); }
+  L->total = o;
+  return RN_OK;
+}
+
+void bind(DetArgs* a, const WsLayout& L, void* ws) {
+  char* b = (char*)ws;
+  a->row_score = (float*)(b + L.off[0]); a->row_class = (int32_t*)(b + L.off[1]);
+  a->wave_count = (int32_t*)(b + L.off[2]); a->wave_off = (int32_t*)(b + L.off[3]);
+  a->keys_in = (uint64_t*)(b + L.off[4]); a->keys_out = (uint64_t*)(b + L.off[5]);
+  a->vals_in = (uint32_t*)(b + L.off[6]); a->vals_out = (uint32_t*)(b + L.off[7]);
+  a->cand_box = (float*)(b + L.off[8]); a->cand_score = (float*)(b + L.off[9]);
+  a->cand_class = (int32_t*)(b + L.off[10]); a->cand_image = (int32_t*)(b + L.off[11]);
+  a->cand_anchor = (int64_t*)(b + L.off[12]);
+  a->seg_start = (int32_t*)(b + L.off[13]); a->seg_keep = (int32_t*)(b + L.off[14]);
+  a->seg_off = (int32_t*)(b + L.off[15]); a->keep_idx = (int32_t*)(b + L.off[16]);
+}
+}  // namespace
+
+extern "C" int rn_decode_boxes(const float* reg, const float* anchor_sizes, float* boxes, int n, int h, int w,
+                               int num_anchors, rn_stream_t stream) {
+  RN_CHECK_ARG(reg && anchor_sizes && boxes && n >= 1 && h >= 1 && w >= 1 && num_anchors >= 1, "decode: bad argument");
+  const int64_t total = (int64_t)n * h * w * num_anchors;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reg, anchor_sizes, boxes, n,
+                     h, w, num_anchors);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" size_t rn_detect_workspace(const rn_det_level* levels, int nlevels, const rn_det_params* p) {
+  DetArgs a = {};
+  WsLayout L;
+  if (plan(levels, nlevels, p, &a, &L)) return 0;
+  return L.total;
+}
+
+namespace {
+// copy the (un-sorted) candidates to the outputs in anchor order (boxes_decode semantics)
+__global__ void det_copy_candidates_kernel(const DetArgs a) {
+  const int64_t ncand = a.counts[0] < a.cap ? a.counts[0] : a.cap;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncand; i += (int64_t)gridDim.x * blockDim.x) {
+    *reinterpret_cast<float4*>(a.out_boxes + i * 4) = *reinterpret_cast<const float4*>(a.cand_box + i * 4);
+    a.out_scores[i] = a.cand_score[i]; a.out_class[i] = a.cand_class[i]; a.out_image[i] = a.cand_image[i];
+    a.out_anchor[i] = a.cand_anchor[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[1] = ncand;
+}
+
+// keys for candidates handed in as arrays (rn_nms_classwise)
+__global__ void det_keys_from_arrays_kernel(const DetArgs a, const int64_t* count_dev) {
+  const int64_t ncand = count_dev[0] < a.cap ? count_dev[0] : a.cap;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.cap; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < ncand) {
+      const uint32_t sb = __float_as_uint(a.cand_score[i]);
+      // order-preserving map of ANY float (scores may be <= 0 here): flip sign bit / all bits
+      const uint32_t ord = (sb & 0x80000000u) ? ~sb : (sb | 0x80000000u);
+      a.keys_in[i] = ((uint64_t)(uint32_t)(a.cand_image[i] * a.C + a.cand_class[i]) << 32) | (uint64_t)(0xFFFFFFFFu - ord);
+      a.vals_in[i] = (uint32_t)i;
+      a.cand_anchor[i] = i;
+    } else {
+      a.keys_in[i] = ~0ull;
+      a.vals_in[i] = 0xFFFFFFFFu;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[0] = count_dev[0];
+}
+
+int sort_and_suppress(DetArgs& a, const WsLayout& L, void* workspace, hipStream_t st) {
+  size_t sort_bytes = L.sort_bytes;
+  hipError_t e = rocprim::radix_sort_pairs((char*)workspace + L.off[17], sort_bytes, a.keys_in, a.keys_out, a.vals_in,
+                                           a.vals_out, (size_t)a.cap, 0, 64, st);
+  if (e != hipSuccess) {
+    rn::set_error("detect: radix sort failed: %s", hipGetErrorString(e));
+    return RN_EHIP;
+  }
+  const int nseg = a.n * a.C;
+  hipLaunchKernelGGL(det_segments_kernel, dim3(rn::ceil_div(nseg + 1, 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(det_nms_kernel, dim3(nseg), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(det_keep_offsets_kernel, dim3(1), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(det_gather_kernel, dim3(nseg), dim3(64), 0, st, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+int run_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, float* out_boxes, float* out_scores,
+               int32_t* out_class, int32_t* out_image, int64_t* out_anchor, int64_t* counts, void* workspace,
+               size_t workspace_bytes, rn_stream_t stream, bool decode_only) {
+  DetArgs a = {};
+  WsLayout L;
+  if (int e = plan(levels, nlevels, p, &a, &L)) return e;
+  RN_CHECK_ARG(out_boxes && out_scores && out_class && out_image && out_anchor && counts && workspace, "detect: null pointer");
+  for (int l = 0; l < nlevels; ++l) RN_CHECK_ARG(levels[l].prob && levels[l].boxes, "detect: null level pointer %d", l);
+  if (workspace_bytes < L.total) {
+    rn::set_error("detect: workspace %zu < %zu", workspace_bytes, L.total);
+    return RN_EWORKSPACE;
+  }
+  bind(&a, L, workspace);
+  a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_class = out_class; a.out_image = out_image;
+  a.out_anchor = out_anchor; a.counts = counts;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nw = (int64_t)a.n * a.waves_per_image;
+  const unsigned wblocks = (unsigned)((nw * 64 + T - 1) / T);
+  hipLaunchKernelGGL(det_scan_kernel, dim3(wblocks), dim3(T), 0, st, a);
+  hipLaunchKernelGGL(det_offsets_kernel, dim3(1), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(det_emit_kernel, dim3(wblocks), dim3(T), 0, st, a);
+  if (decode_only) {
+    hipLaunchKernelGGL(det_copy_candidates_kernel, dim3(256), dim3(256), 0, st, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+  }
+  hipLaunchKernelGGL(det_pad_kernel, dim3(256), dim3(256), 0, st, a);
+  RN_LAUNCH_CHECK();
+  return sort_and_suppress(a, L, workspace, st);
+}
+}  // namespace
+
+extern "C" int rn_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, float* out_boxes,
+                         float* out_scores, int32_t* out_class, int32_t* out_image, int64_t* out_anchor, int64_t* counts,
+                         void* workspace, size_t workspace_bytes, rn_stream_t stream) {
+  return run_detect(levels, nlevels, p, out_boxes, out_scores, out_class, out_image, out_anchor, counts, workspace,
+                    workspace_bytes, stream, false);
+}
+
+extern "C" int rn_boxes_decode(const rn_det_level* levels, int nlevels, const rn_det_params* p, float* out_boxes,
+                               float* out_scores, int32_t* out_class, int32_t* out_image, int64_t* out_anchor,
+                               int64_t* counts, void* workspace, size_t workspace_bytes, rn_stream_t stream) {
+  return run_detect(levels, nlevels, p, out_boxes, out_scores, out_class, out_image, out_anchor, counts, workspace,
+                    workspace_bytes, stream, true);
+}
+
+extern "C" size_t rn_nms_classwise_workspace(const rn_det_params* p) {
+  if (!p) return 0;
+  rn_det_level lv = {nullptr, nullptr, 64};
+  DetArgs a = {};
+  WsLayout L;
+  if (plan(&lv, 1, p, &a, &L)) return 0;
+  return L.total;
+}
+
+extern "C" int rn_nms_classwise(const float* boxes, const float* scores, const int32_t* class_ids, const int32_t* image_ids,
+                                const int64_t* count_dev, const rn_det_params* p, float* out_boxes, float* out_scores,
+                                int32_t* out_class, int32_t* out_image, int64_t* out_index, int64_t* counts, void* workspace,
+                                size_t workspace_bytes, rn_stream_t stream) {
+  RN_CHECK_ARG(boxes && scores && class_ids && image_ids && count_dev && p, "nms_classwise: null input");
+  rn_det_level lv = {nullptr, nullptr, 64};
+  DetArgs a = {};
+  WsLayout L;
+  if (int e = plan(&lv, 1, p, &a, &L)) return e;
+  RN_CHECK_ARG(out_boxes && out_scores && out_class && out_image && out_index && counts && workspace, "nms_classwise: null output");
+  if (workspace_bytes < L.total) {
+    rn::set_error("nms_classwise: workspace %zu < %zu", workspace_bytes, L.total);
+    return RN_EWORKSPACE;
+  }
+  bind(&a, L, workspace);
+  // candidates are the caller's arrays (read-only use)
+  a.cand_box = const_cast<float*>(boxes); a.cand_score = const_cast<float*>(scores);
+  a.cand_class = const_cast<int32_t*>(class_ids); a.cand_image = const_cast<int32_t*>(image_ids);
+  a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_class = out_class; a.out_image = out_image;
+  a.out_anchor = out_index; a.counts = counts;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(det_keys_from_arrays_kernel, dim3(256), dim3(256), 0, st, a, count_dev);
+  RN_LAUNCH_CHECK();
+  return sort_and_suppress(a, L, workspace, st);
+}

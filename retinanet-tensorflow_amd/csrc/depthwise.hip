@@ -1,0 +1,209 @@
+// Depthwise kxk convolution, NHWC fp32, TF SAME padding (mobilenet_v2.py:35-36,
+// tf.nn.depthwise_conv2d with channel multiplier 1; kernel stored [kh,kw,C]).
+// HBM-bound (9 MAC per loaded element): one thread owns 4 channels of one pixel, float4
+// loads along C are fully coalesced, the k*k window re-reads hit L1/L2.
+#include "rn_common.h"
+
+namespace {
+
+constexpr int T = 256;
+
+struct DwArgs {
+  const float* x; const float* w; const float* dy; float* out;
+  int n, h, wd, c, k, stride, oh, ow, pad_t, pad_l;
+  int chunks, ppc;  // wgrad
+  float* partial;
+};
+
+__global__ __launch_bounds__(T) void dw_fwd_kernel(const DwArgs a) {
+  const int CQ = a.c >> 2;
+  const int64_t total = (int64_t)a.n * a.oh * a.ow * CQ;
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < total; i += (int64_t)gridDim.x * T) {
+    const int q4 = (int)(i % CQ);
+    int64_t p = i / CQ;
+    const int ow_ = (int)(p % a.ow); p /= a.ow;
+    const int oh_ = (int)(p % a.oh);
+    const int n_ = (int)(p / a.oh);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < a.k; ++kh) {
+      const int ih = oh_ * a.stride - a.pad_t + kh;
+      if ((unsigned)ih >= (unsigned)a.h) continue;
+      for (int kw = 0; kw < a.k; ++kw) {
+        const int iw = ow_ * a.stride - a.pad_l + kw;
+        if ((unsigned)iw >= (unsigned)a.wd) continue;
+        const float4 xv = *reinterpret_cast<const float4*>(a.x + ((size_t)(n_ * a.h + ih) * a.wd + iw) * a.c + q4 * 4);
+        const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(kh * a.k + kw) * a.c + q4 * 4);
+        acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y);
+        acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
+      }
+    }
+    *reinterpret_cast<float4*>(a.out + (size_t)i * 4) = acc;
+  }
+}
+
+// dx[n,ih,iw,c] = sum_{kh,kw} dy[n,oh,ow,c]*w[kh,kw,c] with oh*s + kh - pad_t == ih
+__global__ __launch_bounds__(T) void dw_dgrad_kernel(const DwArgs a) {
+  const int CQ = a.c >> 2;
+  const int64_t total = (int64_t)a.n * a.h * a.wd * CQ;
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < total; i += (int64_t)gridDim.x * T) {
+    const int q4 = (int)(i % CQ);
+    int64_t p = i / CQ;
+    const int iw = (int)(p % a.wd); p /= a.wd;
+    const int ih = (int)(p % a.h);
+    const int n_ = (int)(p / a.h);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < a.k; ++kh) {
+      const int ohs = ih + a.pad_t - kh;
+      if (ohs < 0 || ohs % a.stride) continue;
+      const int oh_ = ohs / a.stride;
+      if (oh_ >= a.oh) continue;
+      for (int kw = 0; kw < a.k; ++kw) {
+        const int ows = iw + a.pad_l - kw;
+        if (ows < 0 || ows % a.stride) continue;
+        const int ow_ = ows / a.stride;
+        if (ow_ >= a.ow) continue;
+        const float4 dv = *reinterpret_cast<const float4*>(a.dy + ((size_t)(n_ * a.oh + oh_) * a.ow + ow_) * a.c + q4 * 4);
+        const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(kh * a.k + kw) * a.c + q4 * 4);
+        acc.x = fmaf(dv.x, wv.x, acc.x); acc.y = fmaf(dv.y, wv.y, acc.y);
+        acc.z = fmaf(dv.z, wv.z, acc.z); acc.w = fmaf(dv.w, wv.w, acc.w);
+      }
+    }
+    *reinterpret_cast<float4*>(a.out + (size_t)i * 4) = acc;
+  }
+}
+
+// partial[chunk][tap][c] = sum over the chunk's output pixels of x(tap)*dy ; k == 3 only.
+__global__ __launch_bounds__(T) void dw_wgrad_partial_kernel(const DwArgs a) {
+  __shared__ float red[T][4];
+  const int tid = threadIdx.x;
+  const int CQ = a.c >> 2, lanes = T / CQ;
+  const int q4 = tid % CQ, pl = tid / CQ;
+  const int64_t npix = (int64_t)a.n * a.oh * a.ow;
+  const int64_t p_begin = (int64_t)blockIdx.x * a.ppc;
+  const int64_t p_end = p_begin + a.ppc < npix ? p_begin + a.ppc : npix;
+  float4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pl < lanes) {
+    for (int64_t p = p_begin + pl; p < p_end; p += lanes) {
+      const int ow_ = (int)(p % a.ow);
+      const int64_t r = p / a.ow;
+      const int oh_ = (int)(r % a.oh);
+      const int n_ = (int)(r / a.oh);
+      const float4 dv = *reinterpret_cast<const float4*>(a.dy + (size_t)p * a.c + q4 * 4);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh_ * a.stride - a.pad_t + kh;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = ow_ * a.stride - a.pad_l + kw;
+          if ((unsigned)ih < (unsigned)a.h && (unsigned)iw < (unsigned)a.wd) {
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + ((size_t)(n_ * a.h + ih) * a.wd + iw) * a.c + q4 * 4);
+            float4& t = acc[kh * 3 + kw];
+            t.x = fmaf(xv.x, dv.x, t.x); t.y = fmaf(xv.y, dv.y, t.y);
+            t.z = fmaf(xv.z, dv.z, t.z); t.w = fmaf(xv.w, dv.w, t.w);
+          }
+        }
+      }
+    }
+  }
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+    red[tid][0] = acc[t].x; red[tid][1] = acc[t].y; red[tid][2] = acc[t].z; red[tid][3] = acc[t].w;
+    __syncthreads();
+    if (tid < CQ) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int l = 0; l < lanes; ++l) {
+        s0 += red[l * CQ + tid][0]; s1 += red[l * CQ + tid][1];
+        s2 += red[l * CQ + tid][2]; s3 += red[l * CQ + tid][3];
+      }
+      *reinterpret_cast<float4*>(a.partial + ((size_t)blockIdx.x * 9 + t) * a.c + tid * 4) = make_float4(s0, s1, s2, s3);
+    }
+  }
+}
+
+__global__ void dw_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int count, int chunks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double v = 0.0;
+  for (int s = 0; s < chunks; ++s) v += (double)partial[(size_t)s * count + i];
+  dw[i] = (float)v;
+}
+
+int fill(DwArgs* a, int n, int h, int w, int c, int k, int stride) {
+  RN_CHECK_ARG(n >= 1 && h >= 1 && w >= 1 && c >= 1 && k >= 1 && stride >= 1, "depthwise: bad shape");
+  RN_UNSUPPORTED(c % 4 != 0 || c > 1024, "depthwise: c=%d must be a multiple of 4 and <= 1024", c);
+  a->n = n; a->h = h; a->wd = w; a->c = c; a->k = k; a->stride = stride;
+  rn::same_pad(h, k, stride, &a->oh, &a->pad_t);
+  rn::same_pad(w, k, stride, &a->ow, &a->pad_l);
+  return RN_OK;
+}
+
+unsigned grid_for(int64_t total) {
+  int64_t b = (total + T - 1) / T;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+void wgrad_plan(const DwArgs& a, int* chunks, int* ppc) {
+  const int64_t npix = (int64_t)a.n * a.oh * a.ow;
+  int64_t ck = (npix * a.c + 32767) / 32768;
+  if (ck > 2048) ck = 2048;
+  if (ck < 1) ck = 1;
+  *ppc = (int)((npix + ck - 1) / ck);
+  *chunks = (int)((npix + *ppc - 1) / *ppc);
+}
+
+}  // namespace
+
+extern "C" int rn_depthwise_fwd(const float* x, const float* wgt, float* y, int n, int h, int w, int c, int k,
+                                int stride, rn_stream_t stream) {
+  DwArgs a = {};
+  if (int e = fill(&a, n, h, w, c, k, stride)) return e;
+  RN_CHECK_ARG(x && wgt && y, "depthwise fwd: null pointer");
+  a.x = x; a.w = wgt; a.out = y;
+  hipLaunchKernelGGL(dw_fwd_kernel, dim3(grid_for((int64_t)n * a.oh * a.ow * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_depthwise_dgrad(const float* dy, const float* wgt, float* dx, int n, int h, int w, int c, int k,
+                                  int stride, rn_stream_t stream) {
+  DwArgs a = {};
+  if (int e = fill(&a, n, h, w, c, k, stride)) return e;
+  RN_CHECK_ARG(dy && wgt && dx, "depthwise dgrad: null pointer");
+  a.dy = dy; a.w = wgt; a.out = dx;
+  hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_for((int64_t)n * h * w * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" size_t rn_depthwise_wgrad_workspace(int n, int h, int w, int c, int k, int stride) {
+  DwArgs a = {};
+  if (fill(&a, n, h, w, c, k, stride)) return 0;
+  int chunks, ppc;
+  wgrad_plan(a, &chunks, &ppc);
+  return (size_t)chunks * k * k * c * sizeof(float);
+}
+
+extern "C" int rn_depthwise_wgrad(const float* x, const float* dy, float* dw, int n, int h, int w, int c, int k,
+                                  int stride, void* workspace, size_t workspace_bytes, rn_stream_t stream) {
+  DwArgs a = {};
+  if (int e = fill(&a, n, h, w, c, k, stride)) return e;
+  RN_CHECK_ARG(x && dy && dw && workspace, "depthwise wgrad: null pointer");
+  RN_UNSUPPORTED(k != 3, "depthwise wgrad: only 3x3 kernels (got %d)", k);
+  wgrad_plan(a, &a.chunks, &a.ppc);
+  const size_t need = (size_t)a.chunks * 9 * c * sizeof(float);
+  if (workspace_bytes < need) {
+    rn::set_error("depthwise wgrad: workspace %zu < %zu", workspace_bytes, need);
+    return RN_EWORKSPACE;
+  }
+  a.x = x; a.dy = dy; a.partial = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dw_wgrad_partial_kernel, dim3(a.chunks), dim3(T), 0, st, a);
+  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(rn::ceil_div(9 * c, 256)), dim3(256), 0, st, (const float*)workspace,
+                     dw, 9 * c, a.chunks);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}

@@ -1,0 +1,356 @@
+// GroupNorm fused with the activation, dropout and residual add that follow it in every
+// reference block (normalization.py:20-35; Sequential([conv, Normalization(), activation,
+// Dropout]) e.g. mobilenet_v2.py:56-80; residual mobilenet_v2.py:91-92).
+//
+// HBM-bound.  Forward = 1 read for the statistics + 1 read / 1 write for the apply pass;
+// backward = 2 reads of (x, dy) + 1 write.  Statistics are reduced in a fixed order
+// (per-thread fp32 over a short run -> LDS tree -> per-chunk partial -> fp64 finalize), so the
+// result is bitwise reproducible and safe against E[x^2]-E[x]^2 cancellation.
+// Several tensors that share gamma/beta (one head layer over P3..P7) are one launch.
+#include "rn_common.h"
+
+namespace {
+
+constexpr int T = 256;
+
+struct GnSeg {
+  const float* x; float* y; const float* res; const float* dy; float* dx; float* mean; float* rstd;
+  int n, hw;
+  int sample_start;  // first global sample id
+  int chunk_start;   // first partial row
+  int chunks;        // chunks per sample
+  int ppc;           // pixels per chunk
+};
+
+struct GnArgs {
+  GnSeg seg[RN_MAX_SEG];
+  int nseg, c, groups, cpg, act;
+  float eps, drop_rate;
+  uint64_t seed;
+  const uint64_t* seed_dev;  // optional device counter added to seed (graph replays get fresh masks)
+  const float* gamma; const float* beta;
+  float* partial;  // [total_chunks][c][2]
+  float* coef;     // bwd: [samples][groups][2]
+  float* dgamma; float* dbeta;
+  int total_chunks, total_samples;
+};
+
+__device__ __forceinline__ int seg_of_sample(const GnArgs& a, int q) {
+  int s = 0;
+  while (s + 1 < a.nseg && q >= a.seg[s + 1].sample_start) ++s;
+  return s;
+}
+__device__ __forceinline__ int seg_of_chunk(const GnArgs& a, int ch) {
+  int s = 0;
+  while (s + 1 < a.nseg && ch >= a.seg[s + 1].chunk_start) ++s;
+  return s;
+}
+
+// Per-channel partial sums of (v1, v2) over a chunk of pixels.  BWD=false: (x, x^2);
+// BWD=true: (dya, dya*xhat) with dya = dy * dropmask * act'(z).
+template <bool BWD>
+__global__ __launch_bounds__(T) void gn_partial_kernel(const GnArgs a) {
+  __shared__ float red[T][8];
+  __shared__ float tab[1024][4];  // bwd: mean, rstd, gamma, beta per channel
+  const int tid = threadIdx.x;
+  const int ch = blockIdx.x;
+  const int s = seg_of_chunk(a, ch);
+  const GnSeg& sg = a.seg[s];
+  const int local = ch - sg.chunk_start;
+  const int nl = local / sg.chunks, ck = local - nl * sg.chunks;
+  const int C = a.c, CQ = C >> 2;
+  const int lanes = T / CQ;
+  const int p_begin = ck * sg.ppc, p_end = min(p_begin + sg.ppc, sg.hw);
+  const size_t base = (size_t)nl * sg.hw * C;
+  const float* __restrict__ x = sg.x + base;
+  const float* __restrict__ dy = BWD ? sg.dy + base : nullptr;
+
+  if (BWD) {
+    for (int c = tid; c < C; c += T) {
+      const int g = c / a.cpg;
+      tab[c][0] = sg.mean[nl * a.groups + g];
+      tab[c][1] = sg.rstd[nl * a.groups + g];
+      tab[c][2] = a.gamma[c];
+      tab[c][3] = a.beta[c];
+    }
+    __syncthreads();
+  }
+  const bool drop = a.drop_rate > 0.f;
+  const float keep_scale = drop ? 1.f / (1.f - a.drop_rate) : 1.f;
+  const uint64_t samp_off = (uint64_t)(sg.sample_start + nl) * (uint64_t)sg.hw * (uint64_t)C;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int q4 = tid % CQ, pl = tid / CQ;
+  if (pl < lanes) {
+    for (int p = p_begin + pl; p < p_end; p += lanes) {
+      const size_t off = (size_t)p * C + q4 * 4;
+      const float4 xv = *reinterpret_cast<const float4*>(x + off);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      if (!BWD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[j] += xs[j]; s2[j] += xs[j] * xs[j]; }
+      } else {
+        const float4 dv = *reinterpret_cast<const float4*>(dy + off);
+        const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = q4 * 4 + j;
+          const float xh = (xs[j] - tab[c][0]) * tab[c][1];
+          const float z = xh * tab[c][2] + tab[c][3];
+          float g = ds[j];
+          if (drop) g = (rn::uniform01(seed, samp_off + off + j) >= a.drop_rate) ? g * keep_scale : 0.f;
+          g *= rn::act_grad(z, a.act);
+          s1[j] += g;
+          s2[j] += g * xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[tid][j] = s1[j]; red[tid][4 + j] = s2[j]; }
+  __syncthreads();
+  if (tid < CQ) {
+    float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < lanes; ++l)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] += red[l * CQ + tid][j];
+    float* out = a.partial + ((size_t)ch * C + tid * 4) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { out[2 * j] = t[j]; out[2 * j + 1] = t[4 + j]; }
+  }
+}
+
+// One block per sample: fp64 reduction of the chunk partials per group.
+// BWD=false -> mean / rstd.  BWD=true -> coef[g] = (sum_c gamma_c*S1_c, sum_c gamma_c*S2_c)/m.
+template <bool BWD>
+__global__ __launch_bounds__(T) void gn_finalize_kernel(const GnArgs a) {
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int s = seg_of_sample(a, q);
+  const GnSeg& sg = a.seg[s];
+  const int nl = q - sg.sample_start;
+  int gp2 = 1;
+  while (gp2 < a.groups) gp2 <<= 1;
+  if (gp2 < 4) gp2 = 4;  // keep a group's threads inside one wave (tpg <= 64)
+  const int tpg = T / gp2;  // threads per group (power of two, >= 8 for groups <= 32)
+  const int g = tid / tpg, sub = tid % tpg;
+  double v1 = 0.0, v2 = 0.0;
+  if (g < a.groups) {
+    const int items = sg.chunks * a.cpg;
+    const float* base = a.partial + (size_t)(sg.chunk_start + nl * sg.chunks) * a.c * 2;
+    for (int i = sub; i < items; i += tpg) {
+      const int ck = i / a.cpg, c = g * a.cpg + (i - ck * a.cpg);
+      const float* p = base + ((size_t)ck * a.c + c) * 2;
+      const double w = BWD ? (double)a.gamma[c] : 1.0;
+      v1 += w * (double)p[0];
+      v2 += w * (double)p[1];
+    }
+  }
+  for (int o = tpg >> 1; o > 0; o >>= 1) {
+    v1 += __shfl_xor(v1, o, 64);
+    v2 += __shfl_xor(v2, o, 64);
+  }
+  if (g < a.groups && sub == 0) {
+    const double m = (double)sg.hw * (double)a.cpg;
+    if (!BWD) {
+      const double mean = v1 / m;
+      double var = v2 / m - mean * mean;
+      if (var < 0.0) var = 0.0;
+      sg.mean[nl * a.groups + g] = (float)mean;
+      sg.rstd[nl * a.groups + g] = (float)(1.0 / sqrt(var + (double)a.eps));
+    } else {
+      a.coef[((size_t)q * a.groups + g) * 2 + 0] = (float)(v1 / m);
+      a.coef[((size_t)q * a.groups + g) * 2 + 1] = (float)(v2 / m);
+    }
+  }
+}
+
+// dgamma_c = sum over all samples/chunks of S2_c, dbeta_c = sum of S1_c (fixed order).
+__global__ void gn_param_grad_kernel(const GnArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.c) return;
+  double b = 0.0, g = 0.0;
+  for (int r = 0; r < a.total_chunks; ++r) {
+    const float* p = a.partial + ((size_t)r * a.c + c) * 2;
+    b += (double)p[0];
+    g += (double)p[1];
+  }
+  a.dbeta[c] = (float)b;
+  a.dgamma[c] = (float)g;
+}
+
+// grid (blocks_x, samples).  FWD: y = drop(act((x-mean)*rstd*gamma+beta)) + res.
+// BWD: dx = rstd*(gamma*dya - c1 - xhat*c2).
+template <bool BWD>
+__global__ __launch_bounds__(T) void gn_apply_kernel(const GnArgs a) {
+  __shared__ float tab[1024][6];  // mean, rstd*gamma | rstd, beta, gamma, c1, c2
+  const int q = blockIdx.y, tid = threadIdx.x;
+  const int s = seg_of_sample(a, q);
+  const GnSeg& sg = a.seg[s];
+  const int nl = q - sg.sample_start;
+  const int C = a.c, CQ = C >> 2;
+  for (int c = tid; c < C; c += T) {
+    const int g = c / a.cpg;
+    const float mean = sg.mean[nl * a.groups + g], rstd = sg.rstd[nl * a.groups + g];
+    tab[c][0] = mean;
+    tab[c][1] = rstd;
+    tab[c][2] = a.gamma[c];
+    tab[c][3] = a.beta[c];
+    if (BWD) {
+      tab[c][4] = a.coef[((size_t)q * a.groups + g) * 2 + 0];
+      tab[c][5] = a.coef[((size_t)q * a.groups + g) * 2 + 1];
+    }
+  }
+  __syncthreads();
+  const size_t base = (size_t)nl * sg.hw * C;
+  const float* __restrict__ x = sg.x + base;
+  const bool drop = a.drop_rate > 0.f;
+  const float keep_scale = drop ? 1.f / (1.f - a.drop_rate) : 1.f;
+  const uint64_t samp_off = (uint64_t)q * (uint64_t)sg.hw * (uint64_t)C;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+  const int64_t total = (int64_t)sg.hw * CQ;
+  for (int64_t i = (int64_t)blockIdx.x * T + tid; i < total; i += (int64_t)gridDim.x * T) {
+    const int q4 = (int)(i % CQ);
+    const size_t off = (size_t)i * 4;
+    const float4 xv = *reinterpret_cast<const float4*>(x + off);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float o[4];
+    if (!BWD) {
+      float r[4] = {0.f, 0.f, 0.f, 0.f};
+      if (sg.res) {
+        const float4 rv = *reinterpret_cast<const float4*>(sg.res + base + off);
+        r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = q4 * 4 + j;
+        const float z = (xs[j] - tab[c][0]) * tab[c][1] * tab[c][2] + tab[c][3];
+        float v = rn::act_fwd(z, a.act);
+        if (drop) v = (rn::uniform01(seed, samp_off + off + j) >= a.drop_rate) ? v * keep_scale : 0.f;
+        o[j] = v + r[j];
+      }
+      *reinterpret_cast<float4*>(sg.y + base + off) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+      const float4 dv = *reinterpret_cast<const float4*>(sg.dy + base + off);
+      const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = q4 * 4 + j;
+        const float xh = (xs[j] - tab[c][0]) * tab[c][1];
+        const float z = xh * tab[c][2] + tab[c][3];
+        float g = ds[j];
+        if (drop) g = (rn::uniform01(seed, samp_off + off + j) >= a.drop_rate) ? g * keep_scale : 0.f;
+        g *= rn::act_grad(z, a.act);
+        o[j] = tab[c][1] * (tab[c][2] * g - tab[c][4] - xh * tab[c][5]);
+      }
+      *reinterpret_cast<float4*>(sg.dx + base + off) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+int build_args(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, GnArgs* a, bool bwd) {
+  RN_CHECK_ARG(segs && p, "group_norm: null argument");
+  RN_CHECK_ARG(nseg >= 1 && nseg <= RN_MAX_SEG, "group_norm: nseg %d outside [1,%d]", nseg, RN_MAX_SEG);
+  RN_CHECK_ARG(p->c >= 4 && p->groups >= 1 && p->c % p->groups == 0, "group_norm: c=%d groups=%d", p->c, p->groups);
+  RN_UNSUPPORTED(p->c % 4 != 0 || p->c > 1024, "group_norm: c=%d must be a multiple of 4 and <= 1024", p->c);
+  RN_CHECK_ARG(p->drop_rate >= 0.f && p->drop_rate < 1.f, "group_norm: drop_rate %f", p->drop_rate);
+  a->nseg = nseg; a->c = p->c; a->groups = p->groups; a->cpg = p->c / p->groups; a->act = p->act;
+  a->eps = p->eps; a->drop_rate = p->drop_rate; a->seed = p->drop_seed; a->seed_dev = p->drop_seed_dev;
+  int samples = 0, chunks = 0;
+  for (int s = 0; s < nseg; ++s) {
+    RN_CHECK_ARG(segs[s].x && segs[s].mean && segs[s].rstd && segs[s].n >= 1 && segs[s].hw >= 1,
+                 "group_norm: bad segment %d", s);
+    if (bwd) RN_CHECK_ARG(segs[s].dy && segs[s].dx, "group_norm bwd: null dy/dx in segment %d", s);
+    else RN_CHECK_ARG(segs[s].y, "group_norm fwd: null y in segment %d", s);
+    GnSeg& d = a->seg[s];
+    d.x = segs[s].x; d.y = segs[s].y; d.res = segs[s].residual; d.dy = segs[s].dy; d.dx = segs[s].dx;
+    d.mean = segs[s].mean; d.rstd = segs[s].rstd; d.n = segs[s].n; d.hw = segs[s].hw;
+    d.sample_start = samples; d.chunk_start = chunks;
+    long elems = (long)d.hw * p->c;
+    int ck = (int)((elems + 16383) / 16384);
+    if (ck > 256) ck = 256;
+    if (ck > d.hw) ck = d.hw;
+    if (ck < 1) ck = 1;
+    d.ppc = rn::ceil_div(d.hw, ck);
+    d.chunks = rn::ceil_div(d.hw, d.ppc);
+    samples += d.n;
+    chunks += d.n * d.chunks;
+  }
+  a->total_samples = samples; a->total_chunks = chunks;
+  return RN_OK;
+}
+
+size_t ws_bytes(const GnArgs& a) {
+  return rn::align_up((size_t)a.total_chunks * a.c * 2 * sizeof(float), 256) +
+         rn::align_up((size_t)a.total_samples * a.groups * 2 * sizeof(float), 256);
+}
+
+unsigned apply_blocks(const GnArgs& a) {
+  long mx = 0;
+  for (int s = 0; s < a.nseg; ++s) mx = mx > (long)a.seg[s].hw * (a.c / 4) ? mx : (long)a.seg[s].hw * (a.c / 4);
+  long b = (mx + T * 4 - 1) / (T * 4);
+  if (b < 1) b = 1;
+  if (b > 512) b = 512;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" size_t rn_group_norm_workspace(const rn_gn_seg* segs, int nseg, const rn_gn_params* p) {
+  GnArgs a = {};
+  // workspace query tolerates null data pointers
+  if (!segs || !p || nseg < 1 || nseg > RN_MAX_SEG || p->c < 4 || p->groups < 1) return 0;
+  int samples = 0, chunks = 0;
+  for (int s = 0; s < nseg; ++s) {
+    long elems = (long)segs[s].hw * p->c;
+    int ck = (int)((elems + 16383) / 16384);
+    if (ck > 256) ck = 256;
+    if (ck > segs[s].hw) ck = segs[s].hw;
+    if (ck < 1) ck = 1;
+    int ppc = rn::ceil_div(segs[s].hw, ck);
+    samples += segs[s].n;
+    chunks += segs[s].n * rn::ceil_div(segs[s].hw, ppc);
+  }
+  a.total_chunks = chunks; a.total_samples = samples; a.c = p->c; a.groups = p->groups;
+  return ws_bytes(a);
+}
+
+extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, const float* gamma,
+                                 const float* beta, void* workspace, size_t workspace_bytes, rn_stream_t stream) {
+  GnArgs a = {};
+  if (int e = build_args(segs, nseg, p, &a, false)) return e;
+  RN_CHECK_ARG(gamma && beta && workspace, "group_norm fwd: null gamma/beta/workspace");
+  if (workspace_bytes < ws_bytes(a)) {
+    rn::set_error("group_norm fwd: workspace %zu < %zu", workspace_bytes, ws_bytes(a));
+    return RN_EWORKSPACE;
+  }
+  a.gamma = gamma; a.beta = beta; a.partial = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(a.total_chunks), dim3(T), 0, st, a);
+  hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(a.total_samples), dim3(T), 0, st, a);
+  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(apply_blocks(a), a.total_samples), dim3(T), 0, st, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, const float* gamma,
+                                 const float* beta, float* dgamma, float* dbeta, void* workspace,
+                                 size_t workspace_bytes, rn_stream_t stream) {
+  GnArgs a = {};
+  if (int e = build_args(segs, nseg, p, &a, true)) return e;
+  RN_CHECK_ARG(gamma && beta && dgamma && dbeta && workspace, "group_norm bwd: null argument");
+  if (workspace_bytes < ws_bytes(a)) {
+    rn::set_error("group_norm bwd: workspace %zu < %zu", workspace_bytes, ws_bytes(a));
+    return RN_EWORKSPACE;
+  }
+  a.gamma = gamma; a.beta = beta; a.dgamma = dgamma; a.dbeta = dbeta;
+  a.partial = (float*)workspace;
+  a.coef = (float*)((char*)workspace + rn::align_up((size_t)a.total_chunks * a.c * 2 * sizeof(float), 256));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(a.total_chunks), dim3(T), 0, st, a);
+  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(a.total_samples), dim3(T), 0, st, a);
+  hipLaunchKernelGGL(gn_param_grad_kernel, dim3(rn::ceil_div(a.c, 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(apply_blocks(a), a.total_samples), dim3(T), 0, st, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}

@@ -1,0 +1,267 @@
+// Fused detection loss over all anchors of all pyramid levels (losses.py:155-175 behind
+// utils.process_labels_and_logits, utils.py:240-284).
+//
+// The reference compacts the trainable rows with boolean_mask and concatenates P3..P7; the
+// same numbers fall out of treating the mask as a 0/1 row weight, so nothing is gathered:
+//   M      = #trainable rows, fg = trainable row whose max label > 0.5 (utils.py:171-179)
+//   bce_dice: mean_{M,C} BCE + mean_C (1 - 2 I_c / (L_c + P_c))          (losses.py:124-139)
+//   focal   : sum focal / max(#fg, 1)                                     (losses.py:6-15,119-122)
+//   regr    : sum_{fg,4} huber_1(label - pred) / (4 #fg), 0 if no fg      (losses.py:144-152)
+// One wave owns one row at a time (lanes stride over the classes, coalesced 4-B loads of a
+// contiguous row), so the per-class dice sums stay in registers.  Two passes: reduce -> stats,
+// then an elementwise gradient pass that reads the stats.  Fixed-order reduction (per-wave
+// registers -> LDS -> per-block partial -> fp64 finalize): bitwise reproducible.
+#include "rn_common.h"
+
+namespace {
+
+constexpr int T = 256;
+constexpr int WAVES = T / 64;
+constexpr int MAXJ = 4;          // classes per lane => C <= 256
+constexpr int NSCAL = 5;         // M, fg, bce, focal, huber
+constexpr int BLOCKS = 1024;
+
+struct LossSeg {
+  const float* zl; const float* ll; const float* rp; const float* rl; const uint8_t* tm;
+  float* dz; float* dr;
+  int64_t rows; int64_t row_start;
+};
+struct LossArgs {
+  LossSeg seg[RN_MAX_SEG];
+  int nseg, C, mode;
+  int64_t total_rows;
+  float* partial;  // [BLOCKS][NSCAL + 3*C]
+  float* stats;
+  const float* g_cls; const float* g_reg;
+};
+
+__device__ __forceinline__ int seg_of_row(const LossArgs& a, int64_t r) {
+  int s = 0;
+  while (s + 1 < a.nseg && r >= a.seg[s + 1].row_start) ++s;
+  return s;
+}
+__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
+__device__ __forceinline__ float huber1(float e) {
+  const float a = fabsf(e), q = fminf(a, 1.f);
+  return 0.5f * q * q + (a - q);
+}
+
+__global__ __launch_bounds__(T) void loss_reduce_kernel(const LossArgs a) {
+  __shared__ float red[WAVES][NSCAL + 3 * 64 * MAXJ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = a.C;
+  float I[MAXJ], L[MAXJ], P[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) I[j] = L[j] = P[j] = 0.f;
+  float s_m = 0.f, s_fg = 0.f, s_bce = 0.f, s_focal = 0.f, s_hub = 0.f;
+
+  const int64_t wave_id = (int64_t)blockIdx.x * WAVES + wave, nwaves = (int64_t)gridDim.x * WAVES;
+  for (int64_t r = wave_id; r < a.total_rows; r += nwaves) {
+    const int s = seg_of_row(a, r);
+    const LossSeg& sg = a.seg[s];
+    const int64_t lr = r - sg.row_start;
+    if (!sg.tm[lr]) continue;  // wave-uniform
+    const float* __restrict__ zrow = sg.zl + lr * C;
+    const float* __restrict__ lrow = sg.ll + lr * C;
+    float lmax = -1e30f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C) {
+        const float z = zrow[c], l = lrow[c];
+        const float p = sigmoidf(z);
+        lmax = fmaxf(lmax, l);
+        I[j] += l * p; L[j] += l; P[j] += p;
+        if (a.mode == RN_LOSS_BCE_DICE) {
+          s_bce += fmaxf(z, 0.f) - z * l + log1pf(expf(-fabsf(z)));
+        } else {
+          const bool pos = (l == 1.f);
+          const float pt = pos ? p : 1.f - p;
+          const float al = pos ? 0.25f : 0.75f;
+          const float om = 1.f - pt;
+          s_focal += -al * om * om * logf(pt + 1e-7f);
+        }
+      }
+    }
+    lmax = rn::wave_max(lmax);
+    const bool fg = lmax > 0.5f;
+    if (lane == 0) { s_m += 1.f; s_fg += fg ? 1.f : 0.f; }
+    if (fg && lane < 4) s_hub += huber1(sg.rl[lr * 4 + lane] - sg.rp[lr * 4 + lane]);
+  }
+  // wave-level sums of the scalars
+  s_m = rn::wave_sum(s_m); s_fg = rn::wave_sum(s_fg); s_bce = rn::wave_sum(s_bce);
+  s_focal = rn::wave_sum(s_focal); s_hub = rn::wave_sum(s_hub);
+  if (lane == 0) { red[wave][0] = s_m; red[wave][1] = s_fg; red[wave][2] = s_bce; red[wave][3] = s_focal; red[wave][4] = s_hub; }
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int c = lane + 64 * j;
+    red[wave][NSCAL + 3 * c + 0] = I[j];
+    red[wave][NSCAL + 3 * c + 1] = L[j];
+    red[wave][NSCAL + 3 * c + 2] = P[j];
+  }
+  __syncthreads();
+  const int n = NSCAL + 3 * C;
+  for (int i = tid; i < n; i += T) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += red[w][i];
+    a.partial[(size_t)blockIdx.x * n + i] = v;
+  }
+}
+
+__global__ void loss_finalize_kernel(const LossArgs a, int nblocks) {
+  __shared__ double sh[NSCAL + 3 * 64 * MAXJ];
+  const int n = NSCAL + 3 * a.C;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    double v = 0.0;
+    for (int b = 0; b < nblocks; ++b) v += (double)a.partial[(size_t)b * n + i];
+    sh[i] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * a.C; i += blockDim.x) a.stats[RN_LOSS_STATS_HEADER + i] = (float)sh[NSCAL + i];
+  if (threadIdx.x == 0) {
+    const double M = sh[0], fg = sh[1];
+    double cls;
+    if (a.mode == RN_LOSS_BCE_DICE) {
+      double dice = 0.0;
+      for (int c = 0; c < a.C; ++c) {
+        const double I = sh[NSCAL + 3 * c], U = sh[NSCAL + 3 * c + 1] + sh[NSCAL + 3 * c + 2];
+        dice += 1.0 - 2.0 * I / U;
+      }
+      cls = sh[2] / (M * a.C) + dice / a.C;
+    } else {
+      cls = sh[3] / (fg > 1.0 ? fg : 1.0);
+    }
+    const double reg = fg > 0.0 ? sh[4] / (4.0 * fg) : 0.0;
+    a.stats[0] = (float)cls; a.stats[1] = (float)reg; a.stats[2] = (float)M; a.stats[3] = (float)fg;
+    a.stats[4] = (float)sh[2]; a.stats[5] = (float)sh[3]; a.stats[6] = (float)sh[4]; a.stats[7] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(T) void loss_grad_kernel(const LossArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = a.C;
+  const float M = a.stats[2], nfg = a.stats[3];
+  const float gc = a.g_cls[0], gr = a.g_reg[0];
+  const float k_bce = gc / (M * (float)C);
+  const float k_dice = gc * 2.f / (float)C;
+  const float k_focal = gc / fmaxf(nfg, 1.f);
+  const float k_reg = nfg > 0.f ? gr / (4.f * nfg) : 0.f;
+  float Ic[MAXJ], Uc[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int c = lane + 64 * j;
+    Ic[j] = c < C ? a.stats[RN_LOSS_STATS_HEADER + 3 * c] : 0.f;
+    Uc[j] = c < C ? a.stats[RN_LOSS_STATS_HEADER + 3 * c + 1] + a.stats[RN_LOSS_STATS_HEADER + 3 * c + 2] : 1.f;
+  }
+  const int64_t wave_id = (int64_t)blockIdx.x * WAVES + wave, nwaves = (int64_t)gridDim.x * WAVES;
+  for (int64_t r = wave_id; r < a.total_rows; r += nwaves) {
+    const int s = seg_of_row(a, r);
+    const LossSeg& sg = a.seg[s];
+    const int64_t lr = r - sg.row_start;
+    float* __restrict__ dzrow = sg.dz + lr * C;
+    if (!sg.tm[lr]) {
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) { const int c = lane + 64 * j; if (c < C) dzrow[c] = 0.f; }
+      if (lane < 4) sg.dr[lr * 4 + lane] = 0.f;
+      continue;
+    }
+    const float* __restrict__ zrow = sg.zl + lr * C;
+    const float* __restrict__ lrow = sg.ll + lr * C;
+    float lmax = -1e30f;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C) {
+        const float z = zrow[c], l = lrow[c];
+        const float p = sigmoidf(z);
+        lmax = fmaxf(lmax, l);
+        float g;
+        if (a.mode == RN_LOSS_BCE_DICE) {
+          // d/dz [bce/(M C)] = (p - l)/(M C);  d/dz [-(2/C) I/U] = -(2/C) p(1-p) (l U - I)/U^2
+          const float U = Uc[j];
+          g = k_bce * (p - l) - k_dice * p * (1.f - p) * (l * U - Ic[j]) / (U * U);
+        } else {
+          // f = -al (1-pt)^2 log(pt+eps); dpt/dz = +-p(1-p)
+          const bool pos = (l == 1.f);
+          const float pt = pos ? p : 1.f - p;
+          const float al = pos ? 0.25f : 0.75f;
+          const float om = 1.f - pt;
+          const float dfdpt = -al * (-2.f * om * logf(pt + 1e-7f) + om * om / (pt + 1e-7f));
+          g = k_focal * dfdpt * (pos ? 1.f : -1.f) * p * (1.f - p);
+        }
+        dzrow[c] = g;
+      }
+    }
+    lmax = rn::wave_max(lmax);
+    if (lane < 4) {
+      float g = 0.f;
+      if (lmax > 0.5f) {
+        const float e = sg.rp[lr * 4 + lane] - sg.rl[lr * 4 + lane];  // d huber(l - p)/dp = clip(p - l)
+        g = k_reg * fminf(fmaxf(e, -1.f), 1.f);
+      }
+      sg.dr[lr * 4 + lane] = g;
+    }
+  }
+}
+
+int build(const rn_loss_seg* segs, int nseg, int C, int mode, LossArgs* a, bool bwd) {
+  RN_CHECK_ARG(segs && nseg >= 1 && nseg <= RN_MAX_SEG, "loss: bad segments");
+  RN_UNSUPPORTED(C < 1 || C > 64 * MAXJ, "loss: num_classes %d outside [1,%d]", C, 64 * MAXJ);
+  RN_CHECK_ARG(mode == RN_LOSS_BCE_DICE || mode == RN_LOSS_FOCAL, "loss: bad mode %d", mode);
+  a->nseg = nseg; a->C = C; a->mode = mode;
+  int64_t rows = 0;
+  for (int s = 0; s < nseg; ++s) {
+    RN_CHECK_ARG(segs[s].cls_logit && segs[s].cls_label && segs[s].reg_pred && segs[s].reg_label && segs[s].trainable &&
+                 segs[s].rows >= 0, "loss: null pointer in segment %d", s);
+    if (bwd) RN_CHECK_ARG(segs[s].d_cls_logit && segs[s].d_reg_pred, "loss bwd: null gradient buffer in segment %d", s);
+    LossSeg& d = a->seg[s];
+    d.zl = segs[s].cls_logit; d.ll = segs[s].cls_label; d.rp = segs[s].reg_pred; d.rl = segs[s].reg_label;
+    d.tm = segs[s].trainable; d.dz = segs[s].d_cls_logit; d.dr = segs[s].d_reg_pred;
+    d.rows = segs[s].rows; d.row_start = rows;
+    rows += segs[s].rows;
+  }
+  a->total_rows = rows;
+  return RN_OK;
+}
+
+int nblocks_for(int64_t rows) {
+  int64_t b = (rows + WAVES * 8 - 1) / (WAVES * 8);
+  if (b > BLOCKS) b = BLOCKS;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+}  // namespace
+
+extern "C" size_t rn_loss_workspace(const rn_loss_seg*, int, int num_classes) {
+  return (size_t)BLOCKS * (NSCAL + 3 * (size_t)num_classes) * sizeof(float);
+}
+
+extern "C" int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, float* stats, void* workspace,
+                           size_t workspace_bytes, rn_stream_t stream) {
+  LossArgs a = {};
+  if (int e = build(segs, nseg, num_classes, mode, &a, false)) return e;
+  RN_CHECK_ARG(stats && workspace, "loss fwd: null stats/workspace");
+  if (workspace_bytes < rn_loss_workspace(segs, nseg, num_classes)) {
+    rn::set_error("loss fwd: workspace too small");
+    return RN_EWORKSPACE;
+  }
+  a.partial = (float*)workspace; a.stats = stats;
+  const int nb = nblocks_for(a.total_rows);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(nb), dim3(T), 0, st, a);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, a, nb);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_loss_bwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, const float* stats,
+                           const float* g_cls, const float* g_reg, rn_stream_t stream) {
+  LossArgs a = {};
+  if (int e = build(segs, nseg, num_classes, mode, &a, true)) return e;
+  RN_CHECK_ARG(stats && g_cls && g_reg, "loss bwd: null stats/upstream gradient");
+  a.stats = const_cast<float*>(stats); a.g_cls = g_cls; a.g_reg = g_reg;
+  hipLaunchKernelGGL(loss_grad_kernel, dim3(nblocks_for(a.total_rows)), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}

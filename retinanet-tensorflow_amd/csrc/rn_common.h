@@ -1,0 +1,107 @@
+// Shared helpers for the gfx950 kernels of librn_hip.so (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "rn_hip.h"
+
+namespace rn {
+
+void set_error(const char* fmt, ...);
+
+#define RN_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      rn::set_error(__VA_ARGS__);          \
+      return RN_EINVAL;                    \
+    }                                      \
+  } while (0)
+
+#define RN_UNSUPPORTED(cond, ...)          \
+  do {                                     \
+    if (cond) {                            \
+      rn::set_error(__VA_ARGS__);          \
+      return RN_EUNSUPPORTED;              \
+    }                                      \
+  } while (0)
+
+#define RN_LAUNCH_CHECK()                                                     \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) {                                                  \
+      rn::set_error("%s:%d HIP launch error: %s", __FILE__, __LINE__,         \
+                    hipGetErrorString(e__));                                  \
+      return RN_EHIP;                                                         \
+    }                                                                         \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// TF SAME padding
+static inline void same_pad(int n, int k, int s, int* out, int* before) {
+  int o = (n + s - 1) / s;
+  int total = (o - 1) * s + k - n;
+  if (total < 0) total = 0;
+  *out = o;
+  *before = total / 2;
+}
+
+// Blocks are dealt round-robin over the 8 XCDs (each with a private L2).  Remap the linear
+// block id so that consecutive logical tiles (which share operand panels) land on ONE XCD.
+// Bijective for any grid size (cdna_hip_programming.md T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  switch (act) {
+    case RN_ACT_RELU: return z > 0.f ? z : 0.f;
+    case RN_ACT_ELU: return z > 0.f ? z : expm1f(z);
+    case RN_ACT_RELU6: return fminf(fmaxf(z, 0.f), 6.f);
+    case RN_ACT_SIGMOID: return 1.f / (1.f + expf(-z));
+    default: return z;
+  }
+}
+// derivative w.r.t. the pre-activation z
+__device__ __forceinline__ float act_grad(float z, int act) {
+  switch (act) {
+    case RN_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case RN_ACT_ELU: return z > 0.f ? 1.f : expf(z);
+    case RN_ACT_RELU6: return (z > 0.f && z < 6.f) ? 1.f : 0.f;
+    case RN_ACT_SIGMOID: { const float p = 1.f / (1.f + expf(-z)); return p * (1.f - p); }
+    default: return 1.f;
+  }
+}
+
+// counter-based uniform in [0,1): splitmix64 finaliser of (seed, index)
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace rn

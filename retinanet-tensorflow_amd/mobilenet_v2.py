@@ -1,0 +1,104 @@
+"""MobileNetV2 bottom-up network (drop-in for reference mobilenet_v2.py:15-223), GroupNorm
+variant, NHWC fp32 on gfx950 kernels.
+
+    net = MobileNetV2(activation=layers.elu, dropout_rate=0.2)
+    feats = net(image, training=True)      # {'C1'..'C5'}, strides 2..32
+
+Block table (filters, expansion, stride) and the taps follow mobilenet_v2.py:120-223:
+stem 3x3/2 -> 32; 17 inverted-residual bottlenecks (expand 1x1 -> depthwise 3x3 -> linear 1x1,
+each + GroupNorm, dropout; residual iff shapes match, :91-92); final 1x1 -> 32 channels (:178-185,
+SURVEY Q8).  Each [conv, Normalization, activation, Dropout] run is conv kernel + ONE fused
+GroupNorm kernel (the residual add rides in the same kernel).
+"""
+import layers as L
+from model import Model, Sequential
+from normalization import Normalization
+
+# stage -> (filters, expansion, [strides of its blocks])
+_STAGES = (
+    (1, 16, 1, (1,)),
+    (2, 24, 6, (2, 1)),
+    (3, 32, 6, (2, 1, 1)),
+    (4, 64, 6, (2, 1, 1, 1)),
+    (5, 96, 6, (1, 1, 1)),
+    (6, 160, 6, (2, 1, 1)),
+    (7, 320, 6, (1,)),
+)
+_TAP_AFTER = {'bottleneck_1_1': 'C1', 'bottleneck_2_2': 'C2', 'bottleneck_3_3': 'C3', 'bottleneck_5_3': 'C4'}
+
+
+class DepthwiseConv2D(L.DepthwiseConv2D):
+    pass
+
+
+class Bottleneck(Model):
+    def __init__(self, filters, strides, expansion_factor, activation, dropout_rate, kernel_initializer,
+                 kernel_regularizer, name='bottleneck', in_channels=None):
+        super().__init__(name=name)
+        self._cfg = (filters, strides, expansion_factor, L.get_activation(activation), dropout_rate,
+                     kernel_initializer, kernel_regularizer)
+        self.expand_conv = self.depthwise_conv = self.linear_conv = None
+        if in_channels is not None:
+            self.build(in_channels)
+
+    def build(self, in_channels):
+        filters, strides, t, act, rate, init, reg = self._cfg
+        wide = in_channels * t
+
+        def pointwise(cout, cin):
+            return L.Conv2D(cout, 1, use_bias=False, kernel_initializer=init, kernel_regularizer=reg, in_channels=cin)
+
+        self.expand_conv = Sequential([pointwise(wide, in_channels), Normalization(channels=wide), act, L.Dropout(rate)])
+        self.depthwise_conv = Sequential([
+            DepthwiseConv2D(3, strides=strides, padding='same', use_bias=False, kernel_initializer=init,
+                            kernel_regularizer=reg, in_channels=wide),
+            Normalization(channels=wide), act, L.Dropout(rate)])
+        self.linear_conv = Sequential([pointwise(filters, wide), Normalization(channels=filters), L.Dropout(rate)])
+        self._same_shape = (strides == 1 and filters == in_channels)
+
+    def call(self, input, training):
+        if self.expand_conv is None:
+            self.build(input.shape[3])
+            self.to(input.device)
+        identity = input if self._same_shape else None
+        input = self.expand_conv(input, training)
+        input = self.depthwise_conv(input, training)
+        return self.linear_conv(input, training, residual=identity)
+
+
+class MobileNetV2(Model):
+    def __init__(self, activation, dropout_rate, name='mobilenet_v2'):
+        super().__init__(name=name)
+        act = L.relu6 if activation is None else L.get_activation(activation)
+        init = L.VarianceScaling(factor=2.0)
+        reg = L.L2Regularizer(scale=4e-5)
+
+        def conv_block(cout, k, stride, cin):
+            return Sequential([
+                L.Conv2D(cout, k, strides=stride, padding='same', use_bias=False, kernel_initializer=init,
+                         kernel_regularizer=reg, in_channels=cin),
+                Normalization(channels=cout), act, L.Dropout(dropout_rate)])
+
+        self.input_conv = conv_block(32, 3, 2, 3)
+        self.block_names = []
+        channels = 32
+        for stage, filters, t, strides in _STAGES:
+            for i, s in enumerate(strides):
+                name = 'bottleneck_%d_%d' % (stage, i + 1)
+                setattr(self, name, Bottleneck(filters, strides=s, expansion_factor=t, activation=act,
+                                               dropout_rate=dropout_rate, kernel_initializer=init,
+                                               kernel_regularizer=reg, name=name, in_channels=channels))
+                self.block_names.append(name)
+                channels = filters
+        self.output_conv = conv_block(32, 1, 1, channels)
+        self.out_channels = {'C3': 32, 'C4': 96, 'C5': 32}
+
+    def call(self, input, training):
+        out = {}
+        input = self.input_conv(input, training)
+        for name in self.block_names:
+            input = getattr(self, name)(input, training)
+            if name in _TAP_AFTER:
+                out[_TAP_AFTER[name]] = input
+        out['C5'] = self.output_conv(input, training)
+        return out

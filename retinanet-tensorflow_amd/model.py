@@ -1,0 +1,72 @@
+"""Layer containers with the reference's calling convention (reference model.py:5-25).
+
+``Model`` is the base class of every block; ``Sequential(layers)(input, training)`` runs the
+layers in order and hands ``training=`` only to callees whose signature has it
+(model.py:16-25).  Device work happens in the layers (hand-written HIP kernels via ops.py);
+this file is host-side plumbing.  On top of the reference behaviour, ``Sequential`` fuses
+the ubiquitous ``[Normalization, activation, Dropout]`` run into ONE GroupNorm kernel and
+accepts a list of tensors (pyramid levels sharing the layers) that run as one launch per
+layer.
+"""
+import inspect
+
+import torch
+
+import layers as L
+
+
+class Model(torch.nn.Module):
+    def __init__(self, name='model'):
+        super().__init__()
+        self.model_name = name
+
+    def call(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def forward(self, *args, **kwargs):
+        return self.call(*args, **kwargs)
+
+
+def _accepts_training(fn):
+    try:
+        return 'training' in inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+
+
+class Sequential(Model):
+    def __init__(self, layers, name='sequential'):
+        super().__init__(name=name)
+        self.layers = list(layers)
+        # register sub-modules so parameters are found; plain callables (activations) stay as is
+        self._mods = torch.nn.ModuleList([l for l in self.layers if isinstance(l, torch.nn.Module)])
+
+    def call(self, input, training, residual=None):
+        """`residual` (optional) is added after the LAST layer; it is fused into the GroupNorm
+        kernel when the run ends with a fusable [Normalization, act, Dropout] group."""
+        i, n = 0, len(self.layers)
+        while i < n:
+            layer = self.layers[i]
+            if isinstance(layer, L.GroupNormalization):
+                act, drop, j = None, None, i + 1
+                if j < n and L.activation_name(self.layers[j]) is not None:
+                    act, j = L.activation_name(self.layers[j]), j + 1
+                if j < n and isinstance(self.layers[j], L.Dropout):
+                    drop, j = self.layers[j], j + 1
+                res = residual if j == n else None
+                input = layer.fused(input, training, act=act, dropout=drop, residual=res)
+                if res is not None:
+                    residual = None
+                i = j
+                continue
+            target = layer.call if isinstance(layer, Model) else layer
+            if isinstance(layer, torch.nn.Module) and not isinstance(layer, Model):
+                target = layer.forward
+            if _accepts_training(target):
+                input = layer(input, training=training)
+            else:
+                input = layer(input)
+            i += 1
+        if residual is not None:
+            input = L.add(input, residual)
+        return input

@@ -1,0 +1,372 @@
+"""Autograd carriers for the gfx950 kernels (librn_hip.so).
+
+Each ``torch.autograd.Function`` here only allocates outputs, fills the C-ABI segment
+structs with raw pointers and launches the HIP kernels on the current stream; all the
+arithmetic is in ``csrc/``.  Lists of tensors are "segments" that share the layer's
+parameters and run in one launch (the shared heads over P3..P7, reference
+retinanet.py:283-291).
+"""
+import ctypes as C
+
+import torch
+
+import _rn
+
+
+def _as_list(x):
+    return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
+def _conv_segs(xs, w, bias, ys, dys, dxs):
+    cout = w.shape[3]
+    segs = (_rn.ConvSeg * len(xs))()
+    for i, x in enumerate(xs):
+        s = segs[i]
+        s.x = _rn.f32(x) if x is not None else None
+        s.wgt = _rn.f32(w)
+        s.bias = _rn.f32(bias) if bias is not None else None
+        s.y = _rn.f32(ys[i]) if ys is not None else None
+        s.dy = _rn.f32(dys[i]) if dys is not None else None
+        s.dx = _rn.f32(dxs[i]) if dxs is not None else None
+        s.n, s.h, s.w = x.shape[0], x.shape[1], x.shape[2]
+        s.cout = cout
+    return segs
+
+
+class _Conv2dShared(torch.autograd.Function):
+    """tf.layers.Conv2D(padding='same') applied to n inputs that share one kernel."""
+
+    @staticmethod
+    def forward(ctx, stride, w, bias, *xs):
+        kh, kw, cin, cout = w.shape
+        L = _rn.lib()
+        geom = _rn.ConvGeom(kh, kw, stride, cin)
+        ys = []
+        for x in xs:
+            assert x.dim() == 4 and x.shape[3] == cin, "conv2d: input %s vs kernel %s" % (tuple(x.shape), tuple(w.shape))
+            oh, _ = _rn.same_pad(x.shape[1], kh, stride)
+            ow, _ = _rn.same_pad(x.shape[2], kw, stride)
+            ys.append(torch.empty((x.shape[0], oh, ow, cout), dtype=torch.float32, device=x.device))
+        xs = [x.contiguous() for x in xs]
+        segs = _conv_segs(xs, w, bias, ys, None, None)
+        _rn.check(L.rn_conv2d_fwd(segs, len(xs), C.byref(geom), _rn.stream()), "rn_conv2d_fwd")
+        ctx.stride = stride
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(w, *xs)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        w, *xs = ctx.saved_tensors
+        kh, kw, cin, cout = w.shape
+        L = _rn.lib()
+        geom = _rn.ConvGeom(kh, kw, ctx.stride, cin)
+        n = len(xs)
+        dys = [dy.contiguous() if dy is not None else None for dy in dys]
+        for i in range(n):
+            if dys[i] is None:
+                oh, _ = _rn.same_pad(xs[i].shape[1], kh, ctx.stride)
+                ow, _ = _rn.same_pad(xs[i].shape[2], kw, ctx.stride)
+                dys[i] = torch.zeros((xs[i].shape[0], oh, ow, cout), dtype=torch.float32, device=w.device)
+        need_dx = [ctx.needs_input_grad[3 + i] for i in range(n)]
+        dxs = [None] * n
+        if any(need_dx):
+            idx = [i for i in range(n) if need_dx[i]]
+            outs = [torch.empty_like(xs[i]) for i in idx]
+            segs = _conv_segs([xs[i] for i in idx], w, None, None, [dys[i] for i in idx], outs)
+            _rn.check(L.rn_conv2d_dgrad(segs, len(idx), C.byref(geom), _rn.stream()), "rn_conv2d_dgrad")
+            for i, o in zip(idx, outs):
+                dxs[i] = o
+        dw = None
+        if ctx.needs_input_grad[1]:
+            segs = _conv_segs(xs, w, None, None, dys, None)
+            need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
+            ws = _rn.workspace(need, w.device)
+            dw = torch.empty_like(w)
+            _rn.check(L.rn_conv2d_wgrad(segs, n, C.byref(geom), _rn.f32(dw), 0, ws.data_ptr(), ws.numel(),
+                                        _rn.stream()), "rn_conv2d_wgrad")
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            segs = _conv_segs(xs, w, None, None, dys, None)
+            need = L.rn_conv2d_bias_grad_workspace(cout)
+            ws = _rn.workspace(need, w.device)
+            db = torch.empty((cout,), dtype=torch.float32, device=w.device)
+            _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db), ws.data_ptr(), ws.numel(),
+                                            _rn.stream()), "rn_conv2d_bias_grad")
+        return (None, dw, db) + tuple(dxs)
+
+
+def conv2d(x, w, bias=None, stride=1):
+    """NHWC conv, HWIO kernel, TF SAME padding.  `x` may be a list (shared kernel, one launch)."""
+    if isinstance(x, (list, tuple)):
+        return list(_Conv2dShared.apply(stride, w, bias, *x))
+    return _Conv2dShared.apply(stride, w, bias, x)[0]
+
+
+class _Depthwise(torch.autograd.Function):
+    """tf.nn.depthwise_conv2d(padding='SAME'), kernel [k,k,C,1] (mobilenet_v2.py:35-36)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        k = w.shape[0]
+        n, h, wd, c = x.shape
+        assert w.shape[2] == c and w.shape[3] == 1
+        x = x.contiguous()
+        oh, _ = _rn.same_pad(h, k, stride)
+        ow, _ = _rn.same_pad(wd, k, stride)
+        y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
+        _rn.check(_rn.lib().rn_depthwise_fwd(_rn.f32(x), _rn.f32(w), _rn.f32(y), n, h, wd, c, k, stride,
+                                             _rn.stream()), "rn_depthwise_fwd")
+        ctx.stride = stride
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        k = w.shape[0]
+        n, h, wd, c = x.shape
+        dy = dy.contiguous()
+        L = _rn.lib()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _rn.check(L.rn_depthwise_dgrad(_rn.f32(dy), _rn.f32(w), _rn.f32(dx), n, h, wd, c, k, ctx.stride,
+                                           _rn.stream()), "rn_depthwise_dgrad")
+        if ctx.needs_input_grad[1]:
+            need = L.rn_depthwise_wgrad_workspace(n, h, wd, c, k, ctx.stride)
+            ws = _rn.workspace(need, x.device)
+            dw = torch.empty_like(w)
+            _rn.check(L.rn_depthwise_wgrad(_rn.f32(x), _rn.f32(dy), _rn.f32(dw), n, h, wd, c, k, ctx.stride,
+                                           ws.data_ptr(), ws.numel(), _rn.stream()), "rn_depthwise_wgrad")
+        return dx, dw, None
+
+
+def depthwise_conv2d(x, w, stride=1):
+    return _Depthwise.apply(x, w, stride)
+
+
+def gn_groups(c, groups=32):
+    """Largest divisor of c that is <= min(groups, c): the reference's min(32, C) rule
+    (normalization.py:24) made total for C=144, where the reference itself cannot run
+    (SURVEY Q2)."""
+    g = min(groups, c)
+    while c % g:
+        g -= 1
+    return g
+
+
+def _gn_segs(xs, ys, ress, dys, dxs, means, rstds):
+    segs = (_rn.GnSeg * len(xs))()
+    for i, x in enumerate(xs):
+        s = segs[i]
+        s.x = _rn.f32(x)
+        s.y = _rn.f32(ys[i]) if ys is not None else None
+        s.residual = _rn.f32(ress[i]) if ress is not None and ress[i] is not None else None
+        s.dy = _rn.f32(dys[i]) if dys is not None else None
+        s.dx = _rn.f32(dxs[i]) if dxs is not None else None
+        s.mean = _rn.f32(means[i])
+        s.rstd = _rn.f32(rstds[i])
+        s.n = x.shape[0]
+        s.hw = x.shape[1] * x.shape[2]
+    return segs
+
+
+class _GroupNormAct(torch.autograd.Function):
+    """y_i = dropout(act(GN(x_i))) + residual_i for n tensors sharing gamma/beta."""
+
+    @staticmethod
+    def forward(ctx, cfg, gamma, beta, n, *tensors):
+        groups, eps, act, drop_rate, seed, seed_dev = cfg
+        xs = [t.contiguous() for t in tensors[:n]]
+        ress = [t.contiguous() if t is not None else None for t in tensors[n:2 * n]]
+        c = xs[0].shape[3]
+        g = gn_groups(c, groups)
+        L = _rn.lib()
+        dev = xs[0].device
+        ys = [torch.empty_like(x) for x in xs]
+        means = [torch.empty((x.shape[0], g), dtype=torch.float32, device=dev) for x in xs]
+        rstds = [torch.empty((x.shape[0], g), dtype=torch.float32, device=dev) for x in xs]
+        for x, r in zip(xs, ress):
+            assert x.shape[3] == c and (r is None or r.shape == x.shape)
+        params = _rn.GnParams(c, g, _rn.ACT[act], eps, drop_rate, seed,
+                              seed_dev.data_ptr() if seed_dev is not None else None)
+        segs = _gn_segs(xs, ys, ress, None, None, means, rstds)
+        need = L.rn_group_norm_workspace(segs, n, C.byref(params))
+        ws = _rn.workspace(need, dev)
+        _rn.check(L.rn_group_norm_fwd(segs, n, C.byref(params), _rn.f32(gamma), _rn.f32(beta), ws.data_ptr(),
+                                      ws.numel(), _rn.stream()), "rn_group_norm_fwd")
+        ctx.cfg = (c, g, eps, act, drop_rate, seed, seed_dev)
+        ctx.n = n
+        ctx.has_res = [r is not None for r in ress]
+        ctx.save_for_backward(gamma, beta, *xs, *means, *rstds)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        gamma, beta = saved[0], saved[1]
+        xs = list(saved[2:2 + n])
+        means = list(saved[2 + n:2 + 2 * n])
+        rstds = list(saved[2 + 2 * n:2 + 3 * n])
+        c, g, eps, act, drop_rate, seed, seed_dev = ctx.cfg
+        L = _rn.lib()
+        dev = xs[0].device
+        dys = [dy.contiguous() if dy is not None else torch.zeros_like(x) for dy, x in zip(dys, xs)]
+        dxs = [torch.empty_like(x) for x in xs]
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        params = _rn.GnParams(c, g, _rn.ACT[act], eps, drop_rate, seed,
+                              seed_dev.data_ptr() if seed_dev is not None else None)
+        segs = _gn_segs(xs, None, None, dys, dxs, means, rstds)
+        need = L.rn_group_norm_workspace(segs, n, C.byref(params))
+        ws = _rn.workspace(need, dev)
+        _rn.check(L.rn_group_norm_bwd(segs, n, C.byref(params), _rn.f32(gamma), _rn.f32(beta), _rn.f32(dgamma),
+                                      _rn.f32(dbeta), ws.data_ptr(), ws.numel(), _rn.stream()),
+                  "rn_group_norm_bwd")
+        dres = [dys[i] if ctx.has_res[i] else None for i in range(n)]
+        return (None, dgamma, dbeta, None) + tuple(dxs) + tuple(dres)
+
+
+def group_norm_act(x, gamma, beta, groups=32, eps=1e-5, act=None, residual=None, drop_rate=0.0, seed=0,
+                   seed_dev=None):
+    """Fused GroupNorm -> activation -> dropout -> (+ residual).  `x` / `residual` may be lists."""
+    multi = isinstance(x, (list, tuple))
+    xs = _as_list(x)
+    ress = _as_list(residual) if residual is not None else [None] * len(xs)
+    cfg = (groups, float(eps), act, float(drop_rate), int(seed), seed_dev)
+    ys = _GroupNormAct.apply(cfg, gamma, beta, len(xs), *xs, *ress)
+    return list(ys) if multi else ys[0]
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _rn.check(_rn.lib().rn_act_fwd(_rn.f32(x), _rn.f32(y), x.numel(), _rn.ACT[act], _rn.stream()), "rn_act_fwd")
+        ctx.act = act
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _rn.check(_rn.lib().rn_act_bwd(_rn.f32(x), _rn.f32(dy), _rn.f32(dx), x.numel(), _rn.ACT[ctx.act],
+                                       _rn.stream()), "rn_act_bwd")
+        return dx, None
+
+
+def activation(x, act):
+    if _rn.ACT[act] == 0:
+        return x
+    return _Act.apply(x, act)
+
+
+class _UpsampleAdd(torch.autograd.Function):
+    """lateral + resize_nearest(top -> lateral size, align_corners=True) (retinanet.py:153-157)."""
+
+    @staticmethod
+    def forward(ctx, lateral, top):
+        lateral = lateral.contiguous()
+        top = top.contiguous()
+        n, h, w, c = lateral.shape
+        assert top.shape[0] == n and top.shape[3] == c
+        y = torch.empty_like(lateral)
+        _rn.check(_rn.lib().rn_upsample_add_fwd(_rn.f32(lateral), _rn.f32(top), _rn.f32(y), n, h, w, top.shape[1],
+                                                top.shape[2], c, _rn.stream()), "rn_upsample_add_fwd")
+        ctx.shapes = (n, h, w, top.shape[1], top.shape[2], c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, th, tw, c = ctx.shapes
+        dy = dy.contiguous()
+        dtop = None
+        if ctx.needs_input_grad[1]:
+            dtop = torch.empty((n, th, tw, c), dtype=torch.float32, device=dy.device)
+            _rn.check(_rn.lib().rn_upsample_add_bwd_top(_rn.f32(dy), _rn.f32(dtop), n, h, w, th, tw, c, _rn.stream()),
+                      "rn_upsample_add_bwd_top")
+        return (dy if ctx.needs_input_grad[0] else None), dtop
+
+
+def upsample_add(lateral, top):
+    return _UpsampleAdd.apply(lateral, top)
+
+
+def _loss_segs(cls_logits, cls_labels, reg_preds, reg_labels, masks, dcls, dreg):
+    n = len(cls_logits)
+    segs = (_rn.LossSeg * n)()
+    for i in range(n):
+        s = segs[i]
+        s.cls_logit = _rn.f32(cls_logits[i])
+        s.cls_label = _rn.f32(cls_labels[i])
+        s.reg_pred = _rn.f32(reg_preds[i])
+        s.reg_label = _rn.f32(reg_labels[i])
+        s.trainable = _rn.ptr(masks[i])
+        s.d_cls_logit = _rn.f32(dcls[i]) if dcls is not None else None
+        s.d_reg_pred = _rn.f32(dreg[i]) if dreg is not None else None
+        s.rows = masks[i].numel()
+    return segs
+
+
+class _DetectionLoss(torch.autograd.Function):
+    """(class_loss, regr_loss, stats) over all levels; labels and masks carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, mode, num_classes, n, *tensors):
+        cls_logits = [t.contiguous() for t in tensors[:n]]
+        reg_preds = [t.contiguous() for t in tensors[n:2 * n]]
+        cls_labels = [t.contiguous() for t in tensors[2 * n:3 * n]]
+        reg_labels = [t.contiguous() for t in tensors[3 * n:4 * n]]
+        masks = [t.contiguous() for t in tensors[4 * n:5 * n]]
+        for m in masks:
+            assert m.dtype in (torch.uint8, torch.bool)
+        for z, l, m in zip(cls_logits, cls_labels, masks):
+            assert z.shape == l.shape and z.shape[-1] == num_classes and z.numel() == m.numel() * num_classes
+        L = _rn.lib()
+        dev = cls_logits[0].device
+        stats = torch.empty((_rn.LOSS_STATS_HEADER + 3 * num_classes,), dtype=torch.float32, device=dev)
+        segs = _loss_segs(cls_logits, cls_labels, reg_preds, reg_labels, masks, None, None)
+        need = L.rn_loss_workspace(segs, n, num_classes)
+        ws = _rn.workspace(need, dev)
+        _rn.check(L.rn_loss_fwd(segs, n, num_classes, _rn.LOSS_MODE[mode], _rn.f32(stats), ws.data_ptr(), ws.numel(),
+                                _rn.stream()), "rn_loss_fwd")
+        ctx.mode, ctx.num_classes, ctx.n = mode, num_classes, n
+        ctx.save_for_backward(stats, *cls_logits, *reg_preds, *cls_labels, *reg_labels, *masks)
+        ctx.mark_non_differentiable(stats)
+        # separate scalars (not views of `stats`) so autograd sees plain outputs
+        return stats[0].clone(), stats[1].clone(), stats
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg, _g_stats):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        stats = saved[0]
+        cls_logits = list(saved[1:1 + n])
+        reg_preds = list(saved[1 + n:1 + 2 * n])
+        cls_labels = list(saved[1 + 2 * n:1 + 3 * n])
+        reg_labels = list(saved[1 + 3 * n:1 + 4 * n])
+        masks = list(saved[1 + 4 * n:1 + 5 * n])
+        dev = stats.device
+        zero = None
+        if g_cls is None or g_reg is None:
+            zero = torch.zeros((1,), dtype=torch.float32, device=dev)
+        g_cls = g_cls.reshape(1).contiguous().float() if g_cls is not None else zero
+        g_reg = g_reg.reshape(1).contiguous().float() if g_reg is not None else zero
+        dcls = [torch.empty_like(z) for z in cls_logits]
+        dreg = [torch.empty_like(r) for r in reg_preds]
+        segs = _loss_segs(cls_logits, cls_labels, reg_preds, reg_labels, masks, dcls, dreg)
+        _rn.check(_rn.lib().rn_loss_bwd(segs, n, ctx.num_classes, _rn.LOSS_MODE[ctx.mode], _rn.f32(stats),
+                                        _rn.f32(g_cls), _rn.f32(g_reg), _rn.stream()), "rn_loss_bwd")
+        return (None, None, None) + tuple(dcls) + tuple(dreg) + (None,) * (3 * n)
+
+
+def detection_loss(cls_logits, reg_preds, cls_labels, reg_labels, trainable_masks, num_classes, mode="bce_dice"):
+    """Lists over pyramid levels (P3..P7 order).  Returns (class_loss, regr_loss, stats)."""
+    n = len(cls_logits)
+    return _DetectionLoss.apply(mode, num_classes, n, *cls_logits, *reg_preds, *cls_labels, *reg_labels,
+                                *trainable_masks)

@@ -1,0 +1,171 @@
+"""RetinaNet builder (drop-in for reference retinanet.py:12-316) on gfx950 kernels.
+
+    net = RetinaNet(backbone='mobilenet_v2', levels=build_levels(), num_classes=80,
+                    activation=layers.elu, dropout_rate=0.2)
+    out = net(image_nhwc, training=True)
+    out['classifications']['P3']   # [N, H/8, W/8, A, C]
+    out['regressions']['P7']       # [N, H/128, W/128, A, 4]
+
+Same constructor arguments, class names and return structure as the reference.  MI355X-first
+differences that do not change results:
+  * the class / box subnets are applied to all five pyramid levels in ONE launch per layer
+    (the levels share the subnet's weights AND GroupNorm gamma/beta, retinanet.py:257-270,
+    :283-291; GroupNorm statistics stay per level and per sample);
+  * every [Conv2D, Normalization, activation] run is a conv kernel + one fused GroupNorm kernel;
+  * FPN merge = one upsample+add kernel (nearest, align_corners, retinanet.py:153-157).
+"""
+import math
+
+import layers as L
+import mobilenet_v2
+import ops
+from model import Model, Sequential
+from normalization import Normalization
+
+BACKBONES = ['resnet_50', 'densenet_121', 'densenet_169', 'mobilenet_v2']
+
+
+def build_backbone(backbone, activation, dropout_rate):
+    assert backbone in BACKBONES
+    if backbone == 'mobilenet_v2':
+        return mobilenet_v2.MobileNetV2(activation=activation, dropout_rate=dropout_rate)
+    if backbone == 'resnet_50':
+        import resnet
+        return resnet.ResNeXt_50(activation=activation)
+    import densenet
+    if backbone == 'densenet_121':
+        return densenet.DenseNetBC_121(activation=activation, dropout_rate=dropout_rate)
+    return densenet.DenseNetBC_169(activation=activation, dropout_rate=dropout_rate)
+
+
+def _conv_norm(filters, kernel_size, strides, kernel_initializer, kernel_regularizer, in_channels=None, pre=None,
+               post=None):
+    """[pre?] Conv2D(no bias) -> Normalization [-> post?]"""
+    seq = [] if pre is None else [pre]
+    seq += [L.Conv2D(filters, kernel_size, strides, padding='same', use_bias=False,
+                     kernel_initializer=kernel_initializer, kernel_regularizer=kernel_regularizer,
+                     in_channels=in_channels),
+            Normalization(channels=filters)]
+    if post is not None:
+        seq.append(post)
+    return Sequential(seq)
+
+
+class _Subnet(Model):
+    """Four [conv3x3 256, GN, act] blocks and a biased conv3x3 producing num_anchors * last_dim
+    maps, reshaped to [N, H, W, A, last_dim] (retinanet.py:37-71 / :85-115)."""
+
+    def __init__(self, num_anchors, last_dim, activation, kernel_initializer, kernel_regularizer,
+                 bias_initializer, name):
+        super().__init__(name=name)
+        self.num_anchors, self.last_dim = num_anchors, last_dim
+        act = L.get_activation(activation)
+        self.pre_conv = Sequential([
+            _conv_norm(256, 3, 1, kernel_initializer, kernel_regularizer, in_channels=256, post=act)
+            for _ in range(4)])
+        self.out_conv = L.Conv2D(num_anchors * last_dim, 3, 1, padding='same', kernel_initializer=kernel_initializer,
+                                 kernel_regularizer=kernel_regularizer, bias_initializer=bias_initializer,
+                                 in_channels=256)
+
+    def _reshape(self, t):
+        return t.reshape(t.shape[0], t.shape[1], t.shape[2], self.num_anchors, self.last_dim)
+
+    def call(self, input, training):
+        """`input`: one feature map, or a list of maps (all pyramid levels, one launch per layer)."""
+        input = self.pre_conv(input, training)
+        input = self.out_conv(input)
+        if isinstance(input, (list, tuple)):
+            return [self._reshape(t) for t in input]
+        return self._reshape(input)
+
+
+class ClassificationSubnet(_Subnet):
+    def __init__(self, num_anchors, num_classes, activation, kernel_initializer, kernel_regularizer,
+                 name='classification_subnet'):
+        pi = 0.01                                     # prior: sigmoid(bias) = pi (retinanet.py:52-53)
+        super().__init__(num_anchors, num_classes, activation, kernel_initializer, kernel_regularizer,
+                         L.Constant(-math.log((1 - pi) / pi)), name)
+        self.num_classes = num_classes
+
+
+class RegressionSubnet(_Subnet):
+    def __init__(self, num_anchors, activation, kernel_initializer, kernel_regularizer,
+                 name='classification_subnet'):
+        super().__init__(num_anchors, 4, activation, kernel_initializer, kernel_regularizer, None, name)
+
+
+class FeaturePyramidNetwork(Model):
+    class UpsampleMerge(Model):
+        def __init__(self, kernel_initializer, kernel_regularizer, name='upsample_merge', in_channels=None):
+            super().__init__(name=name)
+            self.conv_lateral = _conv_norm(256, 1, 1, kernel_initializer, kernel_regularizer, in_channels=in_channels)
+            self.conv_merge = _conv_norm(256, 3, 1, kernel_initializer, kernel_regularizer, in_channels=256)
+
+        def call(self, lateral, downsampled, training):
+            lateral = self.conv_lateral(lateral, training)
+            merged = ops.upsample_add(lateral, downsampled)
+            return self.conv_merge(merged, training)
+
+    def __init__(self, activation, kernel_initializer, kernel_regularizer, name='feature_pyramid_network',
+                 feature_channels=None):
+        """`feature_channels` (optional {'C3','C4','C5'} -> channels) builds the lateral kernels
+        eagerly; without it they are created on the first call, like tf.layers."""
+        super().__init__(name=name)
+        act = L.get_activation(activation)
+        fc = feature_channels or {}
+        self.p6_from_c5 = _conv_norm(256, 3, 2, kernel_initializer, kernel_regularizer, in_channels=fc.get('C5'))
+        self.p7_from_p6 = _conv_norm(256, 3, 2, kernel_initializer, kernel_regularizer, in_channels=256, pre=act)
+        self.p5_from_c5 = _conv_norm(256, 1, 1, kernel_initializer, kernel_regularizer, in_channels=fc.get('C5'))
+        self.p4_from_c4p5 = FeaturePyramidNetwork.UpsampleMerge(kernel_initializer, kernel_regularizer,
+                                                                name='upsample_merge_c4p5', in_channels=fc.get('C4'))
+        self.p3_from_c3p4 = FeaturePyramidNetwork.UpsampleMerge(kernel_initializer, kernel_regularizer,
+                                                                name='upsample_merge_c3p4', in_channels=fc.get('C3'))
+
+    def call(self, input, training):
+        P6 = self.p6_from_c5(input['C5'], training)
+        P7 = self.p7_from_p6(P6, training)
+        P5 = self.p5_from_c5(input['C5'], training)
+        P4 = self.p4_from_c4p5(input['C4'], P5, training)
+        P3 = self.p3_from_c3p4(input['C3'], P4, training)
+        return {'P3': P3, 'P4': P4, 'P5': P5, 'P6': P6, 'P7': P7}       # order matters
+
+
+class RetinaNetBase(Model):
+    def __init__(self, backbone, levels, num_classes, activation, dropout_rate, kernel_initializer,
+                 kernel_regularizer, name='retinanet_base'):
+        super().__init__(name=name)
+        self.backbone = build_backbone(backbone, activation=activation, dropout_rate=dropout_rate)
+        # the reference's `if backbone == 'densenet'` post-norm never fires for any accepted
+        # backbone name (retinanet.py:238-250 vs :13), so it is not built.
+        self.fpn = FeaturePyramidNetwork(activation=activation, kernel_initializer=kernel_initializer,
+                                         kernel_regularizer=kernel_regularizer,
+                                         feature_channels=getattr(self.backbone, 'out_channels', None))
+        self.classification_subnet = ClassificationSubnet(
+            num_anchors=levels.num_anchors, num_classes=num_classes, activation=activation,
+            kernel_initializer=kernel_initializer, kernel_regularizer=kernel_regularizer,
+            name='classification_subnet')
+        self.regression_subnet = RegressionSubnet(
+            num_anchors=levels.num_anchors, activation=activation, kernel_initializer=kernel_initializer,
+            kernel_regularizer=kernel_regularizer, name='regression_subnet')
+
+    def call(self, input, training):
+        bottom_up = self.backbone(input, training)
+        top_down = self.fpn(bottom_up, training)
+        keys = list(top_down.keys())
+        maps = [top_down[k] for k in keys]
+        classifications = dict(zip(keys, self.classification_subnet(maps, training)))
+        regressions = dict(zip(keys, self.regression_subnet(maps, training)))
+        return {'classifications': classifications, 'regressions': regressions}
+
+
+class RetinaNet(Model):
+    def __init__(self, backbone, levels, num_classes, activation, dropout_rate, name='retinanet'):
+        super().__init__(name=name)
+        self.base = RetinaNetBase(
+            backbone=backbone, levels=levels, num_classes=num_classes, activation=activation,
+            dropout_rate=dropout_rate,
+            kernel_initializer=L.RandomNormal(mean=0.0, stddev=0.01),
+            kernel_regularizer=L.L2Regularizer(scale=1e-4))
+
+    def call(self, input, training):
+        return self.base(input, training)

@@ -1,0 +1,191 @@
+"""Training step for the RetinaNet hot path (step semantics of reference train.py:111-134,
+206-243, 261-273) -- the Estimator / CLI / summary plumbing around it is out of scope.
+
+  model_fn composition   train.py:206-243  ->  Trainer.forward_backward(): net -> process_labels_and_logits
+                                               -> losses.loss -> (+ L2 regulariser, folded into the
+                                               optimizer kernel as wd*w, value from rn_grad_norm_l2reg)
+  build_train_step       train.py:111-134  ->  Trainer.apply(): fused optimizer kernel on one flat arena
+  MirroredStrategy       train.py:261-267  ->  one process per GPU; gradients averaged with ONE RCCL
+                                               all-reduce per bucket over xGMI (torch.distributed 'nccl')
+
+MI355X-first design: all parameters, gradients and optimizer slots live in three flat fp32
+arenas (one allocation each, per-parameter padding to 1024 elements) so that the optimizer is a
+single kernel, the gradient all-reduce is a few large contiguous messages sized for per-link
+xGMI bandwidth, and the whole step (forward, loss, backward, optimizer) can be captured into one
+hipGraph -- the launch-bound small kernels of the pyramid's coarse levels then cost no host time.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import _rn
+import layers as L
+import losses
+import utils
+from levels import build_levels
+
+OPT_BLOCK = _rn.OPT_BLOCK
+
+
+class ParamArena(object):
+    """Flat fp32 storage for every parameter of `model` (and its gradients).
+
+    Each parameter is re-pointed to a view of `self.weights`; `param.grad` is a view of
+    `self.grads`.  Every parameter starts on a 1024-element boundary so the optimizer / norm
+    kernels can look the L2 scale up per block."""
+
+    def __init__(self, model, device):
+        params = [p for p in model.parameters() if p.requires_grad]
+        sizes = [p.numel() for p in params]
+        padded = [(s + OPT_BLOCK - 1) // OPT_BLOCK * OPT_BLOCK for s in sizes]
+        self.count = int(sum(padded))
+        self.num_params = int(sum(sizes))
+        self.weights = torch.zeros(self.count, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(self.count, dtype=torch.float32, device=device)
+        wd = np.zeros(self.count // OPT_BLOCK, dtype=np.float32)
+        self.offsets = []
+        off = 0
+        for p, s, ps in zip(params, sizes, padded):
+            view = self.weights[off:off + s].view(p.shape)
+            view.copy_(p.data.to(device))
+            scale = float(getattr(p, 'l2_scale', 0.0))
+            p.data = view
+            p.grad = self.grads[off:off + s].view(p.shape)
+            wd[off // OPT_BLOCK:(off + ps) // OPT_BLOCK] = scale
+            self.offsets.append((off, s))
+            off += ps
+        self.params = params
+        self.wd_per_block = torch.from_numpy(wd).to(device)
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+
+class Optimizer(object):
+    """tf.train.MomentumOptimizer(lr, 0.9) | RMSPropOptimizer(lr, 0.9, 0.9) | AdamOptimizer(lr)
+    (train.py:114-119) + optional tf.clip_by_global_norm (train.py:127-132), one fused kernel."""
+
+    def __init__(self, arena, kind='momentum', learning_rate=1e-2, grad_clip_norm=None):
+        assert kind in ['momentum', 'adam', 'rmsprop']
+        self.arena, self.kind, self.lr = arena, kind, float(learning_rate)
+        self.clip = float(grad_clip_norm) if grad_clip_norm is not None else 0.0
+        dev = arena.weights.device
+        self.state1 = torch.ones_like(arena.weights) if kind == 'rmsprop' else torch.zeros_like(arena.weights)
+        self.state2 = torch.zeros_like(arena.weights) if kind != 'momentum' else None
+        self.norm_reg = torch.zeros(2, dtype=torch.float32, device=dev)   # [sum g'^2, L2 reg loss]
+        self.step_count = 0
+
+    def step(self, grad_scale=1.0):
+        a = self.arena
+        L_ = _rn.lib()
+        ws = _rn.workspace(L_.rn_optimizer_workspace(a.count), a.weights.device)
+        _rn.check(L_.rn_grad_norm_l2reg(_rn.f32(a.weights), _rn.f32(a.grads), _rn.f32(a.wd_per_block), a.count,
+                                        grad_scale, _rn.f32(self.norm_reg), ws.data_ptr(), ws.numel(), _rn.stream()),
+                  'rn_grad_norm_l2reg')
+        self.step_count += 1
+        _rn.check(L_.rn_optimizer_step(_rn.OPT[self.kind], _rn.f32(a.weights), _rn.f32(a.grads), _rn.f32(self.state1),
+                                       _rn.f32(self.state2) if self.state2 is not None else None,
+                                       _rn.f32(a.wd_per_block), a.count, self.lr, grad_scale, self.clip,
+                                       _rn.f32(self.norm_reg), self.step_count, _rn.stream()), 'rn_optimizer_step')
+
+    @property
+    def regularization_loss(self):
+        """sum_w scale * ||w||^2 / 2 at the weights used for the last gradient (train.py:221)."""
+        return self.norm_reg[1]
+
+
+class GradientAllReduce(object):
+    """MirroredStrategy's cross-replica gradient sum (train.py:261-267) as RCCL all-reduces of
+    contiguous arena slices.  xGMI is point-to-point (7 links x ~153 GB/s), ring collectives are
+    per-link bound, so the arena goes out as FEW LARGE buckets (default 32 MB) rather than one
+    message per tensor; the 1/world_size average is folded into the optimizer kernel."""
+
+    def __init__(self, arena, process_group=None, bucket_bytes=32 << 20):
+        import torch.distributed as dist
+        self.dist, self.group, self.arena = dist, process_group, arena
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        n = arena.count
+        per = max(OPT_BLOCK, (bucket_bytes // 4) // OPT_BLOCK * OPT_BLOCK)
+        self.buckets = [(s, min(s + per, n)) for s in range(0, n, per)]
+
+    def __call__(self):
+        if self.world == 1:
+            return 1.0
+        # reverse order: the heads' gradients (end of the arena, 64 % of the bytes) are complete first
+        works = [self.dist.all_reduce(self.arena.grads[s:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+                 for s, e in reversed(self.buckets)]
+        for w in works:
+            w.wait()
+        return 1.0 / self.world
+
+
+class Trainer(object):
+    """One data-parallel replica.  `step(features)` = forward + loss + backward + gradient
+    all-reduce + optimizer.  With use_graph=True the replica-local part is one hipGraph."""
+
+    def __init__(self, net, levels=None, optimizer='momentum', learning_rate=1e-2, grad_clip_norm=None,
+                 loss_mode='bce_dice', device='cuda', use_graph=False, process_group=None):
+        self.net, self.levels = net, levels or build_levels()
+        self.device = torch.device(device)
+        self.loss_mode = loss_mode
+        self.arena = ParamArena(net, self.device)
+        self.opt = Optimizer(self.arena, optimizer, learning_rate, grad_clip_norm)
+        self.allreduce = GradientAllReduce(self.arena, process_group)
+        self.use_graph = use_graph
+        self._graph = None
+        self._static = None
+        self.drop_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        L.Dropout.seed_device_counter = self.drop_counter
+        self.last = {}
+
+    # -- replica-local work (capturable)
+    def forward_backward(self, features):
+        logits = {'detection': self.net(features['image'], training=True)}
+        inp, logits = utils.process_labels_and_logits(labels=features, logits=logits, levels=self.levels)
+        class_loss, regr_loss = losses.loss(labels=inp['detection_trainable'], logits=logits['detection_trainable'],
+                                            mode=self.loss_mode)
+        self.arena.zero_grad()
+        (class_loss + regr_loss).backward()
+        self.drop_counter += 0x9E3779B9            # fresh dropout masks next step (device-side counter)
+        return class_loss.detach(), regr_loss.detach()
+
+    def _run_local(self, features):
+        if not self.use_graph:
+            return self.forward_backward(features)
+        if self._graph is None:
+            self._static = features
+            # warm-up on a side stream (allocator + workspace sizing), then capture
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self.forward_backward(self._static)
+            torch.cuda.current_stream().wait_stream(s)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._graph_out = self.forward_backward(self._static)
+        else:
+            _copy_tree(self._static, features)
+        self._graph.replay()
+        return self._graph_out
+
+    def step(self, features):
+        class_loss, regr_loss = self._run_local(features)
+        grad_scale = self.allreduce()
+        self.opt.step(grad_scale)
+        self.last = {'class_loss': class_loss, 'regr_loss': regr_loss,
+                     'regularization_loss': self.opt.regularization_loss}
+        return self.last
+
+
+def _copy_tree(dst, src):
+    if torch.is_tensor(dst):
+        if dst.data_ptr() != src.data_ptr():
+            dst.copy_(src)
+    elif isinstance(dst, dict):
+        for k in dst:
+            _copy_tree(dst[k], src[k])
+    elif isinstance(dst, (list, tuple)):
+        for d, s in zip(dst, src):
+            _copy_tree(d, s)

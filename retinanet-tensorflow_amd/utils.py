@@ -1,0 +1,232 @@
+"""Decode / NMS / label-processing API (drop-in for the hot-path part of reference utils.py).
+
+Same names and argument meaning as the reference: ``Detection`` / ``Classification`` /
+``BoxesDecoded`` namedtuples (utils.py:10-13), ``regression_postprocess`` (:108-117),
+``boxes_decode`` (:183-195), ``nms`` / ``nms_classwise`` / ``merge_boxes_decoded`` (:198-227),
+``classmap_decode`` (:171-179), ``dict_map`` / ``dict_starmap`` / ``dict_update`` (:160-167,
+:230-237), ``process_labels_and_logits`` / ``postprocess_and_mask`` (:240-284), ``iou`` (:62-97).
+Tensors are NHWC fp32 torch tensors on the GPU; the arithmetic runs in csrc/decode_nms.hip
+(compiled without fp contraction so NMS indices are bit-identical to the oracle).
+``detect`` is the batched composition the reference only performs inside its summary builder
+(train.py:68-85): all images, all levels, all classes in one pass.
+"""
+import ctypes as C
+from collections import namedtuple
+from typing import List
+
+import numpy as np
+import torch
+
+import _rn
+
+NMS_MAX_OUTPUT_SIZE = 1000
+BoxesDecoded = namedtuple('BoxesDecoded', ['boxes', 'scores', 'class_ids'])
+ClassmapDecoded = namedtuple('ClassmapDecoded', ['fg_mask'])
+Detection = namedtuple('Detection', ['classification', 'regression', 'regression_postprocessed'])
+Classification = namedtuple('Classification', ['unscaled', 'prob'])
+# `detection_trainable` of the reference is the boolean_mask-compacted copy; here it is the same
+# per-level tensors plus the masks that select the rows (the loss kernel applies them as weights)
+DetectionTrainable = namedtuple('DetectionTrainable', Detection._fields + ('trainable_masks',))
+
+ANCHOR_SIZE_MODE = 'trunc_int'     # how `anchor_sizes / image_size` is evaluated
+
+
+def all_same(items):
+    return all(x == items[0] for x in items)
+
+
+def dict_map(f, dict):
+    return {k: f(dict[k]) for k in dict}
+
+
+def dict_starmap(f, dicts):
+    assert all_same([list(d.keys()) for d in dicts])
+    return {k: f(*[d[k] for d in dicts]) for k in dicts[0].keys()}
+
+
+def dict_update(dict, keys, f):
+    if len(keys) == 0:
+        return f(dict)
+    return {**dict, keys[0]: dict_update(dict[keys[0]], keys[1:], f)}
+
+
+def merge_outputs(dict, name='merge_outputs'):
+    return torch.cat(list(dict.values()), 0)
+
+
+def _anchor_tensor(anchor_boxes, device):
+    a = torch.as_tensor(np.asarray(anchor_boxes, dtype=np.float32) if not torch.is_tensor(anchor_boxes) else anchor_boxes,
+                        dtype=torch.float32)
+    return a.to(device).contiguous()
+
+
+def regression_postprocess(regression, anchor_boxes, name='regression_postprocess'):
+    """[N,H,W,A,4] (dy, dx, log h, log w) anchor-relative -> normalised corners [y1,x1,y2,x2].
+    `anchor_boxes`: [A,2] anchor (h, w) already divided by the image size."""
+    n, h, w, a, _ = regression.shape
+    regression = regression.contiguous()
+    anchors = _anchor_tensor(anchor_boxes, regression.device)
+    assert anchors.shape == (a, 2)
+    out = torch.empty_like(regression)
+    _rn.check(_rn.lib().rn_decode_boxes(_rn.f32(regression), _rn.f32(anchors), _rn.f32(out), n, h, w, a,
+                                        _rn.stream()), 'rn_decode_boxes')
+    return out
+
+
+def classmap_decode(classmap, name='classmap_decoder'):
+    return ClassmapDecoded(fg_mask=classmap.max(-1).values > 0.5)
+
+
+def _det_call(fn_name, probs, boxes, num_classes, n, score_threshold, iou_threshold, max_per_class, capacity):
+    """probs/boxes: lists over levels of [n, rows, C] / [n, rows, 4] tensors."""
+    L = _rn.lib()
+    dev = probs[0].device
+    levels = (_rn.DetLevel * len(probs))()
+    total_rows = 0
+    for i, (p, b) in enumerate(zip(probs, boxes)):
+        assert p.shape[0] == n and b.shape[0] == n and p.shape[1] == b.shape[1] and p.shape[2] == num_classes
+        levels[i].prob = _rn.f32(p)
+        levels[i].boxes = _rn.f32(b)
+        levels[i].rows_per_image = p.shape[1]
+        total_rows += p.shape[1]
+    cap = int(capacity) if capacity is not None else n * total_rows
+    params = _rn.DetParams(n, num_classes, max_per_class, score_threshold, iou_threshold, cap)
+    need = L.rn_detect_workspace(levels, len(probs), C.byref(params))
+    ws = _rn.workspace(need, dev)
+    out_boxes = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+    out_scores = torch.empty((cap,), dtype=torch.float32, device=dev)
+    out_class = torch.empty((cap,), dtype=torch.int32, device=dev)
+    out_image = torch.empty((cap,), dtype=torch.int32, device=dev)
+    out_anchor = torch.empty((cap,), dtype=torch.int64, device=dev)
+    counts = torch.zeros((2 + n,), dtype=torch.int64, device=dev)
+    _rn.check(getattr(L, fn_name)(levels, len(probs), C.byref(params), _rn.f32(out_boxes), _rn.f32(out_scores),
+                                  _rn.ptr(out_class), _rn.ptr(out_image), _rn.ptr(out_anchor), _rn.ptr(counts),
+                                  ws.data_ptr(), ws.numel(), _rn.stream()), fn_name)
+    return out_boxes, out_scores, out_class, out_image, out_anchor, counts, cap
+
+
+def boxes_decode(classifications, regressions, name='boxes_decode'):
+    """ONE image / level: `classifications` [..., C] probabilities, `regressions` [..., 4] decoded
+    boxes -> BoxesDecoded of the rows whose max class prob > 0.5, in row-major order."""
+    c = classifications.shape[-1]
+    p = classifications.reshape(1, -1, c).contiguous()
+    b = regressions.reshape(1, -1, 4).contiguous()
+    ob, os_, oc, _, _, counts, cap = _det_call('rn_boxes_decode', [p], [b], c, 1, 0.5, 0.5, NMS_MAX_OUTPUT_SIZE, None)
+    k = int(counts[0].item())
+    assert k <= cap
+    return BoxesDecoded(boxes=ob[:k], scores=os_[:k], class_ids=oc[:k].long())
+
+
+def merge_boxes_decoded(decoded: List[BoxesDecoded]):
+    return BoxesDecoded(boxes=torch.cat([d.boxes for d in decoded], 0),
+                        scores=torch.cat([d.scores for d in decoded], 0),
+                        class_ids=torch.cat([d.class_ids for d in decoded], 0))
+
+
+def _nms_arrays(boxes, scores, class_ids, num_classes, max_output_size):
+    L = _rn.lib()
+    dev = boxes.device
+    k = boxes.shape[0]
+    cap = max(k, 1)
+    boxes = boxes.contiguous().float()
+    scores = scores.contiguous().float()
+    cls32 = class_ids.to(torch.int32).contiguous()
+    img32 = torch.zeros((cap,), dtype=torch.int32, device=dev)
+    count = torch.tensor([k], dtype=torch.int64, device=dev)
+    params = _rn.DetParams(1, num_classes, max_output_size, 0.5, 0.5, cap)
+    need = L.rn_nms_classwise_workspace(C.byref(params))
+    ws = _rn.workspace(need, dev)
+    ob = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+    os_ = torch.empty((cap,), dtype=torch.float32, device=dev)
+    oc = torch.empty((cap,), dtype=torch.int32, device=dev)
+    oi = torch.empty((cap,), dtype=torch.int32, device=dev)
+    oidx = torch.empty((cap,), dtype=torch.int64, device=dev)
+    counts = torch.zeros((3,), dtype=torch.int64, device=dev)
+    if k == 0:
+        return ob[:0], os_[:0], oc[:0].long(), oidx[:0]
+    _rn.check(L.rn_nms_classwise(_rn.f32(boxes), _rn.f32(scores), _rn.ptr(cls32), _rn.ptr(img32), _rn.ptr(count),
+                                 C.byref(params), _rn.f32(ob), _rn.f32(os_), _rn.ptr(oc), _rn.ptr(oi), _rn.ptr(oidx),
+                                 _rn.ptr(counts), ws.data_ptr(), ws.numel(), _rn.stream()), 'rn_nms_classwise')
+    m = int(counts[1].item())
+    return ob[:m], os_[:m], oc[:m].long(), oidx[:m]
+
+
+def nms(decoded: BoxesDecoded, max_output_size=NMS_MAX_OUTPUT_SIZE, name='nms'):
+    """tf.image.non_max_suppression(boxes, scores, max_output_size, iou_threshold=0.5) + gather."""
+    zeros = torch.zeros_like(decoded.class_ids)
+    _, _, _, idx = _nms_arrays(decoded.boxes, decoded.scores, zeros, 1, max_output_size)
+    return BoxesDecoded(boxes=decoded.boxes[idx], scores=decoded.scores[idx], class_ids=decoded.class_ids[idx])
+
+
+def nms_classwise(decoded: BoxesDecoded, num_classes, name='nms_classwise'):
+    """Per-class NMS, output class-major then score-descending (utils.py:198-210)."""
+    ob, os_, oc, _ = _nms_arrays(decoded.boxes, decoded.scores, decoded.class_ids, num_classes, NMS_MAX_OUTPUT_SIZE)
+    return BoxesDecoded(boxes=ob, scores=os_, class_ids=oc)
+
+
+def detect(class_probs, regressions_postprocessed, num_classes, score_threshold=0.5, iou_threshold=0.5,
+           max_per_class=NMS_MAX_OUTPUT_SIZE, capacity=None, return_raw=False):
+    """Batched train.py:68-85: dicts P3..P7 of [N,H,W,A,C] probabilities and [N,H,W,A,4] decoded
+    boxes -> list (one per image) of BoxesDecoded after class-wise NMS.  One pass on the device."""
+    keys = list(class_probs.keys())
+    n = class_probs[keys[0]].shape[0]
+    probs = [class_probs[k].reshape(n, -1, num_classes).contiguous() for k in keys]
+    boxes = [regressions_postprocessed[k].reshape(n, -1, 4).contiguous() for k in keys]
+    ob, os_, oc, oi, oa, counts, cap = _det_call('rn_detect', probs, boxes, num_classes, n, score_threshold,
+                                                 iou_threshold, max_per_class, capacity)
+    if return_raw:
+        return ob, os_, oc, oi, oa, counts
+    cnt = counts.cpu().tolist()
+    if cnt[0] > cap:
+        raise _rn.RnError('detect: %d candidates exceed capacity %d' % (cnt[0], cap))
+    out, off = [], 0
+    for i in range(n):
+        m = cnt[2 + i]
+        out.append(BoxesDecoded(boxes=ob[off:off + m], scores=os_[off:off + m], class_ids=oc[off:off + m].long()))
+        off += m
+    return out
+
+
+def iou(a, b, name='iou'):
+    """utils.py:62-97 with broadcasting (host-side helper: not on the device hot path, the
+    assignment kernel has its own IoU)."""
+    assert bool((a[..., :2] <= a[..., 2:]).all()) and bool((b[..., :2] <= b[..., 2:]).all())
+    y_top = torch.maximum(a[..., 0], b[..., 0])
+    x_left = torch.maximum(a[..., 1], b[..., 1])
+    y_bottom = torch.minimum(a[..., 2], b[..., 2])
+    x_right = torch.minimum(a[..., 3], b[..., 3])
+    invalid = (y_bottom < y_top) | (x_right < x_left)
+    inter = (y_bottom - y_top) * (x_right - x_left)
+    area_a = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
+    area_b = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    val = inter / (area_a + area_b - inter)
+    return torch.where(invalid, torch.zeros_like(val), val)
+
+
+def postprocess_and_mask(input, trainable_masks, image_size, levels, name='postprocess_and_mask'):
+    """utils.py:258-284 without the gather: the per-level tensors and the masks are kept side
+    by side (``detection_trainable`` carries the masks); losses.loss weighs rows by the mask,
+    which gives the reference's numbers without materialising the compacted [M, C] copies."""
+    detection = Detection(
+        classification=input['detection']['classifications'],
+        regression=input['detection']['regressions'],
+        regression_postprocessed=dict_starmap(
+            lambda r, l: regression_postprocess(r, levels[l].normalized_anchor_sizes(image_size, ANCHOR_SIZE_MODE)),
+            (input['detection']['regressions'], {k: k for k in levels})))
+    detection_trainable = DetectionTrainable(
+        classification=detection.classification, regression=detection.regression,
+        regression_postprocessed=detection.regression_postprocessed, trainable_masks=trainable_masks)
+    return {**input, 'detection': detection, 'detection_trainable': detection_trainable,
+            'trainable_masks': trainable_masks}
+
+
+def process_labels_and_logits(labels, logits, levels, name='process_labels_and_logits'):
+    """utils.py:240-255.  `labels`: features dict (image, detection{classifications, regressions},
+    trainable_masks); `logits`: {'detection': net output}."""
+    labels = dict_update(labels, ['detection', 'classifications'], lambda c: Classification(unscaled=None, prob=c))
+    logits = dict_update(logits, ['detection', 'classifications'],
+                         lambda c: Classification(unscaled=c, prob=None))   # sigmoid is fused into the loss kernel
+    image_size = tuple(labels['image'].shape[1:3])
+    labels = postprocess_and_mask(labels, labels['trainable_masks'], image_size=image_size, levels=levels)
+    logits = postprocess_and_mask(logits, labels['trainable_masks'], image_size=image_size, levels=levels)
+    return labels, logits

@@ -1,0 +1,140 @@
+"""End-to-end parity of the RetinaNet hot path (model -> loss -> gradients -> optimizer step)
+with the CPU oracle, through the reference-shaped Python API.  Runs on the MI355X box."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, load_oracle_params, to_oracle_name
+from oracle import dataset_ref, model_ref, train_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+LEVELS = ("P3", "P4", "P5", "P6", "P7")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _tiny_problem(dev, size=64, classes=3, seed=0):
+    import layers, levels, retinanet
+    rng = np.random.default_rng(seed)
+    params = model_ref.init_params("mobilenet_v2", num_classes=classes, seed=seed)
+    # non-trivial gamma/beta so their gradients are exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in params:
+        if k.endswith(".gamma"):
+            params[k] = 1 + 0.2 * torch.randn(params[k].shape, generator=g)
+        elif k.endswith(".beta"):
+            params[k] = 0.1 * torch.randn(params[k].shape, generator=g)
+    net = retinanet.RetinaNet('mobilenet_v2', levels.build_levels(), classes, layers.elu, 0.0).to(dev)
+    load_oracle_params(net, params)
+    image = rng.standard_normal((2, size, size, 3)).astype(np.float32)
+    boxes = np.array([[0.1, 0.15, 0.6, 0.7], [0.5, 0.4, 0.95, 0.9], [0.05, 0.5, 0.4, 0.98]], dtype=np.float32)
+    cids = np.array([0, 2, 1])
+    cls, reg, msk = dataset_ref.build_labels((size, size), cids, boxes, classes)
+    fc, fr, fm, _ = dataset_ref.flip(cls, reg, msk)
+    labels = {"classifications": {}, "regressions": {}, "trainable_masks": {}}
+    for k in cls:
+        labels["classifications"][k] = torch.from_numpy(np.stack([cls[k], fc[k]]))
+        labels["regressions"][k] = torch.from_numpy(np.stack([reg[k], fr[k]]))
+        labels["trainable_masks"][k] = torch.from_numpy(np.stack([msk[k], fm[k]]))
+    return net, params, torch.from_numpy(image), labels
+
+
+def _features(image, labels, dev):
+    return {
+        "image": image.to(dev),
+        "detection": {"classifications": {k: v.to(dev) for k, v in labels["classifications"].items()},
+                      "regressions": {k: v.to(dev) for k, v in labels["regressions"].items()}},
+        "trainable_masks": {k: v.to(torch.uint8).to(dev) for k, v in labels["trainable_masks"].items()},
+    }
+
+
+def test_forward_matches_oracle_and_golden(dev, golden_dir):
+    import layers, levels, retinanet
+    fx = np.load(os.path.join(golden_dir, "oracle_e2e_tiny.npz"))
+    params = model_ref.init_params("mobilenet_v2", num_classes=3, seed=0)
+    net = retinanet.RetinaNet('mobilenet_v2', levels.build_levels(), 3, layers.elu, 0.2).to(dev)
+    load_oracle_params(net, params)
+    image = torch.from_numpy(fx["image"])
+    with torch.no_grad():
+        out = net(image.to(dev), training=False)
+        ref = model_ref.retinanet_forward(params, image, 3)
+    assert list(out["classifications"].keys()) == list(LEVELS)
+    for k in LEVELS:
+        assert out["classifications"][k].shape == ref["classifications"][k].shape
+        assert_close(out["classifications"][k].cpu().numpy(), ref["classifications"][k].numpy(), TOL, "cls " + k)
+        assert_close(out["regressions"][k].cpu().numpy(), ref["regressions"][k].numpy(), TOL, "reg " + k)
+    assert_close(out["classifications"]["P5"].cpu().numpy(), fx["cls_P5"], TOL, "golden cls P5")
+    assert_close(out["regressions"]["P7"].cpu().numpy(), fx["reg_P7"], TOL, "golden reg P7")
+
+
+@pytest.mark.parametrize("mode", ["bce_dice", "focal"])
+def test_loss_and_gradients_match_oracle(dev, mode):
+    import levels as levels_mod, losses, utils
+    net, params, image, labels = _tiny_problem(dev)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    tot, cl, rl, reg = train_ref.total_loss(leaves, image, labels, 3, mode)
+    grads = dict(zip(leaves.keys(), torch.autograd.grad(cl + rl, list(leaves.values()))))
+
+    feats = _features(image, labels, dev)
+    lv = levels_mod.build_levels()
+    logits = {"detection": net(feats["image"], training=True)}
+    inp, logits = utils.process_labels_and_logits(labels=feats, logits=logits, levels=lv)
+    gcl, grl = losses.loss(labels=inp["detection_trainable"], logits=logits["detection_trainable"], mode=mode)
+    (gcl + grl).backward()
+    assert_close(gcl.item(), cl.item(), TOL, "class loss")
+    assert_close(grl.item(), rl.item(), TOL, "regr loss")
+    worst = 0.0
+    for name, p in net.named_parameters():
+        o = to_oracle_name(name)
+        worst = max(worst, assert_close(p.grad.cpu().numpy(), grads[o].numpy(), 5e-4, "grad " + o))
+    print("worst gradient error", worst)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_steps_match_oracle(dev, use_graph):
+    """Three optimizer steps (momentum, L2 regulariser, global-norm clip) == the oracle's."""
+    import levels as levels_mod, train
+    net, params, image, labels = _tiny_problem(dev, seed=3)
+    trainer = train.Trainer(net, levels_mod.build_levels(), optimizer="momentum", learning_rate=1e-2,
+                            grad_clip_norm=5.0, loss_mode="bce_dice", device=dev, use_graph=use_graph)
+    feats = _features(image, labels, dev)
+    state = {}
+    for step in range(1, 4):
+        out = trainer.step(feats)
+        first, _ = train_ref.train_step(params, image, labels, 3, state, lr=1e-2, optimizer="momentum", step=step,
+                                        loss_mode="bce_dice", grad_clip_norm=5.0)
+        torch.cuda.synchronize()
+        assert_close(out["class_loss"].item(), first[1], 2e-4, "class loss step %d" % step)
+        assert_close(out["regr_loss"].item(), first[2], 2e-4, "regr loss step %d" % step)
+        assert_close(out["regularization_loss"].item(), first[3], 2e-4, "reg loss step %d" % step)
+    worst = 0.0
+    for name, p in net.named_parameters():
+        worst = max(worst, assert_close(p.detach().cpu().numpy(), params[to_oracle_name(name)].numpy(), 5e-4, name))
+    print("worst weight error after 3 steps", worst)
+
+
+def test_gradient_average_equals_bigger_batch(dev):
+    """MirroredStrategy semantics: mean of two replicas' gradients == what the
+    GradientAllReduce + grad_scale path applies; checked single-process by accumulation."""
+    import levels as levels_mod, train
+    net, params, image, labels = _tiny_problem(dev, seed=5)
+    trainer = train.Trainer(net, levels_mod.build_levels(), device=dev)
+    feats = _features(image, labels, dev)
+    feats2 = _features(torch.flip(image, [0]), {k: {kk: torch.flip(v, [0]) for kk, v in d.items()}
+                                                for k, d in labels.items()}, dev)
+    trainer.forward_backward(feats)
+    g1 = trainer.arena.grads.clone()
+    trainer.forward_backward(feats2)
+    g2 = trainer.arena.grads.clone()
+    trainer.arena.grads.copy_(g1 + g2)          # what an all-reduce(sum) over 2 ranks leaves behind
+    w0 = trainer.arena.weights.clone()
+    trainer.opt.step(grad_scale=0.5)
+    expect = w0 - 1e-2 * (0.5 * (g1 + g2) + trainer.arena.wd_per_block.repeat_interleave(train.OPT_BLOCK) * w0)
+    assert_close(trainer.arena.weights.cpu().numpy(), expect.cpu().numpy(), 1e-6, "averaged step")

@@ -1,0 +1,410 @@
+"""Parity of every HIP kernel family with the CPU oracle (runs on the MI355X box: -m gpu).
+
+Tolerances: fp32 results within 1e-4 relative (max-norm), as BASELINE.json's north_star
+states; masks / class maps / arg-max / NMS indices bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, coco_like_objects, random_boxes
+from oracle import dataset_ref, levels_ref, losses_ref, tf_ops_ref, train_ref, utils_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    import _rn
+    _rn.lib()          # fails loudly if librn_hip.so is missing
+    return torch.device("cuda:0")
+
+
+def _t(a, dev, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.requires_grad_(grad)
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, bias
+    (2, 16, 16, 256, 256, 3, 1, False),      # head tower conv
+    (2, 8, 8, 256, 720, 3, 1, True),         # class out conv (A*C = 720)
+    (2, 8, 8, 256, 36, 3, 1, True),          # box out conv
+    (2, 33, 31, 3, 32, 3, 2, False),         # stem, odd size, scalar (cin=3) path
+    (2, 16, 16, 32, 256, 3, 2, False),       # P6 from C5
+    (2, 7, 9, 256, 256, 3, 2, False),        # stride 2 on odd maps
+    (2, 32, 32, 16, 96, 1, 1, False),        # MobileNet expand
+    (2, 16, 16, 144, 24, 1, 1, False),       # MobileNet linear, C=144
+    (1, 12, 10, 96, 256, 1, 1, False),       # FPN lateral
+    (1, 20, 20, 8, 12, 7, 2, False),         # 7x7/2 (ResNeXt / DenseNet stem family)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_fwd_bwd(dev, case):
+    import ops
+    n, h, w, cin, cout, k, stride, use_bias = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) if use_bias else None
+    xc, wc = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(wt).requires_grad_(True)
+    bc = torch.from_numpy(b).requires_grad_(True) if use_bias else None
+    yc = tf_ops_ref.conv2d_same(xc, wc, stride, bc)
+    dy = rng.standard_normal(tuple(yc.shape)).astype(np.float32)
+    yc.backward(torch.from_numpy(dy))
+
+    xg, wg = _t(x, dev, True), _t(wt, dev, True)
+    bg = _t(b, dev, True) if use_bias else None
+    yg = ops.conv2d(xg, wg, bg, stride)
+    assert tuple(yg.shape) == tuple(yc.shape)
+    yg.backward(_t(dy, dev))
+    assert_close(yg.detach().cpu().numpy(), yc.detach().numpy(), TOL, "conv fwd")
+    assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), TOL, "conv dgrad")
+    assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), TOL, "conv wgrad")
+    if use_bias:
+        assert_close(bg.grad.cpu().numpy(), bc.grad.numpy(), TOL, "conv bias grad")
+
+
+def test_conv2d_shared_kernel_over_pyramid_levels(dev):
+    """The head layers: one kernel, five maps of different sizes, ONE launch; wgrad sums levels."""
+    import ops
+    rng = np.random.default_rng(7)
+    sizes = [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    wt = (rng.standard_normal((3, 3, 256, 256)) / 48).astype(np.float32)
+    xs = [rng.standard_normal((2, h, w, 256)).astype(np.float32) for h, w in sizes]
+    wc = torch.from_numpy(wt).requires_grad_(True)
+    xcs = [torch.from_numpy(x).requires_grad_(True) for x in xs]
+    ycs = [tf_ops_ref.conv2d_same(x, wc, 1) for x in xcs]
+    dys = [rng.standard_normal(tuple(y.shape)).astype(np.float32) for y in ycs]
+    torch.autograd.backward(ycs, [torch.from_numpy(d) for d in dys])
+    wg = _t(wt, dev, True)
+    xgs = [_t(x, dev, True) for x in xs]
+    ygs = ops.conv2d(xgs, wg, None, 1)
+    torch.autograd.backward(ygs, [_t(d, dev) for d in dys])
+    for yg, yc, xg, xc in zip(ygs, ycs, xgs, xcs):
+        assert_close(yg.detach().cpu().numpy(), yc.detach().numpy(), TOL, "multi fwd")
+        assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), TOL, "multi dgrad")
+    assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), TOL, "multi wgrad")
+
+
+@pytest.mark.parametrize("case", [(2, 17, 15, 32, 1), (2, 16, 16, 144, 2), (1, 9, 9, 960, 1), (2, 8, 8, 96, 2)])
+def test_depthwise_fwd_bwd(dev, case):
+    import ops
+    n, h, w, c, stride = case
+    rng = np.random.default_rng(c + stride)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = rng.standard_normal((3, 3, c, 1)).astype(np.float32) / 3
+    xc, wc = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(wt).requires_grad_(True)
+    yc = tf_ops_ref.depthwise_conv2d_same(xc, wc, stride)
+    dy = rng.standard_normal(tuple(yc.shape)).astype(np.float32)
+    yc.backward(torch.from_numpy(dy))
+    xg, wg = _t(x, dev, True), _t(wt, dev, True)
+    yg = ops.depthwise_conv2d(xg, wg, stride)
+    yg.backward(_t(dy, dev))
+    assert_close(yg.detach().cpu().numpy(), yc.detach().numpy(), TOL, "dw fwd")
+    assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), TOL, "dw dgrad")
+    assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), TOL, "dw wgrad")
+
+
+@pytest.mark.parametrize("c,act,res", [(256, "elu", False), (144, "elu", True), (32, "relu", False), (24, None, True),
+                                       (960, "relu6", False), (16, "elu", False)])
+def test_group_norm_act_fwd_bwd(dev, c, act, res):
+    import ops
+    rng = np.random.default_rng(c)
+    shapes = [(2, 9, 7, c), (2, 3, 3, c)] if c == 256 else [(2, 9, 7, c)]
+    gamma = (1 + 0.3 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(c)).astype(np.float32)
+    xs = [(rng.standard_normal(s) * 2 + 0.5).astype(np.float32) for s in shapes]
+    rs = [rng.standard_normal(s).astype(np.float32) for s in shapes] if res else None
+    gc, bc = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
+    xcs = [torch.from_numpy(x).requires_grad_(True) for x in xs]
+    rcs = [torch.from_numpy(r).requires_grad_(True) for r in rs] if res else None
+    ycs = []
+    for i, x in enumerate(xcs):
+        y = tf_ops_ref.activation(tf_ops_ref.group_norm(x, gc, bc), act)
+        ycs.append(y + rcs[i] if res else y)
+    dys = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    torch.autograd.backward(ycs, [torch.from_numpy(d) for d in dys])
+
+    gg, bg = _t(gamma, dev, True), _t(beta, dev, True)
+    xgs = [_t(x, dev, True) for x in xs]
+    rgs = [_t(r, dev, True) for r in rs] if res else None
+    ygs = ops.group_norm_act(xgs, gg, bg, 32, 1e-5, act, rgs)
+    torch.autograd.backward(ygs, [_t(d, dev) for d in dys])
+    for i in range(len(xs)):
+        assert_close(ygs[i].detach().cpu().numpy(), ycs[i].detach().numpy(), TOL, "gn fwd")
+        assert_close(xgs[i].grad.cpu().numpy(), xcs[i].grad.numpy(), TOL, "gn dx")
+        if res:
+            assert_close(rgs[i].grad.cpu().numpy(), rcs[i].grad.numpy(), TOL, "gn dres")
+    assert_close(gg.grad.cpu().numpy(), gc.grad.numpy(), TOL, "gn dgamma")
+    assert_close(bg.grad.cpu().numpy(), bc.grad.numpy(), TOL, "gn dbeta")
+
+
+def test_group_norm_dropout_is_consistent(dev):
+    """Dropout mask: right keep fraction, inverted scaling, and backward uses the SAME mask."""
+    import ops
+    c = 64
+    x = torch.randn(2, 32, 32, c, device=dev, requires_grad=True)
+    gamma = torch.ones(c, device=dev, requires_grad=True)
+    beta = torch.zeros(c, device=dev, requires_grad=True)
+    y = ops.group_norm_act(x, gamma, beta, 32, 1e-5, None, None, 0.25, 1234)
+    y0 = ops.group_norm_act(x, gamma, beta, 32, 1e-5, None, None, 0.0, 0)
+    kept = (y != 0)
+    frac = kept.float().mean().item()
+    assert abs(frac - 0.75) < 0.01
+    assert torch.allclose(y[kept], y0[kept] / 0.75, rtol=1e-5, atol=1e-6)
+    y2 = ops.group_norm_act(x, gamma, beta, 32, 1e-5, None, None, 0.25, 1234)
+    assert torch.equal(y, y2)                                     # counter-based, reproducible
+    # backward: beta's gradient of sum(y) is sum(mask)/keep per channel
+    y.sum().backward()
+    expect = kept.float().sum((0, 1, 2)) / 0.75
+    assert torch.allclose(beta.grad, expect, rtol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [((2, 8, 8), (4, 4)), ((2, 64, 64), (32, 32)), ((1, 75, 75), (38, 38)), ((1, 5, 7), (3, 4))])
+def test_upsample_add(dev, shape):
+    import ops
+    (n, h, w), (th, tw) = shape
+    c = 8
+    rng = np.random.default_rng(h)
+    lat = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    top = rng.standard_normal((n, th, tw, c)).astype(np.float32)
+    lc, tc = torch.from_numpy(lat).requires_grad_(True), torch.from_numpy(top).requires_grad_(True)
+    yc = lc + tf_ops_ref.upsample_nearest_align_corners(tc, h, w)
+    dy = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    yc.backward(torch.from_numpy(dy))
+    lg, tg = _t(lat, dev, True), _t(top, dev, True)
+    yg = ops.upsample_add(lg, tg)
+    yg.backward(_t(dy, dev))
+    assert np.array_equal(yg.detach().cpu().numpy(), yc.detach().numpy())
+    assert np.array_equal(lg.grad.cpu().numpy(), lc.grad.numpy())
+    assert_close(tg.grad.cpu().numpy(), tc.grad.numpy(), 1e-6, "upsample dtop")
+
+
+def _loss_inputs(rng, c, levels=((2, 8, 8, 9), (2, 4, 4, 9), (2, 2, 2, 9)), fg_rate=0.05):
+    out = []
+    for shp in levels:
+        rows = int(np.prod(shp))
+        z = (rng.standard_normal((rows, c)) * 2 - 2).astype(np.float32)
+        lab = np.zeros((rows, c), np.float32)
+        fg = rng.uniform(size=rows) < fg_rate
+        lab[fg, rng.integers(0, c, fg.sum())] = 1.0
+        rp = rng.standard_normal((rows, 4)).astype(np.float32)
+        rl = (rng.standard_normal((rows, 4)) * 1.5).astype(np.float32)
+        m = (rng.uniform(size=rows) < 0.8) | fg
+        out.append((z.reshape(shp + (c,)), lab.reshape(shp + (c,)), rp.reshape(shp + (4,)), rl.reshape(shp + (4,)),
+                    m.reshape(shp)))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["bce_dice", "focal"])
+@pytest.mark.parametrize("c", [3, 80, 130])
+def test_detection_loss_fwd_bwd(dev, mode, c):
+    import ops
+    rng = np.random.default_rng(c)
+    data = _loss_inputs(rng, c)
+    zc = [torch.from_numpy(d[0]).requires_grad_(True) for d in data]
+    rc = [torch.from_numpy(d[2]).requires_grad_(True) for d in data]
+    masks = [torch.from_numpy(d[4]) for d in data]
+    cat = lambda ts: torch.cat([t[m] for t, m in zip(ts, masks)], 0)
+    cl, rl = losses_ref.loss(cat([torch.from_numpy(d[1]) for d in data]), cat([torch.from_numpy(d[3]) for d in data]),
+                             cat(zc), cat(rc), mode)
+    (1.7 * cl + 0.6 * rl).backward()
+    zg = [_t(d[0], dev, True) for d in data]
+    rg = [_t(d[2], dev, True) for d in data]
+    clg, rlg, stats = ops.detection_loss(zg, rg, [_t(d[1], dev) for d in data], [_t(d[3], dev) for d in data],
+                                         [_t(d[4].astype(np.uint8), dev) for d in data], c, mode)
+    (1.7 * clg + 0.6 * rlg).backward()
+    assert_close(clg.item(), cl.item(), TOL, "class loss")
+    assert_close(rlg.item(), rl.item(), TOL, "regr loss")
+    assert stats[2].item() == sum(int(m.sum()) for m in masks)
+    for a, b in zip(zg, zc):
+        assert_close(a.grad.cpu().numpy(), b.grad.numpy(), TOL, "d cls logits")
+    for a, b in zip(rg, rc):
+        assert_close(a.grad.cpu().numpy(), b.grad.numpy(), TOL, "d reg")
+
+
+def test_regression_loss_reference_kat(dev):
+    """losses_test.py:17-27 through the HIP kernel: == 2.0 (1 class, label 1 => fg)."""
+    import ops
+    import reference_kats as K
+    lab = K.HUBER_FG.astype(np.float32).reshape(3, 1)
+    z = np.zeros((3, 1), np.float32)
+    # labels/logits broadcast over 4 coords with the same numbers keeps the mean: 4*sum/(4*#fg)
+    rp = np.repeat(K.HUBER_LOGITS, 4, 1).astype(np.float32)
+    rl = np.repeat(K.HUBER_LABELS, 4, 1).astype(np.float32)
+    _, reg, _ = ops.detection_loss([_t(z, dev)], [_t(rp, dev)], [_t(lab, dev)], [_t(rl, dev)],
+                                   [_t(np.ones(3, np.uint8), dev)], 1, "bce_dice")
+    assert reg.item() == K.HUBER_EXPECTED
+
+
+@pytest.mark.parametrize("mode", ["trunc_int", "float"])
+def test_anchor_assignment_bit_exact(dev, mode):
+    import dataset
+    import levels
+    dataset.ANCHOR_SIZE_MODE = mode
+    lv = levels.build_levels()
+    rng = np.random.default_rng(5)
+    size = (256, 320)
+    nimg, max_obj, c = 4, 12, 80
+    boxes = np.zeros((nimg, max_obj, 4), np.float32)
+    cids = np.zeros((nimg, max_obj), np.int32)
+    nobj = np.zeros(nimg, np.int32)
+    for i in range(nimg):
+        b, k = coco_like_objects(rng, 256, max_obj)
+        nobj[i] = len(b)
+        boxes[i, :len(b)], cids[i, :len(b)] = b, k
+    # exact ties and the ignore band: duplicate a box (arg-max must keep the FIRST) and add
+    # anchor-shaped boxes whose IoU lands on / near the thresholds
+    boxes[0, 1] = boxes[0, 0]
+    cids[0, 1] = (cids[0, 0] + 1) % c
+    try:
+        for pn in lv:
+            factor = 2 ** int(pn[-1])
+            cls, reg, msk, arg = dataset.level_labels(size, _t(cids, dev), _t(boxes, dev), lv[pn], factor, c,
+                                                      num_obj=_t(nobj, dev), return_argmax=True)
+            for i in range(nimg):
+                oc, orr, om, oarg = dataset_ref.level_labels(size, cids[i, :nobj[i]], boxes[i, :nobj[i]],
+                                                            lv[pn].anchor_sizes, factor, c, mode)
+                assert np.array_equal(arg[i].cpu().numpy(), oarg), pn
+                assert np.array_equal(msk[i].cpu().numpy().astype(bool), om), pn
+                assert np.array_equal(cls[i].cpu().numpy(), oc), pn
+                assert_close(reg[i].cpu().numpy(), orr, TOL, "regression targets " + pn)
+    finally:
+        dataset.ANCHOR_SIZE_MODE = "trunc_int"
+
+
+def test_assignment_reference_kat(dev):
+    """dataset_test.py:8-45 class map through the HIP kernel."""
+    import dataset
+    import levels
+    import reference_kats as K
+    lvl = levels.Level(K.ASSIGN_LEVEL["base"], K.ASSIGN_LEVEL["aspects"], K.ASSIGN_LEVEL["scales"])
+    cls, reg, msk = dataset.level_labels(K.ASSIGN_IMAGE_SIZE, _t(K.ASSIGN_CLASS_IDS.astype(np.int32)[None], dev),
+                                         _t(K.ASSIGN_BOXES.astype(np.float32)[None], dev), lvl, K.ASSIGN_FACTOR, 401)
+    cls = cls[0].cpu().numpy()
+    ids = np.where(cls.max(-1) > 0, cls.argmax(-1), 0)
+    assert np.array_equal(ids, K.ASSIGN_CLASSMAP_EXPECTED)
+
+
+def test_decode_boxes(dev):
+    import levels
+    import utils
+    lv = levels.build_levels()
+    rng = np.random.default_rng(11)
+    for (h, w) in ((3, 4), (16, 20), (1, 1)):
+        reg = (rng.standard_normal((2, h, w, 9, 4)) * 0.5).astype(np.float32)
+        anchors = lv["P4"].normalized_anchor_sizes((h * 16, w * 16))
+        got = utils.regression_postprocess(_t(reg, dev), anchors).cpu().numpy()
+        exp = utils_ref.regression_postprocess(reg, anchors)
+        assert_close(got, exp, TOL, "decode")
+    import reference_kats as K
+    # utils_test.py:44-74 through the kernel: zero regression == the anchor box map
+    z = np.zeros((1, 3, 4, 1, 4), np.float32)
+    got = utils.regression_postprocess(_t(z, dev), K.ANCHOR_BOXMAP_ANCHORS).cpu().numpy()
+    assert np.allclose(got, K.ANCHOR_BOXMAP_EXPECTED, atol=1e-6)
+
+
+def _detection_inputs(rng, n, c, sizes, hot=0.02):
+    probs, boxes = {}, {}
+    for i, (h, w) in enumerate(sizes):
+        k = "P%d" % (3 + i)
+        p = rng.uniform(0, 0.45, (n, h, w, 9, c)).astype(np.float32)
+        sel = rng.uniform(size=(n, h, w, 9)) < hot
+        cls = rng.integers(0, c, sel.sum())
+        p[sel, cls] = rng.uniform(0.5, 1.0, sel.sum()).astype(np.float32)
+        # clustered boxes so that suppression actually happens
+        centres = rng.uniform(0.2, 0.8, (6, 2))
+        pick = rng.integers(0, 6, (n, h, w, 9))
+        ctr = centres[pick] + rng.normal(0, 0.02, (n, h, w, 9, 2))
+        sz = rng.uniform(0.1, 0.3, (n, h, w, 9, 2))
+        b = np.concatenate([ctr - sz / 2, ctr + sz / 2], -1).astype(np.float32)
+        probs[k], boxes[k] = p, b
+    return probs, boxes
+
+
+@pytest.mark.parametrize("n,c,hot", [(2, 5, 0.05), (3, 80, 0.02), (1, 3, 0.6)])
+def test_detect_bit_exact_indices(dev, n, c, hot):
+    """boxes_decode + merge + nms_classwise for a batch == the oracle, index for index."""
+    import utils
+    rng = np.random.default_rng(n * 100 + c)
+    sizes = [(8, 8), (4, 4), (2, 2), (1, 1), (1, 1)]
+    probs, boxes = _detection_inputs(rng, n, c, sizes, hot)
+    # score ties inside one class
+    probs["P3"][0, 0, 0, 0, :] = 0; probs["P3"][0, 0, 0, 0, 1] = 0.9
+    probs["P3"][0, 0, 1, 0, :] = 0; probs["P3"][0, 0, 1, 0, 1] = 0.9
+    got = utils.detect({k: _t(v, dev) for k, v in probs.items()}, {k: _t(v, dev) for k, v in boxes.items()}, c)
+    total_kept = 0
+    for i in range(n):
+        parts = [utils_ref.boxes_decode(probs[k][i], boxes[k][i]) for k in probs]
+        exp = utils_ref.nms_classwise(utils_ref.merge_boxes_decoded(parts), c)
+        assert np.array_equal(got[i].class_ids.cpu().numpy(), exp.class_ids)
+        assert np.array_equal(got[i].scores.cpu().numpy(), exp.scores)
+        assert np.array_equal(got[i].boxes.cpu().numpy(), exp.boxes)
+        total_kept += len(exp.scores)
+    assert total_kept > 0
+
+
+def test_boxes_decode_and_nms_api(dev):
+    import utils
+    rng = np.random.default_rng(3)
+    probs, boxes = _detection_inputs(rng, 1, 4, [(6, 6)], 0.3)
+    p, b = probs["P3"][0], boxes["P3"][0]
+    dec = utils.boxes_decode(_t(p, dev), _t(b, dev))
+    exp = utils_ref.boxes_decode(p, b)
+    assert np.array_equal(dec.boxes.cpu().numpy(), exp.boxes)
+    assert np.array_equal(dec.scores.cpu().numpy(), exp.scores)
+    assert np.array_equal(dec.class_ids.cpu().numpy(), exp.class_ids)
+    kept = utils.nms(dec)
+    ek = utils_ref.nms(exp, fast=False)
+    assert np.array_equal(kept.boxes.cpu().numpy(), ek.boxes) and np.array_equal(kept.class_ids.cpu().numpy(), ek.class_ids)
+    cw = utils.nms_classwise(dec, 4)
+    ecw = utils_ref.nms_classwise(exp, 4)
+    assert np.array_equal(cw.scores.cpu().numpy(), ecw.scores) and np.array_equal(cw.boxes.cpu().numpy(), ecw.boxes)
+    # empty input
+    empty = utils.BoxesDecoded(dec.boxes[:0], dec.scores[:0], dec.class_ids[:0])
+    assert utils.nms(empty).boxes.shape[0] == 0
+
+
+def test_nms_max_output_and_degenerate_boxes(dev):
+    import utils
+    rng = np.random.default_rng(9)
+    k = 1500
+    c = rng.uniform(0, 1, (k, 2))
+    b = np.concatenate([c, c + 1e-3], 1).astype(np.float32)      # tiny, disjoint: nothing suppressed
+    b[5] = [0.3, 0.3, 0.3, 0.3]                                   # zero area
+    b[6] = [0.6, 0.6, 0.5, 0.5]                                   # inverted corners
+    s = rng.uniform(0.5, 1, k).astype(np.float32)
+    dec = utils.BoxesDecoded(_t(b, dev), _t(s, dev), torch.zeros(k, dtype=torch.int64, device=dev))
+    kept = utils.nms(dec)
+    exp = utils_ref.nms_indices(b, s)
+    assert kept.boxes.shape[0] == utils.NMS_MAX_OUTPUT_SIZE == len(exp)
+    assert np.array_equal(kept.boxes.cpu().numpy(), b[exp])
+
+
+@pytest.mark.parametrize("kind", ["momentum", "rmsprop", "adam"])
+def test_optimizer_matches_tf_semantics(dev, kind):
+    import train
+    torch.manual_seed(0)
+    lin = torch.nn.Module()
+    lin.a = torch.nn.Parameter(torch.randn(3, 3, 8, 16))
+    lin.a.l2_scale = 1e-4
+    lin.b = torch.nn.Parameter(torch.randn(700))
+    params = {"a": lin.a.detach().clone(), "b": lin.b.detach().clone()}
+    lin.to(dev)
+    arena = train.ParamArena(lin, dev)
+    opt = train.Optimizer(arena, kind, 1e-2, grad_clip_norm=0.5)
+    state = {}
+    for step in range(1, 4):
+        grads = {"a": torch.randn(3, 3, 8, 16), "b": torch.randn(700)}
+        lin.a.grad.copy_(grads["a"].to(dev)); lin.b.grad.copy_(grads["b"].to(dev))
+        opt.step(grad_scale=0.5)
+        tot = {"a": grads["a"] * 0.5 + 1e-4 * params["a"], "b": grads["b"] * 0.5}
+        clipped, gn = train_ref.clip_by_global_norm([tot["a"], tot["b"]], 0.5)
+        assert_close(opt.norm_reg[0].item() ** 0.5, gn.item(), TOL, "global norm")
+        train_ref.apply_optimizer(kind, params, {"a": clipped[0], "b": clipped[1]}, state, 1e-2, step)
+        assert_close(lin.a.detach().cpu().numpy(), params["a"].numpy(), TOL, "weights a step %d" % step)
+        assert_close(lin.b.detach().cpu().numpy(), params["b"].numpy(), TOL, "weights b step %d" % step)

@@ -1,0 +1,129 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the
+header declares, the anchor API equals the reference fixture, the layer containers follow
+the reference's calling convention, and the product path refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import _rn
+    assert os.path.exists(_rn.LIB_PATH), "build the library first: make -C retinanet-tensorflow_amd/csrc"
+    lib = ctypes.CDLL(_rn.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for sym in declared:
+        assert hasattr(lib, sym), "librn_hip.so does not export %s" % sym
+    assert sorted(_rn.SYMBOLS) == declared
+    assert lib.rn_version() == 100
+
+
+def test_same_pad_c_matches_python():
+    import _rn
+    L = _rn.lib()
+    for n in (1, 2, 7, 25, 64, 512, 800):
+        for k, s in ((1, 1), (3, 1), (3, 2), (7, 2)):
+            out, pad = ctypes.c_int(), ctypes.c_int()
+            L.rn_same_pad(n, k, s, ctypes.byref(out), ctypes.byref(pad))
+            assert (out.value, pad.value) == _rn.same_pad(n, k, s)
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    import _rn
+    L = _rn.lib()
+    geom = _rn.ConvGeom(3, 3, 1, 8)
+    segs = (_rn.ConvSeg * 1)()
+    assert L.rn_conv2d_fwd(segs, 0, ctypes.byref(geom), None) == -1          # RN_EINVAL
+    assert b"nseg" in L.rn_last_error()
+    segs[0].n, segs[0].h, segs[0].w, segs[0].cout = 1, 4, 4, 8
+    assert L.rn_conv2d_fwd(segs, 1, ctypes.byref(geom), None) == -1          # null pointers
+    assert L.rn_depthwise_fwd(None, None, None, 1, 4, 4, 6, 3, 1, None) in (-1, -2)
+
+
+def test_levels_api_matches_reference_fixture(golden_dir):
+    import levels
+    ref = np.load(os.path.join(golden_dir, "levels_reference.npz"))
+    lv = levels.build_levels()
+    assert lv.num_anchors == int(ref["num_anchors"])
+    assert list(lv.keys()) == [str(k) for k in ref["keys"]] == list(iter(lv))
+    for k in lv:
+        assert np.array_equal(lv[k].anchor_sizes, ref["anchor_sizes_" + k])
+    assert np.array_equal(levels.compute_box_size(32, (1, 2), 1), ref["box_size_32_1x2_1"])
+    assert np.array_equal(levels.Level(32, [(1, 4)], [1, 2]).anchor_sizes, ref["level_32_1x4"])
+    from oracle import levels_ref
+    for mode in ("trunc_int", "float"):
+        assert np.array_equal(lv["P5"].normalized_anchor_sizes((512, 640), mode),
+                              levels_ref.normalized_anchor_sizes(lv["P5"].anchor_sizes, (512, 640), mode))
+
+
+def test_model_structure_and_parameter_names():
+    import layers, levels, retinanet
+    from oracle import model_ref
+    from helpers import to_oracle_name
+    net = retinanet.RetinaNet('mobilenet_v2', levels.build_levels(), 80, layers.elu, 0.2)
+    shapes = dict(model_ref.mobilenet_v2_param_shapes())
+    shapes.update(model_ref.fpn_head_param_shapes(32, 96, 32, 9, 80))
+    got = {to_oracle_name(k): tuple(v.shape) for k, v in net.named_parameters()}
+    assert got == {k: tuple(v) for k, v in shapes.items()}
+    assert abs(sum(p.numel() for p in net.parameters()) - 10.13e6) < 0.1e6       # SURVEY: 10.13 M
+    with pytest.raises(AssertionError):
+        retinanet.build_backbone('densenet', layers.elu, 0.2)                    # reference assert, retinanet.py:13
+
+
+def test_sequential_passes_training_only_where_accepted():
+    from model import Model, Sequential
+    seen = []
+
+    class WithTraining(Model):
+        def call(self, input, training):
+            seen.append(('with', training))
+            return input + 1
+
+    def plain(input):
+        seen.append(('plain',))
+        return input * 2
+
+    def fn_training(input, training):
+        seen.append(('fn', training))
+        return input
+
+    out = Sequential([WithTraining(), plain, fn_training])(torch.zeros(1), training=True)
+    assert float(out) == 2.0 and seen == [('with', True), ('plain',), ('fn', True)]
+
+
+def test_no_cpu_fallback():
+    import layers, ops
+    x = torch.zeros(1, 4, 4, 8)
+    w = torch.zeros(3, 3, 8, 8)
+    import _rn
+    with pytest.raises(_rn.RnError):
+        ops.conv2d(x, w)
+    with pytest.raises(_rn.RnError):
+        ops.group_norm_act(x, torch.ones(8), torch.zeros(8))
+
+
+def test_param_arena_layout_cpu():
+    import layers, levels, retinanet, train
+    net = retinanet.RetinaNet('mobilenet_v2', levels.build_levels(), 3, layers.elu, 0.0)
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    arena = train.ParamArena(net, torch.device('cpu'))
+    assert arena.count % train.OPT_BLOCK == 0 and arena.num_params == sum(v.numel() for v in before.values())
+    for (k, p), (off, size) in zip(net.named_parameters(), arena.offsets):
+        assert off % train.OPT_BLOCK == 0
+        assert torch.equal(p.detach(), before[k])
+        assert p.data_ptr() == arena.weights[off:off + size].data_ptr()
+        assert p.grad.data_ptr() == arena.grads[off:off + size].data_ptr()
+    wd = arena.wd_per_block.numpy()
+    assert set(np.unique(wd).tolist()) == {0.0, np.float32(4e-5).item(), np.float32(1e-4).item()}
