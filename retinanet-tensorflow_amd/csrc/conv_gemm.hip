@@ -242,12 +242,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
 // =============================================================================================
 // dgrad: rows = input pixels, K = (kh,kw,co), N = ci.  W tile is read "NK" (ci rows, co contiguous).
 // =============================================================================================
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int VEC>
 __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs args) {
   constexpr int T = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int KQ = BK / 4, RPP = T / KQ, A_PASS = BM / RPP, B_PASS = BN / RPP;
+  constexpr int KQ = BK / VEC, RPP = T / KQ, A_PASS = BM / RPP, B_PASS = BN / RPP;
   static_assert(A_PASS >= 1 && B_PASS >= 1, "tile/threads mismatch");
+  typedef typename Vec<VEC>::type vec_t;
   __shared__ __attribute__((aligned(16))) float smem[BM * LDK + BN * LDK];
   float* As = smem;
   float* Bs = smem + BM * LDK;
@@ -282,9 +283,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
     }
   }
 
-  float4 ra[A_PASS], rb[B_PASS];
+  vec_t ra[A_PASS], rb[B_PASS];
   auto load_tiles = [&](int kt) {
-    const int k = kt * BK + kq * 4;
+    const int k = kt * BK + kq * VEC;
     const bool kok = k < ktotal;
     const int tap = k / cout, co = k - tap * cout;
     const int khh = tap / kw, kww = tap - khh * kw;
@@ -300,21 +301,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
         ok = ok && (oh_ * stride == ohs) && (ow_ * stride == ows);
       }
       ok = ok && oh_ < OH && ow_ < OW;
-      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) ra[i] = *reinterpret_cast<const float4*>(dy + ((size_t)(nb[i] + oh_) * OW + ow_) * cout + co);
+      ra[i] = Vec<VEC>::zero();
+      if (ok) ra[i] = *reinterpret_cast<const vec_t*>(dy + ((size_t)(nb[i] + oh_) * OW + ow_) * cout + co);
     }
 #pragma unroll
     for (int j = 0; j < B_PASS; ++j) {
       const int ci = n0 + r0 + j * RPP;
-      rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kok && ci < cin) rb[j] = *reinterpret_cast<const float4*>(wb + ((size_t)tap * cin + ci) * cout + co);
+      rb[j] = Vec<VEC>::zero();
+      if (kok && ci < cin) rb[j] = *reinterpret_cast<const vec_t*>(wb + ((size_t)tap * cin + ci) * cout + co);
     }
   };
   auto store_tiles = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<float4*>(&As[(r0 + i * RPP) * LDK + kq * 4]) = ra[i];
+    for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<vec_t*>(&As[(r0 + i * RPP) * LDK + kq * VEC]) = ra[i];
 #pragma unroll
-    for (int j = 0; j < B_PASS; ++j) *reinterpret_cast<float4*>(&Bs[(r0 + j * RPP) * LDK + kq * 4]) = rb[j];
+    for (int j = 0; j < B_PASS; ++j) *reinterpret_cast<vec_t*>(&Bs[(r0 + j * RPP) * LDK + kq * VEC]) = rb[j];
   };
 
   f32x16 acc[TM][TN];
@@ -527,9 +528,10 @@ extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
   if (int e = validate_geom(segs, nseg, g)) return e;
   ConvArgs a = {};
   a.nseg = nseg; a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.cin = g->cin;
+  bool vec = true;  // float4 gathers run along cout
   for (int s = 0; s < nseg; ++s) {
     RN_CHECK_ARG(segs[s].dy && segs[s].wgt && segs[s].dx, "conv dgrad: null pointer in segment %d", s);
-    RN_UNSUPPORTED(segs[s].cout % 4 != 0, "conv dgrad: cout %d not a multiple of 4", segs[s].cout);
+    vec = vec && (segs[s].cout % 4 == 0);
     SegDev& d = a.seg[s];
     d.a = segs[s].dy; d.b = segs[s].wgt; d.bias = nullptr; d.out = segs[s].dx;
     d.n = segs[s].n; d.h = segs[s].h; d.w = segs[s].w; d.cout = segs[s].cout;
@@ -547,8 +549,11 @@ extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
     tiles += rn::ceil_div(d.m, kCfgs[c].bm) * d.tiles_n;
   }
   hipStream_t st = (hipStream_t)stream;
-#define RN_DG(BM_, BN_, WM_, WN_) \
-  hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a)
+#define RN_DG(BM_, BN_, WM_, WN_)                                                                    \
+  do {                                                                                               \
+    if (vec) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 4>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+    else hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 1>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a);     \
+  } while (0)
   switch (c) {
     case 0: RN_DG(128, 128, 2, 2); break;
     case 1: RN_DG(128, 64, 2, 2); break;

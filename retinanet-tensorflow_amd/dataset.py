@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 import _rn
+import utils
 
 NEG_IOU_THRESHOLD = 0.4
 POS_IOU_THRESHOLD = 0.5
@@ -32,7 +33,7 @@ def level_labels(image_size, class_id, true_box, level, factor, num_classes, num
     if num_obj is None:
         num_obj = torch.full((n,), o, dtype=torch.int32, device=dev)
     num_obj = num_obj.to(torch.int32).contiguous()
-    anchors = torch.from_numpy(level.normalized_anchor_sizes(image_size, ANCHOR_SIZE_MODE)).to(dev).contiguous()
+    anchors = utils._anchor_tensor(level.normalized_anchor_sizes(image_size, ANCHOR_SIZE_MODE), dev)
     a = anchors.shape[0]
     gh, gw = int(math.ceil(image_size[0] / factor)), int(math.ceil(image_size[1] / factor))
     cls = torch.empty((n, gh, gw, a, num_classes), dtype=torch.float32, device=dev)

@@ -54,10 +54,21 @@ def merge_outputs(dict, name='merge_outputs'):
     return torch.cat(list(dict.values()), 0)
 
 
+_ANCHOR_CACHE = {}
+
+
 def _anchor_tensor(anchor_boxes, device):
-    a = torch.as_tensor(np.asarray(anchor_boxes, dtype=np.float32) if not torch.is_tensor(anchor_boxes) else anchor_boxes,
-                        dtype=torch.float32)
-    return a.to(device).contiguous()
+    """[A,2] anchor table on the device.  Host tables are uploaded once and cached (an H2D copy
+    cannot be captured into a hipGraph, and the tables never change)."""
+    if torch.is_tensor(anchor_boxes):
+        return anchor_boxes.to(device=device, dtype=torch.float32).contiguous()
+    a = np.ascontiguousarray(anchor_boxes, dtype=np.float32)
+    key = (a.tobytes(), a.shape, str(device))
+    t = _ANCHOR_CACHE.get(key)
+    if t is None:
+        t = torch.from_numpy(a).to(device).contiguous()
+        _ANCHOR_CACHE[key] = t
+    return t
 
 
 def regression_postprocess(regression, anchor_boxes, name='regression_postprocess'):

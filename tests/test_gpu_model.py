@@ -90,10 +90,17 @@ def test_loss_and_gradients_match_oracle(dev, mode):
     (gcl + grl).backward()
     assert_close(gcl.item(), cl.item(), TOL, "class loss")
     assert_close(grl.item(), rl.item(), TOL, "regr loss")
+    # Error is measured against max(|grad of this tensor|, 1e-3 * largest gradient in the net): some
+    # gradients are analytically zero (a per-channel shift feeding a 1x1 conv + per-channel GroupNorm,
+    # e.g. bottleneck_7_1.linear_conv.norm.beta) and hold only rounding noise on both sides.
+    scale = max(float(g.abs().max()) for g in grads.values())
     worst = 0.0
     for name, p in net.named_parameters():
         o = to_oracle_name(name)
-        worst = max(worst, assert_close(p.grad.cpu().numpy(), grads[o].numpy(), 5e-4, "grad " + o))
+        ref = grads[o].numpy()
+        err = float(np.abs(p.grad.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-3 * scale)
+        assert err <= 5e-4, "grad %s: relative error %.3e" % (o, err)
+        worst = max(worst, err)
     print("worst gradient error", worst)
 
 

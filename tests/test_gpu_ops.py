@@ -32,6 +32,7 @@ CONV_CASES = [
     (2, 16, 16, 256, 256, 3, 1, False),      # head tower conv
     (2, 8, 8, 256, 720, 3, 1, True),         # class out conv (A*C = 720)
     (2, 8, 8, 256, 36, 3, 1, True),          # box out conv
+    (2, 6, 5, 256, 27, 3, 1, True),          # class out conv, 3 classes: cout % 4 != 0 (scalar paths)
     (2, 33, 31, 3, 32, 3, 2, False),         # stem, odd size, scalar (cin=3) path
     (2, 16, 16, 32, 256, 3, 2, False),       # P6 from C5
     (2, 7, 9, 256, 256, 3, 2, False),        # stride 2 on odd maps
