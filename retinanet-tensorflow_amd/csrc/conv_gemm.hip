@@ -15,6 +15,8 @@
 // LDS, k-contiguous tiles padded to 36 floats so the ds_read_b128 fragments are conflict-free.
 // Tile ids are remapped so neighbouring tiles (which share the activation rows / the weight
 // panel) run on the same XCD and hit its L2.
+#include <stdlib.h>
+
 #include "rn_common.h"
 
 namespace {
@@ -48,18 +50,31 @@ struct ConvArgs {
   float* slab;   // wgrad: [nsplit][ktotal][cout]
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;  // voffset beyond any tensor (< 2 GiB each): buffer loads return 0,
+                                       // buffer stores are dropped -- no branches around memory ops
+
+// Raw buffer access: 32-bit byte offsets + hardware range check against the tensor size.
 template <int VEC>
 struct Vec;
 template <>
 struct Vec<4> {
   typedef float4 type;
-  static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ float4 load(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  }
 };
 template <>
 struct Vec<1> {
   typedef float type;
-  static __device__ __forceinline__ float zero() { return 0.f; }
+  static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0));
+  }
 };
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
 
 // ---------------------------------------------------------------------------------------------
 // MFMA over one staged K-tile.  A fragment: lane l supplies A[row l&31][k-slot l>>5]; we let
@@ -108,24 +123,28 @@ __device__ __forceinline__ void mma_ktile(const float* __restrict__ As, const fl
 }
 
 // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// Stores go through a buffer descriptor sized to exactly `mmax` rows: rows past the end are
+// dropped by the range check, only the column needs a test => 16 back-to-back stores per tile.
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* __restrict__ out,
                                            const float* __restrict__ bias, int m0, int n0, int mmax, int nmax,
                                            int ldc, int wm, int wn, int lane) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   const int l31 = lane & 31, half = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(out, (unsigned)mmax * (unsigned)ldc * 4u);
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = n0 + wn * (BN / WN) + tn * 32 + l31;
-    if (col >= nmax) continue;
-    const float bv = bias ? bias[col] : 0.f;
+    const bool cok = col < nmax;
+    const float bv = (bias != nullptr && cok) ? bias[col] : 0.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int rbase = m0 + wm * (BM / WM) + tm * 32 + 4 * half;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + (r & 3) + 8 * (r >> 2);
-        if (row < mmax) out[(size_t)row * ldc + col] = acc[tm][tn][r] + bv;
+        const unsigned voff = cok ? ((unsigned)row * (unsigned)ldc + (unsigned)col) * 4u : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[tm][tn][r] + bv), rs, voff, 0, 0);
       }
     }
   }
@@ -148,9 +167,10 @@ __device__ __forceinline__ int find_seg(const ConvArgs& args, int id) {
 }
 
 // =============================================================================================
-// forward
+// forward.  TAPU: cin % BK == 0, so every K-tile lies inside ONE filter tap and (kh, kw, ci0) are
+// block-uniform scalars advanced incrementally -- no per-thread division in the K loop.
 // =============================================================================================
-template <int BM, int BN, int WM, int WN, int VEC>
+template <int BM, int BN, int WM, int WN, int VEC, bool TAPU>
 __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs args) {
   constexpr int T = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -173,12 +193,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
   const int H = sg.h, W = sg.w, OW = sg.ow, OHW = sg.oh * sg.ow, M = sg.m, cout = sg.cout;
   const int cin = args.cin, kw = args.kw, stride = args.stride;
   const int ktotal = args.kh * args.kw * cin;
-  const float* __restrict__ xa = sg.a;
-  const float* __restrict__ wb = sg.b;
+  const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a, (unsigned)sg.n * H * W * cin * 4u);
+  const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.b, (unsigned)ktotal * cout * 4u);
 
-  // per-thread im2col row bookkeeping (rows fixed for the whole K loop)
+  // per-thread im2col rows (fixed for the whole K loop): element offset of (n, ih0, iw0, 0)
   const int kq = tid % KQ;
-  int ih0[A_PASS], iw0[A_PASS], nb[A_PASS];
+  int ih0[A_PASS], iw0[A_PASS], rowoff[A_PASS];
 #pragma unroll
   for (int i = 0; i < A_PASS; ++i) {
     const int m = m0 + tid / KQ + i * A_RPP;
@@ -187,34 +207,42 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
       const int oh_ = rem / OW, ow_ = rem - oh_ * OW;
       ih0[i] = oh_ * stride - sg.pad_t;
       iw0[i] = ow_ * stride - sg.pad_l;
-      nb[i] = n_ * H;
+      rowoff[i] = ((n_ * H + ih0[i]) * W + iw0[i]) * cin;
     } else {
-      ih0[i] = -0x40000000; iw0[i] = 0; nb[i] = 0;
+      ih0[i] = -0x40000000; iw0[i] = 0; rowoff[i] = 0;
     }
   }
   const int nq = tid % NQ;
   const int bcol = n0 + nq * VEC;
-  const bool bcol_ok = bcol < cout;
+  // weight rows past ktotal fall outside the descriptor => zeros without a test
+  const unsigned boff0 = bcol < cout ? ((unsigned)(tid / NQ) * cout + bcol) * 4u : OOB;
 
+  int t_kh = 0, t_kw = 0, t_ci = 0;  // TAPU: block-uniform tap state of the tile being loaded
   vec_t ra[A_PASS], rb[B_PASS];
   auto load_tiles = [&](int kt) {
-    const int k = kt * BK + kq * VEC;
-    const bool kok = k < ktotal;
-    const int tap = k / cin, ci = k - tap * cin;
-    const int khh = tap / kw, kww = tap - khh * kw;
+    int khh, kww, tapoff;
+    bool kok = true;
+    if (TAPU) {
+      khh = t_kh; kww = t_kw;
+      tapoff = (khh * W + kww) * cin + t_ci + kq * VEC;
+      t_ci += BK;
+      if (t_ci == cin) { t_ci = 0; if (++t_kw == kw) { t_kw = 0; ++t_kh; } }
+    } else {
+      const int k = kt * BK + kq * VEC;
+      kok = k < ktotal;
+      const int tap = k / cin, ci = k - tap * cin;
+      khh = tap / kw; kww = tap - khh * kw;
+      tapoff = (khh * W + kww) * cin + ci;
+    }
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       const int ih = ih0[i] + khh, iw = iw0[i] + kww;
       const bool ok = kok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-      ra[i] = Vec<VEC>::zero();
-      if (ok) ra[i] = *reinterpret_cast<const vec_t*>(xa + ((size_t)(nb[i] + ih) * W + iw) * cin + ci);
+      ra[i] = Vec<VEC>::load(xa, ok ? (unsigned)(rowoff[i] + tapoff) * 4u : OOB);
     }
+    const unsigned bo = boff0 + (unsigned)kt * BK * cout * 4u;
 #pragma unroll
-    for (int j = 0; j < B_PASS; ++j) {
-      const int kk = kt * BK + tid / NQ + j * B_RPP;
-      rb[j] = Vec<VEC>::zero();
-      if (bcol_ok && kk < ktotal) rb[j] = *reinterpret_cast<const vec_t*>(wb + (size_t)kk * cout + bcol);
-    }
+    for (int j = 0; j < B_PASS; ++j) rb[j] = Vec<VEC>::load(wb, bo + (unsigned)j * B_RPP * cout * 4u);
   };
   auto store_tiles = [&]() {
 #pragma unroll
@@ -241,8 +269,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
 
 // =============================================================================================
 // dgrad: rows = input pixels, K = (kh,kw,co), N = ci.  W tile is read "NK" (ci rows, co contiguous).
+// TAPU: cout % BK == 0 (tap uniform per K-tile).
 // =============================================================================================
-template <int BM, int BN, int WM, int WN, int VEC>
+template <int BM, int BN, int WM, int WN, int VEC, bool TAPU>
 __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs args) {
   constexpr int T = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -264,8 +293,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
   const int W = sg.w, OH = sg.oh, OW = sg.ow, HW = sg.h * sg.w, M = sg.m, cout = sg.cout;
   const int cin = args.cin, kw = args.kw, stride = args.stride;
   const int ktotal = args.kh * args.kw * cout;
-  const float* __restrict__ dy = sg.a;
-  const float* __restrict__ wb = sg.b;
+  const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.a, (unsigned)sg.n * OH * OW * cout * 4u);
+  const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.b, (unsigned)args.kh * args.kw * cin * cout * 4u);
 
   const int kq = tid % KQ, r0 = tid / KQ;
   int ihp[A_PASS], iwp[A_PASS], nb[A_PASS];
@@ -282,13 +311,30 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
       ihp[i] = -0x40000000; iwp[i] = 0; nb[i] = 0;
     }
   }
+  // weight row (ci) of this thread in each B pass; rows >= cin must not alias the next tap
+  unsigned browoff[B_PASS];
+#pragma unroll
+  for (int j = 0; j < B_PASS; ++j) {
+    const int ci = n0 + r0 + j * RPP;
+    browoff[j] = ci < cin ? (unsigned)ci * cout * 4u : OOB;
+  }
 
+  int t_kh = 0, t_kw = 0, t_co = 0;
   vec_t ra[A_PASS], rb[B_PASS];
   auto load_tiles = [&](int kt) {
-    const int k = kt * BK + kq * VEC;
-    const bool kok = k < ktotal;
-    const int tap = k / cout, co = k - tap * cout;
-    const int khh = tap / kw, kww = tap - khh * kw;
+    int khh, kww, co, tap;
+    bool kok = true;
+    if (TAPU) {
+      khh = t_kh; kww = t_kw; tap = khh * kw + kww;
+      co = t_co + kq * VEC;
+      t_co += BK;
+      if (t_co == cout) { t_co = 0; if (++t_kw == kw) { t_kw = 0; ++t_kh; } }
+    } else {
+      const int k = kt * BK + kq * VEC;
+      kok = k < ktotal;
+      tap = k / cout; co = k - tap * cout;
+      khh = tap / kw; kww = tap - khh * kw;
+    }
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       const int ohs = ihp[i] - khh, ows = iwp[i] - kww;
@@ -301,15 +347,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
         ok = ok && (oh_ * stride == ohs) && (ow_ * stride == ows);
       }
       ok = ok && oh_ < OH && ow_ < OW;
-      ra[i] = Vec<VEC>::zero();
-      if (ok) ra[i] = *reinterpret_cast<const vec_t*>(dy + ((size_t)(nb[i] + oh_) * OW + ow_) * cout + co);
+      ra[i] = Vec<VEC>::load(dy, ok ? (unsigned)(((nb[i] + oh_) * OW + ow_) * cout + co) * 4u : OOB);
     }
+    const unsigned tapb = kok ? ((unsigned)tap * cin * cout + co) * 4u : OOB;
 #pragma unroll
-    for (int j = 0; j < B_PASS; ++j) {
-      const int ci = n0 + r0 + j * RPP;
-      rb[j] = Vec<VEC>::zero();
-      if (kok && ci < cin) rb[j] = *reinterpret_cast<const vec_t*>(wb + ((size_t)tap * cin + ci) * cout + co);
-    }
+    for (int j = 0; j < B_PASS; ++j) rb[j] = Vec<VEC>::load(wb, (tapb | browoff[j]) >= OOB ? OOB : tapb + browoff[j]);
   };
   auto store_tiles = [&]() {
 #pragma unroll
@@ -335,7 +377,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
 // =============================================================================================
 // wgrad: rows m' = (kh,kw,ci), cols = co, reduction over output pixels p, split over blocks.
 // A tile is "KM" (pixel rows, m' contiguous = ci contiguous in x), B tile is dY rows.
+// The (n, oh, ow) decomposition of the block's pixel range is done ONCE into an LDS table
+// (element offset of the window origin + packed ih0/iw0), so the K loop has no division.
 // =============================================================================================
+constexpr int WG_MAXPIX = 1024;  // pixels per split (plan_wgrad keeps chunks <= this)
+
 template <int BM, int BN, int WM, int WN, int VEC>
 __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs args) {
   constexpr int T = WM * WN * 64;
@@ -345,6 +391,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
   static_assert(A_PASS >= 1 && B_PASS >= 1 && BK % A_RPP == 0 && BK % B_RPP == 0, "tile/threads mismatch");
   typedef typename Vec<VEC>::type vec_t;
   __shared__ __attribute__((aligned(16))) float smem[BK * BM + BK * BN];
+  __shared__ int2 pixtab[WG_MAXPIX];
   float* As = smem;
   float* Bs = smem + BK * BM;
 
@@ -361,43 +408,46 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
   const int H = sg.h, W = sg.w, OW = sg.ow, OHW = sg.oh * sg.ow;
   const int cin = args.cin, cout = args.cout, kw = args.kw, stride = args.stride;
   const int ktotal = args.ktotal;
-  const float* __restrict__ xa = sg.a;
-  const float* __restrict__ dy = sg.b;
-  const bool pointwise = (args.kh == 1 && args.kw == 1 && stride == 1);
+  const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a, (unsigned)sg.n * H * W * cin * 4u);
+  const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.b, (unsigned)sg.m * cout * 4u);
+
+  for (int i = tid; i < p1 - p0; i += T) {
+    const int p = p0 + i;
+    const int n_ = p / OHW, rem = p - n_ * OHW;
+    const int oh_ = rem / OW, ow_ = rem - oh_ * OW;
+    const int ih0 = oh_ * stride - sg.pad_t, iw0 = ow_ * stride - sg.pad_l;
+    pixtab[i] = make_int2(((n_ * H + ih0) * W + iw0) * cin, (ih0 << 16) | (iw0 & 0xffff));
+  }
+  __syncthreads();
 
   // this thread's m' (fixed): tap and channel
   const int mq = tid % MQ;
   const int mrow = m0 + mq * VEC;
   const bool mok = mrow < ktotal;
   const int tap = mrow / cin, ci = mrow - tap * cin;
-  const int khh = tap / kw - sg.pad_t, kww = tap % kw - sg.pad_l;
+  const int khh = tap / kw, kww = tap - khh * kw;
+  const int tapoff = (khh * W + kww) * cin + ci;
   const int nq = tid % NQ;
   const int bcol = n0 + nq * VEC;
-  const bool bok = bcol < cout;
+  const unsigned boff0 = bcol < cout ? (unsigned)bcol * 4u : OOB;
 
   vec_t ra[A_PASS], rb[B_PASS];
   auto load_tiles = [&](int kt) {
 #pragma unroll
     for (int j = 0; j < A_PASS; ++j) {
-      const int p = p0 + kt * BK + tid / MQ + j * A_RPP;
-      ra[j] = Vec<VEC>::zero();
-      if (mok && p < p1) {
-        if (pointwise) {
-          ra[j] = *reinterpret_cast<const vec_t*>(xa + (size_t)p * cin + ci);
-        } else {
-          const int n_ = p / OHW, rem = p - n_ * OHW;
-          const int oh_ = rem / OW, ow_ = rem - oh_ * OW;
-          const int ih = oh_ * stride + khh, iw = ow_ * stride + kww;
-          if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-            ra[j] = *reinterpret_cast<const vec_t*>(xa + ((size_t)(n_ * H + ih) * W + iw) * cin + ci);
-        }
+      const int pl = kt * BK + tid / MQ + j * A_RPP;
+      unsigned voff = OOB;
+      if (mok && pl < p1 - p0) {
+        const int2 e = pixtab[pl];
+        const int ih = (e.y >> 16) + khh, iw = (int)(short)(e.y & 0xffff) + kww;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) voff = (unsigned)(e.x + tapoff) * 4u;
       }
+      ra[j] = Vec<VEC>::load(xa, voff);
     }
 #pragma unroll
     for (int j = 0; j < B_PASS; ++j) {
       const int p = p0 + kt * BK + tid / NQ + j * B_RPP;
-      rb[j] = Vec<VEC>::zero();
-      if (bok && p < p1) rb[j] = *reinterpret_cast<const vec_t*>(dy + (size_t)p * cout + bcol);
+      rb[j] = Vec<VEC>::load(dy, p < p1 ? boff0 + (unsigned)p * cout * 4u : OOB);
     }
   };
   auto store_tiles = [&]() {
@@ -427,11 +477,22 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
 // dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i], fixed order => bitwise reproducible
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t count, int nsplit,
                                    int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= count) return;
-  float v = accumulate ? dw[i] : 0.f;
-  for (int s = 0; s < nsplit; ++s) v += slab[(size_t)s * count + i];
-  dw[i] = v;
+  if (i + 4 <= count && (count & 3) == 0) {
+    float4 v = accumulate ? *reinterpret_cast<const float4*>(dw + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nsplit; ++s) {
+      const float4 t = *reinterpret_cast<const float4*>(slab + (size_t)s * count + i);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    *reinterpret_cast<float4*>(dw + i) = v;
+  } else {
+    for (int64_t j = i; j < count && j < i + 4; ++j) {
+      float v = accumulate ? dw[j] : 0.f;
+      for (int s = 0; s < nsplit; ++s) v += slab[(size_t)s * count + j];
+      dw[j] = v;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -447,6 +508,10 @@ constexpr int kNumCfg = 4;
 // pick the tile shape with the least padded work, corrected for chip fill (256 CUs)
 template <typename F>
 int choose_cfg(F dims, int nseg) {
+  if (const char* force = getenv("RN_CONV_CFG")) {  // tuning aid: force a tile shape (0..3)
+    const int c = atoi(force);
+    if (c >= 0 && c < kNumCfg) return c;
+  }
   int best = 0;
   double best_cost = 1e300;
   for (int c = 0; c < kNumCfg; ++c) {
@@ -475,8 +540,15 @@ int validate_geom(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
   RN_CHECK_ARG(segs && g, "conv: null argument");
   RN_CHECK_ARG(nseg >= 1 && nseg <= RN_MAX_SEG, "conv: nseg %d outside [1,%d]", nseg, RN_MAX_SEG);
   RN_CHECK_ARG(g->kh >= 1 && g->kw >= 1 && g->stride >= 1 && g->cin >= 1, "conv: bad geometry");
-  for (int s = 0; s < nseg; ++s)
+  for (int s = 0; s < nseg; ++s) {
     RN_CHECK_ARG(segs[s].n >= 1 && segs[s].h >= 1 && segs[s].w >= 1 && segs[s].cout >= 1, "conv: bad segment %d", s);
+    // the kernels address every tensor with 32-bit byte offsets below 2 GiB
+    const double px = (double)segs[s].n * segs[s].h * segs[s].w * 4.0;
+    RN_UNSUPPORTED(px * g->cin >= 2147483648.0 || px * segs[s].cout >= 2147483648.0 ||
+                   (double)g->kh * g->kw * g->cin * segs[s].cout * 4.0 >= 2147483648.0,
+                   "conv: a tensor of segment %d is >= 2 GiB", s);
+    RN_UNSUPPORTED(segs[s].h >= 32768 || segs[s].w >= 32768, "conv: spatial size of segment %d too large", s);
+  }
   return RN_OK;
 }
 
@@ -508,10 +580,12 @@ extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
     tiles += rn::ceil_div(d.m, kCfgs[c].bm) * d.tiles_n;
   }
   hipStream_t st = (hipStream_t)stream;
+  const bool tapu = vec && (g->cin % BK == 0);
 #define RN_FWD(BM_, BN_, WM_, WN_)                                                                   \
   do {                                                                                               \
-    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 4>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
-    else hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 1>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a);     \
+    if (tapu) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 4, true>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+    else if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 4, false>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+    else hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 1, false>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a);     \
   } while (0)
   switch (c) {
     case 0: RN_FWD(128, 128, 2, 2); break;
@@ -549,10 +623,13 @@ extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
     tiles += rn::ceil_div(d.m, kCfgs[c].bm) * d.tiles_n;
   }
   hipStream_t st = (hipStream_t)stream;
+  bool tapu = vec;
+  for (int s = 0; s < nseg; ++s) tapu = tapu && (segs[s].cout % BK == 0);
 #define RN_DG(BM_, BN_, WM_, WN_)                                                                    \
   do {                                                                                               \
-    if (vec) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 4>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
-    else hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 1>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a);     \
+    if (tapu) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 4, true>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+    else if (vec) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 4, false>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+    else hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 1, false>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a);     \
   } while (0)
   switch (c) {
     case 0: RN_DG(128, 128, 2, 2); break;
@@ -598,11 +675,13 @@ int plan_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, WgradPl
   p->tiles_m = rn::ceil_div(p->ktotal, kCfgs[p->cfg].bm);
   p->tiles_n = rn::ceil_div(p->cout, kCfgs[p->cfg].bn);
   const int tiles_mn = p->tiles_m * p->tiles_n;
-  // aim for ~1536 blocks (6 per CU); each split reduces >= 64 pixels
-  long want_splits = (1536 + tiles_mn - 1) / tiles_mn;
+  // aim for ~768 blocks (3 per CU): enough to fill the chip, few enough that the slab traffic
+  // (nsplit x |dW| written + read) stays small; each split reduces >= 64 pixels
+  long want_splits = (768 + tiles_mn - 1) / tiles_mn;
   long chunk = (total_pixels + want_splits - 1) / want_splits;
   chunk = (chunk + BK - 1) / BK * BK;
   if (chunk < 2 * BK) chunk = 2 * BK;
+  if (chunk > WG_MAXPIX) chunk = WG_MAXPIX;
   int nsplit = 0;
   for (int s = 0; s < nseg; ++s) {
     p->chunk[s] = (int)chunk;
@@ -660,7 +739,7 @@ extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
 #undef RN_WG
   RN_LAUNCH_CHECK();
   const int64_t count = (int64_t)p.ktotal * p.cout;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rn::ceil_div64(count, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rn::ceil_div64(count, 1024)), dim3(256), 0, st,
                      (const float*)workspace, dw, count, p.nsplit, accumulate);
   RN_LAUNCH_CHECK();
   return RN_OK;

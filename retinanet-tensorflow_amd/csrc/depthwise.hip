@@ -148,8 +148,8 @@ unsigned grid_for(int64_t total) {
 
 void wgrad_plan(const DwArgs& a, int* chunks, int* ppc) {
   const int64_t npix = (int64_t)a.n * a.oh * a.ow;
-  int64_t ck = (npix * a.c + 32767) / 32768;
-  if (ck > 2048) ck = 2048;
+  int64_t ck = (npix * a.c + 8191) / 8192;
+  if (ck > 4096) ck = 4096;
   if (ck < 1) ck = 1;
   *ppc = (int)((npix + ck - 1) / ck);
   *chunks = (int)((npix + *ppc - 1) / *ppc);

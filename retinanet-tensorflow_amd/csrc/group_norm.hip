@@ -121,62 +121,78 @@ __global__ __launch_bounds__(T) void gn_partial_kernel(const GnArgs a) {
   }
 }
 
-// One block per sample: fp64 reduction of the chunk partials per group.
-// BWD=false -> mean / rstd.  BWD=true -> coef[g] = (sum_c gamma_c*S1_c, sum_c gamma_c*S2_c)/m.
-template <bool BWD>
-__global__ __launch_bounds__(T) void gn_finalize_kernel(const GnArgs a) {
-  const int q = blockIdx.x, tid = threadIdx.x;
-  const int s = seg_of_sample(a, q);
-  const GnSeg& sg = a.seg[s];
-  const int nl = q - sg.sample_start;
-  int gp2 = 1;
-  while (gp2 < a.groups) gp2 <<= 1;
-  if (gp2 < 4) gp2 = 4;  // keep a group's threads inside one wave (tpg <= 64)
-  const int tpg = T / gp2;  // threads per group (power of two, >= 8 for groups <= 32)
-  const int g = tid / tpg, sub = tid % tpg;
-  double v1 = 0.0, v2 = 0.0;
-  if (g < a.groups) {
-    const int items = sg.chunks * a.cpg;
-    const float* base = a.partial + (size_t)(sg.chunk_start + nl * sg.chunks) * a.c * 2;
-    for (int i = sub; i < items; i += tpg) {
-      const int ck = i / a.cpg, c = g * a.cpg + (i - ck * a.cpg);
-      const float* p = base + ((size_t)ck * a.c + c) * 2;
-      const double w = BWD ? (double)a.gamma[c] : 1.0;
-      v1 += w * (double)p[0];
-      v2 += w * (double)p[1];
-    }
-  }
-  for (int o = tpg >> 1; o > 0; o >>= 1) {
-    v1 += __shfl_xor(v1, o, 64);
-    v2 += __shfl_xor(v2, o, 64);
-  }
-  if (g < a.groups && sub == 0) {
-    const double m = (double)sg.hw * (double)a.cpg;
-    if (!BWD) {
-      const double mean = v1 / m;
-      double var = v2 / m - mean * mean;
-      if (var < 0.0) var = 0.0;
-      sg.mean[nl * a.groups + g] = (float)mean;
-      sg.rstd[nl * a.groups + g] = (float)(1.0 / sqrt(var + (double)a.eps));
-    } else {
-      a.coef[((size_t)q * a.groups + g) * 2 + 0] = (float)(v1 / m);
-      a.coef[((size_t)q * a.groups + g) * 2 + 1] = (float)(v2 / m);
-    }
-  }
+// Finalize: fp64 reduction of the chunk partials, one 256-thread block per (sample, group):
+//   BWD=false -> mean / rstd;  BWD=true -> coef[g] = (sum_c gamma_c*S1_c, sum_c gamma_c*S2_c)/m.
+// In the backward launch the blocks after samples*groups compute the parameter gradients
+// (dgamma_c = sum over all samples/chunks of S2_c, dbeta_c = sum of S1_c): 16 channels x 16 row
+// lanes per block, coalesced float2 rows, fixed order => bitwise reproducible.
+__device__ __forceinline__ void block_sum2(double& v1, double& v2, double (*sh)[T / 64]) {
+  v1 = rn::wave_sum_d(v1);
+  v2 = rn::wave_sum_d(v2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sh[0][wave] = v1; sh[1][wave] = v2; }
+  __syncthreads();
+  v1 = 0.0; v2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < T / 64; ++w) { v1 += sh[0][w]; v2 += sh[1][w]; }
 }
 
-// dgamma_c = sum over all samples/chunks of S2_c, dbeta_c = sum of S1_c (fixed order).
-__global__ void gn_param_grad_kernel(const GnArgs a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.c) return;
-  double b = 0.0, g = 0.0;
-  for (int r = 0; r < a.total_chunks; ++r) {
-    const float* p = a.partial + ((size_t)r * a.c + c) * 2;
-    b += (double)p[0];
-    g += (double)p[1];
+template <bool BWD>
+__global__ __launch_bounds__(T) void gn_finalize_kernel(const GnArgs a) {
+  __shared__ double sh[2][T / 64];
+  __shared__ double pg[16][16][2];
+  const int tid = threadIdx.x;
+  const int ngroup_blocks = a.total_samples * a.groups;
+  if ((int)blockIdx.x < ngroup_blocks) {
+    const int q = blockIdx.x / a.groups, g = blockIdx.x - q * a.groups;
+    const int s = seg_of_sample(a, q);
+    const GnSeg& sg = a.seg[s];
+    const int nl = q - sg.sample_start;
+    const int items = sg.chunks * a.cpg;
+    const float* base = a.partial + (size_t)(sg.chunk_start + nl * sg.chunks) * a.c * 2;
+    double v1 = 0.0, v2 = 0.0;
+    for (int i = tid; i < items; i += T) {
+      const int ck = i / a.cpg, c = g * a.cpg + (i - ck * a.cpg);
+      const float2 p = *reinterpret_cast<const float2*>(base + ((size_t)ck * a.c + c) * 2);
+      const double w = BWD ? (double)a.gamma[c] : 1.0;
+      v1 += w * (double)p.x;
+      v2 += w * (double)p.y;
+    }
+    block_sum2(v1, v2, sh);
+    if (tid == 0) {
+      const double m = (double)sg.hw * (double)a.cpg;
+      if (!BWD) {
+        const double mean = v1 / m;
+        double var = v2 / m - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sg.mean[nl * a.groups + g] = (float)mean;
+        sg.rstd[nl * a.groups + g] = (float)(1.0 / sqrt(var + (double)a.eps));
+      } else {
+        a.coef[((size_t)q * a.groups + g) * 2 + 0] = (float)(v1 / m);
+        a.coef[((size_t)q * a.groups + g) * 2 + 1] = (float)(v2 / m);
+      }
+    }
+  } else if (BWD) {
+    const int cl = tid & 15, rl = tid >> 4;
+    const int c = ((int)blockIdx.x - ngroup_blocks) * 16 + cl;
+    double b = 0.0, g = 0.0;
+    if (c < a.c) {
+      for (int r = rl; r < a.total_chunks; r += 16) {
+        const float2 p = *reinterpret_cast<const float2*>(a.partial + ((size_t)r * a.c + c) * 2);
+        b += (double)p.x;
+        g += (double)p.y;
+      }
+    }
+    pg[rl][cl][0] = b; pg[rl][cl][1] = g;
+    __syncthreads();
+    if (rl == 0 && c < a.c) {
+      double sb = 0.0, sgm = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sb += pg[r][cl][0]; sgm += pg[r][cl][1]; }
+      a.dbeta[c] = (float)sb;
+      a.dgamma[c] = (float)sgm;
+    }
   }
-  a.dbeta[c] = (float)b;
-  a.dgamma[c] = (float)g;
 }
 
 // grid (blocks_x, samples).  FWD: y = drop(act((x-mean)*rstd*gamma+beta)) + res.
@@ -327,7 +343,7 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   a.gamma = gamma; a.beta = beta; a.partial = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(a.total_chunks), dim3(T), 0, st, a);
-  hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(a.total_samples), dim3(T), 0, st, a);
+  hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(a.total_samples * a.groups), dim3(T), 0, st, a);
   hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(apply_blocks(a), a.total_samples), dim3(T), 0, st, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
@@ -348,8 +364,7 @@ extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   a.coef = (float*)((char*)workspace + rn::align_up((size_t)a.total_chunks * a.c * 2 * sizeof(float), 256));
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(a.total_chunks), dim3(T), 0, st, a);
-  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(a.total_samples), dim3(T), 0, st, a);
-  hipLaunchKernelGGL(gn_param_grad_kernel, dim3(rn::ceil_div(a.c, 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(a.total_samples * a.groups + rn::ceil_div(a.c, 16)), dim3(T), 0, st, a);
   hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(apply_blocks(a), a.total_samples), dim3(T), 0, st, a);
   RN_LAUNCH_CHECK();
   return RN_OK;

@@ -19,7 +19,7 @@ constexpr int T = 256;
 constexpr int WAVES = T / 64;
 constexpr int MAXJ = 4;          // classes per lane => C <= 256
 constexpr int NSCAL = 5;         // M, fg, bce, focal, huber
-constexpr int BLOCKS = 1024;
+constexpr int BLOCKS = 512;
 
 struct LossSeg {
   const float* zl; const float* ll; const float* rp; const float* rl; const uint8_t* tm;
@@ -109,25 +109,37 @@ __global__ __launch_bounds__(T) void loss_reduce_kernel(const LossArgs a) {
   }
 }
 
-__global__ void loss_finalize_kernel(const LossArgs a, int nblocks) {
-  __shared__ double sh[NSCAL + 3 * 64 * MAXJ];
+// stage 1: sums[i] = sum over blocks of partial[b][i]; 64 values x 4 row lanes per block
+__global__ __launch_bounds__(256) void loss_sum_kernel(const LossArgs a, int nblocks, double* __restrict__ sums) {
+  __shared__ double sh[4][64];
   const int n = NSCAL + 3 * a.C;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    double v = 0.0;
-    for (int b = 0; b < nblocks; ++b) v += (double)a.partial[(size_t)b * n + i];
-    sh[i] = v;
-  }
+  const int il = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + il;
+  double v = 0.0;
+  if (i < n)
+    for (int b = rl; b < nblocks; b += 4) v += (double)a.partial[(size_t)b * n + i];
+  sh[rl][il] = v;
   __syncthreads();
+  if (rl == 0 && i < n) sums[i] = sh[0][il] + sh[1][il] + sh[2][il] + sh[3][il];
+}
+
+// stage 2: loss values and the per-class statistics the gradient pass needs
+__global__ void loss_finalize_kernel(const LossArgs a, const double* __restrict__ sh) {
+  __shared__ double dice_part[256];
   for (int i = threadIdx.x; i < 3 * a.C; i += blockDim.x) a.stats[RN_LOSS_STATS_HEADER + i] = (float)sh[NSCAL + i];
+  double d = 0.0;
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    const double I = sh[NSCAL + 3 * c], U = sh[NSCAL + 3 * c + 1] + sh[NSCAL + 3 * c + 2];
+    d += 1.0 - 2.0 * I / U;
+  }
+  dice_part[threadIdx.x] = d;
+  __syncthreads();
   if (threadIdx.x == 0) {
     const double M = sh[0], fg = sh[1];
     double cls;
     if (a.mode == RN_LOSS_BCE_DICE) {
       double dice = 0.0;
-      for (int c = 0; c < a.C; ++c) {
-        const double I = sh[NSCAL + 3 * c], U = sh[NSCAL + 3 * c + 1] + sh[NSCAL + 3 * c + 2];
-        dice += 1.0 - 2.0 * I / U;
-      }
+      for (int t = 0; t < (int)blockDim.x; ++t) dice += dice_part[t];
       cls = sh[2] / (M * a.C) + dice / a.C;
     } else {
       cls = sh[3] / (fg > 1.0 ? fg : 1.0);
@@ -234,7 +246,8 @@ int nblocks_for(int64_t rows) {
 }  // namespace
 
 extern "C" size_t rn_loss_workspace(const rn_loss_seg*, int, int num_classes) {
-  return (size_t)BLOCKS * (NSCAL + 3 * (size_t)num_classes) * sizeof(float);
+  return rn::align_up((size_t)BLOCKS * (NSCAL + 3 * (size_t)num_classes) * sizeof(float), 256) +
+         (NSCAL + 3 * (size_t)num_classes) * sizeof(double);
 }
 
 extern "C" int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, float* stats, void* workspace,
@@ -250,7 +263,9 @@ extern "C" int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, i
   const int nb = nblocks_for(a.total_rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(nb), dim3(T), 0, st, a);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, a, nb);
+  double* sums = (double*)((char*)workspace + rn::align_up((size_t)BLOCKS * (NSCAL + 3 * (size_t)num_classes) * sizeof(float), 256));
+  hipLaunchKernelGGL(loss_sum_kernel, dim3(rn::ceil_div(NSCAL + 3 * num_classes, 64)), dim3(256), 0, st, a, nb, sums);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, a, (const double*)sums);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }

@@ -35,11 +35,11 @@ __global__ __launch_bounds__(T) void norm_reg_kernel(const float* __restrict__ w
 }
 
 __global__ void norm_reg_finalize_kernel(const double* __restrict__ partial, int nb, float* __restrict__ out2) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double a = 0.0, b = 0.0;
-    for (int i = 0; i < nb; ++i) { a += partial[2 * i]; b += partial[2 * i + 1]; }
-    out2[0] = (float)a; out2[1] = (float)b;
-  }
+  // one wave; lane-strided fixed-order sums
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 64) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+  a = rn::wave_sum_d(a); b = rn::wave_sum_d(b);
+  if (threadIdx.x == 0) { out2[0] = (float)a; out2[1] = (float)b; }
 }
 
 template <int KIND>

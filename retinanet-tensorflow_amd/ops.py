@@ -13,8 +13,24 @@ import torch
 import _rn
 
 
+# When True (set by train.Trainer), parameter gradients are written by the kernels straight into
+# the parameter's pre-allocated `.grad` (a view of the flat gradient arena) and autograd is handed
+# None for them: no per-parameter accumulate kernels, no arena memset.  Requires every parameter
+# to be used by exactly one op call per backward pass (true for this network: shared heads are ONE
+# multi-segment call).
+DIRECT_PARAM_GRADS = False
+
+
 def _as_list(x):
     return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
+def _grad_slot(p):
+    """(buffer to write the gradient of parameter p into, value to return to autograd)."""
+    if DIRECT_PARAM_GRADS and p.grad is not None and p.grad.is_contiguous():
+        return p.grad, None
+    g = torch.empty_like(p)
+    return g, g
 
 
 def _conv_segs(xs, w, bias, ys, dys, dxs):
@@ -52,12 +68,14 @@ class _Conv2dShared(torch.autograd.Function):
         _rn.check(L.rn_conv2d_fwd(segs, len(xs), C.byref(geom), _rn.stream()), "rn_conv2d_fwd")
         ctx.stride = stride
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         ctx.save_for_backward(w, *xs)
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
         w, *xs = ctx.saved_tensors
+        bias = ctx.bias_ref
         kh, kw, cin, cout = w.shape
         L = _rn.lib()
         geom = _rn.ConvGeom(kh, kw, ctx.stride, cin)
@@ -82,16 +100,16 @@ class _Conv2dShared(torch.autograd.Function):
             segs = _conv_segs(xs, w, None, None, dys, None)
             need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
             ws = _rn.workspace(need, w.device)
-            dw = torch.empty_like(w)
-            _rn.check(L.rn_conv2d_wgrad(segs, n, C.byref(geom), _rn.f32(dw), 0, ws.data_ptr(), ws.numel(),
+            dw_buf, dw = _grad_slot(w)
+            _rn.check(L.rn_conv2d_wgrad(segs, n, C.byref(geom), _rn.f32(dw_buf), 0, ws.data_ptr(), ws.numel(),
                                         _rn.stream()), "rn_conv2d_wgrad")
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             segs = _conv_segs(xs, w, None, None, dys, None)
             need = L.rn_conv2d_bias_grad_workspace(cout)
             ws = _rn.workspace(need, w.device)
-            db = torch.empty((cout,), dtype=torch.float32, device=w.device)
-            _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db), ws.data_ptr(), ws.numel(),
+            db_buf, db = _grad_slot(bias)
+            _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws.data_ptr(), ws.numel(),
                                             _rn.stream()), "rn_conv2d_bias_grad")
         return (None, dw, db) + tuple(dxs)
 
@@ -136,8 +154,8 @@ class _Depthwise(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             need = L.rn_depthwise_wgrad_workspace(n, h, wd, c, k, ctx.stride)
             ws = _rn.workspace(need, x.device)
-            dw = torch.empty_like(w)
-            _rn.check(L.rn_depthwise_wgrad(_rn.f32(x), _rn.f32(dy), _rn.f32(dw), n, h, wd, c, k, ctx.stride,
+            dw_buf, dw = _grad_slot(w)
+            _rn.check(L.rn_depthwise_wgrad(_rn.f32(x), _rn.f32(dy), _rn.f32(dw_buf), n, h, wd, c, k, ctx.stride,
                                            ws.data_ptr(), ws.numel(), _rn.stream()), "rn_depthwise_wgrad")
         return dx, dw, None
 
@@ -215,15 +233,15 @@ class _GroupNormAct(torch.autograd.Function):
         dev = xs[0].device
         dys = [dy.contiguous() if dy is not None else torch.zeros_like(x) for dy, x in zip(dys, xs)]
         dxs = [torch.empty_like(x) for x in xs]
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(beta)
+        dgamma_buf, dgamma = _grad_slot(gamma)
+        dbeta_buf, dbeta = _grad_slot(beta)
         params = _rn.GnParams(c, g, _rn.ACT[act], eps, drop_rate, seed,
                               seed_dev.data_ptr() if seed_dev is not None else None)
         segs = _gn_segs(xs, None, None, dys, dxs, means, rstds)
         need = L.rn_group_norm_workspace(segs, n, C.byref(params))
         ws = _rn.workspace(need, dev)
-        _rn.check(L.rn_group_norm_bwd(segs, n, C.byref(params), _rn.f32(gamma), _rn.f32(beta), _rn.f32(dgamma),
-                                      _rn.f32(dbeta), ws.data_ptr(), ws.numel(), _rn.stream()),
+        _rn.check(L.rn_group_norm_bwd(segs, n, C.byref(params), _rn.f32(gamma), _rn.f32(beta), _rn.f32(dgamma_buf),
+                                      _rn.f32(dbeta_buf), ws.data_ptr(), ws.numel(), _rn.stream()),
                   "rn_group_norm_bwd")
         dres = [dys[i] if ctx.has_res[i] else None for i in range(n)]
         return (None, dgamma, dbeta, None) + tuple(dxs) + tuple(dres)

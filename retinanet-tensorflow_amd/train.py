@@ -22,6 +22,7 @@ import torch
 import _rn
 import layers as L
 import losses
+import ops
 import utils
 from levels import build_levels
 
@@ -125,7 +126,8 @@ class Trainer(object):
     all-reduce + optimizer.  With use_graph=True the replica-local part is one hipGraph."""
 
     def __init__(self, net, levels=None, optimizer='momentum', learning_rate=1e-2, grad_clip_norm=None,
-                 loss_mode='bce_dice', device='cuda', use_graph=False, process_group=None):
+                 loss_mode='bce_dice', device='cuda', use_graph=False, process_group=None,
+                 direct_param_grads=True):
         self.net, self.levels = net, levels or build_levels()
         self.device = torch.device(device)
         self.loss_mode = loss_mode
@@ -133,6 +135,9 @@ class Trainer(object):
         self.opt = Optimizer(self.arena, optimizer, learning_rate, grad_clip_norm)
         self.allreduce = GradientAllReduce(self.arena, process_group)
         self.use_graph = use_graph
+        # kernels write parameter gradients straight into the arena (every parameter of this network
+        # is used by exactly one op call per step); see ops.DIRECT_PARAM_GRADS
+        ops.DIRECT_PARAM_GRADS = bool(direct_param_grads)
         self._graph = None
         self._static = None
         self.drop_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -145,7 +150,8 @@ class Trainer(object):
         inp, logits = utils.process_labels_and_logits(labels=features, logits=logits, levels=self.levels)
         class_loss, regr_loss = losses.loss(labels=inp['detection_trainable'], logits=logits['detection_trainable'],
                                             mode=self.loss_mode)
-        self.arena.zero_grad()
+        if not ops.DIRECT_PARAM_GRADS:
+            self.arena.zero_grad()
         (class_loss + regr_loss).backward()
         self.drop_counter += 0x9E3779B9            # fresh dropout masks next step (device-side counter)
         return class_loss.detach(), regr_loss.detach()
