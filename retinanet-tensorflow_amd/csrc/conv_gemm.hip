@@ -474,24 +474,46 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
   store_tile<BM, BN, WM, WN>(acc, out, nullptr, m0, n0, ktotal, cout, cout, wm, wn, lane);
 }
 
-// dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i], fixed order => bitwise reproducible
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t count, int nsplit,
-                                   int accumulate) {
-  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= count) return;
-  if (i + 4 <= count && (count & 3) == 0) {
-    float4 v = accumulate ? *reinterpret_cast<const float4*>(dw + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nsplit; ++s) {
-      const float4 t = *reinterpret_cast<const float4*>(slab + (size_t)s * count + i);
-      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+// out[i] = (accumulate ? out[i] : 0) + sum_r in[r][i], fixed order => bitwise reproducible.
+// Block = 16 float4 columns x 16 row lanes: lane l sums rows l, l+16, ... (coalesced 256-B row
+// segments), the 16 lanes are combined in lane order through LDS.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          int64_t count, int nrows, int accumulate) {
+  __shared__ float4 sh[16][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int64_t i = ((int64_t)blockIdx.x * 16 + cl) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < count) {
+    const bool full = (i + 4 <= count) && ((count & 3) == 0);
+    for (int r = rl; r < nrows; r += 16) {
+      const float* p = in + (size_t)r * count + i;
+      if (full) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      } else {
+        v.x += p[0];
+        if (i + 1 < count) v.y += p[1];
+        if (i + 2 < count) v.z += p[2];
+        if (i + 3 < count) v.w += p[3];
+      }
     }
-    *reinterpret_cast<float4*>(dw + i) = v;
-  } else {
-    for (int64_t j = i; j < count && j < i + 4; ++j) {
-      float v = accumulate ? dw[j] : 0.f;
-      for (int s = 0; s < nsplit; ++s) v += slab[(size_t)s * count + j];
-      dw[j] = v;
+  }
+  sh[rl][cl] = v;
+  __syncthreads();
+  if (rl == 0 && i < count) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (accumulate) {
+      t.x = out[i];
+      if (i + 1 < count) t.y = out[i + 1];
+      if (i + 2 < count) t.z = out[i + 2];
+      if (i + 3 < count) t.w = out[i + 3];
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { t.x += sh[r][cl].x; t.y += sh[r][cl].y; t.z += sh[r][cl].z; t.w += sh[r][cl].w; }
+    out[i] = t.x;
+    if (i + 1 < count) out[i + 1] = t.y;
+    if (i + 2 < count) out[i + 2] = t.z;
+    if (i + 3 < count) out[i + 3] = t.w;
   }
 }
 
@@ -553,6 +575,13 @@ int validate_geom(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
 }
 
 }  // namespace
+
+int rn::launch_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rn::ceil_div64(count, 64)), dim3(256), 0, st, in, out, count, nrows,
+                     accumulate);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
 
 extern "C" void rn_same_pad(int n, int k, int s, int* out, int* pad_before) { rn::same_pad(n, k, s, out, pad_before); }
 
@@ -671,6 +700,10 @@ int plan_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, WgradPl
                  kCfgs[c].bn * kCfgs[c].penalty;
       if (w < best) { best = w; p->cfg = c; }
     }
+    if (const char* force = getenv("RN_WGRAD_CFG")) {  // tuning aid
+      const int c = atoi(force);
+      if (c >= 0 && c < kNumCfg) p->cfg = c;
+    }
   }
   p->tiles_m = rn::ceil_div(p->ktotal, kCfgs[p->cfg].bm);
   p->tiles_n = rn::ceil_div(p->cout, kCfgs[p->cfg].bn);
@@ -738,11 +771,7 @@ extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
   }
 #undef RN_WG
   RN_LAUNCH_CHECK();
-  const int64_t count = (int64_t)p.ktotal * p.cout;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)rn::ceil_div64(count, 1024)), dim3(256), 0, st,
-                     (const float*)workspace, dw, count, p.nsplit, accumulate);
-  RN_LAUNCH_CHECK();
-  return RN_OK;
+  return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)p.ktotal * p.cout, p.nsplit, accumulate, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -797,8 +826,6 @@ extern "C" int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_c
   if (workspace_bytes < rn_conv2d_bias_grad_workspace(a.cout)) { rn::set_error("bias grad: workspace too small"); return RN_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bias_partial_kernel, dim3(BG_BLOCKS), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(bias_final_kernel, dim3(rn::ceil_div(a.cout, 256)), dim3(256), 0, st, (const float*)workspace, dbias,
-                     a.cout, BG_BLOCKS);
   RN_LAUNCH_CHECK();
-  return RN_OK;
+  return rn::launch_reduce_rows((const float*)workspace, dbias, a.cout, BG_BLOCKS, 0, st);
 }

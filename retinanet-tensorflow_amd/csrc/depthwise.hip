@@ -202,8 +202,6 @@ extern "C" int rn_depthwise_wgrad(const float* x, const float* dy, float* dw, in
   a.x = x; a.dy = dy; a.partial = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(dw_wgrad_partial_kernel, dim3(a.chunks), dim3(T), 0, st, a);
-  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3(rn::ceil_div(9 * c, 256)), dim3(256), 0, st, (const float*)workspace,
-                     dw, 9 * c, a.chunks);
   RN_LAUNCH_CHECK();
-  return RN_OK;
+  return rn::launch_reduce_rows((const float*)workspace, dw, 9 * c, a.chunks, 0, st);
 }

@@ -110,14 +110,12 @@ __global__ __launch_bounds__(T) void gn_partial_kernel(const GnArgs a) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) { red[tid][j] = s1[j]; red[tid][4 + j] = s2[j]; }
   __syncthreads();
-  if (tid < CQ) {
-    float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int l = 0; l < lanes; ++l)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] += red[l * CQ + tid][j];
-    float* out = a.partial + ((size_t)ch * C + tid * 4) * 2;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { out[2 * j] = t[j]; out[2 * j + 1] = t[4 + j]; }
+  // combine the pixel lanes: thread (q, comp) sums component comp of channel quad q in lane order
+  for (int e = tid; e < CQ * 8; e += T) {
+    const int q = e >> 3, comp = e & 7;
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += red[l * CQ + q][comp];
+    a.partial[((size_t)ch * C + q * 4 + (comp & 3)) * 2 + (comp >> 2)] = t;
   }
 }
 
@@ -283,7 +281,8 @@ int build_args(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, GnArgs* a
     d.mean = segs[s].mean; d.rstd = segs[s].rstd; d.n = segs[s].n; d.hw = segs[s].hw;
     d.sample_start = samples; d.chunk_start = chunks;
     long elems = (long)d.hw * p->c;
-    int ck = (int)((elems + 16383) / 16384);
+    const long per = elems >= (4L << 20) ? 16384 : 4096;  // small tensors are latency-bound: more, shorter blocks
+    int ck = (int)((elems + per - 1) / per);
     if (ck > 256) ck = 256;
     if (ck > d.hw) ck = d.hw;
     if (ck < 1) ck = 1;
@@ -319,7 +318,8 @@ extern "C" size_t rn_group_norm_workspace(const rn_gn_seg* segs, int nseg, const
   int samples = 0, chunks = 0;
   for (int s = 0; s < nseg; ++s) {
     long elems = (long)segs[s].hw * p->c;
-    int ck = (int)((elems + 16383) / 16384);
+    const long per = elems >= (4L << 20) ? 16384 : 4096;
+    int ck = (int)((elems + per - 1) / per);
     if (ck > 256) ck = 256;
     if (ck > segs[s].hw) ck = segs[s].hw;
     if (ck < 1) ck = 1;

@@ -36,6 +36,10 @@ void set_error(const char* fmt, ...);
     }                                                                         \
   } while (0)
 
+// out[i] = (accumulate ? out[i] : 0) + sum_r in[r][i]  (r = 0..nrows-1, fixed order => reproducible).
+// 16 float4 columns x 16 row lanes per block; defined in conv_gemm.hip.
+int launch_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, hipStream_t st);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -79,13 +83,14 @@ __device__ __forceinline__ float act_grad(float z, int act) {
   }
 }
 
-// counter-based uniform in [0,1): splitmix64 finaliser of (seed, index)
+// counter-based uniform in [0,1): 32-bit murmur3-style avalanche of (seed, 64-bit element index)
 __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
+  uint32_t h = (uint32_t)idx * 0x9E3779B1u + (uint32_t)seed;
+  h ^= (uint32_t)(idx >> 32) * 0x85EBCA77u + (uint32_t)(seed >> 32);
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
