@@ -136,6 +136,50 @@ def time_dominant_kernel(device, iters=20):
     return ms, flops
 
 
+def nms_benchmark(device, batch=16, image_size=1024, hot=0.01, iters=5):
+    """Second half of BASELINE's metric ("NMS boxes/ms"): anchor decode + candidate extraction +
+    batched class-wise NMS at the shape of BASELINE configs[4] (1024x1024, batch 16, 80 classes,
+    196 416 anchors per image, 3.14 M per batch), synthetic class probabilities with ~1 % of the
+    anchors above the 0.5 threshold, fp32.  boxes/ms = candidates entering NMS per ms of
+    decode + compaction + sort + NMS; anchors/ms = rows scanned per ms."""
+    import levels as levels_mod
+    import utils
+    lv = levels_mod.build_levels()
+    g = torch.Generator(device=device).manual_seed(7)
+    probs, regs = {}, {}
+    size = image_size
+    for i, k in enumerate(lv):
+        s = -(-size // (2 ** (3 + i)))
+        p = torch.rand((batch, s, s, 9, NUM_CLASSES), generator=g, device=device) * 0.45
+        sel = torch.rand((batch, s, s, 9), generator=g, device=device) < hot
+        cls = torch.randint(0, NUM_CLASSES, (batch, s, s, 9), generator=g, device=device)
+        val = 0.5 + 0.5 * torch.rand((batch, s, s, 9), generator=g, device=device)
+        p.view(-1, NUM_CLASSES)[sel.view(-1).nonzero().squeeze(1), cls.view(-1)[sel.view(-1)]] = val.view(-1)[sel.view(-1)]
+        probs[k] = p
+        regs[k] = torch.randn((batch, s, s, 9, 4), generator=g, device=device) * 0.3
+    rows = sum(int(v.numel() // NUM_CLASSES) for v in probs.values())
+    anchors = {k: lv[k].normalized_anchor_sizes((image_size, image_size)) for k in lv}
+
+    def run():
+        dec = {k: utils.regression_postprocess(regs[k], anchors[k]) for k in lv}
+        return utils.detect(probs, dec, NUM_CLASSES, capacity=int(rows * 0.05), return_raw=True)
+
+    out = run()
+    torch.cuda.synchronize()
+    counts = out[5].cpu().tolist()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    read_bytes = rows * (NUM_CLASSES + 4) * 4
+    return {"boxes_per_ms": round(counts[0] / ms, 1), "anchors_per_ms": round(rows / ms, 1), "ms_per_batch": round(ms, 3),
+            "candidates": counts[0], "kept": counts[1], "anchors": rows, "scan_GBps": round(read_bytes / ms / 1e6, 1),
+            "config": "BASELINE configs[4] shape: 1024x1024, batch %d, 80 classes, fp32 probabilities, ~1%% of anchors > 0.5" % batch}
+
+
 def cpu_baseline(max_seconds=30.0):
     """Oracle (torch-CPU fp32 restatement of the reference graph) on this host: forward + loss +
     backward + momentum step of the SAME workload (512^2, batch 2, 80 classes), bounded sample."""
@@ -189,6 +233,7 @@ def main():
     ap.add_argument("--loss", default="focal", choices=["focal", "bce_dice"])
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nms", action="store_true", help="skip the decode+NMS throughput measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -249,6 +294,8 @@ def main():
                          "kernel": "conv_fwd_kernel<128,128,2,2,4> 3x3 256->256 over P3..P7 (head tower layer)",
                          "kernel_ms": round(kms, 4), "flops_per_launch": kflops},
         }
+        if not args.no_nms:
+            result["nms"] = nms_benchmark(device)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)
