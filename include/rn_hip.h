@@ -69,6 +69,9 @@ typedef struct rn_conv_seg {
 
 typedef struct rn_conv_geom {
   int32_t kh, kw, stride, cin;
+  int32_t groups; /* 0 or 1 = dense.  G > 1: grouped conv (ResNeXt cardinality, resnet.py:53-59): kernel
+                     [kh,kw,cin/G,cout], output channels [g*cout/G,(g+1)*cout/G) read input channels
+                     [g*cin/G,(g+1)*cin/G); at most 128 channels per group */
 } rn_conv_geom;
 
 int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream);
@@ -111,6 +114,7 @@ typedef struct rn_gn_seg {
   const float* residual; /* fwd: optional, same shape as y, or NULL         */
   const float* dy;       /* bwd in                                          */
   float* dx;             /* bwd out                                         */
+  float* dresidual;      /* bwd out, only with act_after_residual: grad w.r.t. residual */
   float* mean;           /* [n, groups]                                     */
   float* rstd;           /* [n, groups]                                     */
   int32_t n, hw;
@@ -118,6 +122,8 @@ typedef struct rn_gn_seg {
 
 typedef struct rn_gn_params {
   int32_t c, groups, act;
+  int32_t act_after_residual; /* 0: y = drop(act(GN(x))) + residual (MobileNetV2, mobilenet_v2.py:91-92);
+                                 1: y = drop(act(GN(x) + residual))  (ResNeXt, resnet.py:99-101)          */
   float eps;
   float drop_rate;    /* 0 => no dropout                                    */
   uint64_t drop_seed; /* counter-based mask: keep iff hash(seed, elem) >= rate            */
@@ -143,6 +149,19 @@ int rn_upsample_add_fwd(const float* lateral, const float* top, float* y, int n,
                         rn_stream_t stream);
 int rn_upsample_add_bwd_top(const float* dy, float* dtop, int n, int h, int w, int th, int tw, int c,
                             rn_stream_t stream);
+
+/* stand-alone inverted dropout (DenseNet puts tf.layers.Dropout after a conv: densenet.py:44,67,77,143);
+ * the same counter-based mask in forward and backward: dx = rn_dropout(dy) with the same seed. */
+int rn_dropout(const float* x, float* y, int64_t count, float rate, uint64_t seed, const uint64_t* seed_dev,
+               rn_stream_t stream);
+/* tf.layers.MaxPooling2D(k, stride, 'same') (resnet.py:200, densenet.py:180): padded cells never win; the
+ * gradient goes to the first maximum of each window.  tf.layers.AveragePooling2D(k, stride, 'same')
+ * (densenet.py:144): divides by the number of valid cells. */
+int rn_maxpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);
+int rn_maxpool_bwd(const float* x, const float* dy, float* dx, int n, int h, int w, int c, int k, int stride,
+                   rn_stream_t stream);
+int rn_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);
+int rn_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);
 
 /* ------------------------------------------------------------------ loss
  * Replaces utils.process_labels_and_logits/postprocess_and_mask (utils.py:240-284; the

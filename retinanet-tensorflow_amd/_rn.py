@@ -32,17 +32,19 @@ class ConvSeg(C.Structure):
 
 
 class ConvGeom(C.Structure):
-    _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("cin", C.c_int32)]
+    _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("cin", C.c_int32),
+                ("groups", C.c_int32)]
 
 
 class GnSeg(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("residual", C.c_void_p), ("dy", C.c_void_p),
-                ("dx", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("dx", C.c_void_p), ("dresidual", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
                 ("n", C.c_int32), ("hw", C.c_int32)]
 
 
 class GnParams(C.Structure):
-    _fields_ = [("c", C.c_int32), ("groups", C.c_int32), ("act", C.c_int32), ("eps", C.c_float),
+    _fields_ = [("c", C.c_int32), ("groups", C.c_int32), ("act", C.c_int32), ("act_after_residual", C.c_int32),
+                ("eps", C.c_float),
                 ("drop_rate", C.c_float), ("drop_seed", C.c_uint64), ("drop_seed_dev", C.c_void_p)]
 
 
@@ -71,6 +73,7 @@ SYMBOLS = [
     "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad",
     "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
+    "rn_dropout", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_avgpool_fwd", "rn_avgpool_bwd",
     "rn_loss_workspace", "rn_loss_fwd", "rn_loss_bwd",
     "rn_anchor_assign", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
     "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
@@ -113,6 +116,11 @@ def lib():
         L.rn_act_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.rn_upsample_add_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_upsample_add_bwd_top.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_dropout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.rn_maxpool_fwd.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_maxpool_bwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_avgpool_fwd.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_avgpool_bwd.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_loss_workspace.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.rn_loss_fwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                   C.c_void_p]

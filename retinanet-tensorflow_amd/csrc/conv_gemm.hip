@@ -43,6 +43,7 @@ struct ConvArgs {
   SegDev seg[RN_MAX_SEG];
   int nseg;
   int kh, kw, stride, cin;
+  int groups, cin_g;  // grouped conv: cin_g = cin/groups input channels per group; one N-tile per group
   int ktotal;    // fwd: kh*kw*cin   dgrad: kh*kw*cout(seg)  (recomputed per seg)   wgrad: kh*kw*cin
   int tiles_mn;  // wgrad: output tiles per split
   int tiles_n;   // wgrad
@@ -189,11 +190,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
   const SegDev& sg = args.seg[s];
   const int local = bid - sg.start;
   const int tile_n = local % sg.tiles_n, tile_m = local / sg.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int H = sg.h, W = sg.w, OW = sg.ow, OHW = sg.oh * sg.ow, M = sg.m, cout = sg.cout;
-  const int cin = args.cin, kw = args.kw, stride = args.stride;
+  const int ldx = args.cin, kw = args.kw, stride = args.stride;
+  // grouped conv (ResNeXt, resnet.py:53-59): N-tile `tile_n` is group g: its cout/G output channels,
+  // fed by input channels [g*cin_g, (g+1)*cin_g); kernel tensor is [kh,kw,cin_g,cout].
+  const int G = args.groups, cin = args.cin_g;
+  const int cout_g = cout / G;
+  const int m0 = tile_m * BM, n0 = G > 1 ? tile_n * cout_g : tile_n * BN;
+  const int nmax = G > 1 ? n0 + cout_g : cout;
+  const int a_coff = G > 1 ? tile_n * cin : 0;
   const int ktotal = args.kh * args.kw * cin;
-  const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a, (unsigned)sg.n * H * W * cin * 4u);
+  const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a, (unsigned)sg.n * H * W * ldx * 4u);
   const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.b, (unsigned)ktotal * cout * 4u);
 
   // per-thread im2col rows (fixed for the whole K loop): element offset of (n, ih0, iw0, 0)
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
       const int oh_ = rem / OW, ow_ = rem - oh_ * OW;
       ih0[i] = oh_ * stride - sg.pad_t;
       iw0[i] = ow_ * stride - sg.pad_l;
-      rowoff[i] = ((n_ * H + ih0[i]) * W + iw0[i]) * cin;
+      rowoff[i] = ((n_ * H + ih0[i]) * W + iw0[i]) * ldx + a_coff;
     } else {
       ih0[i] = -0x40000000; iw0[i] = 0; rowoff[i] = 0;
     }
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
   const int nq = tid % NQ;
   const int bcol = n0 + nq * VEC;
   // weight rows past ktotal fall outside the descriptor => zeros without a test
-  const unsigned boff0 = bcol < cout ? ((unsigned)(tid / NQ) * cout + bcol) * 4u : OOB;
+  const unsigned boff0 = bcol < nmax ? ((unsigned)(tid / NQ) * cout + bcol) * 4u : OOB;
 
   int t_kh = 0, t_kw = 0, t_ci = 0;  // TAPU: block-uniform tap state of the tile being loaded
   vec_t ra[A_PASS], rb[B_PASS];
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
     bool kok = true;
     if (TAPU) {
       khh = t_kh; kww = t_kw;
-      tapoff = (khh * W + kww) * cin + t_ci + kq * VEC;
+      tapoff = (khh * W + kww) * ldx + t_ci + kq * VEC;
       t_ci += BK;
       if (t_ci == cin) { t_ci = 0; if (++t_kw == kw) { t_kw = 0; ++t_kh; } }
     } else {
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
       kok = k < ktotal;
       const int tap = k / cin, ci = k - tap * cin;
       khh = tap / kw; kww = tap - khh * kw;
-      tapoff = (khh * W + kww) * cin + ci;
+      tapoff = (khh * W + kww) * ldx + ci;
     }
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
     mma_ktile<BM, BN, WM, WN, false, false>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
-  store_tile<BM, BN, WM, WN>(acc, sg.out, sg.bias, m0, n0, M, cout, cout, wm, wn, lane);
+  store_tile<BM, BN, WM, WN>(acc, sg.out, sg.bias, m0, n0, M, nmax, cout, wm, wn, lane);
 }
 
 // =============================================================================================
@@ -289,12 +296,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
   const SegDev& sg = args.seg[s];
   const int local = bid - sg.start;
   const int tile_n = local % sg.tiles_n, tile_m = local / sg.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int W = sg.w, OH = sg.oh, OW = sg.ow, HW = sg.h * sg.w, M = sg.m, cout = sg.cout;
-  const int cin = args.cin, kw = args.kw, stride = args.stride;
+  const int W = sg.w, OH = sg.oh, OW = sg.ow, HW = sg.h * sg.w, M = sg.m;
+  const int kw = args.kw, stride = args.stride;
+  // grouped: N-tile `tile_n` is group g; K runs over (tap, co within the group)
+  const int G = args.groups, cin = args.cin_g, ldy = sg.cout, ldx = args.cin;
+  const int cout = ldy / G;                                  // output channels per group = K per tap
+  const int m0 = tile_m * BM, n0 = G > 1 ? 0 : tile_n * BN;  // n0: first ci (within the group) of the tile
+  const int y_coff = G > 1 ? tile_n * cout : 0;              // channel offset into dy and into w's cout axis
+  const int x_coff = G > 1 ? tile_n * cin : 0;               // channel offset into dx
   const int ktotal = args.kh * args.kw * cout;
-  const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.a, (unsigned)sg.n * OH * OW * cout * 4u);
-  const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.b, (unsigned)args.kh * args.kw * cin * cout * 4u);
+  const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.a, (unsigned)sg.n * OH * OW * ldy * 4u);
+  const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.b, (unsigned)args.kh * args.kw * cin * ldy * 4u);
 
   const int kq = tid % KQ, r0 = tid / KQ;
   int ihp[A_PASS], iwp[A_PASS], nb[A_PASS];
@@ -316,7 +328,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
 #pragma unroll
   for (int j = 0; j < B_PASS; ++j) {
     const int ci = n0 + r0 + j * RPP;
-    browoff[j] = ci < cin ? (unsigned)ci * cout * 4u : OOB;
+    browoff[j] = ci < cin ? ((unsigned)ci * ldy + y_coff) * 4u : OOB;
   }
 
   int t_kh = 0, t_kw = 0, t_co = 0;
@@ -347,9 +359,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
         ok = ok && (oh_ * stride == ohs) && (ow_ * stride == ows);
       }
       ok = ok && oh_ < OH && ow_ < OW;
-      ra[i] = Vec<VEC>::load(dy, ok ? (unsigned)(((nb[i] + oh_) * OW + ow_) * cout + co) * 4u : OOB);
+      ra[i] = Vec<VEC>::load(dy, ok ? (unsigned)(((nb[i] + oh_) * OW + ow_) * ldy + y_coff + co) * 4u : OOB);
     }
-    const unsigned tapb = kok ? ((unsigned)tap * cin * cout + co) * 4u : OOB;
+    const unsigned tapb = kok ? ((unsigned)tap * cin * ldy + co) * 4u : OOB;
 #pragma unroll
     for (int j = 0; j < B_PASS; ++j) rb[j] = Vec<VEC>::load(wb, (tapb | browoff[j]) >= OOB ? OOB : tapb + browoff[j]);
   };
@@ -371,7 +383,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
     mma_ktile<BM, BN, WM, WN, false, true>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
-  store_tile<BM, BN, WM, WN>(acc, sg.out, nullptr, m0, n0, M, cin, cin, wm, wn, lane);
+  store_tile<BM, BN, WM, WN>(acc, sg.out, nullptr, m0, x_coff + n0, M, x_coff + cin, ldx, wm, wn, lane);
 }
 
 // =============================================================================================
@@ -400,15 +412,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
   const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
   const int split = bid / args.tiles_mn, t = bid - split * args.tiles_mn;
   const int tile_n = t % args.tiles_n, tile_m = t / args.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int s = find_seg(args, split);
   const SegDev& sg = args.seg[s];
   const int p0 = (split - sg.start) * sg.chunk;
   const int p1 = min(p0 + sg.chunk, sg.m);
   const int H = sg.h, W = sg.w, OW = sg.ow, OHW = sg.oh * sg.ow;
-  const int cin = args.cin, cout = args.cout, kw = args.kw, stride = args.stride;
+  const int ldx = args.cin, cout = args.cout, kw = args.kw, stride = args.stride;
+  const int G = args.groups, cin = args.cin_g, cout_g = cout / G;
+  const int m0 = tile_m * BM, n0 = G > 1 ? tile_n * cout_g : tile_n * BN;
+  const int nmax = G > 1 ? n0 + cout_g : cout;
+  const int x_coff = G > 1 ? tile_n * cin : 0;
   const int ktotal = args.ktotal;
-  const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a, (unsigned)sg.n * H * W * cin * 4u);
+  const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a, (unsigned)sg.n * H * W * ldx * 4u);
   const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.b, (unsigned)sg.m * cout * 4u);
 
   for (int i = tid; i < p1 - p0; i += T) {
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
     const int n_ = p / OHW, rem = p - n_ * OHW;
     const int oh_ = rem / OW, ow_ = rem - oh_ * OW;
     const int ih0 = oh_ * stride - sg.pad_t, iw0 = ow_ * stride - sg.pad_l;
-    pixtab[i] = make_int2(((n_ * H + ih0) * W + iw0) * cin, (ih0 << 16) | (iw0 & 0xffff));
+    pixtab[i] = make_int2(((n_ * H + ih0) * W + iw0) * ldx + x_coff, (ih0 << 16) | (iw0 & 0xffff));
   }
   __syncthreads();
 
@@ -426,10 +441,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
   const bool mok = mrow < ktotal;
   const int tap = mrow / cin, ci = mrow - tap * cin;
   const int khh = tap / kw, kww = tap - khh * kw;
-  const int tapoff = (khh * W + kww) * cin + ci;
+  const int tapoff = (khh * W + kww) * ldx + ci;
   const int nq = tid % NQ;
   const int bcol = n0 + nq * VEC;
-  const unsigned boff0 = bcol < cout ? (unsigned)bcol * 4u : OOB;
+  const unsigned boff0 = bcol < nmax ? (unsigned)bcol * 4u : OOB;
 
   vec_t ra[A_PASS], rb[B_PASS];
   auto load_tiles = [&](int kt) {
@@ -471,7 +486,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
     __syncthreads();
   }
   float* out = args.slab + (size_t)split * ktotal * cout;
-  store_tile<BM, BN, WM, WN>(acc, out, nullptr, m0, n0, ktotal, cout, cout, wm, wn, lane);
+  store_tile<BM, BN, WM, WN>(acc, out, nullptr, m0, n0, ktotal, nmax, cout, wm, wn, lane);
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_r in[r][i], fixed order => bitwise reproducible.
@@ -558,10 +573,23 @@ int choose_cfg(F dims, int nseg) {
   return best;
 }
 
+// grouped conv: one N-tile per group => the tile must be at least as wide as a group
+int cfg_for_group_width(int width) { return width <= 32 ? 3 : (width <= 64 ? 2 : 0); }
+inline int ngroups(const rn_conv_geom* g) { return g->groups > 1 ? g->groups : 1; }
+
 int validate_geom(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
   RN_CHECK_ARG(segs && g, "conv: null argument");
   RN_CHECK_ARG(nseg >= 1 && nseg <= RN_MAX_SEG, "conv: nseg %d outside [1,%d]", nseg, RN_MAX_SEG);
   RN_CHECK_ARG(g->kh >= 1 && g->kw >= 1 && g->stride >= 1 && g->cin >= 1, "conv: bad geometry");
+  RN_CHECK_ARG(g->groups >= 0 && (g->groups <= 1 || g->cin % g->groups == 0), "conv: cin %d not divisible by groups %d",
+               g->cin, g->groups);
+  if (g->groups > 1) {
+    for (int s = 0; s < nseg; ++s) {
+      RN_CHECK_ARG(segs[s].cout % g->groups == 0, "conv: cout %d not divisible by groups %d", segs[s].cout, g->groups);
+      RN_UNSUPPORTED(segs[s].cout / g->groups > 128 || g->cin / g->groups > 128,
+                     "conv: grouped conv supports at most 128 channels per group");
+    }
+  }
   for (int s = 0; s < nseg; ++s) {
     RN_CHECK_ARG(segs[s].n >= 1 && segs[s].h >= 1 && segs[s].w >= 1 && segs[s].cout >= 1, "conv: bad segment %d", s);
     // the kernels address every tensor with 32-bit byte offsets below 2 GiB
@@ -588,8 +616,10 @@ extern "C" void rn_same_pad(int n, int k, int s, int* out, int* pad_before) { rn
 extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream) {
   if (int e = validate_geom(segs, nseg, g)) return e;
   ConvArgs a = {};
+  const int G = ngroups(g);
   a.nseg = nseg; a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.cin = g->cin;
-  bool vec = (g->cin % 4 == 0);
+  a.groups = G; a.cin_g = g->cin / G;
+  bool vec = (a.cin_g % 4 == 0);
   for (int s = 0; s < nseg; ++s) {
     RN_CHECK_ARG(segs[s].x && segs[s].wgt && segs[s].y, "conv fwd: null pointer in segment %d", s);
     SegDev& d = a.seg[s];
@@ -598,18 +628,19 @@ extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
     rn::same_pad(d.h, g->kh, g->stride, &d.oh, &d.pad_t);
     rn::same_pad(d.w, g->kw, g->stride, &d.ow, &d.pad_l);
     d.m = d.n * d.oh * d.ow;
-    vec = vec && (d.cout % 4 == 0);
+    vec = vec && ((d.cout / G) % 4 == 0);
   }
-  const int c = choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m; *n = a.seg[s].cout; }, nseg);
+  const int c = G > 1 ? cfg_for_group_width(a.seg[0].cout / G)
+                      : choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m; *n = a.seg[s].cout; }, nseg);
   int tiles = 0;
   for (int s = 0; s < nseg; ++s) {
     SegDev& d = a.seg[s];
-    d.tiles_n = rn::ceil_div(d.cout, kCfgs[c].bn);
+    d.tiles_n = G > 1 ? G : rn::ceil_div(d.cout, kCfgs[c].bn);
     d.start = tiles;
     tiles += rn::ceil_div(d.m, kCfgs[c].bm) * d.tiles_n;
   }
   hipStream_t st = (hipStream_t)stream;
-  const bool tapu = vec && (g->cin % BK == 0);
+  const bool tapu = vec && (a.cin_g % BK == 0);
 #define RN_FWD(BM_, BN_, WM_, WN_)                                                                   \
   do {                                                                                               \
     if (tapu) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 4, true>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
@@ -630,11 +661,13 @@ extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
 extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream) {
   if (int e = validate_geom(segs, nseg, g)) return e;
   ConvArgs a = {};
+  const int G = ngroups(g);
   a.nseg = nseg; a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.cin = g->cin;
+  a.groups = G; a.cin_g = g->cin / G;
   bool vec = true;  // float4 gathers run along cout
   for (int s = 0; s < nseg; ++s) {
     RN_CHECK_ARG(segs[s].dy && segs[s].wgt && segs[s].dx, "conv dgrad: null pointer in segment %d", s);
-    vec = vec && (segs[s].cout % 4 == 0);
+    vec = vec && ((segs[s].cout / G) % 4 == 0);
     SegDev& d = a.seg[s];
     d.a = segs[s].dy; d.b = segs[s].wgt; d.bias = nullptr; d.out = segs[s].dx;
     d.n = segs[s].n; d.h = segs[s].h; d.w = segs[s].w; d.cout = segs[s].cout;
@@ -643,17 +676,18 @@ extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
     d.m = d.n * d.h * d.w;
   }
   const int cin = g->cin;
-  const int c = choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m; *n = cin; }, nseg);
+  const int c = G > 1 ? cfg_for_group_width(a.cin_g)
+                      : choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m; *n = cin; }, nseg);
   int tiles = 0;
   for (int s = 0; s < nseg; ++s) {
     SegDev& d = a.seg[s];
-    d.tiles_n = rn::ceil_div(cin, kCfgs[c].bn);
+    d.tiles_n = G > 1 ? G : rn::ceil_div(cin, kCfgs[c].bn);
     d.start = tiles;
     tiles += rn::ceil_div(d.m, kCfgs[c].bm) * d.tiles_n;
   }
   hipStream_t st = (hipStream_t)stream;
   bool tapu = vec;
-  for (int s = 0; s < nseg; ++s) tapu = tapu && (segs[s].cout % BK == 0);
+  for (int s = 0; s < nseg; ++s) tapu = tapu && ((segs[s].cout / G) % BK == 0);
 #define RN_DG(BM_, BN_, WM_, WN_)                                                                    \
   do {                                                                                               \
     if (tapu) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 4, true>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
@@ -679,7 +713,8 @@ struct WgradPlan {
 };
 
 int plan_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, WgradPlan* p) {
-  p->ktotal = g->kh * g->kw * g->cin;
+  const int G = ngroups(g);
+  p->ktotal = g->kh * g->kw * (g->cin / G);
   p->cout = segs[0].cout;
   long total_pixels = 0;
   for (int s = 0; s < nseg; ++s) {
@@ -704,9 +739,10 @@ int plan_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, WgradPl
       const int c = atoi(force);
       if (c >= 0 && c < kNumCfg) p->cfg = c;
     }
+    if (G > 1) p->cfg = cfg_for_group_width(p->cout / G);
   }
   p->tiles_m = rn::ceil_div(p->ktotal, kCfgs[p->cfg].bm);
-  p->tiles_n = rn::ceil_div(p->cout, kCfgs[p->cfg].bn);
+  p->tiles_n = G > 1 ? G : rn::ceil_div(p->cout, kCfgs[p->cfg].bn);
   const int tiles_mn = p->tiles_m * p->tiles_n;
   // aim for ~768 blocks (3 per CU): enough to fill the chip, few enough that the slab traffic
   // (nsplit x |dW| written + read) stays small; each split reduces >= 64 pixels
@@ -746,6 +782,7 @@ extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
   }
   ConvArgs a = {};
   a.nseg = nseg; a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.cin = g->cin;
+  a.groups = ngroups(g); a.cin_g = g->cin / a.groups;
   a.ktotal = p.ktotal; a.cout = p.cout; a.tiles_n = p.tiles_n; a.tiles_mn = p.tiles_m * p.tiles_n;
   a.slab = (float*)workspace;
   for (int s = 0; s < nseg; ++s) {
@@ -755,7 +792,7 @@ extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
     d.oh = p.oh[s]; d.ow = p.ow[s]; d.pad_t = p.pt[s]; d.pad_l = p.pl[s];
     d.m = p.pixels[s]; d.start = p.start[s]; d.chunk = p.chunk[s];
   }
-  const bool vec = (g->cin % 4 == 0) && (p.cout % 4 == 0);
+  const bool vec = (a.cin_g % 4 == 0) && ((p.cout / a.groups) % 4 == 0);
   const int blocks = p.nsplit * a.tiles_mn;
   hipStream_t st = (hipStream_t)stream;
 #define RN_WG(BM_, BN_, WM_, WN_)                                                                    \

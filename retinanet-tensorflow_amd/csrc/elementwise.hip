@@ -73,6 +73,153 @@ __global__ void upsample_add_bwd_kernel(const float* __restrict__ dy, float* __r
   }
 }
 
+// ---- stand-alone dropout (DenseNet places tf.layers.Dropout after a conv, densenet.py:44,67,77,143)
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t count, float rate, uint64_t seed,
+                               const uint64_t* __restrict__ seed_dev) {
+  const uint64_t sd = seed + (seed_dev ? *seed_dev : 0ull);
+  const float ks = 1.f / (1.f - rate);
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < count; i += (int64_t)gridDim.x * T)
+    y[i] = rn::uniform01(sd, (uint64_t)i) >= rate ? x[i] * ks : 0.f;
+}
+
+// ---- 3x3/2 (k x k / s) max pool, TF SAME: padded cells never win (resnet.py:200, densenet.py:180)
+struct PoolArgs { const float* x; const float* dy; float* out; int n, h, w, c, k, s, oh, ow, pt, pl; };
+
+__global__ void maxpool_fwd_kernel(const PoolArgs a) {
+  const int CQ = a.c >> 2;
+  const int64_t total = (int64_t)a.n * a.oh * a.ow * CQ;
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < total; i += (int64_t)gridDim.x * T) {
+    const int q4 = (int)(i % CQ);
+    int64_t p = i / CQ;
+    const int ow_ = (int)(p % a.ow); p /= a.ow;
+    const int oh_ = (int)(p % a.oh);
+    const int n_ = (int)(p / a.oh);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int kh = 0; kh < a.k; ++kh) {
+      const int ih = oh_ * a.s - a.pt + kh;
+      if ((unsigned)ih >= (unsigned)a.h) continue;
+      for (int kw = 0; kw < a.k; ++kw) {
+        const int iw = ow_ * a.s - a.pl + kw;
+        if ((unsigned)iw >= (unsigned)a.w) continue;
+        const float4 v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n_ * a.h + ih) * a.w + iw) * a.c + q4 * 4);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    *reinterpret_cast<float4*>(a.out + (size_t)i * 4) = m;
+  }
+}
+
+// gradient goes to the FIRST maximum of each window (row-major window order); gather form: every
+// input cell sums dy of the windows in which it is that first maximum => deterministic, no atomics
+__global__ void maxpool_bwd_kernel(const PoolArgs a) {
+  const int64_t total = (int64_t)a.n * a.h * a.w * a.c;
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < total; i += (int64_t)gridDim.x * T) {
+    const int c = (int)(i % a.c);
+    int64_t p = i / a.c;
+    const int iw = (int)(p % a.w); p /= a.w;
+    const int ih = (int)(p % a.h);
+    const int n_ = (int)(p / a.h);
+    const float xv = a.x[i];
+    float g = 0.f;
+    for (int kh = 0; kh < a.k; ++kh) {
+      const int ohs = ih + a.pt - kh;
+      if (ohs < 0 || ohs % a.s) continue;
+      const int oh_ = ohs / a.s;
+      if (oh_ >= a.oh) continue;
+      for (int kw = 0; kw < a.k; ++kw) {
+        const int ows = iw + a.pl - kw;
+        if (ows < 0 || ows % a.s) continue;
+        const int ow_ = ows / a.s;
+        if (ow_ >= a.ow) continue;
+        // is (ih, iw) the first max of window (oh_, ow_)?
+        bool first = true;
+        for (int a2 = 0; a2 < a.k && first; ++a2) {
+          const int yy = oh_ * a.s - a.pt + a2;
+          if ((unsigned)yy >= (unsigned)a.h) continue;
+          for (int b2 = 0; b2 < a.k; ++b2) {
+            const int xx = ow_ * a.s - a.pl + b2;
+            if ((unsigned)xx >= (unsigned)a.w) continue;
+            const float v = a.x[((size_t)(n_ * a.h + yy) * a.w + xx) * a.c + c];
+            const bool before = (a2 < kh) || (a2 == kh && b2 < kw);
+            if (v > xv || (before && v == xv)) { first = false; break; }
+          }
+        }
+        if (first) g += a.dy[((size_t)(n_ * a.oh + oh_) * a.ow + ow_) * a.c + c];
+      }
+    }
+    a.out[i] = g;
+  }
+}
+
+// ---- 2x2/2 (k x k / s) average pool, TF SAME: divide by the number of VALID cells (densenet.py:144)
+__global__ void avgpool_fwd_kernel(const PoolArgs a) {
+  const int CQ = a.c >> 2;
+  const int64_t total = (int64_t)a.n * a.oh * a.ow * CQ;
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < total; i += (int64_t)gridDim.x * T) {
+    const int q4 = (int)(i % CQ);
+    int64_t p = i / CQ;
+    const int ow_ = (int)(p % a.ow); p /= a.ow;
+    const int oh_ = (int)(p % a.oh);
+    const int n_ = (int)(p / a.oh);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cnt = 0;
+    for (int kh = 0; kh < a.k; ++kh) {
+      const int ih = oh_ * a.s - a.pt + kh;
+      if ((unsigned)ih >= (unsigned)a.h) continue;
+      for (int kw = 0; kw < a.k; ++kw) {
+        const int iw = ow_ * a.s - a.pl + kw;
+        if ((unsigned)iw >= (unsigned)a.w) continue;
+        const float4 v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n_ * a.h + ih) * a.w + iw) * a.c + q4 * 4);
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        ++cnt;
+      }
+    }
+    const float inv = 1.f / (float)cnt;
+    *reinterpret_cast<float4*>(a.out + (size_t)i * 4) = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv);
+  }
+}
+
+__global__ void avgpool_bwd_kernel(const PoolArgs a) {
+  const int CQ = a.c >> 2;
+  const int64_t total = (int64_t)a.n * a.h * a.w * CQ;
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < total; i += (int64_t)gridDim.x * T) {
+    const int q4 = (int)(i % CQ);
+    int64_t p = i / CQ;
+    const int iw = (int)(p % a.w); p /= a.w;
+    const int ih = (int)(p % a.h);
+    const int n_ = (int)(p / a.h);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < a.k; ++kh) {
+      const int ohs = ih + a.pt - kh;
+      if (ohs < 0 || ohs % a.s) continue;
+      const int oh_ = ohs / a.s;
+      if (oh_ >= a.oh) continue;
+      for (int kw = 0; kw < a.k; ++kw) {
+        const int ows = iw + a.pl - kw;
+        if (ows < 0 || ows % a.s) continue;
+        const int ow_ = ows / a.s;
+        if (ow_ >= a.ow) continue;
+        // valid cells of that window
+        const int y0 = oh_ * a.s - a.pt, x0 = ow_ * a.s - a.pl;
+        const int vy = min(y0 + a.k, a.h) - max(y0, 0), vx = min(x0 + a.k, a.w) - max(x0, 0);
+        const float inv = 1.f / (float)(vy * vx);
+        const float4 d = *reinterpret_cast<const float4*>(a.dy + ((size_t)(n_ * a.oh + oh_) * a.ow + ow_) * a.c + q4 * 4);
+        g.x += d.x * inv; g.y += d.y * inv; g.z += d.z * inv; g.w += d.w * inv;
+      }
+    }
+    *reinterpret_cast<float4*>(a.out + (size_t)i * 4) = g;
+  }
+}
+
+int fill_pool(PoolArgs* a, int n, int h, int w, int c, int k, int s) {
+  RN_CHECK_ARG(n >= 1 && h >= 1 && w >= 1 && c >= 1 && k >= 1 && s >= 1, "pool: bad shape");
+  RN_UNSUPPORTED(c % 4 != 0, "pool: c=%d not a multiple of 4", c);
+  a->n = n; a->h = h; a->w = w; a->c = c; a->k = k; a->s = s;
+  rn::same_pad(h, k, s, &a->oh, &a->pt);
+  rn::same_pad(w, k, s, &a->ow, &a->pl);
+  return RN_OK;
+}
+
 unsigned grid_for(int64_t total) {
   int64_t b = (total + T - 1) / T;
   if (b > 4096) b = 4096;
@@ -113,6 +260,56 @@ extern "C" int rn_upsample_add_bwd_top(const float* dy, float* dtop, int n, int 
   RN_UNSUPPORTED(c % 4 != 0, "upsample_add bwd: c=%d not a multiple of 4", c);
   hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_for((int64_t)n * th * tw * (c / 4))), dim3(T), 0,
                      (hipStream_t)stream, dy, dtop, n, h, w, th, tw, c);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_dropout(const float* x, float* y, int64_t count, float rate, uint64_t seed, const uint64_t* seed_dev,
+                          rn_stream_t stream) {
+  RN_CHECK_ARG(x && y && count >= 0 && rate >= 0.f && rate < 1.f, "dropout: bad argument");
+  if (count == 0) return RN_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(count)), dim3(T), 0, (hipStream_t)stream, x, y, count, rate, seed, seed_dev);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_maxpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream) {
+  PoolArgs a = {};
+  if (int e = fill_pool(&a, n, h, w, c, k, stride)) return e;
+  RN_CHECK_ARG(x && y, "maxpool fwd: null pointer");
+  a.x = x; a.out = y;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)n * a.oh * a.ow * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_maxpool_bwd(const float* x, const float* dy, float* dx, int n, int h, int w, int c, int k, int stride,
+                              rn_stream_t stream) {
+  PoolArgs a = {};
+  if (int e = fill_pool(&a, n, h, w, c, k, stride)) return e;
+  RN_CHECK_ARG(x && dy && dx, "maxpool bwd: null pointer");
+  a.x = x; a.dy = dy; a.out = dx;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)n * h * w * c)), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream) {
+  PoolArgs a = {};
+  if (int e = fill_pool(&a, n, h, w, c, k, stride)) return e;
+  RN_CHECK_ARG(x && y, "avgpool fwd: null pointer");
+  a.x = x; a.out = y;
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((int64_t)n * a.oh * a.ow * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int k, int stride, rn_stream_t stream) {
+  PoolArgs a = {};
+  if (int e = fill_pool(&a, n, h, w, c, k, stride)) return e;
+  RN_CHECK_ARG(dy && dx, "avgpool bwd: null pointer");
+  a.dy = dy; a.out = dx;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((int64_t)n * h * w * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }

@@ -14,7 +14,7 @@ namespace {
 constexpr int T = 256;
 
 struct GnSeg {
-  const float* x; float* y; const float* res; const float* dy; float* dx; float* mean; float* rstd;
+  const float* x; float* y; const float* res; const float* dy; float* dx; float* dres; float* mean; float* rstd;
   int n, hw;
   int sample_start;  // first global sample id
   int chunk_start;   // first partial row
@@ -25,6 +25,7 @@ struct GnSeg {
 struct GnArgs {
   GnSeg seg[RN_MAX_SEG];
   int nseg, c, groups, cpg, act;
+  int act_after_res;  // 1: y = act(GN(x) + residual) (ResNeXt, resnet.py:99-101) instead of act(GN(x)) + residual
   float eps, drop_rate;
   uint64_t seed;
   const uint64_t* seed_dev;  // optional device counter added to seed (graph replays get fresh masks)
@@ -51,7 +52,7 @@ __device__ __forceinline__ int seg_of_chunk(const GnArgs& a, int ch) {
 template <bool BWD>
 __global__ __launch_bounds__(T) void gn_partial_kernel(const GnArgs a) {
   __shared__ float red[T][8];
-  __shared__ float tab[1024][4];  // bwd: mean, rstd, gamma, beta per channel
+  __shared__ float tab[2048][4];  // bwd: mean, rstd, gamma, beta per channel
   const int tid = threadIdx.x;
   const int ch = blockIdx.x;
   const int s = seg_of_chunk(a, ch);
@@ -59,11 +60,13 @@ __global__ __launch_bounds__(T) void gn_partial_kernel(const GnArgs a) {
   const int local = ch - sg.chunk_start;
   const int nl = local / sg.chunks, ck = local - nl * sg.chunks;
   const int C = a.c, CQ = C >> 2;
-  const int lanes = T / CQ;
+  const int QP = CQ < T ? CQ : T;      // channel quads handled per pass (C > 1024 needs several passes)
+  const int lanes = T / QP;
   const int p_begin = ck * sg.ppc, p_end = min(p_begin + sg.ppc, sg.hw);
   const size_t base = (size_t)nl * sg.hw * C;
   const float* __restrict__ x = sg.x + base;
   const float* __restrict__ dy = BWD ? sg.dy + base : nullptr;
+  const float* __restrict__ rs = (BWD && a.act_after_res && sg.res) ? sg.res + base : nullptr;
 
   if (BWD) {
     for (int c = tid; c < C; c += T) {
@@ -80,42 +83,51 @@ __global__ __launch_bounds__(T) void gn_partial_kernel(const GnArgs a) {
   const uint64_t samp_off = (uint64_t)(sg.sample_start + nl) * (uint64_t)sg.hw * (uint64_t)C;
   const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
 
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  const int q4 = tid % CQ, pl = tid / CQ;
-  if (pl < lanes) {
-    for (int p = p_begin + pl; p < p_end; p += lanes) {
-      const size_t off = (size_t)p * C + q4 * 4;
-      const float4 xv = *reinterpret_cast<const float4*>(x + off);
-      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-      if (!BWD) {
+  for (int qbase = 0; qbase < CQ; qbase += QP) {
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int q4 = qbase + tid % QP, pl = tid / QP;
+    if (pl < lanes && q4 < CQ) {
+      for (int p = p_begin + pl; p < p_end; p += lanes) {
+        const size_t off = (size_t)p * C + q4 * 4;
+        const float4 xv = *reinterpret_cast<const float4*>(x + off);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        if (!BWD) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[j] += xs[j]; s2[j] += xs[j] * xs[j]; }
-      } else {
-        const float4 dv = *reinterpret_cast<const float4*>(dy + off);
-        const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+          for (int j = 0; j < 4; ++j) { s1[j] += xs[j]; s2[j] += xs[j] * xs[j]; }
+        } else {
+          const float4 dv = *reinterpret_cast<const float4*>(dy + off);
+          const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+          float rr[4] = {0.f, 0.f, 0.f, 0.f};
+          if (rs) {
+            const float4 rv = *reinterpret_cast<const float4*>(rs + off);
+            rr[0] = rv.x; rr[1] = rv.y; rr[2] = rv.z; rr[3] = rv.w;
+          }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = q4 * 4 + j;
-          const float xh = (xs[j] - tab[c][0]) * tab[c][1];
-          const float z = xh * tab[c][2] + tab[c][3];
-          float g = ds[j];
-          if (drop) g = (rn::uniform01(seed, samp_off + off + j) >= a.drop_rate) ? g * keep_scale : 0.f;
-          g *= rn::act_grad(z, a.act);
-          s1[j] += g;
-          s2[j] += g * xh;
+          for (int j = 0; j < 4; ++j) {
+            const int c = q4 * 4 + j;
+            const float xh = (xs[j] - tab[c][0]) * tab[c][1];
+            const float z = xh * tab[c][2] + tab[c][3] + rr[j];
+            float g = ds[j];
+            if (drop) g = (rn::uniform01(seed, samp_off + off + j) >= a.drop_rate) ? g * keep_scale : 0.f;
+            g *= rn::act_grad(z, a.act);
+            s1[j] += g;
+            s2[j] += g * xh;
+          }
         }
       }
     }
-  }
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { red[tid][j] = s1[j]; red[tid][4 + j] = s2[j]; }
-  __syncthreads();
-  // combine the pixel lanes: thread (q, comp) sums component comp of channel quad q in lane order
-  for (int e = tid; e < CQ * 8; e += T) {
-    const int q = e >> 3, comp = e & 7;
-    float t = 0.f;
-    for (int l = 0; l < lanes; ++l) t += red[l * CQ + q][comp];
-    a.partial[((size_t)ch * C + q * 4 + (comp & 3)) * 2 + (comp >> 2)] = t;
+    for (int j = 0; j < 4; ++j) { red[tid][j] = s1[j]; red[tid][4 + j] = s2[j]; }
+    __syncthreads();
+    // combine the pixel lanes: thread (q, comp) sums component comp of channel quad q in lane order
+    const int nq = min(QP, CQ - qbase);
+    for (int e = tid; e < nq * 8; e += T) {
+      const int q = e >> 3, comp = e & 7;
+      float t = 0.f;
+      for (int l = 0; l < lanes; ++l) t += red[l * QP + q][comp];
+      a.partial[((size_t)ch * C + (qbase + q) * 4 + (comp & 3)) * 2 + (comp >> 2)] = t;
+    }
   }
 }
 
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(T) void gn_finalize_kernel(const GnArgs a) {
 // BWD: dx = rstd*(gamma*dya - c1 - xhat*c2).
 template <bool BWD>
 __global__ __launch_bounds__(T) void gn_apply_kernel(const GnArgs a) {
-  __shared__ float tab[1024][6];  // mean, rstd*gamma | rstd, beta, gamma, c1, c2
+  __shared__ float tab[2048][6];  // mean, rstd, gamma, beta, c1, c2 per channel
   const int q = blockIdx.y, tid = threadIdx.x;
   const int s = seg_of_sample(a, q);
   const GnSeg& sg = a.seg[s];
@@ -239,25 +251,33 @@ __global__ __launch_bounds__(T) void gn_apply_kernel(const GnArgs a) {
       for (int j = 0; j < 4; ++j) {
         const int c = q4 * 4 + j;
         const float z = (xs[j] - tab[c][0]) * tab[c][1] * tab[c][2] + tab[c][3];
-        float v = rn::act_fwd(z, a.act);
+        float v = rn::act_fwd(a.act_after_res ? z + r[j] : z, a.act);
         if (drop) v = (rn::uniform01(seed, samp_off + off + j) >= a.drop_rate) ? v * keep_scale : 0.f;
-        o[j] = v + r[j];
+        o[j] = a.act_after_res ? v : v + r[j];
       }
       *reinterpret_cast<float4*>(sg.y + base + off) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
       const float4 dv = *reinterpret_cast<const float4*>(sg.dy + base + off);
       const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+      float rr[4] = {0.f, 0.f, 0.f, 0.f}, gr[4];
+      const bool aar = a.act_after_res && sg.res;
+      if (aar) {
+        const float4 rv = *reinterpret_cast<const float4*>(sg.res + base + off);
+        rr[0] = rv.x; rr[1] = rv.y; rr[2] = rv.z; rr[3] = rv.w;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = q4 * 4 + j;
         const float xh = (xs[j] - tab[c][0]) * tab[c][1];
-        const float z = xh * tab[c][2] + tab[c][3];
+        const float z = xh * tab[c][2] + tab[c][3] + rr[j];
         float g = ds[j];
         if (drop) g = (rn::uniform01(seed, samp_off + off + j) >= a.drop_rate) ? g * keep_scale : 0.f;
         g *= rn::act_grad(z, a.act);
+        gr[j] = g;
         o[j] = tab[c][1] * (tab[c][2] * g - tab[c][4] - xh * tab[c][5]);
       }
       *reinterpret_cast<float4*>(sg.dx + base + off) = make_float4(o[0], o[1], o[2], o[3]);
+      if (aar && sg.dres) *reinterpret_cast<float4*>(sg.dres + base + off) = make_float4(gr[0], gr[1], gr[2], gr[3]);
     }
   }
 }
@@ -266,9 +286,10 @@ int build_args(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, GnArgs* a
   RN_CHECK_ARG(segs && p, "group_norm: null argument");
   RN_CHECK_ARG(nseg >= 1 && nseg <= RN_MAX_SEG, "group_norm: nseg %d outside [1,%d]", nseg, RN_MAX_SEG);
   RN_CHECK_ARG(p->c >= 4 && p->groups >= 1 && p->c % p->groups == 0, "group_norm: c=%d groups=%d", p->c, p->groups);
-  RN_UNSUPPORTED(p->c % 4 != 0 || p->c > 1024, "group_norm: c=%d must be a multiple of 4 and <= 1024", p->c);
+  RN_UNSUPPORTED(p->c % 4 != 0 || p->c > 2048, "group_norm: c=%d must be a multiple of 4 and <= 2048", p->c);
   RN_CHECK_ARG(p->drop_rate >= 0.f && p->drop_rate < 1.f, "group_norm: drop_rate %f", p->drop_rate);
   a->nseg = nseg; a->c = p->c; a->groups = p->groups; a->cpg = p->c / p->groups; a->act = p->act;
+  a->act_after_res = p->act_after_residual ? 1 : 0;
   a->eps = p->eps; a->drop_rate = p->drop_rate; a->seed = p->drop_seed; a->seed_dev = p->drop_seed_dev;
   int samples = 0, chunks = 0;
   for (int s = 0; s < nseg; ++s) {
@@ -278,6 +299,7 @@ int build_args(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, GnArgs* a
     else RN_CHECK_ARG(segs[s].y, "group_norm fwd: null y in segment %d", s);
     GnSeg& d = a->seg[s];
     d.x = segs[s].x; d.y = segs[s].y; d.res = segs[s].residual; d.dy = segs[s].dy; d.dx = segs[s].dx;
+    d.dres = segs[s].dresidual;
     d.mean = segs[s].mean; d.rstd = segs[s].rstd; d.n = segs[s].n; d.hw = segs[s].hw;
     d.sample_start = samples; d.chunk_start = chunks;
     long elems = (long)d.hw * p->c;

@@ -101,10 +101,11 @@ class Conv2D(torch.nn.Module):
     The kernel is created on the first call (input channels known then), like tf.layers."""
 
     def __init__(self, filters, kernel_size, strides=1, padding='same', use_bias=True, kernel_initializer=None,
-                 kernel_regularizer=None, bias_initializer=None, in_channels=None):
+                 kernel_regularizer=None, bias_initializer=None, in_channels=None, groups=1, name=None):
         super().__init__()
         assert padding == 'same', "the reference only uses padding='same'"
         self.filters, self.kernel_size, self.strides = filters, kernel_size, strides
+        self.groups = groups        # > 1: the `groups` parallel convs of a ResNeXt bottleneck as ONE grouped conv
         self.use_bias = use_bias
         self.kernel_initializer = kernel_initializer or VarianceScaling(1.0)
         self.bias_initializer = bias_initializer or Constant(0.0)
@@ -116,7 +117,8 @@ class Conv2D(torch.nn.Module):
 
     def build(self, in_channels, device=None):
         k = self.kernel_size
-        w = self.kernel_initializer((k, k, in_channels, self.filters))
+        assert in_channels % self.groups == 0 and self.filters % self.groups == 0
+        w = self.kernel_initializer((k, k, in_channels // self.groups, self.filters))
         self.weight = torch.nn.Parameter(w.to(device) if device is not None else w)
         self.weight.l2_scale = self.l2_scale
         if self.use_bias:
@@ -127,7 +129,7 @@ class Conv2D(torch.nn.Module):
         first = input[0] if isinstance(input, (list, tuple)) else input
         if self.weight is None:
             self.build(first.shape[3], first.device)
-        return ops.conv2d(input, self.weight, self.bias, self.strides)
+        return ops.conv2d(input, self.weight, self.bias, self.strides, self.groups)
 
 
 class DepthwiseConv2D(torch.nn.Module):
@@ -172,8 +174,31 @@ class Dropout(torch.nn.Module):
     def forward(self, input, training):
         if not training or self.rate == 0.0:
             return input
-        raise AssertionError('stand-alone Dropout is not on the hot path: place it after a Normalization '
-                             'inside a model.Sequential (it is fused into the GroupNorm kernel)')
+        return ops.dropout(input, self.rate, self.seed, Dropout.seed_device_counter)
+
+
+class MaxPooling2D(torch.nn.Module):
+    """tf.layers.MaxPooling2D(pool_size, strides, padding='same') (resnet.py:200, densenet.py:180)."""
+
+    def __init__(self, pool_size, strides, padding='same'):
+        super().__init__()
+        assert padding == 'same'
+        self.pool_size, self.strides = pool_size, strides
+
+    def forward(self, input):
+        return ops.max_pool(input, self.pool_size, self.strides)
+
+
+class AveragePooling2D(torch.nn.Module):
+    """tf.layers.AveragePooling2D(pool_size, strides, padding='same') (densenet.py:144)."""
+
+    def __init__(self, pool_size, strides, padding='same'):
+        super().__init__()
+        assert padding == 'same'
+        self.pool_size, self.strides = pool_size, strides
+
+    def forward(self, input):
+        return ops.avg_pool(input, self.pool_size, self.strides)
 
 
 class GroupNormalization(torch.nn.Module):
@@ -191,7 +216,7 @@ class GroupNormalization(torch.nn.Module):
         self.gamma = torch.nn.Parameter(torch.ones(c, device=device))
         self.beta = torch.nn.Parameter(torch.zeros(c, device=device))
 
-    def fused(self, input, training, act=None, dropout=None, residual=None):
+    def fused(self, input, training, act=None, dropout=None, residual=None, act_after_residual=False):
         first = input[0] if isinstance(input, (list, tuple)) else input
         if self.gamma is None:
             self.build(first.shape[3], first.device)
@@ -199,7 +224,7 @@ class GroupNormalization(torch.nn.Module):
         if dropout is not None and training and dropout.rate > 0.0:
             rate, seed, seed_dev = dropout.rate, dropout.seed, Dropout.seed_device_counter
         return ops.group_norm_act(input, self.gamma, self.beta, self.groups, self.eps, act, residual, rate, seed,
-                                  seed_dev)
+                                  seed_dev, act_after_residual)
 
     def call(self, input):
         return self.fused(input, False)

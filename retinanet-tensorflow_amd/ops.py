@@ -53,10 +53,12 @@ class _Conv2dShared(torch.autograd.Function):
     """tf.layers.Conv2D(padding='same') applied to n inputs that share one kernel."""
 
     @staticmethod
-    def forward(ctx, stride, w, bias, *xs):
-        kh, kw, cin, cout = w.shape
+    def forward(ctx, stride_groups, w, bias, *xs):
+        stride, groups = stride_groups
+        kh, kw, cin_g, cout = w.shape
+        cin = cin_g * groups
         L = _rn.lib()
-        geom = _rn.ConvGeom(kh, kw, stride, cin)
+        geom = _rn.ConvGeom(kh, kw, stride, cin, groups)
         ys = []
         for x in xs:
             assert x.dim() == 4 and x.shape[3] == cin, "conv2d: input %s vs kernel %s" % (tuple(x.shape), tuple(w.shape))
@@ -67,6 +69,7 @@ class _Conv2dShared(torch.autograd.Function):
         segs = _conv_segs(xs, w, bias, ys, None, None)
         _rn.check(L.rn_conv2d_fwd(segs, len(xs), C.byref(geom), _rn.stream()), "rn_conv2d_fwd")
         ctx.stride = stride
+        ctx.groups = groups
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
         ctx.save_for_backward(w, *xs)
@@ -76,9 +79,10 @@ class _Conv2dShared(torch.autograd.Function):
     def backward(ctx, *dys):
         w, *xs = ctx.saved_tensors
         bias = ctx.bias_ref
-        kh, kw, cin, cout = w.shape
+        kh, kw, cin_g, cout = w.shape
+        cin = cin_g * ctx.groups
         L = _rn.lib()
-        geom = _rn.ConvGeom(kh, kw, ctx.stride, cin)
+        geom = _rn.ConvGeom(kh, kw, ctx.stride, cin, ctx.groups)
         n = len(xs)
         dys = [dy.contiguous() if dy is not None else None for dy in dys]
         for i in range(n):
@@ -114,11 +118,12 @@ class _Conv2dShared(torch.autograd.Function):
         return (None, dw, db) + tuple(dxs)
 
 
-def conv2d(x, w, bias=None, stride=1):
-    """NHWC conv, HWIO kernel, TF SAME padding.  `x` may be a list (shared kernel, one launch)."""
+def conv2d(x, w, bias=None, stride=1, groups=1):
+    """NHWC conv, HWIO kernel [kh,kw,cin/groups,cout], TF SAME padding.  `x` may be a list (shared
+    kernel, one launch).  groups > 1: grouped conv (ResNeXt cardinality)."""
     if isinstance(x, (list, tuple)):
-        return list(_Conv2dShared.apply(stride, w, bias, *x))
-    return _Conv2dShared.apply(stride, w, bias, x)[0]
+        return list(_Conv2dShared.apply((stride, groups), w, bias, *x))
+    return _Conv2dShared.apply((stride, groups), w, bias, x)[0]
 
 
 class _Depthwise(torch.autograd.Function):
@@ -174,10 +179,17 @@ def gn_groups(c, groups=32):
     return g
 
 
-def _gn_segs(xs, ys, ress, dys, dxs, means, rstds):
+def _gn_params(c, g, eps, act, drop_rate, seed, seed_dev, act_after_residual):
+    return _rn.GnParams(c=c, groups=g, act=_rn.ACT[act], act_after_residual=1 if act_after_residual else 0, eps=eps,
+                        drop_rate=drop_rate, drop_seed=seed,
+                        drop_seed_dev=seed_dev.data_ptr() if seed_dev is not None else None)
+
+
+def _gn_segs(xs, ys, ress, dys, dxs, means, rstds, dress=None):
     segs = (_rn.GnSeg * len(xs))()
     for i, x in enumerate(xs):
         s = segs[i]
+        s.dresidual = _rn.f32(dress[i]) if dress is not None and dress[i] is not None else None
         s.x = _rn.f32(x)
         s.y = _rn.f32(ys[i]) if ys is not None else None
         s.residual = _rn.f32(ress[i]) if ress is not None and ress[i] is not None else None
@@ -195,7 +207,7 @@ class _GroupNormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, gamma, beta, n, *tensors):
-        groups, eps, act, drop_rate, seed, seed_dev = cfg
+        groups, eps, act, drop_rate, seed, seed_dev, aar = cfg
         xs = [t.contiguous() for t in tensors[:n]]
         ress = [t.contiguous() if t is not None else None for t in tensors[n:2 * n]]
         c = xs[0].shape[3]
@@ -207,16 +219,17 @@ class _GroupNormAct(torch.autograd.Function):
         rstds = [torch.empty((x.shape[0], g), dtype=torch.float32, device=dev) for x in xs]
         for x, r in zip(xs, ress):
             assert x.shape[3] == c and (r is None or r.shape == x.shape)
-        params = _rn.GnParams(c, g, _rn.ACT[act], eps, drop_rate, seed,
-                              seed_dev.data_ptr() if seed_dev is not None else None)
+        params = _gn_params(c, g, eps, act, drop_rate, seed, seed_dev, aar)
         segs = _gn_segs(xs, ys, ress, None, None, means, rstds)
         need = L.rn_group_norm_workspace(segs, n, C.byref(params))
         ws = _rn.workspace(need, dev)
         _rn.check(L.rn_group_norm_fwd(segs, n, C.byref(params), _rn.f32(gamma), _rn.f32(beta), ws.data_ptr(),
                                       ws.numel(), _rn.stream()), "rn_group_norm_fwd")
-        ctx.cfg = (c, g, eps, act, drop_rate, seed, seed_dev)
+        ctx.cfg = (c, g, eps, act, drop_rate, seed, seed_dev, aar)
         ctx.n = n
         ctx.has_res = [r is not None for r in ress]
+        # act-after-residual needs the residual again in backward (act'(GN(x) + r))
+        ctx.res_saved = [r if (aar and r is not None) else None for r in ress]
         ctx.save_for_backward(gamma, beta, *xs, *means, *rstds)
         return tuple(ys)
 
@@ -228,32 +241,34 @@ class _GroupNormAct(torch.autograd.Function):
         xs = list(saved[2:2 + n])
         means = list(saved[2 + n:2 + 2 * n])
         rstds = list(saved[2 + 2 * n:2 + 3 * n])
-        c, g, eps, act, drop_rate, seed, seed_dev = ctx.cfg
+        c, g, eps, act, drop_rate, seed, seed_dev, aar = ctx.cfg
         L = _rn.lib()
         dev = xs[0].device
         dys = [dy.contiguous() if dy is not None else torch.zeros_like(x) for dy, x in zip(dys, xs)]
         dxs = [torch.empty_like(x) for x in xs]
+        ress = ctx.res_saved
+        dress = [torch.empty_like(x) if r is not None else None for x, r in zip(xs, ress)]
         dgamma_buf, dgamma = _grad_slot(gamma)
         dbeta_buf, dbeta = _grad_slot(beta)
-        params = _rn.GnParams(c, g, _rn.ACT[act], eps, drop_rate, seed,
-                              seed_dev.data_ptr() if seed_dev is not None else None)
-        segs = _gn_segs(xs, None, None, dys, dxs, means, rstds)
+        params = _gn_params(c, g, eps, act, drop_rate, seed, seed_dev, aar)
+        segs = _gn_segs(xs, None, ress, dys, dxs, means, rstds, dress)
         need = L.rn_group_norm_workspace(segs, n, C.byref(params))
         ws = _rn.workspace(need, dev)
         _rn.check(L.rn_group_norm_bwd(segs, n, C.byref(params), _rn.f32(gamma), _rn.f32(beta), _rn.f32(dgamma_buf),
                                       _rn.f32(dbeta_buf), ws.data_ptr(), ws.numel(), _rn.stream()),
                   "rn_group_norm_bwd")
-        dres = [dys[i] if ctx.has_res[i] else None for i in range(n)]
+        dres = [(dress[i] if dress[i] is not None else dys[i]) if ctx.has_res[i] else None for i in range(n)]
         return (None, dgamma, dbeta, None) + tuple(dxs) + tuple(dres)
 
 
 def group_norm_act(x, gamma, beta, groups=32, eps=1e-5, act=None, residual=None, drop_rate=0.0, seed=0,
-                   seed_dev=None):
-    """Fused GroupNorm -> activation -> dropout -> (+ residual).  `x` / `residual` may be lists."""
+                   seed_dev=None, act_after_residual=False):
+    """Fused GroupNorm -> activation -> dropout -> (+ residual); with act_after_residual the order is
+    GroupNorm -> (+ residual) -> activation (ResNeXt).  `x` / `residual` may be lists."""
     multi = isinstance(x, (list, tuple))
     xs = _as_list(x)
     ress = _as_list(residual) if residual is not None else [None] * len(xs)
-    cfg = (groups, float(eps), act, float(drop_rate), int(seed), seed_dev)
+    cfg = (groups, float(eps), act, float(drop_rate), int(seed), seed_dev, bool(act_after_residual))
     ys = _GroupNormAct.apply(cfg, gamma, beta, len(xs), *xs, *ress)
     return list(ys) if multi else ys[0]
 
@@ -388,3 +403,87 @@ def detection_loss(cls_logits, reg_preds, cls_labels, reg_labels, trainable_mask
     n = len(cls_logits)
     return _DetectionLoss.apply(mode, num_classes, n, *cls_logits, *reg_preds, *cls_labels, *reg_labels,
                                 *trainable_masks)
+
+
+class _Dropout(torch.autograd.Function):
+    """tf.layers.Dropout on its own (DenseNet: after a conv).  Same counter-based mask both ways."""
+
+    @staticmethod
+    def forward(ctx, x, rate, seed, seed_dev):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _rn.check(_rn.lib().rn_dropout(_rn.f32(x), _rn.f32(y), x.numel(), rate, seed,
+                                       seed_dev.data_ptr() if seed_dev is not None else None, _rn.stream()), "rn_dropout")
+        ctx.cfg = (rate, seed, seed_dev)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rate, seed, seed_dev = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _rn.check(_rn.lib().rn_dropout(_rn.f32(dy), _rn.f32(dx), dy.numel(), rate, seed,
+                                       seed_dev.data_ptr() if seed_dev is not None else None, _rn.stream()), "rn_dropout")
+        return dx, None, None, None
+
+
+def dropout(x, rate, seed=0, seed_dev=None):
+    if rate == 0.0:
+        return x
+    return _Dropout.apply(x, float(rate), int(seed), seed_dev)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride):
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        oh, _ = _rn.same_pad(h, k, stride)
+        ow, _ = _rn.same_pad(w, k, stride)
+        y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
+        _rn.check(_rn.lib().rn_maxpool_fwd(_rn.f32(x), _rn.f32(y), n, h, w, c, k, stride, _rn.stream()), "rn_maxpool_fwd")
+        ctx.cfg = (k, stride)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        k, stride = ctx.cfg
+        n, h, w, c = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _rn.check(_rn.lib().rn_maxpool_bwd(_rn.f32(x), _rn.f32(dy), _rn.f32(dx), n, h, w, c, k, stride, _rn.stream()),
+                  "rn_maxpool_bwd")
+        return dx, None, None
+
+
+def max_pool(x, k=3, stride=2):
+    """tf.layers.MaxPooling2D(k, stride, padding='same')."""
+    return _MaxPool.apply(x, k, stride)
+
+
+class _AvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride):
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        oh, _ = _rn.same_pad(h, k, stride)
+        ow, _ = _rn.same_pad(w, k, stride)
+        y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
+        _rn.check(_rn.lib().rn_avgpool_fwd(_rn.f32(x), _rn.f32(y), n, h, w, c, k, stride, _rn.stream()), "rn_avgpool_fwd")
+        ctx.cfg = (k, stride, n, h, w, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        k, stride, n, h, w, c = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+        _rn.check(_rn.lib().rn_avgpool_bwd(_rn.f32(dy), _rn.f32(dx), n, h, w, c, k, stride, _rn.stream()), "rn_avgpool_bwd")
+        return dx, None, None
+
+
+def avg_pool(x, k=2, stride=2):
+    """tf.layers.AveragePooling2D(k, stride, padding='same')."""
+    return _AvgPool.apply(x, k, stride)

@@ -1,0 +1,136 @@
+"""ResNeXt-50 bottom-up network, CLI name 'resnet_50' (drop-in for reference resnet.py:15-215),
+GroupNorm variant, NHWC fp32 on gfx950 kernels.
+
+    net = ResNeXt_50(activation=layers.elu)     # `activation` is accepted and ignored exactly as in the
+    feats = net(image, training=True)           # reference: ReLU is hard-coded (resnet.py:85,93,101,157, Q4)
+
+Structure (resnet.py:162-215): 7x7/2 conv -> GN -> ReLU (C1); 3x3/2 max pool; four stages of
+bottlenecks (filters 64/128/256/512, depths 3/4/6/3), widths 256/512/1024/2048 (C2..C5).
+Bottleneck (resnet.py:29-103): 1x1 -> 2f, GN, ReLU; cardinality-32 3x3 (stride 2 on 'down');
+1x1 -> 4f, GN; + identity (1x1 projection, or a 3x3/2 conv on 'down', or the input); ReLU.
+
+MI355X-first restatement with identical results: the reference's 32 separate Conv2D + 32 separate
+GroupNorm on the channel splits (resnet.py:53-64,88-95) are ONE grouped-conv launch + ONE GroupNorm
+launch: a split has c = 2f/32 <= 32 channels, so its GroupNorm uses min(32, c) = c groups of one
+channel (normalization.py:24) -- per-channel statistics -- and the 32 per-split gamma/beta vectors
+concatenate into one [2f] vector.  The final `GN(conv_3) + identity -> ReLU` is one fused kernel.
+"""
+import layers as L
+from model import Model
+from normalization import Normalization
+
+CARDINALITY = 32
+
+
+class ResNeXt_Bottleneck(Model):
+    def __init__(self, filters, project, kernel_initializer, kernel_regularizer, cardinality=CARDINALITY,
+                 name='resnext_bottleneck', in_channels=None):
+        assert filters % cardinality == 0
+        assert project in [True, False, 'down']
+        super().__init__(name=name)
+        self._cfg = (filters, project, kernel_initializer, kernel_regularizer, cardinality)
+        self._built = False
+        if in_channels is not None:
+            self.build(in_channels)
+
+    def build(self, in_channels):
+        f, project, init, reg, card = self._cfg
+
+        def conv(cout, k, stride=1, cin=None, groups=1):
+            return L.Conv2D(cout, k, stride, padding='same', use_bias=False, kernel_initializer=init,
+                            kernel_regularizer=reg, in_channels=cin, groups=groups)
+
+        if project == 'down':
+            self._identity_conv, self._identity_bn = conv(f * 4, 3, 2, in_channels), Normalization(channels=f * 4)
+        elif project:
+            self._identity_conv, self._identity_bn = conv(f * 4, 1, 1, in_channels), Normalization(channels=f * 4)
+        else:
+            self._identity_conv = self._identity_bn = None
+        self._conv_1, self._bn_1 = conv(f * 2, 1, 1, in_channels), Normalization(channels=f * 2)
+        stride = 2 if project == 'down' else 1
+        # the 32 split convs as one grouped conv; per-split GroupNorm == per-channel groups (see module doc)
+        self._conv_2 = conv(f * 2, 3, stride, f * 2, groups=card)
+        self._bn_2 = L.GroupNormalization(groups=f * 2, channels=f * 2)
+        self._conv_3, self._bn_3 = conv(f * 4, 1, 1, f * 2), Normalization(channels=f * 4)
+        self._built = True
+
+    def call(self, input, training):
+        if not self._built:
+            self.build(input.shape[3])
+            self.to(input.device)
+        identity = input
+        if self._identity_conv is not None:
+            identity = self._identity_bn.fused(self._identity_conv(identity), training)
+        x = self._bn_1.fused(self._conv_1(input), training, act='relu')
+        x = self._bn_2.fused(self._conv_2(x), training, act='relu')
+        return self._bn_3.fused(self._conv_3(x), training, act='relu', residual=identity, act_after_residual=True)
+
+
+class ResNeXt_Block(Model):
+    def __init__(self, filters, depth, downsample, kernel_initializer, kernel_regularizer, name='resnext_block',
+                 in_channels=None):
+        super().__init__(name=name)
+        blocks = []
+        c = in_channels
+        for i in range(depth):
+            project = ('down' if downsample else True) if i == 0 else False
+            blocks.append(ResNeXt_Bottleneck(filters, project=project, kernel_initializer=kernel_initializer,
+                                             kernel_regularizer=kernel_regularizer, in_channels=c))
+            c = filters * 4 if c is not None else None
+        self._layers = blocks
+        import torch
+        self._mods = torch.nn.ModuleList(blocks)
+
+    def call(self, input, training):
+        for f in self._layers:
+            input = f(input, training=training)
+        return input
+
+
+class ResNeXt_ConvInput(Model):
+    def __init__(self, kernel_initializer, kernel_regularizer, name='resnext_conv1'):
+        super().__init__(name=name)
+        self._conv = L.Conv2D(64, 7, 2, padding='same', use_bias=False, kernel_initializer=kernel_initializer,
+                              kernel_regularizer=kernel_regularizer, in_channels=3)
+        self._bn = Normalization(channels=64)
+
+    def call(self, input, training):
+        return self._bn.fused(self._conv(input), training, act='relu')
+
+
+class ResNeXt(Model):
+    def __init__(self, kernel_initializer, kernel_regularizer, name='resnext'):
+        super().__init__(name=name)
+        self._kernel_initializer = kernel_initializer
+        self._kernel_regularizer = kernel_regularizer
+
+    def call(self, input, training):
+        out = {}
+        input = self._conv_1(input, training=training)
+        out['C1'] = input
+        input = self._conv_1_max_pool(input)
+        for i, stage in enumerate((self._conv_2, self._conv_3, self._conv_4, self._conv_5)):
+            input = stage(input, training=training)
+            out['C%d' % (i + 2)] = input
+        return out
+
+
+class ResNeXt_50(ResNeXt):
+    def __init__(self, activation, kernel_initializer=None, kernel_regularizer=None, name='resnext_v2_50'):
+        if kernel_initializer is None:
+            kernel_initializer = L.VarianceScaling(factor=2.0)
+        if kernel_regularizer is None:
+            kernel_regularizer = L.L2Regularizer(scale=1e-4)
+        super().__init__(kernel_initializer=kernel_initializer, kernel_regularizer=kernel_regularizer, name=name)
+        init, reg = kernel_initializer, kernel_regularizer
+        self._conv_1 = ResNeXt_ConvInput(kernel_initializer=init, kernel_regularizer=reg)
+        self._conv_1_max_pool = L.MaxPooling2D(3, 2, padding='same')
+        self._conv_2 = ResNeXt_Block(64, depth=3, downsample=False, kernel_initializer=init, kernel_regularizer=reg,
+                                     in_channels=64)
+        self._conv_3 = ResNeXt_Block(128, depth=4, downsample=True, kernel_initializer=init, kernel_regularizer=reg,
+                                     in_channels=256)
+        self._conv_4 = ResNeXt_Block(256, depth=6, downsample=True, kernel_initializer=init, kernel_regularizer=reg,
+                                     in_channels=512)
+        self._conv_5 = ResNeXt_Block(512, depth=3, downsample=True, kernel_initializer=init, kernel_regularizer=reg,
+                                     in_channels=1024)
+        self.out_channels = {'C3': 512, 'C4': 1024, 'C5': 2048}

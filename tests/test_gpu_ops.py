@@ -409,3 +409,80 @@ def test_optimizer_matches_tf_semantics(dev, kind):
         train_ref.apply_optimizer(kind, params, {"a": clipped[0], "b": clipped[1]}, state, 1e-2, step)
         assert_close(lin.a.detach().cpu().numpy(), params["a"].numpy(), TOL, "weights a step %d" % step)
         assert_close(lin.b.detach().cpu().numpy(), params["b"].numpy(), TOL, "weights b step %d" % step)
+
+
+@pytest.mark.parametrize("case", [(2, 9, 8, 128, 128, 3, 1, 32), (2, 9, 8, 256, 256, 3, 2, 32), (1, 7, 7, 1024, 1024, 3, 1, 32),
+                                  (2, 6, 6, 64, 128, 3, 1, 4)])
+def test_grouped_conv_fwd_bwd(dev, case):
+    """ResNeXt cardinality conv: one grouped launch == torch grouped conv (and see test_gpu_backbones for
+    the literal 32-split reference form)."""
+    import ops
+    import torch.nn.functional as F
+    n, h, w, cin, cout, k, stride, groups = case
+    rng = np.random.default_rng(cin + stride)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((k, k, cin // groups, cout)) / np.sqrt(k * k * cin / groups)).astype(np.float32)
+    xc, wc = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(wt).requires_grad_(True)
+    _, pt, pb = tf_ops_ref.same_pad_1d(h, k, stride)
+    _, pl, pr = tf_ops_ref.same_pad_1d(w, k, stride)
+    yc = F.conv2d(F.pad(xc.permute(0, 3, 1, 2), (pl, pr, pt, pb)), wc.permute(3, 2, 0, 1), stride=stride,
+                  groups=groups).permute(0, 2, 3, 1)
+    dy = rng.standard_normal(tuple(yc.shape)).astype(np.float32)
+    yc.backward(torch.from_numpy(dy))
+    xg, wg = _t(x, dev, True), _t(wt, dev, True)
+    yg = ops.conv2d(xg, wg, None, stride, groups)
+    yg.backward(_t(dy, dev))
+    assert_close(yg.detach().cpu().numpy(), yc.detach().numpy(), TOL, "grouped fwd")
+    assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), TOL, "grouped dgrad")
+    assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), TOL, "grouped wgrad")
+
+
+@pytest.mark.parametrize("c,groups", [(2048, 32), (256, 256), (1664, 32)])
+def test_group_norm_wide_and_per_channel(dev, c, groups):
+    """C > 1024 (ResNeXt 2048, DenseNet-169 1664) and per-channel groups (ResNeXt split norm), with the
+    ResNeXt tail y = relu(GN(x) + identity)."""
+    import ops
+    rng = np.random.default_rng(c)
+    shape = (2, 5, 6, c)
+    x = (rng.standard_normal(shape) * 1.5 + 0.3).astype(np.float32)
+    r = rng.standard_normal(shape).astype(np.float32)
+    gamma = (1 + 0.3 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(c)).astype(np.float32)
+    xc, rc = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(r).requires_grad_(True)
+    gc, bc = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
+    yc = torch.relu(tf_ops_ref.group_norm(xc, gc, bc, groups) + rc)
+    dy = rng.standard_normal(shape).astype(np.float32)
+    yc.backward(torch.from_numpy(dy))
+    xg, rg, gg, bg = _t(x, dev, True), _t(r, dev, True), _t(gamma, dev, True), _t(beta, dev, True)
+    yg = ops.group_norm_act(xg, gg, bg, groups, 1e-5, "relu", rg, act_after_residual=True)
+    yg.backward(_t(dy, dev))
+    assert_close(yg.detach().cpu().numpy(), yc.detach().numpy(), TOL, "gn fwd")
+    assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), TOL, "gn dx")
+    assert_close(rg.grad.cpu().numpy(), rc.grad.numpy(), TOL, "gn dres")
+    assert_close(gg.grad.cpu().numpy(), gc.grad.numpy(), TOL, "gn dgamma")
+    assert_close(bg.grad.cpu().numpy(), bc.grad.numpy(), TOL, "gn dbeta")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64), (1, 7, 9, 8), (2, 25, 25, 32)])
+def test_pools_and_dropout(dev, shape):
+    import ops
+    rng = np.random.default_rng(shape[1])
+    x = rng.standard_normal(shape).astype(np.float32)
+    for name, fn, ref, k, s in (("max", ops.max_pool, tf_ops_ref.max_pool_same, 3, 2),
+                                ("avg", ops.avg_pool, tf_ops_ref.avg_pool_same, 2, 2)):
+        xc = torch.from_numpy(x).requires_grad_(True)
+        yc = ref(xc, k, s)
+        dy = rng.standard_normal(tuple(yc.shape)).astype(np.float32)
+        yc.backward(torch.from_numpy(dy))
+        xg = _t(x, dev, True)
+        yg = fn(xg, k, s)
+        yg.backward(_t(dy, dev))
+        assert_close(yg.detach().cpu().numpy(), yc.detach().numpy(), 1e-6, name + " pool fwd")
+        assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), 1e-6, name + " pool bwd")
+    xg = _t(x, dev, True)
+    y = ops.dropout(xg, 0.3, seed=77)
+    keep = (y != 0)
+    assert abs(keep.float().mean().item() - 0.7) < 0.03
+    assert torch.allclose(y[keep], xg.detach()[keep] / 0.7, rtol=1e-6)
+    y.sum().backward()
+    assert torch.allclose(xg.grad, keep.float() / 0.7, rtol=1e-6)
