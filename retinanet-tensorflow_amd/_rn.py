@@ -185,8 +185,14 @@ _workspaces = {}
 WORKSPACE_MIN_BYTES = 256 << 20
 
 
+SIDE_STREAMS = set()   # raw handles of streams that run concurrently with the main one (retinanet.side_stream)
+
+
 def workspace(nbytes, device):
-    key = (device.type, device.index)
+    # one arena for the main stream (whichever stream that currently is: default, warm-up or graph-capture
+    # stream) and one per registered side stream: ops on a side stream run concurrently with the main one
+    h = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (device.type, device.index, h if h in SIDE_STREAMS else 0)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():

@@ -54,7 +54,9 @@ __device__ __forceinline__ void locate_wave(const DetArgs& a, int64_t wid, int* 
   *row0 = (int64_t)(w - a.lv[l].wave_off) * 64;
 }
 
-// ---- 1. scan: lane i of a wave ends up holding (max prob, arg-max) of row row0+i
+// ---- 1. scan: lane i of a wave ends up holding (max prob, arg-max) of row row0+i.
+// Four lanes share a row (float4 loads, 64-B contiguous per row and instruction), 16 rows per
+// pass, 2 shuffle steps to combine; first index wins ties (tf.argmax).  C % 4 == 0 fast path.
 __global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
@@ -66,20 +68,51 @@ __global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
   const int nrow = (int)((lv.rows - row0) < 64 ? (lv.rows - row0) : 64);
   const float* base = lv.prob + ((size_t)img * lv.rows + row0) * a.C;
   float my_s = 0.f; int my_c = 0;
-  for (int i = 0; i < nrow; ++i) {
-    const float* row = base + (size_t)i * a.C;
-    float best = -1e30f; int bi = 0x7fffffff;
-    for (int c = lane; c < a.C; c += 64) {
-      const float v = row[c];
-      if (v > best) { best = v; bi = c; }   // ascending c per lane: keeps the lowest index on ties
-    }
+  if ((a.C & 3) == 0) {
+    const int sub = lane & 3, rsel = lane >> 2;  // 4 lanes per row, 16 rows per pass
+    const int C4 = a.C >> 2;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ob = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = pass * 16 + rsel;
+      float best = -1e30f; int bi = 0x7fffffff;
+      if (r < nrow) {
+        const float4* row = reinterpret_cast<const float4*>(base + (size_t)r * a.C);
+        for (int c4 = sub; c4 < C4; c4 += 4) {
+          const float4 v = row[c4];
+          const int c = c4 * 4;
+          if (v.x > best) { best = v.x; bi = c; }
+          if (v.y > best) { best = v.y; bi = c + 1; }
+          if (v.z > best) { best = v.z; bi = c + 2; }
+          if (v.w > best) { best = v.w; bi = c + 3; }
+        }
+      }
+#pragma unroll
+      for (int o = 1; o <= 2; o <<= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      // row r's result sits in its 4 lanes; hand it to lane r
+      const float sv = __shfl(best, (lane & 15) * 4, 64);
+      const int sc = __shfl(bi, (lane & 15) * 4, 64);
+      if ((lane >> 4) == pass) { my_s = sv; my_c = sc; }
     }
-    if (lane == i) { my_s = best; my_c = bi; }
+  } else {
+    for (int i = 0; i < nrow; ++i) {
+      const float* row = base + (size_t)i * a.C;
+      float best = -1e30f; int bi = 0x7fffffff;
+      for (int c = lane; c < a.C; c += 64) {
+        const float v = row[c];
+        if (v > best) { best = v; bi = c; }   // ascending c per lane: keeps the lowest index on ties
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (lane == i) { my_s = best; my_c = bi; }
+    }
   }
   const bool flag = lane < nrow && my_s > a.score_thr;
   const int64_t g = (int64_t)img * a.rows_per_image + lv.row_off + row0 + lane;

@@ -16,6 +16,9 @@ differences that do not change results:
 """
 import math
 
+import torch
+
+import _rn
 import layers as L
 import mobilenet_v2
 import ops
@@ -23,6 +26,20 @@ from model import Model, Sequential
 from normalization import Normalization
 
 BACKBONES = ['resnet_50', 'densenet_121', 'densenet_169', 'mobilenet_v2']
+
+# The class and box subnets are independent given the pyramid: run them on two HIP streams so their
+# (small, launch- and occupancy-bound) kernels overlap -- forward here, and backward too because
+# autograd replays each node on its forward stream.  Captured into the step's hipGraph as two branches.
+HEADS_TWO_STREAMS = False
+_side_streams = {}
+
+
+def side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+        _rn.SIDE_STREAMS.add(_side_streams[key].cuda_stream)
+    return _side_streams[key]
 
 
 def build_backbone(backbone, activation, dropout_rate):
@@ -153,8 +170,18 @@ class RetinaNetBase(Model):
         top_down = self.fpn(bottom_up, training)
         keys = list(top_down.keys())
         maps = [top_down[k] for k in keys]
-        classifications = dict(zip(keys, self.classification_subnet(maps, training)))
-        regressions = dict(zip(keys, self.regression_subnet(maps, training)))
+        if HEADS_TWO_STREAMS and maps[0].is_cuda:
+            main, side = torch.cuda.current_stream(), side_stream(maps[0].device)
+            side.wait_stream(main)
+            cls_out = self.classification_subnet(maps, training)
+            with torch.cuda.stream(side):
+                reg_out = self.regression_subnet(maps, training)
+            main.wait_stream(side)
+        else:
+            cls_out = self.classification_subnet(maps, training)
+            reg_out = self.regression_subnet(maps, training)
+        classifications = dict(zip(keys, cls_out))
+        regressions = dict(zip(keys, reg_out))
         return {'classifications': classifications, 'regressions': regressions}
 
 

@@ -153,6 +153,11 @@ class Trainer(object):
         if not ops.DIRECT_PARAM_GRADS:
             self.arena.zero_grad()
         (class_loss + regr_loss).backward()
+        # the box subnet's backward ran on the side stream (retinanet.HEADS_TWO_STREAMS) and wrote its
+        # parameter gradients straight into the arena: join it before anything reads the arena
+        import retinanet
+        if retinanet.HEADS_TWO_STREAMS and self.device.type == 'cuda':
+            torch.cuda.current_stream().wait_stream(retinanet.side_stream(self.device))
         self.drop_counter += 0x9E3779B9            # fresh dropout masks next step (device-side counter)
         return class_loss.detach(), regr_loss.detach()
 
