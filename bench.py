@@ -34,6 +34,11 @@ BATCH = 2
 NUM_CLASSES = 80
 MAX_OBJ = 32
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
+# --pmc WRITE_SIZE runs of tools/conv_bench.py, profiles/r01_conv_pmc_fetch_write.csv):
+# FETCH_SIZE 15 207 KB x 2 (gfx950 reports 1/2 of wide 16-B/lane reads, MI355X_MICROARCH.md HBM section)
+# + WRITE_SIZE 10 912 KB.  Algorithmic bytes: 11.2 MB in + 2.4 MB weights + 11.2 MB out = 24.7 MB.
+DOMINANT_KERNEL_HBM_BYTES = (2 * 15207 + 10912) * 1024
 TRAIN_GFLOP_PER_IMAGE = 239.2       # BASELINE.md section 3 (3 x forward conv FLOPs), cfg 2
 
 
@@ -290,8 +295,8 @@ def main():
                        "conv_roofline_frac_whole_step": round(ips / world * TRAIN_GFLOP_PER_IMAGE / 1e3 /
                                                               FP32_MFMA_PEAK_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv_fwd_kernel<128,128,2,2,4> 3x3 256->256 over P3..P7 (head tower layer)",
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": DOMINANT_KERNEL_HBM_BYTES,
+                         "kernel": "conv_fwd_kernel<64,64,2,2,4,true> 3x3 256->256 over P3..P7 (head tower layer)",
                          "kernel_ms": round(kms, 4), "flops_per_launch": kflops},
         }
         if not args.no_nms:

@@ -594,7 +594,11 @@ int validate_geom(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
     RN_CHECK_ARG(segs[s].n >= 1 && segs[s].h >= 1 && segs[s].w >= 1 && segs[s].cout >= 1, "conv: bad segment %d", s);
     // the kernels address every tensor with 32-bit byte offsets below 2 GiB
     const double px = (double)segs[s].n * segs[s].h * segs[s].w * 4.0;
-    RN_UNSUPPORTED(px * g->cin >= 2147483648.0 || px * segs[s].cout >= 2147483648.0 ||
+    int oh_, ow_, pt_, pl_;
+    rn::same_pad(segs[s].h, g->kh, g->stride, &oh_, &pt_);
+    rn::same_pad(segs[s].w, g->kw, g->stride, &ow_, &pl_);
+    const double opx = (double)segs[s].n * oh_ * ow_ * 4.0;
+    RN_UNSUPPORTED(px * g->cin >= 2147483648.0 || opx * segs[s].cout >= 2147483648.0 ||
                    (double)g->kh * g->kw * g->cin * segs[s].cout * 4.0 >= 2147483648.0,
                    "conv: a tensor of segment %d is >= 2 GiB", s);
     RN_UNSUPPORTED(segs[s].h >= 32768 || segs[s].w >= 32768, "conv: spatial size of segment %d too large", s);
