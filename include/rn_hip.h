@@ -65,13 +65,17 @@ typedef struct rn_conv_seg {
   float* dx;         /* dgrad: grad of input [n,h,w,cin]                    */
   int32_t n, h, w;   /* input batch / height / width                        */
   int32_t cout;      /* may differ per segment in fwd/dgrad                 */
+  int32_t x_ld;      /* 0: x (and dx) are dense [n,h,w,cin].  > 0: x / dx are the channel slice
+                        [x_coff, x_coff+cin) of a buffer with x_ld channels per pixel (x, dx point at the
+                        buffer's first element): lets two convs consume / fill halves of one tensor      */
+  int32_t x_coff;
 } rn_conv_seg;
 
 typedef struct rn_conv_geom {
   int32_t kh, kw, stride, cin;
   int32_t groups; /* 0 or 1 = dense.  G > 1: grouped conv (ResNeXt cardinality, resnet.py:53-59): kernel
                      [kh,kw,cin/G,cout], output channels [g*cout/G,(g+1)*cout/G) read input channels
-                     [g*cin/G,(g+1)*cin/G); at most 128 channels per group */
+                     [g*cin/G,(g+1)*cin/G) */
 } rn_conv_geom;
 
 int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream);

@@ -28,7 +28,8 @@ class RnError(RuntimeError):
 class ConvSeg(C.Structure):
     _fields_ = [("x", C.c_void_p), ("wgt", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
                 ("dy", C.c_void_p), ("dx", C.c_void_p),
-                ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cout", C.c_int32)]
+                ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cout", C.c_int32),
+                ("x_ld", C.c_int32), ("x_coff", C.c_int32)]
 
 
 class ConvGeom(C.Structure):

@@ -37,13 +37,15 @@ struct SegDev {
   int tiles_n;        // fwd/dgrad: tiles along N
   int start;          // fwd/dgrad: first tile id; wgrad: first split id
   int chunk;          // wgrad: reduction rows per split (multiple of BK)
+  int x_ld, x_coff;   // pixel stride / first channel of the x (dx) tensor: a channel slice of a wider buffer
 };
 
 struct ConvArgs {
   SegDev seg[RN_MAX_SEG];
   int nseg;
   int kh, kw, stride, cin;
-  int groups, cin_g;  // grouped conv: cin_g = cin/groups input channels per group; one N-tile per group
+  int groups, cin_g;  // grouped conv: cin_g = cin/groups input channels per group
+  int tpg;            // N-tiles per group
   int ktotal;    // fwd: kh*kw*cin   dgrad: kh*kw*cout(seg)  (recomputed per seg)   wgrad: kh*kw*cin
   int tiles_mn;  // wgrad: output tiles per split
   int tiles_n;   // wgrad
@@ -191,14 +193,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
   const int local = bid - sg.start;
   const int tile_n = local % sg.tiles_n, tile_m = local / sg.tiles_n;
   const int H = sg.h, W = sg.w, OW = sg.ow, OHW = sg.oh * sg.ow, M = sg.m, cout = sg.cout;
-  const int ldx = args.cin, kw = args.kw, stride = args.stride;
-  // grouped conv (ResNeXt, resnet.py:53-59): N-tile `tile_n` is group g: its cout/G output channels,
-  // fed by input channels [g*cin_g, (g+1)*cin_g); kernel tensor is [kh,kw,cin_g,cout].
+  const int ldx = sg.x_ld, kw = args.kw, stride = args.stride;
+  // grouped conv (ResNeXt, resnet.py:53-59): group g owns cout/G output channels, fed by input channels
+  // [g*cin_g, (g+1)*cin_g); kernel tensor is [kh,kw,cin_g,cout]; `tpg` N-tiles per group.
   const int G = args.groups, cin = args.cin_g;
   const int cout_g = cout / G;
-  const int m0 = tile_m * BM, n0 = G > 1 ? tile_n * cout_g : tile_n * BN;
-  const int nmax = G > 1 ? n0 + cout_g : cout;
-  const int a_coff = G > 1 ? tile_n * cin : 0;
+  const int grp = tile_n / args.tpg, tn = tile_n - grp * args.tpg;
+  const int m0 = tile_m * BM, n0 = grp * cout_g + tn * BN;
+  const int nmax = (grp + 1) * cout_g;
+  const int a_coff = sg.x_coff + grp * cin;
   const int ktotal = args.kh * args.kw * cin;
   const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a, (unsigned)sg.n * H * W * ldx * 4u);
   const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.b, (unsigned)ktotal * cout * 4u);
@@ -299,11 +302,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
   const int W = sg.w, OH = sg.oh, OW = sg.ow, HW = sg.h * sg.w, M = sg.m;
   const int kw = args.kw, stride = args.stride;
   // grouped: N-tile `tile_n` is group g; K runs over (tap, co within the group)
-  const int G = args.groups, cin = args.cin_g, ldy = sg.cout, ldx = args.cin;
+  const int G = args.groups, cin = args.cin_g, ldy = sg.cout, ldx = sg.x_ld;
   const int cout = ldy / G;                                  // output channels per group = K per tap
-  const int m0 = tile_m * BM, n0 = G > 1 ? 0 : tile_n * BN;  // n0: first ci (within the group) of the tile
-  const int y_coff = G > 1 ? tile_n * cout : 0;              // channel offset into dy and into w's cout axis
-  const int x_coff = G > 1 ? tile_n * cin : 0;               // channel offset into dx
+  const int grp = tile_n / args.tpg, tn = tile_n - grp * args.tpg;
+  const int m0 = tile_m * BM, n0 = tn * BN;                  // n0: first ci (within the group) of the tile
+  const int y_coff = grp * cout;                             // channel offset into dy and into w's cout axis
+  const int x_coff = sg.x_coff + grp * cin;                  // channel offset into dx
   const int ktotal = args.kh * args.kw * cout;
   const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.a, (unsigned)sg.n * OH * OW * ldy * 4u);
   const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.b, (unsigned)args.kh * args.kw * cin * ldy * 4u);
@@ -417,11 +421,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
   const int p0 = (split - sg.start) * sg.chunk;
   const int p1 = min(p0 + sg.chunk, sg.m);
   const int H = sg.h, W = sg.w, OW = sg.ow, OHW = sg.oh * sg.ow;
-  const int ldx = args.cin, cout = args.cout, kw = args.kw, stride = args.stride;
+  const int ldx = sg.x_ld, cout = args.cout, kw = args.kw, stride = args.stride;
   const int G = args.groups, cin = args.cin_g, cout_g = cout / G;
-  const int m0 = tile_m * BM, n0 = G > 1 ? tile_n * cout_g : tile_n * BN;
-  const int nmax = G > 1 ? n0 + cout_g : cout;
-  const int x_coff = G > 1 ? tile_n * cin : 0;
+  const int grp = tile_n / args.tpg, tn = tile_n - grp * args.tpg;
+  const int m0 = tile_m * BM, n0 = grp * cout_g + tn * BN;
+  const int nmax = (grp + 1) * cout_g;
+  const int x_coff = sg.x_coff + grp * cin;
   const int ktotal = args.ktotal;
   const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a, (unsigned)sg.n * H * W * ldx * 4u);
   const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.b, (unsigned)sg.m * cout * 4u);
@@ -573,8 +578,12 @@ int choose_cfg(F dims, int nseg) {
   return best;
 }
 
-// grouped conv: one N-tile per group => the tile must be at least as wide as a group
+// grouped conv with narrow groups: one N-tile per group, as narrow as possible
 int cfg_for_group_width(int width) { return width <= 32 ? 3 : (width <= 64 ? 2 : 0); }
+inline void set_x_view(SegDev& d, const rn_conv_seg& s, int cin) {
+  d.x_ld = s.x_ld > 0 ? s.x_ld : cin;
+  d.x_coff = s.x_ld > 0 ? s.x_coff : 0;
+}
 inline int ngroups(const rn_conv_geom* g) { return g->groups > 1 ? g->groups : 1; }
 
 int validate_geom(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
@@ -586,10 +595,12 @@ int validate_geom(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
   if (g->groups > 1) {
     for (int s = 0; s < nseg; ++s) {
       RN_CHECK_ARG(segs[s].cout % g->groups == 0, "conv: cout %d not divisible by groups %d", segs[s].cout, g->groups);
-      RN_UNSUPPORTED(segs[s].cout / g->groups > 128 || g->cin / g->groups > 128,
-                     "conv: grouped conv supports at most 128 channels per group");
     }
   }
+  for (int s = 0; s < nseg; ++s)
+    RN_CHECK_ARG(segs[s].x_ld == 0 || (segs[s].x_ld >= segs[s].x_coff + g->cin && segs[s].x_coff >= 0 &&
+                                       segs[s].x_ld % 4 == 0 && segs[s].x_coff % 4 == 0),
+                 "conv: bad x_ld/x_coff in segment %d", s);
   for (int s = 0; s < nseg; ++s) {
     RN_CHECK_ARG(segs[s].n >= 1 && segs[s].h >= 1 && segs[s].w >= 1 && segs[s].cout >= 1, "conv: bad segment %d", s);
     // the kernels address every tensor with 32-bit byte offsets below 2 GiB
@@ -632,14 +643,18 @@ extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
     rn::same_pad(d.h, g->kh, g->stride, &d.oh, &d.pad_t);
     rn::same_pad(d.w, g->kw, g->stride, &d.ow, &d.pad_l);
     d.m = d.n * d.oh * d.ow;
+    set_x_view(d, segs[s], g->cin);
     vec = vec && ((d.cout / G) % 4 == 0);
   }
-  const int c = G > 1 ? cfg_for_group_width(a.seg[0].cout / G)
-                      : choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m; *n = a.seg[s].cout; }, nseg);
+  const int c = (G > 1 && a.seg[0].cout / G <= 64)
+                    ? cfg_for_group_width(a.seg[0].cout / G)
+                    : choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m * G; *n = a.seg[s].cout / G; }, nseg);
+  a.tpg = G > 1 ? rn::ceil_div(a.seg[0].cout / G, kCfgs[c].bn) : (1 << 20);  // dense: every N-tile is "group 0"
   int tiles = 0;
   for (int s = 0; s < nseg; ++s) {
     SegDev& d = a.seg[s];
-    d.tiles_n = G > 1 ? G : rn::ceil_div(d.cout, kCfgs[c].bn);
+    RN_UNSUPPORTED(G > 1 && d.cout != a.seg[0].cout, "conv: grouped segments must share cout");
+    d.tiles_n = G > 1 ? G * a.tpg : rn::ceil_div(d.cout, kCfgs[c].bn);
     d.start = tiles;
     tiles += rn::ceil_div(d.m, kCfgs[c].bm) * d.tiles_n;
   }
@@ -678,14 +693,16 @@ extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
     rn::same_pad(d.h, g->kh, g->stride, &d.oh, &d.pad_t);
     rn::same_pad(d.w, g->kw, g->stride, &d.ow, &d.pad_l);
     d.m = d.n * d.h * d.w;
+    set_x_view(d, segs[s], g->cin);
   }
-  const int cin = g->cin;
-  const int c = G > 1 ? cfg_for_group_width(a.cin_g)
-                      : choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m; *n = cin; }, nseg);
+  const int cin_g = a.cin_g;
+  const int c = (G > 1 && cin_g <= 64) ? cfg_for_group_width(cin_g)
+                                        : choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m * G; *n = cin_g; }, nseg);
+  a.tpg = rn::ceil_div(cin_g, kCfgs[c].bn);
   int tiles = 0;
   for (int s = 0; s < nseg; ++s) {
     SegDev& d = a.seg[s];
-    d.tiles_n = G > 1 ? G : rn::ceil_div(cin, kCfgs[c].bn);
+    d.tiles_n = G * a.tpg;
     d.start = tiles;
     tiles += rn::ceil_div(d.m, kCfgs[c].bm) * d.tiles_n;
   }
@@ -711,7 +728,7 @@ extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
 
 namespace {
 struct WgradPlan {
-  int cfg, tiles_m, tiles_n, nsplit, ktotal, cout;
+  int cfg, tiles_m, tiles_n, tpg, nsplit, ktotal, cout;
   int chunk[RN_MAX_SEG], start[RN_MAX_SEG], pixels[RN_MAX_SEG], oh[RN_MAX_SEG], ow[RN_MAX_SEG], pt[RN_MAX_SEG],
       pl[RN_MAX_SEG];
 };
@@ -735,7 +752,7 @@ int plan_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, WgradPl
   {
     double best = 1e300;
     for (int c = 0; c < kNumCfg; ++c) {
-      double w = (double)rn::ceil_div((int)kt, kCfgs[c].bm) * kCfgs[c].bm * rn::ceil_div((int)co, kCfgs[c].bn) *
+      double w = (double)rn::ceil_div((int)kt, kCfgs[c].bm) * kCfgs[c].bm * rn::ceil_div((int)co / G, kCfgs[c].bn) *
                  kCfgs[c].bn * kCfgs[c].penalty;
       if (w < best) { best = w; p->cfg = c; }
     }
@@ -743,10 +760,11 @@ int plan_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, WgradPl
       const int c = atoi(force);
       if (c >= 0 && c < kNumCfg) p->cfg = c;
     }
-    if (G > 1) p->cfg = cfg_for_group_width(p->cout / G);
+    if (G > 1 && p->cout / G <= 64) p->cfg = cfg_for_group_width(p->cout / G);
   }
   p->tiles_m = rn::ceil_div(p->ktotal, kCfgs[p->cfg].bm);
-  p->tiles_n = G > 1 ? G : rn::ceil_div(p->cout, kCfgs[p->cfg].bn);
+  p->tpg = rn::ceil_div(p->cout / G, kCfgs[p->cfg].bn);
+  p->tiles_n = G * p->tpg;
   const int tiles_mn = p->tiles_m * p->tiles_n;
   // aim for ~768 blocks (3 per CU): enough to fill the chip, few enough that the slab traffic
   // (nsplit x |dW| written + read) stays small; each split reduces >= 64 pixels
@@ -786,7 +804,7 @@ extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
   }
   ConvArgs a = {};
   a.nseg = nseg; a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.cin = g->cin;
-  a.groups = ngroups(g); a.cin_g = g->cin / a.groups;
+  a.groups = ngroups(g); a.cin_g = g->cin / a.groups; a.tpg = p.tpg;
   a.ktotal = p.ktotal; a.cout = p.cout; a.tiles_n = p.tiles_n; a.tiles_mn = p.tiles_m * p.tiles_n;
   a.slab = (float*)workspace;
   for (int s = 0; s < nseg; ++s) {
@@ -795,6 +813,7 @@ extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
     d.a = segs[s].x; d.b = segs[s].dy; d.n = segs[s].n; d.h = segs[s].h; d.w = segs[s].w; d.cout = p.cout;
     d.oh = p.oh[s]; d.ow = p.ow[s]; d.pad_t = p.pt[s]; d.pad_l = p.pl[s];
     d.m = p.pixels[s]; d.start = p.start[s]; d.chunk = p.chunk[s];
+    set_x_view(d, segs[s], g->cin);
   }
   const bool vec = (a.cin_g % 4 == 0) && ((p.cout / a.groups) % 4 == 0);
   const int blocks = p.nsplit * a.tiles_mn;

@@ -33,11 +33,12 @@ def _grad_slot(p):
     return g, g
 
 
-def _conv_segs(xs, w, bias, ys, dys, dxs):
+def _conv_segs(xs, w, bias, ys, dys, dxs, x_ld=0, x_coff=0):
     cout = w.shape[3]
     segs = (_rn.ConvSeg * len(xs))()
     for i, x in enumerate(xs):
         s = segs[i]
+        s.x_ld, s.x_coff = x_ld, x_coff
         s.x = _rn.f32(x) if x is not None else None
         s.wgt = _rn.f32(w)
         s.bias = _rn.f32(bias) if bias is not None else None
@@ -116,6 +117,77 @@ class _Conv2dShared(torch.autograd.Function):
             _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws.data_ptr(), ws.numel(),
                                             _rn.stream()), "rn_conv2d_bias_grad")
         return (None, dw, db) + tuple(dxs)
+
+
+class _Conv2dChannelSplit(torch.autograd.Function):
+    """k convs (own kernel + bias each) that read consecutive channel slices of the SAME input tensors:
+    slice j = channels [off_j, off_j + cin_j).  No slice copies: the kernels take the pixel stride and
+    channel offset (rn_conv_seg.x_ld / x_coff); in backward each conv's dgrad fills its slice of one
+    shared dx buffer.  Used for the class / box output convs on the fused 512-channel head towers."""
+
+    @staticmethod
+    def forward(ctx, stride, k, *args):
+        ws, bs, xs = list(args[:k]), list(args[k:2 * k]), [x.contiguous() for x in args[2 * k:]]
+        L = _rn.lib()
+        ld = xs[0].shape[3]
+        outs, off, offs = [], 0, []
+        for w, b in zip(ws, bs):
+            kh, kw, cin, cout = w.shape
+            geom = _rn.ConvGeom(kh, kw, stride, cin, 1)
+            ys = []
+            for x in xs:
+                oh, _ = _rn.same_pad(x.shape[1], kh, stride)
+                ow, _ = _rn.same_pad(x.shape[2], kw, stride)
+                ys.append(torch.empty((x.shape[0], oh, ow, cout), dtype=torch.float32, device=x.device))
+            segs = _conv_segs(xs, w, b, ys, None, None, ld, off)
+            _rn.check(L.rn_conv2d_fwd(segs, len(xs), C.byref(geom), _rn.stream()), "rn_conv2d_fwd")
+            outs += ys
+            offs.append(off)
+            off += cin
+        assert off == ld, "channel slices must cover the input exactly"
+        ctx.cfg = (stride, k, offs, bs)
+        ctx.save_for_backward(*ws, *xs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        stride, k, offs, bs = ctx.cfg
+        saved = ctx.saved_tensors
+        ws, xs = list(saved[:k]), list(saved[k:])
+        n = len(xs)
+        ld = xs[0].shape[3]
+        L = _rn.lib()
+        dev = xs[0].device
+        dxs = [torch.empty_like(x) for x in xs]
+        dws, dbs = [], []
+        for j, w in enumerate(ws):
+            kh, kw, cin, cout = w.shape
+            geom = _rn.ConvGeom(kh, kw, stride, cin, 1)
+            dyj = [dy.contiguous() for dy in dys[j * n:(j + 1) * n]]
+            segs = _conv_segs(xs, w, None, None, dyj, dxs, ld, offs[j])
+            _rn.check(L.rn_conv2d_dgrad(segs, n, C.byref(geom), _rn.stream()), "rn_conv2d_dgrad")
+            need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
+            ws_buf = _rn.workspace(need, dev)
+            dw_buf, dw = _grad_slot(w)
+            _rn.check(L.rn_conv2d_wgrad(segs, n, C.byref(geom), _rn.f32(dw_buf), 0, ws_buf.data_ptr(), ws_buf.numel(),
+                                        _rn.stream()), "rn_conv2d_wgrad")
+            dws.append(dw)
+            db = None
+            if bs[j] is not None:
+                need = L.rn_conv2d_bias_grad_workspace(cout)
+                ws_buf = _rn.workspace(need, dev)
+                db_buf, db = _grad_slot(bs[j])
+                _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws_buf.data_ptr(),
+                                                ws_buf.numel(), _rn.stream()), "rn_conv2d_bias_grad")
+            dbs.append(db)
+        return (None, None) + tuple(dws) + tuple(dbs) + tuple(dxs)
+
+
+def conv2d_channel_split(xs, weights, biases, stride=1):
+    """[conv_j(x[..., off_j:off_j+cin_j]) for j] for every x in xs -> list (per conv) of lists (per x)."""
+    k, n = len(weights), len(xs)
+    out = _Conv2dChannelSplit.apply(stride, k, *weights, *biases, *xs)
+    return [list(out[j * n:(j + 1) * n]) for j in range(k)]
 
 
 def conv2d(x, w, bias=None, stride=1, groups=1):

@@ -27,6 +27,13 @@ from normalization import Normalization
 
 BACKBONES = ['resnet_50', 'densenet_121', 'densenet_169', 'mobilenet_v2']
 
+# The class and box towers have identical shapes (4 x [conv3x3 256->256, GN, act]): run them as ONE
+# tower on 512 channels -- layer 1 a dense 256->512 conv (kernels concatenated along cout), layers 2-4
+# grouped convs with 2 groups, GroupNorm with 64 groups of 8 channels (= 32 + 32) -- so every head
+# launch carries twice the tiles (the per-level maps are small: 2.7 tiles per CU for one tower) and the
+# number of launches halves.  Results are identical to running the subnets one after the other.
+FUSE_HEAD_TOWERS = False   # measured: 163 vs 166 img/s (the fused wgrad is slower), kept as an option
+
 # The class and box subnets are independent given the pyramid: run them on two HIP streams so their
 # (small, launch- and occupancy-bound) kernels overlap -- forward here, and backward too because
 # autograd replays each node on its forward stream.  Captured into the step's hipGraph as two branches.
@@ -170,7 +177,9 @@ class RetinaNetBase(Model):
         top_down = self.fpn(bottom_up, training)
         keys = list(top_down.keys())
         maps = [top_down[k] for k in keys]
-        if HEADS_TWO_STREAMS and maps[0].is_cuda:
+        if FUSE_HEAD_TOWERS and maps[0].is_cuda:
+            cls_out, reg_out = self._fused_heads(maps, training)
+        elif HEADS_TWO_STREAMS and maps[0].is_cuda:
             main, side = torch.cuda.current_stream(), side_stream(maps[0].device)
             side.wait_stream(main)
             cls_out = self.classification_subnet(maps, training)
@@ -183,6 +192,24 @@ class RetinaNetBase(Model):
         classifications = dict(zip(keys, cls_out))
         regressions = dict(zip(keys, reg_out))
         return {'classifications': classifications, 'regressions': regressions}
+
+
+    def _fused_heads(self, maps, training):
+        """Both subnets as one 512-channel tower (see FUSE_HEAD_TOWERS); parameters stay the subnets' own
+        tensors and are concatenated on the fly (a few MB of copies per step)."""
+        cs, rs = self.classification_subnet, self.regression_subnet
+        x = maps
+        for i in range(4):
+            bc, br = cs.pre_conv.layers[i].layers, rs.pre_conv.layers[i].layers      # [conv, norm, act]
+            w = torch.cat([bc[0].weight, br[0].weight], 3)
+            x = ops.conv2d(x, w, None, 1, groups=1 if i == 0 else 2)
+            gamma = torch.cat([bc[1].gamma, br[1].gamma])
+            beta = torch.cat([bc[1].beta, br[1].beta])
+            x = ops.group_norm_act(x, gamma, beta, groups=2 * ops.gn_groups(256, bc[1].groups), eps=bc[1].eps,
+                                   act=L.activation_name(bc[2]))
+        outs = ops.conv2d_channel_split(x, [cs.out_conv.weight, rs.out_conv.weight],
+                                        [cs.out_conv.bias, rs.out_conv.bias], 1)
+        return [cs._reshape(t) for t in outs[0]], [rs._reshape(t) for t in outs[1]]
 
 
 class RetinaNet(Model):

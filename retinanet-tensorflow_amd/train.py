@@ -150,8 +150,9 @@ class Trainer(object):
         inp, logits = utils.process_labels_and_logits(labels=features, logits=logits, levels=self.levels)
         class_loss, regr_loss = losses.loss(labels=inp['detection_trainable'], logits=logits['detection_trainable'],
                                             mode=self.loss_mode)
-        if not ops.DIRECT_PARAM_GRADS:
-            self.arena.zero_grad()
+        # kernels that write a parameter's gradient directly overwrite it; gradients that reach a parameter
+        # through autograd (e.g. the concatenated head kernels) are accumulated -> the arena starts at zero
+        self.arena.zero_grad()
         (class_loss + regr_loss).backward()
         # the box subnet's backward ran on the side stream (retinanet.HEADS_TWO_STREAMS) and wrote its
         # parameter gradients straight into the arena: join it before anything reads the arena

@@ -127,6 +127,22 @@ def test_train_steps_match_oracle(dev, use_graph):
     print("worst weight error after 3 steps", worst)
 
 
+def test_fused_head_towers_equal_separate_subnets(dev):
+    """retinanet.FUSE_HEAD_TOWERS (one 512-channel tower for both subnets) gives the same outputs."""
+    import retinanet
+    net, params, image, labels = _tiny_problem(dev, seed=7)
+    with torch.no_grad():
+        a = net(image.to(dev), training=False)
+        retinanet.FUSE_HEAD_TOWERS = True
+        try:
+            b = net(image.to(dev), training=False)
+        finally:
+            retinanet.FUSE_HEAD_TOWERS = False
+    for k in LEVELS:
+        assert_close(b["classifications"][k].cpu().numpy(), a["classifications"][k].cpu().numpy(), 1e-5, "cls " + k)
+        assert_close(b["regressions"][k].cpu().numpy(), a["regressions"][k].cpu().numpy(), 1e-5, "reg " + k)
+
+
 def test_gradient_average_equals_bigger_batch(dev):
     """MirroredStrategy semantics: mean of two replicas' gradients == what the
     GradientAllReduce + grad_scale path applies; checked single-process by accumulation."""

@@ -486,3 +486,41 @@ def test_pools_and_dropout(dev, shape):
     assert torch.allclose(y[keep], xg.detach()[keep] / 0.7, rtol=1e-6)
     y.sum().backward()
     assert torch.allclose(xg.grad, keep.float() / 0.7, rtol=1e-6)
+
+
+def test_two_group_wide_conv_and_channel_split(dev):
+    """Fused head towers: G=2 grouped conv with 256-wide groups (several N-tiles per group) and the
+    output convs reading channel slices of one tensor == the separate convs."""
+    import ops
+    rng = np.random.default_rng(21)
+    sizes = [(8, 8), (4, 4), (2, 2)]
+    xs = [rng.standard_normal((2, h, w, 512)).astype(np.float32) for h, w in sizes]
+    wa = (rng.standard_normal((3, 3, 256, 256)) / 48).astype(np.float32)
+    wb = (rng.standard_normal((3, 3, 256, 256)) / 48).astype(np.float32)
+    woa = (rng.standard_normal((3, 3, 256, 45)) / 48).astype(np.float32)
+    wob = (rng.standard_normal((3, 3, 256, 36)) / 48).astype(np.float32)
+    boa, bob = rng.standard_normal(45).astype(np.float32), rng.standard_normal(36).astype(np.float32)
+    # oracle: separate dense convs on the two halves
+    leaves = [torch.from_numpy(a).requires_grad_(True) for a in (wa, wb, woa, wob, boa, bob)]
+    xcs = [torch.from_numpy(x).requires_grad_(True) for x in xs]
+    outs_c = []
+    for x in xcs:
+        ya = tf_ops_ref.conv2d_same(x[..., :256], leaves[0], 1)
+        yb = tf_ops_ref.conv2d_same(x[..., 256:], leaves[1], 1)
+        t = torch.cat([ya, yb], -1)
+        outs_c += [tf_ops_ref.conv2d_same(t[..., :256], leaves[2], 1, leaves[4]),
+                   tf_ops_ref.conv2d_same(t[..., 256:], leaves[3], 1, leaves[5])]
+    dys = [rng.standard_normal(tuple(o.shape)).astype(np.float32) for o in outs_c]
+    torch.autograd.backward(outs_c, [torch.from_numpy(d) for d in dys])
+    g = [_t(a, dev, True) for a in (wa, wb, woa, wob, boa, bob)]
+    xgs = [_t(x, dev, True) for x in xs]
+    t = ops.conv2d(xgs, torch.cat([g[0], g[1]], 3), None, 1, groups=2)
+    oa, ob = ops.conv2d_channel_split(t, [g[2], g[3]], [g[4], g[5]], 1)
+    outs_g = [o for pair in zip(oa, ob) for o in pair]
+    torch.autograd.backward(outs_g, [_t(d, dev) for d in dys])
+    for a, b in zip(outs_g, outs_c):
+        assert_close(a.detach().cpu().numpy(), b.detach().numpy(), TOL, "fused heads fwd")
+    for a, b in zip(xgs, xcs):
+        assert_close(a.grad.cpu().numpy(), b.grad.numpy(), TOL, "fused heads dx")
+    for a, b, name in zip(g, leaves, ("wa", "wb", "woa", "wob", "boa", "bob")):
+        assert_close(a.grad.cpu().numpy(), b.grad.numpy(), TOL, "fused heads d" + name)
