@@ -108,7 +108,7 @@ class Step(object):
                         self.local()
                 torch.cuda.current_stream().wait_stream(s)
                 self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):  # RCCL watchdog threads may poll events meanwhile
                     self.out = self.local()
             self.graph.replay()
         else:

@@ -175,7 +175,7 @@ class Trainer(object):
                     self.forward_backward(self._static)
             torch.cuda.current_stream().wait_stream(s)
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
                 self._graph_out = self.forward_backward(self._static)
         else:
             _copy_tree(self._static, features)

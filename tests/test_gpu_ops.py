@@ -524,3 +524,74 @@ def test_two_group_wide_conv_and_channel_split(dev):
         assert_close(a.grad.cpu().numpy(), b.grad.numpy(), TOL, "fused heads dx")
     for a, b, name in zip(g, leaves, ("wa", "wb", "woa", "wob", "boa", "bob")):
         assert_close(a.grad.cpu().numpy(), b.grad.numpy(), TOL, "fused heads d" + name)
+
+
+# ---------------------------------------------------------------------------------- edge cases
+def test_detect_empty_and_overflow(dev):
+    import utils, _rn
+    rng = np.random.default_rng(0)
+    probs = {"P3": rng.uniform(0, 0.49, (2, 4, 4, 9, 7)).astype(np.float32)}
+    boxes = {"P3": rng.uniform(0, 1, (2, 4, 4, 9, 4)).astype(np.float32)}
+    out = utils.detect({k: _t(v, dev) for k, v in probs.items()}, {k: _t(v, dev) for k, v in boxes.items()}, 7)
+    assert len(out) == 2 and all(o.boxes.shape == (0, 4) and o.scores.numel() == 0 for o in out)
+    dec = utils.boxes_decode(_t(probs["P3"][0], dev), _t(boxes["P3"][0], dev))
+    assert dec.boxes.shape == (0, 4) and utils.nms_classwise(dec, 7).boxes.shape[0] == 0
+    probs["P3"][:] = 0.9                                          # every anchor is a candidate
+    with pytest.raises(_rn.RnError):
+        utils.detect({k: _t(v, dev) for k, v in probs.items()}, {k: _t(v, dev) for k, v in boxes.items()}, 7, capacity=10)
+
+
+def test_loss_without_foreground(dev):
+    """No anchor above 0.5 IoU: regr loss is 0 (SUM_BY_NONZERO_WEIGHTS, Q7), focal divides by max(#fg,1)."""
+    import ops
+    rng = np.random.default_rng(1)
+    rows, c = 300, 6
+    z = (rng.standard_normal((rows, c)) - 2).astype(np.float32)
+    lab = np.zeros((rows, c), np.float32)
+    rp, rl = rng.standard_normal((rows, 4)).astype(np.float32), rng.standard_normal((rows, 4)).astype(np.float32)
+    m = rng.uniform(size=rows) < 0.7
+    for mode in ("bce_dice", "focal"):
+        zc = torch.from_numpy(z).requires_grad_(True)
+        cl, rlc = losses_ref.loss(torch.from_numpy(lab)[m], torch.from_numpy(rl)[m], zc[m], torch.from_numpy(rp)[m], mode)
+        cl.backward()
+        zg, rg = _t(z, dev, True), _t(rp, dev, True)
+        clg, rlg, _ = ops.detection_loss([zg], [rg], [_t(lab, dev)], [_t(rl, dev)], [_t(m.astype(np.uint8), dev)], c, mode)
+        (clg + rlg).backward()
+        assert rlg.item() == 0.0 and rlc.item() == 0.0
+        assert_close(clg.item(), cl.item(), TOL, "class loss, no fg, " + mode)
+        assert_close(zg.grad.cpu().numpy(), zc.grad.numpy(), TOL, "d logits, no fg")
+        assert float(rg.grad.abs().max()) == 0.0
+
+
+def test_assignment_single_object_and_padding(dev):
+    """One valid object per image; the padded slots of the [N, max_obj] arrays must be ignored."""
+    import dataset, levels
+    lv = levels.build_levels()
+    boxes = np.zeros((2, 8, 4), np.float32); cids = np.full((2, 8), 5, np.int32)
+    boxes[0, 0] = [0.2, 0.2, 0.7, 0.8]; cids[0, 0] = 3
+    boxes[1, 0] = [0.0, 0.0, 1.0, 1.0]; cids[1, 0] = 1
+    boxes[:, 1:] = [0.4, 0.4, 0.6, 0.6]                           # garbage in the padding: must not be assigned
+    nobj = np.array([1, 1], np.int32)
+    for pn in ("P3", "P5", "P7"):
+        f = 2 ** int(pn[-1])
+        cls, reg, msk, arg = dataset.level_labels((128, 128), _t(cids, dev), _t(boxes, dev), lv[pn], f, 8,
+                                                  num_obj=_t(nobj, dev), return_argmax=True)
+        assert int(arg.max()) == 0
+        for i in range(2):
+            oc, orr, om, _ = dataset_ref.level_labels((128, 128), cids[i, :1], boxes[i, :1], lv[pn].anchor_sizes, f, 8)
+            assert np.array_equal(cls[i].cpu().numpy(), oc) and np.array_equal(msk[i].cpu().numpy().astype(bool), om)
+
+
+def test_tiny_and_ragged_shapes(dev):
+    """1x1 maps, batch 1, odd sizes through conv / GroupNorm / upsample (P7 of small images, scale-600 sizes)."""
+    import ops
+    rng = np.random.default_rng(5)
+    for (n, h, w) in ((1, 1, 1), (1, 1, 3), (3, 5, 1)):
+        x = rng.standard_normal((n, h, w, 256)).astype(np.float32)
+        wt = (rng.standard_normal((3, 3, 256, 256)) / 48).astype(np.float32)
+        g, b = rng.standard_normal(256).astype(np.float32), rng.standard_normal(256).astype(np.float32)
+        ref = tf_ops_ref.activation(tf_ops_ref.group_norm(tf_ops_ref.conv2d_same(torch.from_numpy(x), torch.from_numpy(wt), 1),
+                                                          torch.from_numpy(g), torch.from_numpy(b)), "elu").numpy()
+        got = ops.group_norm_act(ops.conv2d(_t(x, dev), _t(wt, dev)), _t(g, dev), _t(b, dev), 32, 1e-5, "elu")
+        # hw == 1: 8 values per group, variance can be tiny -> rstd ~ 1/sqrt(eps): compare with matching slack
+        assert_close(got.cpu().numpy(), ref, 5e-4, "tiny conv+gn %s" % ((n, h, w),))
