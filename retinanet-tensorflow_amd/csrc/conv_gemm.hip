@@ -547,7 +547,12 @@ struct TileCfg {
 const TileCfg kCfgs[] = {{128, 128, 1.00}, {128, 64, 1.06}, {64, 64, 1.12}, {128, 32, 1.20}};
 constexpr int kNumCfg = 4;
 
-// pick the tile shape with the least padded work, corrected for chip fill (256 CUs)
+// Pick the tile shape from a measured latency model (tools/conv_occupancy.py on MI355X): with b blocks of
+// a shape resident per CU, one K-iteration of every resident block takes about t0 + t1*b nanoseconds
+//   128x128: 700 + 1780 b     128x64: 550 + 1000 b     64x64: 430 + 515 b     128x32: 430 + 560 b
+// (big tiles win once they fill the chip, small tiles win when there are only a few: a 2-block grid of
+// 128x128 tiles is 2.6x slower per iteration than 8 blocks of 64x64).  All segments share K.
+const double kT0[kNumCfg] = {700, 550, 430, 430}, kT1[kNumCfg] = {1780, 1000, 515, 560};
 template <typename F>
 int choose_cfg(F dims, int nseg) {
   if (const char* force = getenv("RN_CONV_CFG")) {  // tuning aid: force a tile shape (0..3)
@@ -557,22 +562,14 @@ int choose_cfg(F dims, int nseg) {
   int best = 0;
   double best_cost = 1e300;
   for (int c = 0; c < kNumCfg; ++c) {
-    double work = 0;
     long tiles = 0;
     for (int s = 0; s < nseg; ++s) {
       long m, n;
       dims(s, &m, &n);
-      long tm = (m + kCfgs[c].bm - 1) / kCfgs[c].bm, tn = (n + kCfgs[c].bn - 1) / kCfgs[c].bn;
-      tiles += tm * tn;
-      work += (double)tm * kCfgs[c].bm * tn * kCfgs[c].bn;
+      tiles += ((m + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((n + kCfgs[c].bn - 1) / kCfgs[c].bn);
     }
-    double fill = 1.0;
-    if (tiles < 1024) {  // few tiles: count whole "rounds" of 256 CUs
-      long rounds = (tiles + 255) / 256;
-      fill = (double)(rounds * 256) / (double)tiles;
-      if (fill > 4.0) fill = 4.0;
-    }
-    double cost = work * kCfgs[c].penalty * fill;
+    const double b = (double)((tiles + 255) / 256);
+    const double cost = kT0[c] + kT1[c] * b;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;

@@ -148,7 +148,7 @@ unsigned grid_for(int64_t total) {
 
 void wgrad_plan(const DwArgs& a, int* chunks, int* ppc) {
   const int64_t npix = (int64_t)a.n * a.oh * a.ow;
-  int64_t ck = (npix * a.c + 8191) / 8192;
+  int64_t ck = (npix * a.c + 2047) / 2048;   // short blocks: the tap loop is latency-bound
   if (ck > 4096) ck = 4096;
   if (ck < 1) ck = 1;
   *ppc = (int)((npix + ck - 1) / ck);

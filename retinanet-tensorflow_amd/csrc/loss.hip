@@ -19,7 +19,7 @@ constexpr int T = 256;
 constexpr int WAVES = T / 64;
 constexpr int MAXJ = 4;          // classes per lane => C <= 256
 constexpr int NSCAL = 5;         // M, fg, bce, focal, huber
-constexpr int BLOCKS = 512;
+constexpr int BLOCKS = 2048;      // 8 waves per SIMD: the per-row load -> math chain is latency-bound
 
 struct LossSeg {
   const float* zl; const float* ll; const float* rp; const float* rl; const uint8_t* tm;
@@ -238,7 +238,7 @@ int build(const rn_loss_seg* segs, int nseg, int C, int mode, LossArgs* a, bool 
 }
 
 int nblocks_for(int64_t rows) {
-  int64_t b = (rows + WAVES * 8 - 1) / (WAVES * 8);
+  int64_t b = (rows + WAVES * 4 - 1) / (WAVES * 4);
   if (b > BLOCKS) b = BLOCKS;
   if (b < 1) b = 1;
   return (int)b;
