@@ -186,7 +186,28 @@ _workspaces = {}
 WORKSPACE_MIN_BYTES = 256 << 20
 
 
-SIDE_STREAMS = set()   # raw handles of streams that run concurrently with the main one (retinanet.side_stream)
+SIDE_STREAMS = set()   # raw handles of streams that run concurrently with the main one
+_side_streams = {}
+
+
+def side_stream(device, index=0):
+    """A stream (per device and index) for work that may overlap the main stream; it gets its own workspace."""
+    key = (device.type, device.index, index)
+    st = _side_streams.get(key)
+    if st is None:
+        lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (0, 0)
+        st = torch.cuda.Stream(device=device, priority=int(os.environ.get('RN_SIDE_PRIO', lo)))  # lowest priority
+        _side_streams[key] = st
+        SIDE_STREAMS.add(st.cuda_stream)
+    return st
+
+
+def join_side_streams(device):
+    """Make the current stream wait for everything queued on this device's side streams."""
+    cur = torch.cuda.current_stream(device)
+    for (t, i, _), st in _side_streams.items():
+        if t == device.type and i == device.index:
+            cur.wait_stream(st)
 
 
 def workspace(nbytes, device):

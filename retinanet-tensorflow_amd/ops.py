@@ -21,6 +21,42 @@ import _rn
 DIRECT_PARAM_GRADS = False
 
 
+# Weight gradients are off the critical path of backward (only the optimizer consumes them) while the
+# dgrad -> GroupNorm-backward chain is a long sequence of small, latency-bound kernels: run wgrad (+ its
+# slab reduce and the bias gradient) on a side stream so the matrix cores work on it underneath that
+# chain.  A replayed hipGraph keeps the two branches concurrent (tools/graph_concurrency.py).  The
+# consumer (train.Trainer / any caller that reads .grad) must call _rn.join_side_streams() first --
+# torch.autograd.backward's own end-of-backward sync only covers streams it knows about.
+WGRAD_SIDE_STREAM = False
+
+
+class _on_side_stream(object):
+    """with _on_side_stream(device, tensors): ...  -- fork after the current stream, keep `tensors` alive
+    for the side stream (caching-allocator record_stream)."""
+
+    def __init__(self, device, tensors, direct=True):
+        # only when the results go straight into pre-allocated .grad buffers: a tensor handed back to
+        # autograd would be consumed on the main stream without waiting for the side stream
+        self.on = WGRAD_SIDE_STREAM and direct and device.type == 'cuda'
+        if self.on:
+            self.side = _rn.side_stream(device, 0)
+            self.side.wait_stream(torch.cuda.current_stream(device))
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.side)
+            self.ctx = torch.cuda.stream(self.side)
+
+    def __enter__(self):
+        if self.on:
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            self.ctx.__exit__(*a)
+        return False
+
+
 def _as_list(x):
     return list(x) if isinstance(x, (list, tuple)) else [x]
 
@@ -100,22 +136,27 @@ class _Conv2dShared(torch.autograd.Function):
             _rn.check(L.rn_conv2d_dgrad(segs, len(idx), C.byref(geom), _rn.stream()), "rn_conv2d_dgrad")
             for i, o in zip(idx, outs):
                 dxs[i] = o
-        dw = None
-        if ctx.needs_input_grad[1]:
-            segs = _conv_segs(xs, w, None, None, dys, None)
-            need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
-            ws = _rn.workspace(need, w.device)
-            dw_buf, dw = _grad_slot(w)
-            _rn.check(L.rn_conv2d_wgrad(segs, n, C.byref(geom), _rn.f32(dw_buf), 0, ws.data_ptr(), ws.numel(),
-                                        _rn.stream()), "rn_conv2d_wgrad")
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            segs = _conv_segs(xs, w, None, None, dys, None)
-            need = L.rn_conv2d_bias_grad_workspace(cout)
-            ws = _rn.workspace(need, w.device)
-            db_buf, db = _grad_slot(bias)
-            _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws.data_ptr(), ws.numel(),
-                                            _rn.stream()), "rn_conv2d_bias_grad")
+        dw = db = None
+        want_dw = ctx.needs_input_grad[1]
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if want_dw or want_db:
+            dw_buf = db_buf = None
+            if want_dw:
+                dw_buf, dw = _grad_slot(w)
+            if want_db:
+                db_buf, db = _grad_slot(bias)
+            with _on_side_stream(w.device, list(xs) + list(dys) + [dw_buf, db_buf], direct=(dw is None and db is None)):
+                segs = _conv_segs(xs, w, None, None, dys, None)
+                if want_dw:
+                    need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
+                    ws = _rn.workspace(need, w.device)
+                    _rn.check(L.rn_conv2d_wgrad(segs, n, C.byref(geom), _rn.f32(dw_buf), 0, ws.data_ptr(), ws.numel(),
+                                                _rn.stream()), "rn_conv2d_wgrad")
+                if want_db:
+                    need = L.rn_conv2d_bias_grad_workspace(cout)
+                    ws = _rn.workspace(need, w.device)
+                    _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws.data_ptr(), ws.numel(),
+                                                    _rn.stream()), "rn_conv2d_bias_grad")
         return (None, dw, db) + tuple(dxs)
 
 
@@ -229,11 +270,12 @@ class _Depthwise(torch.autograd.Function):
             _rn.check(L.rn_depthwise_dgrad(_rn.f32(dy), _rn.f32(w), _rn.f32(dx), n, h, wd, c, k, ctx.stride,
                                            _rn.stream()), "rn_depthwise_dgrad")
         if ctx.needs_input_grad[1]:
-            need = L.rn_depthwise_wgrad_workspace(n, h, wd, c, k, ctx.stride)
-            ws = _rn.workspace(need, x.device)
             dw_buf, dw = _grad_slot(w)
-            _rn.check(L.rn_depthwise_wgrad(_rn.f32(x), _rn.f32(dy), _rn.f32(dw_buf), n, h, wd, c, k, ctx.stride,
-                                           ws.data_ptr(), ws.numel(), _rn.stream()), "rn_depthwise_wgrad")
+            with _on_side_stream(x.device, [x, dy, dw_buf], direct=(dw is None)):
+                need = L.rn_depthwise_wgrad_workspace(n, h, wd, c, k, ctx.stride)
+                ws = _rn.workspace(need, x.device)
+                _rn.check(L.rn_depthwise_wgrad(_rn.f32(x), _rn.f32(dy), _rn.f32(dw_buf), n, h, wd, c, k, ctx.stride,
+                                               ws.data_ptr(), ws.numel(), _rn.stream()), "rn_depthwise_wgrad")
         return dx, dw, None
 
 

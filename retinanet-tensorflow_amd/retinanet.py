@@ -38,15 +38,10 @@ FUSE_HEAD_TOWERS = False   # measured: 163 vs 166 img/s (the fused wgrad is slow
 # (small, launch- and occupancy-bound) kernels overlap -- forward here, and backward too because
 # autograd replays each node on its forward stream.  Captured into the step's hipGraph as two branches.
 HEADS_TWO_STREAMS = False
-_side_streams = {}
 
 
 def side_stream(device):
-    key = (device.type, device.index)
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-        _rn.SIDE_STREAMS.add(_side_streams[key].cuda_stream)
-    return _side_streams[key]
+    return _rn.side_stream(device, 1)
 
 
 def build_backbone(backbone, activation, dropout_rate):

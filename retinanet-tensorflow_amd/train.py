@@ -127,7 +127,7 @@ class Trainer(object):
 
     def __init__(self, net, levels=None, optimizer='momentum', learning_rate=1e-2, grad_clip_norm=None,
                  loss_mode='bce_dice', device='cuda', use_graph=False, process_group=None,
-                 direct_param_grads=True):
+                 direct_param_grads=True, wgrad_side_stream=False):
         self.net, self.levels = net, levels or build_levels()
         self.device = torch.device(device)
         self.loss_mode = loss_mode
@@ -138,6 +138,9 @@ class Trainer(object):
         # kernels write parameter gradients straight into the arena (every parameter of this network
         # is used by exactly one op call per step); see ops.DIRECT_PARAM_GRADS
         ops.DIRECT_PARAM_GRADS = bool(direct_param_grads)
+        # ... which would let the weight-gradient kernels run on a side stream under the dgrad / GroupNorm chain;
+        # measured on MI355X: 162 vs 170 img/s (fork/join edges + CU contention cost more than the overlap buys), so off
+        ops.WGRAD_SIDE_STREAM = bool(direct_param_grads) and bool(wgrad_side_stream)
         self._graph = None
         self._static = None
         self.drop_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -154,11 +157,10 @@ class Trainer(object):
         # through autograd (e.g. the concatenated head kernels) are accumulated -> the arena starts at zero
         self.arena.zero_grad()
         (class_loss + regr_loss).backward()
-        # the box subnet's backward ran on the side stream (retinanet.HEADS_TWO_STREAMS) and wrote its
-        # parameter gradients straight into the arena: join it before anything reads the arena
-        import retinanet
-        if retinanet.HEADS_TWO_STREAMS and self.device.type == 'cuda':
-            torch.cuda.current_stream().wait_stream(retinanet.side_stream(self.device))
+        # weight-gradient kernels run on a side stream (ops.WGRAD_SIDE_STREAM) and write straight into the
+        # arena: join every side stream before anything reads the arena
+        if self.device.type == 'cuda':
+            _rn.join_side_streams(self.device)
         self.drop_counter += 0x9E3779B9            # fresh dropout masks next step (device-side counter)
         return class_loss.detach(), regr_loss.detach()
 
