@@ -109,18 +109,23 @@ __global__ __launch_bounds__(T) void loss_reduce_kernel(const LossArgs a) {
   }
 }
 
-// stage 1: sums[i] = sum over blocks of partial[b][i]; 64 values x 4 row lanes per block
+// stage 1: sums[i] = sum over blocks of partial[b][i]; 16 values x 16 row lanes per block, fixed order
 __global__ __launch_bounds__(256) void loss_sum_kernel(const LossArgs a, int nblocks, double* __restrict__ sums) {
-  __shared__ double sh[4][64];
+  __shared__ double sh[16][16];
   const int n = NSCAL + 3 * a.C;
-  const int il = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + il;
+  const int il = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + il;
   double v = 0.0;
   if (i < n)
-    for (int b = rl; b < nblocks; b += 4) v += (double)a.partial[(size_t)b * n + i];
+    for (int b = rl; b < nblocks; b += 16) v += (double)a.partial[(size_t)b * n + i];
   sh[rl][il] = v;
   __syncthreads();
-  if (rl == 0 && i < n) sums[i] = sh[0][il] + sh[1][il] + sh[2][il] + sh[3][il];
+  if (rl == 0 && i < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += sh[r][il];
+    sums[i] = t;
+  }
 }
 
 // stage 2: loss values and the per-class statistics the gradient pass needs
@@ -264,7 +269,7 @@ extern "C" int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, i
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(nb), dim3(T), 0, st, a);
   double* sums = (double*)((char*)workspace + rn::align_up((size_t)BLOCKS * (NSCAL + 3 * (size_t)num_classes) * sizeof(float), 256));
-  hipLaunchKernelGGL(loss_sum_kernel, dim3(rn::ceil_div(NSCAL + 3 * num_classes, 64)), dim3(256), 0, st, a, nb, sums);
+  hipLaunchKernelGGL(loss_sum_kernel, dim3(rn::ceil_div(NSCAL + 3 * num_classes, 16)), dim3(256), 0, st, a, nb, sums);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, a, (const double*)sums);
   RN_LAUNCH_CHECK();
   return RN_OK;
