@@ -92,6 +92,15 @@ size_t rn_conv2d_bias_grad_workspace(int cout);
 int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dbias, void* workspace,
                         size_t workspace_bytes, rn_stream_t stream);
 
+/* ------------------------------------------------------------------ fp16 inference convolution
+ * BASELINE configs[4] ("Inference-only ResNeXt-50-FPN 1024x1024 bs=16, fp16"): forward conv on the f16
+ * matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate).  Segment fields as rn_conv2d_fwd but x is
+ * fp16 NHWC, wgt is the PACKED kernel Wt[cout][kh*kw*cin/G] (fp16, from rn_pack_weights_f16), bias fp32,
+ * y fp16 (out_f32 = 0) or fp32 (out_f32 = 1).  cin/G must be a multiple of 4. */
+int rn_pack_weights_f16(const float* w, void* wt, int kh, int kw, int cin_g, int cout, rn_stream_t stream);
+int rn_cast_f32_to_f16(const float* x, void* y, int64_t count, rn_stream_t stream);
+int rn_conv2d_fwd_f16(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int out_f32, rn_stream_t stream);
+
 /* ------------------------------------------------------------------ depthwise 3x3
  * Replaces tf.nn.depthwise_conv2d (DepthwiseConv2dNative + its two backprops),
  * mobilenet_v2.py:35-36.  Kernel [kh,kw,C] (channel multiplier 1), padding SAME.
@@ -128,6 +137,7 @@ typedef struct rn_gn_params {
   int32_t c, groups, act;
   int32_t act_after_residual; /* 0: y = drop(act(GN(x))) + residual (MobileNetV2, mobilenet_v2.py:91-92);
                                  1: y = drop(act(GN(x) + residual))  (ResNeXt, resnet.py:99-101)          */
+  int32_t in_f16, out_f16;    /* forward only (inference): x is fp16 / y and residual are fp16           */
   float eps;
   float drop_rate;    /* 0 => no dropout                                    */
   uint64_t drop_seed; /* counter-based mask: keep iff hash(seed, elem) >= rate            */
@@ -162,6 +172,11 @@ int rn_dropout(const float* x, float* y, int64_t count, float rate, uint64_t see
  * gradient goes to the first maximum of each window.  tf.layers.AveragePooling2D(k, stride, 'same')
  * (densenet.py:144): divides by the number of valid cells. */
 int rn_maxpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);
+/* fp16-storage forward variants for the inference path (same semantics) */
+int rn_act_fwd_f16(const void* x, void* y, int64_t count, int act, rn_stream_t stream);
+int rn_maxpool_fwd_f16(const void* x, void* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);
+int rn_upsample_add_fwd_f16(const void* lateral, const void* top, void* y, int n, int h, int w, int th, int tw, int c,
+                            rn_stream_t stream);
 int rn_maxpool_bwd(const float* x, const float* dy, float* dx, int n, int h, int w, int c, int k, int stride,
                    rn_stream_t stream);
 int rn_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);

@@ -45,7 +45,7 @@ class GnSeg(C.Structure):
 
 class GnParams(C.Structure):
     _fields_ = [("c", C.c_int32), ("groups", C.c_int32), ("act", C.c_int32), ("act_after_residual", C.c_int32),
-                ("eps", C.c_float),
+                ("in_f16", C.c_int32), ("out_f16", C.c_int32), ("eps", C.c_float),
                 ("drop_rate", C.c_float), ("drop_seed", C.c_uint64), ("drop_seed_dev", C.c_void_p)]
 
 
@@ -74,7 +74,8 @@ SYMBOLS = [
     "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad",
     "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
-    "rn_dropout", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_avgpool_fwd", "rn_avgpool_bwd",
+    "rn_pack_weights_f16", "rn_cast_f32_to_f16", "rn_conv2d_fwd_f16", "rn_maxpool_fwd_f16", "rn_upsample_add_fwd_f16",
+    "rn_act_fwd_f16", "rn_dropout", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_avgpool_fwd", "rn_avgpool_bwd",
     "rn_loss_workspace", "rn_loss_fwd", "rn_loss_bwd",
     "rn_anchor_assign", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
     "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
@@ -117,6 +118,12 @@ def lib():
         L.rn_act_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.rn_upsample_add_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_upsample_add_bwd_top.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_pack_weights_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.rn_cast_f32_to_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.rn_conv2d_fwd_f16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.rn_maxpool_fwd_f16.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_upsample_add_fwd_f16.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_act_fwd_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.rn_dropout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]
         L.rn_maxpool_fwd.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_maxpool_bwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
@@ -173,7 +180,13 @@ def ptr(t):
 
 def f32(t):
     if t.dtype != torch.float32:
-        raise RnError("rn_hip kernels are fp32 (got %s)" % t.dtype)
+        raise RnError("this rn_hip kernel is fp32 (got %s)" % t.dtype)
+    return ptr(t)
+
+
+def f16(t):
+    if t.dtype != torch.float16:
+        raise RnError("this rn_hip kernel takes fp16 storage (got %s)" % t.dtype)
     return ptr(t)
 
 

@@ -1,0 +1,318 @@
+// fp16 inference convolution: NHWC half activations, implicit GEMM on the f16 matrix cores
+// (v_mfma_f32_32x32x16_f16: fp16 in, fp32 accumulate), forward only.
+// BASELINE configs[4]: "Inference-only ResNeXt-50-FPN 1024x1024 bs=16, fp16".
+//
+//   Y[m=(n,oh,ow)][co] = sum_k A[m][k=(kh,kw,ci)] * Wt[co][k]   (+bias), fp32 accumulate
+//
+// Weights are packed ONCE (rn_pack_weights_f16) from the fp32 HWIO kernel [kh,kw,cin_g,cout] to
+// Wt[cout][K] half (k contiguous), so both operands are k-contiguous in LDS and every MFMA fragment
+// (8 consecutive k of one row) is one ds_read_b128.  K-tile = 64 halfs, rows padded to 72 halfs
+// (144 B, the same conflict-free stride as the fp32 kernels).  Everything else follows conv_gemm.hip:
+// multi-segment launches, buffer loads with hardware range checks, block-uniform filter-tap state,
+// groups (ResNeXt), channel-slice input views, XCD-aware tile order.
+#include <stdlib.h>
+
+#include "rn_common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BK = 64;   // halfs per K-tile
+constexpr int LDH = 72;  // LDS row stride in halfs (144 B)
+constexpr unsigned OOB = 0x80000000u;
+
+struct SegH {
+  const _Float16* x; const _Float16* wt; const float* bias; void* y;
+  int n, h, w, oh, ow, cout, pad_t, pad_l, m, tiles_n, start, x_ld, x_coff;
+};
+struct ArgsH {
+  SegH seg[RN_MAX_SEG];
+  int nseg, kh, kw, stride, cin, groups, cin_g, tpg, out_f32;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+template <int VEC>
+struct VecH;
+template <>
+struct VecH<8> {
+  typedef half8 type;
+  static __device__ __forceinline__ half8 load(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+    return __builtin_bit_cast(half8, v);
+  }
+};
+template <>
+struct VecH<4> {
+  typedef half4 type;
+  static __device__ __forceinline__ half4 load(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+    return __builtin_bit_cast(half4, v);
+  }
+};
+
+__device__ __forceinline__ int find_seg(const ArgsH& a, int id) {
+  int s = 0;
+  while (s + 1 < a.nseg && id >= a.seg[s + 1].start) ++s;
+  return s;
+}
+
+template <int BM, int BN, int WM, int WN, int VEC, bool TAPU>
+__global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args) {
+  constexpr int T = WM * WN * 64;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int KQ = BK / VEC, RPP = T / KQ, A_PASS = BM / RPP, B_PASS = BN / RPP;
+  static_assert(A_PASS >= 1 && B_PASS >= 1 && BM % RPP == 0 && BN % RPP == 0, "tile/threads mismatch");
+  typedef typename VecH<VEC>::type vec_t;
+  __shared__ __attribute__((aligned(16))) _Float16 smem[(BM + BN) * LDH];
+  _Float16* As = smem;
+  _Float16* Bs = smem + BM * LDH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  const int s = find_seg(args, bid);
+  const SegH& sg = args.seg[s];
+  const int local = bid - sg.start;
+  const int tile_n = local % sg.tiles_n, tile_m = local / sg.tiles_n;
+  const int H = sg.h, W = sg.w, OW = sg.ow, OHW = sg.oh * sg.ow, M = sg.m, cout = sg.cout;
+  const int ldx = sg.x_ld, kw = args.kw, stride = args.stride;
+  const int G = args.groups, cin = args.cin_g, cout_g = cout / G;
+  const int grp = tile_n / args.tpg, tn_ = tile_n - grp * args.tpg;
+  const int m0 = tile_m * BM, n0 = grp * cout_g + tn_ * BN;
+  const int nmax = (grp + 1) * cout_g;
+  const int a_coff = sg.x_coff + grp * cin;
+  const int ktotal = args.kh * args.kw * cin;
+  const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.x, (unsigned)sg.n * H * W * ldx * 2u);
+  const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.wt, (unsigned)cout * ktotal * 2u);
+
+  const int kq = tid % KQ, r0 = tid / KQ;
+  int ih0[A_PASS], iw0[A_PASS], rowoff[A_PASS];
+#pragma unroll
+  for (int i = 0; i < A_PASS; ++i) {
+    const int m = m0 + r0 + i * RPP;
+    if (m < M) {
+      const int n_ = m / OHW, rem = m - n_ * OHW;
+      const int oh_ = rem / OW, ow_ = rem - oh_ * OW;
+      ih0[i] = oh_ * stride - sg.pad_t;
+      iw0[i] = ow_ * stride - sg.pad_l;
+      rowoff[i] = ((n_ * H + ih0[i]) * W + iw0[i]) * ldx + a_coff;
+    } else {
+      ih0[i] = -0x40000000; iw0[i] = 0; rowoff[i] = 0;
+    }
+  }
+  unsigned browoff[B_PASS];
+#pragma unroll
+  for (int j = 0; j < B_PASS; ++j) {
+    const int n = n0 + r0 + j * RPP;
+    browoff[j] = n < nmax ? (unsigned)n * ktotal * 2u : OOB;
+  }
+
+  int t_kh = 0, t_kw = 0, t_ci = 0;
+  vec_t ra[A_PASS], rb[B_PASS];
+  auto load_tiles = [&](int kt) {
+    int khh, kww, tapoff;
+    const int k = kt * BK + kq * VEC;
+    const bool kok = k < ktotal;
+    if (TAPU) {
+      khh = t_kh; kww = t_kw;
+      tapoff = (khh * W + kww) * ldx + t_ci + kq * VEC;
+      t_ci += BK;
+      if (t_ci == cin) { t_ci = 0; if (++t_kw == kw) { t_kw = 0; ++t_kh; } }
+    } else {
+      const int tap = k / cin, ci = k - tap * cin;
+      khh = tap / kw; kww = tap - khh * kw;
+      tapoff = (khh * W + kww) * ldx + ci;
+    }
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      const int ih = ih0[i] + khh, iw = iw0[i] + kww;
+      const bool ok = kok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      ra[i] = VecH<VEC>::load(xa, ok ? (unsigned)(rowoff[i] + tapoff) * 2u : OOB);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j)
+      rb[j] = VecH<VEC>::load(wb, (kok && browoff[j] != OOB) ? browoff[j] + (unsigned)k * 2u : OOB);
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<vec_t*>(&As[(r0 + i * RPP) * LDH + kq * VEC]) = ra[i];
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j) *reinterpret_cast<vec_t*>(&Bs[(r0 + j * RPP) * LDH + kq * VEC]) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, half = lane >> 5;
+  const int nk = (ktotal + BK - 1) / BK;
+  load_tiles(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tiles();
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      half8 a[TM], b[TN];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        a[tm] = *reinterpret_cast<const half8*>(&As[(wm * (BM / WM) + tm * 32 + l31) * LDH + ks * 16 + half * 8]);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        b[tn] = *reinterpret_cast<const half8*>(&Bs[(wn * (BN / WN) + tn * 32 + l31) * LDH + ks * 16 + half * 8]);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const unsigned esz = args.out_f32 ? 4u : 2u;
+  const __amdgpu_buffer_rsrc_t ys = make_rsrc(sg.y, (unsigned)M * (unsigned)cout * esz);
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + wn * (BN / WN) + tn * 32 + l31;
+    const bool cok = col < nmax;
+    const float bv = (sg.bias != nullptr && cok) ? sg.bias[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int rbase = m0 + wm * (BM / WM) + tm * 32 + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        const unsigned idx = (unsigned)row * (unsigned)cout + (unsigned)col;
+        const float v = acc[tm][tn][r] + bv;
+        if (args.out_f32) {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ys, cok ? idx * 4u : OOB, 0, 0);
+        } else {
+          const _Float16 hv = (_Float16)v;
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), ys, cok ? idx * 2u : OOB, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// Wt[co][k] (half) <- w[k][co] (fp32 HWIO flattened: k = (kh,kw,ci_g)); tiny, runs once per model
+__global__ void pack_weights_kernel(const float* __restrict__ w, _Float16* __restrict__ wt, int ktotal, int cout) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)ktotal * cout) return;
+  const int co = (int)(i / ktotal), k = (int)(i - (int64_t)co * ktotal);
+  wt[i] = (_Float16)w[(size_t)k * cout + co];
+}
+
+__global__ void cast_f32_to_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = (_Float16)x[i];
+}
+
+struct TileCfg { int bm, bn; };
+const TileCfg kCfgs[4] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
+const double kT0[4] = {700, 550, 430, 430}, kT1[4] = {1780, 1000, 515, 560};
+
+}  // namespace
+
+extern "C" int rn_pack_weights_f16(const float* w, void* wt, int kh, int kw, int cin_g, int cout, rn_stream_t stream) {
+  RN_CHECK_ARG(w && wt && kh >= 1 && kw >= 1 && cin_g >= 1 && cout >= 1, "pack_weights_f16: bad argument");
+  const int64_t total = (int64_t)kh * kw * cin_g * cout;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)rn::ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                     (_Float16*)wt, kh * kw * cin_g, cout);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_cast_f32_to_f16(const float* x, void* y, int64_t count, rn_stream_t stream) {
+  RN_CHECK_ARG(x && y && count >= 0, "cast: bad argument");
+  if (count == 0) return RN_OK;
+  int64_t b = rn::ceil_div64(count, 256);
+  if (b > 4096) b = 4096;
+  hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)y, count);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_conv2d_fwd_f16(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int out_f32,
+                                 rn_stream_t stream) {
+  RN_CHECK_ARG(segs && g && nseg >= 1 && nseg <= RN_MAX_SEG, "conv f16: bad segments");
+  RN_CHECK_ARG(g->kh >= 1 && g->kw >= 1 && g->stride >= 1 && g->cin >= 1, "conv f16: bad geometry");
+  const int G = g->groups > 1 ? g->groups : 1;
+  RN_CHECK_ARG(g->cin % G == 0, "conv f16: cin %d not divisible by groups %d", g->cin, G);
+  ArgsH a = {};
+  a.nseg = nseg; a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.cin = g->cin;
+  a.groups = G; a.cin_g = g->cin / G; a.out_f32 = out_f32 ? 1 : 0;
+  RN_UNSUPPORTED(a.cin_g % 4 != 0, "conv f16: input channels per group (%d) must be a multiple of 4", a.cin_g);
+  for (int s = 0; s < nseg; ++s) {
+    RN_CHECK_ARG(segs[s].x && segs[s].wgt && segs[s].y && segs[s].n >= 1 && segs[s].h >= 1 && segs[s].w >= 1 &&
+                 segs[s].cout >= 1 && segs[s].cout % G == 0, "conv f16: bad segment %d", s);
+    RN_UNSUPPORTED(G > 1 && segs[s].cout != segs[0].cout, "conv f16: grouped segments must share cout");
+    SegH& d = a.seg[s];
+    d.x = (const _Float16*)segs[s].x; d.wt = (const _Float16*)segs[s].wgt; d.bias = segs[s].bias; d.y = segs[s].y;
+    d.n = segs[s].n; d.h = segs[s].h; d.w = segs[s].w; d.cout = segs[s].cout;
+    rn::same_pad(d.h, g->kh, g->stride, &d.oh, &d.pad_t);
+    rn::same_pad(d.w, g->kw, g->stride, &d.ow, &d.pad_l);
+    d.m = d.n * d.oh * d.ow;
+    d.x_ld = segs[s].x_ld > 0 ? segs[s].x_ld : g->cin;
+    d.x_coff = segs[s].x_ld > 0 ? segs[s].x_coff : 0;
+    const double in_b = (double)d.n * d.h * d.w * d.x_ld * 2.0, out_b = (double)d.m * d.cout * 4.0;
+    RN_UNSUPPORTED(in_b >= 2147483648.0 || out_b >= 2147483648.0 || d.h >= 32768 || d.w >= 32768,
+                   "conv f16: a tensor of segment %d is >= 2 GiB", s);
+  }
+  const int cout_g = a.seg[0].cout / G;
+  int c;
+  if (const char* force = getenv("RN_CONV_CFG")) {
+    c = atoi(force) & 3;
+  } else if (G > 1 && cout_g <= 64) {
+    c = cout_g <= 32 ? 3 : 2;
+  } else {
+    double best = 1e300;
+    c = 0;
+    for (int k = 0; k < 4; ++k) {
+      long tiles = 0;
+      for (int s = 0; s < nseg; ++s)
+        tiles += (long)rn::ceil_div(a.seg[s].m, kCfgs[k].bm) * G * rn::ceil_div(a.seg[s].cout / G, kCfgs[k].bn);
+      const double cost = kT0[k] + kT1[k] * (double)((tiles + 255) / 256);
+      if (cost < best) { best = cost; c = k; }
+    }
+  }
+  a.tpg = G > 1 ? rn::ceil_div(cout_g, kCfgs[c].bn) : (1 << 20);
+  int tiles = 0;
+  for (int s = 0; s < nseg; ++s) {
+    SegH& d = a.seg[s];
+    d.tiles_n = G > 1 ? G * a.tpg : rn::ceil_div(d.cout, kCfgs[c].bn);
+    d.start = tiles;
+    tiles += rn::ceil_div(d.m, kCfgs[c].bm) * d.tiles_n;
+  }
+  const bool vec8 = a.cin_g % 8 == 0;
+  const bool tapu = vec8 && a.cin_g % BK == 0;
+  hipStream_t st = (hipStream_t)stream;
+#define RN_F16(BM_, BN_, WM_, WN_)                                                                                  \
+  do {                                                                                                              \
+    if (tapu) hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 8, true>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+    else if (vec8) hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 8, false>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+    else hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 4, false>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+  } while (0)
+  switch (c) {
+    case 0: RN_F16(128, 128, 2, 2); break;
+    case 1: RN_F16(128, 64, 2, 2); break;
+    case 2: RN_F16(64, 64, 2, 2); break;
+    default: RN_F16(128, 32, 4, 1); break;
+  }
+#undef RN_F16
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}

@@ -16,6 +16,14 @@ __global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restr
     dx[i] = dy[i] * rn::act_grad(x[i], act);
 }
 
+__global__ void act_fwd_f16_kernel(const void* __restrict__ x, void* __restrict__ y, int64_t quads, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < quads; i += (int64_t)gridDim.x * T) {
+    float4 v = rn::ld4(x, (size_t)i * 4, 1);
+    v.x = rn::act_fwd(v.x, act); v.y = rn::act_fwd(v.y, act); v.z = rn::act_fwd(v.z, act); v.w = rn::act_fwd(v.w, act);
+    rn::st4(y, (size_t)i * 4, 1, v);
+  }
+}
+
 // [TF-sem] src = min(roundf(dst * (in-1)/(out-1)), in-1); scale evaluated in float32
 __device__ __forceinline__ int nn_src(int dst, int in, int out) {
   const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
@@ -23,8 +31,8 @@ __device__ __forceinline__ int nn_src(int dst, int in, int out) {
   return s < in - 1 ? s : in - 1;
 }
 
-__global__ void upsample_add_kernel(const float* __restrict__ lat, const float* __restrict__ top, float* __restrict__ y,
-                                    int n, int h, int w, int th, int tw, int c) {
+__global__ void upsample_add_kernel(const void* __restrict__ lat, const void* __restrict__ top, void* __restrict__ y,
+                                    int n, int h, int w, int th, int tw, int c, int is_half) {
   const int CQ = c >> 2;
   const int64_t total = (int64_t)n * h * w * CQ;
   for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < total; i += (int64_t)gridDim.x * T) {
@@ -34,9 +42,9 @@ __global__ void upsample_add_kernel(const float* __restrict__ lat, const float* 
     const int y_ = (int)(p % h);
     const int n_ = (int)(p / h);
     const int sy = nn_src(y_, th, h), sx = nn_src(x_, tw, w);
-    const float4 a = *reinterpret_cast<const float4*>(lat + (size_t)i * 4);
-    const float4 b = *reinterpret_cast<const float4*>(top + ((size_t)(n_ * th + sy) * tw + sx) * c + q4 * 4);
-    *reinterpret_cast<float4*>(y + (size_t)i * 4) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    const float4 a = rn::ld4(lat, (size_t)i * 4, is_half);
+    const float4 b = rn::ld4(top, ((size_t)(n_ * th + sy) * tw + sx) * c + q4 * 4, is_half);
+    rn::st4(y, (size_t)i * 4, is_half, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
   }
 }
 
@@ -83,7 +91,7 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 }
 
 // ---- 3x3/2 (k x k / s) max pool, TF SAME: padded cells never win (resnet.py:200, densenet.py:180)
-struct PoolArgs { const float* x; const float* dy; float* out; int n, h, w, c, k, s, oh, ow, pt, pl; };
+struct PoolArgs { const float* x; const float* dy; float* out; int n, h, w, c, k, s, oh, ow, pt, pl; int is_half; };
 
 __global__ void maxpool_fwd_kernel(const PoolArgs a) {
   const int CQ = a.c >> 2;
@@ -101,11 +109,11 @@ __global__ void maxpool_fwd_kernel(const PoolArgs a) {
       for (int kw = 0; kw < a.k; ++kw) {
         const int iw = ow_ * a.s - a.pl + kw;
         if ((unsigned)iw >= (unsigned)a.w) continue;
-        const float4 v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n_ * a.h + ih) * a.w + iw) * a.c + q4 * 4);
+        const float4 v = rn::ld4(a.x, ((size_t)(n_ * a.h + ih) * a.w + iw) * a.c + q4 * 4, a.is_half);
         m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
       }
     }
-    *reinterpret_cast<float4*>(a.out + (size_t)i * 4) = m;
+    rn::st4(a.out, (size_t)i * 4, a.is_half, m);
   }
 }
 
@@ -249,7 +257,17 @@ extern "C" int rn_upsample_add_fwd(const float* lateral, const float* top, float
   RN_CHECK_ARG(lateral && top && y && n >= 1 && h >= 1 && w >= 1 && th >= 1 && tw >= 1, "upsample_add: bad argument");
   RN_UNSUPPORTED(c % 4 != 0, "upsample_add: c=%d not a multiple of 4", c);
   hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((int64_t)n * h * w * (c / 4))), dim3(T), 0, (hipStream_t)stream,
-                     lateral, top, y, n, h, w, th, tw, c);
+                     (const void*)lateral, (const void*)top, (void*)y, n, h, w, th, tw, c, 0);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_upsample_add_fwd_f16(const void* lateral, const void* top, void* y, int n, int h, int w, int th, int tw,
+                                       int c, rn_stream_t stream) {
+  RN_CHECK_ARG(lateral && top && y && n >= 1 && h >= 1 && w >= 1 && th >= 1 && tw >= 1, "upsample_add f16: bad argument");
+  RN_UNSUPPORTED(c % 4 != 0, "upsample_add f16: c=%d not a multiple of 4", c);
+  hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((int64_t)n * h * w * (c / 4))), dim3(T), 0, (hipStream_t)stream,
+                     lateral, top, y, n, h, w, th, tw, c, 1);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
@@ -283,6 +301,16 @@ extern "C" int rn_maxpool_fwd(const float* x, float* y, int n, int h, int w, int
   return RN_OK;
 }
 
+extern "C" int rn_maxpool_fwd_f16(const void* x, void* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream) {
+  PoolArgs a = {};
+  if (int e = fill_pool(&a, n, h, w, c, k, stride)) return e;
+  RN_CHECK_ARG(x && y, "maxpool fwd f16: null pointer");
+  a.x = (const float*)x; a.out = (float*)y; a.is_half = 1;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)n * a.oh * a.ow * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
 extern "C" int rn_maxpool_bwd(const float* x, const float* dy, float* dx, int n, int h, int w, int c, int k, int stride,
                               rn_stream_t stream) {
   PoolArgs a = {};
@@ -310,6 +338,14 @@ extern "C" int rn_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, i
   RN_CHECK_ARG(dy && dx, "avgpool bwd: null pointer");
   a.dy = dy; a.out = dx;
   hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((int64_t)n * h * w * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_act_fwd_f16(const void* x, void* y, int64_t count, int act, rn_stream_t stream) {
+  RN_CHECK_ARG(x && y && count >= 0 && count % 4 == 0, "act fwd f16: bad argument (count must be a multiple of 4)");
+  if (count == 0) return RN_OK;
+  hipLaunchKernelGGL(act_fwd_f16_kernel, dim3(grid_for(count / 4)), dim3(T), 0, (hipStream_t)stream, x, y, count / 4, act);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }

@@ -25,6 +25,7 @@ struct GnSeg {
 struct GnArgs {
   GnSeg seg[RN_MAX_SEG];
   int nseg, c, groups, cpg, act;
+  int in_half, out_half;  // forward only: fp16 storage of x / of y and residual (inference path)
   int act_after_res;  // 1: y = act(GN(x) + residual) (ResNeXt, resnet.py:99-101) instead of act(GN(x)) + residual
   float eps, drop_rate;
   uint64_t seed;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(T) void gn_partial_kernel(const GnArgs a) {
     if (pl < lanes && q4 < CQ) {
       for (int p = p_begin + pl; p < p_end; p += lanes) {
         const size_t off = (size_t)p * C + q4 * 4;
-        const float4 xv = *reinterpret_cast<const float4*>(x + off);
+        const float4 xv = BWD ? *reinterpret_cast<const float4*>(x + off) : rn::ld4(sg.x, base + off, a.in_half);
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         if (!BWD) {
 #pragma unroll
@@ -238,13 +239,13 @@ __global__ __launch_bounds__(T) void gn_apply_kernel(const GnArgs a) {
   for (int64_t i = (int64_t)blockIdx.x * T + tid; i < total; i += (int64_t)gridDim.x * T) {
     const int q4 = (int)(i % CQ);
     const size_t off = (size_t)i * 4;
-    const float4 xv = *reinterpret_cast<const float4*>(x + off);
+    const float4 xv = BWD ? *reinterpret_cast<const float4*>(x + off) : rn::ld4(sg.x, base + off, a.in_half);
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
     float o[4];
     if (!BWD) {
       float r[4] = {0.f, 0.f, 0.f, 0.f};
       if (sg.res) {
-        const float4 rv = *reinterpret_cast<const float4*>(sg.res + base + off);
+        const float4 rv = rn::ld4(sg.res, base + off, a.out_half);
         r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w;
       }
 #pragma unroll
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(T) void gn_apply_kernel(const GnArgs a) {
         if (drop) v = (rn::uniform01(seed, samp_off + off + j) >= a.drop_rate) ? v * keep_scale : 0.f;
         o[j] = a.act_after_res ? v : v + r[j];
       }
-      *reinterpret_cast<float4*>(sg.y + base + off) = make_float4(o[0], o[1], o[2], o[3]);
+      rn::st4(sg.y, base + off, a.out_half, make_float4(o[0], o[1], o[2], o[3]));
     } else {
       const float4 dv = *reinterpret_cast<const float4*>(sg.dy + base + off);
       const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
@@ -290,6 +291,9 @@ int build_args(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, GnArgs* a
   RN_CHECK_ARG(p->drop_rate >= 0.f && p->drop_rate < 1.f, "group_norm: drop_rate %f", p->drop_rate);
   a->nseg = nseg; a->c = p->c; a->groups = p->groups; a->cpg = p->c / p->groups; a->act = p->act;
   a->act_after_res = p->act_after_residual ? 1 : 0;
+  a->in_half = (!bwd && p->in_f16) ? 1 : 0;
+  a->out_half = (!bwd && p->out_f16) ? 1 : 0;
+  RN_UNSUPPORTED(bwd && (p->in_f16 || p->out_f16), "group_norm bwd: fp16 storage is forward-only");
   a->eps = p->eps; a->drop_rate = p->drop_rate; a->seed = p->drop_seed; a->seed_dev = p->drop_seed_dev;
   int samples = 0, chunks = 0;
   for (int s = 0; s < nseg; ++s) {

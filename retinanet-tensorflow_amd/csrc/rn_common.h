@@ -93,6 +93,25 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
   return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
+// 4 consecutive elements at element index i of an fp32 or fp16 tensor (fp16 storage is the inference path)
+typedef _Float16 rn_half4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const void* p, size_t i, int is_half) {
+  if (is_half) {
+    const rn_half4 h = *reinterpret_cast<const rn_half4*>(reinterpret_cast<const _Float16*>(p) + i);
+    return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+}
+__device__ __forceinline__ void st4(void* p, size_t i, int is_half, float4 v) {
+  if (is_half) {
+    rn_half4 h;
+    h.x = (_Float16)v.x; h.y = (_Float16)v.y; h.z = (_Float16)v.z; h.w = (_Float16)v.w;
+    *reinterpret_cast<rn_half4*>(reinterpret_cast<_Float16*>(p) + i) = h;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i) = v;
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

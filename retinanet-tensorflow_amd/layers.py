@@ -13,6 +13,19 @@ import math
 import torch
 
 import ops
+import ops_f16
+
+# Inference in fp16 storage (BASELINE configs[4]): set with layers.set_inference_dtype('f16').  When on, a
+# forward with training=False keeps activations in fp16 after the first GroupNorm, convs run on the f16
+# matrix cores (fp32 accumulate), GroupNorm statistics stay fp32; layers that must emit fp32 (the subnets'
+# output convs) say so with `f16_out_f32`.  Training is always fp32.
+INFERENCE_F16 = False
+
+
+def set_inference_dtype(name):
+    global INFERENCE_F16
+    assert name in ('f32', 'f16')
+    INFERENCE_F16 = (name == 'f16')
 
 
 # ------------------------------------------------------------------ activations
@@ -22,7 +35,9 @@ class _Activation(object):
 
     def __call__(self, input):
         if isinstance(input, (list, tuple)):
-            return [ops.activation(x, self.rn_act) for x in input]
+            return [self(x) for x in input]
+        if input.dtype == torch.float16:
+            return ops_f16.activation(input, self.rn_act)
         return ops.activation(input, self.rn_act)
 
     def __repr__(self):
@@ -106,6 +121,7 @@ class Conv2D(torch.nn.Module):
         assert padding == 'same', "the reference only uses padding='same'"
         self.filters, self.kernel_size, self.strides = filters, kernel_size, strides
         self.groups = groups        # > 1: the `groups` parallel convs of a ResNeXt bottleneck as ONE grouped conv
+        self.f16_out_f32 = False    # fp16 inference: emit fp32 (set on the subnets' output convs)
         self.use_bias = use_bias
         self.kernel_initializer = kernel_initializer or VarianceScaling(1.0)
         self.bias_initializer = bias_initializer or Constant(0.0)
@@ -129,6 +145,8 @@ class Conv2D(torch.nn.Module):
         first = input[0] if isinstance(input, (list, tuple)) else input
         if self.weight is None:
             self.build(first.shape[3], first.device)
+        if first.dtype == torch.float16:
+            return ops_f16.conv2d(input, self.weight, self.bias, self.strides, self.groups, out_f32=self.f16_out_f32)
         return ops.conv2d(input, self.weight, self.bias, self.strides, self.groups)
 
 
@@ -186,6 +204,8 @@ class MaxPooling2D(torch.nn.Module):
         self.pool_size, self.strides = pool_size, strides
 
     def forward(self, input):
+        if input.dtype == torch.float16:
+            return ops_f16.max_pool(input, self.pool_size, self.strides)
         return ops.max_pool(input, self.pool_size, self.strides)
 
 
@@ -220,6 +240,9 @@ class GroupNormalization(torch.nn.Module):
         first = input[0] if isinstance(input, (list, tuple)) else input
         if self.gamma is None:
             self.build(first.shape[3], first.device)
+        if (first.dtype == torch.float16 or INFERENCE_F16) and not training:
+            return ops_f16.group_norm_act(input, self.gamma, self.beta, self.groups, self.eps, act, residual,
+                                          act_after_residual)
         rate, seed, seed_dev = 0.0, 0, None
         if dropout is not None and training and dropout.rate > 0.0:
             rate, seed, seed_dev = dropout.rate, dropout.seed, Dropout.seed_device_counter

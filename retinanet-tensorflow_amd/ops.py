@@ -441,6 +441,9 @@ class _UpsampleAdd(torch.autograd.Function):
 
 
 def upsample_add(lateral, top):
+    if lateral.dtype == torch.float16:
+        import ops_f16
+        return ops_f16.upsample_add(lateral, top)
     return _UpsampleAdd.apply(lateral, top)
 
 

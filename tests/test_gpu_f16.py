@@ -1,0 +1,126 @@
+"""fp16 inference path (BASELINE configs[4]: ResNeXt-50-FPN, fp16): f16 matrix-core convs with fp32 accumulation,
+fp16-storage GroupNorm / pool / upsample.  Tolerances: a conv on fp16-rounded operands must match the fp32 oracle
+on the SAME rounded operands to 1e-3 (fp32 accumulate + one fp16 rounding of the output); a whole network in
+fp16 storage is compared with the fp32 oracle at 3e-2 of each tensor's max."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+from oracle import backbones_ref, tf_ops_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+CASES = [
+    # n, h, w, cin, cout, k, stride, groups, bias, out_f32
+    (2, 16, 16, 256, 256, 3, 1, 1, False, False),
+    (2, 8, 8, 256, 720, 3, 1, 1, True, True),
+    (1, 9, 7, 96, 256, 1, 1, 1, False, False),
+    (2, 17, 15, 64, 128, 3, 2, 1, False, False),
+    (2, 12, 12, 128, 128, 3, 1, 32, False, False),     # ResNeXt stage 2: 4 channels per group (8-byte gathers)
+    (2, 10, 10, 256, 256, 3, 2, 32, False, False),     # 8 per group, stride 2
+    (1, 6, 6, 1024, 1024, 3, 1, 32, False, False),     # 32 per group
+    (1, 5, 5, 2048, 256, 1, 1, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_f16(dev, case):
+    import ops_f16
+    import torch.nn.functional as F
+    n, h, w, cin, cout, k, stride, groups, use_bias, out_f32 = case
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float16)
+    wt = (rng.standard_normal((k, k, cin // groups, cout)) / np.sqrt(k * k * cin / groups)).astype(np.float16).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) if use_bias else None
+    xf = torch.from_numpy(x.astype(np.float32))
+    _, pt, pb = tf_ops_ref.same_pad_1d(h, k, stride)
+    _, pl, pr = tf_ops_ref.same_pad_1d(w, k, stride)
+    ref = F.conv2d(F.pad(xf.permute(0, 3, 1, 2), (pl, pr, pt, pb)), torch.from_numpy(wt).permute(3, 2, 0, 1),
+                   torch.from_numpy(b) if use_bias else None, stride=stride, groups=groups).permute(0, 2, 3, 1).numpy()
+    got = ops_f16.conv2d(torch.from_numpy(x).to(dev), torch.from_numpy(wt).to(dev),
+                         torch.from_numpy(b).to(dev) if use_bias else None, stride, groups, out_f32=out_f32)
+    assert got.dtype == (torch.float32 if out_f32 else torch.float16) and tuple(got.shape) == ref.shape
+    assert_close(got.float().cpu().numpy(), ref, 2e-5 if out_f32 else 1e-3, "conv f16")
+
+
+def test_group_norm_pool_upsample_f16(dev):
+    import ops_f16
+    rng = np.random.default_rng(3)
+    for c, groups, act, aar, in_half in ((256, 32, "elu", False, True), (64, 32, "relu", False, False),
+                                         (2048, 32, "relu", True, True), (256, 256, "relu", False, True)):
+        x = (rng.standard_normal((2, 6, 5, c)) * 2 + 0.3).astype(np.float16 if in_half else np.float32)
+        r = rng.standard_normal((2, 6, 5, c)).astype(np.float16)
+        gamma = (1 + 0.3 * rng.standard_normal(c)).astype(np.float32)
+        beta = (0.2 * rng.standard_normal(c)).astype(np.float32)
+        z = tf_ops_ref.group_norm(torch.from_numpy(x.astype(np.float32)), torch.from_numpy(gamma), torch.from_numpy(beta), groups)
+        rt = torch.from_numpy(r.astype(np.float32))
+        ref = tf_ops_ref.activation(z + rt, act) if aar else tf_ops_ref.activation(z, act) + rt
+        got = ops_f16.group_norm_act(torch.from_numpy(x).to(dev), torch.from_numpy(gamma).to(dev), torch.from_numpy(beta).to(dev),
+                                     groups, 1e-5, act, torch.from_numpy(r).to(dev), aar)
+        assert got.dtype == torch.float16
+        assert_close(got.float().cpu().numpy(), ref.numpy(), 2e-3, "gn f16 c=%d" % c)
+    x = rng.standard_normal((2, 9, 9, 64)).astype(np.float16)
+    got = ops_f16.max_pool(torch.from_numpy(x).to(dev))
+    assert np.array_equal(got.float().cpu().numpy(), tf_ops_ref.max_pool_same(torch.from_numpy(x.astype(np.float32))).numpy())
+    lat, top = rng.standard_normal((1, 8, 8, 16)).astype(np.float16), rng.standard_normal((1, 4, 4, 16)).astype(np.float16)
+    got = ops_f16.upsample_add(torch.from_numpy(lat).to(dev), torch.from_numpy(top).to(dev))
+    ref = torch.from_numpy(lat.astype(np.float32)) + tf_ops_ref.upsample_nearest_align_corners(torch.from_numpy(top.astype(np.float32)), 8, 8)
+    assert_close(got.float().cpu().numpy(), ref.numpy(), 1e-3, "upsample_add f16")
+
+
+def test_resnext_fpn_fp16_inference_matches_fp32(dev):
+    """Whole RetinaNet(resnet_50) forward in fp16 storage vs its own fp32 forward and vs the fp32 oracle backbone."""
+    import layers, levels, retinanet
+    torch.manual_seed(5)
+    net = retinanet.RetinaNet('resnet_50', levels.build_levels(), 80, layers.elu, 0.0)
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if name.endswith("gamma"):
+                p.copy_(1 + 0.2 * torch.randn(p.shape, generator=g))
+            elif name.endswith("beta"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    params = {k[len("base."):]: v.detach().clone() for k, v in net.named_parameters() if k.startswith("base.backbone")}
+    net.to(dev)
+    x = torch.randn(2, 256, 256, 3)      # C5 = 8x8: the per-channel norms of the deep stages still average 64 values
+    with torch.no_grad():
+        ref32 = net(x.to(dev), training=False)
+        feats32 = backbones_ref.resnext50_forward(params, x)
+        layers.set_inference_dtype('f16')
+        try:
+            out16 = net(x.to(dev), training=False)
+            feats16 = net.base.backbone(x.to(dev), training=False)
+        finally:
+            layers.set_inference_dtype('f32')
+    def rel_l2(a, b):
+        a, b = a.double().cpu(), b.double().cpu()
+        return float((a - b).norm() / b.norm())
+
+    worst = 0.0
+    for k in ("C3", "C4", "C5"):
+        assert feats16[k].dtype == torch.float16
+        worst = max(worst, rel_l2(feats16[k].float(), feats32[k]))
+        print(k, "rel L2", rel_l2(feats16[k].float(), feats32[k]))
+    for k in ("P3", "P4", "P5", "P6", "P7"):
+        a, b = out16["classifications"][k], ref32["classifications"][k]
+        assert a.dtype == torch.float32 and a.shape == b.shape          # logits leave the net in fp32
+        e = max(rel_l2(a - a.mean(), b - b.mean()), rel_l2(out16["regressions"][k], ref32["regressions"][k]))
+        print(k, "rel L2", e)
+        if k in ("P6", "P7"):
+            # 2x2 / 1x1 maps at this input size: GroupNorm over a handful of values amplifies the fp16 rounding
+            assert e <= 1e-1, (k, e)
+        else:
+            worst = max(worst, e)
+    print("fp16 vs fp32 worst relative L2 error", worst)
+    # fp16 storage (2^-11 per rounding) through ~75 conv + GroupNorm layers of a randomly initialised ReLU net with
+    # per-channel norms: this net amplifies a single rounding ~60x (its fp32 forward differs from the fp32 oracle by
+    # ~1e-5..1e-4 for 6e-8 roundings, test_gpu_backbones), so 2^-11 * 60 ~ 3e-2 is what fp16 storage costs here
+    assert worst <= 6e-2

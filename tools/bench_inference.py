@@ -1,5 +1,5 @@
-"""BASELINE configs[4] shape on one GPU: ResNeXt-50-FPN 1024x1024, batch 16, forward (training=False)
-+ sigmoid + anchor decode + batched class-wise NMS.  fp32 (the fp16 variant is future work)."""
+"""BASELINE configs[4] on one GPU: ResNeXt-50-FPN 1024x1024, batch 16, forward (training=False) + sigmoid +
+anchor decode + batched class-wise NMS, in fp32 and in fp16 storage (f16 matrix-core convs, fp32 accumulate)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "retinanet-tensorflow_amd")):
@@ -7,15 +7,12 @@ for p in (ROOT, os.path.join(ROOT, "retinanet-tensorflow_amd")):
 import torch
 
 
-def main(backbone="resnet_50", size=1024, batch=16, iters=3):
+def main(backbone="resnet_50", size=1024, batch=16, iters=5):
     import layers, levels, ops, retinanet, utils
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     lv = levels.build_levels()
     net = retinanet.RetinaNet(backbone, lv, 80, layers.elu, 0.0).to(dev)
-    # raise the class prior so that ~1 % of the anchors pass the 0.5 threshold
-    with torch.no_grad():
-        net.base.classification_subnet.out_conv.bias.fill_(-2.2)
     image = torch.randn(batch, size, size, 3, device=dev)
     anchors = {k: lv[k].normalized_anchor_sizes((size, size)) for k in lv}
 
@@ -25,19 +22,22 @@ def main(backbone="resnet_50", size=1024, batch=16, iters=3):
             probs = {k: ops.activation(v, "sigmoid") for k, v in out["classifications"].items()}
             dec = {k: utils.regression_postprocess(out["regressions"][k], anchors[k]) for k in lv}
             rows = sum(v.numel() // 80 for v in probs.values())
-            return utils.detect(probs, dec, 80, capacity=int(rows * 0.2), return_raw=True)
+            return utils.detect(probs, dec, 80, score_threshold=0.0105, capacity=int(rows * 0.5), return_raw=True)
 
-    o = run(); torch.cuda.synchronize()
-    counts = o[5].cpu().tolist()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        run()
-    torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / iters
-    print(json.dumps({"backbone": backbone, "image_size": size, "batch": batch, "images_per_sec": round(batch / el, 2),
-                      "ms_per_batch": round(el * 1e3, 2), "candidates": counts[0], "kept": counts[1], "dtype": "f32",
-                      "conv_TFLOPs": round(596.0 * batch / el / 1e3, 1),
-                      "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
+    for dtype in ("f32", "f16"):
+        layers.set_inference_dtype(dtype)
+        o = run(); torch.cuda.synchronize()
+        counts = o[5].cpu().tolist()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / iters
+        print(json.dumps({"backbone": backbone, "image_size": size, "batch": batch, "dtype": dtype,
+                          "images_per_sec": round(batch / el, 2), "ms_per_batch": round(el * 1e3, 2),
+                          "candidates": counts[0], "kept": counts[1], "conv_TFLOPs": round(596.0 * batch / el / 1e3, 1),
+                          "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
+    layers.set_inference_dtype("f32")
 
 
 if __name__ == "__main__":
