@@ -99,6 +99,8 @@ int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g
  * y fp16 (out_f32 = 0) or fp32 (out_f32 = 1).  cin/G must be a multiple of 4. */
 int rn_pack_weights_f16(const float* w, void* wt, int kh, int kw, int cin_g, int cout, rn_stream_t stream);
 int rn_cast_f32_to_f16(const float* x, void* y, int64_t count, rn_stream_t stream);
+/* image [pixels,3] fp32 -> [pixels,4] fp16 with a zero 4th channel (the stem then gathers 8 bytes per tap) */
+int rn_pad_cast_rgb_f16(const float* x, void* y, int64_t pixels, rn_stream_t stream);
 int rn_conv2d_fwd_f16(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int out_f32, rn_stream_t stream);
 
 /* ------------------------------------------------------------------ depthwise 3x3

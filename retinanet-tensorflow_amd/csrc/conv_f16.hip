@@ -221,6 +221,15 @@ __global__ void cast_f32_to_f16_kernel(const float* __restrict__ x, _Float16* __
     y[i] = (_Float16)x[i];
 }
 
+// image [pixels][3] fp32 -> [pixels][4] fp16 (4th channel 0): lets the 7x7/2 stem use 8-byte fp16 gathers
+__global__ void pad_cast_rgb_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int64_t pixels) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * blockDim.x) {
+    half4 v;
+    v.x = (_Float16)x[i * 3]; v.y = (_Float16)x[i * 3 + 1]; v.z = (_Float16)x[i * 3 + 2]; v.w = (_Float16)0.f;
+    *reinterpret_cast<half4*>(y + i * 4) = v;
+  }
+}
+
 struct TileCfg { int bm, bn; };
 const TileCfg kCfgs[4] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}};
 const double kT0[4] = {700, 550, 430, 430}, kT1[4] = {1780, 1000, 515, 560};
@@ -242,6 +251,16 @@ extern "C" int rn_cast_f32_to_f16(const float* x, void* y, int64_t count, rn_str
   int64_t b = rn::ceil_div64(count, 256);
   if (b > 4096) b = 4096;
   hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)y, count);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_pad_cast_rgb_f16(const float* x, void* y, int64_t pixels, rn_stream_t stream) {
+  RN_CHECK_ARG(x && y && pixels >= 0, "pad_cast_rgb: bad argument");
+  if (pixels == 0) return RN_OK;
+  int64_t b = rn::ceil_div64(pixels, 256);
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(pad_cast_rgb_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, x, (_Float16*)y, pixels);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }

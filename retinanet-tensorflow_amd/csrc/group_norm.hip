@@ -283,6 +283,45 @@ __global__ __launch_bounds__(T) void gn_apply_kernel(const GnArgs a) {
   }
 }
 
+// fp16-storage inference apply: 8 channels (16 B) per thread, no dropout.  y = act(z) + r  or  act(z + r).
+typedef _Float16 gn_half8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(T) void gn_apply_f16x8_kernel(const GnArgs a) {
+  __shared__ float tab[2048][2];  // scale = rstd*gamma, shift = beta - mean*rstd*gamma  (z = x*scale + shift)
+  const int q = blockIdx.y, tid = threadIdx.x;
+  const int s = seg_of_sample(a, q);
+  const GnSeg& sg = a.seg[s];
+  const int nl = q - sg.sample_start;
+  const int C = a.c, C8 = C >> 3;
+  for (int c = tid; c < C; c += T) {
+    const int g = c / a.cpg;
+    const float mean = sg.mean[nl * a.groups + g], rstd = sg.rstd[nl * a.groups + g];
+    const float sc = rstd * a.gamma[c];
+    tab[c][0] = sc;
+    tab[c][1] = a.beta[c] - mean * sc;
+  }
+  __syncthreads();
+  const size_t base = (size_t)nl * sg.hw * C;
+  const _Float16* __restrict__ x = reinterpret_cast<const _Float16*>(sg.x) + base;
+  const _Float16* __restrict__ r = sg.res ? reinterpret_cast<const _Float16*>(sg.res) + base : nullptr;
+  _Float16* __restrict__ y = reinterpret_cast<_Float16*>(sg.y) + base;
+  const int64_t total = (int64_t)sg.hw * C8;
+  for (int64_t i = (int64_t)blockIdx.x * T + tid; i < total; i += (int64_t)gridDim.x * T) {
+    const int c0 = (int)(i % C8) * 8;
+    const gn_half8 xv = *reinterpret_cast<const gn_half8*>(x + i * 8);
+    gn_half8 rv;
+    if (r) rv = *reinterpret_cast<const gn_half8*>(r + i * 8);
+    gn_half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float z = (float)xv[j] * tab[c0 + j][0] + tab[c0 + j][1];
+      const float rr = r ? (float)rv[j] : 0.f;
+      const float v = a.act_after_res ? rn::act_fwd(z + rr, a.act) : rn::act_fwd(z, a.act) + rr;
+      o[j] = (_Float16)v;
+    }
+    *reinterpret_cast<gn_half8*>(y + i * 8) = o;
+  }
+}
+
 int build_args(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, GnArgs* a, bool bwd) {
   RN_CHECK_ARG(segs && p, "group_norm: null argument");
   RN_CHECK_ARG(nseg >= 1 && nseg <= RN_MAX_SEG, "group_norm: nseg %d outside [1,%d]", nseg, RN_MAX_SEG);
@@ -370,7 +409,10 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(a.total_chunks), dim3(T), 0, st, a);
   hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(a.total_samples * a.groups), dim3(T), 0, st, a);
-  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(apply_blocks(a), a.total_samples), dim3(T), 0, st, a);
+  if (a.in_half && a.out_half && a.c % 8 == 0 && a.drop_rate == 0.f)
+    hipLaunchKernelGGL(gn_apply_f16x8_kernel, dim3(apply_blocks(a) * 2, a.total_samples), dim3(T), 0, st, a);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(apply_blocks(a), a.total_samples), dim3(T), 0, st, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }

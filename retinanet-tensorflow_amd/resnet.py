@@ -95,6 +95,9 @@ class ResNeXt_ConvInput(Model):
         self._bn = Normalization(channels=64)
 
     def call(self, input, training):
+        if L.INFERENCE_F16 and not training and input.dtype != L.torch.float16:
+            import ops_f16
+            input = ops_f16.image_to_half4(input)        # fp16 inference: the stem runs on the f16 matrix cores too
         return self._bn.fused(self._conv(input), training, act='relu')
 
 
