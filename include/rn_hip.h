@@ -184,6 +184,12 @@ int rn_maxpool_bwd(const float* x, const float* dy, float* dx, int n, int h, int
 int rn_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);
 int rn_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);
 
+/* augmentation.flip (augmentation.py:5-22): y[o, W-1-j, i] = x[o, j, i] for an [outer, W, inner] tensor of
+ * 4-byte (fp32) or 1-byte (mask) elements; neg_mod > 0 also negates element neg_idx of every group of
+ * neg_mod values along `inner` (the x shift of the [.., A, 4] regression maps: neg_mod 4, neg_idx 1). */
+int rn_flip_width(const void* x, void* y, int64_t outer, int w, int64_t inner, int elem_bytes, int neg_mod, int neg_idx,
+                  rn_stream_t stream);
+
 /* ------------------------------------------------------------------ loss
  * Replaces utils.process_labels_and_logits/postprocess_and_mask (utils.py:240-284; the
  * boolean_mask compaction becomes a 0/1 row weight, result-identical) and losses.loss

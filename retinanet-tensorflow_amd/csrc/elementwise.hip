@@ -349,3 +349,40 @@ extern "C" int rn_act_fwd_f16(const void* x, void* y, int64_t count, int act, rn
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
+
+// ---- horizontal flip of an [outer, W, inner] tensor (augmentation.flip, augmentation.py:5-22): reverse W;
+// for regression maps additionally negate component `neg_idx` of every group of `neg_mod` values (the x shift)
+namespace {
+template <typename TT>
+__global__ void flip_w_kernel(const TT* __restrict__ x, TT* __restrict__ y, int64_t outer, int w, int64_t inner, int neg_mod,
+                              int neg_idx) {
+  const int64_t total = outer * w * inner;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t in_ = i % inner;
+    const int64_t r = i / inner;
+    const int j = (int)(r % w);
+    const int64_t o = r / w;
+    TT v = x[(o * w + (w - 1 - j)) * inner + in_];
+    if (neg_mod > 0 && (in_ % neg_mod) == neg_idx) v = (TT)(-(float)v);
+    y[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int rn_flip_width(const void* x, void* y, int64_t outer, int w, int64_t inner, int elem_bytes, int neg_mod,
+                             int neg_idx, rn_stream_t stream) {
+  RN_CHECK_ARG(x && y && outer >= 0 && w >= 1 && inner >= 1 && (elem_bytes == 1 || elem_bytes == 4), "flip_width: bad argument");
+  RN_CHECK_ARG(elem_bytes == 4 || neg_mod == 0, "flip_width: negation needs fp32 data");
+  const int64_t total = outer * w * inner;
+  if (total == 0) return RN_OK;
+  int64_t b = (total + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL(flip_w_kernel<float>, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y,
+                       outer, w, inner, neg_mod, neg_idx);
+  else
+    hipLaunchKernelGGL(flip_w_kernel<uint8_t>, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)x,
+                       (uint8_t*)y, outer, w, inner, 0, 0);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}

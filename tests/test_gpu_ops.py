@@ -595,3 +595,47 @@ def test_tiny_and_ragged_shapes(dev):
         got = ops.group_norm_act(ops.conv2d(_t(x, dev), _t(wt, dev)), _t(g, dev), _t(b, dev), 32, 1e-5, "elu")
         # hw == 1: 8 values per group, variance can be tiny -> rstd ~ 1/sqrt(eps): compare with matching slack
         assert_close(got.cpu().numpy(), ref, 5e-4, "tiny conv+gn %s" % ((n, h, w),))
+
+
+def test_flip_augmentation_matches_reference_semantics(dev):
+    """augmentation.flip on the device == the oracle (augmentation_test.py:7-45 vectors included), and the
+    flipped labels equal labels built from the flipped boxes where the assignment is unambiguous."""
+    import augmentation
+    import reference_kats as K
+    rng = np.random.default_rng(2)
+    cls = {"P3": rng.uniform(size=(4, 6, 9, 5)).astype(np.float32), "P4": rng.uniform(size=(2, 3, 9, 5)).astype(np.float32)}
+    reg = {"P3": rng.standard_normal((4, 6, 9, 4)).astype(np.float32), "P4": K.FLIP_REGR_INPUT.repeat(9, 2).reshape(2, 3, 9, 4)}
+    msk = {"P3": (rng.uniform(size=(4, 6, 9)) < 0.5), "P4": (rng.uniform(size=(2, 3, 9)) < 0.5)}
+    img = rng.standard_normal((32, 48, 3)).astype(np.float32)
+    sample = {"image": _t(img, dev), "detection": {"classifications": {k: _t(v, dev) for k, v in cls.items()},
+                                                   "regressions": {k: _t(v, dev) for k, v in reg.items()}},
+              "trainable_masks": {k: _t(v.astype(np.uint8), dev) for k, v in msk.items()}}
+    got = augmentation.flip(sample)
+    ec, er, em, ei = dataset_ref.flip(cls, reg, msk, img)
+    assert np.array_equal(got["image"].cpu().numpy(), ei)
+    for k in cls:
+        assert np.array_equal(got["detection"]["classifications"][k].cpu().numpy(), ec[k])
+        assert np.array_equal(got["detection"]["regressions"][k].cpu().numpy(), er[k])
+        assert np.array_equal(got["trainable_masks"][k].cpu().numpy().astype(bool), em[k])
+    pair = augmentation.make_pair(sample)
+    assert pair["image"].shape == (2, 32, 48, 3) and pair["detection"]["regressions"]["P3"].shape == (2, 4, 6, 9, 4)
+    assert torch.equal(pair["image"][1], got["image"])
+
+
+def test_checkpoint_roundtrip(dev, tmp_path):
+    import checkpoint, layers, levels, retinanet, train
+    lv = levels.build_levels()
+    torch.manual_seed(0)
+    net = retinanet.RetinaNet('mobilenet_v2', lv, 3, layers.elu, 0.0).to(dev)
+    tr = train.Trainer(net, lv, optimizer="rmsprop", device=dev)
+    tr.opt.state2.normal_(); tr.opt.step_count = 7
+    ref = {k: v.detach().clone() for k, v in net.named_parameters()}
+    s1, s2 = tr.opt.state1.clone(), tr.opt.state2.clone()
+    path = str(tmp_path / "ckpt" / "model.safetensors")
+    checkpoint.save(path, net, tr, step=123)
+    with torch.no_grad():
+        tr.arena.weights.zero_(); tr.opt.state1.zero_(); tr.opt.state2.zero_()
+    assert checkpoint.load(path, net, tr) == 123 and tr.opt.step_count == 7
+    for k, v in net.named_parameters():
+        assert torch.equal(v, ref[k]) and v.data_ptr() >= tr.arena.weights.data_ptr()      # still views of the arena
+    assert torch.equal(tr.opt.state1, s1) and torch.equal(tr.opt.state2, s2)
