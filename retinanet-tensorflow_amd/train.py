@@ -203,3 +203,97 @@ def _copy_tree(dst, src):
     elif isinstance(dst, (list, tuple)):
         for d, s in zip(dst, src):
             _copy_tree(d, s)
+
+
+# ------------------------------------------------------------------------------------------------ CLI
+# Minimal driver with the reference's flags (train.py:88-108).  Dataset readers (COCO / Pascal, cv2,
+# pycocotools) are out of scope; 'shapes' is a synthetic stand-in following data_loaders/shapes.py:133-176
+# (1-4 filled squares, half-size in [20, S/4], 3 classes), rendered with numpy.
+class ShapesLoader(object):
+    class_names = ['square_r', 'square_g', 'square_b']
+    num_classes = 3
+
+    def __init__(self, image_size=(256, 256), seed=0, length=1 << 30):
+        self.size, self.rng, self.length = image_size, np.random.default_rng(seed), length
+
+    def __iter__(self):
+        h, w = self.size
+        for _ in range(self.length):
+            image = np.full((h, w, 3), 0.5, np.float32) + self.rng.normal(0, 0.02, (h, w, 3)).astype(np.float32)
+            n = int(self.rng.integers(1, 5))
+            boxes, ids = [], []
+            for _ in range(n):
+                half = int(self.rng.integers(20, max(21, min(h, w) // 4)))
+                cy, cx = int(self.rng.integers(20, h - 20)), int(self.rng.integers(20, w - 20))
+                y1, x1, y2, x2 = max(cy - half, 0), max(cx - half, 0), min(cy + half, h), min(cx + half, w)
+                c = int(self.rng.integers(0, 3))
+                image[y1:y2, x1:x2, :] = 0.1
+                image[y1:y2, x1:x2, c] = 0.9
+                boxes.append([y1 / h, x1 / w, y2 / h, x2 / w])
+                ids.append(c)
+            yield {'image': image, 'boxes': np.asarray(boxes, np.float32), 'class_ids': np.asarray(ids, np.int32)}
+
+
+def build_parser():
+    import argparse
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--learning-rate', type=float, default=1e-2)
+    parser.add_argument('--dropout', type=float, default=0.2)
+    parser.add_argument('--dataset', type=str, nargs='+', default=['shapes'])
+    parser.add_argument('--epochs', type=int, default=1)
+    parser.add_argument('--scale', type=int, default=256)
+    parser.add_argument('--experiment', type=str, default=None, help='directory for checkpoints (model.safetensors)')
+    parser.add_argument('--grad-clip-norm', type=float)
+    parser.add_argument('--backbone', type=str, choices=['resnet_50', 'densenet_121', 'densenet_169', 'mobilenet_v2'],
+                        default='mobilenet_v2')
+    parser.add_argument('--optimizer', type=str, choices=['momentum', 'adam', 'rmsprop'], default='momentum')
+    parser.add_argument('--loss', type=str, choices=['bce_dice', 'focal'], default='bce_dice')
+    parser.add_argument('--steps-per-epoch', type=int, default=100)
+    return parser
+
+
+def main(argv=None):
+    import augmentation
+    import checkpoint
+    import dataset
+    import retinanet
+    args = build_parser().parse_args(argv)
+    assert args.dataset[0] == 'shapes', 'only the synthetic shapes loader is built in (file readers are out of scope)'
+    dev = torch.device('cuda', int(__import__('os').environ.get('LOCAL_RANK', '0')))
+    loader = ShapesLoader((args.scale, args.scale))
+    levels = build_levels()
+    net = retinanet.RetinaNet(backbone=args.backbone, levels=levels, num_classes=loader.num_classes, activation=L.elu,
+                              dropout_rate=args.dropout).to(dev)
+    trainer = Trainer(net, levels, optimizer=args.optimizer, learning_rate=args.learning_rate,
+                      grad_clip_norm=args.grad_clip_norm, loss_mode=args.loss, device=dev)
+    mean = torch.tensor(dataset.MEAN, device=dev)
+    std = torch.tensor(dataset.STD, device=dev)
+    step = 0
+    path = None if args.experiment is None else __import__('os').path.join(args.experiment, 'model.safetensors')
+    if path is not None and __import__('os').path.exists(path):
+        step = checkpoint.load(path, net, trainer)
+        print('restored step', step)
+    it = iter(loader)
+    for epoch in range(args.epochs):
+        for _ in range(args.steps_per_epoch):
+            sample = next(it)
+            image = (torch.from_numpy(sample['image']).to(dev) - mean) / std             # train.py:48-49
+            boxes = torch.from_numpy(sample['boxes']).to(dev)[None]
+            ids = torch.from_numpy(sample['class_ids']).to(dev)[None]
+            c, r, m = dataset.build_labels(loader.size, ids, boxes, levels, loader.num_classes)
+            one = {'image': image, 'detection': {'classifications': {k: v[0] for k, v in c.items()},
+                                                 'regressions': {k: v[0] for k, v in r.items()}},
+                   'trainable_masks': {k: v[0] for k, v in m.items()}}
+            out = trainer.step(augmentation.make_pair(one))                                # batch = [image, hflip]
+            step += 1
+            if step % 20 == 0:
+                print('epoch %d step %d class_loss %.4f regr_loss %.4f reg %.4f' % (
+                    epoch, step, out['class_loss'].item(), out['regr_loss'].item(), out['regularization_loss'].item()),
+                    flush=True)
+        if path is not None:
+            checkpoint.save(path, net, trainer, step=step)
+    return step
+
+
+if __name__ == '__main__':
+    main()
