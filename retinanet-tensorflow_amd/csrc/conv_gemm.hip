@@ -856,13 +856,6 @@ __global__ __launch_bounds__(256) void bias_partial_kernel(const BiasArgs a) {
     }
   }
 }
-__global__ void bias_final_kernel(const float* __restrict__ partial, float* __restrict__ dbias, int cout, int nb) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cout) return;
-  double v = 0.0;
-  for (int b = 0; b < nb; ++b) v += (double)partial[(size_t)b * cout + c];
-  dbias[c] = (float)v;
-}
 }  // namespace
 
 extern "C" size_t rn_conv2d_bias_grad_workspace(int cout) { return (size_t)BG_BLOCKS * (size_t)(cout > 0 ? cout : 0) * sizeof(float); }

@@ -122,14 +122,6 @@ __global__ __launch_bounds__(T) void dw_wgrad_partial_kernel(const DwArgs a) {
   }
 }
 
-__global__ void dw_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int count, int chunks) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  double v = 0.0;
-  for (int s = 0; s < chunks; ++s) v += (double)partial[(size_t)s * count + i];
-  dw[i] = (float)v;
-}
-
 int fill(DwArgs* a, int n, int h, int w, int c, int k, int stride) {
   RN_CHECK_ARG(n >= 1 && h >= 1 && w >= 1 && c >= 1 && k >= 1 && stride >= 1, "depthwise: bad shape");
   RN_UNSUPPORTED(c % 4 != 0 || c > 1024, "depthwise: c=%d must be a multiple of 4 and <= 1024", c);
