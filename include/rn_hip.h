@@ -92,6 +92,18 @@ size_t rn_conv2d_bias_grad_workspace(int cout);
 int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dbias, void* workspace,
                         size_t workspace_bytes, rn_stream_t stream);
 
+/* ------------------------------------------------------------------ Winograd F(m x m, 3x3) convolution
+ * The 3x3 / stride-1 / SAME dense convolutions of the head towers and FPN merges (retinanet.py:39-46,87-94,
+ * 138-145) with 2.25x (tile = 2) or 4x (tile = 4) fewer multiply-adds: input transform -> (tile+2)^2 batched
+ * GEMMs on the fp32 matrix cores -> output transform (+ bias).  Segment fields as rn_conv2d_fwd (x, y, n, h, w;
+ * dense NHWC).  w is always the forward kernel [3,3,cin,cout]; with dgrad != 0 the call computes
+ * dx = conv(dy, rot180(w)^T) from the segments' dy / dx instead (the weight gradient keeps the direct
+ * rn_conv2d_wgrad).  cin and cout multiples of 4.  Results differ from the direct kernels only by the fp32
+ * rounding of the transforms (about 1e-6 of the output range for tile 2, 1e-5 for tile 4; tests: <= 1e-4). */
+size_t rn_conv3x3_winograd_workspace(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile);
+int rn_conv3x3_winograd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, const float* bias,
+                        int dgrad, int tile, void* workspace, size_t workspace_bytes, rn_stream_t stream);
+
 /* ------------------------------------------------------------------ fp16 inference convolution
  * BASELINE configs[4] ("Inference-only ResNeXt-50-FPN 1024x1024 bs=16, fp16"): forward conv on the f16
  * matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate).  Segment fields as rn_conv2d_fwd but x is

@@ -70,7 +70,7 @@ _lib = None
 SYMBOLS = [
     "rn_version", "rn_last_error", "rn_same_pad",
     "rn_conv2d_fwd", "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad",
-    "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad",
+    "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
     "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad",
     "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
@@ -94,7 +94,7 @@ def lib():
         L.rn_last_error.restype = C.c_char_p
         for name in ("rn_conv2d_wgrad_workspace", "rn_depthwise_wgrad_workspace", "rn_group_norm_workspace",
                      "rn_loss_workspace", "rn_detect_workspace", "rn_optimizer_workspace",
-                     "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace"):
+                     "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace", "rn_conv3x3_winograd_workspace"):
             getattr(L, name).restype = C.c_size_t
         L.rn_optimizer_workspace.argtypes = [C.c_int64]
         L.rn_depthwise_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
@@ -107,6 +107,9 @@ def lib():
         L.rn_conv2d_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_size_t, C.c_void_p]
         L.rn_conv2d_bias_grad_workspace.argtypes = [C.c_int]
+        L.rn_conv3x3_winograd_workspace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.rn_conv3x3_winograd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_conv2d_bias_grad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p]
         L.rn_group_norm_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

@@ -51,6 +51,10 @@ struct ConvArgs {
   int tiles_n;   // wgrad
   int cout;      // wgrad (all segments share it)
   float* slab;   // wgrad: [nsplit][ktotal][cout]
+  // batched GEMM mode (Winograd: one 1x1 "conv" per transform point): nseg == 1, the grid is nbatch copies of
+  // the segment's tiles, copy b uses a + b*bs_a, b + b*bs_b, out + b*bs_out (strides in floats)
+  int nbatch, btiles;
+  long bs_a, bs_b, bs_out;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -187,7 +191,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  int batch = 0;
+  if (args.nbatch > 1) { batch = bid / args.btiles; bid -= batch * args.btiles; }
   const int s = find_seg(args, bid);
   const SegDev& sg = args.seg[s];
   const int local = bid - sg.start;
@@ -203,8 +209,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
   const int nmax = (grp + 1) * cout_g;
   const int a_coff = sg.x_coff + grp * cin;
   const int ktotal = args.kh * args.kw * cin;
-  const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a, (unsigned)sg.n * H * W * ldx * 4u);
-  const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.b, (unsigned)ktotal * cout * 4u);
+  const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a + batch * args.bs_a, (unsigned)sg.n * H * W * ldx * 4u);
+  const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.b + batch * args.bs_b, (unsigned)ktotal * cout * 4u);
 
   // per-thread im2col rows (fixed for the whole K loop): element offset of (n, ih0, iw0, 0)
   const int kq = tid % KQ;
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
     mma_ktile<BM, BN, WM, WN, false, false>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
-  store_tile<BM, BN, WM, WN>(acc, sg.out, sg.bias, m0, n0, M, nmax, cout, wm, wn, lane);
+  store_tile<BM, BN, WM, WN>(acc, sg.out + batch * args.bs_out, sg.bias, m0, n0, M, nmax, cout, wm, wn, lane);
 }
 
 // =============================================================================================
@@ -294,7 +300,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  int batch = 0;
+  if (args.nbatch > 1) { batch = bid / args.btiles; bid -= batch * args.btiles; }
   const int s = find_seg(args, bid);
   const SegDev& sg = args.seg[s];
   const int local = bid - sg.start;
@@ -309,8 +317,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
   const int y_coff = grp * cout;                             // channel offset into dy and into w's cout axis
   const int x_coff = sg.x_coff + grp * cin;                  // channel offset into dx
   const int ktotal = args.kh * args.kw * cout;
-  const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.a, (unsigned)sg.n * OH * OW * ldy * 4u);
-  const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.b, (unsigned)args.kh * args.kw * cin * ldy * 4u);
+  const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.a + batch * args.bs_a, (unsigned)sg.n * OH * OW * ldy * 4u);
+  const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.b + batch * args.bs_b, (unsigned)args.kh * args.kw * cin * ldy * 4u);
 
   const int kq = tid % KQ, r0 = tid / KQ;
   int ihp[A_PASS], iwp[A_PASS], nb[A_PASS];
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
     mma_ktile<BM, BN, WM, WN, false, true>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
-  store_tile<BM, BN, WM, WN>(acc, sg.out, nullptr, m0, x_coff + n0, M, x_coff + cin, ldx, wm, wn, lane);
+  store_tile<BM, BN, WM, WN>(acc, sg.out + batch * args.bs_out, nullptr, m0, x_coff + n0, M, x_coff + cin, ldx, wm, wn, lane);
 }
 
 // =============================================================================================
@@ -554,7 +562,7 @@ constexpr int kNumCfg = 4;
 // 128x128 tiles is 2.6x slower per iteration than 8 blocks of 64x64).  All segments share K.
 const double kT0[kNumCfg] = {700, 550, 430, 430}, kT1[kNumCfg] = {1780, 1000, 515, 560};
 template <typename F>
-int choose_cfg(F dims, int nseg) {
+int choose_cfg(F dims, int nseg, int nbatch = 1) {
   if (const char* force = getenv("RN_CONV_CFG")) {  // tuning aid: force a tile shape (0..3)
     const int c = atoi(force);
     if (c >= 0 && c < kNumCfg) return c;
@@ -568,6 +576,7 @@ int choose_cfg(F dims, int nseg) {
       dims(s, &m, &n);
       tiles += ((m + kCfgs[c].bm - 1) / kCfgs[c].bm) * ((n + kCfgs[c].bn - 1) / kCfgs[c].bn);
     }
+    tiles *= nbatch;
     const double b = (double)((tiles + 255) / 256);
     const double cost = kT0[c] + kT1[c] * b;
     if (cost < best_cost) { best_cost = cost; best = c; }
@@ -625,9 +634,41 @@ int rn::launch_reduce_rows(const float* in, float* out, int64_t count, int nrows
 
 extern "C" void rn_same_pad(int n, int k, int s, int* out, int* pad_before) { rn::same_pad(n, k, s, out, pad_before); }
 
+namespace {
+struct Batch { int n; long bs_a, bs_b, bs_out; };
+int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream);
+int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream);
+}  // namespace
+
 extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream) {
+  return conv_fwd_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream);
+}
+extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream) {
+  return conv_dgrad_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream);
+}
+
+// C_b [M x N] = A_b [M x K] * B_b   for b = 0..nbatch-1 in one launch (Winograd's per-point products).
+// b_nk == 0: B_b is [K x N] (forward kernel);  b_nk != 0: B_b is [N x K] (the data-gradient kernel's layout).
+int rn::launch_batched_gemm(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, int b_nk,
+                            hipStream_t st) {
+  rn_conv_seg sg = {};
+  sg.n = 1; sg.h = 1; sg.w = M; sg.wgt = B;
+  rn_conv_geom g1 = {1, 1, 1, b_nk ? N : K, 1};
+  const Batch bt = {nbatch, (long)M * K, (long)K * N, (long)M * N};
+  if (b_nk) {
+    sg.dy = A; sg.dx = C; sg.cout = K;
+    return conv_dgrad_impl(&sg, 1, &g1, bt, (rn_stream_t)st);
+  }
+  sg.x = A; sg.y = C; sg.cout = N;
+  return conv_fwd_impl(&sg, 1, &g1, bt, (rn_stream_t)st);
+}
+
+namespace {
+int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream) {
   if (int e = validate_geom(segs, nseg, g)) return e;
+  RN_CHECK_ARG(bt.n == 1 || nseg == 1, "conv: batched mode takes one segment");
   ConvArgs a = {};
+  a.nbatch = bt.n; a.bs_a = bt.bs_a; a.bs_b = bt.bs_b; a.bs_out = bt.bs_out;
   const int G = ngroups(g);
   a.nseg = nseg; a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.cin = g->cin;
   a.groups = G; a.cin_g = g->cin / G;
@@ -645,7 +686,7 @@ extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
   }
   const int c = (G > 1 && a.seg[0].cout / G <= 64)
                     ? cfg_for_group_width(a.seg[0].cout / G)
-                    : choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m * G; *n = a.seg[s].cout / G; }, nseg);
+                    : choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m * G; *n = a.seg[s].cout / G; }, nseg, bt.n);
   a.tpg = G > 1 ? rn::ceil_div(a.seg[0].cout / G, kCfgs[c].bn) : (1 << 20);  // dense: every N-tile is "group 0"
   int tiles = 0;
   for (int s = 0; s < nseg; ++s) {
@@ -655,6 +696,8 @@ extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
     d.start = tiles;
     tiles += rn::ceil_div(d.m, kCfgs[c].bm) * d.tiles_n;
   }
+  a.btiles = tiles;
+  tiles *= bt.n;
   hipStream_t st = (hipStream_t)stream;
   const bool tapu = vec && (a.cin_g % BK == 0);
 #define RN_FWD(BM_, BN_, WM_, WN_)                                                                   \
@@ -674,9 +717,11 @@ extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
   return RN_OK;
 }
 
-extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream) {
+int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream) {
   if (int e = validate_geom(segs, nseg, g)) return e;
+  RN_CHECK_ARG(bt.n == 1 || nseg == 1, "conv: batched mode takes one segment");
   ConvArgs a = {};
+  a.nbatch = bt.n; a.bs_a = bt.bs_a; a.bs_b = bt.bs_b; a.bs_out = bt.bs_out;
   const int G = ngroups(g);
   a.nseg = nseg; a.kh = g->kh; a.kw = g->kw; a.stride = g->stride; a.cin = g->cin;
   a.groups = G; a.cin_g = g->cin / G;
@@ -694,7 +739,7 @@ extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
   }
   const int cin_g = a.cin_g;
   const int c = (G > 1 && cin_g <= 64) ? cfg_for_group_width(cin_g)
-                                        : choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m * G; *n = cin_g; }, nseg);
+                                        : choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m * G; *n = cin_g; }, nseg, bt.n);
   a.tpg = rn::ceil_div(cin_g, kCfgs[c].bn);
   int tiles = 0;
   for (int s = 0; s < nseg; ++s) {
@@ -703,6 +748,8 @@ extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
     d.start = tiles;
     tiles += rn::ceil_div(d.m, kCfgs[c].bm) * d.tiles_n;
   }
+  a.btiles = tiles;
+  tiles *= bt.n;
   hipStream_t st = (hipStream_t)stream;
   bool tapu = vec;
   for (int s = 0; s < nseg; ++s) tapu = tapu && ((segs[s].cout / G) % BK == 0);
@@ -722,6 +769,7 @@ extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
+}  // namespace
 
 namespace {
 struct WgradPlan {

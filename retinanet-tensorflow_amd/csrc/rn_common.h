@@ -36,6 +36,10 @@ void set_error(const char* fmt, ...);
     }                                                                         \
   } while (0)
 
+// C_b [M x N] = A_b [M x K] * B_b (b_nk == 0: B_b is [K x N]; else [N x K]) for nbatch contiguous matrices, one
+// launch of the implicit-GEMM conv kernels; defined in conv_gemm.hip.
+int launch_batched_gemm(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, int b_nk,
+                        hipStream_t st);
 // out[i] = (accumulate ? out[i] : 0) + sum_r in[r][i]  (r = 0..nrows-1, fixed order => reproducible).
 // 16 float4 columns x 16 row lanes per block; defined in conv_gemm.hip.
 int launch_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, hipStream_t st);

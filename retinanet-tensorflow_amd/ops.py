@@ -57,6 +57,36 @@ class _on_side_stream(object):
         return False
 
 
+# Winograd F(4x4,3x3) (or F(2x2,3x3): WINOGRAD_TILE = 2) for dense 3x3 / stride-1 convs wide enough to pay for
+# the transforms (head towers, FPN merges, the 720-wide class output conv): forward and data gradient; the
+# weight gradient stays direct.
+WINOGRAD = True
+WINOGRAD_TILE = 4
+WINOGRAD_MIN_CHANNELS = 64
+WINOGRAD_MAX_WORKSPACE = 1 << 30
+
+
+def _winograd_ok(w, stride, groups, xs):
+    kh, kw, cin, cout = w.shape
+    if not (WINOGRAD and kh == 3 and kw == 3 and stride == 1 and groups == 1):
+        return False
+    if cin % 4 or cout % 4 or min(cin, cout) < WINOGRAD_MIN_CHANNELS:
+        return False
+    m = WINOGRAD_TILE
+    tiles = sum(x.shape[0] * ((x.shape[1] + m - 1) // m) * ((x.shape[2] + m - 1) // m) for x in xs)
+    return 4 * (m + 2) ** 2 * (tiles * (cin + cout) + cin * cout) <= WINOGRAD_MAX_WORKSPACE
+
+
+def _winograd(segs, n, w, bias, dgrad):
+    L = _rn.lib()
+    cin, cout = w.shape[2], w.shape[3]
+    need = L.rn_conv3x3_winograd_workspace(segs, n, cin, cout, WINOGRAD_TILE)
+    ws = _rn.workspace(need, w.device)
+    _rn.check(L.rn_conv3x3_winograd(segs, n, cin, cout, _rn.f32(w), _rn.f32(bias) if bias is not None else None,
+                                    1 if dgrad else 0, WINOGRAD_TILE, ws.data_ptr(), ws.numel(), _rn.stream()),
+              "rn_conv3x3_winograd")
+
+
 def _as_list(x):
     return list(x) if isinstance(x, (list, tuple)) else [x]
 
@@ -104,7 +134,11 @@ class _Conv2dShared(torch.autograd.Function):
             ys.append(torch.empty((x.shape[0], oh, ow, cout), dtype=torch.float32, device=x.device))
         xs = [x.contiguous() for x in xs]
         segs = _conv_segs(xs, w, bias, ys, None, None)
-        _rn.check(L.rn_conv2d_fwd(segs, len(xs), C.byref(geom), _rn.stream()), "rn_conv2d_fwd")
+        ctx.winograd = _winograd_ok(w, stride, groups, xs)
+        if ctx.winograd:
+            _winograd(segs, len(xs), w, bias, False)
+        else:
+            _rn.check(L.rn_conv2d_fwd(segs, len(xs), C.byref(geom), _rn.stream()), "rn_conv2d_fwd")
         ctx.stride = stride
         ctx.groups = groups
         ctx.has_bias = bias is not None
@@ -133,7 +167,10 @@ class _Conv2dShared(torch.autograd.Function):
             idx = [i for i in range(n) if need_dx[i]]
             outs = [torch.empty_like(xs[i]) for i in idx]
             segs = _conv_segs([xs[i] for i in idx], w, None, None, [dys[i] for i in idx], outs)
-            _rn.check(L.rn_conv2d_dgrad(segs, len(idx), C.byref(geom), _rn.stream()), "rn_conv2d_dgrad")
+            if ctx.winograd:
+                _winograd(segs, len(idx), w, None, True)
+            else:
+                _rn.check(L.rn_conv2d_dgrad(segs, len(idx), C.byref(geom), _rn.stream()), "rn_conv2d_dgrad")
             for i, o in zip(idx, outs):
                 dxs[i] = o
         dw = db = None

@@ -40,12 +40,33 @@ CONV_CASES = [
     (2, 16, 16, 144, 24, 1, 1, False),       # MobileNet linear, C=144
     (1, 12, 10, 96, 256, 1, 1, False),       # FPN lateral
     (1, 20, 20, 8, 12, 7, 2, False),         # 7x7/2 (ResNeXt / DenseNet stem family)
+    (2, 7, 9, 64, 128, 3, 1, True),          # odd maps (Winograd edge tiles)
+    (3, 1, 1, 256, 256, 3, 1, False),        # P7-sized map: one partial tile per image
+    (1, 75, 75, 256, 256, 3, 1, False),      # P3 of a 600x600 image
 ]
 
 
-@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv2d_fwd_bwd(dev, case):
+def _winograd_eligible(case):
+    n, h, w, cin, cout, k, stride, use_bias = case
+    return k == 3 and stride == 1 and cin % 4 == 0 and cout % 4 == 0 and min(cin, cout) >= 64
+
+
+@pytest.fixture(params=["winograd4", "winograd2", "direct"])
+def conv_path(request):
+    """3x3 / stride-1 convs have three kernels (Winograd F(4x4,3x3), F(2x2,3x3), direct implicit GEMM): test all."""
     import ops
+    old = ops.WINOGRAD, ops.WINOGRAD_TILE
+    ops.WINOGRAD = request.param != "direct"
+    ops.WINOGRAD_TILE = 2 if request.param == "winograd2" else 4
+    yield request.param
+    ops.WINOGRAD, ops.WINOGRAD_TILE = old
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_fwd_bwd(dev, case, conv_path):
+    import ops
+    if conv_path != "direct" and not _winograd_eligible(case):
+        pytest.skip("direct kernel only")
     n, h, w, cin, cout, k, stride, use_bias = case
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
@@ -69,7 +90,7 @@ def test_conv2d_fwd_bwd(dev, case):
         assert_close(bg.grad.cpu().numpy(), bc.grad.numpy(), TOL, "conv bias grad")
 
 
-def test_conv2d_shared_kernel_over_pyramid_levels(dev):
+def test_conv2d_shared_kernel_over_pyramid_levels(dev, conv_path):
     """The head layers: one kernel, five maps of different sizes, ONE launch; wgrad sums levels."""
     import ops
     rng = np.random.default_rng(7)
