@@ -92,6 +92,16 @@ size_t rn_conv2d_bias_grad_workspace(int cout);
 int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dbias, void* workspace,
                         size_t workspace_bytes, rn_stream_t stream);
 
+/* ------------------------------------------------------------------ deferred gradient reductions
+ * Every weight-gradient entry point (rn_conv2d_wgrad, rn_depthwise_wgrad, rn_conv2d_bias_grad, the GroupNorm
+ * parameter gradients of rn_group_norm_bwd) ends with a fixed-order row reduction of per-block partial results.
+ * A training step has ~130 of them, each a launch-latency-bound kernel.  After rn_defer_reductions(stream, 1) they
+ * are recorded instead of launched and rn_flush_reductions(stream) runs them all as one launch (per 96).  While
+ * deferring, the `workspace` handed to those entry points must stay untouched until the flush (give each call its
+ * own buffer), and the gradients are only valid after the flush.  Results are bitwise identical to immediate mode. */
+int rn_defer_reductions(rn_stream_t stream, int on);
+int rn_flush_reductions(rn_stream_t stream);
+
 /* ------------------------------------------------------------------ Winograd F(m x m, 3x3) convolution
  * The 3x3 / stride-1 / SAME dense convolutions of the head towers and FPN merges (retinanet.py:39-46,87-94,
  * 138-145) with 2.25x (tile = 2) or 4x (tile = 4) fewer multiply-adds: input transform -> (tile+2)^2 batched
@@ -103,6 +113,12 @@ int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g
 size_t rn_conv3x3_winograd_workspace(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile);
 int rn_conv3x3_winograd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, const float* bias,
                         int dgrad, int tile, void* workspace, size_t workspace_bytes, rn_stream_t stream);
+/* Weight gradient of the same convolution in the Winograd domain: dU_xi = sum over tiles of
+ * (B^T d B)_xi^T (A dY A^T)_xi as (tile+2)^2 batched GEMMs with the reduction split across blocks (fixed-order
+ * sum), then dw[3,3,cin,cout] (+)= G^T dU G.  Segments: x, dy, n, h, w. */
+size_t rn_conv3x3_winograd_wgrad_workspace(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile);
+int rn_conv3x3_winograd_wgrad(const rn_conv_seg* segs, int nseg, int cin, int cout, float* dw, int accumulate, int tile,
+                              void* workspace, size_t workspace_bytes, rn_stream_t stream);
 
 /* ------------------------------------------------------------------ fp16 inference convolution
  * BASELINE configs[4] ("Inference-only ResNeXt-50-FPN 1024x1024 bs=16, fp16"): forward conv on the f16

@@ -71,6 +71,7 @@ SYMBOLS = [
     "rn_version", "rn_last_error", "rn_same_pad",
     "rn_conv2d_fwd", "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad",
     "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
+    "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_defer_reductions", "rn_flush_reductions",
     "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad",
     "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
@@ -94,7 +95,8 @@ def lib():
         L.rn_last_error.restype = C.c_char_p
         for name in ("rn_conv2d_wgrad_workspace", "rn_depthwise_wgrad_workspace", "rn_group_norm_workspace",
                      "rn_loss_workspace", "rn_detect_workspace", "rn_optimizer_workspace",
-                     "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace", "rn_conv3x3_winograd_workspace"):
+                     "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace", "rn_conv3x3_winograd_workspace",
+                     "rn_conv3x3_winograd_wgrad_workspace"):
             getattr(L, name).restype = C.c_size_t
         L.rn_optimizer_workspace.argtypes = [C.c_int64]
         L.rn_depthwise_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
@@ -108,6 +110,11 @@ def lib():
                                       C.c_size_t, C.c_void_p]
         L.rn_conv2d_bias_grad_workspace.argtypes = [C.c_int]
         L.rn_conv3x3_winograd_workspace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.rn_defer_reductions.argtypes = [C.c_void_p, C.c_int]
+        L.rn_flush_reductions.argtypes = [C.c_void_p]
+        L.rn_conv3x3_winograd_wgrad_workspace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.rn_conv3x3_winograd_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_conv3x3_winograd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                           C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_conv2d_bias_grad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

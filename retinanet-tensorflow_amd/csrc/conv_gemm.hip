@@ -17,6 +17,10 @@
 // panel) run on the same XCD and hit its L2.
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "rn_common.h"
 
 namespace {
@@ -422,8 +426,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
-  const int split = bid / args.tiles_mn, t = bid - split * args.tiles_mn;
+  int split = bid / args.tiles_mn;
+  const int t = bid - split * args.tiles_mn;
   const int tile_n = t % args.tiles_n, tile_m = t / args.tiles_n;
+  // batched mode (one segment): split id = batch * btiles + split within the batch; the slab is laid out
+  // [split within batch][batch][ktotal][cout] so that ONE row reduction sums the splits of every batch
+  int batch = 0, slab_row = split;
+  if (args.nbatch > 1) {
+    batch = split / args.btiles;
+    split -= batch * args.btiles;
+    slab_row = split * args.nbatch + batch;
+  }
   const int s = find_seg(args, split);
   const SegDev& sg = args.seg[s];
   const int p0 = (split - sg.start) * sg.chunk;
@@ -436,8 +449,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
   const int nmax = (grp + 1) * cout_g;
   const int x_coff = sg.x_coff + grp * cin;
   const int ktotal = args.ktotal;
-  const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a, (unsigned)sg.n * H * W * ldx * 4u);
-  const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.b, (unsigned)sg.m * cout * 4u);
+  const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a + batch * args.bs_a, (unsigned)sg.n * H * W * ldx * 4u);
+  const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.b + batch * args.bs_b, (unsigned)sg.m * cout * 4u);
 
   for (int i = tid; i < p1 - p0; i += T) {
     const int p = p0 + i;
@@ -498,18 +511,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
     mma_ktile<BM, BN, WM, WN, true, false>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
-  float* out = args.slab + (size_t)split * ktotal * cout;
+  float* out = args.slab + (size_t)slab_row * ktotal * cout;
   store_tile<BM, BN, WM, WN>(acc, out, nullptr, m0, n0, ktotal, nmax, cout, wm, wn, lane);
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_r in[r][i], fixed order => bitwise reproducible.
 // Block = 16 float4 columns x 16 row lanes: lane l sums rows l, l+16, ... (coalesced 256-B row
 // segments), the 16 lanes are combined in lane order through LDS.
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                          int64_t count, int nrows, int accumulate) {
+__device__ __forceinline__ void reduce_rows_block(const float* __restrict__ in, float* __restrict__ out, int64_t count, int nrows,
+                                                  int accumulate, int block) {
   __shared__ float4 sh[16][16];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int64_t i = ((int64_t)blockIdx.x * 16 + cl) * 4;
+  const int64_t i = ((int64_t)block * 16 + cl) * 4;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < count) {
     const bool full = (i + 4 <= count) && ((count & 3) == 0);
@@ -543,6 +556,31 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     if (i + 2 < count) out[i + 2] = t.z;
     if (i + 3 < count) out[i + 3] = t.w;
   }
+}
+
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          int64_t count, int nrows, int accumulate) {
+  reduce_rows_block(in, out, count, nrows, accumulate, blockIdx.x);
+}
+
+// Deferred mode (rn_defer_reductions): every row reduction recorded during a backward pass -- the split-K slabs of
+// ~70 weight gradients, the GroupNorm parameter-gradient rows -- runs as ONE launch instead of one
+// launch-latency-bound kernel each.
+constexpr int RN_MAX_REDUCE = 96;
+struct ReduceDesc { const float* in; float* out; int64_t count; int nrows, accumulate; };
+struct ReduceManyArgs {
+  ReduceDesc d[RN_MAX_REDUCE];
+  int block_start[RN_MAX_REDUCE + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void reduce_rows_many_kernel(const ReduceManyArgs a) {
+  int lo = 0, hi = a.n - 1;  // last descriptor whose first block is <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.block_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ReduceDesc& d = a.d[lo];
+  reduce_rows_block(d.in, d.out, d.count, d.nrows, d.accumulate, (int)blockIdx.x - a.block_start[lo]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -625,9 +663,67 @@ int validate_geom(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
 
 }  // namespace
 
+namespace {
+std::mutex g_defer_mu;
+std::map<hipStream_t, std::vector<ReduceDesc>> g_deferred;  // present key = deferring on that stream
+}  // namespace
+
+bool rn::reduce_deferred(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_defer_mu);
+  return g_deferred.count(st) != 0;
+}
+
 int rn::launch_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, hipStream_t st) {
+  {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    auto it = g_deferred.find(st);
+    if (it != g_deferred.end()) {
+      it->second.push_back(ReduceDesc{in, out, count, nrows, accumulate});
+      return RN_OK;
+    }
+  }
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rn::ceil_div64(count, 64)), dim3(256), 0, st, in, out, count, nrows,
                      accumulate);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+// on != 0: row reductions issued on `stream` from now on are recorded, not launched; their inputs (the callers'
+// workspaces) must stay untouched until rn_flush_reductions.  on == 0: flush, then back to immediate mode.
+extern "C" int rn_defer_reductions(rn_stream_t stream, int on) {
+  hipStream_t st = (hipStream_t)stream;
+  if (on) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    g_deferred[st];
+    return RN_OK;
+  }
+  if (int e = rn_flush_reductions(stream)) return e;
+  std::lock_guard<std::mutex> lk(g_defer_mu);
+  g_deferred.erase(st);
+  return RN_OK;
+}
+
+extern "C" int rn_flush_reductions(rn_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<ReduceDesc> todo;
+  {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    auto it = g_deferred.find(st);
+    if (it == g_deferred.end()) return RN_OK;
+    todo.swap(it->second);
+  }
+  for (size_t first = 0; first < todo.size(); first += RN_MAX_REDUCE) {
+    ReduceManyArgs a = {};
+    a.n = (int)(todo.size() - first < (size_t)RN_MAX_REDUCE ? todo.size() - first : (size_t)RN_MAX_REDUCE);
+    int blocks = 0;
+    for (int i = 0; i < a.n; ++i) {
+      a.d[i] = todo[first + i];
+      a.block_start[i] = blocks;
+      blocks += (int)rn::ceil_div64(a.d[i].count, 64);
+    }
+    a.block_start[a.n] = blocks;
+    if (blocks > 0) hipLaunchKernelGGL(reduce_rows_many_kernel, dim3(blocks), dim3(256), 0, st, a);
+  }
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
@@ -778,7 +874,7 @@ struct WgradPlan {
       pl[RN_MAX_SEG];
 };
 
-int plan_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, WgradPlan* p) {
+int plan_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, WgradPlan* p, int nbatch = 1) {
   const int G = ngroups(g);
   p->ktotal = g->kh * g->kw * (g->cin / G);
   p->cout = segs[0].cout;
@@ -801,6 +897,7 @@ int plan_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, WgradPl
                  kCfgs[c].bn * kCfgs[c].penalty;
       if (w < best) { best = w; p->cfg = c; }
     }
+    if (nbatch > 1) p->cfg = 2;  // batched (Winograd) products: many small outputs, 64x64 measured best
     if (const char* force = getenv("RN_WGRAD_CFG")) {  // tuning aid
       const int c = atoi(force);
       if (c >= 0 && c < kNumCfg) p->cfg = c;
@@ -813,7 +910,10 @@ int plan_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, WgradPl
   const int tiles_mn = p->tiles_m * p->tiles_n;
   // aim for ~768 blocks (3 per CU): enough to fill the chip, few enough that the slab traffic
   // (nsplit x |dW| written + read) stays small; each split reduces >= 64 pixels
-  long want_splits = (768 + tiles_mn - 1) / tiles_mn;
+  long want_splits = (768 + (long)tiles_mn * nbatch - 1) / ((long)tiles_mn * nbatch);
+  if (const char* force = getenv("RN_WGRAD_SPLITS")) {  // tuning aid
+    if (atoi(force) > 0) want_splits = atoi(force);
+  }
   long chunk = (total_pixels + want_splits - 1) / want_splits;
   chunk = (chunk + BK - 1) / BK * BK;
   if (chunk < 2 * BK) chunk = 2 * BK;
@@ -836,13 +936,44 @@ extern "C" size_t rn_conv2d_wgrad_workspace(const rn_conv_seg* segs, int nseg, c
   return (size_t)p.nsplit * p.ktotal * p.cout * sizeof(float);
 }
 
+namespace {
+int conv_wgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, int accumulate, void* workspace,
+                    size_t workspace_bytes, const Batch& bt, rn_stream_t stream, int* nsplit_out = nullptr);
+}
 extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, int accumulate,
                                void* workspace, size_t workspace_bytes, rn_stream_t stream) {
-  if (int e = validate_geom(segs, nseg, g)) return e;
-  RN_CHECK_ARG(dw && workspace, "conv wgrad: null dw/workspace");
+  return conv_wgrad_impl(segs, nseg, g, dw, accumulate, workspace, workspace_bytes, Batch{1, 0, 0, 0}, stream);
+}
+
+// C_b [K x N] = A_b^T B_b for A_b [M x K], B_b [M x N], b = 0..nbatch-1 (Winograd weight gradient: the sum over
+// tiles of V_xi^T dM_xi).  The reduction over M is split across blocks; the partial products go through
+// `workspace` (rn::batched_gemm_tn_workspace bytes) and one fixed-order row reduction.
+size_t rn::batched_gemm_tn_workspace(int M, int K, int N, int nbatch) {
+  rn_conv_seg sg = {};
+  sg.n = 1; sg.h = 1; sg.w = M; sg.cout = N;
+  rn_conv_geom g1 = {1, 1, 1, K, 1};
   WgradPlan p;
-  if (int e = plan_wgrad(segs, nseg, g, &p)) return e;
-  const size_t need = (size_t)p.nsplit * p.ktotal * p.cout * sizeof(float);
+  if (plan_wgrad(&sg, 1, &g1, &p, nbatch)) return 0;
+  return (size_t)p.nsplit * nbatch * K * N * sizeof(float);
+}
+int rn::launch_batched_gemm_tn(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, void* workspace,
+                               size_t workspace_bytes, hipStream_t st, int* nsplit_out) {
+  rn_conv_seg sg = {};
+  sg.n = 1; sg.h = 1; sg.w = M; sg.cout = N; sg.x = A; sg.dy = B;
+  rn_conv_geom g1 = {1, 1, 1, K, 1};
+  return conv_wgrad_impl(&sg, 1, &g1, C, 0, workspace, workspace_bytes, Batch{nbatch, (long)M * K, (long)M * N, 0},
+                         (rn_stream_t)st, nsplit_out);
+}
+
+namespace {
+int conv_wgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, int accumulate, void* workspace,
+                    size_t workspace_bytes, const Batch& bt, rn_stream_t stream, int* nsplit_out) {
+  if (int e = validate_geom(segs, nseg, g)) return e;
+  RN_CHECK_ARG((dw || nsplit_out) && workspace, "conv wgrad: null dw/workspace");
+  RN_CHECK_ARG(bt.n == 1 || nseg == 1, "conv: batched mode takes one segment");
+  WgradPlan p;
+  if (int e = plan_wgrad(segs, nseg, g, &p, bt.n)) return e;
+  const size_t need = (size_t)p.nsplit * bt.n * p.ktotal * p.cout * sizeof(float);
   if (workspace_bytes < need) {
     rn::set_error("conv wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
     return RN_EWORKSPACE;
@@ -852,6 +983,7 @@ extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
   a.groups = ngroups(g); a.cin_g = g->cin / a.groups; a.tpg = p.tpg;
   a.ktotal = p.ktotal; a.cout = p.cout; a.tiles_n = p.tiles_n; a.tiles_mn = p.tiles_m * p.tiles_n;
   a.slab = (float*)workspace;
+  a.nbatch = bt.n; a.btiles = p.nsplit; a.bs_a = bt.bs_a; a.bs_b = bt.bs_b;
   for (int s = 0; s < nseg; ++s) {
     RN_CHECK_ARG(segs[s].x && segs[s].dy, "conv wgrad: null pointer in segment %d", s);
     SegDev& d = a.seg[s];
@@ -861,7 +993,7 @@ extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
     set_x_view(d, segs[s], g->cin);
   }
   const bool vec = (a.cin_g % 4 == 0) && ((p.cout / a.groups) % 4 == 0);
-  const int blocks = p.nsplit * a.tiles_mn;
+  const int blocks = p.nsplit * bt.n * a.tiles_mn;
   hipStream_t st = (hipStream_t)stream;
 #define RN_WG(BM_, BN_, WM_, WN_)                                                                    \
   do {                                                                                               \
@@ -876,8 +1008,13 @@ extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
   }
 #undef RN_WG
   RN_LAUNCH_CHECK();
-  return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)p.ktotal * p.cout, p.nsplit, accumulate, st);
+  if (nsplit_out) {  // the caller sums the [nsplit][batch][ktotal][cout] partial products itself
+    *nsplit_out = p.nsplit;
+    return RN_OK;
+  }
+  return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)bt.n * p.ktotal * p.cout, p.nsplit, accumulate, st);
 }
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // bias gradient: column sums of dy over every pixel of every segment (two fixed-order stages)

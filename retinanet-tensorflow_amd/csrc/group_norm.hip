@@ -35,6 +35,8 @@ struct GnArgs {
   float* coef;     // bwd: [samples][groups][2]
   float* dgamma; float* dbeta;
   int total_chunks, total_samples;
+  int slice_wc;    // slice-resident path: channels per block (a whole number of groups), 0 = not used
+  float* pgrad;    // slice-resident bwd: [2][total_samples][c] per-sample sum g (plane 0) and sum g*xhat (plane 1)
 };
 
 __device__ __forceinline__ int seg_of_sample(const GnArgs& a, int q) {
@@ -322,6 +324,302 @@ __global__ __launch_bounds__(T) void gn_apply_f16x8_kernel(const GnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Slice-resident path: when one (sample, group-block) slice fits the registers of a 512-thread block
+// (hw * channels <= 16 K values: the GroupNorms at 1/16 resolution and below, about half of the calls) the whole GroupNorm is ONE kernel -- x is read once, the statistics are an exact two-pass
+// mean / variance over registers, and y is written once -- instead of partial + finalize + apply (three
+// launch-latency-bound kernels and a second read of x).  Backward likewise: x and dy read once, dx written
+// once, per-sample (sum g, sum g*xhat) rows for the parameter gradients summed by a tiny second kernel.
+// A block owns `wc` consecutive channels (gb whole groups, so that narrow groups still give >= 32-byte runs);
+// thread t owns channel t % wc and pixels t / wc + k * ppt, k < R.  All reductions run in a fixed order.
+// ---------------------------------------------------------------------------------------------
+constexpr int ST = 512;  // 8 waves: 256 VGPRs per lane, so 32 values (+ 32 residuals / gradients) stay in registers
+constexpr int SLICE_MAX_R = 32, SLICE_MAX_WC = 64, SLICE_J = ST / SLICE_MAX_WC;
+
+// per-channel sums of NV values over the pixel lanes of the block -> out[cw * NV + i]
+template <int NV>
+__device__ __forceinline__ void slice_channel_sums(const float (&val)[NV], int tid, int wc, int ppt, bool active, float* red,
+                                                   float* red2, float* out) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) red[tid * NV + i] = active ? val[i] : 0.f;
+  __syncthreads();
+  if (tid < wc * SLICE_J) {
+    const int cw = tid % wc, j = tid / wc;
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+    for (int pl = j; pl < ppt; pl += SLICE_J)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc[i] += red[(pl * wc + cw) * NV + i];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red2[(j * SLICE_MAX_WC + cw) * NV + i] = acc[i];
+  }
+  __syncthreads();
+  if (tid < wc) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < SLICE_J; ++j) t += red2[(j * SLICE_MAX_WC + tid) * NV + i];
+      out[tid * NV + i] = t;
+    }
+  }
+  __syncthreads();
+}
+
+template <int R, int ACT>
+__global__ __launch_bounds__(ST) void gn_slice_fwd_kernel(const GnArgs a) {
+  __shared__ float red[ST], red2[SLICE_J * SLICE_MAX_WC], csum[SLICE_MAX_WC], gstat[SLICE_MAX_WC];
+  const int tid = threadIdx.x, wc = a.slice_wc, cpg = a.cpg, C = a.c;
+  const int gb = wc / cpg, gblocks = a.groups / gb;
+  const int q = blockIdx.x / gblocks, gbk = blockIdx.x - q * gblocks;
+  const GnSeg& sg = a.seg[seg_of_sample(a, q)];
+  const int nl = q - sg.sample_start, hw = sg.hw;
+  const int ppt = ST / wc, cw = tid % wc, pl = tid / wc;
+  const bool active = pl < ppt;
+  const int c = gbk * wc + cw;
+  const size_t base = (size_t)nl * hw * C;
+  const float* __restrict__ x = sg.x + base;  // block-uniform base + 32-bit per-lane offsets (p * C + c)
+  float v[R];
+  float s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int p = pl + k * ppt;
+    // branch-free: load from a clamped pixel, then zero the lanes past the end (a conditional load compiles to
+    // a branch + wait per pixel and serialises the R round trips)
+    const float t = x[(unsigned)(min(p, hw - 1) * C + c)];
+    v[k] = t * ((active && p < hw) ? 1.f : 0.f);  // a multiply, not a select: the compiler sinks a selected load
+    s1 += v[k];                                    // back under a branch
+
+  }
+  const float inv_m = 1.f / ((float)hw * (float)cpg);
+  {
+    const float val[1] = {s1};
+    slice_channel_sums<1>(val, tid, wc, ppt, active, red, red2, csum);
+  }
+  if (tid < gb) {
+    float t = 0.f;
+    for (int j = 0; j < cpg; ++j) t += csum[tid * cpg + j];
+    gstat[tid] = t * inv_m;
+  }
+  __syncthreads();
+  const float mean = gstat[cw / cpg];
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int p = pl + k * ppt;
+    const float d = v[k] - mean;
+    s2 += (active && p < hw) ? d * d : 0.f;
+  }
+  __syncthreads();  // gstat (means) read by everyone before it is overwritten below
+  {
+    const float val[1] = {s2};
+    slice_channel_sums<1>(val, tid, wc, ppt, active, red, red2, csum);
+  }
+  if (tid < gb) {
+    float t = 0.f;
+    for (int j = 0; j < cpg; ++j) t += csum[tid * cpg + j];
+    const float rstd = 1.f / sqrtf(t * inv_m + a.eps);
+    const int g = gbk * gb + tid;
+    sg.mean[nl * a.groups + g] = gstat[tid];
+    sg.rstd[nl * a.groups + g] = rstd;
+    gstat[tid] = rstd;
+  }
+  __syncthreads();
+  if (!active) return;
+  const float rstd = gstat[cw / cpg];
+  const float sc = rstd * a.gamma[c], sh = a.beta[c] - mean * sc;
+  const bool drop = a.drop_rate > 0.f;
+  const float keep_scale = drop ? 1.f / (1.f - a.drop_rate) : 1.f;
+  const uint64_t samp_off = (uint64_t)q * (uint64_t)hw * (uint64_t)C;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+  const float* __restrict__ res = sg.res ? sg.res + base : nullptr;
+  float* __restrict__ y = sg.y + base;
+  float rr[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) rr[k] = 0.f;
+  if (res) {  // all residual loads in flight together
+#pragma unroll
+    for (int k = 0; k < R; ++k) rr[k] = res[(unsigned)(min(pl + k * ppt, hw - 1) * C + c)];
+  }
+  const bool aar = a.act_after_res != 0;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int p = pl + k * ppt;
+    const unsigned off = (unsigned)(p * C + c);
+    const float z = v[k] * sc + sh;
+    const float r = rr[k];
+    float o = rn::act_fwd(aar ? z + r : z, ACT);
+    if (drop) o = (rn::uniform01(seed, samp_off + off) >= a.drop_rate) ? o * keep_scale : 0.f;
+    if (p < hw) y[off] = aar ? o : o + r;
+  }
+}
+
+template <int R, int ACT>
+__global__ __launch_bounds__(ST) void gn_slice_bwd_kernel(const GnArgs a) {
+  __shared__ float red[ST * 2], red2[SLICE_J * SLICE_MAX_WC * 2], csum[SLICE_MAX_WC * 2], gcoef[SLICE_MAX_WC][2];
+  const int tid = threadIdx.x, wc = a.slice_wc, cpg = a.cpg, C = a.c;
+  const int gb = wc / cpg, gblocks = a.groups / gb;
+  const int q = blockIdx.x / gblocks, gbk = blockIdx.x - q * gblocks;
+  const GnSeg& sg = a.seg[seg_of_sample(a, q)];
+  const int nl = q - sg.sample_start, hw = sg.hw;
+  const int ppt = ST / wc, cw = tid % wc, pl = tid / wc;
+  const bool active = pl < ppt;
+  const int c = gbk * wc + cw;
+  const int g = c / cpg;
+  const size_t base = (size_t)nl * hw * C;
+  const float mean = sg.mean[nl * a.groups + g], rstd = sg.rstd[nl * a.groups + g];
+  const float gam = a.gamma[c], bet = a.beta[c];
+  const bool aar = a.act_after_res && sg.res;
+  const bool drop = a.drop_rate > 0.f;
+  const float keep_scale = drop ? 1.f / (1.f - a.drop_rate) : 1.f;
+  const uint64_t samp_off = (uint64_t)q * (uint64_t)hw * (uint64_t)C;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+  const float* __restrict__ x = sg.x + base;  // block-uniform bases + 32-bit per-lane offsets (p * C + c)
+  const float* __restrict__ dy = sg.dy + base;
+  const float* __restrict__ res = aar ? sg.res + base : nullptr;
+  // x / dy are loaded once and overwritten in place by xhat / g = dy * dropmask * act'(z)
+  constexpr int RR = R;
+  float xh[RR], gr[RR];
+  auto grad_at = [&](float xv, float dyv, unsigned off, float& h) {
+    h = (xv - mean) * rstd;
+    float z = h * gam + bet;
+    if (res) z += res[off];
+    float gg = dyv;
+    if (drop) gg = (rn::uniform01(seed, samp_off + off) >= a.drop_rate) ? gg * keep_scale : 0.f;
+    return gg * rn::act_grad(z, ACT);
+  };
+  float sb = 0.f, sgm = 0.f;
+  {
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {  // clamped pixel, masked below: unconditional loads, all in flight together
+      const unsigned off = (unsigned)(min(pl + k * ppt, hw - 1) * C + c);
+      xh[k] = x[off];
+      gr[k] = dy[off];
+    }
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {
+      const int p = pl + k * ppt;
+      const unsigned off = (unsigned)(min(p, hw - 1) * C + c);
+      float h;
+      float gg = grad_at(xh[k], gr[k], off, h);
+      gg *= (active && p < hw) ? 1.f : 0.f;  // multiply, not select (see the forward kernel)
+      xh[k] = h;
+      gr[k] = gg;
+      sb += gg; sgm += gg * h;
+    }
+  }
+  {
+    const float val[2] = {sb, sgm};
+    slice_channel_sums<2>(val, tid, wc, ppt, active, red, red2, csum);
+  }
+  if (tid < wc) {  // this sample's contribution to dbeta / dgamma of channel gbk*wc + tid: two [samples][C] planes
+    float* pg = a.pgrad + (size_t)q * C + gbk * wc + tid;
+    pg[0] = csum[tid * 2];
+    pg[(size_t)a.total_samples * C] = csum[tid * 2 + 1];
+  }
+  if (tid < gb) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int j = 0; j < cpg; ++j) {
+      const float gm = a.gamma[gbk * wc + tid * cpg + j];
+      t1 += gm * csum[(tid * cpg + j) * 2];
+      t2 += gm * csum[(tid * cpg + j) * 2 + 1];
+    }
+    const float inv_m = 1.f / ((float)hw * (float)cpg);
+    gcoef[tid][0] = t1 * inv_m;
+    gcoef[tid][1] = t2 * inv_m;
+  }
+  __syncthreads();
+  if (!active) return;
+  const float c1 = gcoef[cw / cpg][0], c2 = gcoef[cw / cpg][1];
+  float* __restrict__ dx = sg.dx + base;
+  float* __restrict__ dres = (aar && sg.dres) ? sg.dres + base : nullptr;
+  {
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {
+      const int p = pl + k * ppt;
+      if (p < hw) {
+        const unsigned off = (unsigned)(p * C + c);
+        dx[off] = rstd * (gam * gr[k] - c1 - xh[k] * c2);
+        if (dres) dres[off] = gr[k];
+      }
+    }
+  }
+}
+
+// dbeta_c / dgamma_c = sum over all samples (fixed order) of the per-sample rows
+__global__ __launch_bounds__(256) void gn_param_grad_kernel(const GnArgs a) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.c) return;
+  const float* pb = a.pgrad + c;
+  const float* pgm = a.pgrad + (size_t)a.total_samples * a.c + c;
+  float b = 0.f, g = 0.f;
+  int q = 0;
+  for (; q + 4 <= a.total_samples; q += 4) {  // eight loads in flight, added in sample order
+    float vb[4], vg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { vb[j] = pb[(size_t)(q + j) * a.c]; vg[j] = pgm[(size_t)(q + j) * a.c]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { b += vb[j]; g += vg[j]; }
+  }
+  for (; q < a.total_samples; ++q) { b += pb[(size_t)q * a.c]; g += pgm[(size_t)q * a.c]; }
+  a.dbeta[c] = b;
+  a.dgamma[c] = g;
+}
+
+// choose the block width of the slice-resident path; returns R (pixels per thread) or 0 when a slice does not fit
+int plan_slices(GnArgs* a) {
+  a->slice_wc = 0;
+  if (getenv("RN_GN_NO_SLICE")) return 0;  // tuning aid: force the three-kernel path
+  if (a->in_half || a->out_half || a->cpg > SLICE_MAX_WC || a->act == RN_ACT_SIGMOID) return 0;
+  int max_hw = 0;
+  for (int s = 0; s < a->nseg; ++s) max_hw = max_hw > a->seg[s].hw ? max_hw : a->seg[s].hw;
+  // gb whole groups per block: the widest run of channels (up to a 128-byte line) that still fits the registers --
+  // a block that uses only part of every line it touches multiplies its L2 traffic
+  int best = 0;
+  for (int gb = 1; gb <= a->groups; ++gb) {
+    if (a->groups % gb) continue;
+    const int wc = gb * a->cpg;
+    if (wc > SLICE_MAX_WC) break;
+    if ((long)max_hw > (long)SLICE_MAX_R * (ST / wc)) break;
+    best = wc;
+    if (wc >= 32) break;
+  }
+  if (!best) return 0;
+  a->slice_wc = best;
+  const int need = rn::ceil_div(max_hw, ST / best);
+  int r = 1;
+  while (r < need) r *= 2;
+  return r;
+}
+
+template <bool BWD, int ACT>
+void launch_slices_act(const GnArgs& a, int r, hipStream_t st) {
+  const unsigned blocks = (unsigned)(a.total_samples * (a.groups / (a.slice_wc / a.cpg)));
+#define RN_GN_SLICE(R_)                                                                                  \
+  do {                                                                                                   \
+    if (BWD) hipLaunchKernelGGL((gn_slice_bwd_kernel<R_, ACT>), dim3(blocks), dim3(ST), 0, st, a);       \
+    else hipLaunchKernelGGL((gn_slice_fwd_kernel<R_, ACT>), dim3(blocks), dim3(ST), 0, st, a);           \
+  } while (0)
+  switch (r) {
+    case 1: case 2: RN_GN_SLICE(2); break;
+    case 4: RN_GN_SLICE(4); break;
+    case 8: RN_GN_SLICE(8); break;
+    case 16: RN_GN_SLICE(16); break;
+    default: RN_GN_SLICE(32); break;
+  }
+#undef RN_GN_SLICE
+}
+template <bool BWD>
+void launch_slices(const GnArgs& a, int r, hipStream_t st) {
+  switch (a.act) {  // the activation is a compile-time constant of the slice kernels (no per-element switch)
+    case RN_ACT_RELU: launch_slices_act<BWD, RN_ACT_RELU>(a, r, st); break;
+    case RN_ACT_ELU: launch_slices_act<BWD, RN_ACT_ELU>(a, r, st); break;
+    case RN_ACT_RELU6: launch_slices_act<BWD, RN_ACT_RELU6>(a, r, st); break;
+    default: launch_slices_act<BWD, RN_ACT_NONE>(a, r, st); break;
+  }
+}
+
 int build_args(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, GnArgs* a, bool bwd) {
   RN_CHECK_ARG(segs && p, "group_norm: null argument");
   RN_CHECK_ARG(nseg >= 1 && nseg <= RN_MAX_SEG, "group_norm: nseg %d outside [1,%d]", nseg, RN_MAX_SEG);
@@ -407,6 +705,11 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   }
   a.gamma = gamma; a.beta = beta; a.partial = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
+  if (const int r = plan_slices(&a)) {
+    launch_slices<false>(a, r, st);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+  }
   hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(a.total_chunks), dim3(T), 0, st, a);
   hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(a.total_samples * a.groups), dim3(T), 0, st, a);
   if (a.in_half && a.out_half && a.c % 8 == 0 && a.drop_rate == 0.f)
@@ -431,6 +734,18 @@ extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   a.partial = (float*)workspace;
   a.coef = (float*)((char*)workspace + rn::align_up((size_t)a.total_chunks * a.c * 2 * sizeof(float), 256));
   hipStream_t st = (hipStream_t)stream;
+  if (const int r = plan_slices(&a)) {
+    a.pgrad = (float*)workspace;  // [2][total_samples][c] <= the chunk-partial area (chunks >= samples)
+    launch_slices<true>(a, r, st);
+    if (rn::reduce_deferred(st)) {  // the two row sums join the step's single deferred reduction launch
+      RN_LAUNCH_CHECK();
+      if (int e = rn::launch_reduce_rows(a.pgrad, dbeta, a.c, a.total_samples, 0, st)) return e;
+      return rn::launch_reduce_rows(a.pgrad + (size_t)a.total_samples * a.c, dgamma, a.c, a.total_samples, 0, st);
+    }
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3(rn::ceil_div(a.c, 256)), dim3(256), 0, st, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+  }
   hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(a.total_chunks), dim3(T), 0, st, a);
   hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(a.total_samples * a.groups + rn::ceil_div(a.c, 16)), dim3(T), 0, st, a);
   hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(apply_blocks(a), a.total_samples), dim3(T), 0, st, a);

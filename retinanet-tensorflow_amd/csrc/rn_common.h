@@ -40,6 +40,13 @@ void set_error(const char* fmt, ...);
 // launch of the implicit-GEMM conv kernels; defined in conv_gemm.hip.
 int launch_batched_gemm(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, int b_nk,
                         hipStream_t st);
+// C_b [K x N] = A_b^T B_b for A_b [M x K], B_b [M x N]; split reduction through `workspace`, fixed order.
+size_t batched_gemm_tn_workspace(int M, int K, int N, int nbatch);
+// nsplit_out != nullptr: no final reduction; the partial products stay in workspace as [nsplit][nbatch][K][N].
+int launch_batched_gemm_tn(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, void* workspace,
+                           size_t workspace_bytes, hipStream_t st, int* nsplit_out = nullptr);
+// true while row reductions on `st` are being recorded for rn_flush_reductions instead of launched
+bool reduce_deferred(hipStream_t st);
 // out[i] = (accumulate ? out[i] : 0) + sum_r in[r][i]  (r = 0..nrows-1, fixed order => reproducible).
 // 16 float4 columns x 16 row lanes per block; defined in conv_gemm.hip.
 int launch_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, hipStream_t st);

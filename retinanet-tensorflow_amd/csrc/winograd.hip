@@ -59,6 +59,16 @@ struct Wino<2> {
   static __device__ __forceinline__ void g(const float (&w)[3], float (&u)[4]) {
     u[0] = w[0]; u[1] = 0.5f * (w[0] + w[1] + w[2]); u[2] = 0.5f * (w[0] - w[1] + w[2]); u[3] = w[2];
   }
+  // A (4x2): the gradient of the output transform, dM = A dY A^T
+  template <typename V>
+  static __device__ __forceinline__ void a(const V (&y)[2], V (&m)[4]) {
+    m[0] = y[0]; m[1] = y[0] + y[1]; m[2] = y[0] - y[1]; m[3] = (V)(0.f) - y[1];
+  }
+  // G^T (3x4): the gradient of the kernel transform, dg = G^T dU G
+  static __device__ __forceinline__ void gt(const float (&u)[4], float (&w)[3]) {
+    const float s = 0.5f * (u[1] + u[2]);
+    w[0] = u[0] + s; w[1] = 0.5f * (u[1] - u[2]); w[2] = s + u[3];
+  }
 };
 
 template <>
@@ -91,6 +101,20 @@ struct Wino<4> {
     u[3] = q + (1.f / 12.f) * w[1];
     u[4] = q - (1.f / 12.f) * w[1];
     u[5] = w[2];
+  }
+  // A (6x4) = [1 0 0 0; 1 1 1 1; 1 -1 1 -1; 1 2 4 8; 1 -2 4 -8; 0 0 0 1]
+  template <typename V>
+  static __device__ __forceinline__ void a(const V (&y)[4], V (&m)[6]) {
+    const V e = y[0] + y[2], o = y[1] + y[3];
+    const V e4 = y[0] + 4.f * y[2], o4 = 2.f * y[1] + 8.f * y[3];
+    m[0] = y[0]; m[1] = e + o; m[2] = e - o; m[3] = e4 + o4; m[4] = e4 - o4; m[5] = y[3];
+  }
+  // G^T (3x6)
+  static __device__ __forceinline__ void gt(const float (&u)[6], float (&w)[3]) {
+    const float s12 = u[1] + u[2], s34 = u[3] + u[4];
+    w[0] = 0.25f * u[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+    w[1] = (1.f / 6.f) * (u[2] - u[1]) + (1.f / 12.f) * (u[3] - u[4]);
+    w[2] = (1.f / 6.f) * (s34 - s12) + u[5];
   }
 };
 
@@ -188,6 +212,82 @@ __global__ __launch_bounds__(NT) void wino_output_kernel(const WArgs a) {
   }
 }
 
+// weight gradient, stage 2: dM [P][T][C] = A dY A^T per m x m output-gradient tile (zeros outside the map)
+template <int M, int W>
+__global__ __launch_bounds__(NT) void wino_dy_kernel(const WArgs a) {
+  typedef typename VecW<W>::type VT;
+  constexpr int P = M + 2;
+  const int CQ = a.c / W;
+  const int64_t total = (int64_t)a.total_tiles * CQ;
+  const size_t plane = (size_t)a.total_tiles * a.c;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int q4 = (int)(i % CQ);
+    const int t = (int)(i / CQ);
+    const WSeg& sg = a.seg[seg_of_tile(a, t)];
+    int lt = t - sg.tile_start;
+    const int tx = lt % sg.tw; lt /= sg.tw;
+    const int ty = lt % sg.th;
+    const int n_ = lt / sg.th;
+    const int y0 = M * ty, x0 = M * tx;
+    VT tm[P][M];  // tm[xi][c] = (A dY)[xi][c]
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      VT col[M], o[P];
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        const bool ok = y0 + r < sg.h && x0 + c < sg.w;
+        const int yc = min(y0 + r, sg.h - 1), xc = min(x0 + c, sg.w - 1);
+        const VT v = *reinterpret_cast<const VT*>(sg.x + ((size_t)(n_ * sg.h + yc) * sg.w + xc) * a.c + q4 * W);
+        col[r] = ok ? v : (VT)(0.f);
+      }
+      Wino<M>::a(col, o);
+#pragma unroll
+      for (int r = 0; r < P; ++r) tm[r][c] = o[r];
+    }
+    float* out = a.buf + (size_t)t * a.c + q4 * W;
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+      VT row[P];
+      Wino<M>::a(tm[r], row);
+#pragma unroll
+      for (int c = 0; c < P; ++c) *reinterpret_cast<VT*>(out + (size_t)(r * P + c) * plane) = row[c];
+    }
+  }
+}
+
+// weight gradient, stage 4: dw[3][3][k][n] (+)= G^T dU G for dU [P][k][n]
+// du holds `nsplit` partial sums of dU (the split reduction of the batched GEMM), added here in split order.
+template <int M>
+__global__ void wino_dw_kernel(const float* __restrict__ du, float* __restrict__ dw, int64_t kn, int nsplit, int accumulate) {
+  constexpr int P = M + 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kn) return;
+  const size_t split_stride = (size_t)P * P * kn;
+  float t[P][3];  // t[b][.] = (G^T dU)[., b]
+#pragma unroll
+  for (int b = 0; b < P; ++b) {
+    float col[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) col[a] = du[(size_t)(a * P + b) * kn + i];
+    for (int sp = 1; sp < nsplit; ++sp)
+#pragma unroll
+      for (int a = 0; a < P; ++a) col[a] += du[sp * split_stride + (size_t)(a * P + b) * kn + i];
+    Wino<M>::gt(col, t[b]);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float row[P], o[3];
+#pragma unroll
+    for (int b = 0; b < P; ++b) row[b] = t[b][a];
+    Wino<M>::gt(row, o);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float* q = dw + (size_t)(a * 3 + b) * kn + i;
+      *q = accumulate ? *q + o[b] : o[b];
+    }
+  }
+}
+
 // U[xi][k][n] = (G g G^T)[xi] for g = w[:, :, k, n] (rot == 0) or its 180-degree rotation (rot != 0, the
 // data-gradient kernel); [k][n] = [cin][cout] either way.
 template <int M>
@@ -213,7 +313,8 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
-int fill(const rn_conv_seg* segs, int nseg, int cin, int cout, int m, bool dgrad, WArgs* in, WArgs* out) {
+int fill(const rn_conv_seg* segs, int nseg, int cin, int cout, int m, bool dgrad, WArgs* in, WArgs* out,
+         bool input_only = false) {
   RN_CHECK_ARG(segs && nseg >= 1 && nseg <= RN_MAX_SEG, "winograd: bad segments");
   RN_CHECK_ARG(m == 2 || m == 4, "winograd: tile %d (2 or 4)", m);
   RN_UNSUPPORTED(cin % 4 != 0 || cout % 4 != 0, "winograd: cin %d / cout %d must be multiples of 4", cin, cout);
@@ -227,7 +328,7 @@ int fill(const rn_conv_seg* segs, int nseg, int cin, int cout, int m, bool dgrad
     a.tile_start = b.tile_start = (int)tiles;
     a.x = dgrad ? segs[s].dy : segs[s].x;
     b.y = dgrad ? segs[s].dx : segs[s].y;
-    RN_CHECK_ARG(a.x && b.y, "winograd: null tensor in segment %d", s);
+    RN_CHECK_ARG(a.x && (b.y || input_only), "winograd: null tensor in segment %d", s);
     RN_UNSUPPORTED((double)a.n * a.h * a.w * (cin > cout ? cin : cout) * 4.0 >= 2147483648.0, "winograd: segment %d >= 2 GiB", s);
     tiles += (int64_t)a.n * a.th * a.tw;
   }
@@ -286,7 +387,62 @@ int run(const WArgs& ia_, const WArgs& oa_, int cin, int cout, const float* w, c
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
+template <int M>
+int run_wgrad(const WArgs& xa_, const WArgs& ya_, int cin, int cout, float* dw, int accumulate, float* dU, float* V, float* dM,
+              void* gemm_ws, size_t gemm_ws_bytes, hipStream_t st) {
+  constexpr int P2 = (M + 2) * (M + 2);
+  WArgs xa = xa_, ya = ya_;
+  const int T_ = xa.total_tiles;
+  xa.buf = V;
+  ya.buf = dM;
+  const int wi = width_for(T_, cin), wo = width_for(T_, cout);
+  RN_WINO_LAUNCH(wino_input_kernel, wi, (int64_t)T_ * cin, xa);
+  RN_WINO_LAUNCH(wino_dy_kernel, wo, (int64_t)T_ * cout, ya);
+  RN_LAUNCH_CHECK();
+  // dU_xi [cin x cout] = V_xi^T [cin x T] * dM_xi [T x cout]
+  int nsplit = 1;
+  if (int e = rn::launch_batched_gemm_tn(V, dM, nullptr, T_, cin, cout, P2, gemm_ws, gemm_ws_bytes, st, &nsplit)) return e;
+  const int64_t kn = (int64_t)cin * cout;
+  hipLaunchKernelGGL(wino_dw_kernel<M>, dim3((unsigned)rn::ceil_div64(kn, 256)), dim3(256), 0, st, (const float*)gemm_ws, dw, kn,
+                     nsplit, accumulate);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
 }  // namespace
+
+// bytes: dU (P*cin*cout) + V (P*T*cin) + dM (P*T*cout) + the split-reduction slab of the batched GEMM
+extern "C" size_t rn_conv3x3_winograd_wgrad_workspace(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile) {
+  if (!segs || nseg < 1 || nseg > RN_MAX_SEG || (tile != 2 && tile != 4)) return 0;
+  const size_t tiles = tiles_of(segs, nseg, tile), p2 = (size_t)(tile + 2) * (tile + 2);
+  return rn::align_up(p2 * cin * cout * 4, 256) + rn::align_up(p2 * tiles * cin * 4, 256) + rn::align_up(p2 * tiles * cout * 4, 256) +
+         rn::batched_gemm_tn_workspace((int)tiles, cin, cout, (int)p2);
+}
+
+// dw[3,3,cin,cout] (+)= sum over segments of the weight gradient of y = conv3x3_same(x, w), from the segments'
+// x and dy:  dU_xi = sum_tiles (B^T d B)_xi^T (A dY A^T)_xi,  dw = G^T dU G.
+extern "C" int rn_conv3x3_winograd_wgrad(const rn_conv_seg* segs, int nseg, int cin, int cout, float* dw, int accumulate, int tile,
+                                         void* workspace, size_t workspace_bytes, rn_stream_t stream) {
+  WArgs xa = {}, ya = {}, unused_in = {}, unused_out = {};
+  // x through the input transform (channels cin); dy through the A-transform (channels cout): reuse fill() twice
+  if (int e = fill(segs, nseg, cin, cout, tile, false, &xa, &unused_out, true)) return e;
+  if (int e = fill(segs, nseg, cin, cout, tile, true, &ya, &unused_in, true)) return e;
+  RN_CHECK_ARG(dw && workspace, "winograd wgrad: null dw / workspace");
+  const size_t need = rn_conv3x3_winograd_wgrad_workspace(segs, nseg, cin, cout, tile);
+  if (workspace_bytes < need) {
+    rn::set_error("winograd wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+    return RN_EWORKSPACE;
+  }
+  const size_t p2 = (size_t)(tile + 2) * (tile + 2);
+  const size_t tiles = xa.total_tiles;
+  char* base = (char*)workspace;
+  float* dU = (float*)base;                 base += rn::align_up(p2 * cin * cout * 4, 256);
+  float* V = (float*)base;                  base += rn::align_up(p2 * tiles * cin * 4, 256);
+  float* dM = (float*)base;                 base += rn::align_up(p2 * tiles * cout * 4, 256);
+  const size_t gemm_ws = workspace_bytes - (size_t)(base - (char*)workspace);
+  hipStream_t st = (hipStream_t)stream;
+  return tile == 2 ? run_wgrad<2>(xa, ya, cin, cout, dw, accumulate, dU, V, dM, base, gemm_ws, st)
+                   : run_wgrad<4>(xa, ya, cin, cout, dw, accumulate, dU, V, dM, base, gemm_ws, st);
+}
 
 // bytes: U (P*cin*cout) + V (P*T*cin) + M (P*T*cout)
 extern "C" size_t rn_conv3x3_winograd_workspace(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile) {

@@ -62,6 +62,7 @@ class _on_side_stream(object):
 # weight gradient stays direct.
 WINOGRAD = True
 WINOGRAD_TILE = 4
+WINOGRAD_WGRAD = True
 WINOGRAD_MIN_CHANNELS = 64
 WINOGRAD_MAX_WORKSPACE = 1 << 30
 
@@ -95,8 +96,41 @@ def _grad_slot(p):
     """(buffer to write the gradient of parameter p into, value to return to autograd)."""
     if DIRECT_PARAM_GRADS and p.grad is not None and p.grad.is_contiguous():
         return p.grad, None
+    assert not _deferring, "deferred reductions need every parameter gradient written in place (DIRECT_PARAM_GRADS)"
     g = torch.empty_like(p)
     return g, g
+
+
+# Deferred gradient reductions (rn_defer_reductions): between begin_deferred_reductions() and
+# end_deferred_reductions() the fixed-order row reductions that finish every weight / bias / GroupNorm-parameter
+# gradient are recorded by the library and run as ONE launch at the end instead of ~130 launch-latency-bound
+# kernels per step.  Their inputs (per-call workspaces) are kept alive here until the flush.
+_deferring = False
+_deferred_keep = []
+
+
+def begin_deferred_reductions():
+    global _deferring
+    assert DIRECT_PARAM_GRADS, "deferred reductions write parameter gradients in place: set DIRECT_PARAM_GRADS"
+    _rn.check(_rn.lib().rn_defer_reductions(_rn.stream(), 1), "rn_defer_reductions")
+    _deferring = True
+
+
+def end_deferred_reductions():
+    global _deferring
+    if _deferring:
+        _rn.check(_rn.lib().rn_defer_reductions(_rn.stream(), 0), "rn_defer_reductions")   # flushes
+        _deferring = False
+        del _deferred_keep[:]
+
+
+def _grad_workspace(need, device):
+    """Workspace of a gradient kernel whose last stage is a row reduction: private while deferring."""
+    if not _deferring:
+        return _rn.workspace(need, device)
+    ws = torch.empty((max(int(need), 256),), dtype=torch.uint8, device=device)
+    _deferred_keep.append(ws)
+    return ws
 
 
 def _conv_segs(xs, w, bias, ys, dys, dxs, x_ld=0, x_coff=0):
@@ -184,14 +218,19 @@ class _Conv2dShared(torch.autograd.Function):
                 db_buf, db = _grad_slot(bias)
             with _on_side_stream(w.device, list(xs) + list(dys) + [dw_buf, db_buf], direct=(dw is None and db is None)):
                 segs = _conv_segs(xs, w, None, None, dys, None)
-                if want_dw:
-                    need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
+                if want_dw and ctx.winograd and WINOGRAD_WGRAD:
+                    need = L.rn_conv3x3_winograd_wgrad_workspace(segs, n, cin, cout, WINOGRAD_TILE)
                     ws = _rn.workspace(need, w.device)
+                    _rn.check(L.rn_conv3x3_winograd_wgrad(segs, n, cin, cout, _rn.f32(dw_buf), 0, WINOGRAD_TILE, ws.data_ptr(),
+                                                          ws.numel(), _rn.stream()), "rn_conv3x3_winograd_wgrad")
+                elif want_dw:
+                    need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
+                    ws = _grad_workspace(need, w.device)
                     _rn.check(L.rn_conv2d_wgrad(segs, n, C.byref(geom), _rn.f32(dw_buf), 0, ws.data_ptr(), ws.numel(),
                                                 _rn.stream()), "rn_conv2d_wgrad")
                 if want_db:
                     need = L.rn_conv2d_bias_grad_workspace(cout)
-                    ws = _rn.workspace(need, w.device)
+                    ws = _grad_workspace(need, w.device)
                     _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws.data_ptr(), ws.numel(),
                                                     _rn.stream()), "rn_conv2d_bias_grad")
         return (None, dw, db) + tuple(dxs)
@@ -245,7 +284,7 @@ class _Conv2dChannelSplit(torch.autograd.Function):
             segs = _conv_segs(xs, w, None, None, dyj, dxs, ld, offs[j])
             _rn.check(L.rn_conv2d_dgrad(segs, n, C.byref(geom), _rn.stream()), "rn_conv2d_dgrad")
             need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
-            ws_buf = _rn.workspace(need, dev)
+            ws_buf = _grad_workspace(need, dev)
             dw_buf, dw = _grad_slot(w)
             _rn.check(L.rn_conv2d_wgrad(segs, n, C.byref(geom), _rn.f32(dw_buf), 0, ws_buf.data_ptr(), ws_buf.numel(),
                                         _rn.stream()), "rn_conv2d_wgrad")
@@ -253,7 +292,7 @@ class _Conv2dChannelSplit(torch.autograd.Function):
             db = None
             if bs[j] is not None:
                 need = L.rn_conv2d_bias_grad_workspace(cout)
-                ws_buf = _rn.workspace(need, dev)
+                ws_buf = _grad_workspace(need, dev)
                 db_buf, db = _grad_slot(bs[j])
                 _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws_buf.data_ptr(),
                                                 ws_buf.numel(), _rn.stream()), "rn_conv2d_bias_grad")
@@ -310,7 +349,7 @@ class _Depthwise(torch.autograd.Function):
             dw_buf, dw = _grad_slot(w)
             with _on_side_stream(x.device, [x, dy, dw_buf], direct=(dw is None)):
                 need = L.rn_depthwise_wgrad_workspace(n, h, wd, c, k, ctx.stride)
-                ws = _rn.workspace(need, x.device)
+                ws = _grad_workspace(need, x.device)
                 _rn.check(L.rn_depthwise_wgrad(_rn.f32(x), _rn.f32(dy), _rn.f32(dw_buf), n, h, wd, c, k, ctx.stride,
                                                ws.data_ptr(), ws.numel(), _rn.stream()), "rn_depthwise_wgrad")
         return dx, dw, None
@@ -404,7 +443,7 @@ class _GroupNormAct(torch.autograd.Function):
         params = _gn_params(c, g, eps, act, drop_rate, seed, seed_dev, aar)
         segs = _gn_segs(xs, None, ress, dys, dxs, means, rstds, dress)
         need = L.rn_group_norm_workspace(segs, n, C.byref(params))
-        ws = _rn.workspace(need, dev)
+        ws = _grad_workspace(need, dev)
         _rn.check(L.rn_group_norm_bwd(segs, n, C.byref(params), _rn.f32(gamma), _rn.f32(beta), _rn.f32(dgamma_buf),
                                       _rn.f32(dbeta_buf), ws.data_ptr(), ws.numel(), _rn.stream()),
                   "rn_group_norm_bwd")

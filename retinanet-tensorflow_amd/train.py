@@ -127,7 +127,7 @@ class Trainer(object):
 
     def __init__(self, net, levels=None, optimizer='momentum', learning_rate=1e-2, grad_clip_norm=None,
                  loss_mode='bce_dice', device='cuda', use_graph=False, process_group=None,
-                 direct_param_grads=True, wgrad_side_stream=False):
+                 direct_param_grads=True, wgrad_side_stream=False, defer_reductions=True):
         self.net, self.levels = net, levels or build_levels()
         self.device = torch.device(device)
         self.loss_mode = loss_mode
@@ -135,6 +135,7 @@ class Trainer(object):
         self.opt = Optimizer(self.arena, optimizer, learning_rate, grad_clip_norm)
         self.allreduce = GradientAllReduce(self.arena, process_group)
         self.use_graph = use_graph
+        self.defer_reductions = bool(defer_reductions) and bool(direct_param_grads)
         # kernels write parameter gradients straight into the arena (every parameter of this network
         # is used by exactly one op call per step); see ops.DIRECT_PARAM_GRADS
         ops.DIRECT_PARAM_GRADS = bool(direct_param_grads)
@@ -156,7 +157,14 @@ class Trainer(object):
         # kernels that write a parameter's gradient directly overwrite it; gradients that reach a parameter
         # through autograd (e.g. the concatenated head kernels) are accumulated -> the arena starts at zero
         self.arena.zero_grad()
-        (class_loss + regr_loss).backward()
+        defer = self.defer_reductions and self.device.type == 'cuda' and ops.DIRECT_PARAM_GRADS
+        if defer:
+            ops.begin_deferred_reductions()        # ~130 gradient row reductions -> one launch after backward
+        try:
+            (class_loss + regr_loss).backward()
+        finally:
+            if defer:
+                ops.end_deferred_reductions()
         # weight-gradient kernels run on a side stream (ops.WGRAD_SIDE_STREAM) and write straight into the
         # arena: join every side stream before anything reads the arena
         if self.device.type == 'cuda':

@@ -44,7 +44,34 @@ def main():
         _rn.check(L.rn_conv3x3_winograd(segs, len(xs), cin, cout, _rn.f32(w), None, dgrad, tile, ws.data_ptr(), ws.numel(),
                                         _rn.stream()), "wino")
 
-    for cfg in ("auto", "0", "1", "2", "3"):
+    dw = torch.empty_like(w)
+
+    def wino_wgrad(tile):
+        need = L.rn_conv3x3_winograd_wgrad_workspace(segs, len(xs), cin, cout, tile)
+        ws = _rn.workspace(need, dev)
+        _rn.check(L.rn_conv3x3_winograd_wgrad(segs, len(xs), cin, cout, _rn.f32(dw), 0, tile, ws.data_ptr(), ws.numel(),
+                                              _rn.stream()), "wino wgrad")
+
+    def direct_wgrad():
+        need = L.rn_conv2d_wgrad_workspace(segs, len(xs), C.byref(geom))
+        ws = _rn.workspace(need, dev)
+        L.rn_conv2d_wgrad(segs, len(xs), C.byref(geom), _rn.f32(dw), 0, ws.data_ptr(), ws.numel(), _rn.stream())
+
+    print("wgrad direct: %.0f us" % timeit(direct_wgrad))
+    for wcfg in ("", "0", "1", "2"):
+        for splits in ("", "1", "2", "3", "4"):
+            os.environ.pop("RN_WGRAD_CFG", None)
+            os.environ.pop("RN_WGRAD_SPLITS", None)
+            if wcfg:
+                os.environ["RN_WGRAD_CFG"] = wcfg
+            if splits:
+                os.environ["RN_WGRAD_SPLITS"] = splits
+            print("wgrad cfg %s splits %s: F2 %.0f us  F4 %.0f us" % (wcfg or "auto", splits or "auto", timeit(lambda: wino_wgrad(2)),
+                                                                    timeit(lambda: wino_wgrad(4))), flush=True)
+    os.environ.pop("RN_WGRAD_CFG", None)
+    os.environ.pop("RN_WGRAD_SPLITS", None)
+
+    for cfg in ("auto", "2"):
         if cfg == "auto":
             os.environ.pop("RN_CONV_CFG", None)
         else:
