@@ -9,9 +9,10 @@ A "step" = anchor assignment for the batch + forward + focal/smooth-L1 loss + ba
 gradient all-reduce + momentum optimizer, fp32, dropout 0.2 (reference default), on a synthetic
 COCO-shaped batch [image, hflip(image)] that is resident in HBM before the timed region.
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     : the dominant kernel (3x3 256->256 head-tower conv on the fp32 matrix cores),
-                 timed live with HIP events on the launch stream, against the 157.3 TFLOP/s
-                 dense fp32 MFMA peak of MI355X_MICROARCH.md;
+  roofline     : the dominant kernel (the batched fp32-MFMA product of the Winograd F(4x4,3x3) head-tower
+                 layer, 3x3 256->256 over P3..P7), timed live with HIP events on the launch stream, against
+                 the 157.3 TFLOP/s dense fp32 MFMA peak of MI355X_MICROARCH.md; executed (not direct-conv
+                 equivalent) FLOPs.  The whole layer's direct-conv-equivalent rate is reported beside it;
   cpu_baseline : the CPU oracle (restatement of the reference's TF semantics, TF itself is not
                  installable) timed on this host's cores on a bounded sample of the same workload.
 """
@@ -35,10 +36,10 @@ NUM_CLASSES = 80
 MAX_OBJ = 32
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 # HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
-# --pmc WRITE_SIZE runs of tools/conv_bench.py, profiles/r01_conv_pmc_fetch_write.csv):
-# FETCH_SIZE 15 207 KB x 2 (gfx950 reports 1/2 of wide 16-B/lane reads, MI355X_MICROARCH.md HBM section)
-# + WRITE_SIZE 10 912 KB.  Algorithmic bytes: 11.2 MB in + 2.4 MB weights + 11.2 MB out = 24.7 MB.
-DOMINANT_KERNEL_HBM_BYTES = (2 * 15207 + 10912) * 1024
+# --pmc WRITE_SIZE runs of tools/gemm_pmc.py, profiles/r01_gemm_pmc_fetch_write.csv):
+# FETCH_SIZE 17 567 KB x 2 (gfx950 reports 1/2 of wide 16-B/lane reads, MI355X_MICROARCH.md HBM section)
+# + WRITE_SIZE 24 552 KB = 61.1 MB.  Algorithmic bytes: 36 x (682x256 in + 256x256 weights + 682x256 out) x 4 = 59.7 MB.
+DOMINANT_KERNEL_HBM_BYTES = (2 * 17567 + 24552) * 1024
 TRAIN_GFLOP_PER_IMAGE = 239.2       # BASELINE.md section 3 (3 x forward conv FLOPs), cfg 2
 
 
@@ -83,9 +84,12 @@ class Step(object):
         import dataset, layers, levels, retinanet, train
         torch.manual_seed(0)                       # identical initial weights on every rank
         self.levels = levels.build_levels()
+        if os.environ.get("RN_HEADS_TWO_STREAMS"):     # tuning aid (see retinanet.HEADS_TWO_STREAMS)
+            retinanet.HEADS_TWO_STREAMS = os.environ["RN_HEADS_TWO_STREAMS"] == "1"
         self.net = retinanet.RetinaNet('mobilenet_v2', self.levels, NUM_CLASSES, layers.elu, dropout).to(device)
         self.trainer = train.Trainer(self.net, self.levels, optimizer='momentum', learning_rate=1e-2,
-                                     loss_mode=loss_mode, device=device, use_graph=False)
+                                     loss_mode=loss_mode, device=device, use_graph=False,
+                                     wgrad_side_stream=os.environ.get("RN_WGRAD_SIDE_STREAM") == "1")
         self.image, self.boxes, self.cls, self.nobj = make_batch(rank, device)
         self.dataset = dataset
         self.use_graph = use_graph
@@ -118,27 +122,43 @@ class Step(object):
         return self.out
 
 
-def time_dominant_kernel(device, iters=20):
-    """Head-tower conv (3x3, 256->256, the five pyramid levels of a 512^2 batch of 2 in ONE launch):
-    average duration from HIP events on the launch stream.  Algorithmic FLOPs per launch =
-    2 * (2*5456 output pixels) * 2304 * 256 = 12.87 GFLOP (kernels table)."""
+def time_dominant_kernel(device, iters=50):
+    """The kernel the training step spends most matrix-core time in: the batched product of the Winograd
+    F(4x4,3x3) head-tower layer (3x3, 256->256, the five pyramid levels of a 512^2 batch of 2 = 682 4x4 tiles):
+    36 x ([682 x 256] x [256 x 256]) in ONE launch of conv_fwd_kernel<64,64,...>.  Executed FLOPs per launch =
+    2 * 36 * 682 * 256 * 256 = 3.218 GFLOP (kernels table); average duration from HIP events on the
+    launch stream.  Also times the whole layer (weight / input transforms + product + output transform) and reports
+    its rate in direct-convolution FLOPs (12.87 GFLOP per layer)."""
+    import _rn
     import ops
     sizes = [64, 32, 16, 8, 4]
-    xs = [torch.randn(BATCH, s, s, 256, device=device) for s in sizes]
-    w = torch.randn(3, 3, 256, 256, device=device) * 0.01
-    with torch.no_grad():
-        for _ in range(3):
-            ops.conv2d(xs, w, None, 1)
+    tiles = BATCH * sum(((s + 3) // 4) ** 2 for s in sizes)
+    A = torch.randn(36, tiles, 256, device=device)
+    B = torch.randn(36, 256, 256, device=device) * 0.01
+    Cm = torch.empty(36, tiles, 256, device=device)
+    L = _rn.lib()
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            ops.conv2d(xs, w, None, 1)
+            fn()
         e1.record()
         e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+        return e0.elapsed_time(e1) / iters
+
+    gemm_ms = timed(lambda: _rn.check(L.rn_gemm_batched(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, 36, 0,
+                                                        _rn.stream()), "rn_gemm_batched"))
+    xs = [torch.randn(BATCH, s, s, 256, device=device) for s in sizes]
+    w = torch.randn(3, 3, 256, 256, device=device) * 0.01
+    with torch.no_grad():
+        layer_ms = timed(lambda: ops.conv2d(xs, w, None, 1))
     pixels = BATCH * sum(s * s for s in sizes)
-    flops = 2.0 * pixels * 2304 * 256
-    return ms, flops
+    return {"gemm_ms": gemm_ms, "gemm_flops": 2.0 * 36 * tiles * 256 * 256, "layer_ms": layer_ms,
+            "layer_direct_flops": 2.0 * pixels * 2304 * 256,
+            "gemm_bytes": 4.0 * 36 * (2 * tiles * 256 + 256 * 256)}
 
 
 def nms_benchmark(device, batch=16, image_size=1024, hot=0.01, iters=5):
@@ -279,8 +299,8 @@ def main():
     result = None
     if rank == 0:
         ips = world * BATCH * args.steps / elapsed
-        kms, kflops = time_dominant_kernel(device)
-        achieved = kflops / (kms * 1e-3) / 1e12
+        dk = time_dominant_kernel(device)
+        achieved = dk["gemm_flops"] / (dk["gemm_ms"] * 1e-3) / 1e12
         result = {
             "metric": "train images/sec (MobileNetV2-FPN RetinaNet 512x512, bs=2/GPU)",
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -296,8 +316,12 @@ def main():
                                                               FP32_MFMA_PEAK_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": DOMINANT_KERNEL_HBM_BYTES,
-                         "kernel": "conv_fwd_kernel<64,64,2,2,4,true> 3x3 256->256 over P3..P7 (head tower layer)",
-                         "kernel_ms": round(kms, 4), "flops_per_launch": kflops},
+                         "kernel": "conv_fwd_kernel<64,64,2,2,4,true>, batched: 36 x [682x256]x[256x256], the product stage of "
+                                   "the Winograd F(4x4,3x3) head-tower layer (3x3 256->256 over P3..P7)",
+                         "kernel_ms": round(dk["gemm_ms"], 4), "flops_per_launch": dk["gemm_flops"],
+                         "algorithmic_bytes_per_launch": dk["gemm_bytes"],
+                         "layer_ms": round(dk["layer_ms"], 4),
+                         "layer_direct_conv_equivalent_tflops": round(dk["layer_direct_flops"] / (dk["layer_ms"] * 1e-3) / 1e12, 1)},
         }
         if not args.no_nms:
             result["nms"] = nms_benchmark(device)

@@ -113,6 +113,11 @@ int rn_flush_reductions(rn_stream_t stream);
 size_t rn_conv3x3_winograd_workspace(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile);
 int rn_conv3x3_winograd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, const float* bias,
                         int dgrad, int tile, void* workspace, size_t workspace_bytes, rn_stream_t stream);
+/* The batched product the Winograd stages run on the fp32 matrix cores, exposed for measurement (bench.py times
+ * the head-tower layer's instance: 36 x [682 x 256] x [256 x 256]) and reuse:
+ *   C_b [M x N] = A_b [M x K] * B_b,  b = 0..nbatch-1, matrices of a batch stored back to back;
+ *   b_nk == 0: B_b is [K x N];  b_nk != 0: B_b is [N x K] (the data-gradient layout).  K and N multiples of 4. */
+int rn_gemm_batched(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, int b_nk, rn_stream_t stream);
 /* Weight gradient of the same convolution in the Winograd domain: dU_xi = sum over tiles of
  * (B^T d B)_xi^T (A dY A^T)_xi as (tile+2)^2 batched GEMMs with the reduction split across blocks (fixed-order
  * sum), then dw[3,3,cin,cout] (+)= G^T dU G.  Segments: x, dy, n, h, w. */

@@ -471,3 +471,10 @@ extern "C" int rn_conv3x3_winograd(const rn_conv_seg* segs, int nseg, int cin, i
   return tile == 2 ? run<2>(ia, oa, cin, cout, w, bias, dgrad != 0, U, V, Mb, st)
                    : run<4>(ia, oa, cin, cout, w, bias, dgrad != 0, U, V, Mb, st);
 }
+
+extern "C" int rn_gemm_batched(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, int b_nk,
+                               rn_stream_t stream) {
+  RN_CHECK_ARG(A && B && C && M >= 1 && K >= 1 && N >= 1 && nbatch >= 1, "gemm_batched: bad argument");
+  RN_UNSUPPORTED(K % 4 != 0 || N % 4 != 0, "gemm_batched: K %d / N %d must be multiples of 4", K, N);
+  return rn::launch_batched_gemm(A, B, C, M, K, N, nbatch, b_nk, (hipStream_t)stream);
+}

@@ -107,21 +107,37 @@ def _grad_slot(p):
 # kernels per step.  Their inputs (per-call workspaces) are kept alive here until the flush.
 _deferring = False
 _deferred_keep = []
+_deferred_streams = []
 
 
-def begin_deferred_reductions():
+def begin_deferred_reductions(extra_streams=()):
+    """Defer on the current stream and on `extra_streams` (torch streams that backward nodes run on, e.g. the
+    second head stream of retinanet.HEADS_TWO_STREAMS)."""
     global _deferring
     assert DIRECT_PARAM_GRADS, "deferred reductions write parameter gradients in place: set DIRECT_PARAM_GRADS"
-    _rn.check(_rn.lib().rn_defer_reductions(_rn.stream(), 1), "rn_defer_reductions")
+    L = _rn.lib()
+    _rn.check(L.rn_defer_reductions(_rn.stream(), 1), "rn_defer_reductions")
+    for st in extra_streams:
+        _rn.check(L.rn_defer_reductions(C.c_void_p(st.cuda_stream), 1), "rn_defer_reductions")
+    _deferred_streams[:] = list(extra_streams)
     _deferring = True
 
 
 def end_deferred_reductions():
+    """Flush: one batched reduction launch per stream; the current stream then waits for the extra streams."""
     global _deferring
     if _deferring:
-        _rn.check(_rn.lib().rn_defer_reductions(_rn.stream(), 0), "rn_defer_reductions")   # flushes
+        L = _rn.lib()
+        _rn.check(L.rn_defer_reductions(_rn.stream(), 0), "rn_defer_reductions")
+        for st in _deferred_streams:
+            # fork again from the current stream first: after autograd's end-of-backward join a side stream is no
+            # longer part of an ongoing hipGraph capture, and its flush would run eagerly instead of being captured
+            st.wait_stream(torch.cuda.current_stream())
+            _rn.check(L.rn_defer_reductions(C.c_void_p(st.cuda_stream), 0), "rn_defer_reductions")
+            torch.cuda.current_stream().wait_stream(st)
         _deferring = False
         del _deferred_keep[:]
+        del _deferred_streams[:]
 
 
 def _grad_workspace(need, device):

@@ -16,6 +16,8 @@ differences that do not change results:
 """
 import math
 
+import os
+
 import torch
 
 import _rn
@@ -37,7 +39,8 @@ FUSE_HEAD_TOWERS = False   # measured: 163 vs 166 img/s (the fused wgrad is slow
 # The class and box subnets are independent given the pyramid: run them on two HIP streams so their
 # (small, launch- and occupancy-bound) kernels overlap -- forward here, and backward too because
 # autograd replays each node on its forward stream.  Captured into the step's hipGraph as two branches.
-HEADS_TWO_STREAMS = False
+# Measured on MI355X with the Winograd towers (4 short kernels per conv): 256 vs 249 img/s.
+HEADS_TWO_STREAMS = os.environ.get("RN_HEADS_TWO_STREAMS", "1") == "1"
 
 
 def side_stream(device):

@@ -15,6 +15,7 @@ xGMI bandwidth, and the whole step (forward, loss, backward, optimizer) can be c
 hipGraph -- the launch-bound small kernels of the pyramid's coarse levels then cost no host time.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -135,7 +136,8 @@ class Trainer(object):
         self.opt = Optimizer(self.arena, optimizer, learning_rate, grad_clip_norm)
         self.allreduce = GradientAllReduce(self.arena, process_group)
         self.use_graph = use_graph
-        self.defer_reductions = bool(defer_reductions) and bool(direct_param_grads)
+        self.defer_reductions = (bool(defer_reductions) and bool(direct_param_grads) and
+                                 os.environ.get("RN_DEFER_REDUCTIONS", "1") == "1")
         # kernels write parameter gradients straight into the arena (every parameter of this network
         # is used by exactly one op call per step); see ops.DIRECT_PARAM_GRADS
         ops.DIRECT_PARAM_GRADS = bool(direct_param_grads)
@@ -158,8 +160,14 @@ class Trainer(object):
         # through autograd (e.g. the concatenated head kernels) are accumulated -> the arena starts at zero
         self.arena.zero_grad()
         defer = self.defer_reductions and self.device.type == 'cuda' and ops.DIRECT_PARAM_GRADS
-        if defer:
-            ops.begin_deferred_reductions()        # ~130 gradient row reductions -> one launch after backward
+        if defer:                                  # ~130 gradient row reductions -> one launch after backward
+            import retinanet
+            extra = [retinanet.side_stream(self.device)] if retinanet.HEADS_TWO_STREAMS else []
+            if ops.WGRAD_SIDE_STREAM:
+                extra.append(_rn.side_stream(self.device, 0))
+            if os.environ.get("RN_DEFER_SIDE", "1") != "1":
+                extra = []
+            ops.begin_deferred_reductions(extra)
         try:
             (class_loss + regr_loss).backward()
         finally:

@@ -660,3 +660,57 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     for k, v in net.named_parameters():
         assert torch.equal(v, ref[k]) and v.data_ptr() >= tr.arena.weights.data_ptr()      # still views of the arena
     assert torch.equal(tr.opt.state1, s1) and torch.equal(tr.opt.state2, s2)
+
+
+def test_batched_gemm_both_layouts(dev):
+    """rn_gemm_batched (the Winograd product stage): C_b = A_b B_b with B as [K,N] and as [N,K]; ragged M."""
+    import _rn
+    L = _rn.lib()
+    rng = np.random.default_rng(11)
+    for (nb, m, k, n) in [(36, 75, 256, 64), (16, 130, 64, 256), (3, 1, 32, 36)]:
+        a = rng.standard_normal((nb, m, k)).astype(np.float32)
+        b = rng.standard_normal((nb, k, n)).astype(np.float32)
+        ref = np.einsum("bmk,bkn->bmn", a.astype(np.float64), b.astype(np.float64))
+        ag, bg = _t(a, dev), _t(b, dev)
+        bt = _t(np.ascontiguousarray(b.transpose(0, 2, 1)), dev)
+        for b_nk, bb in ((0, bg), (1, bt)):
+            c = torch.empty((nb, m, n), dtype=torch.float32, device=dev)
+            _rn.check(L.rn_gemm_batched(_rn.f32(ag), _rn.f32(bb), _rn.f32(c), m, k, n, nb, b_nk, _rn.stream()), "gemm")
+            assert_close(c.cpu().numpy(), ref, 1e-5, "batched gemm b_nk=%d" % b_nk)
+
+
+def test_deferred_reductions_are_bitwise_identical(dev):
+    """rn_defer_reductions: the gradients after the single flushed launch equal the immediate ones bit for bit."""
+    import ops
+    rng = np.random.default_rng(5)
+    x = _t(rng.standard_normal((2, 16, 16, 96)).astype(np.float32), dev)
+    convw = torch.nn.Parameter(_t(rng.standard_normal((1, 1, 96, 24)).astype(np.float32) / 10, dev))
+    bias = torch.nn.Parameter(_t(rng.standard_normal(24).astype(np.float32), dev))
+    dww = torch.nn.Parameter(_t(rng.standard_normal((3, 3, 96, 1)).astype(np.float32) / 3, dev))
+    gamma = torch.nn.Parameter(_t(1 + 0.1 * rng.standard_normal(96).astype(np.float32), dev))
+    beta = torch.nn.Parameter(_t(0.1 * rng.standard_normal(96).astype(np.float32), dev))
+    params = [convw, bias, dww, gamma, beta]
+
+    def run(defer):
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        old = ops.DIRECT_PARAM_GRADS
+        ops.DIRECT_PARAM_GRADS = True
+        try:
+            h = ops.depthwise_conv2d(x, dww, 1)
+            h = ops.group_norm_act(h, gamma, beta, groups=32, act="relu6")
+            y = ops.conv2d(h, convw, bias, 1)
+            if defer:
+                ops.begin_deferred_reductions()
+            y.square().sum().backward()
+            if defer:
+                ops.end_deferred_reductions()
+        finally:
+            ops.DIRECT_PARAM_GRADS = old
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in params]
+
+    immediate, deferred = run(False), run(True)
+    for a, b in zip(immediate, deferred):
+        assert float(a.abs().max()) > 0
+        assert torch.equal(a, b)
