@@ -78,8 +78,15 @@ typedef struct rn_conv_geom {
                      [g*cin/G,(g+1)*cin/G) */
 } rn_conv_geom;
 
-int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream);
-int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream);
+/* workspace: optional scratch for split-K (rn_conv2d_*_workspace bytes, 0 when the launch is large enough not to
+ * want it): grids of a few tiles with a long reduction -- the stride-2 convs that make P6 / P7, the 4x4 and 8x8
+ * pyramid maps -- are otherwise latency-bound on a handful of CUs.  NULL / too small => no split (never an error). */
+size_t rn_conv2d_fwd_workspace(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g);
+size_t rn_conv2d_dgrad_workspace(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g);
+int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, void* workspace, size_t workspace_bytes,
+                  rn_stream_t stream);
+int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, void* workspace, size_t workspace_bytes,
+                    rn_stream_t stream);
 /* dw[kh,kw,cin,cout] = sum over all segments (they share the kernel: shared heads);
  * split-K partial slabs go to `workspace`, reduced in fixed order (bitwise reproducible).
  * If accumulate != 0 the result is added to dw instead of overwriting it. */

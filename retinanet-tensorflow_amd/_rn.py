@@ -69,6 +69,7 @@ _lib = None
 # every symbol include/rn_hip.h declares (tests/test_abi.py checks the .so exports them all)
 SYMBOLS = [
     "rn_version", "rn_last_error", "rn_same_pad",
+    "rn_conv2d_fwd_workspace", "rn_conv2d_dgrad_workspace",
     "rn_conv2d_fwd", "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad",
     "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_defer_reductions", "rn_flush_reductions", "rn_gemm_batched",
@@ -95,7 +96,8 @@ def lib():
         L.rn_last_error.restype = C.c_char_p
         for name in ("rn_conv2d_wgrad_workspace", "rn_depthwise_wgrad_workspace", "rn_group_norm_workspace",
                      "rn_loss_workspace", "rn_detect_workspace", "rn_optimizer_workspace",
-                     "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace", "rn_conv3x3_winograd_workspace",
+                     "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace", "rn_conv3x3_winograd_workspace", "rn_conv2d_fwd_workspace",
+                     "rn_conv2d_dgrad_workspace",
                      "rn_conv3x3_winograd_wgrad_workspace"):
             getattr(L, name).restype = C.c_size_t
         L.rn_optimizer_workspace.argtypes = [C.c_int64]
@@ -103,8 +105,10 @@ def lib():
         L.rn_depthwise_dgrad.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_depthwise_wgrad_workspace.argtypes = [C.c_int] * 6
         L.rn_depthwise_wgrad.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p]
-        L.rn_conv2d_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        L.rn_conv2d_dgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rn_conv2d_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rn_conv2d_dgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rn_conv2d_fwd_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rn_conv2d_dgrad_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_conv2d_wgrad_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_conv2d_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_size_t, C.c_void_p]

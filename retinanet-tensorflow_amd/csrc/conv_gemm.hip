@@ -59,6 +59,9 @@ struct ConvArgs {
   // the segment's tiles, copy b uses a + b*bs_a, b + b*bs_b, out + b*bs_out (strides in floats)
   int nbatch, btiles;
   long bs_a, bs_b, bs_out;
+  // split-K mode (fwd / dgrad of tiny grids, e.g. the 4x4 P7 map: 4 tiles x 72 K-tiles): the "batches" are K ranges of
+  // `ksplit` K-tiles each (bs_a = bs_b = 0), written to slab rows bs_out apart and summed by reduce_rows
+  int ksplit;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -237,7 +240,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
   // weight rows past ktotal fall outside the descriptor => zeros without a test
   const unsigned boff0 = bcol < nmax ? ((unsigned)(tid / NQ) * cout + bcol) * 4u : OOB;
 
+  const int nk = (ktotal + BK - 1) / BK;
+  int kt_begin = 0, kt_end = nk;
+  if (args.ksplit) { kt_begin = batch * args.ksplit; kt_end = min(nk, kt_begin + args.ksplit); }
   int t_kh = 0, t_kw = 0, t_ci = 0;  // TAPU: block-uniform tap state of the tile being loaded
+  if (TAPU && kt_begin) {
+    const int tap0 = kt_begin * BK / cin;
+    t_ci = kt_begin * BK - tap0 * cin; t_kh = tap0 / kw; t_kw = tap0 - t_kh * kw;
+  }
   vec_t ra[A_PASS], rb[B_PASS];
   auto load_tiles = [&](int kt) {
     int khh, kww, tapoff;
@@ -275,16 +285,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  const int nk = (ktotal + BK - 1) / BK;
-  load_tiles(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  load_tiles(kt_begin);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
     store_tiles();
     __syncthreads();
-    if (kt + 1 < nk) load_tiles(kt + 1);
+    if (kt + 1 < kt_end) load_tiles(kt + 1);
     mma_ktile<BM, BN, WM, WN, false, false>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
-  store_tile<BM, BN, WM, WN>(acc, sg.out + batch * args.bs_out, sg.bias, m0, n0, M, nmax, cout, wm, wn, lane);
+  store_tile<BM, BN, WM, WN>(acc, sg.out + batch * args.bs_out, (args.ksplit && batch) ? nullptr : sg.bias, m0, n0, M, nmax, cout,
+                             wm, wn, lane);
 }
 
 // =============================================================================================
@@ -347,7 +357,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
     browoff[j] = ci < cin ? ((unsigned)ci * ldy + y_coff) * 4u : OOB;
   }
 
+  const int nk = (ktotal + BK - 1) / BK;
+  int kt_begin = 0, kt_end = nk;
+  if (args.ksplit) { kt_begin = batch * args.ksplit; kt_end = min(nk, kt_begin + args.ksplit); }
   int t_kh = 0, t_kw = 0, t_co = 0;
+  if (TAPU && kt_begin) {
+    const int tap0 = kt_begin * BK / cout;
+    t_co = kt_begin * BK - tap0 * cout; t_kh = tap0 / kw; t_kw = tap0 - t_kh * kw;
+  }
   vec_t ra[A_PASS], rb[B_PASS];
   auto load_tiles = [&](int kt) {
     int khh, kww, co, tap;
@@ -390,12 +407,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  const int nk = (ktotal + BK - 1) / BK;
-  load_tiles(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  load_tiles(kt_begin);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
     store_tiles();
     __syncthreads();
-    if (kt + 1 < nk) load_tiles(kt + 1);
+    if (kt + 1 < kt_end) load_tiles(kt + 1);
     mma_ktile<BM, BN, WM, WN, false, true>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
@@ -732,15 +748,45 @@ extern "C" void rn_same_pad(int n, int k, int s, int* out, int* pad_before) { rn
 
 namespace {
 struct Batch { int n; long bs_a, bs_b, bs_out; };
-int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream);
-int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream);
+// split-K scratch: ws == nullptr -> never split; need_out != nullptr -> dry run, only report the bytes split-K wants
+struct Scratch { void* ws; size_t bytes; size_t* need_out; };
+int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
+                  const Scratch& sc = Scratch{nullptr, 0, nullptr});
+int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
+                    const Scratch& sc = Scratch{nullptr, 0, nullptr});
+
+// Tiny grids with a long reduction (the stride-2 convs that make P6 / P7, the 4x4 and 8x8 maps: 4..24 tiles x 72+
+// K-tiles) are latency-bound on a handful of CUs: split K over ~384/tiles blocks per tile and sum the partial
+// outputs with the fixed-order row reduction.
+void plan_splitk(int tiles, int nk, int* nsplit, int* ksplit) {
+  *nsplit = 1; *ksplit = 0;
+  if (tiles >= 96 || nk < 16 || getenv("RN_NO_SPLITK")) return;
+  int ns = (384 + tiles - 1) / tiles;
+  if (ns > nk / 4) ns = nk / 4;
+  if (ns < 2) return;
+  const int ks = (nk + ns - 1) / ns;
+  *ksplit = ks;
+  *nsplit = (nk + ks - 1) / ks;
+}
 }  // namespace
 
-extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream) {
-  return conv_fwd_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream);
+extern "C" size_t rn_conv2d_fwd_workspace(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
+  size_t need = 0;
+  if (conv_fwd_impl(segs, nseg, g, Batch{1, 0, 0, 0}, nullptr, Scratch{nullptr, 0, &need})) return 0;
+  return need;
 }
-extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, rn_stream_t stream) {
-  return conv_dgrad_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream);
+extern "C" size_t rn_conv2d_dgrad_workspace(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
+  size_t need = 0;
+  if (conv_dgrad_impl(segs, nseg, g, Batch{1, 0, 0, 0}, nullptr, Scratch{nullptr, 0, &need})) return 0;
+  return need;
+}
+extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, void* workspace, size_t workspace_bytes,
+                             rn_stream_t stream) {
+  return conv_fwd_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream, Scratch{workspace, workspace_bytes, nullptr});
+}
+extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, void* workspace, size_t workspace_bytes,
+                               rn_stream_t stream) {
+  return conv_dgrad_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream, Scratch{workspace, workspace_bytes, nullptr});
 }
 
 // C_b [M x N] = A_b [M x K] * B_b   for b = 0..nbatch-1 in one launch (Winograd's per-point products).
@@ -760,7 +806,8 @@ int rn::launch_batched_gemm(const float* A, const float* B, float* C, int M, int
 }
 
 namespace {
-int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream) {
+int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
+                  const Scratch& sc) {
   if (int e = validate_geom(segs, nseg, g)) return e;
   RN_CHECK_ARG(bt.n == 1 || nseg == 1, "conv: batched mode takes one segment");
   ConvArgs a = {};
@@ -770,7 +817,7 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
   a.groups = G; a.cin_g = g->cin / G;
   bool vec = (a.cin_g % 4 == 0);
   for (int s = 0; s < nseg; ++s) {
-    RN_CHECK_ARG(segs[s].x && segs[s].wgt && segs[s].y, "conv fwd: null pointer in segment %d", s);
+    RN_CHECK_ARG(sc.need_out || (segs[s].x && segs[s].wgt && segs[s].y), "conv fwd: null pointer in segment %d", s);
     SegDev& d = a.seg[s];
     d.a = segs[s].x; d.b = segs[s].wgt; d.bias = segs[s].bias; d.out = segs[s].y;
     d.n = segs[s].n; d.h = segs[s].h; d.w = segs[s].w; d.cout = segs[s].cout;
@@ -796,6 +843,22 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
   tiles *= bt.n;
   hipStream_t st = (hipStream_t)stream;
   const bool tapu = vec && (a.cin_g % BK == 0);
+  // split-K (single dense segment only)
+  int nsplit = 1, ksplit = 0;
+  float* const y_final = a.seg[0].out;
+  const int64_t out_elems = (int64_t)a.seg[0].m * a.seg[0].cout;
+  if (bt.n == 1 && nseg == 1 && G == 1) plan_splitk(tiles, rn::ceil_div(g->kh * g->kw * g->cin, BK), &nsplit, &ksplit);
+  if (sc.need_out) {
+    *sc.need_out = nsplit > 1 ? (size_t)nsplit * out_elems * sizeof(float) : 0;
+    return RN_OK;
+  }
+  if (nsplit > 1 && sc.ws && sc.bytes >= (size_t)nsplit * out_elems * sizeof(float)) {
+    a.ksplit = ksplit; a.nbatch = nsplit; a.bs_a = 0; a.bs_b = 0; a.bs_out = out_elems;
+    a.seg[0].out = (float*)sc.ws;
+    tiles *= nsplit;
+  } else {
+    nsplit = 1;
+  }
 #define RN_FWD(BM_, BN_, WM_, WN_)                                                                   \
   do {                                                                                               \
     if (tapu) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 4, true>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
@@ -810,10 +873,16 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
   }
 #undef RN_FWD
   RN_LAUNCH_CHECK();
+  if (nsplit > 1) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rn::ceil_div64(out_elems, 64)), dim3(256), 0, st, (const float*)sc.ws,
+                       y_final, out_elems, nsplit, 0);
+    RN_LAUNCH_CHECK();
+  }
   return RN_OK;
 }
 
-int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream) {
+int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
+                    const Scratch& sc) {
   if (int e = validate_geom(segs, nseg, g)) return e;
   RN_CHECK_ARG(bt.n == 1 || nseg == 1, "conv: batched mode takes one segment");
   ConvArgs a = {};
@@ -823,7 +892,7 @@ int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, co
   a.groups = G; a.cin_g = g->cin / G;
   bool vec = true;  // float4 gathers run along cout
   for (int s = 0; s < nseg; ++s) {
-    RN_CHECK_ARG(segs[s].dy && segs[s].wgt && segs[s].dx, "conv dgrad: null pointer in segment %d", s);
+    RN_CHECK_ARG(sc.need_out || (segs[s].dy && segs[s].wgt && segs[s].dx), "conv dgrad: null pointer in segment %d", s);
     vec = vec && ((segs[s].cout / G) % 4 == 0);
     SegDev& d = a.seg[s];
     d.a = segs[s].dy; d.b = segs[s].wgt; d.bias = nullptr; d.out = segs[s].dx;
@@ -849,6 +918,23 @@ int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, co
   hipStream_t st = (hipStream_t)stream;
   bool tapu = vec;
   for (int s = 0; s < nseg; ++s) tapu = tapu && ((segs[s].cout / G) % BK == 0);
+  // split-K (single segment writing a dense dx only)
+  int nsplit = 1, ksplit = 0;
+  float* const dx_final = a.seg[0].out;
+  const int64_t out_elems = (int64_t)a.seg[0].m * g->cin;
+  if (bt.n == 1 && nseg == 1 && G == 1 && a.seg[0].x_ld == g->cin && a.seg[0].x_coff == 0)
+    plan_splitk(tiles, rn::ceil_div(g->kh * g->kw * segs[0].cout, BK), &nsplit, &ksplit);
+  if (sc.need_out) {
+    *sc.need_out = nsplit > 1 ? (size_t)nsplit * out_elems * sizeof(float) : 0;
+    return RN_OK;
+  }
+  if (nsplit > 1 && sc.ws && sc.bytes >= (size_t)nsplit * out_elems * sizeof(float)) {
+    a.ksplit = ksplit; a.nbatch = nsplit; a.bs_a = 0; a.bs_b = 0; a.bs_out = out_elems;
+    a.seg[0].out = (float*)sc.ws;
+    tiles *= nsplit;
+  } else {
+    nsplit = 1;
+  }
 #define RN_DG(BM_, BN_, WM_, WN_)                                                                    \
   do {                                                                                               \
     if (tapu) hipLaunchKernelGGL((conv_dgrad_kernel<BM_, BN_, WM_, WN_, 4, true>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
@@ -863,6 +949,11 @@ int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, co
   }
 #undef RN_DG
   RN_LAUNCH_CHECK();
+  if (nsplit > 1) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rn::ceil_div64(out_elems, 64)), dim3(256), 0, st, (const float*)sc.ws,
+                       dx_final, out_elems, nsplit, 0);
+    RN_LAUNCH_CHECK();
+  }
   return RN_OK;
 }
 }  // namespace

@@ -88,6 +88,22 @@ def _winograd(segs, n, w, bias, dgrad):
               "rn_conv3x3_winograd")
 
 
+def _conv_fwd(segs, n, geom, device):
+    L = _rn.lib()
+    need = L.rn_conv2d_fwd_workspace(segs, n, C.byref(geom))           # split-K scratch for tiny grids (0 otherwise)
+    ws = _rn.workspace(need, device) if need else None
+    _rn.check(L.rn_conv2d_fwd(segs, n, C.byref(geom), ws.data_ptr() if need else None, ws.numel() if need else 0,
+                              _rn.stream()), "rn_conv2d_fwd")
+
+
+def _conv_dgrad(segs, n, geom, device):
+    L = _rn.lib()
+    need = L.rn_conv2d_dgrad_workspace(segs, n, C.byref(geom))
+    ws = _rn.workspace(need, device) if need else None
+    _rn.check(L.rn_conv2d_dgrad(segs, n, C.byref(geom), ws.data_ptr() if need else None, ws.numel() if need else 0,
+                                _rn.stream()), "rn_conv2d_dgrad")
+
+
 def _as_list(x):
     return list(x) if isinstance(x, (list, tuple)) else [x]
 
@@ -188,7 +204,7 @@ class _Conv2dShared(torch.autograd.Function):
         if ctx.winograd:
             _winograd(segs, len(xs), w, bias, False)
         else:
-            _rn.check(L.rn_conv2d_fwd(segs, len(xs), C.byref(geom), _rn.stream()), "rn_conv2d_fwd")
+            _conv_fwd(segs, len(xs), geom, xs[0].device)
         ctx.stride = stride
         ctx.groups = groups
         ctx.has_bias = bias is not None
@@ -220,7 +236,7 @@ class _Conv2dShared(torch.autograd.Function):
             if ctx.winograd:
                 _winograd(segs, len(idx), w, None, True)
             else:
-                _rn.check(L.rn_conv2d_dgrad(segs, len(idx), C.byref(geom), _rn.stream()), "rn_conv2d_dgrad")
+                _conv_dgrad(segs, len(idx), geom, w.device)
             for i, o in zip(idx, outs):
                 dxs[i] = o
         dw = db = None
@@ -273,7 +289,7 @@ class _Conv2dChannelSplit(torch.autograd.Function):
                 ow, _ = _rn.same_pad(x.shape[2], kw, stride)
                 ys.append(torch.empty((x.shape[0], oh, ow, cout), dtype=torch.float32, device=x.device))
             segs = _conv_segs(xs, w, b, ys, None, None, ld, off)
-            _rn.check(L.rn_conv2d_fwd(segs, len(xs), C.byref(geom), _rn.stream()), "rn_conv2d_fwd")
+            _conv_fwd(segs, len(xs), geom, xs[0].device)
             outs += ys
             offs.append(off)
             off += cin
@@ -298,7 +314,7 @@ class _Conv2dChannelSplit(torch.autograd.Function):
             geom = _rn.ConvGeom(kh, kw, stride, cin, 1)
             dyj = [dy.contiguous() for dy in dys[j * n:(j + 1) * n]]
             segs = _conv_segs(xs, w, None, None, dyj, dxs, ld, offs[j])
-            _rn.check(L.rn_conv2d_dgrad(segs, n, C.byref(geom), _rn.stream()), "rn_conv2d_dgrad")
+            _rn.check(L.rn_conv2d_dgrad(segs, n, C.byref(geom), None, 0, _rn.stream()), "rn_conv2d_dgrad")
             need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
             ws_buf = _grad_workspace(need, dev)
             dw_buf, dw = _grad_slot(w)

@@ -714,3 +714,33 @@ def test_deferred_reductions_are_bitwise_identical(dev):
     for a, b in zip(immediate, deferred):
         assert float(a.abs().max()) > 0
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", [(2, 4, 4, 256, 256, 3, 1), (2, 16, 16, 320, 256, 3, 2), (1, 8, 8, 256, 64, 3, 2), (2, 2, 2, 1280, 256, 1, 1)])
+def test_split_k_tiny_grids(dev, case):
+    """Tiny output grids with a long reduction (P6 / P7 convs) take the split-K path of rn_conv2d_fwd / dgrad."""
+    import ops
+    import _rn
+    n, h, w, cin, cout, k, stride = case
+    rng = np.random.default_rng(cin + cout + h)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    xc, wc, bc = (torch.from_numpy(a).requires_grad_(True) for a in (x, wt, b))
+    yc = tf_ops_ref.conv2d_same(xc, wc, stride, bc)
+    dy = rng.standard_normal(tuple(yc.shape)).astype(np.float32)
+    yc.backward(torch.from_numpy(dy))
+    old = ops.WINOGRAD
+    ops.WINOGRAD = False
+    try:
+        xg, wg, bg = _t(x, dev, True), _t(wt, dev, True), _t(b, dev, True)
+        segs = ops._conv_segs([xg.detach()], wg.detach(), None, [torch.empty_like(_t(dy, dev))], None, None)
+        geom = _rn.ConvGeom(k, k, stride, cin, 1)
+        assert _rn.lib().rn_conv2d_fwd_workspace(segs, 1, __import__("ctypes").byref(geom)) > 0, "expected a split-K plan"
+        yg = ops.conv2d(xg, wg, bg, stride)
+        yg.backward(_t(dy, dev))
+    finally:
+        ops.WINOGRAD = old
+    assert_close(yg.detach().cpu().numpy(), yc.detach().numpy(), TOL, "split-K fwd")
+    assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), TOL, "split-K dgrad")
+    assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), TOL, "wgrad")

@@ -45,10 +45,10 @@ def test_bad_arguments_are_reported_not_crashed():
     L = _rn.lib()
     geom = _rn.ConvGeom(3, 3, 1, 8)
     segs = (_rn.ConvSeg * 1)()
-    assert L.rn_conv2d_fwd(segs, 0, ctypes.byref(geom), None) == -1          # RN_EINVAL
+    assert L.rn_conv2d_fwd(segs, 0, ctypes.byref(geom), None, 0, None) == -1          # RN_EINVAL
     assert b"nseg" in L.rn_last_error()
     segs[0].n, segs[0].h, segs[0].w, segs[0].cout = 1, 4, 4, 8
-    assert L.rn_conv2d_fwd(segs, 1, ctypes.byref(geom), None) == -1          # null pointers
+    assert L.rn_conv2d_fwd(segs, 1, ctypes.byref(geom), None, 0, None) == -1          # null pointers
     assert L.rn_depthwise_fwd(None, None, None, 1, 4, 4, 6, 3, 1, None) in (-1, -2)
 
 

@@ -42,7 +42,7 @@ def run_one():
         xd = [x.detach() for x in xs]
         dxs = [torch.empty_like(x) for x in xd]
         segs = ops._conv_segs(xd, w.detach(), None, None, dys, dxs)
-        t_d = timeit(lambda: L.rn_conv2d_dgrad(segs, len(xd), C.byref(geom), _rn.stream()))
+        t_d = timeit(lambda: L.rn_conv2d_dgrad(segs, len(xd), C.byref(geom), None, 0, _rn.stream()))
         need = L.rn_conv2d_wgrad_workspace(segs, len(xd), C.byref(geom))
         ws = _rn.workspace(need, dev)
         dw = torch.empty_like(w)

@@ -77,8 +77,8 @@ def main():
         else:
             os.environ["RN_CONV_CFG"] = cfg
         r = {
-            "direct fwd": timeit(lambda: L.rn_conv2d_fwd(segs, len(xs), C.byref(geom), _rn.stream())),
-            "direct dgrad": timeit(lambda: L.rn_conv2d_dgrad(segs, len(xs), C.byref(geom), _rn.stream())),
+            "direct fwd": timeit(lambda: L.rn_conv2d_fwd(segs, len(xs), C.byref(geom), None, 0, _rn.stream())),
+            "direct dgrad": timeit(lambda: L.rn_conv2d_dgrad(segs, len(xs), C.byref(geom), None, 0, _rn.stream())),
         }
         for tile in (2, 4):
             r["F%d fwd" % tile] = timeit(lambda: wino(tile, 0))
