@@ -105,7 +105,9 @@ int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g
  * A training step has ~130 of them, each a launch-latency-bound kernel.  After rn_defer_reductions(stream, 1) they
  * are recorded instead of launched and rn_flush_reductions(stream) runs them all as one launch (per 96).  While
  * deferring, the `workspace` handed to those entry points must stay untouched until the flush (give each call its
- * own buffer), and the gradients are only valid after the flush.  Results are bitwise identical to immediate mode. */
+ * own buffer), and the gradients are only valid after the flush.  Results are bitwise identical to immediate mode,
+ * except the GroupNorm dgamma / dbeta of maps too large for the single-kernel path, whose chunk rows are then summed
+ * in fp32 (fixed order) instead of fp64. */
 int rn_defer_reductions(rn_stream_t stream, int on);
 int rn_flush_reductions(rn_stream_t stream);
 

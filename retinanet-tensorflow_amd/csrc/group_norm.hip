@@ -31,7 +31,7 @@ struct GnArgs {
   uint64_t seed;
   const uint64_t* seed_dev;  // optional device counter added to seed (graph replays get fresh masks)
   const float* gamma; const float* beta;
-  float* partial;  // [total_chunks][c][2]
+  float* partial;  // [2][total_chunks][c]: plane 0 = sum x (bwd: sum g), plane 1 = sum x^2 (bwd: sum g*xhat)
   float* coef;     // bwd: [samples][groups][2]
   float* dgamma; float* dbeta;
   int total_chunks, total_samples;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(T) void gn_partial_kernel(const GnArgs a) {
       const int q = e >> 3, comp = e & 7;
       float t = 0.f;
       for (int l = 0; l < lanes; ++l) t += red[l * QP + q][comp];
-      a.partial[((size_t)ch * C + (qbase + q) * 4 + (comp & 3)) * 2 + (comp >> 2)] = t;
+      a.partial[(size_t)(comp >> 2) * a.total_chunks * C + (size_t)ch * C + (qbase + q) * 4 + (comp & 3)] = t;
     }
   }
 }
@@ -162,14 +162,15 @@ __global__ __launch_bounds__(T) void gn_finalize_kernel(const GnArgs a) {
     const GnSeg& sg = a.seg[s];
     const int nl = q - sg.sample_start;
     const int items = sg.chunks * a.cpg;
-    const float* base = a.partial + (size_t)(sg.chunk_start + nl * sg.chunks) * a.c * 2;
+    const float* base = a.partial + (size_t)(sg.chunk_start + nl * sg.chunks) * a.c;
+    const size_t plane = (size_t)a.total_chunks * a.c;
     double v1 = 0.0, v2 = 0.0;
     for (int i = tid; i < items; i += T) {
       const int ck = i / a.cpg, c = g * a.cpg + (i - ck * a.cpg);
-      const float2 p = *reinterpret_cast<const float2*>(base + ((size_t)ck * a.c + c) * 2);
+      const float p1 = base[(size_t)ck * a.c + c], p2 = base[plane + (size_t)ck * a.c + c];
       const double w = BWD ? (double)a.gamma[c] : 1.0;
-      v1 += w * (double)p.x;
-      v2 += w * (double)p.y;
+      v1 += w * (double)p1;
+      v2 += w * (double)p2;
     }
     block_sum2(v1, v2, sh);
     if (tid == 0) {
@@ -190,10 +191,10 @@ __global__ __launch_bounds__(T) void gn_finalize_kernel(const GnArgs a) {
     const int c = ((int)blockIdx.x - ngroup_blocks) * 16 + cl;
     double b = 0.0, g = 0.0;
     if (c < a.c) {
+      const size_t plane = (size_t)a.total_chunks * a.c;
       for (int r = rl; r < a.total_chunks; r += 16) {
-        const float2 p = *reinterpret_cast<const float2*>(a.partial + ((size_t)r * a.c + c) * 2);
-        b += (double)p.x;
-        g += (double)p.y;
+        b += (double)a.partial[(size_t)r * a.c + c];
+        g += (double)a.partial[plane + (size_t)r * a.c + c];
       }
     }
     pg[rl][cl][0] = b; pg[rl][cl][1] = g;
@@ -747,8 +748,16 @@ extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
     return RN_OK;
   }
   hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(a.total_chunks), dim3(T), 0, st, a);
-  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(a.total_samples * a.groups + rn::ceil_div(a.c, 16)), dim3(T), 0, st, a);
+  // dbeta / dgamma = the column sums of the two partial planes: blocks appended to the finalize launch, or -- while
+  // the step's reductions are deferred -- two rows of the single batched reduction
+  const bool defer = rn::reduce_deferred(st);
+  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(a.total_samples * a.groups + (defer ? 0 : rn::ceil_div(a.c, 16))), dim3(T), 0,
+                     st, a);
   hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(apply_blocks(a), a.total_samples), dim3(T), 0, st, a);
   RN_LAUNCH_CHECK();
+  if (defer) {
+    if (int e = rn::launch_reduce_rows(a.partial, dbeta, a.c, a.total_chunks, 0, st)) return e;
+    return rn::launch_reduce_rows(a.partial + (size_t)a.total_chunks * a.c, dgamma, a.c, a.total_chunks, 0, st);
+  }
   return RN_OK;
 }

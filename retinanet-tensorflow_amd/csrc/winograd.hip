@@ -350,6 +350,10 @@ unsigned grid_for(int64_t total) {
 }
 // widest access that still leaves ~4 waves per SIMD of work on 256 CUs
 int width_for(int64_t tiles, int c) {
+  if (const char* force = getenv("RN_WINO_W")) {  // tuning aid
+    const int w = atoi(force);
+    if (w == 1 || w == 2 || w == 4) return w;
+  }
   const int64_t want = 256 * 1024;
   if (tiles * (c / 4) >= want) return 4;
   return tiles * (c / 2) >= want ? 2 : 1;
