@@ -7,6 +7,7 @@ parameters and run in one launch (the shared heads over P3..P7, reference
 retinanet.py:283-291).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -58,13 +59,13 @@ class _on_side_stream(object):
 
 
 # Winograd F(4x4,3x3) (or F(2x2,3x3): WINOGRAD_TILE = 2) for dense 3x3 / stride-1 convs wide enough to pay for
-# the transforms (head towers, FPN merges, the 720-wide class output conv): forward and data gradient; the
-# weight gradient stays direct.
+# the transforms (head towers, FPN merges, the 720-wide class output conv): forward, data gradient and (WINOGRAD_WGRAD)
+# weight gradient.
 WINOGRAD = True
 WINOGRAD_TILE = 4
 WINOGRAD_WGRAD = True
 WINOGRAD_MIN_CHANNELS = 64
-WINOGRAD_MAX_WORKSPACE = 1 << 30
+WINOGRAD_MAX_WORKSPACE = int(os.environ.get("RN_WINOGRAD_MAX_WS", 8 << 30))   # of 288 GB HBM; the V / M planes of 1024^2 x 16 need 1.7 GB
 
 
 def _winograd_ok(w, stride, groups, xs):
