@@ -121,30 +121,54 @@ __global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
   if (lane == 0) a.wave_count[wid] = __popcll(m);
 }
 
-// ---- 2. exclusive scan of wave counts (single block; n_waves is at most a few 10^4)
-__global__ void det_offsets_kernel(const DetArgs a) {
-  __shared__ int sh[1024];
-  __shared__ int carry;
-  const int64_t nw = (int64_t)a.n * a.waves_per_image;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int64_t base = 0; base < nw; base += 1024) {
-    const int64_t i = base + threadIdx.x;
-    const int v = i < nw ? a.wave_count[i] : 0;
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      const int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-      __syncthreads();
-      sh[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < nw) a.wave_off[i] = carry + sh[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += sh[1023];
-    __syncthreads();
+// exclusive scan of one int per thread across a 1024-thread block (wave shuffles + one LDS hop); returns the
+// exclusive prefix of `v`, *total = block sum
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total) {
+  __shared__ int wsum[16];
+  __shared__ int wtot;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
   }
-  if (threadIdx.x == 0) a.counts[0] = carry;
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    int w = lane < 16 ? wsum[lane] : 0;
+    int winc = w;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int t = __shfl_up(winc, o, 64);
+      if (lane >= o) winc += t;
+    }
+    if (lane < 16) wsum[lane] = winc - w;  // exclusive prefix of the wave totals
+    if (lane == 15) wtot = winc;
+  }
+  __syncthreads();
+  const int ex = wsum[wave] + inc - v;
+  *total = wtot;
+  __syncthreads();
+  return ex;
+}
+
+// ---- 2. exclusive scan of wave counts (single block; n_waves is a few 10^4: a contiguous run per thread, one
+//         block-wide scan of the run totals)
+__global__ __launch_bounds__(1024) void det_offsets_kernel(const DetArgs a) {
+  const int64_t nw = (int64_t)a.n * a.waves_per_image;
+  const int64_t per = (nw + 1023) / 1024;
+  const int64_t b = (int64_t)threadIdx.x * per, e = b + per < nw ? b + per : nw;
+  int local = 0;
+  for (int64_t i = b; i < e; ++i) local += a.wave_count[i];
+  int total;
+  int run = block_exclusive_scan_1024(local, &total);
+  for (int64_t i = b; i < e; ++i) {
+    const int v = a.wave_count[i];
+    a.wave_off[i] = run;
+    run += v;
+  }
+  if (threadIdx.x == 0) a.counts[0] = total;
 }
 
 // ---- 3. emit candidates in anchor order; pad the key array with sentinels
@@ -250,21 +274,26 @@ __global__ __launch_bounds__(64) void det_nms_kernel(const DetArgs a) {
   if (lane == 0) a.seg_keep[k] = nk;
 }
 
-// ---- exclusive scan of kept counts per segment + per-image totals (single block)
-__global__ void det_keep_offsets_kernel(const DetArgs a) {
-  if (threadIdx.x != 0) return;
-  int run = 0;
-  for (int img = 0; img < a.n; ++img) {
-    int tot = 0;
-    for (int c = 0; c < a.C; ++c) {
-      const int k = img * a.C + c;
-      a.seg_off[k] = run;
-      run += a.seg_keep[k];
-      tot += a.seg_keep[k];
-    }
-    a.counts[2 + img] = tot;
+// ---- exclusive scan of kept counts per segment + per-image totals (single 1024-thread block)
+__global__ __launch_bounds__(1024) void det_keep_offsets_kernel(const DetArgs a) {
+  const int nseg = a.n * a.C;
+  const int per = (nseg + 1023) / 1024;
+  const int b = threadIdx.x * per, e = min(b + per, nseg);
+  int local = 0;
+  for (int k = b; k < e; ++k) local += a.seg_keep[k];
+  int total;
+  int run = block_exclusive_scan_1024(local, &total);
+  for (int k = b; k < e; ++k) {
+    a.seg_off[k] = run;
+    run += a.seg_keep[k];
   }
-  a.counts[1] = run;
+  __syncthreads();  // seg_off complete (same block: global writes are visible after the barrier)
+  for (int img = threadIdx.x; img < a.n; img += 1024) {
+    const int first = a.seg_off[img * a.C];
+    const int next = img + 1 < a.n ? a.seg_off[(img + 1) * a.C] : total;
+    a.counts[2 + img] = next - first;
+  }
+  if (threadIdx.x == 0) a.counts[1] = total;
 }
 
 __global__ void det_gather_kernel(const DetArgs a) {
@@ -420,7 +449,7 @@ int sort_and_suppress(DetArgs& a, const WsLayout& L, void* workspace, hipStream_
   const int nseg = a.n * a.C;
   hipLaunchKernelGGL(det_segments_kernel, dim3(rn::ceil_div(nseg + 1, 256)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(det_nms_kernel, dim3(nseg), dim3(64), 0, st, a);
-  hipLaunchKernelGGL(det_keep_offsets_kernel, dim3(1), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(det_keep_offsets_kernel, dim3(1), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(det_gather_kernel, dim3(nseg), dim3(64), 0, st, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
