@@ -90,6 +90,7 @@ __global__ __launch_bounds__(T) void gn_partial_kernel(const GnArgs a) {
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const int q4 = qbase + tid % QP, pl = tid / QP;
     if (pl < lanes && q4 < CQ) {
+#pragma unroll 4
       for (int p = p_begin + pl; p < p_end; p += lanes) {
         const size_t off = (size_t)p * C + q4 * 4;
         const float4 xv = BWD ? *reinterpret_cast<const float4*>(x + off) : rn::ld4(sg.x, base + off, a.in_half);
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(T) void gn_apply_kernel(const GnArgs a) {
   const uint64_t samp_off = (uint64_t)q * (uint64_t)sg.hw * (uint64_t)C;
   const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
   const int64_t total = (int64_t)sg.hw * CQ;
+#pragma unroll 2
   for (int64_t i = (int64_t)blockIdx.x * T + tid; i < total; i += (int64_t)gridDim.x * T) {
     const int q4 = (int)(i % CQ);
     const size_t off = (size_t)i * 4;
@@ -577,6 +579,8 @@ int plan_slices(GnArgs* a) {
   for (int s = 0; s < a->nseg; ++s) max_hw = max_hw > a->seg[s].hw ? max_hw : a->seg[s].hw;
   // gb whole groups per block: the widest run of channels (up to a 128-byte line) that still fits the registers --
   // a block that uses only part of every line it touches multiplies its L2 traffic
+  int min_wc = 8;
+  if (const char* force = getenv("RN_GN_SLICE_WC")) min_wc = atoi(force);  // tuning aid
   int best = 0;
   for (int gb = 1; gb <= a->groups; ++gb) {
     if (a->groups % gb) continue;
@@ -584,7 +588,7 @@ int plan_slices(GnArgs* a) {
     if (wc > SLICE_MAX_WC) break;
     if ((long)max_hw > (long)SLICE_MAX_R * (ST / wc)) break;
     best = wc;
-    if (wc >= 32) break;
+    if (wc >= min_wc) break;
   }
   if (!best) return 0;
   a->slice_wc = best;
@@ -669,7 +673,7 @@ unsigned apply_blocks(const GnArgs& a) {
   for (int s = 0; s < a.nseg; ++s) mx = mx > (long)a.seg[s].hw * (a.c / 4) ? mx : (long)a.seg[s].hw * (a.c / 4);
   long b = (mx + T * 4 - 1) / (T * 4);
   if (b < 1) b = 1;
-  if (b > 512) b = 512;
+  if (b > 2048) b = 2048;  // x samples in grid.y: one float4 per thread for maps up to 2 M elements per sample
   return (unsigned)b;
 }
 
