@@ -232,6 +232,13 @@ int rn_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int k
 int rn_flip_width(const void* x, void* y, int64_t outer, int w, int64_t inner, int elem_bytes, int neg_mod, int neg_idx,
                   rn_stream_t stream);
 
+/* Input pipeline: tf.image.convert_image_dtype (in_u8: uint8 * 1/255) -> bilinear resize with
+ * align_corners=True (dataset.py:145-151 rescale_image; the TF ResizeBilinear arithmetic, operation by operation)
+ * -> optional (v - mean[c]) / std[c] (train.py:48-49 preprocess_image; mean / std are HOST arrays of c floats, both
+ * NULL = no normalisation).  x [n,h,w,c] uint8 or fp32, y [n,oh,ow,c] fp32, c <= 8. */
+int rn_resize_bilinear_normalize(const void* x, int in_u8, float* y, int n, int h, int w, int c, int oh, int ow,
+                                 const float* mean, const float* stdv, rn_stream_t stream);
+
 /* ------------------------------------------------------------------ loss
  * Replaces utils.process_labels_and_logits/postprocess_and_mask (utils.py:240-284; the
  * boolean_mask compaction becomes a 0/1 row weight, result-identical) and losses.loss

@@ -99,3 +99,52 @@ def flip(classifications, regressions, trainable_masks, image=None):
         out_r[k] = r
     img = None if image is None else image[:, ::-1].copy()
     return out_c, out_r, out_m, img
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Input pipeline: rescale_image dataset.py:145-151, preprocess_image train.py:48-49,
+# tf.image.convert_image_dtype (uint8 -> float32 * 1/255).  PARITY UNPINNED against TensorFlow itself (not
+# installable here): this restates the published ResizeBilinear kernel (align_corners=True, half_pixel_centers=False:
+# scale = (in-1)/(out-1); in = dst*scale; lo = floor(in); hi = min(ceil(in), size-1); lerp = in - lo;
+# top = tl + (tr-tl)*xl; bot = bl + (br-bl)*xl; out = top + (bot-top)*yl), one float32 numpy op per TF operation.
+MEAN = np.asarray([0.46618041, 0.44669811, 0.40252436], np.float32)   # dataset.py:12
+STD = np.asarray([0.27940595, 0.27489075, 0.28920765], np.float32)    # dataset.py:13
+
+
+def rescale_size(size, scale):
+    size = np.asarray(size, np.float32)
+    ratio = f32(scale) / size[int(np.argmin(size))]
+    new = np.rint(size * ratio).astype(np.int32)      # tf.round: half to even
+    return int(new[0]), int(new[1])
+
+
+def _interp(out_size, in_size):
+    scale = f32(in_size - 1) / f32(out_size - 1) if out_size > 1 else f32(0)
+    src = np.arange(out_size, dtype=np.float32) * scale
+    lo_f = np.floor(src)
+    lo = np.maximum(lo_f.astype(np.int64), 0)
+    hi = np.minimum(np.ceil(src).astype(np.int64), in_size - 1)
+    return lo, hi, (src - lo_f).astype(np.float32)
+
+
+def resize_bilinear_align_corners(image, out_h, out_w):
+    """image [N,H,W,C] uint8 or float32 -> float32 [N,out_h,out_w,C]."""
+    x = image.astype(np.float32) * f32(1.0 / 255.0) if image.dtype == np.uint8 else image.astype(np.float32)
+    y0, y1, yl = _interp(out_h, x.shape[1])
+    x0, x1, xl = _interp(out_w, x.shape[2])
+    xl = xl[None, None, :, None]
+    yl = yl[None, :, None, None]
+    tl, tr = x[:, y0][:, :, x0], x[:, y0][:, :, x1]
+    bl, br = x[:, y1][:, :, x0], x[:, y1][:, :, x1]
+    top = tl + (tr - tl) * xl
+    bot = bl + (br - bl) * xl
+    return (top + (bot - top) * yl).astype(np.float32)
+
+
+def rescale_image(image, scale):
+    oh, ow = rescale_size(image.shape[-3:-1], scale)
+    return resize_bilinear_align_corners(image if image.ndim == 4 else image[None], oh, ow)[slice(None) if image.ndim == 4 else 0]
+
+
+def preprocess_image(image):
+    return ((image.astype(np.float32) - MEAN) / STD).astype(np.float32)

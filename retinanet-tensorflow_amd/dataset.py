@@ -8,6 +8,7 @@ The tf.data input pipeline of the reference (file reading, JPEG decode, shuffle,
 dataset.py:145-233) is out of scope; what remains of it here is the
 label construction and the ``[image, hflip(image)]`` batch convention (dataset.py:182-204).
 """
+import ctypes as C
 import math
 
 import numpy as np
@@ -61,3 +62,65 @@ def flip_boxes(boxes):
     """h-flip of normalised corner boxes [.., 4] = [y1, x1, y2, x2] (labels of the flipped image
     of the reference's [image, hflip] batch, dataset.py:182-204, are built from these)."""
     return torch.stack([boxes[..., 0], 1.0 - boxes[..., 3], boxes[..., 2], 1.0 - boxes[..., 1]], -1)
+
+
+def rescale_size(size, scale):
+    """New (h, w) of dataset.py:145-151: shorter side -> `scale`, tf.round (half to even) of size * ratio, the
+    arithmetic in float32 as tf.to_float / tf.round do it."""
+    size = np.asarray(size, np.float32)
+    ratio = np.float32(scale) / size[int(np.argmin(size))]
+    new = np.rint(size * ratio).astype(np.int32)                 # np.rint == tf.round: half to even
+    return int(new[0]), int(new[1])
+
+
+def rescale_image(image, scale=None, size=None, normalize=False):
+    """tf.image.resize_images(image, new_size, BILINEAR, align_corners=True) (dataset.py:145-151) on the device.
+    image: [H,W,C] or [N,H,W,C], uint8 (converted like tf.image.convert_image_dtype: * 1/255) or fp32.
+    normalize=True also applies train.py:48-49 preprocess_image ((v - MEAN) / STD) in the same pass."""
+    batched = image.dim() == 4
+    x = (image if batched else image[None]).contiguous()
+    n, h, w, c = x.shape
+    oh, ow = size if size is not None else rescale_size((h, w), scale)
+    y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
+    assert x.dtype in (torch.uint8, torch.float32)
+    mean = std = None
+    if normalize:
+        assert c == 3
+        mean = (C.c_float * 3)(*MEAN)
+        std = (C.c_float * 3)(*STD)
+    _rn.check(_rn.lib().rn_resize_bilinear_normalize(_rn.ptr(x), 1 if x.dtype == torch.uint8 else 0, _rn.f32(y), n, h, w, c,
+                                                     oh, ow, mean, std, _rn.stream()), 'rn_resize_bilinear_normalize')
+    return y if batched else y[0]
+
+
+def preprocess_image(image):
+    """(image - MEAN) / STD (train.py:48-49) for a float image already at its final size."""
+    return rescale_image(image, size=tuple(image.shape[-3:-1]), normalize=True)
+
+
+def build_dataset(data_loader, levels, scale=None, shuffle=None, augment=False, device='cuda', normalize=True):
+    """Generator form of dataset.py:154-215: per sample  decode -> boxes / image_size -> rescale_image ->
+    build_labels -> [sample, hflip(sample)] batch (augmentation.make_pair) -> preprocess_image.  Everything after the
+    host loader runs on the device.  `shuffle` / `augment` are accepted for signature parity (the reference's
+    augment_sample is a TODO stub; shuffling belongs to the loader here)."""
+    import augmentation
+    dev = torch.device(device)
+    for sample in data_loader:
+        image = torch.from_numpy(np.ascontiguousarray(sample['image'])).to(dev)                # uint8 or float [H,W,3]
+        h, w = int(image.shape[0]), int(image.shape[1])
+        boxes = np.asarray(sample['boxes'], np.float32) / np.asarray([h, w, h, w], np.float32)   # dataset.py:163
+        if scale is not None:
+            image = rescale_image(image, scale)
+        elif image.dtype == torch.uint8:
+            image = rescale_image(image, size=(h, w))
+        size = (int(image.shape[0]), int(image.shape[1]))
+        ids = torch.from_numpy(np.asarray(sample['class_ids'], np.int32)).to(dev)[None]
+        c, r, m = build_labels(size, ids, torch.from_numpy(boxes).to(dev)[None], levels, data_loader.num_classes)
+        one = {'image': image, 'image_size': size, 'boxes': boxes, 'class_ids': sample['class_ids'],
+               'detection': {'classifications': {k: v[0] for k, v in c.items()},
+                             'regressions': {k: v[0] for k, v in r.items()}},
+               'trainable_masks': {k: v[0] for k, v in m.items()}}
+        batch = augmentation.make_pair(one)
+        if normalize:
+            batch['image'] = preprocess_image(batch['image'])
+        yield batch

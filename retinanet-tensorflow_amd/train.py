@@ -225,29 +225,40 @@ def _copy_tree(dst, src):
 # Minimal driver with the reference's flags (train.py:88-108).  Dataset readers (COCO / Pascal, cv2,
 # pycocotools) are out of scope; 'shapes' is a synthetic stand-in following data_loaders/shapes.py:133-176
 # (1-4 filled squares, half-size in [20, S/4], 3 classes), rendered with numpy.
-class ShapesLoader(object):
-    class_names = ['square_r', 'square_g', 'square_b']
-    num_classes = 3
-
-    def __init__(self, image_size=(256, 256), seed=0, length=1 << 30):
-        self.size, self.rng, self.length = image_size, np.random.default_rng(seed), length
-
-    def __iter__(self):
-        h, w = self.size
-        for _ in range(self.length):
-            image = np.full((h, w, 3), 0.5, np.float32) + self.rng.normal(0, 0.02, (h, w, 3)).astype(np.float32)
-            n = int(self.rng.integers(1, 5))
-            boxes, ids = [], []
-            for _ in range(n):
-                half = int(self.rng.integers(20, max(21, min(h, w) // 4)))
-                cy, cx = int(self.rng.integers(20, h - 20)), int(self.rng.integers(20, w - 20))
-                y1, x1, y2, x2 = max(cy - half, 0), max(cx - half, 0), min(cy + half, h), min(cx + half, w)
-                c = int(self.rng.integers(0, 3))
-                image[y1:y2, x1:x2, :] = 0.1
-                image[y1:y2, x1:x2, c] = 0.9
-                boxes.append([y1 / h, x1 / w, y2 / h, x2 / w])
-                ids.append(c)
-            yield {'image': image, 'boxes': np.asarray(boxes, np.float32), 'class_ids': np.asarray(ids, np.int32)}
+def evaluate(net, data_loader, levels, num_images, scale=None, device='cuda', score_threshold=0.5):
+    """Inference + decode + class-wise NMS (train.py:68-85) over `num_images` samples of the loader, scored with
+    COCO-style mAP and the reference's two IoU metrics (train.py:137-161); see metrics.py."""
+    import dataset
+    import metrics
+    dets, gts, ciou, riou = [], [], [], []
+    it = dataset.build_dataset(data_loader, levels, scale=scale, device=device)
+    with torch.no_grad():
+        for _ in range(num_images):
+            try:
+                b = next(it)
+            except StopIteration:
+                break
+            image = b['image'][:1]                                                 # the un-flipped half
+            out = net(image, training=False)
+            size = (int(image.shape[1]), int(image.shape[2]))
+            anchors = {k: levels[k].normalized_anchor_sizes(size) for k in levels}
+            probs = {k: ops.activation(v, 'sigmoid') for k, v in out['classifications'].items()}
+            dec = {k: utils.regression_postprocess(out['regressions'][k], anchors[k]) for k in levels}
+            d = utils.detect(probs, dec, data_loader.num_classes, score_threshold=score_threshold)[0]
+            dets.append((d.boxes.cpu().numpy(), d.scores.cpu().numpy(), d.class_ids.cpu().numpy()))
+            gts.append((np.asarray(b['boxes'], np.float32), np.asarray(b['class_ids'])))
+            for k in levels:                                                       # build_metrics inputs, per level
+                m = b['trainable_masks'][k][:1].cpu().numpy().astype(bool)
+                lab = b['detection']['classifications'][k][:1].cpu().numpy()
+                ciou.append((lab[m], probs[k].cpu().numpy()[m]))
+                fg = lab.max(-1) > 0.5
+                true_boxes = utils.regression_postprocess(b['detection']['regressions'][k][:1], anchors[k]).cpu().numpy()
+                riou.append((true_boxes[fg], dec[k].cpu().numpy()[fg]))
+    res = metrics.mean_average_precision(dets, gts, data_loader.num_classes)
+    res['class_iou'] = metrics.class_iou(np.concatenate([a.reshape(-1) for a, _ in ciou]), np.concatenate([p.reshape(-1) for _, p in ciou]))
+    res['regr_iou'] = metrics.regr_iou(np.concatenate([a for a, _ in riou]), np.concatenate([p for _, p in riou]))
+    res['images'] = len(dets)
+    return res
 
 
 def build_parser():
@@ -265,6 +276,7 @@ def build_parser():
     parser.add_argument('--optimizer', type=str, choices=['momentum', 'adam', 'rmsprop'], default='momentum')
     parser.add_argument('--loss', type=str, choices=['bce_dice', 'focal'], default='bce_dice')
     parser.add_argument('--steps-per-epoch', type=int, default=100)
+    parser.add_argument('--eval-images', type=int, default=0, help='after training: mAP / IoU metrics over this many samples')
     return parser
 
 
@@ -276,31 +288,22 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     assert args.dataset[0] == 'shapes', 'only the synthetic shapes loader is built in (file readers are out of scope)'
     dev = torch.device('cuda', int(__import__('os').environ.get('LOCAL_RANK', '0')))
-    loader = ShapesLoader((args.scale, args.scale))
+    from data_loaders.shapes import Shapes
+    loader = Shapes(None, image_size=(args.scale + args.scale // 4, args.scale))   # rescale_image brings it to --scale
     levels = build_levels()
     net = retinanet.RetinaNet(backbone=args.backbone, levels=levels, num_classes=loader.num_classes, activation=L.elu,
                               dropout_rate=args.dropout).to(dev)
     trainer = Trainer(net, levels, optimizer=args.optimizer, learning_rate=args.learning_rate,
                       grad_clip_norm=args.grad_clip_norm, loss_mode=args.loss, device=dev)
-    mean = torch.tensor(dataset.MEAN, device=dev)
-    std = torch.tensor(dataset.STD, device=dev)
     step = 0
     path = None if args.experiment is None else __import__('os').path.join(args.experiment, 'model.safetensors')
     if path is not None and __import__('os').path.exists(path):
         step = checkpoint.load(path, net, trainer)
         print('restored step', step)
-    it = iter(loader)
+    it = dataset.build_dataset(loader, levels, scale=args.scale, device=dev)       # train.py:192-203 train_input_fn
     for epoch in range(args.epochs):
         for _ in range(args.steps_per_epoch):
-            sample = next(it)
-            image = (torch.from_numpy(sample['image']).to(dev) - mean) / std             # train.py:48-49
-            boxes = torch.from_numpy(sample['boxes']).to(dev)[None]
-            ids = torch.from_numpy(sample['class_ids']).to(dev)[None]
-            c, r, m = dataset.build_labels(loader.size, ids, boxes, levels, loader.num_classes)
-            one = {'image': image, 'detection': {'classifications': {k: v[0] for k, v in c.items()},
-                                                 'regressions': {k: v[0] for k, v in r.items()}},
-                   'trainable_masks': {k: v[0] for k, v in m.items()}}
-            out = trainer.step(augmentation.make_pair(one))                                # batch = [image, hflip]
+            out = trainer.step(next(it))                                           # batch = [image, hflip]
             step += 1
             if step % 20 == 0:
                 print('epoch %d step %d class_loss %.4f regr_loss %.4f reg %.4f' % (
@@ -308,6 +311,11 @@ def main(argv=None):
                     flush=True)
         if path is not None:
             checkpoint.save(path, net, trainer, step=step)
+    if args.eval_images:
+        res = evaluate(net, Shapes(None, image_size=(args.scale + args.scale // 4, args.scale), seed=12345), levels,
+                       args.eval_images, scale=args.scale, device=dev)
+        print('eval: mAP %.4f AP50 %.4f AP75 %.4f class_iou %.4f regr_iou %.4f over %d images' % (
+            res['mAP'], res['AP50'], res['AP75'], res['class_iou'], res['regr_iou'], res['images']), flush=True)
     return step
 
 

@@ -744,3 +744,46 @@ def test_split_k_tiny_grids(dev, case):
     assert_close(yg.detach().cpu().numpy(), yc.detach().numpy(), TOL, "split-K fwd")
     assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), TOL, "split-K dgrad")
     assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), TOL, "wgrad")
+
+
+@pytest.mark.parametrize("case", [((2, 37, 53, 3), (64, 91), "u8"), ((1, 120, 80, 3), (48, 32), "f32"), ((1, 5, 7, 3), (1, 1), "f32"),
+                                  ((2, 16, 16, 4), (16, 16), "u8"), ((1, 3, 2, 1), (9, 11), "f32")])
+def test_resize_bilinear_normalize_bit_exact(dev, case):
+    """rescale_image (align_corners bilinear) + convert_image_dtype + preprocess_image == the oracle, bit for bit."""
+    import dataset
+    shape, (oh, ow), kind = case
+    rng = np.random.default_rng(shape[1] * 7 + oh)
+    x = rng.integers(0, 256, shape).astype(np.uint8) if kind == "u8" else rng.random(shape).astype(np.float32)
+    ref = dataset_ref.resize_bilinear_align_corners(x, oh, ow)
+    got = dataset.rescale_image(_t(x, dev), size=(oh, ow))
+    assert np.array_equal(got.cpu().numpy(), ref)
+    if shape[3] == 3:
+        got = dataset.rescale_image(_t(x, dev), size=(oh, ow), normalize=True)
+        assert np.array_equal(got.cpu().numpy(), dataset_ref.preprocess_image(ref))
+    assert dataset.rescale_size((480, 640), 256) == dataset_ref.rescale_size((480, 640), 256) == (256, 341)
+    assert dataset.rescale_size((500, 375), 300) == (400, 300)          # 1.3333334 * 300 = 400.00003 -> 400
+
+
+def test_build_dataset_pipeline(dev):
+    """data_loaders.shapes -> rescale -> labels -> [sample, hflip] -> normalise, all on the device; labels of the
+    flipped half equal labels built from flipped boxes."""
+    import dataset, levels as levels_mod
+    from data_loaders.shapes import Shapes
+    lv = levels_mod.build_levels()
+    loader = Shapes(None, num_samples=2, image_size=(160, 128), seed=3)
+    assert loader.num_classes == 3 and loader.class_names == ['square', 'triangle', 'circle']
+    batches = list(dataset.build_dataset(loader, lv, scale=96, device=dev))
+    assert len(batches) == 2
+    b = batches[0]
+    assert tuple(b['image'].shape) == (2, 120, 96, 3) and b['image'].dtype == torch.float32
+    for k in lv:
+        assert b['detection']['classifications'][k].shape[0] == 2
+        assert b['trainable_masks'][k].dtype in (torch.bool, torch.uint8)
+    # the second half is the h-flip of the first
+    assert torch.equal(b['image'][1], torch.flip(b['image'][0], [1]))
+    flipped_boxes = dataset.flip_boxes(torch.from_numpy(b['boxes']).to(dev))[None]
+    ids = torch.from_numpy(np.asarray(b['class_ids'], np.int32)).to(dev)[None]
+    c2, r2, m2 = dataset.build_labels(b['image_size'], ids, flipped_boxes, lv, 3)
+    for k in lv:
+        assert torch.equal(b['trainable_masks'][k][1], m2[k][0])
+        assert torch.equal(b['detection']['classifications'][k][1], c2[k][0])

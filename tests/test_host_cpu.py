@@ -127,3 +127,38 @@ def test_param_arena_layout_cpu():
         assert p.grad.data_ptr() == arena.grads[off:off + size].data_ptr()
     wd = arena.wd_per_block.numpy()
     assert set(np.unique(wd).tolist()) == {0.0, np.float32(4e-5).item(), np.float32(1e-4).item()}
+
+
+def test_metrics_known_answers_and_oracle():
+    """metrics.mean_average_precision: known answers + agreement with the naive oracle on random detections;
+    class_iou / regr_iou of train.py:137-161."""
+    import metrics
+    from oracle import metrics_ref
+    gt = [(np.array([[0.1, 0.1, 0.4, 0.4], [0.5, 0.5, 0.9, 0.9]]), np.array([0, 1])), (np.array([[0.2, 0.2, 0.6, 0.6]]), np.array([0]))]
+    perfect = [(g[0].copy(), np.array([0.9] * len(g[1])), g[1].copy()) for g in gt]
+    r = metrics.mean_average_precision(perfect, gt, 3)
+    assert abs(r['mAP'] - 1.0) < 1e-12 and abs(r['AP50'] - 1.0) < 1e-12 and np.isnan(r['per_class'][2])
+    # one of the two class-0 objects missed: recall stops at 0.5 -> AP = 51/101 for class 0, 1 for class 1
+    half = [perfect[0], (np.zeros((0, 4)), np.zeros(0), np.zeros(0, int))]
+    r = metrics.mean_average_precision(half, gt, 3, iou_thresholds=[0.5])
+    assert abs(r['per_class'][0] - 51 / 101) < 1e-12 and abs(r['per_class'][1] - 1.0) < 1e-12
+    # a duplicate detection of the same object is a false positive ranked after the true positive: AP unchanged
+    dup = [(np.concatenate([perfect[0][0], perfect[0][0][:1]]), np.array([0.9, 0.9, 0.8]), np.array([0, 1, 0])), perfect[1]]
+    assert abs(metrics.mean_average_precision(dup, gt, 3)['mAP'] - 1.0) < 1e-12
+    rng = np.random.default_rng(0)
+    dets, gts = [], []
+    for _ in range(4):
+        o = int(rng.integers(1, 6))
+        tl = rng.random((o, 2)) * 0.6
+        g = np.concatenate([tl, tl + 0.1 + rng.random((o, 2)) * 0.3], 1)
+        gc = rng.integers(0, 3, o)
+        k = int(rng.integers(2, 12))
+        src = rng.integers(0, o, k)
+        d = g[src] + rng.normal(0, 0.03, (k, 4))
+        dets.append((d, rng.random(k), np.where(rng.random(k) < 0.8, gc[src], rng.integers(0, 3, k))))
+        gts.append((g, gc))
+    thr = np.arange(0.5, 0.96, 0.05)
+    assert abs(metrics.mean_average_precision(dets, gts, 3)['mAP'] - metrics_ref.mean_ap(dets, gts, 3, thr)) < 1e-9
+    # tf.metrics.mean_iou, 2 classes: labels 1 1 0 0, predictions 1 0 0 0 -> IoU(1) = 1/2, IoU(0) = 2/3
+    assert abs(metrics.class_iou([1, 1, 0, 0], [0.9, 0.2, 0.1, 0.3]) - (0.5 + 2 / 3) / 2) < 1e-12
+    assert abs(metrics.regr_iou([[0, 0, 1, 1]], [[0, 0, 1, 0.5]]) - 0.5) < 1e-12
