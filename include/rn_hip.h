@@ -187,6 +187,9 @@ typedef struct rn_gn_params {
   uint64_t drop_seed; /* counter-based mask: keep iff hash(seed, elem) >= rate            */
   const uint64_t* drop_seed_dev; /* optional DEVICE counter added to drop_seed (so a replayed
                                     hipGraph draws a fresh mask every step); may be NULL    */
+  void* sync; /* optional: 4 zero-initialised DEVICE uint32 owned by the caller, private to the stream; enables the
+                 single-kernel path for mid-sized maps (<= 128 blocks meet at a bounded in-kernel barrier).  The
+                 kernels leave words 0-1 at zero; word 2 becomes 1 if a barrier ever timed out.  NULL = not used. */
 } rn_gn_params;
 
 size_t rn_group_norm_workspace(const rn_gn_seg* segs, int nseg, const rn_gn_params* p);

@@ -46,7 +46,7 @@ class GnSeg(C.Structure):
 class GnParams(C.Structure):
     _fields_ = [("c", C.c_int32), ("groups", C.c_int32), ("act", C.c_int32), ("act_after_residual", C.c_int32),
                 ("in_f16", C.c_int32), ("out_f16", C.c_int32), ("eps", C.c_float),
-                ("drop_rate", C.c_float), ("drop_seed", C.c_uint64), ("drop_seed_dev", C.c_void_p)]
+                ("drop_rate", C.c_float), ("drop_seed", C.c_uint64), ("drop_seed_dev", C.c_void_p), ("sync", C.c_void_p)]
 
 
 class LossSeg(C.Structure):
@@ -220,6 +220,25 @@ WORKSPACE_MIN_BYTES = 256 << 20
 
 SIDE_STREAMS = set()   # raw handles of streams that run concurrently with the main one
 _side_streams = {}
+
+
+_sync_words = {}
+
+
+def sync_counters(device):
+    """Four zeroed uint32 words per (device, current stream) for rn_gn_params.sync: the in-kernel barrier of the
+    grid-resident GroupNorm path.  The kernels leave them at zero; word 2 is set if a barrier ever timed out."""
+    key = (device.type, device.index, stream().value)
+    t = _sync_words.get(key)
+    if t is None:
+        t = torch.zeros(4, dtype=torch.int32, device=device)
+        _sync_words[key] = t
+    return t
+
+
+def barrier_timeouts():
+    """Number of (device, stream) counter sets whose error word is set (should always be 0)."""
+    return sum(int(t[2].item()) for t in _sync_words.values())
 
 
 def side_stream(device, index=0):

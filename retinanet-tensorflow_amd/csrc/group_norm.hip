@@ -35,6 +35,9 @@ struct GnArgs {
   float* coef;     // bwd: [samples][groups][2]
   float* dgamma; float* dbeta;
   int total_chunks, total_samples;
+  float* gpart;    // grid-resident path: [total_chunks][groups][2] per-block group sums
+  unsigned* sync;  // grid-resident path: two zero-initialised counters (+ an error word), left at zero
+  int coop_ppc;    // grid-resident path: pixels per block
   int slice_wc;    // slice-resident path: channels per block (a whole number of groups), 0 = not used
   float* pgrad;    // slice-resident bwd: [2][total_samples][c] per-sample sum g (plane 0) and sum g*xhat (plane 1)
 };
@@ -570,6 +573,325 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(const GnArgs a) {
   a.dgamma[c] = g;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Grid-resident path: maps too large for one block per slice but small enough for the registers of <= 128 co-resident
+// blocks (<= 4 M elements: the head towers over P3..P7, the backbone at 1/8 resolution) are ONE kernel as well: every
+// block loads its pixel range (all channels, full 16-byte coalesced rows) into registers, writes per-channel partial
+// sums, meets the other blocks at a grid barrier, derives its sample's statistics from the partial rows and applies
+// them to the registers -- x (and dy) are read once, y (dx) written once, instead of partial + finalize + apply with
+// a second read.  Co-residency: <= 128 blocks of 512 threads, one per CU; two such kernels (the two head streams)
+// still fit the 256 CUs together, nothing else in the step spins.  The barrier is bounded: if the blocks are not all
+// resident within ~10^6 polls it gives up (error word set, results of that call undefined) instead of hanging.
+// ---------------------------------------------------------------------------------------------
+constexpr int CT = 512, COOP_R = 16, COOP_MAX_BLOCKS = 128, COOP_MAX_C = 1024;
+
+// The only data exchanged across the barrier are the per-block group sums: they are written with device-scope
+// (write-through, sc1) stores and read back with device-scope loads, so the barrier itself needs NO cache write-back /
+// invalidate -- an agent-scope release + acquire here is an L2 flush + invalidate per block and cost more than the
+// two launches it replaced.  Order: every wave waits for its stores to be acknowledged, workgroup barrier, then
+// thread 0 announces the block with a relaxed atomic.
+__device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned nblocks) {
+  __shared__ int ok_sh;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool ok = true;
+    __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblocks) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 20)) { ok = false; break; }  // not all blocks resident: give up instead of hanging
+    }
+    if (!ok) atomicExch(&sync[2], 1u);
+    const unsigned d = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == nblocks - 1) {  // last one out: every block is past its poll loop, reset for the next call
+      __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ok_sh = ok ? 1 : 0;
+  }
+  __syncthreads();
+  return ok_sh != 0;
+}
+
+// per-channel (sum v1, sum v2) over the block's pixels -> chan[c][0..1] in LDS, optionally the two partial planes (row
+// `chunk`; the backward's dbeta / dgamma rows), and the per-group sums (weighted by gamma when WEIGHTED) -> gpart
+template <bool WEIGHTED, bool PLANES>
+__device__ __forceinline__ void coop_partials(const GnArgs& a, float (*red)[8], float (*chan)[2], const float (&s1)[4],
+                                              const float (&s2)[4], int chunk, int QP, int lanes, int CQ) {
+  const int tid = threadIdx.x, C = a.c;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[tid][j] = s1[j]; red[tid][4 + j] = s2[j]; }
+  __syncthreads();
+  for (int e = tid; e < CQ * 8; e += CT) {
+    const int q = e >> 3, comp = e & 7;
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += red[l * QP + q][comp];
+    const int c = q * 4 + (comp & 3);
+    chan[c][comp >> 2] = t;
+    if (PLANES) a.partial[(size_t)(comp >> 2) * a.total_chunks * C + (size_t)chunk * C + c] = t;
+  }
+  __syncthreads();
+  for (int e = tid; e < a.groups * 2; e += CT) {
+    const int g = e >> 1, comp = e & 1;
+    float t = 0.f;
+    for (int j = 0; j < a.cpg; ++j) {
+      const int c = g * a.cpg + j;
+      t += WEIGHTED ? a.gamma[c] * chan[c][comp] : chan[c][comp];
+    }
+    __hip_atomic_store(&a.gpart[((size_t)chunk * a.groups + g) * 2 + comp], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// after the barrier: per-group totals of this block's sample over its `rows` chunks (fp64, fixed order) -> out[g][0..1]
+__device__ __forceinline__ void coop_group_totals(const GnArgs& a, const float* gp, int rows, double (*lane_sum)[2], double (*out)[2]) {
+  const int tid = threadIdx.x, G2 = a.groups * 2;
+  const int RL = CT / G2 >= 1 ? CT / G2 : 1;  // row lanes per (group, component)
+  for (int e0 = 0; e0 < G2; e0 += CT) {      // G2 > CT: several passes with one row lane
+    const int e = e0 + (tid % (G2 < CT ? G2 : CT)), rl = tid / (G2 < CT ? G2 : CT);
+    double t = 0.0;
+    if (e < G2 && rl < RL) {
+#pragma unroll 4
+      for (int r = rl; r < rows; r += RL) t += (double)__hip_atomic_load(gp + (size_t)r * G2 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (G2 < CT) {
+      __syncthreads();
+      lane_sum[tid][0] = t;
+      __syncthreads();
+      if (tid < G2) {
+        double u = 0.0;
+        for (int l = 0; l < RL; ++l) u += lane_sum[l * G2 + tid][0];
+        out[tid >> 1][tid & 1] = u;
+      }
+    } else if (e < G2) {
+      out[e >> 1][e & 1] = t;
+    }
+  }
+  __syncthreads();
+}
+
+template <int ACT>
+__global__ __launch_bounds__(CT) void gn_coop_fwd_kernel(const GnArgs a) {
+  __shared__ float red[CT][8];
+  __shared__ float chan[COOP_MAX_C][2];
+  __shared__ double lane_sum[CT][2], gtot[COOP_MAX_C][2];
+  __shared__ float gstat[COOP_MAX_C][2];
+  const int tid = threadIdx.x, C = a.c, CQ = C >> 2, QP = CQ, lanes = CT / QP;
+  const int ch = blockIdx.x;
+  const GnSeg& sg = a.seg[seg_of_chunk(a, ch)];
+  const int local = ch - sg.chunk_start;
+  const int nl = local / sg.chunks, ck = local - nl * sg.chunks;
+  const int q = sg.sample_start + nl;
+  const int p_begin = ck * sg.ppc, p_end = min(p_begin + sg.ppc, sg.hw);
+  const size_t base = (size_t)nl * sg.hw * C;
+  const float* __restrict__ x = sg.x + base;
+  const int q4 = tid % QP, pl = tid / QP;
+  const bool active = pl < lanes;
+  float4 v[COOP_R];
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < COOP_R; ++k) {
+    const int p = p_begin + pl + k * lanes;
+    const float m = (active && p < p_end) ? 1.f : 0.f;
+    const float4 t = *reinterpret_cast<const float4*>(x + (size_t)min(p, sg.hw - 1) * C + q4 * 4);  // clamped, masked
+    v[k] = make_float4(t.x * m, t.y * m, t.z * m, t.w * m);
+    s1[0] += v[k].x; s1[1] += v[k].y; s1[2] += v[k].z; s1[3] += v[k].w;
+    s2[0] += v[k].x * v[k].x; s2[1] += v[k].y * v[k].y; s2[2] += v[k].z * v[k].z; s2[3] += v[k].w * v[k].w;
+  }
+  if (!active) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  }
+  coop_partials<false, false>(a, red, chan, s1, s2, ch, QP, lanes, CQ);
+  const bool ok = grid_barrier(a.sync, gridDim.x);
+  // statistics of this block's sample from the group rows of all its chunks (fp64, fixed order)
+  coop_group_totals(a, a.gpart + (size_t)(sg.chunk_start + nl * sg.chunks) * a.groups * 2, sg.chunks, lane_sum, gtot);
+  for (int g = tid; g < a.groups; g += CT) {
+    const double m = (double)sg.hw * (double)a.cpg;
+    const double mean = gtot[g][0] / m;
+    double var = gtot[g][1] / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    gstat[g][0] = (float)mean; gstat[g][1] = rstd;
+    if (ck == 0) { sg.mean[nl * a.groups + g] = (float)mean; sg.rstd[nl * a.groups + g] = rstd; }
+  }
+  __syncthreads();
+  if (!active || !ok) return;
+  float sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = q4 * 4 + j, g = c / a.cpg;
+    sc[j] = gstat[g][1] * a.gamma[c];
+    sh[j] = a.beta[c] - gstat[g][0] * sc[j];
+  }
+  const bool drop = a.drop_rate > 0.f;
+  const float keep_scale = drop ? 1.f / (1.f - a.drop_rate) : 1.f;
+  const uint64_t samp_off = (uint64_t)q * (uint64_t)sg.hw * (uint64_t)C;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+  const float* __restrict__ res = sg.res ? sg.res + base : nullptr;
+  float* __restrict__ y = sg.y + base;
+  const bool aar = a.act_after_res != 0;
+#pragma unroll
+  for (int k = 0; k < COOP_R; ++k) {
+    const int p = p_begin + pl + k * lanes;
+    if (p < p_end) {
+      const size_t off = (size_t)p * C + q4 * 4;
+      float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (res) rv = *reinterpret_cast<const float4*>(res + off);
+      const float xs[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      const float r[4] = {rv.x, rv.y, rv.z, rv.w};
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float z = xs[j] * sc[j] + sh[j];
+        float t = rn::act_fwd(aar ? z + r[j] : z, ACT);
+        if (drop) t = (rn::uniform01(seed, samp_off + off + j) >= a.drop_rate) ? t * keep_scale : 0.f;
+        o[j] = aar ? t : t + r[j];
+      }
+      *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(CT) void gn_coop_bwd_kernel(const GnArgs a) {
+  __shared__ float red[CT][8];
+  __shared__ float chan[COOP_MAX_C][2];
+  __shared__ double lane_sum[CT][2], gtot[COOP_MAX_C][2];
+  __shared__ float gcoef[COOP_MAX_C][2];
+  const int tid = threadIdx.x, C = a.c, CQ = C >> 2, QP = CQ, lanes = CT / QP;
+  const int ch = blockIdx.x;
+  const GnSeg& sg = a.seg[seg_of_chunk(a, ch)];
+  const int local = ch - sg.chunk_start;
+  const int nl = local / sg.chunks, ck = local - nl * sg.chunks;
+  const int q = sg.sample_start + nl;
+  const int p_begin = ck * sg.ppc, p_end = min(p_begin + sg.ppc, sg.hw);
+  const size_t base = (size_t)nl * sg.hw * C;
+  const float* __restrict__ x = sg.x + base;
+  const float* __restrict__ dy = sg.dy + base;
+  const bool aar = a.act_after_res && sg.res;
+  const float* __restrict__ res = aar ? sg.res + base : nullptr;
+  const int q4 = tid % QP, pl = tid / QP;
+  const bool active = pl < lanes;
+  float mean[4], rstd[4], gam[4], bet[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = min(q4 * 4 + j, C - 1), g = c / a.cpg;
+    mean[j] = sg.mean[nl * a.groups + g]; rstd[j] = sg.rstd[nl * a.groups + g];
+    gam[j] = a.gamma[c]; bet[j] = a.beta[c];
+  }
+  const bool drop = a.drop_rate > 0.f;
+  const float keep_scale = drop ? 1.f / (1.f - a.drop_rate) : 1.f;
+  const uint64_t samp_off = (uint64_t)q * (uint64_t)sg.hw * (uint64_t)C;
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+  float4 xh[COOP_R], gr[COOP_R];  // loaded as x / dy, overwritten by xhat / g = dy * dropmask * act'(z)
+#pragma unroll
+  for (int k = 0; k < COOP_R; ++k) {
+    const size_t off = (size_t)min(p_begin + pl + k * lanes, sg.hw - 1) * C + q4 * 4;
+    xh[k] = *reinterpret_cast<const float4*>(x + off);
+    gr[k] = *reinterpret_cast<const float4*>(dy + off);
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < COOP_R; ++k) {
+    const int p = p_begin + pl + k * lanes;
+    const float m = (active && p < p_end) ? 1.f : 0.f;
+    const size_t off = (size_t)min(p, sg.hw - 1) * C + q4 * 4;
+    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res) rv = *reinterpret_cast<const float4*>(res + off);
+    const float xs[4] = {xh[k].x, xh[k].y, xh[k].z, xh[k].w};
+    const float ds[4] = {gr[k].x, gr[k].y, gr[k].z, gr[k].w};
+    const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+    float h[4], g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[j] = (xs[j] - mean[j]) * rstd[j];
+      const float z = h[j] * gam[j] + bet[j] + rr[j];
+      float t = ds[j];
+      if (drop) t = (rn::uniform01(seed, samp_off + off + j) >= a.drop_rate) ? t * keep_scale : 0.f;
+      g[j] = t * rn::act_grad(z, ACT) * m;
+      s1[j] += g[j];
+      s2[j] += g[j] * h[j];
+    }
+    xh[k] = make_float4(h[0], h[1], h[2], h[3]);
+    gr[k] = make_float4(g[0], g[1], g[2], g[3]);
+  }
+  coop_partials<true, true>(a, red, chan, s1, s2, ch, QP, lanes, CQ);
+  const bool ok = grid_barrier(a.sync, gridDim.x);
+  coop_group_totals(a, a.gpart + (size_t)(sg.chunk_start + nl * sg.chunks) * a.groups * 2, sg.chunks, lane_sum, gtot);
+  for (int g = tid; g < a.groups; g += CT) {
+    const double m = (double)sg.hw * (double)a.cpg;
+    gcoef[g][0] = (float)(gtot[g][0] / m); gcoef[g][1] = (float)(gtot[g][1] / m);
+  }
+  __syncthreads();
+  if (!active || !ok) return;
+  float c1[4], c2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = (q4 * 4 + j) / a.cpg;
+    c1[j] = gcoef[g][0]; c2[j] = gcoef[g][1];
+  }
+  float* __restrict__ dx = sg.dx + base;
+  float* __restrict__ dres = (aar && sg.dres) ? sg.dres + base : nullptr;
+#pragma unroll
+  for (int k = 0; k < COOP_R; ++k) {
+    const int p = p_begin + pl + k * lanes;
+    if (p < p_end) {
+      const size_t off = (size_t)p * C + q4 * 4;
+      const float hs[4] = {xh[k].x, xh[k].y, xh[k].z, xh[k].w};
+      const float gs[4] = {gr[k].x, gr[k].y, gr[k].z, gr[k].w};
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = rstd[j] * (gam[j] * gs[j] - c1[j] - hs[j] * c2[j]);
+      *reinterpret_cast<float4*>(dx + off) = make_float4(o[0], o[1], o[2], o[3]);
+      if (dres) *reinterpret_cast<float4*>(dres + off) = gr[k];
+    }
+  }
+}
+
+// chunking of the grid-resident path; false when the call does not qualify
+bool plan_coop(GnArgs* a) {
+  if (!a->sync || getenv("RN_GN_NO_COOP")) return false;
+  if (a->in_half || a->out_half || a->act == RN_ACT_SIGMOID) return false;
+  const int CQ = a->c / 4;
+  if (a->c > COOP_MAX_C || a->groups > COOP_MAX_C || CQ > CT) return false;
+  const int lanes = CT / CQ;
+  const int ppc = lanes * COOP_R;
+  int chunks = 0;
+  for (int s = 0; s < a->nseg; ++s) {
+    const int per = rn::ceil_div(a->seg[s].hw, ppc);
+    chunks += a->seg[s].n * per;
+    if (chunks > COOP_MAX_BLOCKS) return false;
+  }
+  chunks = 0;
+  for (int s = 0; s < a->nseg; ++s) {
+    GnSeg& d = a->seg[s];
+    d.ppc = ppc;
+    d.chunks = rn::ceil_div(d.hw, ppc);
+    d.chunk_start = chunks;
+    chunks += d.n * d.chunks;
+  }
+  a->total_chunks = chunks;
+  a->coop_ppc = ppc;
+  return true;
+}
+
+template <bool BWD>
+void launch_coop(const GnArgs& a, hipStream_t st) {
+#define RN_GN_COOP(ACT_)                                                                                     \
+  do {                                                                                                       \
+    if (BWD) hipLaunchKernelGGL((gn_coop_bwd_kernel<ACT_>), dim3(a.total_chunks), dim3(CT), 0, st, a);       \
+    else hipLaunchKernelGGL((gn_coop_fwd_kernel<ACT_>), dim3(a.total_chunks), dim3(CT), 0, st, a);           \
+  } while (0)
+  switch (a.act) {
+    case RN_ACT_RELU: RN_GN_COOP(RN_ACT_RELU); break;
+    case RN_ACT_ELU: RN_GN_COOP(RN_ACT_ELU); break;
+    case RN_ACT_RELU6: RN_GN_COOP(RN_ACT_RELU6); break;
+    default: RN_GN_COOP(RN_ACT_NONE); break;
+  }
+#undef RN_GN_COOP
+}
+
 // choose the block width of the slice-resident path; returns R (pixels per thread) or 0 when a slice does not fit
 int plan_slices(GnArgs* a) {
   a->slice_wc = 0;
@@ -637,6 +959,7 @@ int build_args(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, GnArgs* a
   a->out_half = (!bwd && p->out_f16) ? 1 : 0;
   RN_UNSUPPORTED(bwd && (p->in_f16 || p->out_f16), "group_norm bwd: fp16 storage is forward-only");
   a->eps = p->eps; a->drop_rate = p->drop_rate; a->seed = p->drop_seed; a->seed_dev = p->drop_seed_dev;
+  a->sync = (unsigned*)p->sync;
   int samples = 0, chunks = 0;
   for (int s = 0; s < nseg; ++s) {
     RN_CHECK_ARG(segs[s].x && segs[s].mean && segs[s].rstd && segs[s].n >= 1 && segs[s].hw >= 1,
@@ -664,8 +987,9 @@ int build_args(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, GnArgs* a
 }
 
 size_t ws_bytes(const GnArgs& a) {
+  const size_t rows = (size_t)a.total_samples > (size_t)COOP_MAX_BLOCKS ? a.total_samples : COOP_MAX_BLOCKS;
   return rn::align_up((size_t)a.total_chunks * a.c * 2 * sizeof(float), 256) +
-         rn::align_up((size_t)a.total_samples * a.groups * 2 * sizeof(float), 256);
+         rn::align_up(rows * a.groups * 2 * sizeof(float), 256);  // bwd coefficients / grid-resident group rows
 }
 
 unsigned apply_blocks(const GnArgs& a) {
@@ -715,6 +1039,15 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
     RN_LAUNCH_CHECK();
     return RN_OK;
   }
+  {
+    GnArgs c = a;  // the chunking differs from the three-kernel path's; the workspace (chunks <= 128 rows) always fits
+    if (plan_coop(&c) && ws_bytes(c) <= workspace_bytes) {
+      c.gpart = (float*)((char*)workspace + rn::align_up((size_t)c.total_chunks * c.c * 2 * sizeof(float), 256));
+      launch_coop<false>(c, st);
+      RN_LAUNCH_CHECK();
+      return RN_OK;
+    }
+  }
   hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(a.total_chunks), dim3(T), 0, st, a);
   hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(a.total_samples * a.groups), dim3(T), 0, st, a);
   if (a.in_half && a.out_half && a.c % 8 == 0 && a.drop_rate == 0.f)
@@ -750,6 +1083,17 @@ extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
     hipLaunchKernelGGL(gn_param_grad_kernel, dim3(rn::ceil_div(a.c, 256)), dim3(256), 0, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
+  }
+  {
+    GnArgs c = a;
+    if (plan_coop(&c) && ws_bytes(c) <= workspace_bytes) {
+      c.gpart = (float*)((char*)workspace + rn::align_up((size_t)c.total_chunks * c.c * 2 * sizeof(float), 256));
+      launch_coop<true>(c, st);
+      RN_LAUNCH_CHECK();
+      // dbeta / dgamma = column sums of the two partial planes (one deferred launch per step, or two small ones now)
+      if (int e = rn::launch_reduce_rows(c.partial, dbeta, c.c, c.total_chunks, 0, st)) return e;
+      return rn::launch_reduce_rows(c.partial + (size_t)c.total_chunks * c.c, dgamma, c.c, c.total_chunks, 0, st);
+    }
   }
   hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(a.total_chunks), dim3(T), 0, st, a);
   // dbeta / dgamma = the column sums of the two partial planes: blocks appended to the finalize launch, or -- while

@@ -402,10 +402,15 @@ def gn_groups(c, groups=32):
     return g
 
 
-def _gn_params(c, g, eps, act, drop_rate, seed, seed_dev, act_after_residual):
+# single-kernel GroupNorm for mid-sized maps (<= 128 co-resident blocks meeting at a bounded in-kernel barrier)
+GN_GRID_RESIDENT = os.environ.get("RN_GN_GRID_RESIDENT", "1") == "1"
+
+
+def _gn_params(c, g, eps, act, drop_rate, seed, seed_dev, act_after_residual, device=None):
+    sync = _rn.sync_counters(device).data_ptr() if (GN_GRID_RESIDENT and device is not None and device.type == 'cuda') else None
     return _rn.GnParams(c=c, groups=g, act=_rn.ACT[act], act_after_residual=1 if act_after_residual else 0, eps=eps,
                         drop_rate=drop_rate, drop_seed=seed,
-                        drop_seed_dev=seed_dev.data_ptr() if seed_dev is not None else None)
+                        drop_seed_dev=seed_dev.data_ptr() if seed_dev is not None else None, sync=sync)
 
 
 def _gn_segs(xs, ys, ress, dys, dxs, means, rstds, dress=None):
@@ -442,7 +447,7 @@ class _GroupNormAct(torch.autograd.Function):
         rstds = [torch.empty((x.shape[0], g), dtype=torch.float32, device=dev) for x in xs]
         for x, r in zip(xs, ress):
             assert x.shape[3] == c and (r is None or r.shape == x.shape)
-        params = _gn_params(c, g, eps, act, drop_rate, seed, seed_dev, aar)
+        params = _gn_params(c, g, eps, act, drop_rate, seed, seed_dev, aar, dev)
         segs = _gn_segs(xs, ys, ress, None, None, means, rstds)
         need = L.rn_group_norm_workspace(segs, n, C.byref(params))
         ws = _rn.workspace(need, dev)
@@ -473,7 +478,7 @@ class _GroupNormAct(torch.autograd.Function):
         dress = [torch.empty_like(x) if r is not None else None for x, r in zip(xs, ress)]
         dgamma_buf, dgamma = _grad_slot(gamma)
         dbeta_buf, dbeta = _grad_slot(beta)
-        params = _gn_params(c, g, eps, act, drop_rate, seed, seed_dev, aar)
+        params = _gn_params(c, g, eps, act, drop_rate, seed, seed_dev, aar, dev)
         segs = _gn_segs(xs, None, ress, dys, dxs, means, rstds, dress)
         need = L.rn_group_norm_workspace(segs, n, C.byref(params))
         ws = _grad_workspace(need, dev)
