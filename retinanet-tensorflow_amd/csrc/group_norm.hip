@@ -1034,7 +1034,10 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   }
   a.gamma = gamma; a.beta = beta; a.partial = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  if (const int r = plan_slices(&a)) {
+  // slice-resident kernel when its blocks read runs of >= 32 bytes; else the grid-resident kernel (full rows); else
+  // the narrow slice kernel; else three kernels
+  const int r = plan_slices(&a);
+  if (r && a.slice_wc >= 8) {
     launch_slices<false>(a, r, st);
     RN_LAUNCH_CHECK();
     return RN_OK;
@@ -1047,6 +1050,11 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
       RN_LAUNCH_CHECK();
       return RN_OK;
     }
+  }
+  if (r) {
+    launch_slices<false>(a, r, st);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
   }
   hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(a.total_chunks), dim3(T), 0, st, a);
   hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(a.total_samples * a.groups), dim3(T), 0, st, a);
@@ -1072,7 +1080,13 @@ extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   a.partial = (float*)workspace;
   a.coef = (float*)((char*)workspace + rn::align_up((size_t)a.total_chunks * a.c * 2 * sizeof(float), 256));
   hipStream_t st = (hipStream_t)stream;
-  if (const int r = plan_slices(&a)) {
+  const int r = plan_slices(&a);
+  bool coop_first = r && a.slice_wc < 8;
+  if (coop_first) {
+    GnArgs c = a;
+    coop_first = plan_coop(&c) && ws_bytes(c) <= workspace_bytes;
+  }
+  if (r && !coop_first) {
     a.pgrad = (float*)workspace;  // [2][total_samples][c] <= the chunk-partial area (chunks >= samples)
     launch_slices<true>(a, r, st);
     if (rn::reduce_deferred(st)) {  // the two row sums join the step's single deferred reduction launch
