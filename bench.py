@@ -312,6 +312,7 @@ def main():
                        "global_batch": world * BATCH, "image_size": IMAGE_SIZE, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "final_class_loss": round(losses[0], 6),
                        "final_regr_loss": round(losses[1], 6),
+                       "gn_barrier_timeouts": __import__("_rn").barrier_timeouts(),
                        "conv_roofline_frac_whole_step": round(ips / world * TRAIN_GFLOP_PER_IMAGE / 1e3 /
                                                               FP32_MFMA_PEAK_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,

@@ -37,7 +37,7 @@ struct GnArgs {
   int total_chunks, total_samples;
   float* gpart;    // grid-resident path: [total_chunks][groups][2] per-block group sums
   unsigned* sync;  // grid-resident path: two zero-initialised counters (+ an error word), left at zero
-  int coop_ppc;    // grid-resident path: pixels per block
+  int coop_ppc, coop_r;  // grid-resident path: pixels per block, float4 values per thread
   int slice_wc;    // slice-resident path: channels per block (a whole number of groups), 0 = not used
   float* pgrad;    // slice-resident bwd: [2][total_samples][c] per-sample sum g (plane 0) and sum g*xhat (plane 1)
 };
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(const GnArgs a) {
 // still fit the 256 CUs together, nothing else in the step spins.  The barrier is bounded: if the blocks are not all
 // resident within ~10^6 polls it gives up (error word set, results of that call undefined) instead of hanging.
 // ---------------------------------------------------------------------------------------------
-constexpr int CT = 512, COOP_R = 16, COOP_MAX_BLOCKS = 128, COOP_MAX_C = 1024;
+constexpr int CT = 512, COOP_MAX_R = 16, COOP_MAX_BLOCKS = 128, COOP_MAX_C = 1024;
 
 // The only data exchanged across the barrier are the per-block group sums: they are written with device-scope
 // (write-through, sc1) stores and read back with device-scope loads, so the barrier itself needs NO cache write-back /
@@ -670,7 +670,7 @@ __device__ __forceinline__ void coop_group_totals(const GnArgs& a, const float* 
   __syncthreads();
 }
 
-template <int ACT>
+template <int ACT, int COOP_R>
 __global__ __launch_bounds__(CT) void gn_coop_fwd_kernel(const GnArgs a) {
   __shared__ float red[CT][8];
   __shared__ float chan[COOP_MAX_C][2];
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(CT) void gn_coop_fwd_kernel(const GnArgs a) {
   }
 }
 
-template <int ACT>
+template <int ACT, int COOP_R>
 __global__ __launch_bounds__(CT) void gn_coop_bwd_kernel(const GnArgs a) {
   __shared__ float red[CT][8];
   __shared__ float chan[COOP_MAX_C][2];
@@ -856,13 +856,18 @@ bool plan_coop(GnArgs* a) {
   const int CQ = a->c / 4;
   if (a->c > COOP_MAX_C || a->groups > COOP_MAX_C || CQ > CT) return false;
   const int lanes = CT / CQ;
-  const int ppc = lanes * COOP_R;
-  int chunks = 0;
-  for (int s = 0; s < a->nseg; ++s) {
-    const int per = rn::ceil_div(a->seg[s].hw, ppc);
-    chunks += a->seg[s].n * per;
-    if (chunks > COOP_MAX_BLOCKS) return false;
+  // smallest per-thread depth (most blocks, most parallelism) that keeps the grid within COOP_MAX_BLOCKS
+  int r = 0, ppc = 0, chunks = 0;
+  for (int cand = 4; cand <= COOP_MAX_R; cand *= 2) {
+    ppc = lanes * cand;
+    chunks = 0;
+    for (int s = 0; s < a->nseg; ++s) chunks += a->seg[s].n * rn::ceil_div(a->seg[s].hw, ppc);
+    // depth 4 needs ~80 VGPRs: three blocks fit a CU, so two concurrent kernels of 256 blocks are still co-resident;
+    // deeper variants (up to 245 VGPRs, one block per CU) stay within 128 blocks each
+    if (chunks <= (cand == 4 ? 2 * COOP_MAX_BLOCKS : COOP_MAX_BLOCKS)) { r = cand; break; }
   }
+  if (!r) return false;
+  a->coop_r = r;
   chunks = 0;
   for (int s = 0; s < a->nseg; ++s) {
     GnSeg& d = a->seg[s];
@@ -878,10 +883,16 @@ bool plan_coop(GnArgs* a) {
 
 template <bool BWD>
 void launch_coop(const GnArgs& a, hipStream_t st) {
-#define RN_GN_COOP(ACT_)                                                                                     \
-  do {                                                                                                       \
-    if (BWD) hipLaunchKernelGGL((gn_coop_bwd_kernel<ACT_>), dim3(a.total_chunks), dim3(CT), 0, st, a);       \
-    else hipLaunchKernelGGL((gn_coop_fwd_kernel<ACT_>), dim3(a.total_chunks), dim3(CT), 0, st, a);           \
+#define RN_GN_COOP2(ACT_, R_)                                                                                   \
+  do {                                                                                                          \
+    if (BWD) hipLaunchKernelGGL((gn_coop_bwd_kernel<ACT_, R_>), dim3(a.total_chunks), dim3(CT), 0, st, a);      \
+    else hipLaunchKernelGGL((gn_coop_fwd_kernel<ACT_, R_>), dim3(a.total_chunks), dim3(CT), 0, st, a);          \
+  } while (0)
+#define RN_GN_COOP(ACT_)                                                                                       \
+  do {                                                                                                          \
+    if (a.coop_r == 4) RN_GN_COOP2(ACT_, 4);                                                                    \
+    else if (a.coop_r == 8) RN_GN_COOP2(ACT_, 8);                                                               \
+    else RN_GN_COOP2(ACT_, 16);                                                                                 \
   } while (0)
   switch (a.act) {
     case RN_ACT_RELU: RN_GN_COOP(RN_ACT_RELU); break;
@@ -889,6 +900,7 @@ void launch_coop(const GnArgs& a, hipStream_t st) {
     case RN_ACT_RELU6: RN_GN_COOP(RN_ACT_RELU6); break;
     default: RN_GN_COOP(RN_ACT_NONE); break;
   }
+#undef RN_GN_COOP2
 #undef RN_GN_COOP
 }
 
@@ -987,7 +999,7 @@ int build_args(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, GnArgs* a
 }
 
 size_t ws_bytes(const GnArgs& a) {
-  const size_t rows = (size_t)a.total_samples > (size_t)COOP_MAX_BLOCKS ? a.total_samples : COOP_MAX_BLOCKS;
+  const size_t rows = (size_t)a.total_samples > (size_t)2 * COOP_MAX_BLOCKS ? a.total_samples : 2 * COOP_MAX_BLOCKS;
   return rn::align_up((size_t)a.total_chunks * a.c * 2 * sizeof(float), 256) +
          rn::align_up(rows * a.groups * 2 * sizeof(float), 256);  // bwd coefficients / grid-resident group rows
 }

@@ -161,3 +161,10 @@ def test_gradient_average_equals_bigger_batch(dev):
     trainer.opt.step(grad_scale=0.5)
     expect = w0 - 1e-2 * (0.5 * (g1 + g2) + trainer.arena.wd_per_block.repeat_interleave(train.OPT_BLOCK) * w0)
     assert_close(trainer.arena.weights.cpu().numpy(), expect.cpu().numpy(), 1e-6, "averaged step")
+
+
+def test_no_group_norm_barrier_timeouts(dev):
+    """The grid-resident GroupNorm kernels meet at a bounded in-kernel barrier; after everything this test module ran
+    (eager, hipGraph, two head streams) no barrier may have given up."""
+    import _rn
+    assert _rn.barrier_timeouts() == 0
