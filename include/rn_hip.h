@@ -120,8 +120,16 @@ int rn_flush_reductions(rn_stream_t stream);
  * rn_conv2d_wgrad).  cin and cout multiples of 4.  Results differ from the direct kernels only by the fp32
  * rounding of the transforms (about 1e-6 of the output range for tile 2, 1e-5 for tile 4; tests: <= 1e-4). */
 size_t rn_conv3x3_winograd_workspace(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile);
+/* v_buf / urot_buf (optional, caller-owned, sizes from rn_conv3x3_winograd_keep_bytes) let a training step reuse two
+ * intermediates instead of recomputing them in the backward pass: a forward call (dgrad == 0) writes the transformed
+ * input into v_buf (rn_conv3x3_winograd_wgrad then skips its input transform) and the transformed ROTATED kernel into
+ * urot_buf (same launch as the forward kernel transform); a data-gradient call (dgrad != 0) that is handed urot_buf
+ * skips its weight transform.  NULL = compute everything in the workspace. */
+int rn_conv3x3_winograd_keep_bytes(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile, size_t* v_bytes,
+                                   size_t* urot_bytes);
 int rn_conv3x3_winograd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, const float* bias,
-                        int dgrad, int tile, void* workspace, size_t workspace_bytes, rn_stream_t stream);
+                        int dgrad, int tile, void* workspace, size_t workspace_bytes, float* v_buf, float* urot_buf,
+                        rn_stream_t stream);
 /* The batched product the Winograd stages run on the fp32 matrix cores, exposed for measurement (bench.py times
  * the head-tower layer's instance: 36 x [682 x 256] x [256 x 256]) and reuse:
  *   C_b [M x N] = A_b [M x K] * B_b,  b = 0..nbatch-1, matrices of a batch stored back to back;
@@ -132,7 +140,7 @@ int rn_gemm_batched(const float* A, const float* B, float* C, int M, int K, int 
  * sum), then dw[3,3,cin,cout] (+)= G^T dU G.  Segments: x, dy, n, h, w. */
 size_t rn_conv3x3_winograd_wgrad_workspace(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile);
 int rn_conv3x3_winograd_wgrad(const rn_conv_seg* segs, int nseg, int cin, int cout, float* dw, int accumulate, int tile,
-                              void* workspace, size_t workspace_bytes, rn_stream_t stream);
+                              void* workspace, size_t workspace_bytes, const float* v_buf, rn_stream_t stream);
 
 /* ------------------------------------------------------------------ fp16 inference convolution
  * BASELINE configs[4] ("Inference-only ResNeXt-50-FPN 1024x1024 bs=16, fp16"): forward conv on the f16

@@ -290,26 +290,39 @@ __global__ void wino_dw_kernel(const float* __restrict__ du, float* __restrict__
 
 // U[xi][k][n] = (G g G^T)[xi] for g = w[:, :, k, n] (rot == 0) or its 180-degree rotation (rot != 0, the
 // data-gradient kernel); [k][n] = [cin][cout] either way.
+// u2 != nullptr: also the transform of the rotated kernel (what the data gradient will need) from the same 9 loads.
 template <int M>
-__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int64_t kn, int rot) {
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, float* __restrict__ u2, int64_t kn,
+                                   int rot) {
   constexpr int P = M + 2;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= kn) return;
-  float t[3][P];  // t[b][a] = (G g)[a][b]
+  float g9[3][3];
 #pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    float col[3];
+  for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) col[a] = rot ? w[(size_t)((2 - a) * 3 + (2 - b)) * kn + i] : w[(size_t)(a * 3 + b) * kn + i];
-    Wino<M>::g(col, t[b]);
-  }
+    for (int b = 0; b < 3; ++b) g9[a][b] = w[(size_t)(a * 3 + b) * kn + i];
 #pragma unroll
-  for (int a = 0; a < P; ++a) {
-    const float row[3] = {t[0][a], t[1][a], t[2][a]};
-    float o[P];
-    Wino<M>::g(row, o);
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool r = pass ? true : (rot != 0);
+    float* out = pass ? u2 : u;
+    if (pass && !u2) break;
+    float t[3][P];  // t[b][a] = (G g)[a][b]
 #pragma unroll
-    for (int b = 0; b < P; ++b) u[(size_t)(a * P + b) * kn + i] = o[b];
+    for (int b = 0; b < 3; ++b) {
+      float col[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) col[a] = r ? g9[2 - a][2 - b] : g9[a][b];
+      Wino<M>::g(col, t[b]);
+    }
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+      const float row[3] = {t[0][a], t[1][a], t[2][a]};
+      float o[P];
+      Wino<M>::g(row, o);
+#pragma unroll
+      for (int b = 0; b < P; ++b) out[(size_t)(a * P + b) * kn + i] = o[b];
+    }
   }
 }
 
@@ -373,12 +386,18 @@ size_t tiles_of(const rn_conv_seg* segs, int nseg, int m) {
 
 template <int M>
 int run(const WArgs& ia_, const WArgs& oa_, int cin, int cout, const float* w, const float* bias, bool dgrad, float* U, float* V,
-        float* Mb, hipStream_t st) {
+        float* Mb, float* v_buf, float* urot_buf, hipStream_t st) {
   constexpr int P2 = (M + 2) * (M + 2);
   WArgs ia = ia_, oa = oa_;
   const int T_ = ia.total_tiles, kc = ia.c, nc = oa.c;
   const int64_t kn = (int64_t)cin * cout;
-  hipLaunchKernelGGL(wino_weight_kernel<M>, dim3((unsigned)rn::ceil_div64(kn, 256)), dim3(256), 0, st, w, U, kn, dgrad ? 1 : 0);
+  if (dgrad && urot_buf) {
+    U = urot_buf;  // transformed (rotated) kernel kept by the forward call
+  } else {
+    hipLaunchKernelGGL(wino_weight_kernel<M>, dim3((unsigned)rn::ceil_div64(kn, 256)), dim3(256), 0, st, w, U,
+                       dgrad ? nullptr : urot_buf, kn, dgrad ? 1 : 0);
+  }
+  if (!dgrad && v_buf) V = v_buf;  // keep the transformed input for the weight gradient
   ia.buf = V;
   const int wi = width_for(T_, kc), wo = width_for(T_, nc);
   RN_WINO_LAUNCH(wino_input_kernel, wi, (int64_t)T_ * kc, ia);
@@ -393,14 +412,15 @@ int run(const WArgs& ia_, const WArgs& oa_, int cin, int cout, const float* w, c
 }
 template <int M>
 int run_wgrad(const WArgs& xa_, const WArgs& ya_, int cin, int cout, float* dw, int accumulate, float* dU, float* V, float* dM,
-              void* gemm_ws, size_t gemm_ws_bytes, hipStream_t st) {
+              void* gemm_ws, size_t gemm_ws_bytes, const float* v_buf, hipStream_t st) {
   constexpr int P2 = (M + 2) * (M + 2);
   WArgs xa = xa_, ya = ya_;
   const int T_ = xa.total_tiles;
   xa.buf = V;
   ya.buf = dM;
   const int wi = width_for(T_, cin), wo = width_for(T_, cout);
-  RN_WINO_LAUNCH(wino_input_kernel, wi, (int64_t)T_ * cin, xa);
+  if (v_buf) V = const_cast<float*>(v_buf);  // the forward call's transformed input
+  else RN_WINO_LAUNCH(wino_input_kernel, wi, (int64_t)T_ * cin, xa);
   RN_WINO_LAUNCH(wino_dy_kernel, wo, (int64_t)T_ * cout, ya);
   RN_LAUNCH_CHECK();
   // dU_xi [cin x cout] = V_xi^T [cin x T] * dM_xi [T x cout]
@@ -425,7 +445,7 @@ extern "C" size_t rn_conv3x3_winograd_wgrad_workspace(const rn_conv_seg* segs, i
 // dw[3,3,cin,cout] (+)= sum over segments of the weight gradient of y = conv3x3_same(x, w), from the segments'
 // x and dy:  dU_xi = sum_tiles (B^T d B)_xi^T (A dY A^T)_xi,  dw = G^T dU G.
 extern "C" int rn_conv3x3_winograd_wgrad(const rn_conv_seg* segs, int nseg, int cin, int cout, float* dw, int accumulate, int tile,
-                                         void* workspace, size_t workspace_bytes, rn_stream_t stream) {
+                                         void* workspace, size_t workspace_bytes, const float* v_buf, rn_stream_t stream) {
   WArgs xa = {}, ya = {}, unused_in = {}, unused_out = {};
   // x through the input transform (channels cin); dy through the A-transform (channels cout): reuse fill() twice
   if (int e = fill(segs, nseg, cin, cout, tile, false, &xa, &unused_out, true)) return e;
@@ -444,8 +464,8 @@ extern "C" int rn_conv3x3_winograd_wgrad(const rn_conv_seg* segs, int nseg, int 
   float* dM = (float*)base;                 base += rn::align_up(p2 * tiles * cout * 4, 256);
   const size_t gemm_ws = workspace_bytes - (size_t)(base - (char*)workspace);
   hipStream_t st = (hipStream_t)stream;
-  return tile == 2 ? run_wgrad<2>(xa, ya, cin, cout, dw, accumulate, dU, V, dM, base, gemm_ws, st)
-                   : run_wgrad<4>(xa, ya, cin, cout, dw, accumulate, dU, V, dM, base, gemm_ws, st);
+  return tile == 2 ? run_wgrad<2>(xa, ya, cin, cout, dw, accumulate, dU, V, dM, base, gemm_ws, v_buf, st)
+                   : run_wgrad<4>(xa, ya, cin, cout, dw, accumulate, dU, V, dM, base, gemm_ws, v_buf, st);
 }
 
 // bytes: U (P*cin*cout) + V (P*T*cin) + M (P*T*cout)
@@ -458,7 +478,8 @@ extern "C" size_t rn_conv3x3_winograd_workspace(const rn_conv_seg* segs, int nse
 // dgrad == 0: y = conv3x3_same(x, w) + bias.   dgrad != 0: dx = conv3x3_same(dy, rot180(w)^T)  (w is always
 // the forward kernel [3,3,cin,cout]).
 extern "C" int rn_conv3x3_winograd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, const float* bias,
-                                   int dgrad, int tile, void* workspace, size_t workspace_bytes, rn_stream_t stream) {
+                                   int dgrad, int tile, void* workspace, size_t workspace_bytes, float* v_buf, float* urot_buf,
+                                   rn_stream_t stream) {
   WArgs ia = {}, oa = {};
   if (int e = fill(segs, nseg, cin, cout, tile, dgrad != 0, &ia, &oa)) return e;
   RN_CHECK_ARG(w && workspace, "winograd: null weights / workspace");
@@ -472,8 +493,8 @@ extern "C" int rn_conv3x3_winograd(const rn_conv_seg* segs, int nseg, int cin, i
   float* V = (float*)((char*)workspace + rn::align_up(p2 * cin * cout * 4, 256));
   float* Mb = (float*)((char*)V + rn::align_up(p2 * ia.total_tiles * ia.c * 4, 256));
   hipStream_t st = (hipStream_t)stream;
-  return tile == 2 ? run<2>(ia, oa, cin, cout, w, bias, dgrad != 0, U, V, Mb, st)
-                   : run<4>(ia, oa, cin, cout, w, bias, dgrad != 0, U, V, Mb, st);
+  return tile == 2 ? run<2>(ia, oa, cin, cout, w, bias, dgrad != 0, U, V, Mb, v_buf, urot_buf, st)
+                   : run<4>(ia, oa, cin, cout, w, bias, dgrad != 0, U, V, Mb, v_buf, urot_buf, st);
 }
 
 extern "C" int rn_gemm_batched(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, int b_nk,
@@ -481,4 +502,16 @@ extern "C" int rn_gemm_batched(const float* A, const float* B, float* C, int M, 
   RN_CHECK_ARG(A && B && C && M >= 1 && K >= 1 && N >= 1 && nbatch >= 1, "gemm_batched: bad argument");
   RN_UNSUPPORTED(K % 4 != 0 || N % 4 != 0, "gemm_batched: K %d / N %d must be multiples of 4", K, N);
   return rn::launch_batched_gemm(A, B, C, M, K, N, nbatch, b_nk, (hipStream_t)stream);
+}
+
+// bytes of the two optional buffers a forward call can fill for its backward pass: the transformed input V
+// ([P][tiles][cin], reused by the weight gradient) and the transformed rotated kernel ([P][cin][cout], reused by the
+// data gradient)
+extern "C" int rn_conv3x3_winograd_keep_bytes(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile, size_t* v_bytes,
+                                              size_t* urot_bytes) {
+  RN_CHECK_ARG(segs && nseg >= 1 && nseg <= RN_MAX_SEG && (tile == 2 || tile == 4) && v_bytes && urot_bytes, "winograd: bad argument");
+  const size_t p2 = (size_t)(tile + 2) * (tile + 2);
+  *v_bytes = p2 * tiles_of(segs, nseg, tile) * cin * 4;
+  *urot_bytes = p2 * cin * cout * 4;
+  return RN_OK;
 }

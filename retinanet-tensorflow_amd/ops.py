@@ -64,6 +64,7 @@ class _on_side_stream(object):
 WINOGRAD = True
 WINOGRAD_TILE = 4
 WINOGRAD_WGRAD = True
+WINOGRAD_KEEP = True      # forward keeps the transformed input / rotated kernel for backward (a few hundred MB per step)
 WINOGRAD_MIN_CHANNELS = 64
 WINOGRAD_MAX_WORKSPACE = int(os.environ.get("RN_WINOGRAD_MAX_WS", 8 << 30))   # of 288 GB HBM; the V / M planes of 1024^2 x 16 need 1.7 GB
 
@@ -79,14 +80,28 @@ def _winograd_ok(w, stride, groups, xs):
     return 4 * (m + 2) ** 2 * (tiles * (cin + cout) + cin * cout) <= WINOGRAD_MAX_WORKSPACE
 
 
-def _winograd(segs, n, w, bias, dgrad):
+def _winograd(segs, n, w, bias, dgrad, v_buf=None, urot_buf=None):
     L = _rn.lib()
     cin, cout = w.shape[2], w.shape[3]
     need = L.rn_conv3x3_winograd_workspace(segs, n, cin, cout, WINOGRAD_TILE)
     ws = _rn.workspace(need, w.device)
     _rn.check(L.rn_conv3x3_winograd(segs, n, cin, cout, _rn.f32(w), _rn.f32(bias) if bias is not None else None,
-                                    1 if dgrad else 0, WINOGRAD_TILE, ws.data_ptr(), ws.numel(), _rn.stream()),
+                                    1 if dgrad else 0, WINOGRAD_TILE, ws.data_ptr(), ws.numel(),
+                                    _rn.f32(v_buf) if v_buf is not None else None,
+                                    _rn.f32(urot_buf) if urot_buf is not None else None, _rn.stream()),
               "rn_conv3x3_winograd")
+
+
+def _winograd_keep_buffers(segs, n, w, want_v, want_urot):
+    """Buffers a training-mode forward call fills for its backward pass (see rn_conv3x3_winograd)."""
+    if not WINOGRAD_KEEP or not (want_v or want_urot):
+        return None, None
+    vb, ub = C.c_size_t(0), C.c_size_t(0)
+    _rn.check(_rn.lib().rn_conv3x3_winograd_keep_bytes(segs, n, w.shape[2], w.shape[3], WINOGRAD_TILE, C.byref(vb), C.byref(ub)),
+              "rn_conv3x3_winograd_keep_bytes")
+    v = torch.empty((vb.value // 4,), dtype=torch.float32, device=w.device) if want_v else None
+    u = torch.empty((ub.value // 4,), dtype=torch.float32, device=w.device) if want_urot else None
+    return v, u
 
 
 def _conv_fwd(segs, n, geom, device):
@@ -202,8 +217,12 @@ class _Conv2dShared(torch.autograd.Function):
         xs = [x.contiguous() for x in xs]
         segs = _conv_segs(xs, w, bias, ys, None, None)
         ctx.winograd = _winograd_ok(w, stride, groups, xs)
+        ctx.wino_v = ctx.wino_urot = None
         if ctx.winograd:
-            _winograd(segs, len(xs), w, bias, False)
+            if torch.is_grad_enabled():
+                ctx.wino_v, ctx.wino_urot = _winograd_keep_buffers(
+                    segs, len(xs), w, w.requires_grad and WINOGRAD_WGRAD, any(x.requires_grad for x in xs))
+            _winograd(segs, len(xs), w, bias, False, ctx.wino_v, ctx.wino_urot)
         else:
             _conv_fwd(segs, len(xs), geom, xs[0].device)
         ctx.stride = stride
@@ -235,7 +254,7 @@ class _Conv2dShared(torch.autograd.Function):
             outs = [torch.empty_like(xs[i]) for i in idx]
             segs = _conv_segs([xs[i] for i in idx], w, None, None, [dys[i] for i in idx], outs)
             if ctx.winograd:
-                _winograd(segs, len(idx), w, None, True)
+                _winograd(segs, len(idx), w, None, True, None, ctx.wino_urot)
             else:
                 _conv_dgrad(segs, len(idx), geom, w.device)
             for i, o in zip(idx, outs):
@@ -255,7 +274,8 @@ class _Conv2dShared(torch.autograd.Function):
                     need = L.rn_conv3x3_winograd_wgrad_workspace(segs, n, cin, cout, WINOGRAD_TILE)
                     ws = _rn.workspace(need, w.device)
                     _rn.check(L.rn_conv3x3_winograd_wgrad(segs, n, cin, cout, _rn.f32(dw_buf), 0, WINOGRAD_TILE, ws.data_ptr(),
-                                                          ws.numel(), _rn.stream()), "rn_conv3x3_winograd_wgrad")
+                                                          ws.numel(), _rn.f32(ctx.wino_v) if ctx.wino_v is not None else None,
+                                                          _rn.stream()), "rn_conv3x3_winograd_wgrad")
                 elif want_dw:
                     need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
                     ws = _grad_workspace(need, w.device)

@@ -42,7 +42,7 @@ def main():
         need = L.rn_conv3x3_winograd_workspace(segs, len(xs), cin, cout, tile)
         ws = _rn.workspace(need, dev)
         _rn.check(L.rn_conv3x3_winograd(segs, len(xs), cin, cout, _rn.f32(w), None, dgrad, tile, ws.data_ptr(), ws.numel(),
-                                        _rn.stream()), "wino")
+                                        None, None, _rn.stream()), "wino")
 
     dw = torch.empty_like(w)
 
@@ -50,7 +50,7 @@ def main():
         need = L.rn_conv3x3_winograd_wgrad_workspace(segs, len(xs), cin, cout, tile)
         ws = _rn.workspace(need, dev)
         _rn.check(L.rn_conv3x3_winograd_wgrad(segs, len(xs), cin, cout, _rn.f32(dw), 0, tile, ws.data_ptr(), ws.numel(),
-                                              _rn.stream()), "wino wgrad")
+                                              None, _rn.stream()), "wino wgrad")
 
     def direct_wgrad():
         need = L.rn_conv2d_wgrad_workspace(segs, len(xs), C.byref(geom))
