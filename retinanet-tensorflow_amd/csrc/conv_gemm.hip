@@ -42,6 +42,10 @@ struct SegDev {
   int start;          // fwd/dgrad: first tile id; wgrad: first split id
   int chunk;          // wgrad: reduction rows per split (multiple of BK)
   int x_ld, x_coff;   // pixel stride / first channel of the x (dx) tensor: a channel slice of a wider buffer
+  // stride-2 dgrad, phase decomposition: this (pseudo-)segment covers the input pixels (2i+py, 2j+px) only, an
+  // hc x wc grid per image; they see the taps kh = kh0, kh0+2, .. and kw = kw0, kw0+2, .. (nkh x nkw of them) --
+  // the other 3/4 of the taps multiply structural zeros and are never touched.  par == 0: plain segment.
+  int par, py, px, hc, wc, kh0, kw0, nkh, nkw;
 };
 
 struct ConvArgs {
@@ -323,6 +327,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
   const int tile_n = local % sg.tiles_n, tile_m = local / sg.tiles_n;
   const int W = sg.w, OH = sg.oh, OW = sg.ow, HW = sg.h * sg.w, M = sg.m;
   const int kw = args.kw, stride = args.stride;
+  const int par = sg.par, tstep = par ? 2 : 1, kh0 = par ? sg.kh0 : 0, kw0 = par ? sg.kw0 : 0;
+  const int nkw_c = par ? sg.nkw : kw;                      // taps per kernel row seen by this segment
   // grouped: N-tile `tile_n` is group g; K runs over (tap, co within the group)
   const int G = args.groups, cin = args.cin_g, ldy = sg.cout, ldx = sg.x_ld;
   const int cout = ldy / G;                                  // output channels per group = K per tap
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
   const int m0 = tile_m * BM, n0 = tn * BN;                  // n0: first ci (within the group) of the tile
   const int y_coff = grp * cout;                             // channel offset into dy and into w's cout axis
   const int x_coff = sg.x_coff + grp * cin;                  // channel offset into dx
-  const int ktotal = args.kh * args.kw * cout;
+  const int ktotal = (par ? sg.nkh * sg.nkw : args.kh * args.kw) * cout;
   const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.a + batch * args.bs_a, (unsigned)sg.n * OH * OW * ldy * 4u);
   const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.b + batch * args.bs_b, (unsigned)args.kh * args.kw * cin * ldy * 4u);
 
@@ -340,8 +346,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
   for (int i = 0; i < A_PASS; ++i) {
     const int m = m0 + r0 + i * RPP;
     if (m < M) {
-      const int n_ = m / HW, rem = m - n_ * HW;
-      const int ih = rem / W, iw = rem - ih * W;
+      int n_, ih, iw;
+      if (par) {
+        const int hw_c = sg.hc * sg.wc;
+        n_ = m / hw_c;
+        const int rem = m - n_ * hw_c, i_ = rem / sg.wc;
+        ih = 2 * i_ + sg.py; iw = 2 * (rem - i_ * sg.wc) + sg.px;
+      } else {
+        n_ = m / HW;
+        const int rem = m - n_ * HW;
+        ih = rem / W; iw = rem - ih * W;
+      }
       ihp[i] = ih + sg.pad_t;
       iwp[i] = iw + sg.pad_l;
       nb[i] = n_ * OH;
@@ -360,10 +375,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
   const int nk = (ktotal + BK - 1) / BK;
   int kt_begin = 0, kt_end = nk;
   if (args.ksplit) { kt_begin = batch * args.ksplit; kt_end = min(nk, kt_begin + args.ksplit); }
-  int t_kh = 0, t_kw = 0, t_co = 0;
+  int t_kh = kh0, t_kw = kw0, t_co = 0;
   if (TAPU && kt_begin) {
     const int tap0 = kt_begin * BK / cout;
-    t_co = kt_begin * BK - tap0 * cout; t_kh = tap0 / kw; t_kw = tap0 - t_kh * kw;
+    t_co = kt_begin * BK - tap0 * cout; t_kh = kh0 + tstep * (tap0 / nkw_c); t_kw = kw0 + tstep * (tap0 % nkw_c);
   }
   vec_t ra[A_PASS], rb[B_PASS];
   auto load_tiles = [&](int kt) {
@@ -373,12 +388,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
       khh = t_kh; kww = t_kw; tap = khh * kw + kww;
       co = t_co + kq * VEC;
       t_co += BK;
-      if (t_co == cout) { t_co = 0; if (++t_kw == kw) { t_kw = 0; ++t_kh; } }
+      if (t_co == cout) { t_co = 0; t_kw += tstep; if (t_kw >= kw) { t_kw = kw0; t_kh += tstep; } }
     } else {
       const int k = kt * BK + kq * VEC;
       kok = k < ktotal;
-      tap = k / cout; co = k - tap * cout;
-      khh = tap / kw; kww = tap - khh * kw;
+      const int tc = k / cout;
+      co = k - tc * cout;
+      const int tr = tc / nkw_c;
+      khh = kh0 + tstep * tr; kww = kw0 + tstep * (tc - tr * nkw_c);
+      tap = khh * kw + kww;
     }
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
@@ -407,7 +425,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  load_tiles(kt_begin);
+  if (kt_begin < kt_end) load_tiles(kt_begin);  // a phase can have no taps at all (1x1 / stride 2): it stores zeros
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     store_tiles();
     __syncthreads();
@@ -415,7 +433,42 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
     mma_ktile<BM, BN, WM, WN, false, true>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
-  store_tile<BM, BN, WM, WN>(acc, sg.out + batch * args.bs_out, nullptr, m0, x_coff + n0, M, x_coff + cin, ldx, wm, wn, lane);
+  if (!par) {
+    store_tile<BM, BN, WM, WN>(acc, sg.out + batch * args.bs_out, nullptr, m0, x_coff + n0, M, x_coff + cin, ldx, wm, wn, lane);
+    return;
+  }
+  // phase rows are not consecutive pixels: pixel index of each of the tile's rows via LDS (the operand tiles are dead)
+  int* rowpix = reinterpret_cast<int*>(smem);
+  for (int r = tid; r < BM; r += T) {
+    const int m = m0 + r;
+    int pix = -1;
+    if (m < M) {
+      const int hw_c = sg.hc * sg.wc, n_ = m / hw_c, rem = m - n_ * hw_c, i_ = rem / sg.wc;
+      pix = (n_ * sg.h + 2 * i_ + sg.py) * W + 2 * (rem - i_ * sg.wc) + sg.px;
+    }
+    rowpix[r] = pix;
+  }
+  __syncthreads();
+  {
+    const int l31 = lane & 31, half = lane >> 5;
+    float* out = sg.out;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(out, (unsigned)sg.n * sg.h * W * (unsigned)ldx * 4u);
+#pragma unroll
+    for (int tn2 = 0; tn2 < TN; ++tn2) {
+      const int col = x_coff + n0 + wn * (BN / WN) + tn2 * 32 + l31;
+      const bool cok = col < x_coff + cin;
+#pragma unroll
+      for (int tm2 = 0; tm2 < TM; ++tm2) {
+        const int rbase = wm * (BM / WM) + tm2 * 32 + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int pix = rowpix[rbase + (r & 3) + 8 * (r >> 2)];
+          const unsigned voff = (cok && pix >= 0) ? ((unsigned)pix * (unsigned)ldx + (unsigned)col) * 4u : OOB;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[tm2][tn2][r]), rs, voff, 0, 0);
+        }
+      }
+    }
+  }
 }
 
 // =============================================================================================
@@ -902,6 +955,35 @@ int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, co
     d.m = d.n * d.h * d.w;
     set_x_view(d, segs[s], g->cin);
   }
+  // stride 2: an input pixel only sees the taps of its own row / column parity -- the plain implicit GEMM multiplies
+  // 3/4 structural zeros (ResNeXt's three 3x3/2 identity convs alone: 3 x 142 of 189 GFLOP per cfg-3 step).  Phase
+  // decomposition: every segment becomes up to four pseudo-segments, one per (row, column) parity, each with its own
+  // tap subset.  Large maps only (small ones are latency-bound and take the split-K path instead).
+  long total_rows = 0;
+  for (int s = 0; s < nseg; ++s) total_rows += a.seg[s].m;
+  if (g->stride == 2 && bt.n == 1 && nseg * 4 <= RN_MAX_SEG && total_rows >= 4096 && !getenv("RN_NO_PHASE_DGRAD")) {
+    SegDev src[RN_MAX_SEG];
+    for (int s = 0; s < nseg; ++s) src[s] = a.seg[s];
+    int k = 0;
+    for (int s = 0; s < nseg; ++s) {
+      for (int py = 0; py < 2; ++py) {
+        for (int px = 0; px < 2; ++px) {
+          SegDev d = src[s];
+          d.par = 1; d.py = py; d.px = px;
+          d.hc = (d.h - py + 1) / 2; d.wc = (d.w - px + 1) / 2;
+          if (d.hc <= 0 || d.wc <= 0) continue;
+          d.kh0 = (py + d.pad_t) & 1; d.kw0 = (px + d.pad_l) & 1;
+          d.nkh = d.kh0 < g->kh ? (g->kh - d.kh0 + 1) / 2 : 0;
+          d.nkw = d.kw0 < g->kw ? (g->kw - d.kw0 + 1) / 2 : 0;
+          if (d.nkh == 0 || d.nkw == 0) { d.nkh = 0; d.nkw = 1; }  // no taps: the phase is all zeros
+          d.m = d.n * d.hc * d.wc;
+          a.seg[k++] = d;
+        }
+      }
+    }
+    nseg = k;
+    a.nseg = k;
+  }
   const int cin_g = a.cin_g;
   const int c = (G > 1 && cin_g <= 64) ? cfg_for_group_width(cin_g)
                                         : choose_cfg([&](int s, long* m, long* n) { *m = a.seg[s].m * G; *n = cin_g; }, nseg, bt.n);
@@ -917,12 +999,12 @@ int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, co
   tiles *= bt.n;
   hipStream_t st = (hipStream_t)stream;
   bool tapu = vec;
-  for (int s = 0; s < nseg; ++s) tapu = tapu && ((segs[s].cout / G) % BK == 0);
+  for (int s = 0; s < nseg; ++s) tapu = tapu && ((a.seg[s].cout / G) % BK == 0);
   // split-K (single segment writing a dense dx only)
   int nsplit = 1, ksplit = 0;
   float* const dx_final = a.seg[0].out;
   const int64_t out_elems = (int64_t)a.seg[0].m * g->cin;
-  if (bt.n == 1 && nseg == 1 && G == 1 && a.seg[0].x_ld == g->cin && a.seg[0].x_coff == 0)
+  if (bt.n == 1 && nseg == 1 && !a.seg[0].par && G == 1 && a.seg[0].x_ld == g->cin && a.seg[0].x_coff == 0)
     plan_splitk(tiles, rn::ceil_div(g->kh * g->kw * segs[0].cout, BK), &nsplit, &ksplit);
   if (sc.need_out) {
     *sc.need_out = nsplit > 1 ? (size_t)nsplit * out_elems * sizeof(float) : 0;

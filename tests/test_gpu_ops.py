@@ -43,6 +43,10 @@ CONV_CASES = [
     (2, 7, 9, 64, 128, 3, 1, True),          # odd maps (Winograd edge tiles)
     (3, 1, 1, 256, 256, 3, 1, False),        # P7-sized map: one partial tile per image
     (1, 75, 75, 256, 256, 3, 1, False),      # P3 of a 600x600 image
+    (2, 48, 48, 64, 128, 3, 2, False),       # stride 2 on a large map: phase-decomposed data gradient
+    (1, 65, 67, 32, 64, 3, 2, True),         # ... odd sizes (unequal phases)
+    (2, 48, 48, 64, 32, 1, 2, False),        # ... 1x1 / stride 2: three of the four phases have no taps (zeros)
+    (1, 70, 70, 8, 12, 7, 2, False),         # ... 7x7 / stride 2
 ]
 
 
@@ -433,6 +437,7 @@ def test_optimizer_matches_tf_semantics(dev, kind):
 
 
 @pytest.mark.parametrize("case", [(2, 9, 8, 128, 128, 3, 1, 32), (2, 9, 8, 256, 256, 3, 2, 32), (1, 7, 7, 1024, 1024, 3, 1, 32),
+                                  (2, 48, 50, 128, 128, 3, 2, 32), (1, 64, 64, 256, 256, 3, 2, 32),
                                   (2, 6, 6, 64, 128, 3, 1, 4)])
 def test_grouped_conv_fwd_bwd(dev, case):
     """ResNeXt cardinality conv: one grouped launch == torch grouped conv (and see test_gpu_backbones for
