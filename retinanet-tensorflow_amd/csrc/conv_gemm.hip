@@ -508,8 +508,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
   }
   const int s = find_seg(args, split);
   const SegDev& sg = args.seg[s];
-  const int p0 = (split - sg.start) * sg.chunk;
-  const int p1 = min(p0 + sg.chunk, sg.m);
+  const int p0_all = (split - sg.start) * sg.chunk;
+  const int p1_all = min(p0_all + sg.chunk, sg.m);
+  int p0 = p0_all, p1 = min(p0_all + WG_MAXPIX, p1_all);  // current window of <= WG_MAXPIX pixels (the LDS table's size)
   const int H = sg.h, W = sg.w, OW = sg.ow, OHW = sg.oh * sg.ow;
   const int ldx = sg.x_ld, cout = args.cout, kw = args.kw, stride = args.stride;
   const int G = args.groups, cin = args.cin_g, cout_g = cout / G;
@@ -521,14 +522,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
   const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.a + batch * args.bs_a, (unsigned)sg.n * H * W * ldx * 4u);
   const __amdgpu_buffer_rsrc_t dy = make_rsrc(sg.b + batch * args.bs_b, (unsigned)sg.m * cout * 4u);
 
-  for (int i = tid; i < p1 - p0; i += T) {
-    const int p = p0 + i;
-    const int n_ = p / OHW, rem = p - n_ * OHW;
-    const int oh_ = rem / OW, ow_ = rem - oh_ * OW;
-    const int ih0 = oh_ * stride - sg.pad_t, iw0 = ow_ * stride - sg.pad_l;
-    pixtab[i] = make_int2(((n_ * H + ih0) * W + iw0) * ldx + x_coff, (ih0 << 16) | (iw0 & 0xffff));
-  }
-  __syncthreads();
+  auto fill_pixtab = [&]() {
+    for (int i = tid; i < p1 - p0; i += T) {
+      const int p = p0 + i;
+      const int n_ = p / OHW, rem = p - n_ * OHW;
+      const int oh_ = rem / OW, ow_ = rem - oh_ * OW;
+      const int ih0 = oh_ * stride - sg.pad_t, iw0 = ow_ * stride - sg.pad_l;
+      pixtab[i] = make_int2(((n_ * H + ih0) * W + iw0) * ldx + x_coff, (ih0 << 16) | (iw0 & 0xffff));
+    }
+    __syncthreads();
+  };
 
   // this thread's m' (fixed): tap and channel
   const int mq = tid % MQ;
@@ -571,14 +574,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  const int nk = (p1 - p0 + BK - 1) / BK;
-  if (nk > 0) load_tiles(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    store_tiles();
-    __syncthreads();
-    if (kt + 1 < nk) load_tiles(kt + 1);
-    mma_ktile<BM, BN, WM, WN, true, false>(As, Bs, acc, wm, wn, lane);
-    __syncthreads();
+  for (;;) {  // windows of the split's pixel range (one window unless the split is longer than the LDS table)
+    fill_pixtab();
+    const int nk = (p1 - p0 + BK - 1) / BK;
+    if (nk > 0) load_tiles(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      store_tiles();
+      __syncthreads();
+      if (kt + 1 < nk) load_tiles(kt + 1);
+      mma_ktile<BM, BN, WM, WN, true, false>(As, Bs, acc, wm, wn, lane);
+      __syncthreads();
+    }
+    if (p1 >= p1_all) break;
+    p0 = p1;
+    p1 = min(p0 + WG_MAXPIX, p1_all);
   }
   float* out = args.slab + (size_t)slab_row * ktotal * cout;
   store_tile<BM, BN, WM, WN>(acc, out, nullptr, m0, n0, ktotal, nmax, cout, wm, wn, lane);
@@ -1090,7 +1099,8 @@ int plan_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, WgradPl
   long chunk = (total_pixels + want_splits - 1) / want_splits;
   chunk = (chunk + BK - 1) / BK * BK;
   if (chunk < 2 * BK) chunk = 2 * BK;
-  if (chunk > WG_MAXPIX) chunk = WG_MAXPIX;
+  // (a split longer than WG_MAXPIX pixels walks its range in windows: big-kernel layers -- many output tiles already
+  // fill the chip -- then need no split at all, and no slab traffic)
   int nsplit = 0;
   for (int s = 0; s < nseg; ++s) {
     p->chunk[s] = (int)chunk;
@@ -1156,6 +1166,8 @@ int conv_wgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, fl
   a.groups = ngroups(g); a.cin_g = g->cin / a.groups; a.tpg = p.tpg;
   a.ktotal = p.ktotal; a.cout = p.cout; a.tiles_n = p.tiles_n; a.tiles_mn = p.tiles_m * p.tiles_n;
   a.slab = (float*)workspace;
+  const bool direct = p.nsplit == 1 && bt.n == 1 && !accumulate && !nsplit_out;  // one split: straight into dw
+  if (direct) a.slab = dw;
   a.nbatch = bt.n; a.btiles = p.nsplit; a.bs_a = bt.bs_a; a.bs_b = bt.bs_b;
   for (int s = 0; s < nseg; ++s) {
     RN_CHECK_ARG(segs[s].x && segs[s].dy, "conv wgrad: null pointer in segment %d", s);
@@ -1185,6 +1197,7 @@ int conv_wgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, fl
     *nsplit_out = p.nsplit;
     return RN_OK;
   }
+  if (direct) return RN_OK;
   return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)bt.n * p.ktotal * p.cout, p.nsplit, accumulate, st);
 }
 }  // namespace

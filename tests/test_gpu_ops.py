@@ -47,6 +47,8 @@ CONV_CASES = [
     (1, 65, 67, 32, 64, 3, 2, True),         # ... odd sizes (unequal phases)
     (2, 48, 48, 64, 32, 1, 2, False),        # ... 1x1 / stride 2: three of the four phases have no taps (zeros)
     (1, 70, 70, 8, 12, 7, 2, False),         # ... 7x7 / stride 2
+    (1, 48, 48, 1024, 1024, 3, 1, False),    # big kernel, many pixels: wgrad splits longer than its LDS pixel table (windows)
+    (1, 10, 10, 1024, 2048, 3, 1, False),    # ResNeXt stage-5 identity conv: one split, wgrad written straight into dw
 ]
 
 
