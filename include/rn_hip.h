@@ -226,14 +226,20 @@ int rn_dropout(const float* x, float* y, int64_t count, float rate, uint64_t see
 /* tf.layers.MaxPooling2D(k, stride, 'same') (resnet.py:200, densenet.py:180): padded cells never win; the
  * gradient goes to the first maximum of each window.  tf.layers.AveragePooling2D(k, stride, 'same')
  * (densenet.py:144): divides by the number of valid cells. */
-int rn_maxpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);
+/* argmax (optional, uint8 [n,oh,ow,c]): tap index kh*k+kw of each window's first maximum, for rn_maxpool_bwd_arg */
+int rn_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int n, int h, int w, int c, int k, int stride,
+                   rn_stream_t stream);
 /* fp16-storage forward variants for the inference path (same semantics) */
 int rn_act_fwd_f16(const void* x, void* y, int64_t count, int act, rn_stream_t stream);
 int rn_maxpool_fwd_f16(const void* x, void* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);
 int rn_upsample_add_fwd_f16(const void* lateral, const void* top, void* y, int n, int h, int w, int th, int tw, int c,
                             rn_stream_t stream);
+/* two forms of the same gradient: from x (re-scans every window) or from the forward pass's argmax bytes (5 bytes
+ * read per window; what the autograd carrier uses) */
 int rn_maxpool_bwd(const float* x, const float* dy, float* dx, int n, int h, int w, int c, int k, int stride,
                    rn_stream_t stream);
+int rn_maxpool_bwd_arg(const uint8_t* argmax, const float* dy, float* dx, int n, int h, int w, int c, int k, int stride,
+                       rn_stream_t stream);
 int rn_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);
 int rn_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);
 

@@ -77,7 +77,7 @@ SYMBOLS = [
     "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
     "rn_pack_weights_f16", "rn_cast_f32_to_f16", "rn_pad_cast_rgb_f16", "rn_conv2d_fwd_f16", "rn_maxpool_fwd_f16", "rn_upsample_add_fwd_f16",
-    "rn_act_fwd_f16", "rn_flip_width", "rn_dropout", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_avgpool_fwd", "rn_avgpool_bwd",
+    "rn_act_fwd_f16", "rn_flip_width", "rn_dropout", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_maxpool_bwd_arg", "rn_avgpool_fwd", "rn_avgpool_bwd",
     "rn_loss_workspace", "rn_loss_fwd", "rn_loss_bwd",
     "rn_anchor_assign", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
     "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
@@ -145,7 +145,8 @@ def lib():
         L.rn_act_fwd_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.rn_flip_width.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.rn_dropout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]
-        L.rn_maxpool_fwd.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_maxpool_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_maxpool_bwd_arg.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_maxpool_bwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_avgpool_fwd.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_avgpool_bwd.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]

@@ -91,7 +91,7 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 }
 
 // ---- 3x3/2 (k x k / s) max pool, TF SAME: padded cells never win (resnet.py:200, densenet.py:180)
-struct PoolArgs { const float* x; const float* dy; float* out; int n, h, w, c, k, s, oh, ow, pt, pl; int is_half; };
+struct PoolArgs { const float* x; const float* dy; float* out; int n, h, w, c, k, s, oh, ow, pt, pl; int is_half; uint8_t* arg; };
 
 __global__ void maxpool_fwd_kernel(const PoolArgs a) {
   const int CQ = a.c >> 2;
@@ -103,6 +103,7 @@ __global__ void maxpool_fwd_kernel(const PoolArgs a) {
     const int oh_ = (int)(p % a.oh);
     const int n_ = (int)(p / a.oh);
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uchar4 am = make_uchar4(0, 0, 0, 0);  // tap index (kh * k + kw) of the FIRST maximum, for the backward pass
     for (int kh = 0; kh < a.k; ++kh) {
       const int ih = oh_ * a.s - a.pt + kh;
       if ((unsigned)ih >= (unsigned)a.h) continue;
@@ -110,10 +111,15 @@ __global__ void maxpool_fwd_kernel(const PoolArgs a) {
         const int iw = ow_ * a.s - a.pl + kw;
         if ((unsigned)iw >= (unsigned)a.w) continue;
         const float4 v = rn::ld4(a.x, ((size_t)(n_ * a.h + ih) * a.w + iw) * a.c + q4 * 4, a.is_half);
-        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        const unsigned char t = (unsigned char)(kh * a.k + kw);
+        if (v.x > m.x) { m.x = v.x; am.x = t; }
+        if (v.y > m.y) { m.y = v.y; am.y = t; }
+        if (v.z > m.z) { m.z = v.z; am.z = t; }
+        if (v.w > m.w) { m.w = v.w; am.w = t; }
       }
     }
     rn::st4(a.out, (size_t)i * 4, a.is_half, m);
+    if (a.arg) *reinterpret_cast<uchar4*>(a.arg + (size_t)i * 4) = am;
   }
 }
 
@@ -291,11 +297,49 @@ extern "C" int rn_dropout(const float* x, float* y, int64_t count, float rate, u
   return RN_OK;
 }
 
-extern "C" int rn_maxpool_fwd(const float* x, float* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream) {
+// backward from the forward pass's arg-max taps: each input cell (4 channels per thread) adds dy of the <= (k/s)^2
+// windows whose first maximum it is -- gather form, deterministic, 5 bytes read per window instead of re-scanning it
+__global__ void maxpool_bwd_arg_kernel(const PoolArgs a) {
+  const int CQ = a.c >> 2;
+  const int64_t total = (int64_t)a.n * a.h * a.w * CQ;
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < total; i += (int64_t)gridDim.x * T) {
+    const int q4 = (int)(i % CQ);
+    int64_t p = i / CQ;
+    const int iw = (int)(p % a.w); p /= a.w;
+    const int ih = (int)(p % a.h);
+    const int n_ = (int)(p / a.h);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kh = 0; kh < a.k; ++kh) {
+      const int ohs = ih + a.pt - kh;
+      if (ohs < 0 || ohs % a.s) continue;
+      const int oh_ = ohs / a.s;
+      if (oh_ >= a.oh) continue;
+      for (int kw = 0; kw < a.k; ++kw) {
+        const int ows = iw + a.pl - kw;
+        if (ows < 0 || ows % a.s) continue;
+        const int ow_ = ows / a.s;
+        if (ow_ >= a.ow) continue;
+        const size_t o = ((size_t)(n_ * a.oh + oh_) * a.ow + ow_) * a.c + q4 * 4;
+        const uchar4 am = *reinterpret_cast<const uchar4*>(a.arg + o);
+        const float4 d = *reinterpret_cast<const float4*>(a.dy + o);
+        const unsigned char t = (unsigned char)(kh * a.k + kw);
+        if (am.x == t) g.x += d.x;
+        if (am.y == t) g.y += d.y;
+        if (am.z == t) g.z += d.z;
+        if (am.w == t) g.w += d.w;
+      }
+    }
+    *reinterpret_cast<float4*>(a.out + (size_t)i * 4) = g;
+  }
+}
+
+extern "C" int rn_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int n, int h, int w, int c, int k, int stride,
+                              rn_stream_t stream) {
   PoolArgs a = {};
   if (int e = fill_pool(&a, n, h, w, c, k, stride)) return e;
   RN_CHECK_ARG(x && y, "maxpool fwd: null pointer");
-  a.x = x; a.out = y;
+  RN_UNSUPPORTED(argmax && k * k > 255, "maxpool fwd: window %dx%d too large for byte tap indices", k, k);
+  a.x = x; a.out = y; a.arg = argmax;
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)n * a.oh * a.ow * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
@@ -318,6 +362,17 @@ extern "C" int rn_maxpool_bwd(const float* x, const float* dy, float* dx, int n,
   RN_CHECK_ARG(x && dy && dx, "maxpool bwd: null pointer");
   a.x = x; a.dy = dy; a.out = dx;
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)n * h * w * c)), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_maxpool_bwd_arg(const uint8_t* argmax, const float* dy, float* dx, int n, int h, int w, int c, int k, int stride,
+                                  rn_stream_t stream) {
+  PoolArgs a = {};
+  if (int e = fill_pool(&a, n, h, w, c, k, stride)) return e;
+  RN_CHECK_ARG(argmax && dy && dx, "maxpool bwd: null pointer");
+  a.arg = const_cast<uint8_t*>(argmax); a.dy = dy; a.out = dx;
+  hipLaunchKernelGGL(maxpool_bwd_arg_kernel, dim3(grid_for((int64_t)n * h * w * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }

@@ -692,20 +692,23 @@ class _MaxPool(torch.autograd.Function):
         oh, _ = _rn.same_pad(h, k, stride)
         ow, _ = _rn.same_pad(w, k, stride)
         y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
-        _rn.check(_rn.lib().rn_maxpool_fwd(_rn.f32(x), _rn.f32(y), n, h, w, c, k, stride, _rn.stream()), "rn_maxpool_fwd")
-        ctx.cfg = (k, stride)
-        ctx.save_for_backward(x)
+        # training: keep the arg-max tap of every window (1 byte per output) instead of x for the backward pass
+        arg = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=x.device) if x.requires_grad else None
+        _rn.check(_rn.lib().rn_maxpool_fwd(_rn.f32(x), _rn.f32(y), _rn.ptr(arg) if arg is not None else None, n, h, w, c, k,
+                                           stride, _rn.stream()), "rn_maxpool_fwd")
+        ctx.cfg = (k, stride, tuple(x.shape))
+        ctx.save_for_backward(arg)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        k, stride = ctx.cfg
-        n, h, w, c = x.shape
+        (arg,) = ctx.saved_tensors
+        k, stride, shape = ctx.cfg
+        n, h, w, c = shape
         dy = dy.contiguous()
-        dx = torch.empty_like(x)
-        _rn.check(_rn.lib().rn_maxpool_bwd(_rn.f32(x), _rn.f32(dy), _rn.f32(dx), n, h, w, c, k, stride, _rn.stream()),
-                  "rn_maxpool_bwd")
+        dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
+        _rn.check(_rn.lib().rn_maxpool_bwd_arg(_rn.ptr(arg), _rn.f32(dy), _rn.f32(dx), n, h, w, c, k, stride, _rn.stream()),
+                  "rn_maxpool_bwd_arg")
         return dx, None, None
 
 

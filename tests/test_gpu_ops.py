@@ -507,6 +507,13 @@ def test_pools_and_dropout(dev, shape):
         yg.backward(_t(dy, dev))
         assert_close(yg.detach().cpu().numpy(), yc.detach().numpy(), 1e-6, name + " pool fwd")
         assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), 1e-6, name + " pool bwd")
+        if name == "max":        # the other ABI form of the same gradient: re-scan the windows of x (no arg-max bytes)
+            import _rn
+            dx = torch.empty_like(xg)
+            n, h, w, c = shape
+            _rn.check(_rn.lib().rn_maxpool_bwd(_rn.f32(xg.detach()), _rn.f32(_t(dy, dev)), _rn.f32(dx), n, h, w, c, k, s,
+                                               _rn.stream()), "rn_maxpool_bwd")
+            assert torch.equal(dx, xg.grad)
     xg = _t(x, dev, True)
     y = ops.dropout(xg, 0.3, seed=77)
     keep = (y != 0)
