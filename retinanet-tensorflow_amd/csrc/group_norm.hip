@@ -932,6 +932,16 @@ int plan_slices(GnArgs* a) {
   return r;
 }
 
+// The slice kernel reads runs of slice_wc channels: fine for small maps and for runs of >= 64 bytes; larger maps with
+// narrow groups (ResNeXt's per-channel GroupNorm, MobileNet's 1..3-channel groups) go to the grid-resident kernel,
+// which reads whole rows.
+bool slice_preferred(const GnArgs& a) {
+  long elems = 0;
+  for (int s = 0; s < a.nseg; ++s) elems += (long)a.seg[s].n * a.seg[s].hw * a.c;
+  static const long big = getenv("RN_GN_SLICE_BIG") ? atol(getenv("RN_GN_SLICE_BIG")) : 262144;
+  return a.slice_wc >= 16 || (a.slice_wc >= 8 && elems < big);
+}
+
 template <bool BWD, int ACT>
 void launch_slices_act(const GnArgs& a, int r, hipStream_t st) {
   const unsigned blocks = (unsigned)(a.total_samples * (a.groups / (a.slice_wc / a.cpg)));
@@ -1049,7 +1059,7 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   // slice-resident kernel when its blocks read runs of >= 32 bytes; else the grid-resident kernel (full rows); else
   // the narrow slice kernel; else three kernels
   const int r = plan_slices(&a);
-  if (r && a.slice_wc >= 8) {
+  if (r && slice_preferred(a)) {
     launch_slices<false>(a, r, st);
     RN_LAUNCH_CHECK();
     return RN_OK;
@@ -1093,7 +1103,7 @@ extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   a.coef = (float*)((char*)workspace + rn::align_up((size_t)a.total_chunks * a.c * 2 * sizeof(float), 256));
   hipStream_t st = (hipStream_t)stream;
   const int r = plan_slices(&a);
-  bool coop_first = r && a.slice_wc < 8;
+  bool coop_first = r && !slice_preferred(a);
   if (coop_first) {
     GnArgs c = a;
     coop_first = plan_coop(&c) && ws_bytes(c) <= workspace_bytes;
