@@ -171,9 +171,16 @@ def test_group_norm_act_fwd_bwd(dev, c, act, res):
     assert_close(bg.grad.cpu().numpy(), bc.grad.numpy(), TOL, "gn dbeta")
 
 
-def test_group_norm_dropout_is_consistent(dev):
-    """Dropout mask: right keep fraction, inverted scaling, and backward uses the SAME mask."""
+@pytest.mark.parametrize("mode", ["default", "grid_resident", "three_kernel"])
+def test_group_norm_dropout_is_consistent(dev, monkeypatch, mode):
+    """Dropout mask: right keep fraction, inverted scaling, and backward uses the SAME mask -- and the SAME mask in all
+    three GroupNorm implementations (the mask is a function of the element index only)."""
     import ops
+    if mode != "default":
+        monkeypatch.setenv("RN_GN_NO_SLICE", "1")
+    if mode == "three_kernel":
+        monkeypatch.setenv("RN_GN_NO_COOP", "1")
+    torch.manual_seed(0)
     c = 64
     x = torch.randn(2, 32, 32, c, device=dev, requires_grad=True)
     gamma = torch.ones(c, device=dev, requires_grad=True)
@@ -190,6 +197,11 @@ def test_group_norm_dropout_is_consistent(dev):
     y.sum().backward()
     expect = kept.float().sum((0, 1, 2)) / 0.75
     assert torch.allclose(beta.grad, expect, rtol=1e-4)
+    _DROPOUT_MASKS.append(kept.cpu())
+    assert torch.equal(_DROPOUT_MASKS[0], _DROPOUT_MASKS[-1])       # same mask whichever kernel path produced it
+
+
+_DROPOUT_MASKS = []
 
 
 @pytest.mark.parametrize("shape", [((2, 8, 8), (4, 4)), ((2, 64, 64), (32, 32)), ((1, 75, 75), (38, 38)), ((1, 5, 7), (3, 4))])
@@ -801,3 +813,44 @@ def test_build_dataset_pipeline(dev):
     for k in lv:
         assert torch.equal(b['trainable_masks'][k][1], m2[k][0])
         assert torch.equal(b['detection']['classifications'][k][1], c2[k][0])
+
+
+@pytest.mark.parametrize("mode", ["default", "grid_resident", "three_kernel"])
+@pytest.mark.parametrize("c,act,res", [(96, "relu6", False), (256, "elu", True), (24, None, False)])
+def test_group_norm_all_kernel_paths(dev, monkeypatch, mode, c, act, res):
+    """The three GroupNorm implementations (slice-resident, grid-resident with the in-kernel barrier, partial + finalize +
+    apply) on mid-sized multi-segment inputs, each against the oracle; no barrier may time out."""
+    import _rn
+    import ops
+    if mode != "default":
+        monkeypatch.setenv("RN_GN_NO_SLICE", "1")
+    if mode == "three_kernel":
+        monkeypatch.setenv("RN_GN_NO_COOP", "1")
+    rng = np.random.default_rng(c + len(mode))
+    shapes = [(2, 40, 36, c), (2, 20, 18, c), (2, 3, 3, c)]
+    gamma = (1 + 0.3 * rng.standard_normal(c)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(c)).astype(np.float32)
+    xs = [(rng.standard_normal(s) * 2 + 0.5).astype(np.float32) for s in shapes]
+    rs = [rng.standard_normal(s).astype(np.float32) for s in shapes] if res else None
+    gc, bc = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
+    xcs = [torch.from_numpy(x).requires_grad_(True) for x in xs]
+    rcs = [torch.from_numpy(r).requires_grad_(True) for r in rs] if res else None
+    ycs = []
+    for i, x in enumerate(xcs):
+        y = tf_ops_ref.activation(tf_ops_ref.group_norm(x, gc, bc), act)
+        ycs.append(y + rcs[i] if res else y)
+    dys = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    torch.autograd.backward(ycs, [torch.from_numpy(d) for d in dys])
+    gg, bg = _t(gamma, dev, True), _t(beta, dev, True)
+    xgs = [_t(x, dev, True) for x in xs]
+    rgs = [_t(r, dev, True) for r in rs] if res else None
+    ygs = ops.group_norm_act(xgs, gg, bg, 32, 1e-5, act, rgs)
+    torch.autograd.backward(ygs, [_t(d, dev) for d in dys])
+    for i in range(len(xs)):
+        assert_close(ygs[i].detach().cpu().numpy(), ycs[i].detach().numpy(), TOL, "gn fwd " + mode)
+        assert_close(xgs[i].grad.cpu().numpy(), xcs[i].grad.numpy(), TOL, "gn dx " + mode)
+        if res:
+            assert_close(rgs[i].grad.cpu().numpy(), rcs[i].grad.numpy(), TOL, "gn dres " + mode)
+    assert_close(gg.grad.cpu().numpy(), gc.grad.numpy(), TOL, "gn dgamma " + mode)
+    assert_close(bg.grad.cpu().numpy(), bc.grad.numpy(), TOL, "gn dbeta " + mode)
+    assert _rn.barrier_timeouts() == 0
