@@ -182,6 +182,37 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
   }
 
   // epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  if (!args.out_f32 && (cout_g & 7) == 0) {
+    // fp16 output: stage the tile through LDS (the operand tiles are dead) and write it as whole 16-byte row pieces --
+    // 8 global stores per thread instead of 64 two-byte ones, every row of the tile a contiguous 2*BN-byte run.
+    constexpr int LDS_ROW = BN + 8;  // halfs; +8 keeps the two half-waves (rows r, r+4) on different banks
+    static_assert(BM * LDS_ROW <= (BM + BN) * LDH, "staging tile must fit the operand tiles' LDS");
+    _Float16* Cs = smem;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int lc = wn * (BN / WN) + tn * 32 + l31;
+      const int col = n0 + lc;
+      const float bv = (sg.bias != nullptr && col < nmax) ? sg.bias[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int rb = wm * (BM / WM) + tm * 32 + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Cs[(rb + (r & 3) + 8 * (r >> 2)) * LDS_ROW + lc] = (_Float16)(acc[tm][tn][r] + bv);
+      }
+    }
+    __syncthreads();
+    constexpr int VPR = BN / 8;  // 16-byte vectors per tile row
+    const __amdgpu_buffer_rsrc_t ys = make_rsrc(sg.y, (unsigned)M * (unsigned)cout * 2u);
+#pragma unroll
+    for (int v = tid; v < BM * VPR; v += T) {
+      const int row = v / VPR, cv = v - row * VPR;
+      const int col = n0 + cv * 8;
+      const u32x4 d = *reinterpret_cast<const u32x4*>(&Cs[row * LDS_ROW + cv * 8]);
+      const bool ok = col < nmax;  // cout_g % 8 == 0: a vector never straddles a group
+      __builtin_amdgcn_raw_buffer_store_b128(d, ys, ok ? ((unsigned)(m0 + row) * (unsigned)cout + (unsigned)col) * 2u : OOB, 0, 0);
+    }
+    return;
+  }
   const unsigned esz = args.out_f32 ? 4u : 2u;
   const __amdgpu_buffer_rsrc_t ys = make_rsrc(sg.y, (unsigned)M * (unsigned)cout * esz);
 #pragma unroll

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(T) void gn_apply_kernel(const GnArgs a) {
   const GnSeg& sg = a.seg[s];
   const int nl = q - sg.sample_start;
   const int C = a.c, CQ = C >> 2;
+  if ((int64_t)blockIdx.x * T >= (int64_t)sg.hw * CQ) return;  // the grid is sized for the largest segment
   for (int c = tid; c < C; c += T) {
     const int g = c / a.cpg;
     const float mean = sg.mean[nl * a.groups + g], rstd = sg.rstd[nl * a.groups + g];
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(T) void gn_apply_kernel(const GnArgs a) {
 
 // fp16-storage inference apply: 8 channels (16 B) per thread, no dropout.  y = act(z) + r  or  act(z + r).
 typedef _Float16 gn_half8 __attribute__((ext_vector_type(8)));
+template <int ACT>
 __global__ __launch_bounds__(T) void gn_apply_f16x8_kernel(const GnArgs a) {
   __shared__ float tab[2048][2];  // scale = rstd*gamma, shift = beta - mean*rstd*gamma  (z = x*scale + shift)
   const int q = blockIdx.y, tid = threadIdx.x;
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(T) void gn_apply_f16x8_kernel(const GnArgs a) {
   const GnSeg& sg = a.seg[s];
   const int nl = q - sg.sample_start;
   const int C = a.c, C8 = C >> 3;
+  if ((int64_t)blockIdx.x * T >= (int64_t)sg.hw * C8) return;  // the grid is sized for the largest segment
   for (int c = tid; c < C; c += T) {
     const int g = c / a.cpg;
     const float mean = sg.mean[nl * a.groups + g], rstd = sg.rstd[nl * a.groups + g];
@@ -313,6 +316,8 @@ __global__ __launch_bounds__(T) void gn_apply_f16x8_kernel(const GnArgs a) {
   const _Float16* __restrict__ r = sg.res ? reinterpret_cast<const _Float16*>(sg.res) + base : nullptr;
   _Float16* __restrict__ y = reinterpret_cast<_Float16*>(sg.y) + base;
   const int64_t total = (int64_t)sg.hw * C8;
+  const bool aar = a.act_after_res != 0;
+#pragma unroll 2
   for (int64_t i = (int64_t)blockIdx.x * T + tid; i < total; i += (int64_t)gridDim.x * T) {
     const int c0 = (int)(i % C8) * 8;
     const gn_half8 xv = *reinterpret_cast<const gn_half8*>(x + i * 8);
@@ -321,9 +326,10 @@ __global__ __launch_bounds__(T) void gn_apply_f16x8_kernel(const GnArgs a) {
     gn_half8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float z = (float)xv[j] * tab[c0 + j][0] + tab[c0 + j][1];
+      const float2 t = *reinterpret_cast<const float2*>(&tab[c0 + j][0]);
+      const float z = (float)xv[j] * t.x + t.y;
       const float rr = r ? (float)rv[j] : 0.f;
-      const float v = a.act_after_res ? rn::act_fwd(z + rr, a.act) : rn::act_fwd(z, a.act) + rr;
+      const float v = aar ? rn::act_fwd(z + rr, ACT) : rn::act_fwd(z, ACT) + rr;
       o[j] = (_Float16)v;
     }
     *reinterpret_cast<gn_half8*>(y + i * 8) = o;
@@ -1014,12 +1020,20 @@ size_t ws_bytes(const GnArgs& a) {
          rn::align_up(rows * a.groups * 2 * sizeof(float), 256);  // bwd coefficients / grid-resident group rows
 }
 
-unsigned apply_blocks(const GnArgs& a) {
-  long mx = 0;
-  for (int s = 0; s < a.nseg; ++s) mx = mx > (long)a.seg[s].hw * (a.c / 4) ? mx : (long)a.seg[s].hw * (a.c / 4);
-  long b = (mx + T * 4 - 1) / (T * 4);
+// blocks per sample of the apply pass (grid.y = samples).  Every block first builds the per-channel scale / shift table
+// (a ~1.5 us dependent chain), so blocks get `per` vectors per thread: 4 when the launch is small (latency-bound: more
+// blocks), 16 once there are already >= 8 blocks per CU without it (bandwidth-bound: amortise the table).
+unsigned apply_blocks(const GnArgs& a, int vec = 4) {
+  long mx = 0, all = 0;
+  for (int s = 0; s < a.nseg; ++s) {
+    const long v = (long)a.seg[s].hw * (a.c / vec);
+    mx = mx > v ? mx : v;
+    all += v * a.seg[s].n;
+  }
+  const long per = all >= 16L * 2048 * T ? 16 : 4;
+  long b = (mx + T * per - 1) / (T * per);
   if (b < 1) b = 1;
-  if (b > 2048) b = 2048;  // x samples in grid.y: one float4 per thread for maps up to 2 M elements per sample
+  if (b > 4096) b = 4096;
   return (unsigned)b;
 }
 
@@ -1081,7 +1095,13 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(a.total_chunks), dim3(T), 0, st, a);
   hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(a.total_samples * a.groups), dim3(T), 0, st, a);
   if (a.in_half && a.out_half && a.c % 8 == 0 && a.drop_rate == 0.f)
-    hipLaunchKernelGGL(gn_apply_f16x8_kernel, dim3(apply_blocks(a) * 2, a.total_samples), dim3(T), 0, st, a);
+    switch (a.act) {  // activation as a template parameter: no per-element switch in a bandwidth-bound pass
+      case RN_ACT_RELU: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_RELU>, dim3(apply_blocks(a, 8), a.total_samples), dim3(T), 0, st, a); break;
+      case RN_ACT_ELU: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_ELU>, dim3(apply_blocks(a, 8), a.total_samples), dim3(T), 0, st, a); break;
+      case RN_ACT_RELU6: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_RELU6>, dim3(apply_blocks(a, 8), a.total_samples), dim3(T), 0, st, a); break;
+      case RN_ACT_SIGMOID: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_SIGMOID>, dim3(apply_blocks(a, 8), a.total_samples), dim3(T), 0, st, a); break;
+      default: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_NONE>, dim3(apply_blocks(a, 8), a.total_samples), dim3(T), 0, st, a); break;
+    }
   else
     hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(apply_blocks(a), a.total_samples), dim3(T), 0, st, a);
   RN_LAUNCH_CHECK();
