@@ -51,6 +51,16 @@ def test_conv_f16(dev, case):
     assert_close(got.float().cpu().numpy(), ref, 2e-5 if out_f32 else 1e-3, "conv f16")
 
 
+@pytest.mark.parametrize("cfg", ["4", "5"])
+@pytest.mark.parametrize("case", [(2, 40, 38, 256, 384, 3, 1, 1, True, False), (1, 67, 33, 128, 264, 1, 1, 1, False, False),
+                                  (2, 30, 30, 64, 256, 3, 2, 1, False, True)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_f16_large_tiles(dev, monkeypatch, case, cfg):
+    """The 256x128 / 256x256 tile shapes (chosen automatically only for the 3x3 head convs of large batches): forced
+    here on moderate shapes with ragged M / N edges; same checks as test_conv_f16."""
+    monkeypatch.setenv("RN_CONV_CFG", cfg)
+    test_conv_f16(dev, case)
+
+
 def test_group_norm_pool_upsample_f16(dev):
     import ops_f16
     rng = np.random.default_rng(3)
