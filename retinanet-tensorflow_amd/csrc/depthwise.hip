@@ -15,6 +15,7 @@ struct DwArgs {
   float* partial;
 };
 
+template <bool K3>
 __global__ __launch_bounds__(T) void dw_fwd_kernel(const DwArgs a) {
   const int CQ = a.c >> 2;
   const int64_t total = (int64_t)a.n * a.oh * a.ow * CQ;
@@ -25,16 +26,36 @@ __global__ __launch_bounds__(T) void dw_fwd_kernel(const DwArgs a) {
     const int oh_ = (int)(p % a.oh);
     const int n_ = (int)(p / a.oh);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int kh = 0; kh < a.k; ++kh) {
-      const int ih = oh_ * a.stride - a.pad_t + kh;
-      if ((unsigned)ih >= (unsigned)a.h) continue;
-      for (int kw = 0; kw < a.k; ++kw) {
-        const int iw = ow_ * a.stride - a.pad_l + kw;
-        if ((unsigned)iw >= (unsigned)a.wd) continue;
-        const float4 xv = *reinterpret_cast<const float4*>(a.x + ((size_t)(n_ * a.h + ih) * a.wd + iw) * a.c + q4 * 4);
-        const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(kh * a.k + kw) * a.c + q4 * 4);
-        acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y);
-        acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
+    if (K3) {
+      // branch-free 3x3: every tap is loaded from a clamped address and multiplied by a 0/1 mask -- loads under
+      // `if (in bounds)` compile to a branch + wait per tap, i.e. nine serialised round trips
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh_ * a.stride - a.pad_t + kh;
+        const int ihc = min(max(ih, 0), a.h - 1);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = ow_ * a.stride - a.pad_l + kw;
+          const int iwc = min(max(iw, 0), a.wd - 1);
+          const float m = ((unsigned)ih < (unsigned)a.h && (unsigned)iw < (unsigned)a.wd) ? 1.f : 0.f;
+          const float4 xv = *reinterpret_cast<const float4*>(a.x + ((size_t)(n_ * a.h + ihc) * a.wd + iwc) * a.c + q4 * 4);
+          const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(kh * 3 + kw) * a.c + q4 * 4);
+          acc.x = fmaf(xv.x * m, wv.x, acc.x); acc.y = fmaf(xv.y * m, wv.y, acc.y);
+          acc.z = fmaf(xv.z * m, wv.z, acc.z); acc.w = fmaf(xv.w * m, wv.w, acc.w);
+        }
+      }
+    } else {
+      for (int kh = 0; kh < a.k; ++kh) {
+        const int ih = oh_ * a.stride - a.pad_t + kh;
+        if ((unsigned)ih >= (unsigned)a.h) continue;
+        for (int kw = 0; kw < a.k; ++kw) {
+          const int iw = ow_ * a.stride - a.pad_l + kw;
+          if ((unsigned)iw >= (unsigned)a.wd) continue;
+          const float4 xv = *reinterpret_cast<const float4*>(a.x + ((size_t)(n_ * a.h + ih) * a.wd + iw) * a.c + q4 * 4);
+          const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(kh * a.k + kw) * a.c + q4 * 4);
+          acc.x = fmaf(xv.x, wv.x, acc.x); acc.y = fmaf(xv.y, wv.y, acc.y);
+          acc.z = fmaf(xv.z, wv.z, acc.z); acc.w = fmaf(xv.w, wv.w, acc.w);
+        }
       }
     }
     *reinterpret_cast<float4*>(a.out + (size_t)i * 4) = acc;
@@ -42,6 +63,7 @@ __global__ __launch_bounds__(T) void dw_fwd_kernel(const DwArgs a) {
 }
 
 // dx[n,ih,iw,c] = sum_{kh,kw} dy[n,oh,ow,c]*w[kh,kw,c] with oh*s + kh - pad_t == ih
+template <bool K3>
 __global__ __launch_bounds__(T) void dw_dgrad_kernel(const DwArgs a) {
   const int CQ = a.c >> 2;
   const int64_t total = (int64_t)a.n * a.h * a.wd * CQ;
@@ -52,20 +74,41 @@ __global__ __launch_bounds__(T) void dw_dgrad_kernel(const DwArgs a) {
     const int ih = (int)(p % a.h);
     const int n_ = (int)(p / a.h);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int kh = 0; kh < a.k; ++kh) {
-      const int ohs = ih + a.pad_t - kh;
-      if (ohs < 0 || ohs % a.stride) continue;
-      const int oh_ = ohs / a.stride;
-      if (oh_ >= a.oh) continue;
-      for (int kw = 0; kw < a.k; ++kw) {
-        const int ows = iw + a.pad_l - kw;
-        if (ows < 0 || ows % a.stride) continue;
-        const int ow_ = ows / a.stride;
-        if (ow_ >= a.ow) continue;
-        const float4 dv = *reinterpret_cast<const float4*>(a.dy + ((size_t)(n_ * a.oh + oh_) * a.ow + ow_) * a.c + q4 * 4);
-        const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(kh * a.k + kw) * a.c + q4 * 4);
-        acc.x = fmaf(dv.x, wv.x, acc.x); acc.y = fmaf(dv.y, wv.y, acc.y);
-        acc.z = fmaf(dv.z, wv.z, acc.z); acc.w = fmaf(dv.w, wv.w, acc.w);
+    if (K3) {  // branch-free (see dw_fwd_kernel); stride 1 or 2
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ohs = ih + a.pad_t - kh;
+        const int oh_ = ohs / a.stride;
+        const bool rok = ohs >= 0 && oh_ * a.stride == ohs && oh_ < a.oh;
+        const int ohc = min(max(oh_, 0), a.oh - 1);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ows = iw + a.pad_l - kw;
+          const int ow_ = ows / a.stride;
+          const float m = (rok && ows >= 0 && ow_ * a.stride == ows && ow_ < a.ow) ? 1.f : 0.f;
+          const int owc = min(max(ow_, 0), a.ow - 1);
+          const float4 dv = *reinterpret_cast<const float4*>(a.dy + ((size_t)(n_ * a.oh + ohc) * a.ow + owc) * a.c + q4 * 4);
+          const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(kh * 3 + kw) * a.c + q4 * 4);
+          acc.x = fmaf(dv.x * m, wv.x, acc.x); acc.y = fmaf(dv.y * m, wv.y, acc.y);
+          acc.z = fmaf(dv.z * m, wv.z, acc.z); acc.w = fmaf(dv.w * m, wv.w, acc.w);
+        }
+      }
+    } else {
+      for (int kh = 0; kh < a.k; ++kh) {
+        const int ohs = ih + a.pad_t - kh;
+        if (ohs < 0 || ohs % a.stride) continue;
+        const int oh_ = ohs / a.stride;
+        if (oh_ >= a.oh) continue;
+        for (int kw = 0; kw < a.k; ++kw) {
+          const int ows = iw + a.pad_l - kw;
+          if (ows < 0 || ows % a.stride) continue;
+          const int ow_ = ows / a.stride;
+          if (ow_ >= a.ow) continue;
+          const float4 dv = *reinterpret_cast<const float4*>(a.dy + ((size_t)(n_ * a.oh + oh_) * a.ow + ow_) * a.c + q4 * 4);
+          const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(kh * a.k + kw) * a.c + q4 * 4);
+          acc.x = fmaf(dv.x, wv.x, acc.x); acc.y = fmaf(dv.y, wv.y, acc.y);
+          acc.z = fmaf(dv.z, wv.z, acc.z); acc.w = fmaf(dv.w, wv.w, acc.w);
+        }
       }
     }
     *reinterpret_cast<float4*>(a.out + (size_t)i * 4) = acc;
@@ -97,12 +140,12 @@ __global__ __launch_bounds__(T) void dw_wgrad_partial_kernel(const DwArgs a) {
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const int iw = ow_ * a.stride - a.pad_l + kw;
-          if ((unsigned)ih < (unsigned)a.h && (unsigned)iw < (unsigned)a.wd) {
-            const float4 xv = *reinterpret_cast<const float4*>(a.x + ((size_t)(n_ * a.h + ih) * a.wd + iw) * a.c + q4 * 4);
-            float4& t = acc[kh * 3 + kw];
-            t.x = fmaf(xv.x, dv.x, t.x); t.y = fmaf(xv.y, dv.y, t.y);
-            t.z = fmaf(xv.z, dv.z, t.z); t.w = fmaf(xv.w, dv.w, t.w);
-          }
+          const float m = ((unsigned)ih < (unsigned)a.h && (unsigned)iw < (unsigned)a.wd) ? 1.f : 0.f;  // branch-free
+          const int ihc = min(max(ih, 0), a.h - 1), iwc = min(max(iw, 0), a.wd - 1);
+          const float4 xv = *reinterpret_cast<const float4*>(a.x + ((size_t)(n_ * a.h + ihc) * a.wd + iwc) * a.c + q4 * 4);
+          float4& t = acc[kh * 3 + kw];
+          t.x = fmaf(xv.x * m, dv.x, t.x); t.y = fmaf(xv.y * m, dv.y, t.y);
+          t.z = fmaf(xv.z * m, dv.z, t.z); t.w = fmaf(xv.w * m, dv.w, t.w);
         }
       }
     }
@@ -155,7 +198,8 @@ extern "C" int rn_depthwise_fwd(const float* x, const float* wgt, float* y, int 
   if (int e = fill(&a, n, h, w, c, k, stride)) return e;
   RN_CHECK_ARG(x && wgt && y, "depthwise fwd: null pointer");
   a.x = x; a.w = wgt; a.out = y;
-  hipLaunchKernelGGL(dw_fwd_kernel, dim3(grid_for((int64_t)n * a.oh * a.ow * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
+  if (k == 3) hipLaunchKernelGGL(dw_fwd_kernel<true>, dim3(grid_for((int64_t)n * a.oh * a.ow * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(dw_fwd_kernel<false>, dim3(grid_for((int64_t)n * a.oh * a.ow * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
@@ -166,7 +210,8 @@ extern "C" int rn_depthwise_dgrad(const float* dy, const float* wgt, float* dx, 
   if (int e = fill(&a, n, h, w, c, k, stride)) return e;
   RN_CHECK_ARG(dy && wgt && dx, "depthwise dgrad: null pointer");
   a.dy = dy; a.w = wgt; a.out = dx;
-  hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_for((int64_t)n * h * w * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
+  if (k == 3) hipLaunchKernelGGL(dw_dgrad_kernel<true>, dim3(grid_for((int64_t)n * h * w * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(dw_dgrad_kernel<false>, dim3(grid_for((int64_t)n * h * w * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
