@@ -116,8 +116,17 @@ __global__ __launch_bounds__(256) void loss_sum_kernel(const LossArgs a, int nbl
   const int il = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int i = blockIdx.x * 16 + il;
   double v = 0.0;
-  if (i < n)
-    for (int b = rl; b < nblocks; b += 16) v += (double)a.partial[(size_t)b * n + i];
+  if (i < n) {
+    int b = rl;
+    for (; b + 16 * 7 < nblocks; b += 16 * 8) {  // eight loads in flight, added in row order
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = a.partial[(size_t)(b + 16 * u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += (double)t[u];
+    }
+    for (; b < nblocks; b += 16) v += (double)a.partial[(size_t)b * n + i];
+  }
   sh[rl][il] = v;
   __syncthreads();
   if (rl == 0 && i < n) {
