@@ -44,4 +44,5 @@ class Shapes(Base):
                 image[mask] = color
                 boxes.append([y - s, x - s, y + s, x + s])
                 class_ids.append(shape)
-            yield {'image': image, 'class_ids': np.asarray(class_ids, np.int32), 'boxes': np.asarray(boxes, np.float32)}
+            yield self.check_sample({'image': image, 'class_ids': np.asarray(class_ids, np.int32),
+                                     'boxes': np.asarray(boxes, np.float32)})
