@@ -214,6 +214,41 @@ def iou(a, b, name='iou'):
     return torch.where(invalid, torch.zeros_like(val), val)
 
 
+class _LazyLevels(dict):
+    """Per-level dict whose values are computed on first access.  In the reference these tensors are graph nodes that a
+    training step never fetches (only summaries / metrics read `regression_postprocessed`), so TensorFlow prunes them; a
+    define-by-run host has to be lazy explicitly or it pays ten decode launches per step for nothing."""
+
+    def __init__(self, keys, fn):
+        super().__init__()
+        self._keys, self._fn = list(keys), fn
+
+    def __missing__(self, k):
+        if k not in self._keys:
+            raise KeyError(k)
+        v = self._fn(k)
+        dict.__setitem__(self, k, v)
+        return v
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def __len__(self):
+        return len(self._keys)
+
+    def keys(self):
+        return list(self._keys)
+
+    def values(self):
+        return [self[k] for k in self._keys]
+
+    def items(self):
+        return [(k, self[k]) for k in self._keys]
+
+    def __contains__(self, k):
+        return k in self._keys
+
+
 def postprocess_and_mask(input, trainable_masks, image_size, levels, name='postprocess_and_mask'):
     """utils.py:258-284 without the gather: the per-level tensors and the masks are kept side
     by side (``detection_trainable`` carries the masks); losses.loss weighs rows by the mask,
@@ -221,9 +256,9 @@ def postprocess_and_mask(input, trainable_masks, image_size, levels, name='postp
     detection = Detection(
         classification=input['detection']['classifications'],
         regression=input['detection']['regressions'],
-        regression_postprocessed=dict_starmap(
-            lambda r, l: regression_postprocess(r, levels[l].normalized_anchor_sizes(image_size, ANCHOR_SIZE_MODE)),
-            (input['detection']['regressions'], {k: k for k in levels})))
+        regression_postprocessed=_LazyLevels(
+            levels, lambda l: regression_postprocess(input['detection']['regressions'][l],
+                                                     levels[l].normalized_anchor_sizes(image_size, ANCHOR_SIZE_MODE))))
     detection_trainable = DetectionTrainable(
         classification=detection.classification, regression=detection.regression,
         regression_postprocessed=detection.regression_postprocessed, trainable_masks=trainable_masks)

@@ -88,6 +88,13 @@ def test_loss_and_gradients_match_oracle(dev, mode):
     inp, logits = utils.process_labels_and_logits(labels=feats, logits=logits, levels=lv)
     gcl, grl = losses.loss(labels=inp["detection_trainable"], logits=logits["detection_trainable"], mode=mode)
     (gcl + grl).backward()
+    # `regression_postprocessed` (only summaries / metrics read it) is decoded lazily, per level, on first access
+    rp = logits["detection"].regression_postprocessed
+    assert list(rp.keys()) == list(lv) and len(dict.keys(rp)) == 0
+    p3 = rp["P3"]
+    size = tuple(feats["image"].shape[1:3])
+    want = utils.regression_postprocess(logits["detection"].regression["P3"], lv["P3"].normalized_anchor_sizes(size, utils.ANCHOR_SIZE_MODE))
+    assert torch.equal(p3, want) and list(dict.keys(rp)) == ["P3"] and len(rp.items()) == len(list(lv))
     assert_close(gcl.item(), cl.item(), TOL, "class loss")
     assert_close(grl.item(), rl.item(), TOL, "regr loss")
     # Error is measured against max(|grad of this tensor|, 1e-3 * largest gradient in the net): some
