@@ -162,6 +162,9 @@ int rn_depthwise_fwd(const float* x, const float* wgt, float* y, int n, int h, i
 int rn_depthwise_dgrad(const float* dy, const float* wgt, float* dx, int n, int h, int w, int c, int k,
                        int stride, rn_stream_t stream);
 size_t rn_depthwise_wgrad_workspace(int n, int h, int w, int c, int k, int stride);
+/* both gradients of a 3x3 depthwise conv in one launch (workspace: rn_depthwise_wgrad_workspace bytes) */
+int rn_depthwise_bwd(const float* x, const float* dy, const float* wgt, float* dx, float* dw, int n, int h, int w, int c, int k,
+                     int stride, void* workspace, size_t workspace_bytes, rn_stream_t stream);
 int rn_depthwise_wgrad(const float* x, const float* dy, float* dw, int n, int h, int w, int c, int k, int stride,
                        void* workspace, size_t workspace_bytes, rn_stream_t stream);
 

@@ -64,10 +64,10 @@ __global__ __launch_bounds__(T) void dw_fwd_kernel(const DwArgs a) {
 
 // dx[n,ih,iw,c] = sum_{kh,kw} dy[n,oh,ow,c]*w[kh,kw,c] with oh*s + kh - pad_t == ih
 template <bool K3>
-__global__ __launch_bounds__(T) void dw_dgrad_kernel(const DwArgs a) {
+__device__ __forceinline__ void dw_dgrad_body(const DwArgs& a, int bid, int nblk) {
   const int CQ = a.c >> 2;
   const int64_t total = (int64_t)a.n * a.h * a.wd * CQ;
-  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < total; i += (int64_t)gridDim.x * T) {
+  for (int64_t i = (int64_t)bid * T + threadIdx.x; i < total; i += (int64_t)nblk * T) {
     const int q4 = (int)(i % CQ);
     int64_t p = i / CQ;
     const int iw = (int)(p % a.wd); p /= a.wd;
@@ -115,14 +115,19 @@ __global__ __launch_bounds__(T) void dw_dgrad_kernel(const DwArgs a) {
   }
 }
 
+template <bool K3>
+__global__ __launch_bounds__(T) void dw_dgrad_kernel(const DwArgs a) {
+  dw_dgrad_body<K3>(a, blockIdx.x, gridDim.x);
+}
+
 // partial[chunk][tap][c] = sum over the chunk's output pixels of x(tap)*dy ; k == 3 only.
-__global__ __launch_bounds__(T) void dw_wgrad_partial_kernel(const DwArgs a) {
+__device__ __forceinline__ void dw_wgrad_partial_body(const DwArgs& a, int chunk) {
   __shared__ float red[T][4];
   const int tid = threadIdx.x;
   const int CQ = a.c >> 2, lanes = T / CQ;
   const int q4 = tid % CQ, pl = tid / CQ;
   const int64_t npix = (int64_t)a.n * a.oh * a.ow;
-  const int64_t p_begin = (int64_t)blockIdx.x * a.ppc;
+  const int64_t p_begin = (int64_t)chunk * a.ppc;
   const int64_t p_end = p_begin + a.ppc < npix ? p_begin + a.ppc : npix;
   float4 acc[9];
 #pragma unroll
@@ -160,9 +165,19 @@ __global__ __launch_bounds__(T) void dw_wgrad_partial_kernel(const DwArgs a) {
         s0 += red[l * CQ + tid][0]; s1 += red[l * CQ + tid][1];
         s2 += red[l * CQ + tid][2]; s3 += red[l * CQ + tid][3];
       }
-      *reinterpret_cast<float4*>(a.partial + ((size_t)blockIdx.x * 9 + t) * a.c + tid * 4) = make_float4(s0, s1, s2, s3);
+      *reinterpret_cast<float4*>(a.partial + ((size_t)chunk * 9 + t) * a.c + tid * 4) = make_float4(s0, s1, s2, s3);
     }
   }
+}
+
+__global__ __launch_bounds__(T) void dw_wgrad_partial_kernel(const DwArgs a) { dw_wgrad_partial_body(a, blockIdx.x); }
+
+// both gradients of a 3x3 depthwise conv in ONE launch: blocks [0, dgrad_blocks) compute dx, the rest the weight-gradient
+// partials (independent work on the same dy; two launch-latency-bound kernels otherwise)
+struct DwBwdArgs { DwArgs d, w; int dgrad_blocks; };
+__global__ __launch_bounds__(T) void dw_bwd_kernel(const DwBwdArgs b) {
+  if ((int)blockIdx.x < b.dgrad_blocks) dw_dgrad_body<true>(b.d, blockIdx.x, b.dgrad_blocks);
+  else dw_wgrad_partial_body(b.w, (int)blockIdx.x - b.dgrad_blocks);
 }
 
 int fill(DwArgs* a, int n, int h, int w, int c, int k, int stride) {
@@ -241,4 +256,28 @@ extern "C" int rn_depthwise_wgrad(const float* x, const float* dy, float* dw, in
   hipLaunchKernelGGL(dw_wgrad_partial_kernel, dim3(a.chunks), dim3(T), 0, st, a);
   RN_LAUNCH_CHECK();
   return rn::launch_reduce_rows((const float*)workspace, dw, 9 * c, a.chunks, 0, st);
+}
+
+// dx and dw of a 3x3 depthwise conv from one launch (+ the fixed-order row reduction of the dw partials, which joins
+// the step's deferred reduction when that is active).  Workspace: rn_depthwise_wgrad_workspace bytes.
+extern "C" int rn_depthwise_bwd(const float* x, const float* dy, const float* wgt, float* dx, float* dw, int n, int h, int w, int c,
+                                int k, int stride, void* workspace, size_t workspace_bytes, rn_stream_t stream) {
+  DwBwdArgs b = {};
+  if (int e = fill(&b.d, n, h, w, c, k, stride)) return e;
+  RN_CHECK_ARG(x && dy && wgt && dx && dw && workspace, "depthwise bwd: null pointer");
+  RN_UNSUPPORTED(k != 3, "depthwise bwd: only 3x3 kernels (got %d)", k);
+  b.w = b.d;
+  wgrad_plan(b.w, &b.w.chunks, &b.w.ppc);
+  const size_t need = (size_t)b.w.chunks * 9 * c * sizeof(float);
+  if (workspace_bytes < need) {
+    rn::set_error("depthwise bwd: workspace %zu < %zu", workspace_bytes, need);
+    return RN_EWORKSPACE;
+  }
+  b.d.dy = dy; b.d.w = wgt; b.d.out = dx;
+  b.w.x = x; b.w.dy = dy; b.w.partial = (float*)workspace;
+  b.dgrad_blocks = (int)grid_for((int64_t)n * h * w * (c / 4));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dw_bwd_kernel, dim3(b.dgrad_blocks + b.w.chunks), dim3(T), 0, st, b);
+  RN_LAUNCH_CHECK();
+  return rn::launch_reduce_rows((const float*)workspace, dw, 9 * c, b.w.chunks, 0, st);
 }

@@ -394,6 +394,14 @@ class _Depthwise(torch.autograd.Function):
         dy = dy.contiguous()
         L = _rn.lib()
         dx = dw = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and k == 3 and not WGRAD_SIDE_STREAM:
+            dx = torch.empty_like(x)                                  # both gradients from one launch
+            dw_buf, dw = _grad_slot(w)
+            need = L.rn_depthwise_wgrad_workspace(n, h, wd, c, k, ctx.stride)
+            ws = _grad_workspace(need, x.device)
+            _rn.check(L.rn_depthwise_bwd(_rn.f32(x), _rn.f32(dy), _rn.f32(w), _rn.f32(dx), _rn.f32(dw_buf), n, h, wd, c, k,
+                                         ctx.stride, ws.data_ptr(), ws.numel(), _rn.stream()), "rn_depthwise_bwd")
+            return dx, dw, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _rn.check(L.rn_depthwise_dgrad(_rn.f32(dy), _rn.f32(w), _rn.f32(dx), n, h, wd, c, k, ctx.stride,

@@ -135,6 +135,16 @@ def test_depthwise_fwd_bwd(dev, case):
     assert_close(yg.detach().cpu().numpy(), yc.detach().numpy(), TOL, "dw fwd")
     assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), TOL, "dw dgrad")
     assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), TOL, "dw wgrad")
+    # autograd used the one-launch rn_depthwise_bwd; the two separate entry points give the same bits
+    import _rn
+    L = _rn.lib()
+    dyg = _t(dy, dev)
+    dx2, dw2 = torch.empty_like(xg), torch.empty_like(wg)
+    _rn.check(L.rn_depthwise_dgrad(_rn.f32(dyg), _rn.f32(wg.detach()), _rn.f32(dx2), n, h, w, c, 3, stride, _rn.stream()), "dgrad")
+    ws = _rn.workspace(L.rn_depthwise_wgrad_workspace(n, h, w, c, 3, stride), dev)
+    _rn.check(L.rn_depthwise_wgrad(_rn.f32(xg.detach()), _rn.f32(dyg), _rn.f32(dw2), n, h, w, c, 3, stride, ws.data_ptr(), ws.numel(),
+                                   _rn.stream()), "wgrad")
+    assert torch.equal(dx2, xg.grad) and torch.equal(dw2, wg.grad)
 
 
 @pytest.mark.parametrize("c,act,res", [(256, "elu", False), (144, "elu", True), (32, "relu", False), (24, None, True),
