@@ -94,6 +94,13 @@ size_t rn_conv2d_wgrad_workspace(const rn_conv_seg* segs, int nseg, const rn_con
 int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, int accumulate,
                     void* workspace, size_t workspace_bytes, rn_stream_t stream);
 
+/* Both gradients of one convolution (segments: x, wgt, dy, dx as for the two calls above; dw overwritten).  Small
+ * problems -- the backbone's 1x1 convs -- run as ONE launch whose blocks are of two kinds (data-gradient tiles and
+ * weight-gradient splits); anything else falls back to rn_conv2d_dgrad (without split-K) + rn_conv2d_wgrad.
+ * workspace: rn_conv2d_wgrad_workspace bytes. */
+int rn_conv2d_bwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, void* workspace,
+                  size_t workspace_bytes, rn_stream_t stream);
+
 /* dbias[cout] = sum over all segments / pixels of dy (the out_conv biases, retinanet.py:46-53). */
 size_t rn_conv2d_bias_grad_workspace(int cout);
 int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dbias, void* workspace,

@@ -70,7 +70,7 @@ _lib = None
 SYMBOLS = [
     "rn_version", "rn_last_error", "rn_same_pad",
     "rn_conv2d_fwd_workspace", "rn_conv2d_dgrad_workspace",
-    "rn_conv2d_fwd", "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad",
+    "rn_conv2d_fwd", "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad", "rn_conv2d_bwd",
     "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes", "rn_defer_reductions", "rn_flush_reductions", "rn_gemm_batched", "rn_resize_bilinear_normalize",
     "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad", "rn_depthwise_bwd",
@@ -110,6 +110,7 @@ def lib():
         L.rn_conv2d_dgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_conv2d_fwd_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_conv2d_dgrad_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.rn_conv2d_bwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_conv2d_wgrad_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_conv2d_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_size_t, C.c_void_p]

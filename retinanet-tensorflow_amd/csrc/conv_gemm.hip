@@ -48,8 +48,9 @@ struct SegDev {
   int par, py, px, hc, wc, kh0, kw0, nkh, nkw;
 };
 
-struct ConvArgs {
-  SegDev seg[RN_MAX_SEG];
+template <int NS>
+struct ConvArgsT {
+  SegDev seg[NS];
   int nseg;
   int kh, kw, stride, cin;
   int groups, cin_g;  // grouped conv: cin_g = cin/groups input channels per group
@@ -67,6 +68,8 @@ struct ConvArgs {
   // `ksplit` K-tiles each (bs_a = bs_b = 0), written to slab rows bs_out apart and summed by reduce_rows
   int ksplit;
 };
+typedef ConvArgsT<RN_MAX_SEG> ConvArgs;
+typedef ConvArgsT<4> ConvArgs4;  // compact copy (<= 4 segments) so that TWO argument blocks fit one 4 KB kernarg
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0x80000000u;  // voffset beyond any tensor (< 2 GiB each): buffer loads return 0,
@@ -178,7 +181,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
-__device__ __forceinline__ int find_seg(const ConvArgs& args, int id) {
+template <typename A>
+__device__ __forceinline__ int find_seg(const A& args, int id) {
   int s = 0;
   while (s + 1 < args.nseg && id >= args.seg[s + 1].start) ++s;
   return s;
@@ -305,20 +309,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
 // dgrad: rows = input pixels, K = (kh,kw,co), N = ci.  W tile is read "NK" (ci rows, co contiguous).
 // TAPU: cout % BK == 0 (tap uniform per K-tile).
 // =============================================================================================
-template <int BM, int BN, int WM, int WN, int VEC, bool TAPU>
-__global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs args) {
+template <int BM, int BN>
+constexpr int dgrad_lds_floats() { return BM * LDK + BN * LDK; }
+
+// body of the data-gradient kernel: block `blk` of `nblk`, operand tiles in `smem` (dgrad_lds_floats floats)
+template <int BM, int BN, int WM, int WN, int VEC, bool TAPU, typename A>
+__device__ __forceinline__ void conv_dgrad_body(const A& args, float* smem, int blk, int nblk) {
   constexpr int T = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int KQ = BK / VEC, RPP = T / KQ, A_PASS = BM / RPP, B_PASS = BN / RPP;
   static_assert(A_PASS >= 1 && B_PASS >= 1, "tile/threads mismatch");
   typedef typename Vec<VEC>::type vec_t;
-  __shared__ __attribute__((aligned(16))) float smem[BM * LDK + BN * LDK];
   float* As = smem;
   float* Bs = smem + BM * LDK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  int bid = rn::xcd_remap(blk, nblk);
   int batch = 0;
   if (args.nbatch > 1) { batch = bid / args.btiles; bid -= batch * args.btiles; }
   const int s = find_seg(args, bid);
@@ -471,6 +478,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
   }
 }
 
+template <int BM, int BN, int WM, int WN, int VEC, bool TAPU>
+__global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs args) {
+  __shared__ __attribute__((aligned(16))) float smem[dgrad_lds_floats<BM, BN>()];
+  conv_dgrad_body<BM, BN, WM, WN, VEC, TAPU>(args, smem, blockIdx.x, gridDim.x);
+}
+
 // =============================================================================================
 // wgrad: rows m' = (kh,kw,ci), cols = co, reduction over output pixels p, split over blocks.
 // A tile is "KM" (pixel rows, m' contiguous = ci contiguous in x), B tile is dY rows.
@@ -479,22 +492,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_dgrad_kernel(const ConvArgs 
 // =============================================================================================
 constexpr int WG_MAXPIX = 1024;  // pixels per split (plan_wgrad keeps chunks <= this)
 
-template <int BM, int BN, int WM, int WN, int VEC>
-__global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs args) {
+template <int BM, int BN>
+constexpr int wgrad_lds_floats() { return BK * BM + BK * BN + 2 * WG_MAXPIX; }  // operand tiles + the pixel table (int2)
+
+// body of the weight-gradient kernel: block `blk` of `nblk`, LDS in `smem` (wgrad_lds_floats floats)
+template <int BM, int BN, int WM, int WN, int VEC, typename A>
+__device__ __forceinline__ void conv_wgrad_body(const A& args, float* smem, int blk, int nblk) {
   constexpr int T = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int MQ = BM / VEC, A_RPP = T / MQ, A_PASS = BK / A_RPP;
   constexpr int NQ = BN / VEC, B_RPP = T / NQ, B_PASS = BK / B_RPP;
   static_assert(A_PASS >= 1 && B_PASS >= 1 && BK % A_RPP == 0 && BK % B_RPP == 0, "tile/threads mismatch");
   typedef typename Vec<VEC>::type vec_t;
-  __shared__ __attribute__((aligned(16))) float smem[BK * BM + BK * BN];
-  __shared__ int2 pixtab[WG_MAXPIX];
   float* As = smem;
   float* Bs = smem + BK * BM;
+  int2* pixtab = reinterpret_cast<int2*>(smem + BK * BM + BK * BN);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = rn::xcd_remap(blk, nblk);
   int split = bid / args.tiles_mn;
   const int t = bid - split * args.tiles_mn;
   const int tile_n = t % args.tiles_n, tile_m = t / args.tiles_n;
@@ -591,6 +607,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
   }
   float* out = args.slab + (size_t)slab_row * ktotal * cout;
   store_tile<BM, BN, WM, WN>(acc, out, nullptr, m0, n0, ktotal, nmax, cout, wm, wn, lane);
+}
+
+template <int BM, int BN, int WM, int WN, int VEC>
+__global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs args) {
+  __shared__ __attribute__((aligned(16))) float smem[wgrad_lds_floats<BM, BN>()];
+  conv_wgrad_body<BM, BN, WM, WN, VEC>(args, smem, blockIdx.x, gridDim.x);
+}
+
+// Both gradients of one convolution in ONE launch: blocks [0, dblocks) run the data-gradient tiles, the rest the
+// weight-gradient splits (independent work on the same dy).  The small backbone convs are launch-latency-bound, and two
+// half-empty grids fill the chip better together.  Two compact argument blocks (<= 4 segments each) fit the kernarg.
+template <int DBM, int DBN, int DWM, int DWN, bool DTAPU, int WBM, int WBN, int WWM, int WWN>
+__global__ __launch_bounds__(256) void conv_bwd_kernel(const ConvArgs4 d, const ConvArgs4 w, int dblocks) {
+  constexpr int LDSF = dgrad_lds_floats<DBM, DBN>() > wgrad_lds_floats<WBM, WBN>() ? dgrad_lds_floats<DBM, DBN>()
+                                                                                   : wgrad_lds_floats<WBM, WBN>();
+  static_assert(DWM * DWN == 4 && WWM * WWN == 4, "both halves use 256-thread blocks");
+  __shared__ __attribute__((aligned(16))) float smem[LDSF];
+  if ((int)blockIdx.x < dblocks) conv_dgrad_body<DBM, DBN, DWM, DWN, 4, DTAPU>(d, smem, blockIdx.x, dblocks);
+  else conv_wgrad_body<WBM, WBN, WWM, WWN, 4>(w, smem, (int)blockIdx.x - dblocks, (int)gridDim.x - dblocks);
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_r in[r][i], fixed order => bitwise reproducible.
@@ -810,12 +845,20 @@ extern "C" void rn_same_pad(int n, int k, int s, int* out, int* pad_before) { rn
 
 namespace {
 struct Batch { int n; long bs_a, bs_b, bs_out; };
+// what a dgrad / wgrad call WOULD launch (filled instead of launching when requested): lets rn_conv2d_bwd put both
+// gradients of a convolution into one launch
+struct Planned {
+  ConvArgs a;
+  int cfg, blocks;
+  bool vec, tapu, simple;  // simple: one plain kernel (no split-K, no phase decomposition, no batch)
+  int nsplit; bool direct; int64_t count;  // wgrad: the row reduction that follows
+};
 // split-K scratch: ws == nullptr -> never split; need_out != nullptr -> dry run, only report the bytes split-K wants
 struct Scratch { void* ws; size_t bytes; size_t* need_out; };
 int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
                   const Scratch& sc = Scratch{nullptr, 0, nullptr});
 int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
-                    const Scratch& sc = Scratch{nullptr, 0, nullptr});
+                    const Scratch& sc = Scratch{nullptr, 0, nullptr}, Planned* plan = nullptr);
 
 // Tiny grids with a long reduction (the stride-2 convs that make P6 / P7, the 4x4 and 8x8 maps: 4..24 tiles x 72+
 // K-tiles) are latency-bound on a handful of CUs: split K over ~384/tiles blocks per tile and sum the partial
@@ -944,7 +987,7 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
 }
 
 int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
-                    const Scratch& sc) {
+                    const Scratch& sc, Planned* plan) {
   if (int e = validate_geom(segs, nseg, g)) return e;
   RN_CHECK_ARG(bt.n == 1 || nseg == 1, "conv: batched mode takes one segment");
   ConvArgs a = {};
@@ -1025,6 +1068,11 @@ int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, co
     tiles *= nsplit;
   } else {
     nsplit = 1;
+  }
+  if (plan) {
+    plan->a = a; plan->cfg = c; plan->blocks = tiles; plan->vec = vec; plan->tapu = tapu;
+    plan->simple = nsplit == 1 && !a.seg[0].par && bt.n == 1;
+    return RN_OK;
   }
 #define RN_DG(BM_, BN_, WM_, WN_)                                                                    \
   do {                                                                                               \
@@ -1121,7 +1169,8 @@ extern "C" size_t rn_conv2d_wgrad_workspace(const rn_conv_seg* segs, int nseg, c
 
 namespace {
 int conv_wgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, int accumulate, void* workspace,
-                    size_t workspace_bytes, const Batch& bt, rn_stream_t stream, int* nsplit_out = nullptr);
+                    size_t workspace_bytes, const Batch& bt, rn_stream_t stream, int* nsplit_out = nullptr,
+                    Planned* plan = nullptr);
 }
 extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, int accumulate,
                                void* workspace, size_t workspace_bytes, rn_stream_t stream) {
@@ -1150,7 +1199,7 @@ int rn::launch_batched_gemm_tn(const float* A, const float* B, float* C, int M, 
 
 namespace {
 int conv_wgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, int accumulate, void* workspace,
-                    size_t workspace_bytes, const Batch& bt, rn_stream_t stream, int* nsplit_out) {
+                    size_t workspace_bytes, const Batch& bt, rn_stream_t stream, int* nsplit_out, Planned* plan) {
   if (int e = validate_geom(segs, nseg, g)) return e;
   RN_CHECK_ARG((dw || nsplit_out) && workspace, "conv wgrad: null dw/workspace");
   RN_CHECK_ARG(bt.n == 1 || nseg == 1, "conv: batched mode takes one segment");
@@ -1180,6 +1229,11 @@ int conv_wgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, fl
   const bool vec = (a.cin_g % 4 == 0) && ((p.cout / a.groups) % 4 == 0);
   const int blocks = p.nsplit * bt.n * a.tiles_mn;
   hipStream_t st = (hipStream_t)stream;
+  if (plan) {
+    plan->a = a; plan->cfg = p.cfg; plan->blocks = blocks; plan->vec = vec; plan->tapu = false; plan->simple = bt.n == 1;
+    plan->nsplit = p.nsplit; plan->direct = direct; plan->count = (int64_t)p.ktotal * p.cout;
+    return RN_OK;
+  }
 #define RN_WG(BM_, BN_, WM_, WN_)                                                                    \
   do {                                                                                               \
     if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, WM_, WN_, 4>), dim3(blocks), dim3(WM_* WN_ * 64), 0, st, a); \
@@ -1201,6 +1255,54 @@ int conv_wgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, fl
   return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)bt.n * p.ktotal * p.cout, p.nsplit, accumulate, st);
 }
 }  // namespace
+
+namespace {
+ConvArgs4 compact(const ConvArgs& a) {
+  ConvArgs4 c = {};
+  for (int s = 0; s < a.nseg && s < 4; ++s) c.seg[s] = a.seg[s];
+  c.nseg = a.nseg; c.kh = a.kh; c.kw = a.kw; c.stride = a.stride; c.cin = a.cin; c.groups = a.groups; c.cin_g = a.cin_g;
+  c.tpg = a.tpg; c.ktotal = a.ktotal; c.tiles_mn = a.tiles_mn; c.tiles_n = a.tiles_n; c.cout = a.cout; c.slab = a.slab;
+  c.nbatch = a.nbatch; c.btiles = a.btiles; c.bs_a = a.bs_a; c.bs_b = a.bs_b; c.bs_out = a.bs_out; c.ksplit = a.ksplit;
+  return c;
+}
+}  // namespace
+
+// dx (segments' dx) and dw of one convolution.  Small problems (<= 4 segments, the 64x64 dgrad tile, no split-K / phase
+// decomposition) run as ONE launch of conv_bwd_kernel; everything else as rn_conv2d_dgrad followed by rn_conv2d_wgrad.
+// workspace: rn_conv2d_wgrad_workspace bytes.
+extern "C" int rn_conv2d_bwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, void* workspace,
+                             size_t workspace_bytes, rn_stream_t stream) {
+  static const bool enabled = getenv("RN_NO_MERGED_BWD") == nullptr;
+  Planned pd, pw;
+  bool merge = enabled && nseg <= 4;
+  if (merge) {
+    if (int e = conv_dgrad_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream, Scratch{nullptr, 0, nullptr}, &pd)) return e;
+    if (int e = conv_wgrad_impl(segs, nseg, g, dw, 0, workspace, workspace_bytes, Batch{1, 0, 0, 0}, stream, nullptr, &pw)) return e;
+    merge = pd.simple && pd.vec && pw.vec && pd.cfg == 2 && pd.a.nseg <= 4 && pw.a.nseg <= 4;
+  }
+  if (!merge) {
+    if (int e = conv_dgrad_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream)) return e;
+    return conv_wgrad_impl(segs, nseg, g, dw, 0, workspace, workspace_bytes, Batch{1, 0, 0, 0}, stream);
+  }
+  const ConvArgs4 d4 = compact(pd.a), w4 = compact(pw.a);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(pd.blocks + pw.blocks));
+#define RN_BWD(WBM_, WBN_, WWM_, WWN_)                                                                                          \
+  do {                                                                                                                          \
+    if (pd.tapu) hipLaunchKernelGGL((conv_bwd_kernel<64, 64, 2, 2, true, WBM_, WBN_, WWM_, WWN_>), grid, dim3(256), 0, st, d4, w4, pd.blocks); \
+    else hipLaunchKernelGGL((conv_bwd_kernel<64, 64, 2, 2, false, WBM_, WBN_, WWM_, WWN_>), grid, dim3(256), 0, st, d4, w4, pd.blocks);        \
+  } while (0)
+  switch (pw.cfg) {
+    case 0: RN_BWD(128, 128, 2, 2); break;
+    case 1: RN_BWD(128, 64, 2, 2); break;
+    case 2: RN_BWD(64, 64, 2, 2); break;
+    default: RN_BWD(128, 32, 4, 1); break;
+  }
+#undef RN_BWD
+  RN_LAUNCH_CHECK();
+  if (pw.direct) return RN_OK;
+  return rn::launch_reduce_rows((const float*)workspace, dw, pw.count, pw.nsplit, 0, st);
+}
 
 // ---------------------------------------------------------------------------------------------
 // bias gradient: column sums of dy over every pixel of every segment (two fixed-order stages)

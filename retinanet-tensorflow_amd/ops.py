@@ -64,6 +64,7 @@ class _on_side_stream(object):
 WINOGRAD = True
 WINOGRAD_TILE = 4
 WINOGRAD_WGRAD = True
+MERGED_CONV_BWD = True    # data + weight gradient of a small conv in one launch (rn_conv2d_bwd)
 WINOGRAD_KEEP = True      # forward keeps the transformed input / rotated kernel for backward (a few hundred MB per step)
 WINOGRAD_MIN_CHANNELS = 64
 WINOGRAD_MAX_WORKSPACE = int(os.environ.get("RN_WINOGRAD_MAX_WS", 8 << 30))   # of 288 GB HBM; the V / M planes of 1024^2 x 16 need 1.7 GB
@@ -249,6 +250,25 @@ class _Conv2dShared(torch.autograd.Function):
                 dys[i] = torch.zeros((xs[i].shape[0], oh, ow, cout), dtype=torch.float32, device=w.device)
         need_dx = [ctx.needs_input_grad[3 + i] for i in range(n)]
         dxs = [None] * n
+        want_dw0 = ctx.needs_input_grad[1]
+        if (all(need_dx) and want_dw0 and not ctx.winograd and not WGRAD_SIDE_STREAM and n <= 4 and MERGED_CONV_BWD):
+            # both gradients from one launch (small convs are launch-latency-bound); not when dgrad would take split-K
+            outs = [torch.empty_like(x) for x in xs]
+            segs = _conv_segs(xs, w, None, None, dys, outs)
+            if L.rn_conv2d_dgrad_workspace(segs, n, C.byref(geom)) == 0:
+                dw_buf, dw = _grad_slot(w)
+                need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
+                ws = _grad_workspace(need, w.device)
+                _rn.check(L.rn_conv2d_bwd(segs, n, C.byref(geom), _rn.f32(dw_buf), ws.data_ptr(), ws.numel(), _rn.stream()),
+                          "rn_conv2d_bwd")
+                db = None
+                if ctx.has_bias and ctx.needs_input_grad[2]:
+                    db_buf, db = _grad_slot(bias)
+                    need = L.rn_conv2d_bias_grad_workspace(cout)
+                    ws = _grad_workspace(need, w.device)
+                    _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws.data_ptr(), ws.numel(),
+                                                    _rn.stream()), "rn_conv2d_bias_grad")
+                return (None, dw, db) + tuple(outs)
         if any(need_dx):
             idx = [i for i in range(n) if need_dx[i]]
             outs = [torch.empty_like(xs[i]) for i in idx]

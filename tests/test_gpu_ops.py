@@ -864,3 +864,34 @@ def test_group_norm_all_kernel_paths(dev, monkeypatch, mode, c, act, res):
     assert_close(gg.grad.cpu().numpy(), gc.grad.numpy(), TOL, "gn dgamma " + mode)
     assert_close(bg.grad.cpu().numpy(), bc.grad.numpy(), TOL, "gn dbeta " + mode)
     assert _rn.barrier_timeouts() == 0
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 96, 24, 1, 1), (2, 16, 16, 144, 32, 1, 1), (1, 20, 20, 64, 128, 3, 1), (2, 8, 8, 320, 1280, 1, 1)])
+def test_merged_conv_backward_equals_separate_calls(dev, case):
+    """rn_conv2d_bwd (data + weight gradient in one launch) gives the same bits as rn_conv2d_dgrad + rn_conv2d_wgrad."""
+    import ctypes as C
+    import _rn
+    import ops
+    n, h, w, cin, cout, k, stride = case
+    g = torch.Generator(device=dev).manual_seed(cin + cout)
+    x = torch.randn((n, h, w, cin), generator=g, device=dev)
+    wt = torch.randn((k, k, cin, cout), generator=g, device=dev) * 0.05
+    dy = torch.randn((n, h, w, cout), generator=g, device=dev)
+    L = _rn.lib()
+    geom = _rn.ConvGeom(k, k, stride, cin, 1)
+
+    def run(merged):
+        dx, dw = torch.empty_like(x), torch.empty_like(wt)
+        segs = ops._conv_segs([x], wt, None, None, [dy], [dx])
+        ws = torch.empty(max(int(L.rn_conv2d_wgrad_workspace(segs, 1, C.byref(geom))), 256), dtype=torch.uint8, device=dev)
+        if merged:
+            _rn.check(L.rn_conv2d_bwd(segs, 1, C.byref(geom), _rn.f32(dw), ws.data_ptr(), ws.numel(), _rn.stream()), "bwd")
+        else:
+            _rn.check(L.rn_conv2d_dgrad(segs, 1, C.byref(geom), None, 0, _rn.stream()), "dgrad")
+            _rn.check(L.rn_conv2d_wgrad(segs, 1, C.byref(geom), _rn.f32(dw), 0, ws.data_ptr(), ws.numel(), _rn.stream()), "wgrad")
+        torch.cuda.synchronize()
+        return dx, dw
+
+    (dx1, dw1), (dx2, dw2) = run(True), run(False)
+    assert float(dx1.abs().max()) > 0 and float(dw1.abs().max()) > 0
+    assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2)
