@@ -149,6 +149,15 @@ size_t rn_conv3x3_winograd_wgrad_workspace(const rn_conv_seg* segs, int nseg, in
 int rn_conv3x3_winograd_wgrad(const rn_conv_seg* segs, int nseg, int cin, int cout, float* dw, int accumulate, int tile,
                               void* workspace, size_t workspace_bytes, const float* v_buf, rn_stream_t stream);
 
+/* The whole backward pass of such a layer -- dx for every segment and dw -- in three launches whose blocks are of two
+ * kinds each: [B^T dy B | A dy A^T], [data-gradient products | weight-gradient partial products],
+ * [output transform -> dx | G^T dU G -> dw].  Same results as rn_conv3x3_winograd(dgrad = 1) followed by
+ * rn_conv3x3_winograd_wgrad.  Segments: x, dy, dx.  v_buf / urot_buf: the buffers a forward call kept (either may be
+ * NULL: then it is rebuilt here; say so in the workspace query). */
+size_t rn_conv3x3_winograd_bwd_workspace(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile, int have_v, int have_urot);
+int rn_conv3x3_winograd_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, float* dw, int accumulate, int tile,
+                            void* workspace, size_t workspace_bytes, const float* v_buf, const float* urot_buf, rn_stream_t stream);
+
 /* ------------------------------------------------------------------ fp16 inference convolution
  * BASELINE configs[4] ("Inference-only ResNeXt-50-FPN 1024x1024 bs=16, fp16"): forward conv on the f16
  * matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate).  Segment fields as rn_conv2d_fwd but x is

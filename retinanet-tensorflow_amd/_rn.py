@@ -72,7 +72,8 @@ SYMBOLS = [
     "rn_conv2d_fwd_workspace", "rn_conv2d_dgrad_workspace",
     "rn_conv2d_fwd", "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad", "rn_conv2d_bwd",
     "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
-    "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes", "rn_defer_reductions", "rn_flush_reductions", "rn_gemm_batched", "rn_resize_bilinear_normalize",
+    "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes",
+    "rn_conv3x3_winograd_bwd_workspace", "rn_conv3x3_winograd_bwd", "rn_defer_reductions", "rn_flush_reductions", "rn_gemm_batched", "rn_resize_bilinear_normalize",
     "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad", "rn_depthwise_bwd",
     "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
@@ -98,7 +99,7 @@ def lib():
                      "rn_loss_workspace", "rn_detect_workspace", "rn_optimizer_workspace",
                      "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace", "rn_conv3x3_winograd_workspace", "rn_conv2d_fwd_workspace",
                      "rn_conv2d_dgrad_workspace",
-                     "rn_conv3x3_winograd_wgrad_workspace"):
+                     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_bwd_workspace"):
             getattr(L, name).restype = C.c_size_t
         L.rn_optimizer_workspace.argtypes = [C.c_int64]
         L.rn_depthwise_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
@@ -124,6 +125,9 @@ def lib():
         L.rn_conv3x3_winograd_wgrad_workspace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.rn_conv3x3_winograd_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.rn_conv3x3_winograd_bwd_workspace.argtypes = [C.c_void_p] + [C.c_int] * 6
+        L.rn_conv3x3_winograd_bwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rn_conv3x3_winograd_keep_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.rn_conv3x3_winograd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]

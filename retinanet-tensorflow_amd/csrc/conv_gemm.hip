@@ -1304,6 +1304,51 @@ extern "C" int rn_conv2d_bwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
   return rn::launch_reduce_rows((const float*)workspace, dw, pw.count, pw.nsplit, 0, st);
 }
 
+// The two batched products of a Winograd backward pass in ONE launch (same trick as rn_conv2d_bwd):
+//   data gradient    Cd_b [M x Nd] = Ad_b [M x Kd] * Bd_b^T          (Bd_b stored [Nd x Kd])
+//   weight gradient  partial sums of Aw_b^T [Kw x M] * Bw_b [M x Nw] (split over M; *nsplit_out slabs
+//                    [nsplit][nbatch][Kw][Nw] are left in `workspace` for the caller's back-transform to add up)
+int rn::launch_winograd_bwd_products(const float* Ad, const float* Bd, float* Cd, int M, int Kd, int Nd, const float* Aw,
+                                     const float* Bw, int Kw, int Nw, int nbatch, void* workspace, size_t workspace_bytes,
+                                     hipStream_t st, int* nsplit_out) {
+  rn_conv_seg sd = {}, sw = {};
+  sd.n = 1; sd.h = 1; sd.w = M; sd.wgt = Bd; sd.dy = Ad; sd.dx = Cd; sd.cout = Kd;
+  rn_conv_geom gd = {1, 1, 1, Nd, 1};
+  const Batch bd = {nbatch, (long)M * Kd, (long)Kd * Nd, (long)M * Nd};
+  sw.n = 1; sw.h = 1; sw.w = M; sw.cout = Nw; sw.x = Aw; sw.dy = Bw;
+  rn_conv_geom gw = {1, 1, 1, Kw, 1};
+  const Batch bw = {nbatch, (long)M * Kw, (long)M * Nw, 0};
+  Planned pd, pw;
+  static const bool enabled = getenv("RN_NO_MERGED_BWD") == nullptr;
+  bool merge = enabled;
+  if (merge) {
+    if (int e = conv_dgrad_impl(&sd, 1, &gd, bd, (rn_stream_t)st, Scratch{nullptr, 0, nullptr}, &pd)) return e;
+    if (int e = conv_wgrad_impl(&sw, 1, &gw, nullptr, 0, workspace, workspace_bytes, bw, (rn_stream_t)st, nsplit_out, &pw)) return e;
+    merge = pd.vec && pw.vec && pd.cfg == 2 && !pd.a.seg[0].par && pd.a.ksplit == 0;
+  }
+  if (!merge) {
+    if (int e = conv_dgrad_impl(&sd, 1, &gd, bd, (rn_stream_t)st)) return e;
+    return conv_wgrad_impl(&sw, 1, &gw, nullptr, 0, workspace, workspace_bytes, bw, (rn_stream_t)st, nsplit_out);
+  }
+  *nsplit_out = pw.nsplit;
+  const ConvArgs4 d4 = compact(pd.a), w4 = compact(pw.a);
+  const dim3 grid((unsigned)(pd.blocks + pw.blocks));
+#define RN_BWD(WBM_, WBN_, WWM_, WWN_)                                                                                          \
+  do {                                                                                                                          \
+    if (pd.tapu) hipLaunchKernelGGL((conv_bwd_kernel<64, 64, 2, 2, true, WBM_, WBN_, WWM_, WWN_>), grid, dim3(256), 0, st, d4, w4, pd.blocks); \
+    else hipLaunchKernelGGL((conv_bwd_kernel<64, 64, 2, 2, false, WBM_, WBN_, WWM_, WWN_>), grid, dim3(256), 0, st, d4, w4, pd.blocks);        \
+  } while (0)
+  switch (pw.cfg) {
+    case 0: RN_BWD(128, 128, 2, 2); break;
+    case 1: RN_BWD(128, 64, 2, 2); break;
+    case 2: RN_BWD(64, 64, 2, 2); break;
+    default: RN_BWD(128, 32, 4, 1); break;
+  }
+#undef RN_BWD
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // bias gradient: column sums of dy over every pixel of every segment (two fixed-order stages)
 // ---------------------------------------------------------------------------------------------

@@ -45,6 +45,10 @@ size_t batched_gemm_tn_workspace(int M, int K, int N, int nbatch);
 // nsplit_out != nullptr: no final reduction; the partial products stay in workspace as [nsplit][nbatch][K][N].
 int launch_batched_gemm_tn(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, void* workspace,
                            size_t workspace_bytes, hipStream_t st, int* nsplit_out = nullptr);
+// data-gradient product + weight-gradient partial products of a Winograd backward pass in one launch
+int launch_winograd_bwd_products(const float* Ad, const float* Bd, float* Cd, int M, int Kd, int Nd, const float* Aw,
+                                 const float* Bw, int Kw, int Nw, int nbatch, void* workspace, size_t workspace_bytes,
+                                 hipStream_t st, int* nsplit_out);
 // true while row reductions on `st` are being recorded for rn_flush_reductions instead of launched
 bool reduce_deferred(hipStream_t st);
 // out[i] = (accumulate ? out[i] : 0) + sum_r in[r][i]  (r = 0..nrows-1, fixed order => reproducible).

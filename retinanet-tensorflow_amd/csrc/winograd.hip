@@ -120,13 +120,13 @@ struct Wino<4> {
 
 // one thread: one tile x W channels
 template <int M, int W>
-__global__ __launch_bounds__(NT) void wino_input_kernel(const WArgs a) {
+__device__ __forceinline__ void wino_input_body(const WArgs& a, int blk, int nblk) {
   typedef typename VecW<W>::type VT;
   constexpr int P = M + 2;
   const int CQ = a.c / W;
   const int64_t total = (int64_t)a.total_tiles * CQ;
   const size_t plane = (size_t)a.total_tiles * a.c;
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+  for (int64_t i = (int64_t)blk * NT + threadIdx.x; i < total; i += (int64_t)nblk * NT) {
     const int q4 = (int)(i % CQ);
     const int t = (int)(i / CQ);
     const WSeg& sg = a.seg[seg_of_tile(a, t)];
@@ -170,13 +170,13 @@ __global__ __launch_bounds__(NT) void wino_input_kernel(const WArgs a) {
 }
 
 template <int M, int W>
-__global__ __launch_bounds__(NT) void wino_output_kernel(const WArgs a) {
+__device__ __forceinline__ void wino_output_body(const WArgs& a, int blk, int nblk) {
   typedef typename VecW<W>::type VT;
   constexpr int P = M + 2;
   const int CQ = a.c / W;
   const int64_t total = (int64_t)a.total_tiles * CQ;
   const size_t plane = (size_t)a.total_tiles * a.c;
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+  for (int64_t i = (int64_t)blk * NT + threadIdx.x; i < total; i += (int64_t)nblk * NT) {
     const int q4 = (int)(i % CQ);
     const int t = (int)(i / CQ);
     const WSeg& sg = a.seg[seg_of_tile(a, t)];
@@ -214,13 +214,13 @@ __global__ __launch_bounds__(NT) void wino_output_kernel(const WArgs a) {
 
 // weight gradient, stage 2: dM [P][T][C] = A dY A^T per m x m output-gradient tile (zeros outside the map)
 template <int M, int W>
-__global__ __launch_bounds__(NT) void wino_dy_kernel(const WArgs a) {
+__device__ __forceinline__ void wino_dy_body(const WArgs& a, int blk, int nblk) {
   typedef typename VecW<W>::type VT;
   constexpr int P = M + 2;
   const int CQ = a.c / W;
   const int64_t total = (int64_t)a.total_tiles * CQ;
   const size_t plane = (size_t)a.total_tiles * a.c;
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+  for (int64_t i = (int64_t)blk * NT + threadIdx.x; i < total; i += (int64_t)nblk * NT) {
     const int q4 = (int)(i % CQ);
     const int t = (int)(i / CQ);
     const WSeg& sg = a.seg[seg_of_tile(a, t)];
@@ -255,12 +255,20 @@ __global__ __launch_bounds__(NT) void wino_dy_kernel(const WArgs a) {
   }
 }
 
+template <int M, int W>
+__global__ __launch_bounds__(NT) void wino_input_kernel(const WArgs a) { wino_input_body<M, W>(a, blockIdx.x, gridDim.x); }
+template <int M, int W>
+__global__ __launch_bounds__(NT) void wino_output_kernel(const WArgs a) { wino_output_body<M, W>(a, blockIdx.x, gridDim.x); }
+template <int M, int W>
+__global__ __launch_bounds__(NT) void wino_dy_kernel(const WArgs a) { wino_dy_body<M, W>(a, blockIdx.x, gridDim.x); }
+
 // weight gradient, stage 4: dw[3][3][k][n] (+)= G^T dU G for dU [P][k][n]
 // du holds `nsplit` partial sums of dU (the split reduction of the batched GEMM), added here in split order.
 template <int M>
-__global__ void wino_dw_kernel(const float* __restrict__ du, float* __restrict__ dw, int64_t kn, int nsplit, int accumulate) {
+__device__ __forceinline__ void wino_dw_body(const float* __restrict__ du, float* __restrict__ dw, int64_t kn, int nsplit,
+                                             int accumulate, int blk) {
   constexpr int P = M + 2;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = (int64_t)blk * NT + threadIdx.x;
   if (i >= kn) return;
   const size_t split_stride = (size_t)P * P * kn;
   float t[P][3];  // t[b][.] = (G^T dU)[., b]
@@ -292,10 +300,10 @@ __global__ void wino_dw_kernel(const float* __restrict__ du, float* __restrict__
 // data-gradient kernel); [k][n] = [cin][cout] either way.
 // u2 != nullptr: also the transform of the rotated kernel (what the data gradient will need) from the same 9 loads.
 template <int M>
-__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, float* __restrict__ u2, int64_t kn,
-                                   int rot) {
+__device__ __forceinline__ void wino_weight_body(const float* __restrict__ w, float* __restrict__ u, float* __restrict__ u2,
+                                                 int64_t kn, int rot, int blk) {
   constexpr int P = M + 2;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = (int64_t)blk * NT + threadIdx.x;
   if (i >= kn) return;
   float g9[3][3];
 #pragma unroll
@@ -324,6 +332,41 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
       for (int b = 0; b < P; ++b) out[(size_t)(a * P + b) * kn + i] = o[b];
     }
   }
+}
+
+template <int M>
+__global__ __launch_bounds__(NT) void wino_dw_kernel(const float* __restrict__ du, float* __restrict__ dw, int64_t kn, int nsplit,
+                                                    int accumulate) {
+  wino_dw_body<M>(du, dw, kn, nsplit, accumulate, blockIdx.x);
+}
+template <int M>
+__global__ __launch_bounds__(NT) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, float* __restrict__ u2,
+                                                        int64_t kn, int rot) {
+  wino_weight_body<M>(w, u, u2, kn, rot, blockIdx.x);
+}
+
+// Independent stages of one layer share a launch (blocks of two kinds) -- every launch saved is ~5 us of a step that
+// is a chain of ~500 short kernels:
+//   forward  : input transform of x            | kernel transform (+ the rotated one kept for backward)
+//   backward : B^T dy B (for the data gradient) | A dy A^T (for the weight gradient)      -- both read dy
+//   backward : output transform -> dx           | G^T dU G -> dw
+struct WeightArgs { const float* w; float* u; float* u2; int64_t kn; int rot; };
+struct DwArgs2 { const float* du; float* dw; int64_t kn; int nsplit, accumulate; };
+
+template <int M, int W>
+__global__ __launch_bounds__(NT) void wino_fwd_pre_kernel(const WArgs in, const WeightArgs wa, int nb_in) {
+  if ((int)blockIdx.x < nb_in) wino_input_body<M, W>(in, blockIdx.x, nb_in);
+  else wino_weight_body<M>(wa.w, wa.u, wa.u2, wa.kn, wa.rot, (int)blockIdx.x - nb_in);
+}
+template <int M, int W>
+__global__ __launch_bounds__(NT) void wino_bwd_pre_kernel(const WArgs dgrad_in, const WArgs wgrad_dy, int nb_first) {
+  if ((int)blockIdx.x < nb_first) wino_input_body<M, W>(dgrad_in, blockIdx.x, nb_first);
+  else wino_dy_body<M, W>(wgrad_dy, (int)blockIdx.x - nb_first, (int)gridDim.x - nb_first);
+}
+template <int M, int W>
+__global__ __launch_bounds__(NT) void wino_bwd_post_kernel(const WArgs out, const DwArgs2 d, int nb_out) {
+  if ((int)blockIdx.x < nb_out) wino_output_body<M, W>(out, blockIdx.x, nb_out);
+  else wino_dw_body<M>(d.du, d.dw, d.kn, d.nsplit, d.accumulate, (int)blockIdx.x - nb_out);
 }
 
 int fill(const rn_conv_seg* segs, int nseg, int cin, int cout, int m, bool dgrad, WArgs* in, WArgs* out,
@@ -391,16 +434,19 @@ int run(const WArgs& ia_, const WArgs& oa_, int cin, int cout, const float* w, c
   WArgs ia = ia_, oa = oa_;
   const int T_ = ia.total_tiles, kc = ia.c, nc = oa.c;
   const int64_t kn = (int64_t)cin * cout;
-  if (dgrad && urot_buf) {
-    U = urot_buf;  // transformed (rotated) kernel kept by the forward call
-  } else {
-    hipLaunchKernelGGL(wino_weight_kernel<M>, dim3((unsigned)rn::ceil_div64(kn, 256)), dim3(256), 0, st, w, U,
-                       dgrad ? nullptr : urot_buf, kn, dgrad ? 1 : 0);
-  }
   if (!dgrad && v_buf) V = v_buf;  // keep the transformed input for the weight gradient
   ia.buf = V;
   const int wi = width_for(T_, kc), wo = width_for(T_, nc);
-  RN_WINO_LAUNCH(wino_input_kernel, wi, (int64_t)T_ * kc, ia);
+  if (dgrad && urot_buf) {
+    U = urot_buf;  // transformed (rotated) kernel kept by the forward call
+    RN_WINO_LAUNCH(wino_input_kernel, wi, (int64_t)T_ * kc, ia);
+  } else {  // kernel transform and input transform: independent, one launch
+    const WeightArgs wa = {w, U, dgrad ? nullptr : urot_buf, kn, dgrad ? 1 : 0};
+    const int nb_in = (int)grid_for((int64_t)T_ * kc / wi), nb_w = (int)rn::ceil_div64(kn, NT);
+    if (wi == 4) hipLaunchKernelGGL((wino_fwd_pre_kernel<M, 4>), dim3(nb_in + nb_w), dim3(NT), 0, st, ia, wa, nb_in);
+    else if (wi == 2) hipLaunchKernelGGL((wino_fwd_pre_kernel<M, 2>), dim3(nb_in + nb_w), dim3(NT), 0, st, ia, wa, nb_in);
+    else hipLaunchKernelGGL((wino_fwd_pre_kernel<M, 1>), dim3(nb_in + nb_w), dim3(NT), 0, st, ia, wa, nb_in);
+  }
   RN_LAUNCH_CHECK();
   // forward: M_xi [T x cout] = V_xi [T x cin] * U_xi [cin x cout];  dgrad: [T x cin] = V_xi [T x cout] * U_xi^T
   if (int e = rn::launch_batched_gemm(V, U, Mb, T_, kc, nc, P2, dgrad ? 1 : 0, st)) return e;
@@ -514,4 +560,99 @@ extern "C" int rn_conv3x3_winograd_keep_bytes(const rn_conv_seg* segs, int nseg,
   *v_bytes = p2 * tiles_of(segs, nseg, tile) * cin * 4;
   *urot_bytes = p2 * cin * cout * 4;
   return RN_OK;
+}
+
+// ---- the whole backward pass of a Winograd layer in three launches (+ the rare two that rebuild what forward did
+// not keep): [B^T dy B | A dy A^T]  ->  [data-gradient products | weight-gradient partial products]  ->
+// [output transform -> dx | G^T dU G -> dw].  Segments: x, dy, dx.  v_buf / urot_buf as for rn_conv3x3_winograd.
+namespace {
+struct BwdLayout { size_t vdy, mdx, dm, v, urot, slab, total; };
+BwdLayout bwd_layout(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile, bool need_v, bool need_urot) {
+  const size_t tiles = tiles_of(segs, nseg, tile), p2 = (size_t)(tile + 2) * (tile + 2);
+  BwdLayout L;
+  size_t off = 0;
+  L.vdy = off; off += rn::align_up(p2 * tiles * cout * 4, 256);
+  L.mdx = off; off += rn::align_up(p2 * tiles * cin * 4, 256);
+  L.dm = off; off += rn::align_up(p2 * tiles * cout * 4, 256);
+  L.v = off; off += need_v ? rn::align_up(p2 * tiles * cin * 4, 256) : 0;
+  L.urot = off; off += need_urot ? rn::align_up(p2 * cin * cout * 4, 256) : 0;
+  L.slab = off; off += rn::batched_gemm_tn_workspace((int)tiles, cin, cout, (int)p2);
+  L.total = off;
+  return L;
+}
+
+template <int M>
+int run_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, float* dw, int accumulate, char* ws,
+            const BwdLayout& L, size_t ws_bytes, const float* v_buf, const float* urot_buf, hipStream_t st) {
+  constexpr int P2 = (M + 2) * (M + 2);
+  WArgs ia = {}, oa = {}, ya = {}, xa = {}, unused = {};
+  if (int e = fill(segs, nseg, cin, cout, M, true, &ia, &oa)) return e;            // dy -> (products) -> dx
+  if (int e = fill(segs, nseg, cin, cout, M, true, &ya, &unused, true)) return e;  // dy, for the weight gradient
+  const int T_ = ia.total_tiles;
+  const int64_t kn = (int64_t)cin * cout;
+  float* Vdy = (float*)(ws + L.vdy);
+  float* Mdx = (float*)(ws + L.mdx);
+  float* dM = (float*)(ws + L.dm);
+  const float* V = v_buf;
+  const float* Urot = urot_buf;
+  if (!Urot) {
+    float* u = (float*)(ws + L.urot);
+    hipLaunchKernelGGL(wino_weight_kernel<M>, dim3((unsigned)rn::ceil_div64(kn, NT)), dim3(NT), 0, st, w, u, (float*)nullptr, kn, 1);
+    Urot = u;
+  }
+  if (!V) {
+    if (int e = fill(segs, nseg, cin, cout, M, false, &xa, &unused, true)) return e;
+    xa.buf = (float*)(ws + L.v);
+    const int wx = width_for(T_, cin);
+    RN_WINO_LAUNCH(wino_input_kernel, wx, (int64_t)T_ * cin, xa);
+    V = xa.buf;
+  }
+  ia.buf = Vdy;
+  ya.buf = dM;
+  const int wy = width_for(T_, cout), wo = width_for(T_, cin);
+  {
+    const int nb = (int)grid_for((int64_t)T_ * cout / wy);
+    if (wy == 4) hipLaunchKernelGGL((wino_bwd_pre_kernel<M, 4>), dim3(2 * nb), dim3(NT), 0, st, ia, ya, nb);
+    else if (wy == 2) hipLaunchKernelGGL((wino_bwd_pre_kernel<M, 2>), dim3(2 * nb), dim3(NT), 0, st, ia, ya, nb);
+    else hipLaunchKernelGGL((wino_bwd_pre_kernel<M, 1>), dim3(2 * nb), dim3(NT), 0, st, ia, ya, nb);
+  }
+  RN_LAUNCH_CHECK();
+  int nsplit = 1;
+  if (int e = rn::launch_winograd_bwd_products(Vdy, Urot, Mdx, T_, cout, cin, V, dM, cin, cout, P2, ws + L.slab, ws_bytes - L.slab, st,
+                                               &nsplit))
+    return e;
+  oa.buf = Mdx;
+  oa.bias = nullptr;
+  {
+    const DwArgs2 d = {(const float*)(ws + L.slab), dw, kn, nsplit, accumulate};
+    const int nb_out = (int)grid_for((int64_t)T_ * cin / wo), nb_dw = (int)rn::ceil_div64(kn, NT);
+    if (wo == 4) hipLaunchKernelGGL((wino_bwd_post_kernel<M, 4>), dim3(nb_out + nb_dw), dim3(NT), 0, st, oa, d, nb_out);
+    else if (wo == 2) hipLaunchKernelGGL((wino_bwd_post_kernel<M, 2>), dim3(nb_out + nb_dw), dim3(NT), 0, st, oa, d, nb_out);
+    else hipLaunchKernelGGL((wino_bwd_post_kernel<M, 1>), dim3(nb_out + nb_dw), dim3(NT), 0, st, oa, d, nb_out);
+  }
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+}  // namespace
+
+extern "C" size_t rn_conv3x3_winograd_bwd_workspace(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile, int have_v,
+                                                    int have_urot) {
+  if (!segs || nseg < 1 || nseg > RN_MAX_SEG || (tile != 2 && tile != 4)) return 0;
+  return bwd_layout(segs, nseg, cin, cout, tile, !have_v, !have_urot).total;
+}
+
+extern "C" int rn_conv3x3_winograd_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, float* dw, int accumulate,
+                                       int tile, void* workspace, size_t workspace_bytes, const float* v_buf, const float* urot_buf,
+                                       rn_stream_t stream) {
+  RN_CHECK_ARG(segs && nseg >= 1 && nseg <= RN_MAX_SEG && (tile == 2 || tile == 4), "winograd bwd: bad segments / tile");
+  RN_CHECK_ARG(w && dw && workspace, "winograd bwd: null pointer");
+  for (int s = 0; s < nseg; ++s) RN_CHECK_ARG(segs[s].x && segs[s].dy && segs[s].dx, "winograd bwd: null tensor in segment %d", s);
+  const BwdLayout L = bwd_layout(segs, nseg, cin, cout, tile, v_buf == nullptr, urot_buf == nullptr);
+  if (workspace_bytes < L.total) {
+    rn::set_error("winograd bwd: workspace %zu < %zu bytes", workspace_bytes, L.total);
+    return RN_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return tile == 2 ? run_bwd<2>(segs, nseg, cin, cout, w, dw, accumulate, (char*)workspace, L, workspace_bytes, v_buf, urot_buf, st)
+                   : run_bwd<4>(segs, nseg, cin, cout, w, dw, accumulate, (char*)workspace, L, workspace_bytes, v_buf, urot_buf, st);
 }

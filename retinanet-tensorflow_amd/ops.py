@@ -251,6 +251,25 @@ class _Conv2dShared(torch.autograd.Function):
         need_dx = [ctx.needs_input_grad[3 + i] for i in range(n)]
         dxs = [None] * n
         want_dw0 = ctx.needs_input_grad[1]
+        if all(need_dx) and want_dw0 and ctx.winograd and WINOGRAD_WGRAD and not WGRAD_SIDE_STREAM and MERGED_CONV_BWD:
+            # the whole backward pass of a Winograd layer in three launches (transforms, products, back-transforms)
+            outs = [torch.empty_like(x) for x in xs]
+            segs = _conv_segs(xs, w, None, None, dys, outs)
+            dw_buf, dw = _grad_slot(w)
+            have_v, have_u = ctx.wino_v is not None, ctx.wino_urot is not None
+            need = L.rn_conv3x3_winograd_bwd_workspace(segs, n, cin, cout, WINOGRAD_TILE, 1 if have_v else 0, 1 if have_u else 0)
+            ws = _rn.workspace(need, w.device)
+            _rn.check(L.rn_conv3x3_winograd_bwd(segs, n, cin, cout, _rn.f32(w), _rn.f32(dw_buf), 0, WINOGRAD_TILE, ws.data_ptr(),
+                                                ws.numel(), _rn.f32(ctx.wino_v) if have_v else None,
+                                                _rn.f32(ctx.wino_urot) if have_u else None, _rn.stream()), "rn_conv3x3_winograd_bwd")
+            db = None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db_buf, db = _grad_slot(bias)
+                need = L.rn_conv2d_bias_grad_workspace(cout)
+                ws = _grad_workspace(need, w.device)
+                _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws.data_ptr(), ws.numel(), _rn.stream()),
+                          "rn_conv2d_bias_grad")
+            return (None, dw, db) + tuple(outs)
         if (all(need_dx) and want_dw0 and not ctx.winograd and not WGRAD_SIDE_STREAM and n <= 4 and MERGED_CONV_BWD):
             # both gradients from one launch (small convs are launch-latency-bound); not when dgrad would take split-K
             outs = [torch.empty_like(x) for x in xs]

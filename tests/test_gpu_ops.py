@@ -895,3 +895,59 @@ def test_merged_conv_backward_equals_separate_calls(dev, case):
     (dx1, dw1), (dx2, dw2) = run(True), run(False)
     assert float(dx1.abs().max()) > 0 and float(dw1.abs().max()) > 0
     assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2)
+
+
+@pytest.mark.parametrize("tile", [4, 2])
+@pytest.mark.parametrize("keep", [True, False])
+def test_winograd_merged_backward_equals_separate_calls(dev, tile, keep):
+    """rn_conv3x3_winograd_bwd (three launches of two-kind blocks) == rn_conv3x3_winograd(dgrad) + rn_conv3x3_winograd_wgrad,
+    bit for bit, with and without the buffers a forward call keeps; five pyramid levels in one call."""
+    import ctypes as C
+    import _rn
+    import ops
+    g = torch.Generator(device=dev).manual_seed(tile + keep)
+    cin, cout = 64, 128
+    sizes = [(12, 12), (6, 6), (3, 3), (2, 2), (1, 1)]
+    xs = [torch.randn((2, h, w, cin), generator=g, device=dev) for h, w in sizes]
+    dys = [torch.randn((2, h, w, cout), generator=g, device=dev) for h, w in sizes]
+    wt = torch.randn((3, 3, cin, cout), generator=g, device=dev) * 0.05
+    L = _rn.lib()
+    n = len(xs)
+    v = u = None
+    if keep:   # what a training-mode forward call leaves behind
+        ys = [torch.empty((2, h, w, cout), device=dev) for h, w in sizes]
+        fs = ops._conv_segs(xs, wt, None, ys, None, None)
+        vb, ub = C.c_size_t(0), C.c_size_t(0)
+        _rn.check(L.rn_conv3x3_winograd_keep_bytes(fs, n, cin, cout, tile, C.byref(vb), C.byref(ub)), "keep")
+        v = torch.empty(vb.value // 4, device=dev)
+        u = torch.empty(ub.value // 4, device=dev)
+        ws = torch.empty(L.rn_conv3x3_winograd_workspace(fs, n, cin, cout, tile), dtype=torch.uint8, device=dev)
+        _rn.check(L.rn_conv3x3_winograd(fs, n, cin, cout, _rn.f32(wt), None, 0, tile, ws.data_ptr(), ws.numel(), _rn.f32(v),
+                                        _rn.f32(u), _rn.stream()), "fwd")
+
+    def separate():
+        dxs, dw = [torch.empty_like(x) for x in xs], torch.empty_like(wt)
+        segs = ops._conv_segs(xs, wt, None, None, dys, dxs)
+        ws = torch.empty(L.rn_conv3x3_winograd_workspace(segs, n, cin, cout, tile), dtype=torch.uint8, device=dev)
+        _rn.check(L.rn_conv3x3_winograd(segs, n, cin, cout, _rn.f32(wt), None, 1, tile, ws.data_ptr(), ws.numel(), None,
+                                        _rn.f32(u) if keep else None, _rn.stream()), "dgrad")
+        ws = torch.empty(L.rn_conv3x3_winograd_wgrad_workspace(segs, n, cin, cout, tile), dtype=torch.uint8, device=dev)
+        _rn.check(L.rn_conv3x3_winograd_wgrad(segs, n, cin, cout, _rn.f32(dw), 0, tile, ws.data_ptr(), ws.numel(),
+                                              _rn.f32(v) if keep else None, _rn.stream()), "wgrad")
+        return dxs, dw
+
+    def merged():
+        dxs, dw = [torch.empty_like(x) for x in xs], torch.empty_like(wt)
+        segs = ops._conv_segs(xs, wt, None, None, dys, dxs)
+        need = L.rn_conv3x3_winograd_bwd_workspace(segs, n, cin, cout, tile, 1 if keep else 0, 1 if keep else 0)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _rn.check(L.rn_conv3x3_winograd_bwd(segs, n, cin, cout, _rn.f32(wt), _rn.f32(dw), 0, tile, ws.data_ptr(), ws.numel(),
+                                            _rn.f32(v) if keep else None, _rn.f32(u) if keep else None, _rn.stream()), "bwd")
+        return dxs, dw
+
+    (dx1, dw1), (dx2, dw2) = separate(), merged()
+    torch.cuda.synchronize()
+    assert float(dw1.abs().max()) > 0
+    for a, b in zip(dx1, dx2):
+        assert torch.equal(a, b)
+    assert torch.equal(dw1, dw2)
