@@ -315,6 +315,19 @@ int rn_anchor_assign(const float* boxes, const int32_t* class_ids, const int32_t
                      const float* anchor_sizes, int num_anchors, int grid_h, int grid_w, int num_classes,
                      float* cls_out, float* reg_out, uint8_t* trainable_out, int32_t* argmax_out,
                      rn_stream_t stream);
+/* build_labels (dataset.py:126-142): the same for every pyramid level of the batch in one launch. */
+#define RN_MAX_LEVELS 8
+typedef struct rn_assign_level {
+  const float* anchor_sizes; /* [A,2] of this level, normalised */
+  int grid_h, grid_w;
+  float* cls_out;            /* [nimg, grid_h, grid_w, A, C] */
+  float* reg_out;            /* [nimg, grid_h, grid_w, A, 4] */
+  uint8_t* trainable_out;    /* [nimg, grid_h, grid_w, A] */
+  int32_t* argmax_out;       /* optional (NULL): index of the matched object */
+} rn_assign_level;
+int rn_anchor_assign_levels(const float* boxes, const int32_t* class_ids, const int32_t* num_obj, int nimg, int max_obj,
+                            const rn_assign_level* levels, int nlevel, int num_anchors, int num_classes,
+                            rn_stream_t stream);
 
 /* ------------------------------------------------------------------ decode + NMS
  * rn_decode_boxes: utils.regression_postprocess (utils.py:108-117): exp, anchor scale, add

@@ -32,6 +32,11 @@ class ConvSeg(C.Structure):
                 ("x_ld", C.c_int32), ("x_coff", C.c_int32)]
 
 
+class AssignLevel(C.Structure):
+    _fields_ = [("anchor_sizes", C.c_void_p), ("grid_h", C.c_int32), ("grid_w", C.c_int32), ("cls_out", C.c_void_p),
+                ("reg_out", C.c_void_p), ("trainable_out", C.c_void_p), ("argmax_out", C.c_void_p)]
+
+
 class ConvGeom(C.Structure):
     _fields_ = [("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("cin", C.c_int32),
                 ("groups", C.c_int32)]
@@ -80,7 +85,7 @@ SYMBOLS = [
     "rn_pack_weights_f16", "rn_cast_f32_to_f16", "rn_pad_cast_rgb_f16", "rn_conv2d_fwd_f16", "rn_maxpool_fwd_f16", "rn_upsample_add_fwd_f16",
     "rn_act_fwd_f16", "rn_flip_width", "rn_dropout", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_maxpool_bwd_arg", "rn_avgpool_fwd", "rn_avgpool_bwd",
     "rn_loss_workspace", "rn_loss_fwd", "rn_loss_bwd",
-    "rn_anchor_assign", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
+    "rn_anchor_assign", "rn_anchor_assign_levels", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
     "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
     "rn_optimizer_workspace", "rn_grad_norm_l2reg", "rn_optimizer_step",
 ]
@@ -163,6 +168,8 @@ def lib():
                                   C.c_void_p]
         L.rn_anchor_assign.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 4 + \
                                       [C.c_void_p] * 4 + [C.c_void_p]
+        L.rn_anchor_assign_levels.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p]
         L.rn_decode_boxes.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
         L.rn_detect_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_detect.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 6 + [C.c_void_p, C.c_size_t,

@@ -11,11 +11,16 @@
 namespace {
 constexpr int T = 256;
 
+struct LevelArgs {
+  const float* anchor_sizes; int H, W;
+  float* cls_out; float* reg_out; uint8_t* tr_out; int32_t* arg_out;
+  int64_t iter0;  // first 64-anchor wave iteration of this level (levels laid end to end)
+};
 struct AssignArgs {
   const float* boxes; const int32_t* class_ids; const int32_t* num_obj;
-  int nimg, max_obj;
-  const float* anchor_sizes; int A, H, W, C;
-  float* cls_out; float* reg_out; uint8_t* tr_out; int32_t* arg_out;
+  int nimg, max_obj, A, C, nlevel;
+  int64_t iters;  // wave iterations of all levels
+  LevelArgs lv[RN_MAX_LEVELS];
 };
 
 // cell centre i of `size` cells: tf.linspace(cell/2, 1-cell/2, size)[i] in float32
@@ -32,12 +37,15 @@ __device__ __forceinline__ float cell_center(int i, int size) {
 
 __global__ __launch_bounds__(T) void assign_kernel(const AssignArgs a) {
   const int lane = threadIdx.x & 63;
-  const int64_t per_img = (int64_t)a.H * a.W * a.A;
-  const int64_t total = per_img * a.nimg;
-  const int64_t nwave_iters = (total + 63) / 64;
   const int64_t wave0 = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * T) >> 6;
-  for (int64_t wi = wave0; wi < nwave_iters; wi += nwaves) {
+  for (int64_t gi = wave0; gi < a.iters; gi += nwaves) {
+    int l = 0;  // the pyramid level this wave iteration belongs to (wave-uniform)
+    while (l + 1 < a.nlevel && gi >= a.lv[l + 1].iter0) ++l;
+    const LevelArgs& L = a.lv[l];
+    const int64_t wi = gi - L.iter0;
+    const int64_t per_img = (int64_t)L.H * L.W * a.A;
+    const int64_t total = per_img * a.nimg;
     const int64_t r = wi * 64 + lane;
     const bool active = r < total;
     int cls = -1;
@@ -46,10 +54,10 @@ __global__ __launch_bounds__(T) void assign_kernel(const AssignArgs a) {
       const int img = (int)(r / per_img);
       int64_t q = r - (int64_t)img * per_img;
       const int an = (int)(q % a.A); q /= a.A;
-      const int x_ = (int)(q % a.W);
-      const int y_ = (int)(q / a.W);
-      const float ay = cell_center(y_, a.H), ax = cell_center(x_, a.W);
-      const float ah = a.anchor_sizes[an * 2], aw = a.anchor_sizes[an * 2 + 1];
+      const int x_ = (int)(q % L.W);
+      const int y_ = (int)(q / L.W);
+      const float ay = cell_center(y_, L.H), ax = cell_center(x_, L.W);
+      const float ah = L.anchor_sizes[an * 2], aw = L.anchor_sizes[an * 2 + 1];
       // from_center_box(anchor) (dataset.py:35-39)
       const float hh = ah / 2.0f, hw = aw / 2.0f;
       const float a0 = ay - hh, a1 = ax - hw, a2 = ay + hh, a3 = ax + hw;
@@ -86,9 +94,9 @@ __global__ __launch_bounds__(T) void assign_kernel(const AssignArgs a) {
       rg.y = (bcx - ax) / aw;
       rg.z = logf(bsh / ah);
       rg.w = logf(bsw / aw);
-      *reinterpret_cast<float4*>(a.reg_out + (size_t)r * 4) = rg;
-      a.tr_out[r] = trainable ? 1 : 0;
-      if (a.arg_out) a.arg_out[r] = best_i;
+      *reinterpret_cast<float4*>(L.reg_out + (size_t)r * 4) = rg;
+      L.tr_out[r] = trainable ? 1 : 0;
+      if (L.arg_out) L.arg_out[r] = best_i;
     }
     const int hot = (active && !bg && cls >= 0 && cls < a.C) ? cls : -1;
     // cooperative one-hot rows
@@ -96,27 +104,42 @@ __global__ __launch_bounds__(T) void assign_kernel(const AssignArgs a) {
     const int nrow = (int)((total - rbase) < 64 ? (total - rbase) : 64);
     for (int i = 0; i < nrow; ++i) {
       const int h = __shfl(hot, i, 64);
-      float* row = a.cls_out + (size_t)(rbase + i) * a.C;
+      float* row = L.cls_out + (size_t)(rbase + i) * a.C;
       for (int c = lane; c < a.C; c += 64) row[c] = (c == h) ? 1.f : 0.f;
     }
   }
 }
 }  // namespace
 
-extern "C" int rn_anchor_assign(const float* boxes, const int32_t* class_ids, const int32_t* num_obj, int nimg,
-                                int max_obj, const float* anchor_sizes, int num_anchors, int grid_h, int grid_w,
-                                int num_classes, float* cls_out, float* reg_out, uint8_t* trainable_out,
-                                int32_t* argmax_out, rn_stream_t stream) {
-  RN_CHECK_ARG(boxes && class_ids && num_obj && anchor_sizes && cls_out && reg_out && trainable_out,
-               "anchor_assign: null pointer");
-  RN_CHECK_ARG(nimg >= 1 && max_obj >= 1 && num_anchors >= 1 && grid_h >= 1 && grid_w >= 1 && num_classes >= 1,
-               "anchor_assign: bad shape");
-  AssignArgs a = {boxes, class_ids, num_obj, nimg, max_obj, anchor_sizes, num_anchors, grid_h, grid_w, num_classes,
-                  cls_out, reg_out, trainable_out, argmax_out};
-  const int64_t total = (int64_t)nimg * grid_h * grid_w * num_anchors;
-  int64_t blocks = (total + T - 1) / T;
+extern "C" int rn_anchor_assign_levels(const float* boxes, const int32_t* class_ids, const int32_t* num_obj, int nimg,
+                                       int max_obj, const rn_assign_level* levels, int nlevel, int num_anchors,
+                                       int num_classes, rn_stream_t stream) {
+  RN_CHECK_ARG(boxes && class_ids && num_obj && levels, "anchor_assign: null pointer");
+  RN_CHECK_ARG(nlevel >= 1 && nlevel <= RN_MAX_LEVELS, "anchor_assign: 1..%d levels", RN_MAX_LEVELS);
+  RN_CHECK_ARG(nimg >= 1 && max_obj >= 1 && num_anchors >= 1 && num_classes >= 1, "anchor_assign: bad shape");
+  AssignArgs a = {};
+  a.boxes = boxes; a.class_ids = class_ids; a.num_obj = num_obj;
+  a.nimg = nimg; a.max_obj = max_obj; a.A = num_anchors; a.C = num_classes; a.nlevel = nlevel;
+  int64_t iters = 0;
+  for (int l = 0; l < nlevel; ++l) {
+    const rn_assign_level& v = levels[l];
+    RN_CHECK_ARG(v.anchor_sizes && v.cls_out && v.reg_out && v.trainable_out, "anchor_assign: null pointer (level %d)", l);
+    RN_CHECK_ARG(v.grid_h >= 1 && v.grid_w >= 1, "anchor_assign: bad grid (level %d)", l);
+    a.lv[l] = {v.anchor_sizes, v.grid_h, v.grid_w, v.cls_out, v.reg_out, v.trainable_out, v.argmax_out, iters};
+    iters += ((int64_t)nimg * v.grid_h * v.grid_w * num_anchors + 63) / 64;
+  }
+  a.iters = iters;
+  int64_t blocks = (iters * 64 + T - 1) / T;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(assign_kernel, dim3((unsigned)blocks), dim3(T), 0, (hipStream_t)stream, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
+}
+
+extern "C" int rn_anchor_assign(const float* boxes, const int32_t* class_ids, const int32_t* num_obj, int nimg,
+                                int max_obj, const float* anchor_sizes, int num_anchors, int grid_h, int grid_w,
+                                int num_classes, float* cls_out, float* reg_out, uint8_t* trainable_out,
+                                int32_t* argmax_out, rn_stream_t stream) {
+  const rn_assign_level one = {anchor_sizes, grid_h, grid_w, cls_out, reg_out, trainable_out, argmax_out};
+  return rn_anchor_assign_levels(boxes, class_ids, num_obj, nimg, max_obj, &one, 1, num_anchors, num_classes, stream);
 }

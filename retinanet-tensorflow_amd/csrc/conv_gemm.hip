@@ -639,7 +639,24 @@ __device__ __forceinline__ void reduce_rows_block(const float* __restrict__ in, 
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < count) {
     const bool full = (i + 4 <= count) && ((count & 3) == 0);
-    for (int r = rl; r < nrows; r += 16) {
+    int r = rl;
+    if (full) {  // four rows in flight per lane (the loop is latency-bound: one 16-B load per row)
+      float4 v1 = v, v2 = v, v3 = v;
+      for (; r + 48 < nrows; r += 64) {
+        const float* p = in + (size_t)r * count + i;
+        const float4 t0 = *reinterpret_cast<const float4*>(p);
+        const float4 t1 = *reinterpret_cast<const float4*>(p + (size_t)16 * count);
+        const float4 t2 = *reinterpret_cast<const float4*>(p + (size_t)32 * count);
+        const float4 t3 = *reinterpret_cast<const float4*>(p + (size_t)48 * count);
+        v.x += t0.x; v.y += t0.y; v.z += t0.z; v.w += t0.w;
+        v1.x += t1.x; v1.y += t1.y; v1.z += t1.z; v1.w += t1.w;
+        v2.x += t2.x; v2.y += t2.y; v2.z += t2.z; v2.w += t2.w;
+        v3.x += t3.x; v3.y += t3.y; v3.z += t3.z; v3.w += t3.w;
+      }
+      v.x = (v.x + v1.x) + (v2.x + v3.x); v.y = (v.y + v1.y) + (v2.y + v3.y);
+      v.z = (v.z + v1.z) + (v2.z + v3.z); v.w = (v.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; r < nrows; r += 16) {
       const float* p = in + (size_t)r * count + i;
       if (full) {
         const float4 t = *reinterpret_cast<const float4*>(p);
@@ -1353,7 +1370,7 @@ int rn::launch_winograd_bwd_products(const float* Ad, const float* Bd, float* Cd
 // bias gradient: column sums of dy over every pixel of every segment (two fixed-order stages)
 // ---------------------------------------------------------------------------------------------
 namespace {
-constexpr int BG_BLOCKS = 256;
+constexpr int BG_BLOCKS = 1024;  // ~10 rows per block for the 10912-row head gradient: the row loop is latency-bound
 struct BiasArgs {
   const float* dy[RN_MAX_SEG];
   int rows[RN_MAX_SEG];
@@ -1368,7 +1385,15 @@ __global__ __launch_bounds__(256) void bias_partial_kernel(const BiasArgs a) {
     if (c < a.cout) {
       for (int s = 0; s < a.nseg; ++s) {
         const float* p = a.dy[s];
-        for (int r = blockIdx.x; r < a.rows[s]; r += gridDim.x) acc += p[(size_t)r * a.cout + c];
+        const int rows = a.rows[s], g = gridDim.x;
+        int r = blockIdx.x;
+        float acc1 = 0.f;
+        for (; r + g < rows; r += 2 * g) {  // two independent loads in flight
+          acc += p[(size_t)r * a.cout + c];
+          acc1 += p[(size_t)(r + g) * a.cout + c];
+        }
+        if (r < rows) acc += p[(size_t)r * a.cout + c];
+        acc += acc1;
       }
       a.partial[(size_t)blockIdx.x * a.cout + c] = acc;
     }

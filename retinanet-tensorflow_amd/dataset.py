@@ -50,11 +50,33 @@ def level_labels(image_size, class_id, true_box, level, factor, num_classes, num
 
 
 def build_labels(image_size, class_ids, boxes, levels, num_classes, num_obj=None):
-    labels = {pn: level_labels(image_size, class_ids, boxes, level=levels[pn], factor=2 ** int(pn[-1]),
-                               num_classes=num_classes, num_obj=num_obj) for pn in levels}
-    classifications = {pn: labels[pn][0] for pn in labels}
-    regressions = {pn: labels[pn][1] for pn in labels}
-    trainable_masks = {pn: labels[pn][2] for pn in labels}
+    """dataset.py:126-142 for a batch: every level's maps from one launch (rn_anchor_assign_levels); the per-level
+    results are the ones `level_labels` gives."""
+    dev = boxes.device
+    n, o = boxes.shape[0], boxes.shape[1]
+    boxes = boxes.contiguous().float()
+    class_ids = class_ids.to(torch.int32).contiguous()
+    if num_obj is None:
+        num_obj = torch.full((n,), o, dtype=torch.int32, device=dev)
+    num_obj = num_obj.to(torch.int32).contiguous()
+    names = list(levels)
+    lv = (_rn.AssignLevel * len(names))()
+    classifications, regressions, trainable_masks, keep = {}, {}, {}, []
+    a = None
+    for i, pn in enumerate(names):
+        factor = 2 ** int(pn[-1])
+        anchors = utils._anchor_tensor(levels[pn].normalized_anchor_sizes(image_size, ANCHOR_SIZE_MODE), dev)
+        assert a in (None, anchors.shape[0]), "every level carries the same number of anchors (levels.py:32-44)"
+        a = anchors.shape[0]
+        gh, gw = int(math.ceil(image_size[0] / factor)), int(math.ceil(image_size[1] / factor))
+        classifications[pn] = torch.empty((n, gh, gw, a, num_classes), dtype=torch.float32, device=dev)
+        regressions[pn] = torch.empty((n, gh, gw, a, 4), dtype=torch.float32, device=dev)
+        trainable_masks[pn] = torch.empty((n, gh, gw, a), dtype=torch.uint8, device=dev)
+        keep.append(anchors)
+        lv[i] = _rn.AssignLevel(anchors.data_ptr(), gh, gw, classifications[pn].data_ptr(), regressions[pn].data_ptr(),
+                                trainable_masks[pn].data_ptr(), None)
+    _rn.check(_rn.lib().rn_anchor_assign_levels(_rn.f32(boxes), _rn.ptr(class_ids), _rn.ptr(num_obj), n, o, lv, len(names),
+                                                a, num_classes, _rn.stream()), 'rn_anchor_assign_levels')
     return classifications, regressions, trainable_masks
 
 

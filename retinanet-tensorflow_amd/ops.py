@@ -220,9 +220,10 @@ class _Conv2dShared(torch.autograd.Function):
         ctx.winograd = _winograd_ok(w, stride, groups, xs)
         ctx.wino_v = ctx.wino_urot = None
         if ctx.winograd:
-            if torch.is_grad_enabled():
+            # (grad mode is always off inside Function.forward: ctx.needs_input_grad is what says "training")
+            if any(ctx.needs_input_grad):
                 ctx.wino_v, ctx.wino_urot = _winograd_keep_buffers(
-                    segs, len(xs), w, w.requires_grad and WINOGRAD_WGRAD, any(x.requires_grad for x in xs))
+                    segs, len(xs), w, ctx.needs_input_grad[1] and WINOGRAD_WGRAD, any(ctx.needs_input_grad[3:]))
             _winograd(segs, len(xs), w, bias, False, ctx.wino_v, ctx.wino_urot)
         else:
             _conv_fwd(segs, len(xs), geom, xs[0].device)

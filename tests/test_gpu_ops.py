@@ -323,6 +323,13 @@ def test_anchor_assignment_bit_exact(dev, mode):
                 assert np.array_equal(msk[i].cpu().numpy().astype(bool), om), pn
                 assert np.array_equal(cls[i].cpu().numpy(), oc), pn
                 assert_close(reg[i].cpu().numpy(), orr, TOL, "regression targets " + pn)
+        # build_labels fills every level from ONE launch (rn_anchor_assign_levels): same bits as the per-level calls
+        ac, ar, am = dataset.build_labels(size, _t(cids, dev), _t(boxes, dev), lv, c, num_obj=_t(nobj, dev))
+        assert list(ac.keys()) == list(lv)
+        for pn in lv:
+            cls, reg, msk = dataset.level_labels(size, _t(cids, dev), _t(boxes, dev), lv[pn], 2 ** int(pn[-1]), c,
+                                                 num_obj=_t(nobj, dev))
+            assert torch.equal(ac[pn], cls) and torch.equal(ar[pn], reg) and torch.equal(am[pn], msk), pn
     finally:
         dataset.ANCHOR_SIZE_MODE = "trunc_int"
 
@@ -951,3 +958,35 @@ def test_winograd_merged_backward_equals_separate_calls(dev, tile, keep):
     for a, b in zip(dx1, dx2):
         assert torch.equal(a, b)
     assert torch.equal(dw1, dw2)
+
+
+def test_winograd_forward_keeps_buffers_only_when_training(dev):
+    """A training-mode conv2d on the Winograd path leaves the transformed input / rotated kernel on its backward node
+    (so the backward pass skips both transforms); under no_grad nothing is kept; gradients agree to rounding either way."""
+    import ops
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn((2, 10, 10, 64), generator=g, device=dev, requires_grad=True)
+    w = (torch.randn((3, 3, 64, 64), generator=g, device=dev) * 0.05).requires_grad_(True)
+    assert ops.WINOGRAD and ops.WINOGRAD_KEEP
+    y = ops.conv2d(x, w, None, 1)
+    assert y.grad_fn.wino_v is not None and y.grad_fn.wino_urot is not None
+    dy = torch.randn(y.shape, generator=g, device=dev)
+    dx1, dw1 = torch.autograd.grad(y, (x, w), dy)
+    ops.WINOGRAD_KEEP = False
+    try:
+        y2 = ops.conv2d(x, w, None, 1)
+        assert y2.grad_fn.wino_v is None and y2.grad_fn.wino_urot is None
+        dx2, dw2 = torch.autograd.grad(y2, (x, w), dy)
+    finally:
+        ops.WINOGRAD_KEEP = True
+    assert torch.equal(y, y2)
+    for name, p_, q_ in (("dx", dx1, dx2), ("dw", dw1, dw2)):
+        print(name, "kept vs recomputed: max abs diff", float((p_ - q_).abs().max()), "of", float(q_.abs().max()))
+        # the kept rotated kernel comes out of the forward's two-output transform, the recomputed one out of the stand-alone
+        # kernel: same formula, different fma contraction => a few ulp (observed 2e-6 of the range)
+        assert_close(p_.cpu().numpy(), q_.cpu().numpy(), 1e-5, name + " kept vs recomputed transforms")
+    xf = x.detach().requires_grad_(True)
+    y3 = ops.conv2d(xf, w.detach(), None, 1)      # only the data gradient is wanted: no transformed input kept
+    assert y3.grad_fn.wino_v is None and y3.grad_fn.wino_urot is not None
+    with torch.no_grad():
+        assert torch.equal(ops.conv2d(x, w, None, 1), y)
