@@ -214,11 +214,13 @@ typedef struct rn_gn_params {
   uint64_t drop_seed; /* counter-based mask: keep iff hash(seed, elem) >= rate            */
   const uint64_t* drop_seed_dev; /* optional DEVICE counter added to drop_seed (so a replayed
                                     hipGraph draws a fresh mask every step); may be NULL    */
-  void* sync; /* optional: 4 zero-initialised DEVICE uint32 owned by the caller, private to the stream; enables the
-                 single-kernel path for mid-sized maps (<= 128 blocks meet at a bounded in-kernel barrier).  The
-                 kernels leave words 0-1 at zero; word 2 becomes 1 if a barrier ever timed out.  NULL = not used. */
+  void* sync; /* optional: rn_group_norm_sync_bytes() zero-initialised DEVICE bytes owned by the caller, private to the
+                 stream, written by these kernels only; enables the single-kernel path for mid-sized maps (<= 128 blocks
+                 exchange tagged per-group sums through it, bounded polling).  Word 0 is left at zero, word 1 counts the
+                 calls, word 2 becomes 1 if a wait ever timed out.  NULL = not used. */
 } rn_gn_params;
 
+size_t rn_group_norm_sync_bytes(void);
 size_t rn_group_norm_workspace(const rn_gn_seg* segs, int nseg, const rn_gn_params* p);
 int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, const float* gamma,
                       const float* beta, void* workspace, size_t workspace_bytes, rn_stream_t stream);

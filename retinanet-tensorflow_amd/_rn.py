@@ -80,7 +80,7 @@ SYMBOLS = [
     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes",
     "rn_conv3x3_winograd_bwd_workspace", "rn_conv3x3_winograd_bwd", "rn_defer_reductions", "rn_flush_reductions", "rn_gemm_batched", "rn_resize_bilinear_normalize",
     "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad", "rn_depthwise_bwd",
-    "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
+    "rn_group_norm_sync_bytes", "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
     "rn_pack_weights_f16", "rn_cast_f32_to_f16", "rn_pad_cast_rgb_f16", "rn_conv2d_fwd_f16", "rn_maxpool_fwd_f16", "rn_upsample_add_fwd_f16",
     "rn_act_fwd_f16", "rn_flip_width", "rn_dropout", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_maxpool_bwd_arg", "rn_avgpool_fwd", "rn_avgpool_bwd",
@@ -100,7 +100,8 @@ def lib():
                           "`make -C retinanet-tensorflow_amd/csrc` (there is no fallback path)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         L.rn_last_error.restype = C.c_char_p
-        for name in ("rn_conv2d_wgrad_workspace", "rn_depthwise_wgrad_workspace", "rn_group_norm_workspace",
+        L.rn_group_norm_sync_bytes.argtypes = []
+        for name in ("rn_conv2d_wgrad_workspace", "rn_depthwise_wgrad_workspace", "rn_group_norm_workspace", "rn_group_norm_sync_bytes",
                      "rn_loss_workspace", "rn_detect_workspace", "rn_optimizer_workspace",
                      "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace", "rn_conv3x3_winograd_workspace", "rn_conv2d_fwd_workspace",
                      "rn_conv2d_dgrad_workspace",
@@ -241,12 +242,12 @@ _sync_words = {}
 
 
 def sync_counters(device):
-    """Four zeroed uint32 words per (device, current stream) for rn_gn_params.sync: the in-kernel barrier of the
-    grid-resident GroupNorm path.  The kernels leave them at zero; word 2 is set if a barrier ever timed out."""
+    """The zeroed region (rn_group_norm_sync_bytes()) per (device, current stream) for rn_gn_params.sync: counters and
+    exchange rows of the grid-resident GroupNorm path.  Word 2 is set if a wait ever timed out."""
     key = (device.type, device.index, stream().value)
     t = _sync_words.get(key)
     if t is None:
-        t = torch.zeros(4, dtype=torch.int32, device=device)
+        t = torch.zeros(lib().rn_group_norm_sync_bytes() // 4, dtype=torch.int32, device=device)
         _sync_words[key] = t
     return t
 

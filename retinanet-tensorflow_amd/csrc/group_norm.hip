@@ -35,8 +35,8 @@ struct GnArgs {
   float* coef;     // bwd: [samples][groups][2]
   float* dgamma; float* dbeta;
   int total_chunks, total_samples;
-  float* gpart;    // grid-resident path: [total_chunks][groups][2] per-block group sums
-  unsigned* sync;  // grid-resident path: two zero-initialised counters (+ an error word), left at zero
+  unsigned long long* xchg;  // grid-resident path: [total_chunks][groups][2] tagged per-block group sums (inside the sync region)
+  unsigned* sync;            // grid-resident path: leave counter, call counter, error word (caller-owned, zero-initialised)
   int coop_ppc, coop_r;  // grid-resident path: pixels per block, float4 values per thread
   int slice_wc;    // slice-resident path: channels per block (a whole number of groups), 0 = not used
   float* pgrad;    // slice-resident bwd: [2][total_samples][c] per-sample sum g (plane 0) and sum g*xhat (plane 1)
@@ -582,49 +582,42 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(const GnArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Grid-resident path: maps too large for one block per slice but small enough for the registers of <= 128 co-resident
 // blocks (<= 4 M elements: the head towers over P3..P7, the backbone at 1/8 resolution) are ONE kernel as well: every
-// block loads its pixel range (all channels, full 16-byte coalesced rows) into registers, writes per-channel partial
-// sums, meets the other blocks at a grid barrier, derives its sample's statistics from the partial rows and applies
-// them to the registers -- x (and dy) are read once, y (dx) written once, instead of partial + finalize + apply with
-// a second read.  Co-residency: <= 128 blocks of 512 threads, one per CU; two such kernels (the two head streams)
-// still fit the 256 CUs together, nothing else in the step spins.  The barrier is bounded: if the blocks are not all
-// resident within ~10^6 polls it gives up (error word set, results of that call undefined) instead of hanging.
+// block loads its pixel range (all channels, full 16-byte coalesced rows) into registers, publishes its per-group
+// partial sums, collects the sums of the other blocks of its sample, derives the statistics and applies them to the
+// registers -- x (and dy) are read once, y (dx) written once, instead of partial + finalize + apply with a second
+// read.  Co-residency: <= 128 blocks of 512 threads, one per CU; two such kernels (the two head streams) still fit the
+// 256 CUs together, nothing else in the step spins.  The wait is bounded: if a sample's blocks are not all resident
+// within ~10^6 polls it gives up (error word set, results of that call undefined) instead of hanging.
 // ---------------------------------------------------------------------------------------------
 constexpr int CT = 512, COOP_MAX_R = 16, COOP_MAX_BLOCKS = 128, COOP_MAX_C = 1024;
 
-// The only data exchanged across the barrier are the per-block group sums: they are written with device-scope
-// (write-through, sc1) stores and read back with device-scope loads, so the barrier itself needs NO cache write-back /
-// invalidate -- an agent-scope release + acquire here is an L2 flush + invalidate per block and cost more than the
-// two launches it replaced.  Order: every wave waits for its stores to be acknowledged, workgroup barrier, then
-// thread 0 announces the block with a relaxed atomic.
-__device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned nblocks) {
-  __shared__ int ok_sh;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    bool ok = true;
-    __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblocks) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 20)) { ok = false; break; }  // not all blocks resident: give up instead of hanging
-    }
-    if (!ok) atomicExch(&sync[2], 1u);
-    const unsigned d = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d == nblocks - 1) {  // last one out: every block is past its poll loop, reset for the next call
-      __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    ok_sh = ok ? 1 : 0;
+// The blocks of a sample exchange their per-group sums WITHOUT a barrier and without a cache write-back / invalidate:
+// every sum travels as one 8-byte word {value, tag} written with a device-scope (write-through, sc1) store into a
+// region only these kernels ever write (rn_gn_params.sync + 256 bytes); readers poll the words they need with
+// device-scope loads until the tag is the current call's.  The tag is a device-side call counter (word 1) + 1: it is read
+// at kernel start, and bumped by the last block to leave the kernel (word 0 counts the leavers and is reset by that
+// block), so a replayed hipGraph and eager calls share it without host involvement.  Stale words always carry an
+// older tag.  Critical path: store -> L2 -> load, instead of store-ack + arrive-atomic + poll + leave-atomic + load.
+// The poll is bounded (~10^6 tries): if a sample's blocks are not all resident it gives up and sets the error word
+// (word 2) instead of hanging.
+constexpr size_t COOP_XCHG_OFFSET = 256;  // bytes from rn_gn_params.sync to the exchange rows
+constexpr size_t COOP_XCHG_BYTES = 1 << 20;  // 256 blocks x 256 groups x 2 sums x 8 bytes
+__device__ __forceinline__ unsigned coop_tag(const unsigned* sync) {
+  return __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+}
+__device__ __forceinline__ void coop_leave(unsigned* sync, unsigned nblocks) {  // one thread per block, after its polls
+  const unsigned d = __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (d == nblocks - 1) {  // every block has read the tag and finished polling: next call gets a new one
+    __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();
-  return ok_sh != 0;
 }
 
 // per-channel (sum v1, sum v2) over the block's pixels -> chan[c][0..1] in LDS, optionally the two partial planes (row
-// `chunk`; the backward's dbeta / dgamma rows), and the per-group sums (weighted by gamma when WEIGHTED) -> gpart
+// `chunk`; the backward's dbeta / dgamma rows), and the per-group sums (weighted by gamma when WEIGHTED) -> tagged exchange words
 template <bool WEIGHTED, bool PLANES>
 __device__ __forceinline__ void coop_partials(const GnArgs& a, float (*red)[8], float (*chan)[2], const float (&s1)[4],
-                                              const float (&s2)[4], int chunk, int QP, int lanes, int CQ) {
+                                              const float (&s2)[4], int chunk, int QP, int lanes, int CQ, unsigned tag) {
   const int tid = threadIdx.x, C = a.c;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { red[tid][j] = s1[j]; red[tid][4 + j] = s2[j]; }
@@ -645,20 +638,46 @@ __device__ __forceinline__ void coop_partials(const GnArgs& a, float (*red)[8], 
       const int c = g * a.cpg + j;
       t += WEIGHTED ? a.gamma[c] * chan[c][comp] : chan[c][comp];
     }
-    __hip_atomic_store(&a.gpart[((size_t)chunk * a.groups + g) * 2 + comp], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long word = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(t);
+    __hip_atomic_store(&a.xchg[((size_t)chunk * a.groups + g) * 2 + comp], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-// after the barrier: per-group totals of this block's sample over its `rows` chunks (fp64, fixed order) -> out[g][0..1]
-__device__ __forceinline__ void coop_group_totals(const GnArgs& a, const float* gp, int rows, double (*lane_sum)[2], double (*out)[2]) {
+// per-group totals of this block's sample over its `rows` chunks (fp64, fixed order) -> out[g][0..1]; polls the other
+// blocks' tagged words (four in flight per thread).  Returns false if a word never arrived.
+__device__ __forceinline__ bool coop_group_totals(const GnArgs& a, const unsigned long long* gp, int rows, unsigned tag,
+                                                  double (*lane_sum)[2], double (*out)[2]) {
+  __shared__ int fail_sh;
   const int tid = threadIdx.x, G2 = a.groups * 2;
   const int RL = CT / G2 >= 1 ? CT / G2 : 1;  // row lanes per (group, component)
+  if (tid == 0) fail_sh = 0;
+  if (G2 >= CT) __syncthreads();  // (the other branch has barriers of its own before fail_sh is written again)
+  bool fail = false;
   for (int e0 = 0; e0 < G2; e0 += CT) {      // G2 > CT: several passes with one row lane
     const int e = e0 + (tid % (G2 < CT ? G2 : CT)), rl = tid / (G2 < CT ? G2 : CT);
     double t = 0.0;
     if (e < G2 && rl < RL) {
-#pragma unroll 4
-      for (int r = rl; r < rows; r += RL) t += (double)__hip_atomic_load(gp + (size_t)r * G2 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int r0 = rl; r0 < rows; r0 += 4 * RL) {
+        unsigned long long w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = min(r0 + j * RL, rows - 1);
+          w[j] = __hip_atomic_load(gp + (size_t)r * G2 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = r0 + j * RL;
+          if (r < rows) {
+            unsigned spins = 0;
+            while ((unsigned)(w[j] >> 32) != tag) {
+              if (++spins > (1u << 20)) { fail = true; break; }  // that block is not resident: give up instead of hanging
+              __builtin_amdgcn_s_sleep(1);
+              w[j] = __hip_atomic_load(gp + (size_t)r * G2 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            t += (double)__uint_as_float((unsigned)w[j]);
+          }
+        }
+      }
     }
     if (G2 < CT) {
       __syncthreads();
@@ -673,7 +692,14 @@ __device__ __forceinline__ void coop_group_totals(const GnArgs& a, const float* 
       out[e >> 1][e & 1] = t;
     }
   }
+  if (fail) fail_sh = 1;
   __syncthreads();
+  const bool ok = fail_sh == 0;
+  if (tid == 0) {
+    if (!ok) atomicExch(&a.sync[2], 1u);
+    coop_leave(a.sync, gridDim.x);
+  }
+  return ok;
 }
 
 template <int ACT, int COOP_R>
@@ -693,6 +719,11 @@ __global__ __launch_bounds__(CT) void gn_coop_fwd_kernel(const GnArgs a) {
   const float* __restrict__ x = sg.x + base;
   const int q4 = tid % QP, pl = tid / QP;
   const bool active = pl < lanes;
+  const unsigned tag = coop_tag(a.sync);  // in flight together with the data loads, like the parameters below
+  float gam[4], bet[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { gam[j] = a.gamma[min(q4 * 4 + j, C - 1)]; bet[j] = a.beta[min(q4 * 4 + j, C - 1)]; }
+  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
   float4 v[COOP_R];
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -708,10 +739,20 @@ __global__ __launch_bounds__(CT) void gn_coop_fwd_kernel(const GnArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   }
-  coop_partials<false, false>(a, red, chan, s1, s2, ch, QP, lanes, CQ);
-  const bool ok = grid_barrier(a.sync, gridDim.x);
+  // the residual rows are fetched now (clamped addresses, all in flight) and wait in registers for the statistics
+  const float* __restrict__ res = sg.res ? sg.res + base : nullptr;
+  float4 rres[COOP_R];
+  if (res) {
+#pragma unroll
+    for (int k = 0; k < COOP_R; ++k)
+      rres[k] = *reinterpret_cast<const float4*>(res + (size_t)min(p_begin + pl + k * lanes, sg.hw - 1) * C + q4 * 4);
+  } else {
+#pragma unroll
+    for (int k = 0; k < COOP_R; ++k) rres[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  coop_partials<false, false>(a, red, chan, s1, s2, ch, QP, lanes, CQ, tag);
   // statistics of this block's sample from the group rows of all its chunks (fp64, fixed order)
-  coop_group_totals(a, a.gpart + (size_t)(sg.chunk_start + nl * sg.chunks) * a.groups * 2, sg.chunks, lane_sum, gtot);
+  const bool ok = coop_group_totals(a, a.xchg + (size_t)(sg.chunk_start + nl * sg.chunks) * a.groups * 2, sg.chunks, tag, lane_sum, gtot);
   for (int g = tid; g < a.groups; g += CT) {
     const double m = (double)sg.hw * (double)a.cpg;
     const double mean = gtot[g][0] / m;
@@ -727,14 +768,12 @@ __global__ __launch_bounds__(CT) void gn_coop_fwd_kernel(const GnArgs a) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int c = q4 * 4 + j, g = c / a.cpg;
-    sc[j] = gstat[g][1] * a.gamma[c];
-    sh[j] = a.beta[c] - gstat[g][0] * sc[j];
+    sc[j] = gstat[g][1] * gam[j];
+    sh[j] = bet[j] - gstat[g][0] * sc[j];
   }
   const bool drop = a.drop_rate > 0.f;
   const float keep_scale = drop ? 1.f / (1.f - a.drop_rate) : 1.f;
   const uint64_t samp_off = (uint64_t)q * (uint64_t)sg.hw * (uint64_t)C;
-  const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
-  const float* __restrict__ res = sg.res ? sg.res + base : nullptr;
   float* __restrict__ y = sg.y + base;
   const bool aar = a.act_after_res != 0;
 #pragma unroll
@@ -742,8 +781,7 @@ __global__ __launch_bounds__(CT) void gn_coop_fwd_kernel(const GnArgs a) {
     const int p = p_begin + pl + k * lanes;
     if (p < p_end) {
       const size_t off = (size_t)p * C + q4 * 4;
-      float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (res) rv = *reinterpret_cast<const float4*>(res + off);
+      const float4 rv = rres[k];
       const float xs[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
       const float r[4] = {rv.x, rv.y, rv.z, rv.w};
       float o[4];
@@ -779,6 +817,7 @@ __global__ __launch_bounds__(CT) void gn_coop_bwd_kernel(const GnArgs a) {
   const float* __restrict__ res = aar ? sg.res + base : nullptr;
   const int q4 = tid % QP, pl = tid / QP;
   const bool active = pl < lanes;
+  const unsigned tag = coop_tag(a.sync);
   float mean[4], rstd[4], gam[4], bet[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -822,9 +861,8 @@ __global__ __launch_bounds__(CT) void gn_coop_bwd_kernel(const GnArgs a) {
     xh[k] = make_float4(h[0], h[1], h[2], h[3]);
     gr[k] = make_float4(g[0], g[1], g[2], g[3]);
   }
-  coop_partials<true, true>(a, red, chan, s1, s2, ch, QP, lanes, CQ);
-  const bool ok = grid_barrier(a.sync, gridDim.x);
-  coop_group_totals(a, a.gpart + (size_t)(sg.chunk_start + nl * sg.chunks) * a.groups * 2, sg.chunks, lane_sum, gtot);
+  coop_partials<true, true>(a, red, chan, s1, s2, ch, QP, lanes, CQ, tag);
+  const bool ok = coop_group_totals(a, a.xchg + (size_t)(sg.chunk_start + nl * sg.chunks) * a.groups * 2, sg.chunks, tag, lane_sum, gtot);
   for (int g = tid; g < a.groups; g += CT) {
     const double m = (double)sg.hw * (double)a.cpg;
     gcoef[g][0] = (float)(gtot[g][0] / m); gcoef[g][1] = (float)(gtot[g][1] / m);
@@ -873,6 +911,7 @@ bool plan_coop(GnArgs* a) {
     if (chunks <= (cand == 4 ? 2 * COOP_MAX_BLOCKS : COOP_MAX_BLOCKS)) { r = cand; break; }
   }
   if (!r) return false;
+  if ((size_t)chunks * a->groups * 2 * sizeof(unsigned long long) > COOP_XCHG_BYTES) return false;  // rows must fit the sync region
   a->coop_r = r;
   chunks = 0;
   for (int s = 0; s < a->nseg; ++s) {
@@ -1039,6 +1078,10 @@ unsigned apply_blocks(const GnArgs& a, int vec = 4) {
 
 }  // namespace
 
+extern "C" size_t rn_group_norm_sync_bytes(void) {
+  return COOP_XCHG_OFFSET + COOP_XCHG_BYTES;
+}
+
 extern "C" size_t rn_group_norm_workspace(const rn_gn_seg* segs, int nseg, const rn_gn_params* p) {
   GnArgs a = {};
   // workspace query tolerates null data pointers
@@ -1081,7 +1124,7 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   {
     GnArgs c = a;  // the chunking differs from the three-kernel path's; the workspace (chunks <= 128 rows) always fits
     if (plan_coop(&c) && ws_bytes(c) <= workspace_bytes) {
-      c.gpart = (float*)((char*)workspace + rn::align_up((size_t)c.total_chunks * c.c * 2 * sizeof(float), 256));
+      c.xchg = (unsigned long long*)((char*)c.sync + COOP_XCHG_OFFSET);
       launch_coop<false>(c, st);
       RN_LAUNCH_CHECK();
       return RN_OK;
@@ -1143,7 +1186,7 @@ extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   {
     GnArgs c = a;
     if (plan_coop(&c) && ws_bytes(c) <= workspace_bytes) {
-      c.gpart = (float*)((char*)workspace + rn::align_up((size_t)c.total_chunks * c.c * 2 * sizeof(float), 256));
+      c.xchg = (unsigned long long*)((char*)c.sync + COOP_XCHG_OFFSET);
       launch_coop<true>(c, st);
       RN_LAUNCH_CHECK();
       // dbeta / dgamma = column sums of the two partial planes (one deferred launch per step, or two small ones now)

@@ -1,0 +1,56 @@
+"""Where a step's time goes, from a rocprofv3 kernel trace of `bench.py` (host-side analysis, no GPU needed):
+usage: python tools/timeline.py gpurun_out/final_prof/bench_kernel_trace.csv
+Takes the last full step (from one anchor-assignment kernel to the next), and reports: wall time, time with >= 1 kernel
+running, idle time, time with two kernels overlapping, kernels per step, and the per-kernel-family totals."""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(n):
+    n = re.sub(r'^void\s+', '', n).replace('(anonymous namespace)::', '').replace('at::native::', '')
+    return re.sub(r'[<(].*', '', n)
+
+
+def main(path):
+    rows = [r for r in csv.DictReader(open(path))]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    marks = [i for i, r in enumerate(rows) if 'assign_kernel' in r['Kernel_Name']]
+    # steps = spans between consecutive assign kernels; use the median-length one among the last ten
+    spans = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1)]
+    spans = [s for s in spans if 300 < s[1] - s[0] < 700][-10:]
+    lo, hi = spans[len(spans) // 2]
+    step = rows[lo:hi]
+    t0 = int(step[0]['Start_Timestamp'])
+    t1 = int(rows[hi]['Start_Timestamp'])
+    ev = []
+    for r in step:
+        ev.append((int(r['Start_Timestamp']), 1))
+        ev.append((int(r['End_Timestamp']), -1))
+    ev.sort()
+    depth, last, busy, over = 0, t0, 0, 0
+    for t, d in ev:
+        if depth >= 1:
+            busy += t - last
+        if depth >= 2:
+            over += t - last
+        depth += d
+        last = t
+    fam = defaultdict(lambda: [0, 0.0])
+    for r in step:
+        k = short(r['Kernel_Name'])
+        fam[k][0] += 1
+        fam[k][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    wall = (t1 - t0) / 1e3
+    print("step: %d kernels, wall %.0f us, >=1 kernel running %.0f us (%.0f%%), idle %.0f us (%.0f%%), two overlapping %.0f us"
+          % (len(step), wall, busy / 1e3, 100 * busy / 1e3 / wall, wall - busy / 1e3, 100 * (wall - busy / 1e3) / wall, over / 1e3))
+    print("queues:", sorted(set(r['Queue_Id'] for r in step)))
+    tot = sum(v[1] for v in fam.values())
+    print("sum of kernel durations %.0f us" % tot)
+    for k, (n, us) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        print("  %-34s %4d launches %8.1f us  %5.1f%%" % (k, n, us, 100 * us / tot))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
