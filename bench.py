@@ -139,8 +139,13 @@ def time_dominant_kernel(device, iters=50):
     L = _rn.lib()
 
     def timed(fn):
-        for _ in range(5):
-            fn()
+        # steady state: the clocks of an idle MI355X take ~10 ms of continuous work to come up (the same kernel measures
+        # 41 us in the first 50 launches after a pause and 36 us from then on), so warm up for >= 30 ms, not 5 launches
+        t_end = time.perf_counter() + 0.03
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
