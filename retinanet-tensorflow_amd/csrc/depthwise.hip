@@ -74,7 +74,31 @@ __device__ __forceinline__ void dw_dgrad_body(const DwArgs& a, int bid, int nblk
     const int ih = (int)(p % a.h);
     const int n_ = (int)(p / a.h);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (K3) {  // branch-free (see dw_fwd_kernel); stride 1 or 2
+    if (K3 && a.stride == 2) {
+      // stride 2: only the taps whose parity matches the input pixel's reach an output (<= 2 x 2 of the 3 x 3): visit
+      // just those, in the same ascending order as the full loop (same bits), branch-free
+      const int kh0 = (ih + a.pad_t) & 1, kw0 = (iw + a.pad_l) & 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kh = kh0 + 2 * j;
+        const int ohs = ih + a.pad_t - kh;  // even
+        const int oh_ = ohs >> 1;
+        const bool rok = kh < 3 && ohs >= 0 && oh_ < a.oh;
+        const int ohc = min(max(oh_, 0), a.oh - 1), khc = min(kh, 2);
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          const int kw = kw0 + 2 * i2;
+          const int ows = iw + a.pad_l - kw;
+          const int ow_ = ows >> 1;
+          const float m = (rok && kw < 3 && ows >= 0 && ow_ < a.ow) ? 1.f : 0.f;
+          const int owc = min(max(ow_, 0), a.ow - 1), kwc = min(kw, 2);
+          const float4 dv = *reinterpret_cast<const float4*>(a.dy + ((size_t)(n_ * a.oh + ohc) * a.ow + owc) * a.c + q4 * 4);
+          const float4 wv = *reinterpret_cast<const float4*>(a.w + (size_t)(khc * 3 + kwc) * a.c + q4 * 4);
+          acc.x = fmaf(dv.x * m, wv.x, acc.x); acc.y = fmaf(dv.y * m, wv.y, acc.y);
+          acc.z = fmaf(dv.z * m, wv.z, acc.z); acc.w = fmaf(dv.w * m, wv.w, acc.w);
+        }
+      }
+    } else if (K3) {  // branch-free (see dw_fwd_kernel); stride 1 (or any other stride)
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int ohs = ih + a.pad_t - kh;

@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-timeout 300 python bench.py --no-cpu-baseline > gpurun_out/bench5.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_prof -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/final_prof.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "depthwise or tiny_and_ragged" 2>&1 | tail -3 > gpurun_out/t5.log
+timeout 600 python -m pytest tests/test_gpu_model.py -q -m gpu -x 2>&1 | tail -3 >> gpurun_out/t5.log
+timeout 300 python bench.py --no-cpu-baseline --no-nms > gpurun_out/bench6.log 2>&1
