@@ -629,25 +629,31 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const ConvArgs4 d, const 
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_r in[r][i], fixed order => bitwise reproducible.
-// Block = 16 float4 columns x 16 row lanes: lane l sums rows l, l+16, ... (coalesced 256-B row
-// segments), the 16 lanes are combined in lane order through LDS.
-__device__ __forceinline__ void reduce_rows_block(const float* __restrict__ in, float* __restrict__ out, int64_t count, int nrows,
-                                                  int accumulate, int block) {
-  __shared__ float4 sh[16][16];
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int64_t i = ((int64_t)block * 16 + cl) * 4;
+// Block = (256 / RL) float4 columns x RL row lanes: lane l sums rows l, l+RL, ... (four loads in flight: the loop is
+// latency-bound), the lanes are combined in lane order through LDS.  RL = 16 (coalesced 256-B row segments) for short
+// reductions, RL = 64 for tall ones (>= REDUCE_TALL rows: the depthwise weight-gradient partials have up to 4096), where
+// the length of a lane's dependent chain matters more than the segment width.
+constexpr int REDUCE_TALL = 512;
+__host__ __device__ inline int64_t reduce_cols_per_block(int nrows) { return nrows >= REDUCE_TALL ? 16 : 64; }
+
+template <int RL>
+__device__ __forceinline__ void reduce_rows_lanes(const float* __restrict__ in, float* __restrict__ out, int64_t count, int nrows,
+                                                  int accumulate, int block, float4* sh) {
+  constexpr int CL = 256 / RL;
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int64_t i = ((int64_t)block * CL + cl) * 4;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < count) {
     const bool full = (i + 4 <= count) && ((count & 3) == 0);
     int r = rl;
-    if (full) {  // four rows in flight per lane (the loop is latency-bound: one 16-B load per row)
+    if (full) {
       float4 v1 = v, v2 = v, v3 = v;
-      for (; r + 48 < nrows; r += 64) {
+      for (; r + 3 * RL < nrows; r += 4 * RL) {
         const float* p = in + (size_t)r * count + i;
         const float4 t0 = *reinterpret_cast<const float4*>(p);
-        const float4 t1 = *reinterpret_cast<const float4*>(p + (size_t)16 * count);
-        const float4 t2 = *reinterpret_cast<const float4*>(p + (size_t)32 * count);
-        const float4 t3 = *reinterpret_cast<const float4*>(p + (size_t)48 * count);
+        const float4 t1 = *reinterpret_cast<const float4*>(p + (size_t)RL * count);
+        const float4 t2 = *reinterpret_cast<const float4*>(p + (size_t)(2 * RL) * count);
+        const float4 t3 = *reinterpret_cast<const float4*>(p + (size_t)(3 * RL) * count);
         v.x += t0.x; v.y += t0.y; v.z += t0.z; v.w += t0.w;
         v1.x += t1.x; v1.y += t1.y; v1.z += t1.z; v1.w += t1.w;
         v2.x += t2.x; v2.y += t2.y; v2.z += t2.z; v2.w += t2.w;
@@ -656,7 +662,7 @@ __device__ __forceinline__ void reduce_rows_block(const float* __restrict__ in, 
       v.x = (v.x + v1.x) + (v2.x + v3.x); v.y = (v.y + v1.y) + (v2.y + v3.y);
       v.z = (v.z + v1.z) + (v2.z + v3.z); v.w = (v.w + v1.w) + (v2.w + v3.w);
     }
-    for (; r < nrows; r += 16) {
+    for (; r < nrows; r += RL) {
       const float* p = in + (size_t)r * count + i;
       if (full) {
         const float4 t = *reinterpret_cast<const float4*>(p);
@@ -669,8 +675,21 @@ __device__ __forceinline__ void reduce_rows_block(const float* __restrict__ in, 
       }
     }
   }
-  sh[rl][cl] = v;
+  sh[rl * CL + cl] = v;
   __syncthreads();
+  if (RL > 16) {  // 64 lanes -> 16 (lanes 4q..4q+3 in order), then the common tail
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < 16) {
+#pragma unroll
+      for (int k = 0; k < RL / 16; ++k) {
+        const float4 u = sh[(rl * (RL / 16) + k) * CL + cl];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+    }
+    __syncthreads();
+    if (rl < 16) sh[rl * CL + cl] = t;
+    __syncthreads();
+  }
   if (rl == 0 && i < count) {
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (accumulate) {
@@ -680,12 +699,19 @@ __device__ __forceinline__ void reduce_rows_block(const float* __restrict__ in, 
       if (i + 3 < count) t.w = out[i + 3];
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { t.x += sh[r][cl].x; t.y += sh[r][cl].y; t.z += sh[r][cl].z; t.w += sh[r][cl].w; }
+    for (int r = 0; r < 16; ++r) { const float4 u = sh[r * CL + cl]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
     out[i] = t.x;
     if (i + 1 < count) out[i + 1] = t.y;
     if (i + 2 < count) out[i + 2] = t.z;
     if (i + 3 < count) out[i + 3] = t.w;
   }
+}
+
+__device__ __forceinline__ void reduce_rows_block(const float* __restrict__ in, float* __restrict__ out, int64_t count, int nrows,
+                                                  int accumulate, int block) {
+  __shared__ float4 sh[256];
+  if (nrows >= REDUCE_TALL) reduce_rows_lanes<64>(in, out, count, nrows, accumulate, block, sh);  // block-uniform
+  else reduce_rows_lanes<16>(in, out, count, nrows, accumulate, block, sh);
 }
 
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -812,7 +838,7 @@ int rn::launch_reduce_rows(const float* in, float* out, int64_t count, int nrows
       return RN_OK;
     }
   }
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rn::ceil_div64(count, 64)), dim3(256), 0, st, in, out, count, nrows,
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rn::ceil_div64(count, reduce_cols_per_block(nrows))), dim3(256), 0, st, in, out, count, nrows,
                      accumulate);
   RN_LAUNCH_CHECK();
   return RN_OK;
@@ -849,7 +875,7 @@ extern "C" int rn_flush_reductions(rn_stream_t stream) {
     for (int i = 0; i < a.n; ++i) {
       a.d[i] = todo[first + i];
       a.block_start[i] = blocks;
-      blocks += (int)rn::ceil_div64(a.d[i].count, 64);
+      blocks += (int)rn::ceil_div64(a.d[i].count, reduce_cols_per_block(a.d[i].nrows));
     }
     a.block_start[a.n] = blocks;
     if (blocks > 0) hipLaunchKernelGGL(reduce_rows_many_kernel, dim3(blocks), dim3(256), 0, st, a);
@@ -996,7 +1022,7 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
 #undef RN_FWD
   RN_LAUNCH_CHECK();
   if (nsplit > 1) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rn::ceil_div64(out_elems, 64)), dim3(256), 0, st, (const float*)sc.ws,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rn::ceil_div64(out_elems, reduce_cols_per_block(nsplit))), dim3(256), 0, st, (const float*)sc.ws,
                        y_final, out_elems, nsplit, 0);
     RN_LAUNCH_CHECK();
   }
@@ -1106,7 +1132,7 @@ int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, co
 #undef RN_DG
   RN_LAUNCH_CHECK();
   if (nsplit > 1) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rn::ceil_div64(out_elems, 64)), dim3(256), 0, st, (const float*)sc.ws,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rn::ceil_div64(out_elems, reduce_cols_per_block(nsplit))), dim3(256), 0, st, (const float*)sc.ws,
                        dx_final, out_elems, nsplit, 0);
     RN_LAUNCH_CHECK();
   }
@@ -1370,7 +1396,7 @@ int rn::launch_winograd_bwd_products(const float* Ad, const float* Bd, float* Cd
 // bias gradient: column sums of dy over every pixel of every segment (two fixed-order stages)
 // ---------------------------------------------------------------------------------------------
 namespace {
-constexpr int BG_BLOCKS = 1024;  // ~10 rows per block for the 10912-row head gradient: the row loop is latency-bound
+constexpr int BG_BLOCKS = 256;  // row groups: ~43 rows each for the 10912-row head gradient, and a 256-row reduce after
 struct BiasArgs {
   const float* dy[RN_MAX_SEG];
   int rows[RN_MAX_SEG];
@@ -1378,26 +1404,26 @@ struct BiasArgs {
   float* partial;  // [BG_BLOCKS][cout]
 };
 __global__ __launch_bounds__(256) void bias_partial_kernel(const BiasArgs a) {
-  // thread owns column c = tid % cout (cout <= 256 fast path, else loops), rows strided
-  for (int c0 = 0; c0 < a.cout; c0 += 256) {
-    const int c = c0 + threadIdx.x;
-    float acc = 0.f;
-    if (c < a.cout) {
-      for (int s = 0; s < a.nseg; ++s) {
-        const float* p = a.dy[s];
-        const int rows = a.rows[s], g = gridDim.x;
-        int r = blockIdx.x;
-        float acc1 = 0.f;
-        for (; r + g < rows; r += 2 * g) {  // two independent loads in flight
-          acc += p[(size_t)r * a.cout + c];
-          acc1 += p[(size_t)(r + g) * a.cout + c];
-        }
-        if (r < rows) acc += p[(size_t)r * a.cout + c];
-        acc += acc1;
-      }
-      a.partial[(size_t)blockIdx.x * a.cout + c] = acc;
+  // grid (row groups, 256-column groups): thread owns one column, rows strided by the row groups, four loads in flight
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= a.cout) return;
+  const int g = gridDim.x;
+  float acc = 0.f;
+  for (int s = 0; s < a.nseg; ++s) {
+    const float* p = a.dy[s] + c;
+    const int rows = a.rows[s];
+    int r = blockIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (; r + 3 * g < rows; r += 4 * g) {
+      a0 += p[(size_t)r * a.cout];
+      a1 += p[(size_t)(r + g) * a.cout];
+      a2 += p[(size_t)(r + 2 * g) * a.cout];
+      a3 += p[(size_t)(r + 3 * g) * a.cout];
     }
+    for (; r < rows; r += g) a0 += p[(size_t)r * a.cout];
+    acc += (a0 + a1) + (a2 + a3);
   }
+  a.partial[(size_t)blockIdx.x * a.cout + c] = acc;
 }
 }  // namespace
 
@@ -1418,7 +1444,7 @@ extern "C" int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_c
   }
   if (workspace_bytes < rn_conv2d_bias_grad_workspace(a.cout)) { rn::set_error("bias grad: workspace too small"); return RN_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bias_partial_kernel, dim3(BG_BLOCKS), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bias_partial_kernel, dim3(BG_BLOCKS, (unsigned)rn::ceil_div(a.cout, 256)), dim3(256), 0, st, a);
   RN_LAUNCH_CHECK();
   return rn::launch_reduce_rows((const float*)workspace, dbias, a.cout, BG_BLOCKS, 0, st);
 }
