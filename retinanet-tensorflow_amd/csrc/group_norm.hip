@@ -987,6 +987,16 @@ bool slice_preferred(const GnArgs& a) {
   return a.slice_wc >= 16 || (a.slice_wc >= 8 && elems < big);
 }
 
+// After the grid-resident path has declined (map too large): a slice kernel that reads runs narrower than 32 bytes
+// (ResNeXt's per-channel GroupNorm: 4 bytes of every 128-byte line) only pays while the whole tensor is small and
+// launch latency is what counts; past that the three full-row passes are 2x faster (measured at 2 x 100 x 100 x 256).
+bool narrow_slice_ok(const GnArgs& a) {
+  if (a.slice_wc >= 8) return true;
+  long elems = 0;
+  for (int s = 0; s < a.nseg; ++s) elems += (long)a.seg[s].n * a.seg[s].hw * a.c;
+  return elems * (8 / a.slice_wc) <= (1L << 21);
+}
+
 template <bool BWD, int ACT>
 void launch_slices_act(const GnArgs& a, int r, hipStream_t st) {
   const unsigned blocks = (unsigned)(a.total_samples * (a.groups / (a.slice_wc / a.cpg)));
@@ -1130,7 +1140,7 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
       return RN_OK;
     }
   }
-  if (r) {
+  if (r && narrow_slice_ok(a)) {
     launch_slices<false>(a, r, st);
     RN_LAUNCH_CHECK();
     return RN_OK;
@@ -1165,11 +1175,12 @@ extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   a.partial = (float*)workspace;
   a.coef = (float*)((char*)workspace + rn::align_up((size_t)a.total_chunks * a.c * 2 * sizeof(float), 256));
   hipStream_t st = (hipStream_t)stream;
-  const int r = plan_slices(&a);
+  int r = plan_slices(&a);
   bool coop_first = r && !slice_preferred(a);
   if (coop_first) {
     GnArgs c = a;
     coop_first = plan_coop(&c) && ws_bytes(c) <= workspace_bytes;
+    if (!coop_first && !narrow_slice_ok(a)) r = 0;  // neither: three kernels
   }
   if (r && !coop_first) {
     a.pgrad = (float*)workspace;  // [2][total_samples][c] <= the chunk-partial area (chunks >= samples)
