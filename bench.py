@@ -122,7 +122,7 @@ class Step(object):
         return self.out
 
 
-def time_dominant_kernel(device, iters=50):
+def time_dominant_kernel(device, iters=100):
     """The kernel the training step spends most matrix-core time in: the batched product of the Winograd
     F(4x4,3x3) head-tower layer (3x3, 256->256, the five pyramid levels of a 512^2 batch of 2 = 682 4x4 tiles):
     36 x ([682 x 256] x [256 x 256]) in ONE launch of conv_fwd_kernel<64,64,...>.  Executed FLOPs per launch =
@@ -139,9 +139,9 @@ def time_dominant_kernel(device, iters=50):
     L = _rn.lib()
 
     def timed(fn):
-        # steady state: the clocks of an idle MI355X take ~10 ms of continuous work to come up (the same kernel measures
-        # 41 us in the first 50 launches after a pause and 36 us from then on), so warm up for >= 30 ms, not 5 launches
-        t_end = time.perf_counter() + 0.03
+        # steady state: the clocks of an idle MI355X take >= 10 ms of continuous work to come up (the same kernel measures
+        # 41 us in the first 50 launches after a pause and 35-36 us from then on), so warm up for 100 ms, not 5 launches
+        t_end = time.perf_counter() + 0.1
         while time.perf_counter() < t_end:
             for _ in range(20):
                 fn()
