@@ -325,7 +325,9 @@ __device__ __forceinline__ void conv_dgrad_body(const A& args, float* smem, int 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  int bid = rn::xcd_remap(blk, nblk);
+  // phase-decomposed launches keep the hardware's round-robin order: their pseudo-segments differ 4x in K (1 / 2 / 2 / 4
+  // taps), and handing each XCD a contiguous tile range would give two XCDs all the 4-tap tiles (4/9 of the work)
+  int bid = args.seg[0].par ? blk : rn::xcd_remap(blk, nblk);
   int batch = 0;
   if (args.nbatch > 1) { batch = bid / args.btiles; bid -= batch * args.btiles; }
   const int s = find_seg(args, bid);
