@@ -14,7 +14,6 @@ single kernel, the gradient all-reduce is a few large contiguous messages sized 
 xGMI bandwidth, and the whole step (forward, loss, backward, optimizer) can be captured into one
 hipGraph -- the launch-bound small kernels of the pyramid's coarse levels then cost no host time.
 """
-import ctypes as C
 import os
 
 import numpy as np
@@ -281,7 +280,6 @@ def build_parser():
 
 
 def main(argv=None):
-    import augmentation
     import checkpoint
     import dataset
     import retinanet

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from helpers import assert_close
-from oracle import backbones_ref, model_ref
+from oracle import backbones_ref
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
