@@ -99,10 +99,11 @@ class Optimizer(object):
 class GradientAllReduce(object):
     """MirroredStrategy's cross-replica gradient sum (train.py:261-267) as RCCL all-reduces of
     contiguous arena slices.  xGMI is point-to-point (7 links x ~153 GB/s), ring collectives are
-    per-link bound, so the arena goes out as FEW LARGE buckets (default 32 MB) rather than one
+    per-link bound, so the arena goes out as FEW LARGE buckets (default 64 MB: the whole 40 MB arena of the
+    headline config is ONE message) rather than one
     message per tensor; the 1/world_size average is folded into the optimizer kernel."""
 
-    def __init__(self, arena, process_group=None, bucket_bytes=32 << 20):
+    def __init__(self, arena, process_group=None, bucket_bytes=64 << 20):
         import torch.distributed as dist
         self.dist, self.group, self.arena = dist, process_group, arena
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
