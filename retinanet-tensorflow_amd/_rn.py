@@ -244,7 +244,10 @@ _sync_words = {}
 def sync_counters(device):
     """The zeroed region (rn_group_norm_sync_bytes()) per (device, current stream) for rn_gn_params.sync: counters and
     exchange rows of the grid-resident GroupNorm path.  Word 2 is set if a wait ever timed out."""
-    key = (device.type, device.index, stream().value)
+    # like workspace(): one region for the main stream (default, warm-up or graph-capture stream -- never concurrent
+    # with each other) and one per registered side stream, so nothing is allocated (and zero-filled) inside a capture
+    h = stream().value
+    key = (device.type, device.index, h if h in SIDE_STREAMS else 0)
     t = _sync_words.get(key)
     if t is None:
         t = torch.zeros(lib().rn_group_norm_sync_bytes() // 4, dtype=torch.int32, device=device)

@@ -724,13 +724,14 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 // Deferred mode (rn_defer_reductions): every row reduction recorded during a backward pass -- the split-K slabs of
 // ~70 weight gradients, the GroupNorm parameter-gradient rows -- runs as ONE launch instead of one
 // launch-latency-bound kernel each.
-constexpr int RN_MAX_REDUCE = 96;
-struct ReduceDesc { const float* in; float* out; int64_t count; int nrows, accumulate; };
+constexpr int RN_MAX_REDUCE = 140;  // 24-byte descriptors + block starts: the whole step's ~135 reductions in one 4 KB kernarg
+struct ReduceDesc { const float* in; float* out; int count; unsigned short nrows, accumulate; };
 struct ReduceManyArgs {
   ReduceDesc d[RN_MAX_REDUCE];
   int block_start[RN_MAX_REDUCE + 1];
   int n;
 };
+static_assert(sizeof(ReduceDesc) == 24 && sizeof(ReduceManyArgs) <= 4096, "descriptors must fit the kernel-argument segment");
 __global__ __launch_bounds__(256) void reduce_rows_many_kernel(const ReduceManyArgs a) {
   int lo = 0, hi = a.n - 1;  // last descriptor whose first block is <= blockIdx.x
   while (lo < hi) {
@@ -835,8 +836,8 @@ int rn::launch_reduce_rows(const float* in, float* out, int64_t count, int nrows
   {
     std::lock_guard<std::mutex> lk(g_defer_mu);
     auto it = g_deferred.find(st);
-    if (it != g_deferred.end()) {
-      it->second.push_back(ReduceDesc{in, out, count, nrows, accumulate});
+    if (it != g_deferred.end() && count < (int64_t)1 << 31 && nrows < 65536) {
+      it->second.push_back(ReduceDesc{in, out, (int)count, (unsigned short)nrows, (unsigned short)(accumulate ? 1 : 0)});
       return RN_OK;
     }
   }
