@@ -110,7 +110,7 @@ int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g
  * Every weight-gradient entry point (rn_conv2d_wgrad, rn_depthwise_wgrad, rn_conv2d_bias_grad, the GroupNorm
  * parameter gradients of rn_group_norm_bwd) ends with a fixed-order row reduction of per-block partial results.
  * A training step has ~130 of them, each a launch-latency-bound kernel.  After rn_defer_reductions(stream, 1) they
- * are recorded instead of launched and rn_flush_reductions(stream) runs them all as one launch (per 96).  While
+ * are recorded instead of launched and rn_flush_reductions(stream) runs them all as one launch (per 140).  While
  * deferring, the `workspace` handed to those entry points must stay untouched until the flush (give each call its
  * own buffer), and the gradients are only valid after the flush.  Results are bitwise identical to immediate mode,
  * except the GroupNorm dgamma / dbeta of maps too large for the single-kernel path, whose chunk rows are then summed
