@@ -147,6 +147,7 @@ class Trainer(object):
         self._graph = None
         self._static = None
         self.drop_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._one = torch.ones((), dtype=torch.float32, device=self.device)
         L.Dropout.seed_device_counter = self.drop_counter
         self.last = {}
 
@@ -169,7 +170,8 @@ class Trainer(object):
                 extra = []
             ops.begin_deferred_reductions(extra)
         try:
-            (class_loss + regr_loss).backward()
+            # d(class_loss + regr_loss): both roots seeded with the same pre-allocated 1 (no add / fill kernels in the step)
+            torch.autograd.backward([class_loss, regr_loss], [self._one, self._one])
         finally:
             if defer:
                 ops.end_deferred_reductions()
