@@ -153,22 +153,62 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total) {
   return ex;
 }
 
-// ---- 2. exclusive scan of wave counts (single block; n_waves is a few 10^4: a contiguous run per thread, one
-//         block-wide scan of the run totals)
-__global__ __launch_bounds__(1024) void det_offsets_kernel(const DetArgs a) {
+// ---- 2. exclusive scan of the wave counts (a few 10^4 entries), coalesced, in two small launches:
+//   a) one block per 1024 entries: exclusive scan inside the chunk -> wave_off; the chunk's total is parked in the
+//      chunk's first wave_count slot (the counts are not read again: the emit pass re-derives its flags)
+//   b) one block: exclusive scan of the (<= 1024) chunk totals, added to every entry of wave_off; counts[0] = total.
+// (A single block walking a contiguous run per thread took 77 us at the 1024^2 x 16 shape -- 64 uncoalesced lines per
+// load instruction through one CU's address path; with the run held in registers still 57.)
+__global__ __launch_bounds__(1024) void det_offsets_chunk_kernel(const DetArgs a) {
   const int64_t nw = (int64_t)a.n * a.waves_per_image;
-  const int64_t per = (nw + 1023) / 1024;
-  const int64_t b = (int64_t)threadIdx.x * per, e = b + per < nw ? b + per : nw;
-  int local = 0;
-  for (int64_t i = b; i < e; ++i) local += a.wave_count[i];
+  const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  const int v = i < nw ? a.wave_count[i] : 0;
   int total;
-  int run = block_exclusive_scan_1024(local, &total);
-  for (int64_t i = b; i < e; ++i) {
-    const int v = a.wave_count[i];
-    a.wave_off[i] = run;
-    run += v;
+  const int ex = block_exclusive_scan_1024(v, &total);
+  if (i < nw) a.wave_off[i] = ex;
+  if (threadIdx.x == 0) a.wave_count[(int64_t)blockIdx.x * 1024] = total;
+}
+
+__global__ __launch_bounds__(1024) void det_offsets_kernel(const DetArgs a) {
+  __shared__ int base[1024];
+  const int64_t nw = (int64_t)a.n * a.waves_per_image;
+  const int nchunk = (int)((nw + 1023) / 1024);
+  if (nchunk <= 1024) {
+    const int t = (int)threadIdx.x < nchunk ? a.wave_count[(int64_t)threadIdx.x * 1024] : 0;
+    int total;
+    base[threadIdx.x] = block_exclusive_scan_1024(t, &total);
+    __syncthreads();
+    for (int c0 = 1; c0 < nchunk; c0 += 8) {  // chunk 0 is already final; eight loads in flight, then eight stores
+      int v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t i = (int64_t)(c0 + j) * 1024 + threadIdx.x;
+        v[j] = a.wave_off[i < nw ? i : nw - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t i = (int64_t)(c0 + j) * 1024 + threadIdx.x;
+        if (c0 + j < nchunk && i < nw) a.wave_off[i] = v[j] + base[c0 + j];
+      }
+    }
+    if (threadIdx.x == 0) a.counts[0] = total;
+    return;
   }
-  if (threadIdx.x == 0) a.counts[0] = total;
+  // more than 2^20 waves: chunk totals walked by thread 0 (never reached by the shapes of this network)
+  if (threadIdx.x == 0) {
+    long long run = 0;
+    for (int c = 0; c < nchunk; ++c) {
+      const int t = a.wave_count[(int64_t)c * 1024];
+      a.wave_count[(int64_t)c * 1024] = (int)run;
+      run += t;
+    }
+    a.counts[0] = run;
+  }
+  __syncthreads();
+  for (int c = 1; c < nchunk; ++c) {
+    const int64_t i = (int64_t)c * 1024 + threadIdx.x;
+    if (i < nw) a.wave_off[i] += a.wave_count[(int64_t)c * 1024];
+  }
 }
 
 // ---- 3. emit candidates in anchor order; pad the key array with sentinels
@@ -440,8 +480,12 @@ __global__ void det_keys_from_arrays_kernel(const DetArgs a, const int64_t* coun
 
 int sort_and_suppress(DetArgs& a, const WsLayout& L, void* workspace, hipStream_t st) {
   size_t sort_bytes = L.sort_bytes;
+  // key = (image * C + class) << 32 | ~score bits: only the bits that can differ are sorted.  The padding keys are all
+  // ones, so with nb >= bits(n * C) their truncated segment id still exceeds every real one and they stay at the end.
+  int nb = 1;
+  while (((1ll << nb) - 1) < (long long)a.n * a.C) ++nb;
   hipError_t e = rocprim::radix_sort_pairs((char*)workspace + L.off[17], sort_bytes, a.keys_in, a.keys_out, a.vals_in,
-                                           a.vals_out, (size_t)a.cap, 0, 64, st);
+                                           a.vals_out, (size_t)a.cap, 0, 32 + nb, st);
   if (e != hipSuccess) {
     rn::set_error("detect: radix sort failed: %s", hipGetErrorString(e));
     return RN_EHIP;
@@ -474,6 +518,7 @@ int run_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, 
   const int64_t nw = (int64_t)a.n * a.waves_per_image;
   const unsigned wblocks = (unsigned)((nw * 64 + T - 1) / T);
   hipLaunchKernelGGL(det_scan_kernel, dim3(wblocks), dim3(T), 0, st, a);
+  hipLaunchKernelGGL(det_offsets_chunk_kernel, dim3((unsigned)((nw + 1023) / 1024)), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(det_offsets_kernel, dim3(1), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(det_emit_kernel, dim3(wblocks), dim3(T), 0, st, a);
   if (decode_only) {
