@@ -57,6 +57,48 @@ __device__ __forceinline__ void locate_wave(const DetArgs& a, int64_t wid, int* 
 // ---- 1. scan: lane i of a wave ends up holding (max prob, arg-max) of row row0+i.
 // Four lanes share a row (float4 loads, 64-B contiguous per row and instruction), 16 rows per
 // pass, 2 shuffle steps to combine; first index wins ties (tf.argmax).  C % 4 == 0 fast path.
+// per-row (max, lowest arg-max) of the wave's (up to) 64 rows of C = 4 * C4 probabilities: 4 lanes per row, 16 rows per
+// pass, Q float4 chunks per lane; lane l ends up with row l's result
+template <int Q>
+__device__ __forceinline__ void scan_rows_unrolled(const float* __restrict__ base, int C, int nrow, int lane, float* out_s, int* out_c) {
+  const int sub = lane & 3, rsel = lane >> 2, C4 = C >> 2;
+  float4 v[4][Q];
+  int cc[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) cc[q] = min(sub + 4 * q, C4 - 1);
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = min(pass * 16 + rsel, nrow - 1);
+    const float4* row = reinterpret_cast<const float4*>(base + (size_t)r * C);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[pass][q] = row[cc[q]];
+  }
+  float my_s = 0.f; int my_c = 0;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    float best = -1e30f; int bi = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {  // ascending chunk index per lane: strict > keeps the lowest index on ties
+      const int c = cc[q] * 4;
+      const float4 t = v[pass][q];
+      if (t.x > best) { best = t.x; bi = c; }
+      if (t.y > best) { best = t.y; bi = c + 1; }
+      if (t.z > best) { best = t.z; bi = c + 2; }
+      if (t.w > best) { best = t.w; bi = c + 3; }
+    }
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    const float sv = __shfl(best, (lane & 15) * 4, 64);
+    const int sc = __shfl(bi, (lane & 15) * 4, 64);
+    if ((lane >> 4) == pass) { my_s = sv; my_c = sc; }
+  }
+  *out_s = my_s; *out_c = my_c;
+}
+
 __global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
@@ -68,7 +110,21 @@ __global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
   const int nrow = (int)((lv.rows - row0) < 64 ? (lv.rows - row0) : 64);
   const float* base = lv.prob + ((size_t)img * lv.rows + row0) * a.C;
   float my_s = 0.f; int my_c = 0;
-  if ((a.C & 3) == 0) {
+  const int q_per_lane = ((a.C >> 2) + 3) >> 2;  // float4 chunks per lane when 4 lanes share a row
+  if ((a.C & 3) == 0 && q_per_lane <= 8) {
+    // every load of the wave's 64 rows is issued before the first compare (clamped addresses: a duplicated chunk or row
+    // cannot change a max / lowest-index arg-max), instead of one dependent load per loop iteration
+    switch (q_per_lane) {
+      case 1: scan_rows_unrolled<1>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 2: scan_rows_unrolled<2>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 3: scan_rows_unrolled<3>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 4: scan_rows_unrolled<4>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 5: scan_rows_unrolled<5>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 6: scan_rows_unrolled<6>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 7: scan_rows_unrolled<7>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      default: scan_rows_unrolled<8>(base, a.C, nrow, lane, &my_s, &my_c); break;
+    }
+  } else if ((a.C & 3) == 0) {
     const int sub = lane & 3, rsel = lane >> 2;  // 4 lanes per row, 16 rows per pass
     const int C4 = a.C >> 2;
 #pragma unroll
