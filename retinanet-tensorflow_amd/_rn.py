@@ -61,7 +61,9 @@ class LossSeg(C.Structure):
 
 
 class DetLevel(C.Structure):
-    _fields_ = [("prob", C.c_void_p), ("boxes", C.c_void_p), ("rows_per_image", C.c_int64)]
+    _fields_ = [("prob", C.c_void_p), ("boxes", C.c_void_p), ("rows_per_image", C.c_int64),
+                ("regression", C.c_void_p), ("anchor_sizes", C.c_void_p),
+                ("grid_h", C.c_int32), ("grid_w", C.c_int32), ("num_anchors", C.c_int32)]
 
 
 class DetParams(C.Structure):

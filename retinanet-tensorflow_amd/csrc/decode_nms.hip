@@ -28,7 +28,10 @@ namespace {
 constexpr int T = 256;
 constexpr int MAXL = 8;
 
-struct DetLevel { const float* prob; const float* boxes; int64_t rows; int64_t row_off; int wave_off; };
+struct DetLevel {
+  const float* prob; const float* boxes; int64_t rows; int64_t row_off; int wave_off;
+  const float* reg; const float* anch; int h, w, A;  // boxes == nullptr: decode candidates from the raw regression
+};
 struct DetArgs {
   DetLevel lv[MAXL];
   int nlv, n, C, max_keep;
@@ -267,6 +270,27 @@ __global__ __launch_bounds__(1024) void det_offsets_kernel(const DetArgs a) {
   }
 }
 
+// ---- anchor decode (utils.py:108-117, SURVEY Q13)
+__device__ __forceinline__ float cell_center(int i, int size) {
+  const float cell = (float)(1.0 / (double)size);
+  const float start = cell / 2.0f;
+  if (size == 1) return start;
+  const float stop = 1.0f - start;
+  const float step = (stop - start) / (float)(size - 1);
+  const float t = step * (float)i;
+  return start + t;
+}
+
+// one anchor's box from its raw regression (utils.regression_postprocess, utils.py:100-117): the ONLY copy of this
+// arithmetic -- the full-map kernel and the candidate-only path of det_emit_kernel both call it (same bits)
+__device__ __forceinline__ float4 decode_one(const float4 r, float ah, float aw, int y_, int x_, int h, int w) {
+  const float sy = r.x * ah, sx = r.y * aw;
+  const float bh = expf(r.z) * ah, bw = expf(r.w) * aw;
+  const float cy = sy + cell_center(y_, h), cx = sx + cell_center(x_, w);
+  const float hh = bh / 2.0f, hw = bw / 2.0f;
+  return make_float4(cy - hh, cx - hw, cy + hh, cx + hw);
+}
+
 // ---- 3. emit candidates in anchor order; pad the key array with sentinels
 __global__ __launch_bounds__(T) void det_emit_kernel(const DetArgs a) {
   const int lane = threadIdx.x & 63;
@@ -286,7 +310,17 @@ __global__ __launch_bounds__(T) void det_emit_kernel(const DetArgs a) {
   if (!flag) return;
   const int64_t pos = (int64_t)a.wave_off[wid] + __popcll(m & ((1ull << lane) - 1ull));
   if (pos >= a.cap) return;  // overflow is reported through counts[0] > capacity
-  const float4 b = *reinterpret_cast<const float4*>(lv.boxes + ((size_t)img * lv.rows + row0 + lane) * 4);
+  float4 b;
+  if (lv.boxes) {
+    b = *reinterpret_cast<const float4*>(lv.boxes + ((size_t)img * lv.rows + row0 + lane) * 4);
+  } else {  // decode this candidate only
+    int64_t q = row0 + lane;
+    const int an = (int)(q % lv.A); q /= lv.A;
+    const int x_ = (int)(q % lv.w);
+    const int y_ = (int)(q / lv.w);
+    const float4 r = *reinterpret_cast<const float4*>(lv.reg + ((size_t)img * lv.rows + row0 + lane) * 4);
+    b = decode_one(r, lv.anch[an * 2], lv.anch[an * 2 + 1], y_, x_, lv.h, lv.w);
+  }
   *reinterpret_cast<float4*>(a.cand_box + pos * 4) = b;
   a.cand_score[pos] = s; a.cand_class[pos] = c; a.cand_image[pos] = img; a.cand_anchor[pos] = in_img;
   const uint32_t sb = __float_as_uint(s);  // s > 0: bit pattern is monotone in the value
@@ -405,17 +439,6 @@ __global__ void det_gather_kernel(const DetArgs a) {
   }
 }
 
-// ---- anchor decode (utils.py:108-117, SURVEY Q13)
-__device__ __forceinline__ float cell_center(int i, int size) {
-  const float cell = (float)(1.0 / (double)size);
-  const float start = cell / 2.0f;
-  if (size == 1) return start;
-  const float stop = 1.0f - start;
-  const float step = (stop - start) / (float)(size - 1);
-  const float t = step * (float)i;
-  return start + t;
-}
-
 __global__ void decode_kernel(const float* __restrict__ reg, const float* __restrict__ anchors, float* __restrict__ out,
                               int n, int h, int w, int A) {
   const int64_t total = (int64_t)n * h * w * A;
@@ -425,12 +448,7 @@ __global__ void decode_kernel(const float* __restrict__ reg, const float* __rest
     const int x_ = (int)(q % w); q /= w;
     const int y_ = (int)(q % h);
     const float4 r = *reinterpret_cast<const float4*>(reg + i * 4);
-    const float ah = anchors[an * 2], aw = anchors[an * 2 + 1];
-    const float sy = r.x * ah, sx = r.y * aw;
-    const float bh = expf(r.z) * ah, bw = expf(r.w) * aw;
-    const float cy = sy + cell_center(y_, h), cx = sx + cell_center(x_, w);
-    const float hh = bh / 2.0f, hw = bw / 2.0f;
-    *reinterpret_cast<float4*>(out + i * 4) = make_float4(cy - hh, cx - hw, cy + hh, cx + hw);
+    *reinterpret_cast<float4*>(out + i * 4) = decode_one(r, anchors[an * 2], anchors[an * 2 + 1], y_, x_, h, w);
   }
 }
 
@@ -447,6 +465,13 @@ int plan(const rn_det_level* levels, int nlevels, const rn_det_params* p, DetArg
   for (int l = 0; l < nlevels; ++l) {
     RN_CHECK_ARG(levels[l].rows_per_image >= 1, "detect: empty level %d", l);
     a->lv[l].prob = levels[l].prob; a->lv[l].boxes = levels[l].boxes; a->lv[l].rows = levels[l].rows_per_image;
+    a->lv[l].reg = levels[l].regression; a->lv[l].anch = levels[l].anchor_sizes;
+    a->lv[l].h = levels[l].grid_h; a->lv[l].w = levels[l].grid_w; a->lv[l].A = levels[l].num_anchors;
+    if (!levels[l].boxes && levels[l].regression)
+      RN_CHECK_ARG(levels[l].anchor_sizes && levels[l].grid_h >= 1 && levels[l].grid_w >= 1 && levels[l].num_anchors >= 1 &&
+                       (int64_t)levels[l].grid_h * levels[l].grid_w * levels[l].num_anchors == levels[l].rows_per_image,
+                   "detect: level %d: regression grid %d x %d x %d does not match %lld rows", l, levels[l].grid_h,
+                   levels[l].grid_w, levels[l].num_anchors, (long long)levels[l].rows_per_image);
     a->lv[l].row_off = rows; a->lv[l].wave_off = waves;
     rows += levels[l].rows_per_image;
     waves += (int)((levels[l].rows_per_image + 63) / 64);
@@ -562,7 +587,8 @@ int run_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, 
   WsLayout L;
   if (int e = plan(levels, nlevels, p, &a, &L)) return e;
   RN_CHECK_ARG(out_boxes && out_scores && out_class && out_image && out_anchor && counts && workspace, "detect: null pointer");
-  for (int l = 0; l < nlevels; ++l) RN_CHECK_ARG(levels[l].prob && levels[l].boxes, "detect: null level pointer %d", l);
+  for (int l = 0; l < nlevels; ++l)
+    RN_CHECK_ARG(levels[l].prob && (levels[l].boxes || levels[l].regression), "detect: null level pointer %d", l);
   if (workspace_bytes < L.total) {
     rn::set_error("detect: workspace %zu < %zu", workspace_bytes, L.total);
     return RN_EWORKSPACE;

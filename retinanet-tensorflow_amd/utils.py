@@ -88,17 +88,28 @@ def classmap_decode(classmap, name='classmap_decoder'):
     return ClassmapDecoded(fg_mask=classmap.max(-1).values > 0.5)
 
 
-def _det_call(fn_name, probs, boxes, num_classes, n, score_threshold, iou_threshold, max_per_class, capacity):
-    """probs/boxes: lists over levels of [n, rows, C] / [n, rows, 4] tensors."""
+def _det_call(fn_name, probs, boxes, num_classes, n, score_threshold, iou_threshold, max_per_class, capacity, raw=None):
+    """probs/boxes: lists over levels of [n, rows, C] / [n, rows, 4] tensors; or boxes=None and raw = list over levels of
+    (regression [n,H,W,A,4], anchor tensor [A,2]): candidates are decoded on the fly (see rn_det_level)."""
     L = _rn.lib()
     dev = probs[0].device
     levels = (_rn.DetLevel * len(probs))()
     total_rows = 0
-    for i, (p, b) in enumerate(zip(probs, boxes)):
-        assert p.shape[0] == n and b.shape[0] == n and p.shape[1] == b.shape[1] and p.shape[2] == num_classes
+    for i, p in enumerate(probs):
+        assert p.shape[0] == n and p.shape[2] == num_classes
         levels[i].prob = _rn.f32(p)
-        levels[i].boxes = _rn.f32(b)
         levels[i].rows_per_image = p.shape[1]
+        if raw is None:
+            assert boxes[i].shape[0] == n and p.shape[1] == boxes[i].shape[1]
+            levels[i].boxes = _rn.f32(boxes[i])
+        else:
+            reg, anc = raw[i]
+            assert reg.dim() == 5 and reg.shape[0] == n and reg.shape[4] == 4 and reg.shape[3] == anc.shape[0]
+            assert reg.shape[1] * reg.shape[2] * reg.shape[3] == p.shape[1]
+            levels[i].boxes = None
+            levels[i].regression = _rn.f32(reg)
+            levels[i].anchor_sizes = _rn.f32(anc)
+            levels[i].grid_h, levels[i].grid_w, levels[i].num_anchors = reg.shape[1], reg.shape[2], reg.shape[3]
         total_rows += p.shape[1]
     cap = int(capacity) if capacity is not None else n * total_rows
     params = _rn.DetParams(n, num_classes, max_per_class, score_threshold, iou_threshold, cap)
@@ -185,6 +196,31 @@ def detect(class_probs, regressions_postprocessed, num_classes, score_threshold=
     boxes = [regressions_postprocessed[k].reshape(n, -1, 4).contiguous() for k in keys]
     ob, os_, oc, oi, oa, counts, cap = _det_call('rn_detect', probs, boxes, num_classes, n, score_threshold,
                                                  iou_threshold, max_per_class, capacity)
+    if return_raw:
+        return ob, os_, oc, oi, oa, counts
+    cnt = counts.cpu().tolist()
+    if cnt[0] > cap:
+        raise _rn.RnError('detect: %d candidates exceed capacity %d' % (cnt[0], cap))
+    out, off = [], 0
+    for i in range(n):
+        m = cnt[2 + i]
+        out.append(BoxesDecoded(boxes=ob[off:off + m], scores=os_[off:off + m], class_ids=oc[off:off + m].long()))
+        off += m
+    return out
+
+
+def detect_raw(class_probs, regressions, anchor_sizes, num_classes, score_threshold=0.5, iou_threshold=0.5,
+               max_per_class=NMS_MAX_OUTPUT_SIZE, capacity=None, return_raw=False):
+    """`detect` without the full-map decode: dicts P3..P7 of [N,H,W,A,C] probabilities, RAW regressions [N,H,W,A,4] and
+    normalised anchor sizes (`Level.normalized_anchor_sizes`).  Only the rows that pass the score threshold are decoded
+    (same arithmetic as `regression_postprocess`, same results as `detect(probs, regression_postprocess(...))`)."""
+    keys = list(class_probs.keys())
+    n = class_probs[keys[0]].shape[0]
+    probs = [class_probs[k].reshape(n, -1, num_classes).contiguous() for k in keys]
+    dev = probs[0].device
+    raw = [(regressions[k].contiguous().float(), _anchor_tensor(anchor_sizes[k], dev)) for k in keys]
+    ob, os_, oc, oi, oa, counts, cap = _det_call('rn_detect', probs, None, num_classes, n, score_threshold, iou_threshold,
+                                                 max_per_class, capacity, raw=raw)
     if return_raw:
         return ob, os_, oc, oi, oa, counts
     cnt = counts.cpu().tolist()

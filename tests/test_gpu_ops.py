@@ -405,6 +405,41 @@ def test_detect_bit_exact_indices(dev, n, c, hot):
     assert total_kept > 0
 
 
+def test_detect_raw_equals_decode_then_detect(dev):
+    """utils.detect_raw (candidates decoded on the fly inside the emit pass) == regression_postprocess + detect, bit for
+    bit, and == the oracle; ragged pyramid, two images, non-square grids."""
+    import levels
+    import utils
+    rng = np.random.default_rng(21)
+    n, c = 2, 5
+    lv = levels.build_levels()
+    size = (96, 160)
+    probs, regs, anchors = {}, {}, {}
+    for k in lv:
+        f = 2 ** int(k[1])
+        gh, gw = -(-size[0] // f), -(-size[1] // f)
+        p = rng.uniform(0, 0.45, (n, gh, gw, 9, c)).astype(np.float32)
+        hot = rng.uniform(size=(n, gh, gw, 9)) < 0.15
+        p[hot, rng.integers(0, c, int(hot.sum()))] = rng.uniform(0.5, 1.0, int(hot.sum())).astype(np.float32)
+        probs[k] = p
+        regs[k] = (rng.standard_normal((n, gh, gw, 9, 4)) * 0.3).astype(np.float32)
+        anchors[k] = lv[k].normalized_anchor_sizes(size)
+    tp = {k: _t(v, dev) for k, v in probs.items()}
+    tr = {k: _t(v, dev) for k, v in regs.items()}
+    dec = {k: utils.regression_postprocess(tr[k], anchors[k]) for k in lv}
+    want = utils.detect(tp, dec, c)
+    got = utils.detect_raw(tp, tr, anchors, c)
+    kept = 0
+    for i in range(n):
+        assert torch.equal(got[i].boxes, want[i].boxes) and torch.equal(got[i].scores, want[i].scores)
+        assert torch.equal(got[i].class_ids, want[i].class_ids)
+        parts = [utils_ref.boxes_decode(probs[k][i], dec[k][i].cpu().numpy()) for k in lv]
+        exp = utils_ref.nms_classwise(utils_ref.merge_boxes_decoded(parts), c)
+        assert np.array_equal(got[i].boxes.cpu().numpy(), exp.boxes) and np.array_equal(got[i].class_ids.cpu().numpy(), exp.class_ids)
+        kept += len(exp.scores)
+    assert kept > 0
+
+
 def test_boxes_decode_and_nms_api(dev):
     import utils
     rng = np.random.default_rng(3)

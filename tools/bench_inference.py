@@ -20,9 +20,9 @@ def main(backbone="resnet_50", size=1024, batch=16, iters=5):
         with torch.no_grad():
             out = net(image, training=False)
             probs = {k: ops.activation(v, "sigmoid") for k, v in out["classifications"].items()}
-            dec = {k: utils.regression_postprocess(out["regressions"][k], anchors[k]) for k in lv}
             rows = sum(v.numel() // 80 for v in probs.values())
-            return utils.detect(probs, dec, 80, score_threshold=0.0105, capacity=int(rows * 0.5), return_raw=True)
+            return utils.detect_raw(probs, out["regressions"], anchors, 80, score_threshold=0.0105, capacity=int(rows * 0.5),
+                                    return_raw=True)
 
     for dtype in ("f32", "f16"):
         layers.set_inference_dtype(dtype)
