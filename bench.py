@@ -78,48 +78,33 @@ def make_batch(rank, device):
 
 
 class Step(object):
-    """assignment + train step; everything device-side is enqueued on the current stream."""
+    """assignment + train step; the replica-local work is train.Trainer's two backward segments (each one hipGraph), the
+    gradient all-reduce of the heads + FPN region runs under the backbone's backward pass."""
 
-    def __init__(self, device, use_graph, loss_mode, dropout, rank):
+    def __init__(self, device, use_graph, loss_mode, dropout, rank, overlap=True, force_collective=False):
         import dataset, layers, levels, retinanet, train
         torch.manual_seed(0)                       # identical initial weights on every rank
         self.levels = levels.build_levels()
         if os.environ.get("RN_HEADS_TWO_STREAMS"):     # tuning aid (see retinanet.HEADS_TWO_STREAMS)
             retinanet.HEADS_TWO_STREAMS = os.environ["RN_HEADS_TWO_STREAMS"] == "1"
         self.net = retinanet.RetinaNet('mobilenet_v2', self.levels, NUM_CLASSES, layers.elu, dropout).to(device)
-        self.trainer = train.Trainer(self.net, self.levels, optimizer='momentum', learning_rate=1e-2,
-                                     loss_mode=loss_mode, device=device, use_graph=False,
-                                     wgrad_side_stream=os.environ.get("RN_WGRAD_SIDE_STREAM") == "1")
         self.image, self.boxes, self.cls, self.nobj = make_batch(rank, device)
         self.dataset = dataset
-        self.use_graph = use_graph
-        self.graph = None
-        self.out = None
+        self.trainer = train.Trainer(self.net, self.levels, optimizer='momentum', learning_rate=1e-2,
+                                     loss_mode=loss_mode, device=device, use_graph=use_graph, overlap=overlap,
+                                     force_collective=force_collective, input_fn=self.features,
+                                     wgrad_side_stream=os.environ.get("RN_WGRAD_SIDE_STREAM") == "1")
+        train.broadcast_initial_state(self.trainer)
 
-    def local(self):
+    def features(self):
+        """Device-side anchor assignment of the batch (inside the timed step, inside segment A's graph)."""
         c, r, m = self.dataset.build_labels((IMAGE_SIZE, IMAGE_SIZE), self.cls, self.boxes, self.levels, NUM_CLASSES,
                                             num_obj=self.nobj)
-        feats = {'image': self.image, 'detection': {'classifications': c, 'regressions': r}, 'trainable_masks': m}
-        return self.trainer.forward_backward(feats)
+        return {'image': self.image, 'detection': {'classifications': c, 'regressions': r}, 'trainable_masks': m}
 
     def __call__(self):
-        if self.use_graph:
-            if self.graph is None:
-                s = torch.cuda.Stream()
-                s.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s):
-                    for _ in range(2):
-                        self.local()
-                torch.cuda.current_stream().wait_stream(s)
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):  # RCCL watchdog threads may poll events meanwhile
-                    self.out = self.local()
-            self.graph.replay()
-        else:
-            self.out = self.local()
-        scale = self.trainer.allreduce()
-        self.trainer.opt.step(scale)
-        return self.out
+        out = self.trainer.step()
+        return out['class_loss'], out['regr_loss']
 
 
 def time_dominant_kernel(device, iters=100):
@@ -266,40 +251,89 @@ def cpu_baseline(max_seconds=30.0):
                       "torch-CPU fp32 oracle restating the reference's TF graph (TensorFlow not installable)" % steps}
 
 
+def _free_port():
+    import socket
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) with
+    torch.distributed.run as a CHILD process and hand back its exit code.  This parent has not touched the GPU
+    (torch.cuda.device_count() does not initialise it), and it never replaces itself with another program."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if args.gpus > have:
+        raise SystemExit("bench.py --gpus %d: this node has %d GPU(s)" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def ensure_built():
+    """(Re)build librn_hip.so when it is missing or older than a kernel source (hipcc cross-compiles; seconds when warm)."""
+    import glob
+    import subprocess
+    src = os.path.join(ROOT, "retinanet-tensorflow_amd", "csrc")
+    so = os.path.join(ROOT, "retinanet-tensorflow_amd", "librn_hip.so")
+    deps = glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")) + glob.glob(os.path.join(src, "*.cpp")) + \
+        [os.path.join(ROOT, "include", "rn_hip.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.run(["make", "-C", src, "-j8"], check=True, stdout=sys.stderr)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraphs")
     ap.add_argument("--loss", default="focal", choices=["focal", "bce_dice"])
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true", help="skip the decode+NMS throughput measurement")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the kernel micro-timings behind `roofline`")
+    ap.add_argument("--no-overlap", action="store_true", help="one backward segment, all-reduce after it (A/B aid)")
+    ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="issue the RCCL all-reduces even with one rank (self-test of the multi-GPU path on a 1-GPU box)")
     args = ap.parse_args()
+
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not launched and (args.gpus > 1 or args.spawn):
+        ensure_built()
+        sys.exit(spawn_ranks(args, [a for a in sys.argv[1:] if a != "--spawn"]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
+    if launched and world != args.gpus:
+        raise SystemExit("bench.py --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if rank == 0 and not launched:
+        ensure_built()
+    import train
+    device, rank, world, started = train.init_distributed()
+    dist = None
+    if started:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        world = dist.get_world_size()              # the ranks RCCL actually connected
     import _rn
     _rn.lib()
 
-    step = Step(device, use_graph=not args.no_graph, loss_mode=args.loss, dropout=args.dropout, rank=rank)
+    step = Step(device, use_graph=not args.no_graph, loss_mode=args.loss, dropout=args.dropout, rank=rank,
+                overlap=not args.no_overlap, force_collective=args.force_collective)
     for _ in range(args.warmup):
         step()
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    step.trainer.timing = {}
 
     barrier()
     t0 = time.perf_counter()
@@ -307,11 +341,13 @@ def main():
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    exposed = step.trainer.allreduce_exposed_ms()
+    if dist is not None:
+        t = torch.tensor([elapsed, exposed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, exposed = float(t[0].item()), float(t[1].item())
     losses = [float(x) for x in out]
+    step.trainer.check_device_errors()
 
     result = None
     if rank == 0:
@@ -327,7 +363,13 @@ def main():
                                    "%s + smooth-L1, dropout %.2f, momentum SGD, anchor assignment in the step" %
                                    (args.loss, args.dropout),
                        "global_batch": world * BATCH, "image_size": IMAGE_SIZE, "parallelism": "dp%d" % world,
-                       "hip_graph": not args.no_graph, "final_class_loss": round(losses[0], 6),
+                       "hip_graph": not args.no_graph, "backward_segments": 2 if step.trainer.cut_offset else 1,
+                       "allreduce": {"backend": "rccl" if dist is not None else None, "ranks": world,
+                                     "collectives_issued": bool(step.trainer.allreduce.active),
+                                     "bytes_overlapped_with_backbone_backward": 4 * (step.trainer.arena.count - step.trainer.cut_offset),
+                                     "bytes_after_backward": 4 * step.trainer.cut_offset,
+                                     "allreduce_exposed_ms": round(exposed, 4)},
+                       "final_class_loss": round(losses[0], 6),
                        "final_regr_loss": round(losses[1], 6),
                        "gn_barrier_timeouts": __import__("_rn").barrier_timeouts(),
                        "conv_roofline_frac_whole_step": round(ips / world * TRAIN_GFLOP_PER_IMAGE / 1e3 /
@@ -346,7 +388,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -306,6 +306,16 @@ int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, fl
 int rn_loss_bwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, const float* stats,
                 const float* g_cls, const float* g_reg, rn_stream_t stream);
 
+/* ------------------------------------------------------------------ IoU
+ * Replaces utils.iou (utils.py:62-97; known answers utils_test.py:99-118): boxes are corners [y1, x1, y2, x2].
+ * pairwise != 0: out[i * nb + j] = IoU(a[i], b[j]) -- the [O,1,1,1,4] x [1,H,W,A,4] -> [O,H,W,A] broadcast of
+ * dataset.py:57-60; pairwise == 0 (na == nb): out[i] = IoU(a[i], b[i]).  Boxes that do not overlap give 0
+ * (utils.py:82-86); `malformed` (one int32, zeroed by the caller) is set to 1 if any box has y2 < y1 or x2 < x1
+ * (the reference's tf.assert_* at utils.py:65-68).  Same float32 operation order as the assignment kernel.
+ */
+int rn_iou(const float* a, int64_t na, const float* b, int64_t nb, int pairwise, float* out, int32_t* malformed,
+           rn_stream_t stream);
+
 /* ------------------------------------------------------------------ anchor assignment
  * Replaces dataset.level_labels / build_labels (dataset.py:43-142) for a batch of images:
  * IoU of every anchor with every object -> arg-max/max -> one-hot class (zero where IoU<0.5),

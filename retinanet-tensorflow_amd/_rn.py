@@ -87,7 +87,7 @@ SYMBOLS = [
     "rn_pack_weights_f16", "rn_cast_f32_to_f16", "rn_pad_cast_rgb_f16", "rn_conv2d_fwd_f16", "rn_maxpool_fwd_f16", "rn_upsample_add_fwd_f16",
     "rn_act_fwd_f16", "rn_flip_width", "rn_dropout", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_maxpool_bwd_arg", "rn_avgpool_fwd", "rn_avgpool_bwd",
     "rn_loss_workspace", "rn_loss_fwd", "rn_loss_bwd",
-    "rn_anchor_assign", "rn_anchor_assign_levels", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
+    "rn_iou", "rn_anchor_assign", "rn_anchor_assign_levels", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
     "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
     "rn_optimizer_workspace", "rn_grad_norm_l2reg", "rn_optimizer_step",
 ]
@@ -169,6 +169,7 @@ def lib():
                                   C.c_void_p]
         L.rn_loss_bwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]
+        L.rn_iou.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rn_anchor_assign.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 4 + \
                                       [C.c_void_p] * 4 + [C.c_void_p]
         L.rn_anchor_assign_levels.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -35,6 +35,29 @@ __device__ __forceinline__ float cell_center(int i, int size) {
   return start + t;
 }
 
+// utils.iou (utils.py:62-97) of two corner boxes, every float32 operation rounded on its own and in the reference's order
+__device__ __forceinline__ float iou_corners(float a0, float a1, float a2, float a3, float area_a,
+                                             float b0, float b1, float b2, float b3) {
+  const float yt = fmaxf(a0, b0), xl = fmaxf(a1, b1), yb = fminf(a2, b2), xr = fminf(a3, b3);
+  const bool invalid = (yb < yt) || (xr < xl);
+  const float inter = (yb - yt) * (xr - xl);
+  const float area_b = (b2 - b0) * (b3 - b1);
+  const float den = (area_a + area_b) - inter;
+  const float v = inter / den;
+  return invalid ? 0.f : v;
+}
+
+__global__ __launch_bounds__(T) void iou_kernel(const float4* __restrict__ a, int64_t na, const float4* __restrict__ b,
+                                                int64_t nb, int pairwise, float* __restrict__ out, int32_t* malformed) {
+  const int64_t total = pairwise ? na * nb : na;
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < total; i += (int64_t)gridDim.x * T) {
+    const float4 pa = a[pairwise ? i / nb : i];
+    const float4 pb = b[pairwise ? i % nb : i];
+    if (malformed && (pa.z < pa.x || pa.w < pa.y || pb.z < pb.x || pb.w < pb.y)) *malformed = 1;
+    out[i] = iou_corners(pa.x, pa.y, pa.z, pa.w, (pa.z - pa.x) * (pa.w - pa.y), pb.x, pb.y, pb.z, pb.w);
+  }
+}
+
 __global__ __launch_bounds__(T) void assign_kernel(const AssignArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
@@ -73,14 +96,7 @@ __global__ __launch_bounds__(T) void assign_kernel(const AssignArgs a) {
         const float cy = tb[0] + sh / 2.0f, cx = tb[1] + sw / 2.0f;
         const float th = sh / 2.0f, tw = sw / 2.0f;
         const float b0 = cy - th, b1 = cx - tw, b2 = cy + th, b3 = cx + tw;
-        // utils.iou (utils.py:62-97)
-        const float yt = fmaxf(a0, b0), xl = fmaxf(a1, b1), yb = fminf(a2, b2), xr = fminf(a3, b3);
-        const bool invalid = (yb < yt) || (xr < xl);
-        const float inter = (yb - yt) * (xr - xl);
-        const float area_b = (b2 - b0) * (b3 - b1);
-        const float den = (area_a + area_b) - inter;
-        float v = inter / den;
-        if (invalid) v = 0.f;
+        const float v = iou_corners(a0, a1, a2, a3, area_a, b0, b1, b2, b3);   // utils.iou (utils.py:62-97)
         if (o == 0 || v > best) {  // arg-max keeps the FIRST maximum
           best = v; best_i = o; bcy = cy; bcx = cx; bsh = sh; bsw = sw;
         }
@@ -110,6 +126,20 @@ __global__ __launch_bounds__(T) void assign_kernel(const AssignArgs a) {
   }
 }
 }  // namespace
+
+extern "C" int rn_iou(const float* a, int64_t na, const float* b, int64_t nb, int pairwise, float* out, int32_t* malformed,
+                      rn_stream_t stream) {
+  RN_CHECK_ARG(a && b && out, "iou: null pointer");
+  RN_CHECK_ARG(na >= 0 && nb >= 0 && (pairwise || na == nb), "iou: element-wise mode needs na == nb");
+  const int64_t total = pairwise ? na * nb : na;
+  if (total == 0) return RN_OK;
+  int64_t blocks = (total + T - 1) / T;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(iou_kernel, dim3((unsigned)blocks), dim3(T), 0, (hipStream_t)stream, (const float4*)a, na,
+                     (const float4*)b, nb, pairwise, out, malformed);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
 
 extern "C" int rn_anchor_assign_levels(const float* boxes, const int32_t* class_ids, const int32_t* num_obj, int nimg,
                                        int max_obj, const rn_assign_level* levels, int nlevel, int num_anchors,

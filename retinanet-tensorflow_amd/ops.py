@@ -726,6 +726,11 @@ class _Dropout(torch.autograd.Function):
         return dx, None, None, None
 
 
+def advance_dropout_counter(counter):
+    """Next step's dropout masks: the device-side word every fused dropout hashes with (captured in the step's graph)."""
+    counter += 0x9E3779B9
+
+
 def dropout(x, rate, seed=0, seed_dev=None):
     if rate == 0.0:
         return x

@@ -170,9 +170,14 @@ class RetinaNetBase(Model):
         self.regression_subnet = RegressionSubnet(
             num_anchors=levels.num_anchors, activation=activation, kernel_initializer=kernel_initializer,
             kernel_regularizer=kernel_regularizer, name='regression_subnet')
+        # train.Trainer installs a callable here that replaces the taps the FPN reads by detached leaves, so the
+        # backward pass runs in two segments (heads + FPN first, their gradient all-reduce under the backbone's)
+        self.backward_cut = None
 
     def call(self, input, training):
         bottom_up = self.backbone(input, training)
+        if self.backward_cut is not None and training and torch.is_grad_enabled():
+            bottom_up = self.backward_cut(bottom_up)
         top_down = self.fpn(bottom_up, training)
         keys = list(top_down.keys())
         maps = [top_down[k] for k in keys]

@@ -99,43 +99,91 @@ class Optimizer(object):
 class GradientAllReduce(object):
     """MirroredStrategy's cross-replica gradient sum (train.py:261-267) as RCCL all-reduces of
     contiguous arena slices.  xGMI is point-to-point (7 links x ~153 GB/s), ring collectives are
-    per-link bound, so the arena goes out as FEW LARGE buckets (default 64 MB: the whole 40 MB arena of the
-    headline config is ONE message) rather than one
-    message per tensor; the 1/world_size average is folded into the optimizer kernel."""
+    per-link bound, so a region goes out as FEW LARGE buckets (default 64 MB: the whole 40 MB arena of the
+    headline config would be ONE message) rather than one message per tensor; the 1/world_size average is
+    folded into the optimizer kernel.
 
-    def __init__(self, arena, process_group=None, bucket_bytes=64 << 20):
+    launch(start, end) enqueues the (asynchronous) all-reduce of grads[start:end] behind the work already
+    queued on the current stream and returns at once: the collective runs on the process group's own
+    stream while the current stream goes on with the next backward segment; wait() joins."""
+
+    def __init__(self, arena, process_group=None, bucket_bytes=64 << 20, force=False):
         import torch.distributed as dist
         self.dist, self.group, self.arena = dist, process_group, arena
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        n = arena.count
-        per = max(OPT_BLOCK, (bucket_bytes // 4) // OPT_BLOCK * OPT_BLOCK)
-        self.buckets = [(s, min(s + per, n)) for s in range(0, n, per)]
+        # force: issue the collectives even with one rank (self-tests of the RCCL path on a 1-GPU box)
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
+        self.per = max(OPT_BLOCK, (int(bucket_bytes) // 4) // OPT_BLOCK * OPT_BLOCK)
+        # a backend without device collectives (gloo: debugging, tests with several processes on one GPU) gets the
+        # bucket through host memory, synchronously; the production backend ('nccl' = RCCL) reduces in place in HBM
+        self.host_staged = bool(self.active and arena.grads.is_cuda and dist.get_backend(process_group) != 'nccl')
+        self.buckets = self.buckets_of(0, arena.count)
+        self._works = []
+        self.launched = []          # (start, end) of every bucket issued since the last wait(): for tests
+
+    def buckets_of(self, start, end):
+        return [(s, min(s + self.per, end)) for s in range(start, end, self.per)]
+
+    def launch(self, start=0, end=None):
+        end = self.arena.count if end is None else end
+        if not self.active or end <= start:
+            return
+        # last bucket first: within a region the later layers' gradients were produced first
+        for s, e in reversed(self.buckets_of(start, end)):
+            if self.host_staged:
+                host = self.arena.grads[s:e].cpu()
+                self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+                self.arena.grads[s:e].copy_(host)
+                self.launched.append((s, e))
+                continue
+            self._works.append(self.dist.all_reduce(self.arena.grads[s:e], op=self.dist.ReduceOp.SUM, group=self.group,
+                                                    async_op=True))
+            self.launched.append((s, e))
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        del self._works[:]
+        return 1.0 / self.world
 
     def __call__(self):
-        if self.world == 1:
-            return 1.0
-        # reverse order: the heads' gradients (end of the arena, 64 % of the bytes) are complete first
-        works = [self.dist.all_reduce(self.arena.grads[s:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-                 for s, e in reversed(self.buckets)]
-        for w in works:
-            w.wait()
-        return 1.0 / self.world
+        self.launch(0, self.arena.count)
+        return self.wait()
 
 
 class Trainer(object):
     """One data-parallel replica.  `step(features)` = forward + loss + backward + gradient
-    all-reduce + optimizer.  With use_graph=True the replica-local part is one hipGraph."""
+    all-reduce + optimizer.
+
+    Backward runs in TWO segments (`overlap=True`): (A) forward, loss and the backward pass of the heads + FPN --
+    82 % of the gradient bytes of the headline config, complete first -- then (B) the backward pass of the
+    backbone.  The all-reduce of region A's slice of the gradient arena is launched between the two and runs on
+    RCCL's stream underneath segment B; only the (small) backbone slice is reduced after it.  The cut is made
+    with detached leaves at the backbone taps the FPN reads (RetinaNetBase.backward_cut), so the arithmetic is
+    unchanged.  With use_graph=True each segment is one hipGraph (shared memory pool, always replayed A then
+    B); the collectives stay eager launches between the replays."""
 
     def __init__(self, net, levels=None, optimizer='momentum', learning_rate=1e-2, grad_clip_norm=None,
                  loss_mode='bce_dice', device='cuda', use_graph=False, process_group=None,
-                 direct_param_grads=True, wgrad_side_stream=False, defer_reductions=True):
+                 direct_param_grads=True, wgrad_side_stream=False, defer_reductions=True, overlap=True,
+                 force_collective=False, input_fn=None, check_interval=50):
         self.net, self.levels = net, levels or build_levels()
         self.device = torch.device(device)
+        if self.device.type == 'cuda':
+            if self.device.index is None:
+                self.device = torch.device('cuda', torch.cuda.current_device())
+            # the kernels are launched on the CURRENT device's current stream with raw pointers
+            assert torch.cuda.current_device() == self.device.index, \
+                "call torch.cuda.set_device(%d) before building the Trainer" % self.device.index
+        if optimizer == 'adam' and use_graph:
+            raise ValueError("optimizer='adam' cannot run with use_graph=True: its bias-corrected learning rate changes "
+                             "every step and is a launch argument of the optimizer kernel")
         self.loss_mode = loss_mode
         self.arena = ParamArena(net, self.device)
         self.opt = Optimizer(self.arena, optimizer, learning_rate, grad_clip_norm)
-        self.allreduce = GradientAllReduce(self.arena, process_group)
+        self.allreduce = GradientAllReduce(self.arena, process_group, force=force_collective)
         self.use_graph = use_graph
+        self.input_fn = input_fn       # optional: features = input_fn(), run INSIDE segment A (e.g. device-side label assignment)
         self.defer_reductions = (bool(defer_reductions) and bool(direct_param_grads) and
                                  os.environ.get("RN_DEFER_REDUCTIONS", "1") == "1")
         # kernels write parameter gradients straight into the arena (every parameter of this network
@@ -144,24 +192,39 @@ class Trainer(object):
         # ... which would let the weight-gradient kernels run on a side stream under the dgrad / GroupNorm chain;
         # measured on MI355X: 162 vs 170 img/s (fork/join edges + CU contention cost more than the overlap buys), so off
         ops.WGRAD_SIDE_STREAM = bool(direct_param_grads) and bool(wgrad_side_stream)
-        self._graph = None
+        # backward segments: arena offset where the FPN's parameters start (arena order = registration order =
+        # backbone, fpn, classification_subnet, regression_subnet)
+        self.cut_offset = 0
+        base = getattr(net, 'base', None)
+        if overlap and base is not None and hasattr(base, 'backward_cut') and hasattr(base, 'fpn'):
+            first = next(iter(base.fpn.parameters()), None)
+            for p, (off, _) in zip(self.arena.params, self.arena.offsets):
+                if p is first:
+                    self.cut_offset = off
+            if self.cut_offset:
+                base.backward_cut = self._cut
+        self._cut_src = self._cut_leaves = None
+        self._graphs = None
         self._static = None
         self.drop_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
         L.Dropout.seed_device_counter = self.drop_counter
+        self.check_interval = int(check_interval)
+        self.steps_done = 0
+        self.timing = None             # set to {} to collect 'allreduce_exposed_ms' (events around the final wait)
         self.last = {}
 
     # -- replica-local work (capturable)
-    def forward_backward(self, features):
-        logits = {'detection': self.net(features['image'], training=True)}
-        inp, logits = utils.process_labels_and_logits(labels=features, logits=logits, levels=self.levels)
-        class_loss, regr_loss = losses.loss(labels=inp['detection_trainable'], logits=logits['detection_trainable'],
-                                            mode=self.loss_mode)
-        # kernels that write a parameter's gradient directly overwrite it; gradients that reach a parameter
-        # through autograd (e.g. the concatenated head kernels) are accumulated -> the arena starts at zero
-        self.arena.zero_grad()
+    def _cut(self, taps):
+        """RetinaNetBase.backward_cut: the FPN reads detached leaves; segment B feeds their gradients back."""
+        keys = [k for k in ('C3', 'C4', 'C5') if k in taps]
+        self._cut_src = [taps[k] for k in keys]
+        self._cut_leaves = [t.detach().requires_grad_(True) for t in self._cut_src]
+        return {**taps, **dict(zip(keys, self._cut_leaves))}
+
+    def _backward(self, roots, grads):
         defer = self.defer_reductions and self.device.type == 'cuda' and ops.DIRECT_PARAM_GRADS
-        if defer:                                  # ~130 gradient row reductions -> one launch after backward
+        if defer:                                  # ~130 gradient row reductions -> one launch per segment
             import retinanet
             extra = [retinanet.side_stream(self.device)] if retinanet.HEADS_TWO_STREAMS else []
             if ops.WGRAD_SIDE_STREAM:
@@ -170,45 +233,108 @@ class Trainer(object):
                 extra = []
             ops.begin_deferred_reductions(extra)
         try:
-            # d(class_loss + regr_loss): both roots seeded with the same pre-allocated 1 (no add / fill kernels in the step)
-            torch.autograd.backward([class_loss, regr_loss], [self._one, self._one])
+            torch.autograd.backward(roots, grads)
         finally:
             if defer:
                 ops.end_deferred_reductions()
-        # weight-gradient kernels run on a side stream (ops.WGRAD_SIDE_STREAM) and write straight into the
-        # arena: join every side stream before anything reads the arena
+        # weight-gradient kernels may run on side streams and write straight into the arena: join them before
+        # anything (the collective, the optimizer) reads it
         if self.device.type == 'cuda':
             _rn.join_side_streams(self.device)
-        self.drop_counter += 0x9E3779B9            # fresh dropout masks next step (device-side counter)
+
+    def segment_a(self, features=None):
+        """forward + loss + backward of the heads and the FPN (the whole backward pass when there is no cut)."""
+        if features is None:
+            features = self.input_fn()
+        self._cut_src = self._cut_leaves = None
+        logits = {'detection': self.net(features['image'], training=True)}
+        inp, logits = utils.process_labels_and_logits(labels=features, logits=logits, levels=self.levels)
+        class_loss, regr_loss = losses.loss(labels=inp['detection_trainable'], logits=logits['detection_trainable'],
+                                            mode=self.loss_mode)
+        # kernels that write a parameter's gradient directly overwrite it; gradients that reach a parameter
+        # through autograd (e.g. the concatenated head kernels) are accumulated -> the arena starts at zero
+        self.arena.zero_grad()
+        # d(class_loss + regr_loss): both roots seeded with the same pre-allocated 1 (no add / fill kernels in the step)
+        self._backward([class_loss, regr_loss], [self._one, self._one])
         return class_loss.detach(), regr_loss.detach()
 
-    def _run_local(self, features):
-        if not self.use_graph:
-            return self.forward_backward(features)
-        if self._graph is None:
-            self._static = features
-            # warm-up on a side stream (allocator + workspace sizing), then capture
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(2):
-                    self.forward_backward(self._static)
-            torch.cuda.current_stream().wait_stream(s)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
-                self._graph_out = self.forward_backward(self._static)
-        else:
-            _copy_tree(self._static, features)
-        self._graph.replay()
-        return self._graph_out
+    def segment_b(self):
+        """backward of the backbone from the gradients segment A left at the cut."""
+        if self._cut_src is not None:
+            src, leaves = self._cut_src, self._cut_leaves
+            self._cut_src = self._cut_leaves = None
+            self._backward(src, [l.grad for l in leaves])
+        ops.advance_dropout_counter(self.drop_counter)    # fresh dropout masks next step (device-side counter)
 
-    def step(self, features):
-        class_loss, regr_loss = self._run_local(features)
-        grad_scale = self.allreduce()
+    def forward_backward(self, features=None):
+        out = self.segment_a(features)
+        self.segment_b()
+        return out
+
+    def _capture(self, features):
+        self._static = features
+        # warm-up on a side stream (allocator + workspace sizing), then capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.forward_backward(self._static)
+        torch.cuda.current_stream().wait_stream(s)
+        ga = torch.cuda.CUDAGraph()
+        # thread_local: RCCL's watchdog thread may poll events while the capture is open
+        with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+            self._graph_out = self.segment_a(self._static)
+        gb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+            self.segment_b()
+        self._graphs = (ga, gb)
+
+    def step(self, features=None):
+        if self.use_graph:
+            if self._graphs is None:
+                self._capture(features)
+            elif features is not None:
+                _copy_tree(self._static, features)
+            self._graphs[0].replay()
+            class_loss, regr_loss = self._graph_out
+        else:
+            class_loss, regr_loss = self.segment_a(features)
+        self.allreduce.launch(self.cut_offset, self.arena.count)      # heads + FPN: under the backbone's backward pass
+        if self.use_graph:
+            self._graphs[1].replay()
+        else:
+            self.segment_b()
+        self.allreduce.launch(0, self.cut_offset)
+        if self.timing is not None and self.device.type == 'cuda':
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            grad_scale = self.allreduce.wait()
+            e1.record()
+            self.timing.setdefault('exposed_events', []).append((e0, e1))
+        else:
+            grad_scale = self.allreduce.wait()
         self.opt.step(grad_scale)
+        self.steps_done += 1
+        if self.check_interval and self.steps_done % self.check_interval == 0:
+            self.check_device_errors()
         self.last = {'class_loss': class_loss, 'regr_loss': regr_loss,
                      'regularization_loss': self.opt.regularization_loss}
         return self.last
+
+    def allreduce_exposed_ms(self):
+        """Mean time the compute stream waited for collectives after the last backward kernel (needs timing = {})."""
+        ev = (self.timing or {}).get('exposed_events', [])
+        if not ev:
+            return 0.0
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in ev) / len(ev))
+
+    def check_device_errors(self):
+        """Raise if any kernel of this process has flagged an error on the device (synchronises)."""
+        n = _rn.barrier_timeouts()
+        if n:
+            raise _rn.RnError("%d GroupNorm exchange wait(s) timed out: the results of this run are invalid "
+                              "(set RN_GN_GRID_RESIDENT=0 on a shared / partitioned GPU)" % n)
 
 
 def _copy_tree(dst, src):
@@ -282,41 +408,84 @@ def build_parser():
     return parser
 
 
+def init_distributed(backend=None):
+    """One process per GPU, like the reference picks MirroredStrategy from the number of GPUs (train.py:261-267):
+    rank / world size / device come from the launcher's environment (python -m torch.distributed.run, or
+    bench.py --gpus N which starts that itself).  Returns (device, rank, world, process_group_initialised).
+    Must run before anything else touches the GPU: it selects the device every kernel launch then uses."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise _rn.RnError("training needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    started = False
+    if 'WORLD_SIZE' in os.environ and 'RANK' in os.environ:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if not dist.is_initialized():
+            dist.init_process_group(backend or 'nccl', rank=rank, world_size=world,
+                                    **({'device_id': dev} if (backend or 'nccl') == 'nccl' else {}))
+            started = True
+    return dev, rank, world, started
+
+
+def broadcast_initial_state(trainer, src=0):
+    """Replicas must start from identical variables (MirroredStrategy creates them once and mirrors them)."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(trainer.arena.weights, src=src)
+        dist.broadcast(trainer.opt.state1, src=src)
+        if trainer.opt.state2 is not None:
+            dist.broadcast(trainer.opt.state2, src=src)
+
+
 def main(argv=None):
     import checkpoint
     import dataset
     import retinanet
     args = build_parser().parse_args(argv)
     assert args.dataset[0] == 'shapes', 'only the synthetic shapes loader is built in (file readers are out of scope)'
-    dev = torch.device('cuda', int(__import__('os').environ.get('LOCAL_RANK', '0')))
+    dev, rank, world, started = init_distributed()
     from data_loaders.shapes import Shapes
-    loader = Shapes(None, image_size=(args.scale + args.scale // 4, args.scale))   # rescale_image brings it to --scale
+    # every replica draws its own samples (dataset.py:182-204: a replica's batch is [sample, hflip(sample)])
+    loader = Shapes(None, image_size=(args.scale + args.scale // 4, args.scale), seed=rank)   # rescale_image brings it to --scale
     levels = build_levels()
+    torch.manual_seed(0)                                                           # same initial weights on every rank
     net = retinanet.RetinaNet(backbone=args.backbone, levels=levels, num_classes=loader.num_classes, activation=L.elu,
                               dropout_rate=args.dropout).to(dev)
     trainer = Trainer(net, levels, optimizer=args.optimizer, learning_rate=args.learning_rate,
                       grad_clip_norm=args.grad_clip_norm, loss_mode=args.loss, device=dev)
     step = 0
-    path = None if args.experiment is None else __import__('os').path.join(args.experiment, 'model.safetensors')
-    if path is not None and __import__('os').path.exists(path):
-        step = checkpoint.load(path, net, trainer)
-        print('restored step', step)
+    path = None if args.experiment is None else os.path.join(args.experiment, 'model.safetensors')
+    if path is not None and os.path.exists(path):
+        step = checkpoint.load(path, net, trainer)                                 # every rank reads the same file
+        if rank == 0:
+            print('restored step', step)
+    broadcast_initial_state(trainer)
     it = dataset.build_dataset(loader, levels, scale=args.scale, device=dev)       # train.py:192-203 train_input_fn
     for epoch in range(args.epochs):
         for _ in range(args.steps_per_epoch):
             out = trainer.step(next(it))                                           # batch = [image, hflip]
             step += 1
-            if step % 20 == 0:
+            if step % 20 == 0 and rank == 0:
                 print('epoch %d step %d class_loss %.4f regr_loss %.4f reg %.4f' % (
                     epoch, step, out['class_loss'].item(), out['regr_loss'].item(), out['regularization_loss'].item()),
                     flush=True)
-        if path is not None:
+        trainer.check_device_errors()
+        if path is not None and rank == 0:                                         # replicas are identical: rank 0 writes
             checkpoint.save(path, net, trainer, step=step)
-    if args.eval_images:
+    if args.eval_images and rank == 0:
         res = evaluate(net, Shapes(None, image_size=(args.scale + args.scale // 4, args.scale), seed=12345), levels,
                        args.eval_images, scale=args.scale, device=dev)
         print('eval: mAP %.4f AP50 %.4f AP75 %.4f class_iou %.4f regr_iou %.4f over %d images' % (
             res['mAP'], res['AP50'], res['AP75'], res['class_iou'], res['regr_iou'], res['images']), flush=True)
+    if started:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return step
 
 

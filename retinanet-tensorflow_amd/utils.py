@@ -235,19 +235,35 @@ def detect_raw(class_probs, regressions, anchor_sizes, num_classes, score_thresh
 
 
 def iou(a, b, name='iou'):
-    """utils.py:62-97 with broadcasting (host-side helper: not on the device hot path, the
-    assignment kernel has its own IoU)."""
-    assert bool((a[..., :2] <= a[..., 2:]).all()) and bool((b[..., :2] <= b[..., 2:]).all())
-    y_top = torch.maximum(a[..., 0], b[..., 0])
-    x_left = torch.maximum(a[..., 1], b[..., 1])
-    y_bottom = torch.minimum(a[..., 2], b[..., 2])
-    x_right = torch.minimum(a[..., 3], b[..., 3])
-    invalid = (y_bottom < y_top) | (x_right < x_left)
-    inter = (y_bottom - y_top) * (x_right - x_left)
-    area_a = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
-    area_b = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
-    val = inter / (area_a + area_b - inter)
-    return torch.where(invalid, torch.zeros_like(val), val)
+    """utils.py:62-97 with broadcasting, on the device (rn_iou; the arithmetic the assignment kernel uses).
+    The reference's call shape -- a [O,1,1,1,4] against b [1,H,W,A,4] (dataset.py:57-60): the broadcast dims of a and
+    b do not overlap -- is a pairwise launch; equal shapes are element-wise; any other broadcast is expanded first."""
+    assert a.shape[-1] == 4 and b.shape[-1] == 4
+    sa, sb = tuple(a.shape[:-1]), tuple(b.shape[:-1])
+    nd = max(len(sa), len(sb))
+    sa, sb = (1,) * (nd - len(sa)) + sa, (1,) * (nd - len(sb)) + sb
+    out_shape = tuple(max(x, y) for x, y in zip(sa, sb))
+    assert all(x in (1, o) and y in (1, o) for x, y, o in zip(sa, sb, out_shape)), "iou: shapes do not broadcast"
+    af, bf = a.reshape(-1, 4).contiguous().float(), b.reshape(-1, 4).contiguous().float()
+    # pairwise iff every non-1 dim of a comes before every non-1 dim of b (then out[i, j] flattens to out_shape)
+    last_a = max([i for i, x in enumerate(sa) if x != 1], default=-1)
+    first_b = min([i for i, y in enumerate(sb) if y != 1], default=nd)
+    if sa == sb:
+        pairwise = 0
+    elif last_a < first_b:
+        pairwise = 1
+    else:
+        af = a.reshape(sa + (4,)).expand(out_shape + (4,)).reshape(-1, 4).contiguous().float()
+        bf = b.reshape(sb + (4,)).expand(out_shape + (4,)).reshape(-1, 4).contiguous().float()
+        pairwise = 0
+    out = torch.empty((af.shape[0] * bf.shape[0] if pairwise else af.shape[0],), dtype=torch.float32, device=a.device)
+    if out.numel() == 0:
+        return out.reshape(out_shape)
+    bad = torch.zeros((1,), dtype=torch.int32, device=a.device)
+    _rn.check(_rn.lib().rn_iou(_rn.f32(af), af.shape[0], _rn.f32(bf), bf.shape[0], pairwise, _rn.f32(out), _rn.ptr(bad),
+                               _rn.stream()), 'rn_iou')
+    assert int(bad.item()) == 0, 'iou: a box with y2 < y1 or x2 < x1 (utils.py:65-68)'
+    return out.reshape(out_shape)
 
 
 class _LazyLevels(dict):

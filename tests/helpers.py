@@ -35,9 +35,25 @@ def rel_err(a, b):
     return d / max(np.abs(b).max() if b.size else 0.0, 1e-30)
 
 
-def assert_close(a, b, tol, what=""):
+def elementwise_rel_err(a, b, floor_frac=1e-3):
+    """max_i |a_i - b_i| / max(|b_i|, floor_frac * max|b|): the element-wise relative error, with a floor so that
+    elements that are (analytically) zero and hold only rounding noise do not divide by ~0."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if not a.size:
+        return 0.0
+    floor = max(floor_frac * np.abs(b).max(), 1e-30)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor)).max())
+
+
+def assert_close(a, b, tol, what="", elementwise_tol=None):
+    """Max-norm relative error <= tol (the bar for tensors); the element-wise figure is computed and reported beside it,
+    and asserted too when `elementwise_tol` is given (losses, boxes: the quantities north_star's 1e-4 is stated on)."""
     e = rel_err(a, b)
-    assert e <= tol, "%s: max-norm relative error %.3e > %.1e" % (what, e, tol)
+    ew = elementwise_rel_err(a, b)
+    assert e <= tol, "%s: max-norm relative error %.3e > %.1e (element-wise %.3e)" % (what, e, tol, ew)
+    if elementwise_tol is not None:
+        assert ew <= elementwise_tol, "%s: element-wise relative error %.3e > %.1e (max-norm %.3e)" % (what, ew, elementwise_tol, e)
     return e
 
 

@@ -56,6 +56,98 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _trainer_worker(rank, world, port, out_dir):
+    """The REAL train.Trainer of a MobileNetV2-FPN RetinaNet (its parameter arena, its two backward segments, its
+    collective schedule and bucket arithmetic) with the device work replaced: the segments write rank-specific
+    gradients instead of launching kernels, the optimizer is a plain SGD update on the arena."""
+    for p in (ROOT, os.path.join(ROOT, "retinanet-tensorflow_amd")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import layers, levels, retinanet, train
+    torch.manual_seed(0)
+    lv = levels.build_levels()
+    net = retinanet.RetinaNet('mobilenet_v2', lv, 3, layers.elu, 0.0)
+    events = []
+
+    class FakeKernels(train.Trainer):
+        def segment_a(self, features=None):
+            g = torch.Generator().manual_seed(1000 * self.steps_done + rank)
+            self.arena.grads.zero_()
+            self.arena.grads[self.cut_offset:].copy_(torch.randn(self.arena.count - self.cut_offset, generator=g))
+            events.append("A")
+            return torch.zeros(()), torch.zeros(())
+
+        def segment_b(self):
+            # region A's collective was launched before this runs; it may already have summed that slice
+            g = torch.Generator().manual_seed(5000 + 1000 * self.steps_done + rank)
+            self.arena.grads[:self.cut_offset].copy_(torch.randn(self.cut_offset, generator=g))
+            events.append("B")
+
+    tr = FakeKernels(net, lv, device='cpu', learning_rate=0.1)
+    tr.allreduce.per = 1 << 18                                  # 1 MB buckets: several per region
+    first_fpn = next(iter(net.base.fpn.parameters()))
+    offs = {id(p): o for p, (o, _) in zip(tr.arena.params, tr.arena.offsets)}
+    assert tr.cut_offset == offs[id(first_fpn)] > 0
+    assert all(offs[id(p)] < tr.cut_offset for p in net.base.backbone.parameters())
+    assert all(offs[id(p)] >= tr.cut_offset for m in (net.base.fpn, net.base.classification_subnet, net.base.regression_subnet)
+               for p in m.parameters())
+    assert net.base.backward_cut is not None and tr.allreduce.active and tr.allreduce.world == world
+
+    def sgd(scale):
+        events.append("opt")
+        tr.arena.weights.sub_(tr.opt.lr * scale * tr.arena.grads)
+    tr.opt.step = sgd
+    orig_launch = tr.allreduce.launch
+
+    def launch(start=0, end=None):
+        events.append(("launch", start, tr.arena.count if end is None else end))
+        orig_launch(start, end)
+    tr.allreduce.launch = launch
+    for step in range(2):
+        del tr.allreduce.launched[:]
+        del events[:]
+        tr.step({})
+        # schedule: A, all-reduce(heads + FPN), B, all-reduce(backbone), optimizer
+        assert events == ["A", ("launch", tr.cut_offset, tr.arena.count), "B", ("launch", 0, tr.cut_offset), "opt"], events
+        # buckets tile the arena exactly once, on OPT_BLOCK boundaries
+        cover = sorted(tr.allreduce.launched)
+        assert cover[0][0] == 0 and cover[-1][1] == tr.arena.count and len(cover) > 4
+        assert all(a[1] == b[0] for a, b in zip(cover, cover[1:])) and all(s % train.OPT_BLOCK == 0 for s, _ in cover)
+        # the arena now holds the sum over ranks of what each rank's segments wrote
+        want = torch.zeros_like(tr.arena.grads)
+        for r in range(world):
+            g = torch.Generator().manual_seed(1000 * step + r)
+            want[tr.cut_offset:] += torch.randn(tr.arena.count - tr.cut_offset, generator=g)
+            g = torch.Generator().manual_seed(5000 + 1000 * step + r)
+            want[:tr.cut_offset] += torch.randn(tr.cut_offset, generator=g)
+        assert torch.allclose(tr.arena.grads, want, atol=1e-6)
+    w = [torch.zeros_like(tr.arena.weights) for _ in range(world)]
+    dist.all_gather(w, tr.arena.weights)
+    assert all(torch.equal(w[0], x) for x in w)                  # replicas identical after averaged updates
+    # the parameters still alias the arena (p.data / p.grad are views)
+    p0 = tr.arena.params[-1]
+    assert p0.data_ptr() == tr.arena.weights[tr.arena.offsets[-1][0]:].data_ptr()
+    np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([1]))
+    dist.destroy_process_group()
+
+
+def test_real_trainer_schedule_and_arena_world2(tmp_path):
+    world = 2
+    mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok_%d.npy" % r)) for r in range(world))
+
+
+def test_adam_with_graph_replay_is_refused():
+    sys.path.insert(0, os.path.join(ROOT, "retinanet-tensorflow_amd"))
+    import train
+    m = torch.nn.Module()
+    m.a = torch.nn.Parameter(torch.randn(10))
+    with pytest.raises(ValueError):
+        train.Trainer(m, device='cpu', optimizer='adam', use_graph=True)
+
+
 def test_bucketed_gradient_allreduce_world2(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)

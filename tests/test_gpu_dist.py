@@ -1,0 +1,76 @@
+"""The multi-GPU path on the 1-GPU box: RCCL process group of one rank with the collectives forced, the rank
+launcher of bench.py, and two processes averaging gradients.  Each case runs in fresh processes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _env():
+    return dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+
+
+def test_rccl_world1_forced_collectives_bit_equal_to_plain_step(tmp_path):
+    out = str(tmp_path / "nccl1.json")
+    r = subprocess.run([sys.executable, WORKER, "nccl1", out], env=_env(), timeout=600, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.load(open(out))
+    assert res["bit_equal_weights"], res
+    assert res["losses_plain"] == res["losses_dist"], res
+    assert 0 < res["cut_offset"] < res["count"]
+    # heads + FPN region first (issued under the backbone's backward pass), the backbone region after it
+    assert res["launched"][0][0] >= res["cut_offset"] and res["launched"][res["buckets_per_step"] - 1][1] <= res["cut_offset"]
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts the ranks itself (here N = 1 through the same path)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--force-collective",
+                        "--steps", "4", "--warmup", "3", "--no-cpu-baseline", "--no-nms", "--no-roofline"],
+                       env={k: v for k, v in _env().items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")},
+                       timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["steps"] == 4
+    ar = res["config"]["allreduce"]
+    assert ar["backend"] == "rccl" and ar["ranks"] == 1 and ar["collectives_issued"]
+    assert res["config"]["backward_segments"] == 2 and ar["bytes_overlapped_with_backbone_backward"] > ar["bytes_after_backward"] > 0
+    assert res["config"]["gn_barrier_timeouts"] == 0
+
+
+def test_two_replicas_equal_one_process_accumulating(tmp_path):
+    """R replicas (own batch each, gradients averaged by the collective) == one process accumulating the R
+    batches; replicas stay identical.  Two processes share cuda:0, gloo carries the sums (RCCL needs one GPU per rank)."""
+    world, port = 2, _free_port()
+    procs = [subprocess.Popen([sys.executable, WORKER, "pair", str(r), str(world), str(port), str(tmp_path)], env=_env(),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    w0, w1 = np.load(tmp_path / "w_0.npy"), np.load(tmp_path / "w_1.npy")
+    ws = np.load(tmp_path / "w_single.npy")
+    assert np.array_equal(w0, w1)
+    scale = float(np.abs(ws).max())
+    assert float(np.abs(w0 - ws).max()) <= 1e-6 * scale, float(np.abs(w0 - ws).max())
