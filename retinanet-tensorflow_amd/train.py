@@ -277,8 +277,10 @@ class Trainer(object):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
+            counter = self.drop_counter.clone()
             for _ in range(2):
                 self.forward_backward(self._static)
+            self.drop_counter.copy_(counter)       # the warm-up passes do not count: replay i draws the masks eager step i draws
         torch.cuda.current_stream().wait_stream(s)
         ga = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread may poll events while the capture is open

@@ -31,8 +31,8 @@ def test_rccl_world1_forced_collectives_bit_equal_to_plain_step(tmp_path):
     r = subprocess.run([sys.executable, WORKER, "nccl1", out], env=_env(), timeout=600, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.load(open(out))
-    assert res["bit_equal_weights"], res
     assert res["losses_plain"] == res["losses_dist"], res
+    assert res["bit_equal_weights"], res
     assert 0 < res["cut_offset"] < res["count"]
     # heads + FPN region first (issued under the backbone's backward pass), the backbone region after it
     assert res["launched"][0][0] >= res["cut_offset"] and res["launched"][res["buckets_per_step"] - 1][1] <= res["cut_offset"]
