@@ -306,6 +306,58 @@ int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, fl
 int rn_loss_bwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, const float* stats,
                 const float* g_cls, const float* g_reg, rn_stream_t stream);
 
+/* ------------------------------------------------------------------ GroupNorm folded into Winograd layers
+ * A chain [conv3x3, GroupNorm, activation] x k -> conv3x3 (the class / box subnets, retinanet.py:37-71,85-115; the
+ * GroupNorm is normalization.py:20-35) without GroupNorm kernels and without ever writing the normalised tensor:
+ * the output transform of a layer emits, per chunk of 16 Winograd tiles of one sample, the per-group statistics
+ * (count, mean, M2 = sum (y - mean)^2, unused) of the RAW conv output ("stat rows", rn_wino_gn_rows() rows of
+ * [groups][4] floats); the input transform of the next layer merges its sample's rows (Chan et al.'s pairwise
+ * update, fp64, chunk order: no E[y^2] - E[y]^2 cancellation) into mean / rstd and loads act(GN(y)) on the fly.  Backward likewise: the data gradient of the next layer leaves its output transform as
+ * g = dA * act'(z) together with rows of (sum g, sum g xhat) -- per channel for dgamma / dbeta (rn_reduce_rows) and
+ * gamma-weighted per group -- and the dy transforms of this layer load dy = rstd (gamma g - c1 - xhat c2) from g
+ * and the raw y.  No exchange between blocks, no atomics: every sum runs over rows an earlier launch wrote.
+ * Needs cin, cout multiples of 64 and 64 % (channels / groups) == 0 on a folded side (RN_EUNSUPPORTED otherwise).
+ */
+typedef struct rn_wino_gn {
+  /* input side: segs[].x is the raw output of the previous conv; NULL in_rows = x is used as it is */
+  const float* in_rows;   /* [rows][in_groups][4] written by the previous layer's call */
+  const float* in_gamma;  /* [cin] */
+  const float* in_beta;   /* [cin] */
+  int32_t in_groups, in_act;
+  float in_eps;
+  /* output side: NULL out_rows = no statistics */
+  float* out_rows;        /* [rows][out_groups][4] */
+  int32_t out_groups;
+} rn_wino_gn;
+size_t rn_wino_gn_rows(const rn_conv_seg* segs, int nseg, int tile);
+/* y = conv3x3_same(act(GN(x)), w) (+ bias).  Workspace / v_buf / urot_buf as rn_conv3x3_winograd. */
+int rn_conv3x3_winograd_gn(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, const float* bias, int tile,
+                           const rn_wino_gn* gn, void* workspace, size_t workspace_bytes, float* v_buf, float* urot_buf,
+                           rn_stream_t stream);
+typedef struct rn_wino_gn_bwd {
+  /* input side folded (in_rows != NULL): segs[].x = raw input tensor, segs[].dx receives g of the input's GroupNorm */
+  const float* in_rows;
+  const float* in_gamma;
+  const float* in_beta;
+  int32_t in_groups, in_act;
+  float in_eps;
+  float* in_g_rows_group; /* out: [rows][in_groups][2] (sum gamma g, sum gamma g xhat) */
+  float* in_g_rows_chan;  /* out: [2][rows][cin]: plane 0 sum g (-> dbeta), plane 1 sum g xhat (-> dgamma) */
+  /* output side folded (out_rows != NULL): segs[].y = raw conv output, segs[].dy = g of the GroupNorm after it */
+  const float* out_rows;
+  const float* out_g_rows_group;
+  const float* out_gamma;
+  int32_t out_groups;
+  float out_eps;
+} rn_wino_gn_bwd;
+/* dx (or g, see above) for every segment and dw (+)=; workspace rn_conv3x3_winograd_bwd_workspace bytes. */
+int rn_conv3x3_winograd_gn_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, float* dw, int accumulate,
+                               int tile, const rn_wino_gn_bwd* gn, void* workspace, size_t workspace_bytes, const float* v_buf,
+                               const float* urot_buf, rn_stream_t stream);
+/* out[i] = (accumulate ? out[i] : 0) + sum_r in[r * count + i], r < nrows, fixed order (bit-reproducible); joins the
+ * deferred batch while rn_defer_reductions is on for the stream.  Finishes dgamma / dbeta from in_g_rows_chan. */
+int rn_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, rn_stream_t stream);
+
 /* ------------------------------------------------------------------ IoU
  * Replaces utils.iou (utils.py:62-97; known answers utils_test.py:99-118): boxes are corners [y1, x1, y2, x2].
  * pairwise != 0: out[i * nb + j] = IoU(a[i], b[j]) -- the [O,1,1,1,4] x [1,H,W,A,4] -> [O,H,W,A] broadcast of

@@ -42,6 +42,18 @@ class ConvGeom(C.Structure):
                 ("groups", C.c_int32)]
 
 
+class WinoGn(C.Structure):
+    _fields_ = [("in_rows", C.c_void_p), ("in_gamma", C.c_void_p), ("in_beta", C.c_void_p), ("in_groups", C.c_int32),
+                ("in_act", C.c_int32), ("in_eps", C.c_float), ("out_rows", C.c_void_p), ("out_groups", C.c_int32)]
+
+
+class WinoGnBwd(C.Structure):
+    _fields_ = [("in_rows", C.c_void_p), ("in_gamma", C.c_void_p), ("in_beta", C.c_void_p), ("in_groups", C.c_int32),
+                ("in_act", C.c_int32), ("in_eps", C.c_float), ("in_g_rows_group", C.c_void_p), ("in_g_rows_chan", C.c_void_p),
+                ("out_rows", C.c_void_p), ("out_g_rows_group", C.c_void_p), ("out_gamma", C.c_void_p),
+                ("out_groups", C.c_int32), ("out_eps", C.c_float)]
+
+
 class GnSeg(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("residual", C.c_void_p), ("dy", C.c_void_p),
                 ("dx", C.c_void_p), ("dresidual", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
@@ -80,7 +92,8 @@ SYMBOLS = [
     "rn_conv2d_fwd", "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad", "rn_conv2d_bwd",
     "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes",
-    "rn_conv3x3_winograd_bwd_workspace", "rn_conv3x3_winograd_bwd", "rn_defer_reductions", "rn_flush_reductions", "rn_gemm_batched", "rn_resize_bilinear_normalize",
+    "rn_conv3x3_winograd_bwd_workspace", "rn_conv3x3_winograd_bwd", "rn_defer_reductions", "rn_flush_reductions", "rn_gemm_batched",
+    "rn_wino_gn_rows", "rn_conv3x3_winograd_gn", "rn_conv3x3_winograd_gn_bwd", "rn_reduce_rows", "rn_resize_bilinear_normalize",
     "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad", "rn_depthwise_bwd",
     "rn_group_norm_sync_bytes", "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
@@ -107,7 +120,7 @@ def lib():
                      "rn_loss_workspace", "rn_detect_workspace", "rn_optimizer_workspace",
                      "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace", "rn_conv3x3_winograd_workspace", "rn_conv2d_fwd_workspace",
                      "rn_conv2d_dgrad_workspace",
-                     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_bwd_workspace"):
+                     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_bwd_workspace", "rn_wino_gn_rows"):
             getattr(L, name).restype = C.c_size_t
         L.rn_optimizer_workspace.argtypes = [C.c_int64]
         L.rn_depthwise_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
@@ -139,6 +152,12 @@ def lib():
         L.rn_conv3x3_winograd_keep_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.rn_conv3x3_winograd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rn_wino_gn_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.rn_conv3x3_winograd_gn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rn_conv3x3_winograd_gn_bwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rn_reduce_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         L.rn_conv2d_bias_grad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p]
         L.rn_group_norm_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

@@ -887,6 +887,11 @@ extern "C" int rn_flush_reductions(rn_stream_t stream) {
   return RN_OK;
 }
 
+extern "C" int rn_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, rn_stream_t stream) {
+  RN_CHECK_ARG(in && out && count >= 1 && nrows >= 1, "reduce_rows: bad argument");
+  return rn::launch_reduce_rows(in, out, count, nrows, accumulate, (hipStream_t)stream);
+}
+
 extern "C" void rn_same_pad(int n, int k, int s, int* out, int* pad_before) { rn::same_pad(n, k, s, out, pad_before); }
 
 namespace {

@@ -656,3 +656,648 @@ extern "C" int rn_conv3x3_winograd_bwd(const rn_conv_seg* segs, int nseg, int ci
   return tile == 2 ? run_bwd<2>(segs, nseg, cin, cout, w, dw, accumulate, (char*)workspace, L, workspace_bytes, v_buf, urot_buf, st)
                    : run_bwd<4>(segs, nseg, cin, cout, w, dw, accumulate, (char*)workspace, L, workspace_bytes, v_buf, urot_buf, st);
 }
+
+// =============================================================================================================
+// GroupNorm folded into a chain of Winograd layers (the class / box towers: 4 x [conv3x3 256->256, GroupNorm,
+// activation] + an output conv, retinanet.py:37-71).  Between two such convs the normalised, activated tensor is never
+// written and never read:
+//   forward   output transform of layer i : writes the RAW conv output y_i and, per chunk of 16 tiles, the per-group
+//                                           partial statistics (count, mean, M2)                ("stat rows")
+//             input transform of layer i+1: finalises mean / rstd of its sample's groups from <= a few rows (fp64,
+//                                           fixed order, a few hundred bytes per block) and loads act(GN(y_i)) on the fly
+//   backward  output transform of layer i+1's data gradient: from dA (in registers) and y_i forms
+//                                           g = dA * act'(z), writes g, and per chunk the sums (sum g, sum g xhat)
+//                                           per channel (-> dbeta / dgamma) and gamma-weighted per group
+//             dy transforms of layer i    : load dy = rstd (gamma g - c1 - xhat c2) on the fly from g and y_i
+// so a tower layer is three launches forward and three backward with NO GroupNorm kernel, no exchange between
+// blocks and no spinning: every reduction is a fixed-order sum over rows written by an earlier launch.
+// Organisation: a block = one chunk (16 consecutive tiles of ONE sample) x 64 channels (whole groups), 256 threads
+// = 16 tiles x 16 channel quads.  Needs C % 64 == 0 and 64 % (C / groups) == 0 on the folded side.
+// =============================================================================================================
+namespace {
+constexpr int CK_TILES = 16, CK_CH = 64;
+
+struct CSeg { const float* x; const float* aux; float* y; int n, h, w, th, tw, tile_start, chunk_start, cps; };
+struct CArgs {
+  CSeg seg[RN_MAX_SEG];
+  int nseg, c, total_tiles, total_chunks;
+  float* buf;          // V or M planes [P][total_tiles][c]
+  const float* bias;
+};
+// GroupNorm parameters of the folded side
+struct Fold {
+  const float* rows;        // [chunks][groups][4] (count, mean, M2, -) of the normalised tensor
+  const float* grows;       // backward, output side: [chunks][groups][2] (sum gamma g, sum gamma g xhat)
+  const float* gamma; const float* beta;
+  float* out_rows;          // forward, output side: rows to write
+  float* g_rows_group;      // backward, input side: rows to write [chunks][groups][2]
+  float* g_rows_chan;       // backward, input side: [2][chunks][c]
+  int groups, cpg, act;
+  float eps;
+};
+
+__device__ __forceinline__ int cseg_of_chunk(const CArgs& a, int ch) {
+  int s = 0;
+  while (s + 1 < a.nseg && ch >= a.seg[s + 1].chunk_start) ++s;
+  return s;
+}
+
+struct BlockPos { int s, sample, k, tl, q, lt, t_global, c0; bool tile_ok; };
+__device__ __forceinline__ BlockPos block_pos(const CArgs& a, int chunk, int slab) {
+  BlockPos p;
+  p.s = cseg_of_chunk(a, chunk);
+  const CSeg& sg = a.seg[p.s];
+  const int local = chunk - sg.chunk_start;
+  p.sample = local / sg.cps;
+  p.k = local - p.sample * sg.cps;
+  p.tl = threadIdx.x >> 4;
+  p.q = threadIdx.x & 15;
+  p.lt = p.k * CK_TILES + p.tl;
+  const int tps = sg.th * sg.tw;
+  p.tile_ok = p.lt < tps;
+  p.t_global = sg.tile_start + p.sample * tps + min(p.lt, tps - 1);
+  p.c0 = slab * CK_CH + p.q * 4;
+  return p;
+}
+
+// per-group sums of `rows` over the chunks of this block's sample -> sh[g_local][comp] (fp64, chunk order)
+__device__ __forceinline__ void sample_group_sums(const float* rows, const CSeg& sg, int sample, int groups, int g0, int ng,
+                                                  double (*sh)[2]) {
+  const int t = threadIdx.x;
+  if (t < ng * 2) {
+    const int gl = t >> 1, comp = t & 1;
+    const float* p = rows + ((size_t)(sg.chunk_start + sample * sg.cps) * groups + g0 + gl) * 2 + comp;
+    double acc = 0.0;
+    for (int k = 0; k < sg.cps; ++k) acc += (double)p[(size_t)k * groups * 2];
+    sh[gl][comp] = acc;
+  }
+  __syncthreads();
+}
+
+// ---- tap loaders: the value of the tensor at (pixel offset `off` in elements, this thread's 4 channels)
+struct LoadPlain {
+  const float* x;
+  __device__ __forceinline__ float4 operator()(size_t off) const { return *reinterpret_cast<const float4*>(x + off); }
+};
+struct LoadGnAct {   // act(GN(x)): x * sc + sh per channel
+  const float* x; float4 sc, sh; int act;
+  __device__ __forceinline__ float4 operator()(size_t off) const {
+    const float4 v = *reinterpret_cast<const float4*>(x + off);
+    return make_float4(rn::act_fwd(v.x * sc.x + sh.x, act), rn::act_fwd(v.y * sc.y + sh.y, act),
+                       rn::act_fwd(v.z * sc.z + sh.z, act), rn::act_fwd(v.w * sc.w + sh.w, act));
+  }
+};
+struct LoadGnBwd {   // dy = rstd (gamma g - c1 - xhat c2), xhat = (y - mean) rstd; g in `x`, y in `aux`
+  const float* x; const float* aux; float4 mean, rstd, gam, c1, c2;
+  __device__ __forceinline__ float4 operator()(size_t off) const {
+    const float4 g = *reinterpret_cast<const float4*>(x + off);
+    const float4 y = *reinterpret_cast<const float4*>(aux + off);
+    float4 o;
+    o.x = rstd.x * (gam.x * g.x - c1.x - (y.x - mean.x) * rstd.x * c2.x);
+    o.y = rstd.y * (gam.y * g.y - c1.y - (y.y - mean.y) * rstd.y * c2.y);
+    o.z = rstd.z * (gam.z * g.z - c1.z - (y.z - mean.z) * rstd.z * c2.z);
+    o.w = rstd.w * (gam.w * g.w - c1.w - (y.w - mean.w) * rstd.w * c2.w);
+    return o;
+  }
+};
+
+__device__ __forceinline__ float4 lane4(const float (*st)[2], int c_local, int cpg, int comp) {
+  return make_float4(st[(c_local) / cpg][comp], st[(c_local + 1) / cpg][comp], st[(c_local + 2) / cpg][comp],
+                     st[(c_local + 3) / cpg][comp]);
+}
+
+// mean / rstd of the block's groups -> st[g_local][0..1]: the stat rows hold (count, mean, M2 = sum (y - mean)^2) per
+// (chunk, group) and are merged in chunk order with the pairwise update of Chan et al. in fp64 -- no E[y^2] - E[y]^2
+// cancellation, however few values a group has (a 1x1 pyramid level has C / groups of them)
+constexpr int ROW_F = 4;  // floats per (chunk, group) of a statistics row: count, mean, M2, unused
+__device__ __forceinline__ void block_stats(const Fold& f, const CSeg& sg, int sample, int slab, double (*shd)[2], float (*st)[2]) {
+  const int ng = CK_CH / f.cpg, g0 = slab * ng;
+  if ((int)threadIdx.x < ng) {
+    const float* p = f.rows + ((size_t)(sg.chunk_start + sample * sg.cps) * f.groups + g0 + threadIdx.x) * ROW_F;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int k = 0; k < sg.cps; ++k) {
+      const float4 r = *reinterpret_cast<const float4*>(p + (size_t)k * f.groups * ROW_F);
+      const double nr = (double)r.x, d = (double)r.y - mean, nn = n + nr;
+      if (nr > 0.0) {
+        mean += d * nr / nn;
+        m2 += (double)r.z + d * d * n * nr / nn;
+        n = nn;
+      }
+    }
+    const double var = n > 0.0 ? m2 / n : 0.0;
+    st[threadIdx.x][0] = (float)mean;
+    st[threadIdx.x][1] = (float)(1.0 / sqrt(var + (double)f.eps));
+  }
+  __syncthreads();
+}
+
+template <typename L>
+__device__ __forceinline__ L make_loader(const CArgs& a, const Fold& f, const CSeg& sg, const BlockPos& p, int slab);
+
+template <>
+__device__ __forceinline__ LoadPlain make_loader<LoadPlain>(const CArgs&, const Fold&, const CSeg& sg, const BlockPos&, int) {
+  return LoadPlain{sg.x};
+}
+template <>
+__device__ __forceinline__ LoadGnAct make_loader<LoadGnAct>(const CArgs&, const Fold& f, const CSeg& sg, const BlockPos& p, int slab) {
+  __shared__ double shd[CK_CH][2];
+  __shared__ float st[CK_CH][2];
+  block_stats(f, sg, p.sample, slab, shd, st);
+  const int cl = p.q * 4;
+  const float4 mean = lane4(st, cl, f.cpg, 0), rstd = lane4(st, cl, f.cpg, 1);
+  const float4 gam = *reinterpret_cast<const float4*>(f.gamma + p.c0), bet = *reinterpret_cast<const float4*>(f.beta + p.c0);
+  LoadGnAct l;
+  l.x = sg.x; l.act = f.act;
+  l.sc = make_float4(rstd.x * gam.x, rstd.y * gam.y, rstd.z * gam.z, rstd.w * gam.w);
+  l.sh = make_float4(bet.x - mean.x * l.sc.x, bet.y - mean.y * l.sc.y, bet.z - mean.z * l.sc.z, bet.w - mean.w * l.sc.w);
+  return l;
+}
+template <>
+__device__ __forceinline__ LoadGnBwd make_loader<LoadGnBwd>(const CArgs&, const Fold& f, const CSeg& sg, const BlockPos& p, int slab) {
+  __shared__ double shd[CK_CH][2];
+  __shared__ float st[CK_CH][2], co[CK_CH][2];
+  block_stats(f, sg, p.sample, slab, shd, st);
+  const int ng = CK_CH / f.cpg, g0 = slab * ng;
+  sample_group_sums(f.grows, sg, p.sample, f.groups, g0, ng, shd);
+  if ((int)threadIdx.x < ng) {
+    const double m = (double)sg.h * (double)sg.w * (double)f.cpg;
+    co[threadIdx.x][0] = (float)(shd[threadIdx.x][0] / m);
+    co[threadIdx.x][1] = (float)(shd[threadIdx.x][1] / m);
+  }
+  __syncthreads();
+  const int cl = p.q * 4;
+  LoadGnBwd l;
+  l.x = sg.x; l.aux = sg.aux;
+  l.mean = lane4(st, cl, f.cpg, 0); l.rstd = lane4(st, cl, f.cpg, 1);
+  l.c1 = lane4(co, cl, f.cpg, 0); l.c2 = lane4(co, cl, f.cpg, 1);
+  l.gam = *reinterpret_cast<const float4*>(f.gamma + p.c0);
+  return l;
+}
+
+// ---- input transform of a chunk: V[xi][tile][c] = (B^T d B)[xi], d = the (M+2)^2 patch read through loader L
+template <int M, typename L>
+__device__ __forceinline__ void chunk_input_body(const CArgs& a, const Fold& f, int chunk, int slab) {
+  typedef float4 VT;
+  constexpr int P = M + 2;
+  const BlockPos p = block_pos(a, chunk, slab);
+  const CSeg& sg = a.seg[p.s];
+  const L ld = make_loader<L>(a, f, sg, p, slab);
+  if (!p.tile_ok) return;
+  const int ty = p.lt / sg.tw, tx = p.lt - ty * sg.tw;
+  const int y0 = M * ty - 1, x0 = M * tx - 1;
+  const size_t plane = (size_t)a.total_tiles * a.c;
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  v4 d[P][P];
+#pragma unroll
+  for (int r = 0; r < P; ++r) {
+    const int yy = y0 + r;
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      const int xx = x0 + c;
+      const bool ok = (unsigned)yy < (unsigned)sg.h && (unsigned)xx < (unsigned)sg.w;
+      const int yc = min(max(yy, 0), sg.h - 1), xc = min(max(xx, 0), sg.w - 1);
+      const VT v = ld(((size_t)(p.sample * sg.h + yc) * sg.w + xc) * a.c + p.c0);   // the padding is zero AFTER the activation
+      const float m = ok ? 1.f : 0.f;
+      d[c][r] = (v4){v.x * m, v.y * m, v.z * m, v.w * m};
+    }
+  }
+  v4 tm[P][P];
+#pragma unroll
+  for (int c = 0; c < P; ++c) {
+    v4 col[P];
+    Wino<M>::bt(d[c], col);
+#pragma unroll
+    for (int r = 0; r < P; ++r) tm[r][c] = col[r];
+  }
+  float* out = a.buf + (size_t)p.t_global * a.c + p.c0;
+#pragma unroll
+  for (int r = 0; r < P; ++r) {
+    v4 row[P];
+    Wino<M>::bt(tm[r], row);
+#pragma unroll
+    for (int c = 0; c < P; ++c) *reinterpret_cast<v4*>(out + (size_t)(r * P + c) * plane) = row[c];
+  }
+}
+
+// ---- A dY A^T of a chunk (weight gradient), dY read through loader L
+template <int M, typename L>
+__device__ __forceinline__ void chunk_dy_body(const CArgs& a, const Fold& f, int chunk, int slab) {
+  constexpr int P = M + 2;
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const BlockPos p = block_pos(a, chunk, slab);
+  const CSeg& sg = a.seg[p.s];
+  const L ld = make_loader<L>(a, f, sg, p, slab);
+  if (!p.tile_ok) return;
+  const int ty = p.lt / sg.tw, tx = p.lt - ty * sg.tw;
+  const int y0 = M * ty, x0 = M * tx;
+  const size_t plane = (size_t)a.total_tiles * a.c;
+  v4 tm[P][M];
+#pragma unroll
+  for (int c = 0; c < M; ++c) {
+    v4 col[M], o[P];
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      const bool ok = y0 + r < sg.h && x0 + c < sg.w;
+      const int yc = min(y0 + r, sg.h - 1), xc = min(x0 + c, sg.w - 1);
+      const float4 v = ld(((size_t)(p.sample * sg.h + yc) * sg.w + xc) * a.c + p.c0);
+      const float m = ok ? 1.f : 0.f;
+      col[r] = (v4){v.x * m, v.y * m, v.z * m, v.w * m};
+    }
+    Wino<M>::a(col, o);
+#pragma unroll
+    for (int r = 0; r < P; ++r) tm[r][c] = o[r];
+  }
+  float* out = a.buf + (size_t)p.t_global * a.c + p.c0;
+#pragma unroll
+  for (int r = 0; r < P; ++r) {
+    v4 row[P];
+    Wino<M>::a(tm[r], row);
+#pragma unroll
+    for (int c = 0; c < P; ++c) *reinterpret_cast<v4*>(out + (size_t)(r * P + c) * plane) = row[c];
+  }
+}
+
+// ---- output transform of a chunk.  MODE 0: y = A^T m A (+ bias), optional stat rows of y.
+//      MODE 1 (data gradient into a folded GroupNorm): o = dA; g = o * act'(z) from the raw tensor in seg.aux; writes g
+//      and the rows (sum g, sum g xhat) per channel and gamma-weighted per group.
+template <int M, int MODE>
+__device__ __forceinline__ void chunk_output_body(const CArgs& a, const Fold& f, int chunk, int slab) {
+  constexpr int P = M + 2;
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  __shared__ float red[256][8];
+  __shared__ float chan[CK_CH][2];
+  __shared__ double shd[CK_CH][2];
+  __shared__ float st[CK_CH][2];
+  const BlockPos p = block_pos(a, chunk, slab);
+  const CSeg& sg = a.seg[p.s];
+  const int tid = threadIdx.x;
+  v4 sc = (v4)(0.f), sh = (v4)(0.f), mean = (v4)(0.f), rstd = (v4)(0.f);
+  if (MODE == 1) {
+    block_stats(f, sg, p.sample, slab, shd, st);
+    const int cl = p.q * 4;
+    const float4 mu = lane4(st, cl, f.cpg, 0), rs = lane4(st, cl, f.cpg, 1);
+    const float4 gam = *reinterpret_cast<const float4*>(f.gamma + p.c0), bet = *reinterpret_cast<const float4*>(f.beta + p.c0);
+    mean = (v4){mu.x, mu.y, mu.z, mu.w}; rstd = (v4){rs.x, rs.y, rs.z, rs.w};
+    sc = (v4){gam.x, gam.y, gam.z, gam.w}; sh = (v4){bet.x, bet.y, bet.z, bet.w};
+  }
+  v4 s1 = (v4)(0.f), s2 = (v4)(0.f);
+  float nvalid = 0.f;
+  const bool want_rows = MODE == 1 || f.out_rows != nullptr;
+  if (p.tile_ok) {
+    const int ty = p.lt / sg.tw, tx = p.lt - ty * sg.tw;
+    const size_t plane = (size_t)a.total_tiles * a.c;
+    const float* in = a.buf + (size_t)p.t_global * a.c + p.c0;
+    v4 rr[M][P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      v4 col[P], o[M];
+#pragma unroll
+      for (int r = 0; r < P; ++r) col[r] = *reinterpret_cast<const v4*>(in + (size_t)(r * P + c) * plane);
+      Wino<M>::at(col, o);
+#pragma unroll
+      for (int i2 = 0; i2 < M; ++i2) rr[i2][c] = o[i2];
+    }
+    v4 b = (v4)(0.f);
+    if (a.bias) b = *reinterpret_cast<const v4*>(a.bias + p.c0);
+    const int y0 = M * ty, x0 = M * tx;
+    v4 vals[M][M];
+#pragma unroll
+    for (int i2 = 0; i2 < M; ++i2) {
+      v4 o[M];
+      Wino<M>::at(rr[i2], o);
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const bool ok = y0 + i2 < sg.h && x0 + j < sg.w;
+        const size_t off = ((size_t)(p.sample * sg.h + min(y0 + i2, sg.h - 1)) * sg.w + min(x0 + j, sg.w - 1)) * a.c + p.c0;
+        v4 v = o[j] + b;
+        if (MODE == 1) {
+          const v4 yv = *reinterpret_cast<const v4*>(sg.aux + off);      // clamped address: always valid
+          const v4 xh = (yv - mean) * rstd;
+          const v4 z = xh * sc + sh;
+          v4 ag;
+          ag.x = rn::act_grad(z.x, f.act); ag.y = rn::act_grad(z.y, f.act); ag.z = rn::act_grad(z.z, f.act); ag.w = rn::act_grad(z.w, f.act);
+          v = v * ag;
+          if (ok) { s1 += v; s2 += v * xh; }
+        } else if (ok) {
+          s1 += v; nvalid += 1.f;
+        }
+        vals[i2][j] = ok ? v : (v4)(0.f);
+        if (ok) *reinterpret_cast<v4*>(sg.y + off) = v;
+      }
+    }
+    if (MODE == 0 && want_rows) {   // second pass over the registers: M2 about this thread's own per-channel mean
+      const v4 mu = s1 * (1.f / fmaxf(nvalid, 1.f));
+      s1 = mu;
+#pragma unroll
+      for (int i2 = 0; i2 < M; ++i2)
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          const bool ok = y0 + i2 < sg.h && x0 + j < sg.w;
+          const v4 d = vals[i2][j] - mu;
+          if (ok) s2 += d * d;
+        }
+    }
+  }
+  if (!want_rows) return;
+  red[tid][0] = s1.x; red[tid][1] = s1.y; red[tid][2] = s1.z; red[tid][3] = s1.w;
+  red[tid][4] = s2.x; red[tid][5] = s2.y; red[tid][6] = s2.z; red[tid][7] = s2.w;
+  __shared__ float cnt[CK_TILES];
+  if ((tid & 15) == 0) cnt[tid >> 4] = nvalid;
+  __syncthreads();
+  if (MODE == 1) {
+    if (tid < CK_CH * 2) {   // per-channel sums over the chunk's 16 tiles, tile order
+      const int cl = tid >> 1, comp = tid & 1;
+      float t = 0.f;
+#pragma unroll
+      for (int tl = 0; tl < CK_TILES; ++tl) t += red[tl * 16 + (cl >> 2)][comp * 4 + (cl & 3)];
+      chan[cl][comp] = t;
+      f.g_rows_chan[((size_t)comp * a.total_chunks + chunk) * a.c + slab * CK_CH + cl] = t;
+    }
+    __syncthreads();
+    const int ng = CK_CH / f.cpg;
+    if (tid < ng * 2) {
+      const int gl = tid >> 1, comp = tid & 1;
+      float t = 0.f;
+      for (int j = 0; j < f.cpg; ++j) {
+        const int cl = gl * f.cpg + j;
+        t += f.gamma[slab * CK_CH + cl] * chan[cl][comp];
+      }
+      f.g_rows_group[((size_t)chunk * f.groups + slab * ng + gl) * 2 + comp] = t;
+    }
+    return;
+  }
+  // MODE 0: (count, mean, M2) per channel over the chunk's tiles (tile order), then per group over its channels
+  __shared__ float cstat[CK_CH][3];
+  if (tid < CK_CH) {
+    const int cl = tid;
+    float n = 0.f, mu = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < CK_TILES; ++tl) {
+      const float nr = cnt[tl];
+      if (nr > 0.f) {
+        const float mr = red[tl * 16 + (cl >> 2)][cl & 3], qr = red[tl * 16 + (cl >> 2)][4 + (cl & 3)];
+        const float d = mr - mu, nn = n + nr;
+        mu += d * nr / nn;
+        m2 += qr + d * d * n * nr / nn;
+        n = nn;
+      }
+    }
+    cstat[cl][0] = n; cstat[cl][1] = mu; cstat[cl][2] = m2;
+  }
+  __syncthreads();
+  const int ng = CK_CH / f.cpg;
+  if (tid < ng) {
+    float n = 0.f, mu = 0.f, m2 = 0.f;
+    for (int j = 0; j < f.cpg; ++j) {
+      const int cl = tid * f.cpg + j;
+      const float nr = cstat[cl][0];
+      if (nr > 0.f) {
+        const float d = cstat[cl][1] - mu, nn = n + nr;
+        mu += d * nr / nn;
+        m2 += cstat[cl][2] + d * d * n * nr / nn;
+        n = nn;
+      }
+    }
+    *reinterpret_cast<float4*>(f.out_rows + ((size_t)chunk * f.groups + slab * ng + tid) * ROW_F) = make_float4(n, mu, m2, 0.f);
+  }
+}
+
+// launches: blocks [0, nb_chunk) run a chunk body (chunk = b / slabs, slab = b % slabs), the rest the second body
+template <int M, typename L>
+__global__ __launch_bounds__(NT) void wino_gn_fwd_pre_kernel(const CArgs in, const Fold f, const WeightArgs wa, int nb_chunk, int slabs) {
+  const int b = blockIdx.x;
+  if (b < nb_chunk) chunk_input_body<M, L>(in, f, b / slabs, b % slabs);
+  else wino_weight_body<M>(wa.w, wa.u, wa.u2, wa.kn, wa.rot, b - nb_chunk);
+}
+template <int M, typename L>
+__global__ __launch_bounds__(NT) void wino_gn_input_kernel(const CArgs in, const Fold f, int slabs) {
+  chunk_input_body<M, L>(in, f, blockIdx.x / slabs, blockIdx.x % slabs);
+}
+template <int M>
+__global__ __launch_bounds__(NT) void wino_gn_output_kernel(const CArgs out, const Fold f, int slabs) {
+  chunk_output_body<M, 0>(out, f, blockIdx.x / slabs, blockIdx.x % slabs);
+}
+template <int M, typename L>
+__global__ __launch_bounds__(NT) void wino_gn_bwd_pre_kernel(const CArgs dgrad_in, const CArgs wgrad_dy, const Fold f, int nb_first,
+                                                             int slabs) {
+  const int b = blockIdx.x;
+  if (b < nb_first) chunk_input_body<M, L>(dgrad_in, f, b / slabs, b % slabs);
+  else chunk_dy_body<M, L>(wgrad_dy, f, (b - nb_first) / slabs, (b - nb_first) % slabs);
+}
+template <int M, int MODE>
+__global__ __launch_bounds__(NT) void wino_gn_bwd_post_kernel(const CArgs out, const Fold f, const DwArgs2 d, int nb_out, int slabs) {
+  const int b = blockIdx.x;
+  if (b < nb_out) chunk_output_body<M, MODE>(out, f, b / slabs, b % slabs);
+  else wino_dw_body<M>(d.du, d.dw, d.kn, d.nsplit, d.accumulate, b - nb_out);
+}
+
+// x_of / y_of: which tensors of the segment feed this stage
+int cfill(const rn_conv_seg* segs, int nseg, int c, int m, CArgs* a, const float* const* xs, const float* const* auxs, float* const* ys) {
+  int64_t tiles = 0, chunks = 0;
+  for (int s = 0; s < nseg; ++s) {
+    CSeg& d = a->seg[s];
+    d.n = segs[s].n; d.h = segs[s].h; d.w = segs[s].w;
+    d.th = (d.h + m - 1) / m; d.tw = (d.w + m - 1) / m;
+    d.tile_start = (int)tiles; d.chunk_start = (int)chunks;
+    d.cps = (d.th * d.tw + CK_TILES - 1) / CK_TILES;
+    d.x = xs ? xs[s] : nullptr; d.aux = auxs ? auxs[s] : nullptr; d.y = ys ? ys[s] : nullptr;
+    tiles += (int64_t)d.n * d.th * d.tw;
+    chunks += (int64_t)d.n * d.cps;
+  }
+  a->nseg = nseg; a->c = c; a->total_tiles = (int)tiles; a->total_chunks = (int)chunks;
+  return RN_OK;
+}
+
+bool fold_ok(int c, int groups) { return c % CK_CH == 0 && groups >= 1 && c % groups == 0 && CK_CH % (c / groups) == 0; }
+}  // namespace
+
+extern "C" size_t rn_wino_gn_rows(const rn_conv_seg* segs, int nseg, int tile) {
+  if (!segs || nseg < 1 || nseg > RN_MAX_SEG || (tile != 2 && tile != 4)) return 0;
+  size_t chunks = 0;
+  for (int s = 0; s < nseg; ++s) {
+    const size_t tps = (size_t)((segs[s].h + tile - 1) / tile) * ((segs[s].w + tile - 1) / tile);
+    chunks += (size_t)segs[s].n * ((tps + CK_TILES - 1) / CK_TILES);
+  }
+  return chunks;
+}
+
+namespace {
+template <int M>
+int run_gn_fwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, const float* bias, const rn_wino_gn* gn, float* U,
+               float* V, float* Mb, float* v_buf, float* urot_buf, hipStream_t st) {
+  constexpr int P2 = (M + 2) * (M + 2);
+  const float* xs[RN_MAX_SEG]; float* ys[RN_MAX_SEG];
+  for (int s = 0; s < nseg; ++s) { xs[s] = segs[s].x; ys[s] = segs[s].y; }
+  CArgs ia = {}, oa = {};
+  cfill(segs, nseg, cin, M, &ia, xs, nullptr, nullptr);
+  cfill(segs, nseg, cout, M, &oa, nullptr, nullptr, ys);
+  if (v_buf) V = v_buf;
+  ia.buf = V;
+  const int64_t kn = (int64_t)cin * cout;
+  const WeightArgs wa = {w, U, urot_buf, kn, 0};
+  Fold fi = {};
+  const bool fold_in = gn->in_rows != nullptr;
+  if (fold_in) {
+    fi.rows = gn->in_rows; fi.gamma = gn->in_gamma; fi.beta = gn->in_beta; fi.groups = gn->in_groups; fi.cpg = cin / gn->in_groups;
+    fi.act = gn->in_act; fi.eps = gn->in_eps;
+  }
+  const int slabs_in = cin / CK_CH, nb_chunk = ia.total_chunks * slabs_in, nb_w = (int)rn::ceil_div64(kn, NT);
+  if (fold_in) hipLaunchKernelGGL((wino_gn_fwd_pre_kernel<M, LoadGnAct>), dim3(nb_chunk + nb_w), dim3(NT), 0, st, ia, fi, wa, nb_chunk, slabs_in);
+  else hipLaunchKernelGGL((wino_gn_fwd_pre_kernel<M, LoadPlain>), dim3(nb_chunk + nb_w), dim3(NT), 0, st, ia, fi, wa, nb_chunk, slabs_in);
+  RN_LAUNCH_CHECK();
+  if (int e = rn::launch_batched_gemm(V, U, Mb, ia.total_tiles, cin, cout, P2, 0, st)) return e;
+  if (!gn->out_rows) {  // no statistics wanted: the grid-stride output transform (any cout % 4 == 0, e.g. the 720 class maps)
+    WArgs wi = {}, wo = {};
+    if (int e = fill(segs, nseg, cin, cout, M, false, &wi, &wo)) return e;
+    wo.buf = Mb; wo.bias = bias;
+    const int wd = width_for(wo.total_tiles, cout);
+    RN_WINO_LAUNCH(wino_output_kernel, wd, (int64_t)wo.total_tiles * cout, wo);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+  }
+  oa.buf = Mb; oa.bias = bias;
+  Fold fo = {};
+  fo.out_rows = gn->out_rows; fo.groups = gn->out_groups; fo.cpg = cout / gn->out_groups;
+  const int slabs_out = cout / CK_CH;
+  hipLaunchKernelGGL((wino_gn_output_kernel<M>), dim3(oa.total_chunks * slabs_out), dim3(NT), 0, st, oa, fo, slabs_out);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+template <int M>
+int run_gn_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, float* dw, int accumulate, const rn_wino_gn_bwd* gn,
+               char* ws, const BwdLayout& L, size_t ws_bytes, const float* v_buf, const float* urot_buf, hipStream_t st) {
+  constexpr int P2 = (M + 2) * (M + 2);
+  const float* dys[RN_MAX_SEG]; const float* youts[RN_MAX_SEG]; const float* xins[RN_MAX_SEG]; float* dxs[RN_MAX_SEG];
+  for (int s = 0; s < nseg; ++s) { dys[s] = segs[s].dy; youts[s] = segs[s].y; xins[s] = segs[s].x; dxs[s] = segs[s].dx; }
+  const bool fold_out = gn->out_rows != nullptr, fold_in = gn->in_rows != nullptr;
+  CArgs ia = {}, ya = {}, oa = {};
+  cfill(segs, nseg, cout, M, &ia, dys, fold_out ? youts : nullptr, nullptr);   // dy (or g + raw y) -> B^T . B
+  ya = ia;                                                                      // the same tensor  -> A . A^T
+  cfill(segs, nseg, cin, M, &oa, nullptr, fold_in ? xins : nullptr, dxs);      // products -> dx (or g of the input's GroupNorm)
+  const int T_ = ia.total_tiles;
+  const int64_t kn = (int64_t)cin * cout;
+  float* Vdy = (float*)(ws + L.vdy);
+  float* Mdx = (float*)(ws + L.mdx);
+  float* dM = (float*)(ws + L.dm);
+  const float* V = v_buf;
+  const float* Urot = urot_buf;
+  if (!Urot) {
+    float* u = (float*)(ws + L.urot);
+    hipLaunchKernelGGL(wino_weight_kernel<M>, dim3((unsigned)rn::ceil_div64(kn, NT)), dim3(NT), 0, st, w, u, (float*)nullptr, kn, 1);
+    Urot = u;
+  }
+  Fold fi = {};
+  if (fold_in) {
+    fi.rows = gn->in_rows; fi.gamma = gn->in_gamma; fi.beta = gn->in_beta; fi.groups = gn->in_groups; fi.cpg = cin / gn->in_groups;
+    fi.act = gn->in_act; fi.eps = gn->in_eps; fi.g_rows_group = gn->in_g_rows_group; fi.g_rows_chan = gn->in_g_rows_chan;
+  }
+  if (!V) {  // the forward pass did not keep its transformed input: rebuild it (through the folded GroupNorm if there is one)
+    CArgs xa = {};
+    cfill(segs, nseg, cin, M, &xa, xins, nullptr, nullptr);
+    xa.buf = (float*)(ws + L.v);
+    const int slabs = cin / CK_CH;
+    if (fold_in) hipLaunchKernelGGL((wino_gn_input_kernel<M, LoadGnAct>), dim3(xa.total_chunks * slabs), dim3(NT), 0, st, xa, fi, slabs);
+    else hipLaunchKernelGGL((wino_gn_input_kernel<M, LoadPlain>), dim3(xa.total_chunks * slabs), dim3(NT), 0, st, xa, fi, slabs);
+    V = xa.buf;
+  }
+  ia.buf = Vdy;
+  ya.buf = dM;
+  Fold fo = {};
+  if (fold_out) {
+    fo.rows = gn->out_rows; fo.grows = gn->out_g_rows_group; fo.gamma = gn->out_gamma; fo.groups = gn->out_groups;
+    fo.cpg = cout / gn->out_groups; fo.eps = gn->out_eps;
+  }
+  if (fold_out) {
+    const int slabs = cout / CK_CH, nb = ia.total_chunks * slabs;
+    hipLaunchKernelGGL((wino_gn_bwd_pre_kernel<M, LoadGnBwd>), dim3(2 * nb), dim3(NT), 0, st, ia, ya, fo, nb, slabs);
+  } else {  // plain dy (any cout % 4 == 0): the grid-stride transforms
+    WArgs wia = {}, woa = {}, wya = {}, unused = {};
+    if (int e = fill(segs, nseg, cin, cout, M, true, &wia, &woa, true)) return e;
+    if (int e = fill(segs, nseg, cin, cout, M, true, &wya, &unused, true)) return e;
+    wia.buf = Vdy; wya.buf = dM;
+    const int wy = width_for(T_, cout);
+    const int nb = (int)grid_for((int64_t)T_ * cout / wy);
+    if (wy == 4) hipLaunchKernelGGL((wino_bwd_pre_kernel<M, 4>), dim3(2 * nb), dim3(NT), 0, st, wia, wya, nb);
+    else if (wy == 2) hipLaunchKernelGGL((wino_bwd_pre_kernel<M, 2>), dim3(2 * nb), dim3(NT), 0, st, wia, wya, nb);
+    else hipLaunchKernelGGL((wino_bwd_pre_kernel<M, 1>), dim3(2 * nb), dim3(NT), 0, st, wia, wya, nb);
+  }
+  RN_LAUNCH_CHECK();
+  int nsplit = 1;
+  if (int e = rn::launch_winograd_bwd_products(Vdy, Urot, Mdx, T_, cout, cin, V, dM, cin, cout, P2, ws + L.slab, ws_bytes - L.slab, st,
+                                               &nsplit))
+    return e;
+  oa.buf = Mdx; oa.bias = nullptr;
+  {
+    const DwArgs2 d = {(const float*)(ws + L.slab), dw, kn, nsplit, accumulate};
+    const int slabs = cin / CK_CH, nb_out = oa.total_chunks * slabs, nb_dw = (int)rn::ceil_div64(kn, NT);
+    if (!fold_in) { fi.groups = 1; fi.cpg = CK_CH; }
+    if (fold_in) hipLaunchKernelGGL((wino_gn_bwd_post_kernel<M, 1>), dim3(nb_out + nb_dw), dim3(NT), 0, st, oa, fi, d, nb_out, slabs);
+    else hipLaunchKernelGGL((wino_gn_bwd_post_kernel<M, 0>), dim3(nb_out + nb_dw), dim3(NT), 0, st, oa, fi, d, nb_out, slabs);
+  }
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+int check_fold(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile) {
+  RN_CHECK_ARG(segs && nseg >= 1 && nseg <= RN_MAX_SEG && (tile == 2 || tile == 4), "winograd gn: bad segments / tile");
+  RN_UNSUPPORTED(cin % CK_CH != 0 || cout % 4 != 0, "winograd gn: cin %d must be a multiple of %d, cout %d of 4", cin, CK_CH, cout);
+  for (int s = 0; s < nseg; ++s) {
+    RN_CHECK_ARG(segs[s].n >= 1 && segs[s].h >= 1 && segs[s].w >= 1, "winograd gn: bad segment %d", s);
+    RN_UNSUPPORTED((double)segs[s].n * segs[s].h * segs[s].w * (cin > cout ? cin : cout) * 4.0 >= 2147483648.0,
+                   "winograd gn: segment %d >= 2 GiB", s);
+  }
+  return RN_OK;
+}
+}  // namespace
+
+extern "C" int rn_conv3x3_winograd_gn(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, const float* bias, int tile,
+                                      const rn_wino_gn* gn, void* workspace, size_t workspace_bytes, float* v_buf, float* urot_buf,
+                                      rn_stream_t stream) {
+  if (int e = check_fold(segs, nseg, cin, cout, tile)) return e;
+  RN_CHECK_ARG(w && workspace && gn, "winograd gn: null pointer");
+  for (int s = 0; s < nseg; ++s) RN_CHECK_ARG(segs[s].x && segs[s].y, "winograd gn: null tensor in segment %d", s);
+  if (gn->in_rows) {
+    RN_CHECK_ARG(gn->in_gamma && gn->in_beta, "winograd gn: null gamma / beta");
+    RN_UNSUPPORTED(!fold_ok(cin, gn->in_groups), "winograd gn: %d channels in %d groups cannot be folded", cin, gn->in_groups);
+  }
+  if (gn->out_rows) RN_UNSUPPORTED(!fold_ok(cout, gn->out_groups), "winograd gn: %d channels in %d groups cannot be folded", cout, gn->out_groups);
+  const size_t need = rn_conv3x3_winograd_workspace(segs, nseg, cin, cout, tile);
+  if (workspace_bytes < need) {
+    rn::set_error("winograd gn: workspace %zu < %zu bytes", workspace_bytes, need);
+    return RN_EWORKSPACE;
+  }
+  const size_t p2 = (size_t)(tile + 2) * (tile + 2), tiles = tiles_of(segs, nseg, tile);
+  RN_UNSUPPORTED((double)tiles * (cin > cout ? cin : cout) * 4.0 >= 2147483648.0, "winograd gn: a transform plane is >= 2 GiB");
+  float* U = (float*)workspace;
+  float* V = (float*)((char*)workspace + rn::align_up(p2 * cin * cout * 4, 256));
+  float* Mb = (float*)((char*)V + rn::align_up(p2 * tiles * cin * 4, 256));
+  hipStream_t st = (hipStream_t)stream;
+  return tile == 2 ? run_gn_fwd<2>(segs, nseg, cin, cout, w, bias, gn, U, V, Mb, v_buf, urot_buf, st)
+                   : run_gn_fwd<4>(segs, nseg, cin, cout, w, bias, gn, U, V, Mb, v_buf, urot_buf, st);
+}
+
+extern "C" int rn_conv3x3_winograd_gn_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, float* dw, int accumulate,
+                                          int tile, const rn_wino_gn_bwd* gn, void* workspace, size_t workspace_bytes, const float* v_buf,
+                                          const float* urot_buf, rn_stream_t stream) {
+  if (int e = check_fold(segs, nseg, cin, cout, tile)) return e;
+  RN_CHECK_ARG(w && dw && workspace && gn, "winograd gn bwd: null pointer");
+  for (int s = 0; s < nseg; ++s) RN_CHECK_ARG(segs[s].x && segs[s].dy && segs[s].dx, "winograd gn bwd: null tensor in segment %d", s);
+  if (gn->in_rows) {
+    RN_CHECK_ARG(gn->in_gamma && gn->in_beta && gn->in_g_rows_group && gn->in_g_rows_chan, "winograd gn bwd: null input-side pointer");
+    RN_UNSUPPORTED(!fold_ok(cin, gn->in_groups), "winograd gn bwd: %d channels in %d groups cannot be folded", cin, gn->in_groups);
+  }
+  if (gn->out_rows) {
+    RN_CHECK_ARG(gn->out_g_rows_group && gn->out_gamma, "winograd gn bwd: null output-side pointer");
+    for (int s = 0; s < nseg; ++s) RN_CHECK_ARG(segs[s].y, "winograd gn bwd: the folded output side needs the raw conv output y (segment %d)", s);
+    RN_UNSUPPORTED(!fold_ok(cout, gn->out_groups), "winograd gn bwd: %d channels in %d groups cannot be folded", cout, gn->out_groups);
+  }
+  const BwdLayout L = bwd_layout(segs, nseg, cin, cout, tile, v_buf == nullptr, urot_buf == nullptr);
+  if (workspace_bytes < L.total) {
+    rn::set_error("winograd gn bwd: workspace %zu < %zu bytes", workspace_bytes, L.total);
+    return RN_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return tile == 2 ? run_gn_bwd<2>(segs, nseg, cin, cout, w, dw, accumulate, gn, (char*)workspace, L, workspace_bytes, v_buf, urot_buf, st)
+                   : run_gn_bwd<4>(segs, nseg, cin, cout, w, dw, accumulate, gn, (char*)workspace, L, workspace_bytes, v_buf, urot_buf, st);
+}

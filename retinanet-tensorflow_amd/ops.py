@@ -408,6 +408,176 @@ def conv2d(x, w, bias=None, stride=1, groups=1):
     return _Conv2dShared.apply((stride, groups), w, bias, x)[0]
 
 
+# GroupNorm folded into chains of Winograd layers (rn_conv3x3_winograd_gn): the head towers run without GroupNorm kernels
+WINO_GN_FOLD = os.environ.get("RN_WINO_GN_FOLD", "1") == "1"
+
+
+def wino_tower_ok(xs, tower, out_w, groups):
+    """Can [conv3x3, GroupNorm, act] x k (+ an output conv3x3) run as folded Winograd layers?  `tower`: [(w, gamma, beta)]."""
+    if not (WINO_GN_FOLD and WINOGRAD and xs and all(x.is_cuda and x.dtype == torch.float32 for x in xs)):
+        return False
+    cin = xs[0].shape[3]
+    for w, gamma, beta in tower:
+        kh, kw, ci, co = w.shape
+        g = gn_groups(co, groups)
+        if not (kh == 3 and kw == 3 and ci == cin and ci % 64 == 0 and co % 64 == 0 and 64 % (co // g) == 0):
+            return False
+        cin = co
+    if out_w is not None and not (out_w.shape[0] == 3 and out_w.shape[1] == 3 and out_w.shape[2] == cin and out_w.shape[3] % 4 == 0):
+        return False
+    m = WINOGRAD_TILE
+    tiles = sum(x.shape[0] * ((x.shape[1] + m - 1) // m) * ((x.shape[2] + m - 1) // m) for x in xs)
+    widest = max([cin] + [t[0].shape[3] for t in tower] + ([out_w.shape[3]] if out_w is not None else []))
+    return 4 * (m + 2) ** 2 * (tiles * 2 * widest + widest * widest) <= WINOGRAD_MAX_WORKSPACE
+
+
+class _WinoTower(torch.autograd.Function):
+    """k x [conv3x3 (no bias) -> GroupNorm -> activation] (+ optionally a final conv3x3 with bias) on n tensors that share
+    every parameter, as k (+1) folded Winograd layers: see rn_conv3x3_winograd_gn.  Without the final conv the last
+    GroupNorm is NOT part of the node: it returns the raw output of conv k (a plain tensor with a plain gradient)."""
+
+    @staticmethod
+    def forward(ctx, cfg, n, *args):
+        groups, eps, act, k, with_out = cfg
+        xs = [x.contiguous() for x in args[:n]]
+        params = list(args[n:])
+        tower = [(params[3 * i], params[3 * i + 1], params[3 * i + 2]) for i in range(k)]
+        out_w, out_b = (params[3 * k], params[3 * k + 1]) if with_out else (None, None)
+        L = _rn.lib()
+        dev = xs[0].device
+        tile = WINOGRAD_TILE
+        training = any(ctx.needs_input_grad)
+        convs = [(w, None) for (w, _, _) in tower] + ([(out_w, out_b)] if with_out else [])
+        nfold = k if with_out else k - 1               # GroupNorms folded between two convs of this node
+        cur, ys_all, rows_all, keep = xs, [], [], []
+        nrows = None
+        for i, (w, b) in enumerate(convs):
+            cin, cout = w.shape[2], w.shape[3]
+            ys = [torch.empty((x.shape[0], x.shape[1], x.shape[2], cout), dtype=torch.float32, device=dev) for x in cur]
+            segs = _conv_segs(cur, w, b, ys, None, None)
+            if nrows is None:
+                nrows = int(L.rn_wino_gn_rows(segs, n, tile))
+            gn = _rn.WinoGn()
+            if i > 0:                                   # the input is the raw output of conv i-1: normalise while loading
+                _, gamma, beta = tower[i - 1]
+                g_in = gn_groups(cin, groups)
+                gn.in_rows, gn.in_gamma, gn.in_beta = rows_all[i - 1].data_ptr(), _rn.f32(gamma), _rn.f32(beta)
+                gn.in_groups, gn.in_act, gn.in_eps = g_in, _rn.ACT[act], eps
+            rows = None
+            if i < nfold:                               # its output feeds a folded GroupNorm: emit the statistics rows
+                g_out = gn_groups(cout, groups)
+                rows = torch.empty((nrows, g_out, 4), dtype=torch.float32, device=dev)
+                gn.out_rows, gn.out_groups = rows.data_ptr(), g_out
+            v_buf, u_buf = _winograd_keep_buffers(segs, n, w, training and WINOGRAD_WGRAD, training)
+            need = L.rn_conv3x3_winograd_workspace(segs, n, cin, cout, tile)
+            ws = _rn.workspace(need, dev)
+            _rn.check(L.rn_conv3x3_winograd_gn(segs, n, cin, cout, _rn.f32(w), _rn.f32(b) if b is not None else None, tile,
+                                               C.byref(gn), ws.data_ptr(), ws.numel(),
+                                               _rn.f32(v_buf) if v_buf is not None else None,
+                                               _rn.f32(u_buf) if u_buf is not None else None, _rn.stream()),
+                      "rn_conv3x3_winograd_gn")
+            ys_all.append(ys)
+            rows_all.append(rows)
+            keep.append((v_buf, u_buf))
+            cur = ys
+        ctx.cfg, ctx.n = cfg, n
+        ctx.keep, ctx.rows, ctx.nrows = keep, rows_all, nrows
+        ctx.out_b = out_b
+        flat = [t for ys in ys_all[:-1] for t in ys]    # raw outputs of the convs whose GroupNorm is folded
+        ctx.save_for_backward(*xs, *flat, *params)
+        return tuple(ys_all[-1])
+
+    @staticmethod
+    def backward(ctx, *dys):
+        groups, eps, act, k, with_out = ctx.cfg
+        n = ctx.n
+        saved = ctx.saved_tensors
+        nconv = k + 1 if with_out else k
+        xs = list(saved[:n])
+        raw = [list(saved[n * (1 + i):n * (2 + i)]) for i in range(nconv - 1)]
+        params = list(saved[n * nconv:])
+        tower = [(params[3 * i], params[3 * i + 1], params[3 * i + 2]) for i in range(k)]
+        convs = [t[0] for t in tower] + ([params[3 * k]] if with_out else [])
+        out_b = params[3 * k + 1] if with_out else None
+        L = _rn.lib()
+        dev = xs[0].device
+        tile = WINOGRAD_TILE
+        nfold = k if with_out else k - 1
+        inputs = [xs] + raw                              # input tensors of conv i (raw[i-1] = raw output of conv i-1)
+        cur_dy = [dy.contiguous() if dy is not None else None for dy in dys]
+        for j in range(n):
+            if cur_dy[j] is None:
+                x = inputs[-1][j]
+                cur_dy[j] = torch.zeros((x.shape[0], x.shape[1], x.shape[2], convs[-1].shape[3]), dtype=torch.float32, device=dev)
+        grads = [None] * len(params)
+        g_rows_group_next = None                         # rows of the GroupNorm after conv i (written by conv i+1's pass)
+        for i in range(nconv - 1, -1, -1):
+            w = convs[i]
+            cin, cout = w.shape[2], w.shape[3]
+            x_in = inputs[i]
+            dxs = [torch.empty_like(x) for x in x_in]
+            segs = _conv_segs(x_in, w, None, None, cur_dy, dxs)
+            gnb = _rn.WinoGnBwd()
+            grg = grc = None
+            if i > 0:                                    # input side folded: dx leaves as g of GroupNorm i-1
+                _, gamma, beta = tower[i - 1]
+                g_in = gn_groups(cin, groups)
+                grg = torch.empty((ctx.nrows, g_in, 2), dtype=torch.float32, device=dev)
+                grc = torch.empty((2, ctx.nrows, cin), dtype=torch.float32, device=dev)
+                gnb.in_rows, gnb.in_gamma, gnb.in_beta = ctx.rows[i - 1].data_ptr(), _rn.f32(gamma), _rn.f32(beta)
+                gnb.in_groups, gnb.in_act, gnb.in_eps = g_in, _rn.ACT[act], eps
+                gnb.in_g_rows_group, gnb.in_g_rows_chan = grg.data_ptr(), grc.data_ptr()
+            if i < nfold:                                # output side folded: cur_dy holds g of GroupNorm i
+                _, gamma_o, _b = tower[i]
+                for j in range(n):
+                    segs[j].y = _rn.f32(inputs[i + 1][j])
+                gnb.out_rows, gnb.out_g_rows_group = ctx.rows[i].data_ptr(), g_rows_group_next.data_ptr()
+                gnb.out_gamma, gnb.out_groups, gnb.out_eps = _rn.f32(gamma_o), gn_groups(cout, groups), eps
+            v_buf, u_buf = ctx.keep[i]
+            dw_buf, dw = _grad_slot(w)
+            need = L.rn_conv3x3_winograd_bwd_workspace(segs, n, cin, cout, tile, 1 if v_buf is not None else 0,
+                                                       1 if u_buf is not None else 0)
+            ws = _rn.workspace(need, dev)
+            _rn.check(L.rn_conv3x3_winograd_gn_bwd(segs, n, cin, cout, _rn.f32(w), _rn.f32(dw_buf), 0, tile, C.byref(gnb),
+                                                   ws.data_ptr(), ws.numel(),
+                                                   _rn.f32(v_buf) if v_buf is not None else None,
+                                                   _rn.f32(u_buf) if u_buf is not None else None, _rn.stream()),
+                      "rn_conv3x3_winograd_gn_bwd")
+            grads[3 * i if i < k else 3 * k] = dw
+            if i == nconv - 1 and out_b is not None and ctx.needs_input_grad[2 + n + 3 * k + 1]:
+                db_buf, db = _grad_slot(out_b)
+                geom = _rn.ConvGeom(3, 3, 1, cin, 1)
+                need = L.rn_conv2d_bias_grad_workspace(cout)
+                wsb = _grad_workspace(need, dev)
+                _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), wsb.data_ptr(), wsb.numel(), _rn.stream()),
+                          "rn_conv2d_bias_grad")
+                grads[3 * k + 1] = db
+            if i > 0:                                    # dbeta / dgamma of GroupNorm i-1 from the per-channel rows
+                _, gamma, beta = tower[i - 1]
+                dg_buf, dg = _grad_slot(gamma)
+                db_buf, db = _grad_slot(beta)
+                if _deferring:
+                    _deferred_keep.append(grc)
+                _rn.check(L.rn_reduce_rows(_rn.f32(grc[0]), _rn.f32(db_buf), cin, ctx.nrows, 0, _rn.stream()), "rn_reduce_rows")
+                _rn.check(L.rn_reduce_rows(_rn.f32(grc[1]), _rn.f32(dg_buf), cin, ctx.nrows, 0, _rn.stream()), "rn_reduce_rows")
+                grads[3 * (i - 1) + 1], grads[3 * (i - 1) + 2] = dg, db
+            cur_dy = dxs
+            g_rows_group_next = grg
+        return (None, None) + tuple(cur_dy) + tuple(grads)
+
+
+def wino_tower(xs, tower, out_w=None, out_b=None, groups=32, eps=1e-5, act=None):
+    """[conv3x3 -> GroupNorm -> act] for every (w, gamma, beta) of `tower`, then (if out_w is given) conv3x3(out_w) + out_b,
+    applied to every tensor of the list `xs` (shared parameters), as GroupNorm-folded Winograd layers.  Without out_w the
+    result is the RAW output of the last conv: its GroupNorm + activation are left to the caller."""
+    k = len(tower)
+    cfg = (groups, float(eps), act, k, out_w is not None)
+    flat = [t for layer in tower for t in layer]
+    if out_w is not None:
+        flat += [out_w, out_b]
+    return list(_WinoTower.apply(cfg, len(xs), *xs, *flat))
+
+
 class _Depthwise(torch.autograd.Function):
     """tf.nn.depthwise_conv2d(padding='SAME'), kernel [k,k,C,1] (mobilenet_v2.py:35-36)."""
 

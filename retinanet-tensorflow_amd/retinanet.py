@@ -93,13 +93,33 @@ class _Subnet(Model):
     def _reshape(self, t):
         return t.reshape(t.shape[0], t.shape[1], t.shape[2], self.num_anchors, self.last_dim)
 
+    def _folded(self, maps, training):
+        """The subnet as GroupNorm-folded Winograd layers (ops.wino_tower): no GroupNorm kernels, the normalised tensors are
+        never written.  None when the shapes / dtype do not qualify (then the layers run one by one)."""
+        if L.INFERENCE_F16 and not training:
+            return None
+        blocks = [blk.layers for blk in self.pre_conv.layers]          # [conv, norm, act] each
+        if any(b[0].weight is None or b[1].gamma is None for b in blocks) or self.out_conv.weight is None:
+            return None
+        tower = [(b[0].weight, b[1].gamma, b[1].beta) for b in blocks]
+        norm, act = blocks[0][1], L.activation_name(blocks[0][2])
+        if ops.wino_tower_ok(maps, tower, self.out_conv.weight, norm.groups):
+            return ops.wino_tower(maps, tower, self.out_conv.weight, self.out_conv.bias, norm.groups, norm.eps, act)
+        if ops.wino_tower_ok(maps, tower, None, norm.groups):
+            # the output conv cannot run as a Winograd layer (cout % 4 != 0): the last GroupNorm is materialised
+            raw = ops.wino_tower(maps, tower, None, None, norm.groups, norm.eps, act)
+            return self.out_conv(blocks[-1][1].fused(raw, training, act=act))
+        return None
+
     def call(self, input, training):
         """`input`: one feature map, or a list of maps (all pyramid levels, one launch per layer)."""
-        input = self.pre_conv(input, training)
-        input = self.out_conv(input)
-        if isinstance(input, (list, tuple)):
-            return [self._reshape(t) for t in input]
-        return self._reshape(input)
+        multi = isinstance(input, (list, tuple))
+        out = self._folded(list(input) if multi else [input], training)
+        if out is None:
+            out = self.out_conv(self.pre_conv(input, training))
+            out = list(out) if multi else [out]
+        out = [self._reshape(t) for t in out]
+        return out if multi else out[0]
 
 
 class ClassificationSubnet(_Subnet):

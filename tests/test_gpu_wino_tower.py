@@ -1,0 +1,141 @@
+"""GroupNorm folded into chains of Winograd layers (ops.wino_tower / rn_conv3x3_winograd_gn): the class / box towers without
+GroupNorm kernels.  Checked against the same chain run layer by layer through the stand-alone kernels (conv2d +
+group_norm_act), forward and every gradient, and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+from oracle import tf_ops_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import _rn
+    _rn.lib()
+    return torch.device("cuda:0")
+
+
+def _params(rng, k, c, cout, dev):
+    tower = []
+    for _ in range(k):
+        w = torch.from_numpy((rng.standard_normal((3, 3, c, c)) * 0.05).astype(np.float32)).to(dev).requires_grad_(True)
+        g = torch.from_numpy((1 + 0.3 * rng.standard_normal(c)).astype(np.float32)).to(dev).requires_grad_(True)
+        b = torch.from_numpy((0.2 * rng.standard_normal(c)).astype(np.float32)).to(dev).requires_grad_(True)
+        tower.append((w, g, b))
+    ow = ob = None
+    if cout:
+        ow = torch.from_numpy((rng.standard_normal((3, 3, c, cout)) * 0.05).astype(np.float32)).to(dev).requires_grad_(True)
+        ob = torch.from_numpy((0.1 * rng.standard_normal(cout)).astype(np.float32)).to(dev).requires_grad_(True)
+    return tower, ow, ob
+
+
+def _layerwise(xs, tower, ow, ob, act, groups):
+    import ops
+    cur = xs
+    for i, (w, g, b) in enumerate(tower):
+        cur = ops.conv2d(cur, w, None, 1)
+        if ow is None and i == len(tower) - 1:
+            return cur
+        cur = ops.group_norm_act(cur, g, b, groups=groups, eps=1e-5, act=act)
+    return ops.conv2d(cur, ow, ob, 1)
+
+
+SHAPES = [  # (list of (n, h, w)), channels, out channels (0: no output conv), layers, act, tile
+    ([(2, 16, 16), (2, 8, 8), (2, 4, 4), (2, 2, 2), (2, 1, 1)], 64, 36, 2, "elu", 4),     # pyramid incl. 1x1 map, box-like output
+    ([(2, 19, 13), (1, 7, 9)], 128, 72, 3, "relu", 4),                                    # ragged: partial tiles and partial chunks
+    ([(2, 16, 16), (2, 5, 5)], 64, 0, 2, "elu", 4),                                       # no output conv: last conv's raw output
+    ([(1, 33, 31), (2, 6, 6)], 64, 64, 2, "elu", 2),                                      # F(2x2,3x3)
+    ([(2, 64, 64), (2, 32, 32), (2, 16, 16), (2, 8, 8), (2, 4, 4)], 256, 36, 4, "elu", 4),  # the box subnet at the headline size
+]
+
+
+@pytest.mark.parametrize("case", SHAPES, ids=[str(i) for i in range(len(SHAPES))])
+def test_folded_tower_matches_layer_by_layer(dev, case):
+    import ops
+    shapes, c, cout, k, act, tile = case
+    rng = np.random.default_rng(hash(str(case)) % 1000)
+    old = ops.WINOGRAD_TILE
+    ops.WINOGRAD_TILE = tile
+    try:
+        tower, ow, ob = _params(rng, k, c, cout, dev)
+        xs = [torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).to(dev).requires_grad_(True) for n, h, w in shapes]
+        assert ops.wino_tower_ok(xs, tower, ow, 32)
+        got = ops.wino_tower(xs, tower, ow, ob, groups=32, eps=1e-5, act=act)
+        ref = _layerwise(xs, tower, ow, ob, act, 32)
+        dys = [torch.from_numpy(rng.standard_normal(tuple(r.shape)).astype(np.float32)).to(dev) for r in ref]
+        used = tower if ow is not None else tower[:-1] + [(tower[-1][0],)]    # without the output conv the last GroupNorm is not part of the chain
+        leaves = xs + [t for layer in used for t in layer] + ([ow, ob] if ow is not None else [])
+        g_got = torch.autograd.grad(got, leaves, dys)
+        g_ref = torch.autograd.grad(ref, leaves, dys)
+        for a, b in zip(got, ref):
+            assert_close(a.detach().cpu().numpy(), b.detach().cpu().numpy(), 2e-5, "forward")
+        names = ["dx%d" % i for i in range(len(xs))] + [n + str(i) for i in range(k) for n in ("dw", "dgamma", "dbeta")][:len(leaves) - len(xs) - (2 if ow is not None else 0)] + ["dw_out", "db_out"]
+        assert len(g_got) == len(g_ref) == len(leaves)
+        for name, a, b in zip(names, g_got, g_ref):
+            assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4, name)
+    finally:
+        ops.WINOGRAD_TILE = old
+
+
+def test_folded_tower_matches_oracle(dev):
+    """The folded chain against the CPU oracle's conv / GroupNorm / ELU, forward and gradients (1e-4)."""
+    import ops
+    rng = np.random.default_rng(3)
+    c, cout, k = 64, 72, 2
+    tower, ow, ob = _params(rng, k, c, cout, dev)
+    shapes = [(2, 12, 12), (2, 6, 6), (2, 3, 3)]
+    xs = [torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).to(dev).requires_grad_(True) for n, h, w in shapes]
+    got = ops.wino_tower(xs, tower, ow, ob, groups=32, eps=1e-5, act="elu")
+    cpu = [x.detach().cpu().requires_grad_(True) for x in xs]
+    ctower = [tuple(t.detach().cpu().requires_grad_(True) for t in layer) for layer in tower]
+    cow, cob = ow.detach().cpu().requires_grad_(True), ob.detach().cpu().requires_grad_(True)
+    ref = []
+    for x in cpu:
+        h = x
+        for w, g, b in ctower:
+            h = tf_ops_ref.activation(tf_ops_ref.group_norm(tf_ops_ref.conv2d_same(h, w, 1), g, b, 32), "elu")
+        ref.append(tf_ops_ref.conv2d_same(h, cow, 1, bias=cob))
+    dys = [torch.from_numpy(rng.standard_normal(tuple(r.shape)).astype(np.float32)) for r in ref]
+    leaves_c = cpu + [t for layer in ctower for t in layer] + [cow, cob]
+    leaves_g = xs + [t for layer in tower for t in layer] + [ow, ob]
+    g_ref = torch.autograd.grad(ref, leaves_c, dys)
+    g_got = torch.autograd.grad(got, leaves_g, [d.to(dev) for d in dys])
+    for a, b in zip(got, ref):
+        assert_close(a.detach().cpu().numpy(), b.detach().numpy(), 1e-4, "forward vs oracle")
+    for i, (a, b) in enumerate(zip(g_got, g_ref)):
+        assert_close(a.cpu().numpy(), b.numpy(), 1e-4, "gradient %d vs oracle" % i)
+
+
+def test_subnet_uses_the_folded_path_and_equals_unfolded(dev):
+    """retinanet._Subnet through both paths (fold on / off), incl. a class count whose output conv cannot be a Winograd layer."""
+    import layers, ops, retinanet
+    for classes in (80, 3):
+        torch.manual_seed(1)
+        sub = retinanet.ClassificationSubnet(9, classes, layers.elu, layers.RandomNormal(0.0, 0.05), layers.L2Regularizer(1e-4)).to(dev)
+        g = torch.Generator().manual_seed(2)
+        with torch.no_grad():
+            for name, p in sub.named_parameters():
+                if name.endswith("gamma"):
+                    p.copy_((1 + 0.2 * torch.randn(p.shape, generator=g)).to(dev))
+                elif name.endswith("beta"):
+                    p.copy_((0.1 * torch.randn(p.shape, generator=g)).to(dev))
+        xs = [torch.randn(2, s, s, 256, generator=g).to(dev).requires_grad_(True) for s in (8, 4, 2)]
+        outs, grads = [], []
+        for fold in (True, False):
+            ops.WINO_GN_FOLD = fold
+            try:
+                o = sub(xs, training=True)
+            finally:
+                ops.WINO_GN_FOLD = True
+            loss = sum((t * t).mean() for t in o)
+            grads.append(torch.autograd.grad(loss, xs + list(sub.parameters())))
+            outs.append(o)
+        for a, b in zip(outs[0], outs[1]):
+            assert a.shape == (2, a.shape[1], a.shape[2], 9, classes)
+            assert_close(a.detach().cpu().numpy(), b.detach().cpu().numpy(), 2e-5, "subnet forward")
+        for a, b in zip(grads[0], grads[1]):
+            assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4, "subnet gradient")
