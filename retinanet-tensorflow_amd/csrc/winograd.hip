@@ -671,11 +671,15 @@ extern "C" int rn_conv3x3_winograd_bwd(const rn_conv_seg* segs, int nseg, int ci
 //             dy transforms of layer i    : load dy = rstd (gamma g - c1 - xhat c2) on the fly from g and y_i
 // so a tower layer is three launches forward and three backward with NO GroupNorm kernel, no exchange between
 // blocks and no spinning: every reduction is a fixed-order sum over rows written by an earlier launch.
-// Organisation: a block = one chunk (16 consecutive tiles of ONE sample) x 64 channels (whole groups), 256 threads
-// = 16 tiles x 16 channel quads.  Needs C % 64 == 0 and 64 % (C / groups) == 0 on the folded side.
+// Organisation: a block (256 threads) = one chunk (16 consecutive tiles of ONE sample) x 16 channel lanes of W channels
+// each (whole groups): W = 4 when the launch fills the chip with that, else 2 or 1 -- the pyramids of a 512^2 batch
+// are latency-, not bandwidth-bound, and narrow lanes put 4x the blocks in flight.  Needs C % 64 == 0 and
+// 64 % (C / groups) == 0 on the folded side.
 // =============================================================================================================
 namespace {
-constexpr int CK_TILES = 16, CK_CH = 64;
+constexpr int CK_TILES = 16, CK_LANES = 16, CK_T = CK_TILES * CK_LANES;  // a block: 16 tiles x 16 channel lanes of W channels
+constexpr int CK_MAXCH = 64;  // channels per block with W = 4
+constexpr int ROW_F = 4;  // floats per (chunk, group) of a statistics row: count, mean, M2, unused
 
 struct CSeg { const float* x; const float* aux; float* y; int n, h, w, th, tw, tile_start, chunk_start, cps; };
 struct CArgs {
@@ -702,169 +706,222 @@ __device__ __forceinline__ int cseg_of_chunk(const CArgs& a, int ch) {
   return s;
 }
 
-struct BlockPos { int s, sample, k, tl, q, lt, t_global, c0; bool tile_ok; };
+struct BlockPos { int s, sample, k, tl, q, lt, t_global, c0, cl; bool tile_ok; };
+template <int W>
 __device__ __forceinline__ BlockPos block_pos(const CArgs& a, int chunk, int slab) {
+  constexpr int LANES = CK_LANES;
   BlockPos p;
   p.s = cseg_of_chunk(a, chunk);
   const CSeg& sg = a.seg[p.s];
   const int local = chunk - sg.chunk_start;
   p.sample = local / sg.cps;
   p.k = local - p.sample * sg.cps;
-  p.tl = threadIdx.x >> 4;
-  p.q = threadIdx.x & 15;
+  p.tl = threadIdx.x / LANES;
+  p.q = threadIdx.x % LANES;
   p.lt = p.k * CK_TILES + p.tl;
   const int tps = sg.th * sg.tw;
   p.tile_ok = p.lt < tps;
   p.t_global = sg.tile_start + p.sample * tps + min(p.lt, tps - 1);
-  p.c0 = slab * CK_CH + p.q * 4;
+  p.cl = p.q * W;
+  p.c0 = slab * (CK_LANES * W) + p.cl;
   return p;
 }
 
-// per-group sums of `rows` over the chunks of this block's sample -> sh[g_local][comp] (fp64, chunk order)
-__device__ __forceinline__ void sample_group_sums(const float* rows, const CSeg& sg, int sample, int groups, int g0, int ng,
-                                                  double (*sh)[2]) {
-  const int t = threadIdx.x;
-  if (t < ng * 2) {
-    const int gl = t >> 1, comp = t & 1;
-    const float* p = rows + ((size_t)(sg.chunk_start + sample * sg.cps) * groups + g0 + gl) * 2 + comp;
-    double acc = 0.0;
-    for (int k = 0; k < sg.cps; ++k) acc += (double)p[(size_t)k * groups * 2];
-    sh[gl][comp] = acc;
+template <int W>
+__device__ __forceinline__ typename VecW<W>::type ldv(const float* p) { return *reinterpret_cast<const typename VecW<W>::type*>(p); }
+template <int W>
+__device__ __forceinline__ typename VecW<W>::type lanes(const float (*st)[2], int cl, int cpg, int comp) {
+  if constexpr (W == 1) {
+    return st[cl / cpg][comp];
+  } else {
+    typename VecW<W>::type v;
+#pragma unroll
+    for (int i = 0; i < W; ++i) v[i] = st[(cl + i) / cpg][comp];
+    return v;
   }
-  __syncthreads();
 }
-
-// ---- tap loaders: the value of the tensor at (pixel offset `off` in elements, this thread's 4 channels)
-struct LoadPlain {
-  const float* x;
-  __device__ __forceinline__ float4 operator()(size_t off) const { return *reinterpret_cast<const float4*>(x + off); }
-};
-struct LoadGnAct {   // act(GN(x)): x * sc + sh per channel
-  const float* x; float4 sc, sh; int act;
-  __device__ __forceinline__ float4 operator()(size_t off) const {
-    const float4 v = *reinterpret_cast<const float4*>(x + off);
-    return make_float4(rn::act_fwd(v.x * sc.x + sh.x, act), rn::act_fwd(v.y * sc.y + sh.y, act),
-                       rn::act_fwd(v.z * sc.z + sh.z, act), rn::act_fwd(v.w * sc.w + sh.w, act));
-  }
-};
-struct LoadGnBwd {   // dy = rstd (gamma g - c1 - xhat c2), xhat = (y - mean) rstd; g in `x`, y in `aux`
-  const float* x; const float* aux; float4 mean, rstd, gam, c1, c2;
-  __device__ __forceinline__ float4 operator()(size_t off) const {
-    const float4 g = *reinterpret_cast<const float4*>(x + off);
-    const float4 y = *reinterpret_cast<const float4*>(aux + off);
-    float4 o;
-    o.x = rstd.x * (gam.x * g.x - c1.x - (y.x - mean.x) * rstd.x * c2.x);
-    o.y = rstd.y * (gam.y * g.y - c1.y - (y.y - mean.y) * rstd.y * c2.y);
-    o.z = rstd.z * (gam.z * g.z - c1.z - (y.z - mean.z) * rstd.z * c2.z);
-    o.w = rstd.w * (gam.w * g.w - c1.w - (y.w - mean.w) * rstd.w * c2.w);
+template <int W, bool GRAD, int ACT>
+__device__ __forceinline__ typename VecW<W>::type map_act(typename VecW<W>::type z) {
+  if constexpr (W == 1) {
+    return GRAD ? rn::act_grad(z, ACT) : rn::act_fwd(z, ACT);
+  } else {
+    typename VecW<W>::type o;
+#pragma unroll
+    for (int i = 0; i < W; ++i) o[i] = GRAD ? rn::act_grad(z[i], ACT) : rn::act_fwd(z[i], ACT);
     return o;
   }
-};
-
-__device__ __forceinline__ float4 lane4(const float (*st)[2], int c_local, int cpg, int comp) {
-  return make_float4(st[(c_local) / cpg][comp], st[(c_local + 1) / cpg][comp], st[(c_local + 2) / cpg][comp],
-                     st[(c_local + 3) / cpg][comp]);
+}
+// the activation is a runtime argument of the call but a compile-time constant of the per-element code: ONE uniform
+// switch around the whole loop (a switch per element puts a branch between the loads of consecutive taps, and the
+// compiler then waits for each load before issuing the next: 36 serialised round trips)
+template <int A>
+struct ActTag { static constexpr int value = A; };
+template <typename F>
+__device__ __forceinline__ void dispatch_act(int act, F fn) {
+  switch (act) {
+    case RN_ACT_RELU: fn(ActTag<RN_ACT_RELU>{}); break;
+    case RN_ACT_ELU: fn(ActTag<RN_ACT_ELU>{}); break;
+    case RN_ACT_RELU6: fn(ActTag<RN_ACT_RELU6>{}); break;
+    default: fn(ActTag<RN_ACT_NONE>{}); break;
+  }
+}
+template <int W>
+__device__ __forceinline__ float lane_of(typename VecW<W>::type v, int i) {
+  if constexpr (W == 1) return v; else return v[i];
 }
 
 // mean / rstd of the block's groups -> st[g_local][0..1]: the stat rows hold (count, mean, M2 = sum (y - mean)^2) per
-// (chunk, group) and are merged in chunk order with the pairwise update of Chan et al. in fp64 -- no E[y^2] - E[y]^2
-// cancellation, however few values a group has (a 1x1 pyramid level has C / groups of them)
-constexpr int ROW_F = 4;  // floats per (chunk, group) of a statistics row: count, mean, M2, unused
-__device__ __forceinline__ void block_stats(const Fold& f, const CSeg& sg, int sample, int slab, double (*shd)[2], float (*st)[2]) {
-  const int ng = CK_CH / f.cpg, g0 = slab * ng;
-  if ((int)threadIdx.x < ng) {
-    const float* p = f.rows + ((size_t)(sg.chunk_start + sample * sg.cps) * f.groups + g0 + threadIdx.x) * ROW_F;
-    double n = 0.0, mean = 0.0, m2 = 0.0;
+// (chunk, group); they are combined in fp64 in chunk order, mean first, then M2 about it -- no E[y^2] - E[y]^2
+// cancellation, however few values a group has (a 1x1 pyramid level has C / groups of them).  The rows of the sample
+// are fetched by all threads at once into LDS (one round trip instead of one per row), then summed in order.
+constexpr int STAGE_ROWS = 1024;  // (chunk, group) rows staged per block: 16 KB
+__device__ __forceinline__ void block_stats(const Fold& f, const CSeg& sg, int sample, int slab, int ch, float (*st)[2]) {
+  __shared__ float4 stage[STAGE_ROWS];
+  const int ng = ch / f.cpg, g0 = slab * ng, total = ng * sg.cps, tid = threadIdx.x;
+  const float* p = f.rows + ((size_t)(sg.chunk_start + sample * sg.cps) * f.groups + g0) * ROW_F;
+  const bool staged = total <= STAGE_ROWS;
+  if (staged) {
+    for (int i = tid; i < total; i += blockDim.x) {
+      const int k = i / ng, gl = i - k * ng;
+      stage[i] = *reinterpret_cast<const float4*>(p + ((size_t)k * f.groups + gl) * ROW_F);
+    }
+    __syncthreads();
+  }
+  if (tid < ng) {
+    auto row = [&](int k) { return staged ? stage[k * ng + tid] : *reinterpret_cast<const float4*>(p + ((size_t)k * f.groups + tid) * ROW_F); };
+    double n = 0.0, sm = 0.0;
     for (int k = 0; k < sg.cps; ++k) {
-      const float4 r = *reinterpret_cast<const float4*>(p + (size_t)k * f.groups * ROW_F);
-      const double nr = (double)r.x, d = (double)r.y - mean, nn = n + nr;
-      if (nr > 0.0) {
-        mean += d * nr / nn;
-        m2 += (double)r.z + d * d * n * nr / nn;
-        n = nn;
-      }
+      const float4 r = row(k);
+      n += (double)r.x;
+      sm += (double)r.x * (double)r.y;
+    }
+    const double mean = n > 0.0 ? sm / n : 0.0;
+    double m2 = 0.0;
+    for (int k = 0; k < sg.cps; ++k) {
+      const float4 r = row(k);
+      const double d = (double)r.y - mean;
+      m2 += (double)r.z + (double)r.x * d * d;
     }
     const double var = n > 0.0 ? m2 / n : 0.0;
-    st[threadIdx.x][0] = (float)mean;
-    st[threadIdx.x][1] = (float)(1.0 / sqrt(var + (double)f.eps));
+    st[tid][0] = (float)mean;
+    st[tid][1] = (float)(1.0 / sqrt(var + (double)f.eps));
   }
   __syncthreads();
 }
-
-template <typename L>
-__device__ __forceinline__ L make_loader(const CArgs& a, const Fold& f, const CSeg& sg, const BlockPos& p, int slab);
-
-template <>
-__device__ __forceinline__ LoadPlain make_loader<LoadPlain>(const CArgs&, const Fold&, const CSeg& sg, const BlockPos&, int) {
-  return LoadPlain{sg.x};
-}
-template <>
-__device__ __forceinline__ LoadGnAct make_loader<LoadGnAct>(const CArgs&, const Fold& f, const CSeg& sg, const BlockPos& p, int slab) {
-  __shared__ double shd[CK_CH][2];
-  __shared__ float st[CK_CH][2];
-  block_stats(f, sg, p.sample, slab, shd, st);
-  const int cl = p.q * 4;
-  const float4 mean = lane4(st, cl, f.cpg, 0), rstd = lane4(st, cl, f.cpg, 1);
-  const float4 gam = *reinterpret_cast<const float4*>(f.gamma + p.c0), bet = *reinterpret_cast<const float4*>(f.beta + p.c0);
-  LoadGnAct l;
-  l.x = sg.x; l.act = f.act;
-  l.sc = make_float4(rstd.x * gam.x, rstd.y * gam.y, rstd.z * gam.z, rstd.w * gam.w);
-  l.sh = make_float4(bet.x - mean.x * l.sc.x, bet.y - mean.y * l.sc.y, bet.z - mean.z * l.sc.z, bet.w - mean.w * l.sc.w);
-  return l;
-}
-template <>
-__device__ __forceinline__ LoadGnBwd make_loader<LoadGnBwd>(const CArgs&, const Fold& f, const CSeg& sg, const BlockPos& p, int slab) {
-  __shared__ double shd[CK_CH][2];
-  __shared__ float st[CK_CH][2], co[CK_CH][2];
-  block_stats(f, sg, p.sample, slab, shd, st);
-  const int ng = CK_CH / f.cpg, g0 = slab * ng;
-  sample_group_sums(f.grows, sg, p.sample, f.groups, g0, ng, shd);
-  if ((int)threadIdx.x < ng) {
+// (sum gamma g, sum gamma g xhat) / m of the block's groups -> co[g_local][0..1]
+__device__ __forceinline__ void block_coefs(const Fold& f, const CSeg& sg, int sample, int slab, int ch, float (*co)[2]) {
+  __shared__ float2 stage2[STAGE_ROWS];
+  const int ng = ch / f.cpg, g0 = slab * ng, total = ng * sg.cps, tid = threadIdx.x;
+  const float* p = f.grows + ((size_t)(sg.chunk_start + sample * sg.cps) * f.groups + g0) * 2;
+  const bool staged = total <= STAGE_ROWS;
+  if (staged) {
+    for (int i = tid; i < total; i += blockDim.x) {
+      const int k = i / ng, gl = i - k * ng;
+      stage2[i] = *reinterpret_cast<const float2*>(p + ((size_t)k * f.groups + gl) * 2);
+    }
+    __syncthreads();
+  }
+  if (tid < ng) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int k = 0; k < sg.cps; ++k) {
+      const float2 r = staged ? stage2[k * ng + tid] : *reinterpret_cast<const float2*>(p + ((size_t)k * f.groups + tid) * 2);
+      a0 += (double)r.x; a1 += (double)r.y;
+    }
     const double m = (double)sg.h * (double)sg.w * (double)f.cpg;
-    co[threadIdx.x][0] = (float)(shd[threadIdx.x][0] / m);
-    co[threadIdx.x][1] = (float)(shd[threadIdx.x][1] / m);
+    co[tid][0] = (float)(a0 / m);
+    co[tid][1] = (float)(a1 / m);
   }
   __syncthreads();
-  const int cl = p.q * 4;
-  LoadGnBwd l;
-  l.x = sg.x; l.aux = sg.aux;
-  l.mean = lane4(st, cl, f.cpg, 0); l.rstd = lane4(st, cl, f.cpg, 1);
-  l.c1 = lane4(co, cl, f.cpg, 0); l.c2 = lane4(co, cl, f.cpg, 1);
-  l.gam = *reinterpret_cast<const float4*>(f.gamma + p.c0);
-  return l;
 }
+
+// ---- tap loaders: fetch() issues the loads of one tap (element offset `off`, this thread's W channels), fin<ACT>() turns
+// them into the value the transform sees.  The bodies fetch every tap first and finish them in a second loop, so all
+// the loads of a thread are in flight together.
+template <int W>
+struct LoadPlain {
+  typedef typename VecW<W>::type VT;
+  static constexpr int NLOAD = 1;
+  const float* x;
+  __device__ __forceinline__ void init(const Fold&, const CSeg& sg, const BlockPos&, int) { x = sg.x; }
+  __device__ __forceinline__ int act_id() const { return RN_ACT_NONE; }
+  __device__ __forceinline__ void fetch(size_t off, VT& a, VT&) const { a = ldv<W>(x + off); }
+  template <int ACT>
+  __device__ __forceinline__ VT fin(VT a, VT) const { return a; }
+};
+template <int W>
+struct LoadGnAct {   // act(GN(x)): x * sc + sh per channel
+  typedef typename VecW<W>::type VT;
+  static constexpr int NLOAD = 1;
+  const float* x; VT sc, sh; int act;
+  __device__ __forceinline__ void init(const Fold& f, const CSeg& sg, const BlockPos& p, int slab) {
+    __shared__ float st[CK_MAXCH][2];
+    block_stats(f, sg, p.sample, slab, CK_LANES * W, st);
+    const VT mean = lanes<W>(st, p.cl, f.cpg, 0), rstd = lanes<W>(st, p.cl, f.cpg, 1);
+    x = sg.x; act = f.act;
+    sc = rstd * ldv<W>(f.gamma + p.c0);
+    sh = ldv<W>(f.beta + p.c0) - mean * sc;
+  }
+  __device__ __forceinline__ int act_id() const { return act; }
+  __device__ __forceinline__ void fetch(size_t off, VT& a, VT&) const { a = ldv<W>(x + off); }
+  template <int ACT>
+  __device__ __forceinline__ VT fin(VT a, VT) const { return map_act<W, false, ACT>(a * sc + sh); }
+};
+template <int W>
+struct LoadGnBwd {   // dy = rstd (gamma g - c1 - xhat c2), xhat = (y - mean) rstd; g in `x`, y in `aux`
+  typedef typename VecW<W>::type VT;
+  static constexpr int NLOAD = 2;
+  const float* x; const float* aux; VT mean, rstd, gam, c1, c2;
+  __device__ __forceinline__ void init(const Fold& f, const CSeg& sg, const BlockPos& p, int slab) {
+    __shared__ float st[CK_MAXCH][2], co[CK_MAXCH][2];
+    block_stats(f, sg, p.sample, slab, CK_LANES * W, st);
+    block_coefs(f, sg, p.sample, slab, CK_LANES * W, co);
+    x = sg.x; aux = sg.aux;
+    mean = lanes<W>(st, p.cl, f.cpg, 0); rstd = lanes<W>(st, p.cl, f.cpg, 1);
+    c1 = lanes<W>(co, p.cl, f.cpg, 0); c2 = lanes<W>(co, p.cl, f.cpg, 1);
+    gam = ldv<W>(f.gamma + p.c0);
+  }
+  __device__ __forceinline__ int act_id() const { return RN_ACT_NONE; }
+  __device__ __forceinline__ void fetch(size_t off, VT& g, VT& y) const { g = ldv<W>(x + off); y = ldv<W>(aux + off); }
+  template <int ACT>
+  __device__ __forceinline__ VT fin(VT g, VT y) const { return rstd * (gam * g - c1 - (y - mean) * rstd * c2); }
+};
 
 // ---- input transform of a chunk: V[xi][tile][c] = (B^T d B)[xi], d = the (M+2)^2 patch read through loader L
-template <int M, typename L>
+template <int M, int W, template <int> class LT>
 __device__ __forceinline__ void chunk_input_body(const CArgs& a, const Fold& f, int chunk, int slab) {
-  typedef float4 VT;
+  typedef typename VecW<W>::type VT;
   constexpr int P = M + 2;
-  const BlockPos p = block_pos(a, chunk, slab);
+  const BlockPos p = block_pos<W>(a, chunk, slab);
   const CSeg& sg = a.seg[p.s];
-  const L ld = make_loader<L>(a, f, sg, p, slab);
+  LT<W> ld;
+  ld.init(f, sg, p, slab);
   if (!p.tile_ok) return;
   const int ty = p.lt / sg.tw, tx = p.lt - ty * sg.tw;
   const int y0 = M * ty - 1, x0 = M * tx - 1;
   const size_t plane = (size_t)a.total_tiles * a.c;
-  typedef float v4 __attribute__((ext_vector_type(4)));
-  v4 d[P][P];
+  VT d[P][P], e[LT<W>::NLOAD == 2 ? P : 1][LT<W>::NLOAD == 2 ? P : 1];
 #pragma unroll
   for (int r = 0; r < P; ++r) {
-    const int yy = y0 + r;
+    const int yc = min(max(y0 + r, 0), sg.h - 1);
 #pragma unroll
-    for (int c = 0; c < P; ++c) {
-      const int xx = x0 + c;
-      const bool ok = (unsigned)yy < (unsigned)sg.h && (unsigned)xx < (unsigned)sg.w;
-      const int yc = min(max(yy, 0), sg.h - 1), xc = min(max(xx, 0), sg.w - 1);
-      const VT v = ld(((size_t)(p.sample * sg.h + yc) * sg.w + xc) * a.c + p.c0);   // the padding is zero AFTER the activation
-      const float m = ok ? 1.f : 0.f;
-      d[c][r] = (v4){v.x * m, v.y * m, v.z * m, v.w * m};
+    for (int c = 0; c < P; ++c) {   // clamped addresses: every load is unconditional
+      const int xc = min(max(x0 + c, 0), sg.w - 1);
+      ld.fetch(((size_t)(p.sample * sg.h + yc) * sg.w + xc) * a.c + p.c0, d[c][r], e[LT<W>::NLOAD == 2 ? c : 0][LT<W>::NLOAD == 2 ? r : 0]);
     }
   }
-  v4 tm[P][P];
+  dispatch_act(ld.act_id(), [&](auto tag) {
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+#pragma unroll
+      for (int c = 0; c < P; ++c) {  // 0/1 mask: the padding is zero AFTER the activation
+        const bool ok = (unsigned)(y0 + r) < (unsigned)sg.h && (unsigned)(x0 + c) < (unsigned)sg.w;
+        d[c][r] = ld.template fin<decltype(tag)::value>(d[c][r], e[LT<W>::NLOAD == 2 ? c : 0][LT<W>::NLOAD == 2 ? r : 0]) * (ok ? 1.f : 0.f);
+      }
+  });
+  VT tm[P][P];
 #pragma unroll
   for (int c = 0; c < P; ++c) {
-    v4 col[P];
+    VT col[P];
     Wino<M>::bt(d[c], col);
 #pragma unroll
     for (int r = 0; r < P; ++r) tm[r][c] = col[r];
@@ -872,37 +929,49 @@ __device__ __forceinline__ void chunk_input_body(const CArgs& a, const Fold& f, 
   float* out = a.buf + (size_t)p.t_global * a.c + p.c0;
 #pragma unroll
   for (int r = 0; r < P; ++r) {
-    v4 row[P];
+    VT row[P];
     Wino<M>::bt(tm[r], row);
 #pragma unroll
-    for (int c = 0; c < P; ++c) *reinterpret_cast<v4*>(out + (size_t)(r * P + c) * plane) = row[c];
+    for (int c = 0; c < P; ++c) *reinterpret_cast<VT*>(out + (size_t)(r * P + c) * plane) = row[c];
   }
 }
 
 // ---- A dY A^T of a chunk (weight gradient), dY read through loader L
-template <int M, typename L>
+template <int M, int W, template <int> class LT>
 __device__ __forceinline__ void chunk_dy_body(const CArgs& a, const Fold& f, int chunk, int slab) {
+  typedef typename VecW<W>::type VT;
   constexpr int P = M + 2;
-  typedef float v4 __attribute__((ext_vector_type(4)));
-  const BlockPos p = block_pos(a, chunk, slab);
+  const BlockPos p = block_pos<W>(a, chunk, slab);
   const CSeg& sg = a.seg[p.s];
-  const L ld = make_loader<L>(a, f, sg, p, slab);
+  LT<W> ld;
+  ld.init(f, sg, p, slab);
   if (!p.tile_ok) return;
   const int ty = p.lt / sg.tw, tx = p.lt - ty * sg.tw;
   const int y0 = M * ty, x0 = M * tx;
   const size_t plane = (size_t)a.total_tiles * a.c;
-  v4 tm[P][M];
+  VT d[M][M], e[LT<W>::NLOAD == 2 ? M : 1][LT<W>::NLOAD == 2 ? M : 1];
 #pragma unroll
-  for (int c = 0; c < M; ++c) {
-    v4 col[M], o[P];
+  for (int c = 0; c < M; ++c)
 #pragma unroll
     for (int r = 0; r < M; ++r) {
-      const bool ok = y0 + r < sg.h && x0 + c < sg.w;
       const int yc = min(y0 + r, sg.h - 1), xc = min(x0 + c, sg.w - 1);
-      const float4 v = ld(((size_t)(p.sample * sg.h + yc) * sg.w + xc) * a.c + p.c0);
-      const float m = ok ? 1.f : 0.f;
-      col[r] = (v4){v.x * m, v.y * m, v.z * m, v.w * m};
+      ld.fetch(((size_t)(p.sample * sg.h + yc) * sg.w + xc) * a.c + p.c0, d[c][r], e[LT<W>::NLOAD == 2 ? c : 0][LT<W>::NLOAD == 2 ? r : 0]);
     }
+  dispatch_act(ld.act_id(), [&](auto tag) {
+#pragma unroll
+    for (int c = 0; c < M; ++c)
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        const bool ok = y0 + r < sg.h && x0 + c < sg.w;
+        d[c][r] = ld.template fin<decltype(tag)::value>(d[c][r], e[LT<W>::NLOAD == 2 ? c : 0][LT<W>::NLOAD == 2 ? r : 0]) * (ok ? 1.f : 0.f);
+      }
+  });
+  VT tm[P][M];
+#pragma unroll
+  for (int c = 0; c < M; ++c) {
+    VT col[M], o[P];
+#pragma unroll
+    for (int r = 0; r < M; ++r) col[r] = d[c][r];
     Wino<M>::a(col, o);
 #pragma unroll
     for (int r = 0; r < P; ++r) tm[r][c] = o[r];
@@ -910,188 +979,198 @@ __device__ __forceinline__ void chunk_dy_body(const CArgs& a, const Fold& f, int
   float* out = a.buf + (size_t)p.t_global * a.c + p.c0;
 #pragma unroll
   for (int r = 0; r < P; ++r) {
-    v4 row[P];
+    VT row[P];
     Wino<M>::a(tm[r], row);
 #pragma unroll
-    for (int c = 0; c < P; ++c) *reinterpret_cast<v4*>(out + (size_t)(r * P + c) * plane) = row[c];
+    for (int c = 0; c < P; ++c) *reinterpret_cast<VT*>(out + (size_t)(r * P + c) * plane) = row[c];
   }
 }
 
 // ---- output transform of a chunk.  MODE 0: y = A^T m A (+ bias), optional stat rows of y.
 //      MODE 1 (data gradient into a folded GroupNorm): o = dA; g = o * act'(z) from the raw tensor in seg.aux; writes g
 //      and the rows (sum g, sum g xhat) per channel and gamma-weighted per group.
-template <int M, int MODE>
+template <int M, int W, int MODE>
 __device__ __forceinline__ void chunk_output_body(const CArgs& a, const Fold& f, int chunk, int slab) {
-  constexpr int P = M + 2;
-  typedef float v4 __attribute__((ext_vector_type(4)));
-  __shared__ float red[256][8];
-  __shared__ float chan[CK_CH][2];
-  __shared__ double shd[CK_CH][2];
-  __shared__ float st[CK_CH][2];
-  const BlockPos p = block_pos(a, chunk, slab);
+  typedef typename VecW<W>::type VT;
+  constexpr int P = M + 2, LANES = CK_LANES, T = CK_T, CH = CK_LANES * W;
+  __shared__ float red[T][2 * W];
+  __shared__ float chan[CH][3];
+  __shared__ float st[CH][2];
+  __shared__ float cnt[CK_TILES];
+  const BlockPos p = block_pos<W>(a, chunk, slab);
   const CSeg& sg = a.seg[p.s];
   const int tid = threadIdx.x;
-  v4 sc = (v4)(0.f), sh = (v4)(0.f), mean = (v4)(0.f), rstd = (v4)(0.f);
+  VT gam = (VT)(0.f), bet = (VT)(0.f), mean = (VT)(0.f), rstd = (VT)(0.f);
   if (MODE == 1) {
-    block_stats(f, sg, p.sample, slab, shd, st);
-    const int cl = p.q * 4;
-    const float4 mu = lane4(st, cl, f.cpg, 0), rs = lane4(st, cl, f.cpg, 1);
-    const float4 gam = *reinterpret_cast<const float4*>(f.gamma + p.c0), bet = *reinterpret_cast<const float4*>(f.beta + p.c0);
-    mean = (v4){mu.x, mu.y, mu.z, mu.w}; rstd = (v4){rs.x, rs.y, rs.z, rs.w};
-    sc = (v4){gam.x, gam.y, gam.z, gam.w}; sh = (v4){bet.x, bet.y, bet.z, bet.w};
+    block_stats(f, sg, p.sample, slab, CH, st);
+    mean = lanes<W>(st, p.cl, f.cpg, 0); rstd = lanes<W>(st, p.cl, f.cpg, 1);
+    gam = ldv<W>(f.gamma + p.c0); bet = ldv<W>(f.beta + p.c0);
   }
-  v4 s1 = (v4)(0.f), s2 = (v4)(0.f);
+  VT s1 = (VT)(0.f), s2 = (VT)(0.f);
   float nvalid = 0.f;
   const bool want_rows = MODE == 1 || f.out_rows != nullptr;
   if (p.tile_ok) {
     const int ty = p.lt / sg.tw, tx = p.lt - ty * sg.tw;
     const size_t plane = (size_t)a.total_tiles * a.c;
     const float* in = a.buf + (size_t)p.t_global * a.c + p.c0;
-    v4 rr[M][P];
+    VT rr[M][P];
 #pragma unroll
     for (int c = 0; c < P; ++c) {
-      v4 col[P], o[M];
+      VT col[P], o[M];
 #pragma unroll
-      for (int r = 0; r < P; ++r) col[r] = *reinterpret_cast<const v4*>(in + (size_t)(r * P + c) * plane);
+      for (int r = 0; r < P; ++r) col[r] = ldv<W>(in + (size_t)(r * P + c) * plane);
       Wino<M>::at(col, o);
 #pragma unroll
       for (int i2 = 0; i2 < M; ++i2) rr[i2][c] = o[i2];
     }
-    v4 b = (v4)(0.f);
-    if (a.bias) b = *reinterpret_cast<const v4*>(a.bias + p.c0);
+    VT b = (VT)(0.f);
+    if (a.bias) b = ldv<W>(a.bias + p.c0);
     const int y0 = M * ty, x0 = M * tx;
-    v4 vals[M][M];
+    VT vals[M][M], xh[MODE == 1 ? M : 1][MODE == 1 ? M : 1];
+    if (MODE == 1) {   // the raw tensor at the tile's pixels (clamped addresses: always valid), all loads in flight
+#pragma unroll
+      for (int i2 = 0; i2 < M; ++i2)
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+          xh[MODE == 1 ? i2 : 0][MODE == 1 ? j : 0] =
+              ldv<W>(sg.aux + ((size_t)(p.sample * sg.h + min(y0 + i2, sg.h - 1)) * sg.w + min(x0 + j, sg.w - 1)) * a.c + p.c0);
+    }
 #pragma unroll
     for (int i2 = 0; i2 < M; ++i2) {
-      v4 o[M];
+      VT o[M];
       Wino<M>::at(rr[i2], o);
+#pragma unroll
+      for (int j = 0; j < M; ++j) vals[i2][j] = o[j] + b;
+    }
+    if (MODE == 1) {
+      dispatch_act(f.act, [&](auto tag) {
+#pragma unroll
+        for (int i2 = 0; i2 < M; ++i2)
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            const VT h = (xh[MODE == 1 ? i2 : 0][MODE == 1 ? j : 0] - mean) * rstd;
+            xh[MODE == 1 ? i2 : 0][MODE == 1 ? j : 0] = h;
+            vals[i2][j] = vals[i2][j] * map_act<W, true, decltype(tag)::value>(h * gam + bet);
+          }
+      });
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < M; ++i2)
 #pragma unroll
       for (int j = 0; j < M; ++j) {
         const bool ok = y0 + i2 < sg.h && x0 + j < sg.w;
         const size_t off = ((size_t)(p.sample * sg.h + min(y0 + i2, sg.h - 1)) * sg.w + min(x0 + j, sg.w - 1)) * a.c + p.c0;
-        v4 v = o[j] + b;
-        if (MODE == 1) {
-          const v4 yv = *reinterpret_cast<const v4*>(sg.aux + off);      // clamped address: always valid
-          const v4 xh = (yv - mean) * rstd;
-          const v4 z = xh * sc + sh;
-          v4 ag;
-          ag.x = rn::act_grad(z.x, f.act); ag.y = rn::act_grad(z.y, f.act); ag.z = rn::act_grad(z.z, f.act); ag.w = rn::act_grad(z.w, f.act);
-          v = v * ag;
-          if (ok) { s1 += v; s2 += v * xh; }
-        } else if (ok) {
-          s1 += v; nvalid += 1.f;
+        const VT v = vals[i2][j];
+        if (ok) {
+          s1 += v;
+          if (MODE == 1) s2 += v * xh[MODE == 1 ? i2 : 0][MODE == 1 ? j : 0];
+          else nvalid += 1.f;
+          *reinterpret_cast<VT*>(sg.y + off) = v;
         }
-        vals[i2][j] = ok ? v : (v4)(0.f);
-        if (ok) *reinterpret_cast<v4*>(sg.y + off) = v;
       }
-    }
     if (MODE == 0 && want_rows) {   // second pass over the registers: M2 about this thread's own per-channel mean
-      const v4 mu = s1 * (1.f / fmaxf(nvalid, 1.f));
+      const VT mu = s1 * (1.f / fmaxf(nvalid, 1.f));
       s1 = mu;
 #pragma unroll
       for (int i2 = 0; i2 < M; ++i2)
 #pragma unroll
         for (int j = 0; j < M; ++j) {
-          const bool ok = y0 + i2 < sg.h && x0 + j < sg.w;
-          const v4 d = vals[i2][j] - mu;
-          if (ok) s2 += d * d;
+          const VT d = vals[i2][j] - mu;
+          if (y0 + i2 < sg.h && x0 + j < sg.w) s2 += d * d;
         }
     }
   }
   if (!want_rows) return;
-  red[tid][0] = s1.x; red[tid][1] = s1.y; red[tid][2] = s1.z; red[tid][3] = s1.w;
-  red[tid][4] = s2.x; red[tid][5] = s2.y; red[tid][6] = s2.z; red[tid][7] = s2.w;
-  __shared__ float cnt[CK_TILES];
-  if ((tid & 15) == 0) cnt[tid >> 4] = nvalid;
+#pragma unroll
+  for (int i = 0; i < W; ++i) { red[tid][i] = lane_of<W>(s1, i); red[tid][W + i] = lane_of<W>(s2, i); }
+  if (p.q == 0) cnt[p.tl] = nvalid;
   __syncthreads();
+  const int ng = CH / f.cpg;
   if (MODE == 1) {
-    if (tid < CK_CH * 2) {   // per-channel sums over the chunk's 16 tiles, tile order
+    if (tid < CH * 2) {   // per-channel sums over the chunk's 16 tiles, tile order
       const int cl = tid >> 1, comp = tid & 1;
       float t = 0.f;
 #pragma unroll
-      for (int tl = 0; tl < CK_TILES; ++tl) t += red[tl * 16 + (cl >> 2)][comp * 4 + (cl & 3)];
+      for (int tl = 0; tl < CK_TILES; ++tl) t += red[tl * LANES + cl / W][comp * W + cl % W];
       chan[cl][comp] = t;
-      f.g_rows_chan[((size_t)comp * a.total_chunks + chunk) * a.c + slab * CK_CH + cl] = t;
+      f.g_rows_chan[((size_t)comp * a.total_chunks + chunk) * a.c + slab * CH + cl] = t;
     }
     __syncthreads();
-    const int ng = CK_CH / f.cpg;
     if (tid < ng * 2) {
       const int gl = tid >> 1, comp = tid & 1;
       float t = 0.f;
       for (int j = 0; j < f.cpg; ++j) {
         const int cl = gl * f.cpg + j;
-        t += f.gamma[slab * CK_CH + cl] * chan[cl][comp];
+        t += f.gamma[slab * CH + cl] * chan[cl][comp];
       }
       f.g_rows_group[((size_t)chunk * f.groups + slab * ng + gl) * 2 + comp] = t;
     }
     return;
   }
-  // MODE 0: (count, mean, M2) per channel over the chunk's tiles (tile order), then per group over its channels
-  __shared__ float cstat[CK_CH][3];
-  if (tid < CK_CH) {
+  // MODE 0: (count, mean, M2) per channel over the chunk's tiles (mean first, then M2 about it), then per group
+  if (tid < CH) {
     const int cl = tid;
-    float n = 0.f, mu = 0.f, m2 = 0.f;
+    float n = 0.f, sm = 0.f;
+#pragma unroll
+    for (int tl = 0; tl < CK_TILES; ++tl) { n += cnt[tl]; sm += cnt[tl] * red[tl * LANES + cl / W][cl % W]; }
+    const float mu = n > 0.f ? sm / n : 0.f;
+    float m2 = 0.f;
 #pragma unroll
     for (int tl = 0; tl < CK_TILES; ++tl) {
-      const float nr = cnt[tl];
-      if (nr > 0.f) {
-        const float mr = red[tl * 16 + (cl >> 2)][cl & 3], qr = red[tl * 16 + (cl >> 2)][4 + (cl & 3)];
-        const float d = mr - mu, nn = n + nr;
-        mu += d * nr / nn;
-        m2 += qr + d * d * n * nr / nn;
-        n = nn;
-      }
+      const float d = red[tl * LANES + cl / W][cl % W] - mu;
+      m2 += red[tl * LANES + cl / W][W + cl % W] + cnt[tl] * d * d;
     }
-    cstat[cl][0] = n; cstat[cl][1] = mu; cstat[cl][2] = m2;
+    chan[cl][0] = n; chan[cl][1] = mu; chan[cl][2] = m2;
   }
   __syncthreads();
-  const int ng = CK_CH / f.cpg;
   if (tid < ng) {
-    float n = 0.f, mu = 0.f, m2 = 0.f;
+    float n = 0.f, sm = 0.f;
+    for (int j = 0; j < f.cpg; ++j) { n += chan[tid * f.cpg + j][0]; sm += chan[tid * f.cpg + j][0] * chan[tid * f.cpg + j][1]; }
+    const float mu = n > 0.f ? sm / n : 0.f;
+    float m2 = 0.f;
     for (int j = 0; j < f.cpg; ++j) {
-      const int cl = tid * f.cpg + j;
-      const float nr = cstat[cl][0];
-      if (nr > 0.f) {
-        const float d = cstat[cl][1] - mu, nn = n + nr;
-        mu += d * nr / nn;
-        m2 += cstat[cl][2] + d * d * n * nr / nn;
-        n = nn;
-      }
+      const float d = chan[tid * f.cpg + j][1] - mu;
+      m2 += chan[tid * f.cpg + j][2] + chan[tid * f.cpg + j][0] * d * d;
     }
     *reinterpret_cast<float4*>(f.out_rows + ((size_t)chunk * f.groups + slab * ng + tid) * ROW_F) = make_float4(n, mu, m2, 0.f);
   }
 }
 
-// launches: blocks [0, nb_chunk) run a chunk body (chunk = b / slabs, slab = b % slabs), the rest the second body
-template <int M, typename L>
-__global__ __launch_bounds__(NT) void wino_gn_fwd_pre_kernel(const CArgs in, const Fold f, const WeightArgs wa, int nb_chunk, int slabs) {
+// launches: blocks [0, nb_chunk) run a chunk body (chunk = b / slabs, slab = b % slabs) with all T threads; the second
+// kind of block (kernel transform, G^T dU G) uses the first NT threads of as many blocks as it needs
+template <int W>
+constexpr int chunk_threads() { return CK_T; }
+
+template <int M, int W, template <int> class LT>
+__global__ __launch_bounds__(chunk_threads<W>()) void wino_gn_fwd_pre_kernel(const CArgs in, const Fold f, const WeightArgs wa,
+                                                                               int nb_chunk, int slabs) {
   const int b = blockIdx.x;
-  if (b < nb_chunk) chunk_input_body<M, L>(in, f, b / slabs, b % slabs);
+  if (b < nb_chunk) chunk_input_body<M, W, LT>(in, f, b / slabs, b % slabs);
   else wino_weight_body<M>(wa.w, wa.u, wa.u2, wa.kn, wa.rot, b - nb_chunk);
 }
-template <int M, typename L>
-__global__ __launch_bounds__(NT) void wino_gn_input_kernel(const CArgs in, const Fold f, int slabs) {
-  chunk_input_body<M, L>(in, f, blockIdx.x / slabs, blockIdx.x % slabs);
+template <int M, int W, template <int> class LT>
+__global__ __launch_bounds__(chunk_threads<W>()) void wino_gn_input_kernel(const CArgs in, const Fold f, int slabs) {
+  chunk_input_body<M, W, LT>(in, f, blockIdx.x / slabs, blockIdx.x % slabs);
 }
-template <int M>
-__global__ __launch_bounds__(NT) void wino_gn_output_kernel(const CArgs out, const Fold f, int slabs) {
-  chunk_output_body<M, 0>(out, f, blockIdx.x / slabs, blockIdx.x % slabs);
+template <int M, int W>
+__global__ __launch_bounds__(chunk_threads<W>()) void wino_gn_output_kernel(const CArgs out, const Fold f, int slabs) {
+  chunk_output_body<M, W, 0>(out, f, blockIdx.x / slabs, blockIdx.x % slabs);
 }
-template <int M, typename L>
-__global__ __launch_bounds__(NT) void wino_gn_bwd_pre_kernel(const CArgs dgrad_in, const CArgs wgrad_dy, const Fold f, int nb_first,
-                                                             int slabs) {
+template <int M, int W, template <int> class LT>
+__global__ __launch_bounds__(chunk_threads<W>()) void wino_gn_bwd_pre_kernel(const CArgs dgrad_in, const CArgs wgrad_dy, const Fold f,
+                                                                               int nb_first, int slabs) {
   const int b = blockIdx.x;
-  if (b < nb_first) chunk_input_body<M, L>(dgrad_in, f, b / slabs, b % slabs);
-  else chunk_dy_body<M, L>(wgrad_dy, f, (b - nb_first) / slabs, (b - nb_first) % slabs);
+  if (b < nb_first) chunk_input_body<M, W, LT>(dgrad_in, f, b / slabs, b % slabs);
+  else chunk_dy_body<M, W, LT>(wgrad_dy, f, (b - nb_first) / slabs, (b - nb_first) % slabs);
 }
-template <int M, int MODE>
-__global__ __launch_bounds__(NT) void wino_gn_bwd_post_kernel(const CArgs out, const Fold f, const DwArgs2 d, int nb_out, int slabs) {
+template <int M, int W, int MODE>
+__global__ __launch_bounds__(chunk_threads<W>()) void wino_gn_bwd_post_kernel(const CArgs out, const Fold f, const DwArgs2 d, int nb_out,
+                                                                                int slabs) {
   const int b = blockIdx.x;
-  if (b < nb_out) chunk_output_body<M, MODE>(out, f, b / slabs, b % slabs);
+  if (b < nb_out) chunk_output_body<M, W, MODE>(out, f, b / slabs, b % slabs);
   else wino_dw_body<M>(d.du, d.dw, d.kn, d.nsplit, d.accumulate, b - nb_out);
 }
 
-// x_of / y_of: which tensors of the segment feed this stage
 int cfill(const rn_conv_seg* segs, int nseg, int c, int m, CArgs* a, const float* const* xs, const float* const* auxs, float* const* ys) {
   int64_t tiles = 0, chunks = 0;
   for (int s = 0; s < nseg; ++s) {
@@ -1108,7 +1187,21 @@ int cfill(const rn_conv_seg* segs, int nseg, int c, int m, CArgs* a, const float
   return RN_OK;
 }
 
-bool fold_ok(int c, int groups) { return c % CK_CH == 0 && groups >= 1 && c % groups == 0 && CK_CH % (c / groups) == 0; }
+// a block covers 16 W channels, W in {1, 2, 4}: they must be whole groups on a folded side
+bool width_ok(int c, int cpg, int w) { return c % (CK_LANES * w) == 0 && (cpg == 0 || (CK_LANES * w) % cpg == 0); }
+bool fold_ok(int c, int groups) { return groups >= 1 && c % groups == 0 && width_ok(c, c / groups, 4); }
+// channels per thread of the chunked kernels: 4 once that still fills the chip (>= 4 waves per SIMD on 256 CUs), else 2
+// -- the pyramids of a 512^2 batch are latency-, not bandwidth-bound, and narrower lanes put more blocks in flight
+// (measured on one head subnet, forward + backward: W = 1 / 2 / 4 -> 1215 / 1144 / 1176 us; layer by layer with
+// stand-alone GroupNorm kernels: 1185 us)
+int chunk_width(int64_t tiles, int c, int cpg) {
+  if (const char* force = getenv("RN_WINO_GN_W")) {  // tuning aid
+    const int w = atoi(force);
+    if ((w == 1 || w == 2 || w == 4) && width_ok(c, cpg, w)) return w;
+  }
+  if (tiles * (c / 4) >= 256 * 1024 || !width_ok(c, cpg, 2)) return 4;
+  return 2;
+}
 }  // namespace
 
 extern "C" size_t rn_wino_gn_rows(const rn_conv_seg* segs, int nseg, int tile) {
@@ -1122,6 +1215,13 @@ extern "C" size_t rn_wino_gn_rows(const rn_conv_seg* segs, int nseg, int tile) {
 }
 
 namespace {
+#define RN_WGN(W_, CALL)                          \
+  do {                                            \
+    if (W_ == 4) { constexpr int W = 4; CALL; }   \
+    else if (W_ == 2) { constexpr int W = 2; CALL; } \
+    else { constexpr int W = 1; CALL; }           \
+  } while (0)
+
 template <int M>
 int run_gn_fwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, const float* bias, const rn_wino_gn* gn, float* U,
                float* V, float* Mb, float* v_buf, float* urot_buf, hipStream_t st) {
@@ -1141,25 +1241,27 @@ int run_gn_fwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float
     fi.rows = gn->in_rows; fi.gamma = gn->in_gamma; fi.beta = gn->in_beta; fi.groups = gn->in_groups; fi.cpg = cin / gn->in_groups;
     fi.act = gn->in_act; fi.eps = gn->in_eps;
   }
-  const int slabs_in = cin / CK_CH, nb_chunk = ia.total_chunks * slabs_in, nb_w = (int)rn::ceil_div64(kn, NT);
-  if (fold_in) hipLaunchKernelGGL((wino_gn_fwd_pre_kernel<M, LoadGnAct>), dim3(nb_chunk + nb_w), dim3(NT), 0, st, ia, fi, wa, nb_chunk, slabs_in);
-  else hipLaunchKernelGGL((wino_gn_fwd_pre_kernel<M, LoadPlain>), dim3(nb_chunk + nb_w), dim3(NT), 0, st, ia, fi, wa, nb_chunk, slabs_in);
+  const int wi = chunk_width(ia.total_tiles, cin, fold_in ? fi.cpg : 0);
+  const int slabs_in = cin / (CK_LANES * wi), nb_chunk = ia.total_chunks * slabs_in, nb_w = (int)rn::ceil_div64(kn, NT);
+  if (fold_in) RN_WGN(wi, hipLaunchKernelGGL((wino_gn_fwd_pre_kernel<M, W, LoadGnAct>), dim3(nb_chunk + nb_w), dim3(chunk_threads<W>()), 0, st, ia, fi, wa, nb_chunk, slabs_in));
+  else RN_WGN(wi, hipLaunchKernelGGL((wino_gn_fwd_pre_kernel<M, W, LoadPlain>), dim3(nb_chunk + nb_w), dim3(chunk_threads<W>()), 0, st, ia, fi, wa, nb_chunk, slabs_in));
   RN_LAUNCH_CHECK();
   if (int e = rn::launch_batched_gemm(V, U, Mb, ia.total_tiles, cin, cout, P2, 0, st)) return e;
   if (!gn->out_rows) {  // no statistics wanted: the grid-stride output transform (any cout % 4 == 0, e.g. the 720 class maps)
-    WArgs wi = {}, wo = {};
-    if (int e = fill(segs, nseg, cin, cout, M, false, &wi, &wo)) return e;
-    wo.buf = Mb; wo.bias = bias;
-    const int wd = width_for(wo.total_tiles, cout);
-    RN_WINO_LAUNCH(wino_output_kernel, wd, (int64_t)wo.total_tiles * cout, wo);
+    WArgs wia = {}, woa = {};
+    if (int e = fill(segs, nseg, cin, cout, M, false, &wia, &woa)) return e;
+    woa.buf = Mb; woa.bias = bias;
+    const int wd = width_for(woa.total_tiles, cout);
+    RN_WINO_LAUNCH(wino_output_kernel, wd, (int64_t)woa.total_tiles * cout, woa);
     RN_LAUNCH_CHECK();
     return RN_OK;
   }
   oa.buf = Mb; oa.bias = bias;
   Fold fo = {};
   fo.out_rows = gn->out_rows; fo.groups = gn->out_groups; fo.cpg = cout / gn->out_groups;
-  const int slabs_out = cout / CK_CH;
-  hipLaunchKernelGGL((wino_gn_output_kernel<M>), dim3(oa.total_chunks * slabs_out), dim3(NT), 0, st, oa, fo, slabs_out);
+  const int wo = chunk_width(oa.total_tiles, cout, fo.cpg);
+  const int slabs_out = cout / (CK_LANES * wo);
+  RN_WGN(wo, hipLaunchKernelGGL((wino_gn_output_kernel<M, W>), dim3(oa.total_chunks * slabs_out), dim3(chunk_threads<W>()), 0, st, oa, fo, slabs_out));
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
@@ -1192,25 +1294,25 @@ int run_gn_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float
     fi.rows = gn->in_rows; fi.gamma = gn->in_gamma; fi.beta = gn->in_beta; fi.groups = gn->in_groups; fi.cpg = cin / gn->in_groups;
     fi.act = gn->in_act; fi.eps = gn->in_eps; fi.g_rows_group = gn->in_g_rows_group; fi.g_rows_chan = gn->in_g_rows_chan;
   }
+  const int wi = chunk_width(T_, cin, fold_in ? fi.cpg : 0);
   if (!V) {  // the forward pass did not keep its transformed input: rebuild it (through the folded GroupNorm if there is one)
     CArgs xa = {};
     cfill(segs, nseg, cin, M, &xa, xins, nullptr, nullptr);
     xa.buf = (float*)(ws + L.v);
-    const int slabs = cin / CK_CH;
-    if (fold_in) hipLaunchKernelGGL((wino_gn_input_kernel<M, LoadGnAct>), dim3(xa.total_chunks * slabs), dim3(NT), 0, st, xa, fi, slabs);
-    else hipLaunchKernelGGL((wino_gn_input_kernel<M, LoadPlain>), dim3(xa.total_chunks * slabs), dim3(NT), 0, st, xa, fi, slabs);
+    const int slabs = cin / (CK_LANES * wi);
+    if (fold_in) RN_WGN(wi, hipLaunchKernelGGL((wino_gn_input_kernel<M, W, LoadGnAct>), dim3(xa.total_chunks * slabs), dim3(chunk_threads<W>()), 0, st, xa, fi, slabs));
+    else RN_WGN(wi, hipLaunchKernelGGL((wino_gn_input_kernel<M, W, LoadPlain>), dim3(xa.total_chunks * slabs), dim3(chunk_threads<W>()), 0, st, xa, fi, slabs));
     V = xa.buf;
   }
   ia.buf = Vdy;
   ya.buf = dM;
-  Fold fo = {};
   if (fold_out) {
+    Fold fo = {};
     fo.rows = gn->out_rows; fo.grows = gn->out_g_rows_group; fo.gamma = gn->out_gamma; fo.groups = gn->out_groups;
     fo.cpg = cout / gn->out_groups; fo.eps = gn->out_eps;
-  }
-  if (fold_out) {
-    const int slabs = cout / CK_CH, nb = ia.total_chunks * slabs;
-    hipLaunchKernelGGL((wino_gn_bwd_pre_kernel<M, LoadGnBwd>), dim3(2 * nb), dim3(NT), 0, st, ia, ya, fo, nb, slabs);
+    const int wy = chunk_width(T_, cout, fo.cpg);
+    const int slabs = cout / (CK_LANES * wy), nb = ia.total_chunks * slabs;
+    RN_WGN(wy, hipLaunchKernelGGL((wino_gn_bwd_pre_kernel<M, W, LoadGnBwd>), dim3(2 * nb), dim3(chunk_threads<W>()), 0, st, ia, ya, fo, nb, slabs));
   } else {  // plain dy (any cout % 4 == 0): the grid-stride transforms
     WArgs wia = {}, woa = {}, wya = {}, unused = {};
     if (int e = fill(segs, nseg, cin, cout, M, true, &wia, &woa, true)) return e;
@@ -1230,18 +1332,19 @@ int run_gn_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float
   oa.buf = Mdx; oa.bias = nullptr;
   {
     const DwArgs2 d = {(const float*)(ws + L.slab), dw, kn, nsplit, accumulate};
-    const int slabs = cin / CK_CH, nb_out = oa.total_chunks * slabs, nb_dw = (int)rn::ceil_div64(kn, NT);
-    if (!fold_in) { fi.groups = 1; fi.cpg = CK_CH; }
-    if (fold_in) hipLaunchKernelGGL((wino_gn_bwd_post_kernel<M, 1>), dim3(nb_out + nb_dw), dim3(NT), 0, st, oa, fi, d, nb_out, slabs);
-    else hipLaunchKernelGGL((wino_gn_bwd_post_kernel<M, 0>), dim3(nb_out + nb_dw), dim3(NT), 0, st, oa, fi, d, nb_out, slabs);
+    const int slabs = cin / (CK_LANES * wi), nb_out = oa.total_chunks * slabs, nb_dw = (int)rn::ceil_div64(kn, NT);
+    if (!fold_in) { fi.groups = 1; fi.cpg = CK_LANES * wi; }
+    if (fold_in) RN_WGN(wi, hipLaunchKernelGGL((wino_gn_bwd_post_kernel<M, W, 1>), dim3(nb_out + nb_dw), dim3(chunk_threads<W>()), 0, st, oa, fi, d, nb_out, slabs));
+    else RN_WGN(wi, hipLaunchKernelGGL((wino_gn_bwd_post_kernel<M, W, 0>), dim3(nb_out + nb_dw), dim3(chunk_threads<W>()), 0, st, oa, fi, d, nb_out, slabs));
   }
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
+#undef RN_WGN
 
 int check_fold(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile) {
   RN_CHECK_ARG(segs && nseg >= 1 && nseg <= RN_MAX_SEG && (tile == 2 || tile == 4), "winograd gn: bad segments / tile");
-  RN_UNSUPPORTED(cin % CK_CH != 0 || cout % 4 != 0, "winograd gn: cin %d must be a multiple of %d, cout %d of 4", cin, CK_CH, cout);
+  RN_UNSUPPORTED(cin % CK_MAXCH != 0 || cout % 4 != 0, "winograd gn: cin %d must be a multiple of %d, cout %d of 4", cin, CK_MAXCH, cout);
   for (int s = 0; s < nseg; ++s) {
     RN_CHECK_ARG(segs[s].n >= 1 && segs[s].h >= 1 && segs[s].w >= 1, "winograd gn: bad segment %d", s);
     RN_UNSUPPORTED((double)segs[s].n * segs[s].h * segs[s].w * (cin > cout ? cin : cout) * 4.0 >= 2147483648.0,
