@@ -43,6 +43,9 @@ enum rn_opt { RN_OPT_MOMENTUM = 0, RN_OPT_RMSPROP = 1, RN_OPT_ADAM = 2 };
 
 #define RN_MAX_SEG 16
 
+/* caller-owned list that collects deferred row reductions (see "deferred gradient reductions" below) */
+typedef struct rn_reduce_list rn_reduce_list;
+
 int rn_version(void);
 const char* rn_last_error(void);
 
@@ -92,31 +95,44 @@ int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, vo
  * If accumulate != 0 the result is added to dw instead of overwriting it. */
 size_t rn_conv2d_wgrad_workspace(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g);
 int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, int accumulate,
-                    void* workspace, size_t workspace_bytes, rn_stream_t stream);
+                    void* workspace, size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer);
 
 /* Both gradients of one convolution (segments: x, wgt, dy, dx as for the two calls above; dw overwritten).  Small
  * problems -- the backbone's 1x1 convs -- run as ONE launch whose blocks are of two kinds (data-gradient tiles and
  * weight-gradient splits); anything else falls back to rn_conv2d_dgrad (without split-K) + rn_conv2d_wgrad.
  * workspace: rn_conv2d_wgrad_workspace bytes. */
 int rn_conv2d_bwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, void* workspace,
-                  size_t workspace_bytes, rn_stream_t stream);
+                  size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer);
 
 /* dbias[cout] = sum over all segments / pixels of dy (the out_conv biases, retinanet.py:46-53). */
 size_t rn_conv2d_bias_grad_workspace(int cout);
 int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dbias, void* workspace,
-                        size_t workspace_bytes, rn_stream_t stream);
+                        size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer);
 
 /* ------------------------------------------------------------------ deferred gradient reductions
- * Every weight-gradient entry point (rn_conv2d_wgrad, rn_depthwise_wgrad, rn_conv2d_bias_grad, the GroupNorm
- * parameter gradients of rn_group_norm_bwd) ends with a fixed-order row reduction of per-block partial results.
- * A training step has ~130 of them, each a launch-latency-bound kernel.  After rn_defer_reductions(stream, 1) they
- * are recorded instead of launched and rn_flush_reductions(stream) runs them all as one launch (per 140).  While
- * deferring, the `workspace` handed to those entry points must stay untouched until the flush (give each call its
- * own buffer), and the gradients are only valid after the flush.  Results are bitwise identical to immediate mode,
- * except the GroupNorm dgamma / dbeta of maps too large for the single-kernel path, whose chunk rows are then summed
- * in fp32 (fixed order) instead of fp64. */
-int rn_defer_reductions(rn_stream_t stream, int on);
-int rn_flush_reductions(rn_stream_t stream);
+ * Every weight-gradient entry point (rn_conv2d_wgrad, rn_conv2d_bwd, rn_depthwise_wgrad, rn_depthwise_bwd,
+ * rn_conv2d_bias_grad, the GroupNorm parameter gradients of rn_group_norm_bwd, rn_reduce_rows) ends with a
+ * fixed-order row reduction of per-block partial results.  A training step has ~130 of them, each a
+ * launch-latency-bound kernel.  Each of those entry points therefore takes a trailing `rn_reduce_list* defer`:
+ * NULL = reduce now; otherwise the reduction is only RECORDED in the caller's list (host memory the caller owns:
+ * the library keeps nothing between calls) and rn_flush_reductions(list, stream) runs everything recorded as one
+ * launch (per 140) and empties the list.  While deferring, the `workspace` handed to those entry points must stay
+ * untouched until the flush (give each call its own buffer), and the gradients are only valid after the flush.
+ * Results are bitwise identical to immediate mode, except the GroupNorm dgamma / dbeta of maps too large for the
+ * single-kernel path, whose chunk rows are then summed in fp32 (fixed order) instead of fp64.
+ * A full list is an error (RN_EWORKSPACE), never a silent immediate launch. */
+typedef struct rn_reduce_desc {
+  const float* in;   /* [nrows][count] partial rows */
+  float* out;        /* [count] */
+  int32_t count;
+  uint16_t nrows, accumulate;
+} rn_reduce_desc;
+struct rn_reduce_list {
+  rn_reduce_desc* desc; /* caller-owned array of `capacity` entries */
+  int32_t capacity;
+  int32_t count;        /* entries recorded so far */
+};
+int rn_flush_reductions(rn_reduce_list* list, rn_stream_t stream);
 
 /* ------------------------------------------------------------------ Winograd F(m x m, 3x3) convolution
  * The 3x3 / stride-1 / SAME dense convolutions of the head towers and FPN merges (retinanet.py:39-46,87-94,
@@ -180,9 +196,9 @@ int rn_depthwise_dgrad(const float* dy, const float* wgt, float* dx, int n, int 
 size_t rn_depthwise_wgrad_workspace(int n, int h, int w, int c, int k, int stride);
 /* both gradients of a 3x3 depthwise conv in one launch (workspace: rn_depthwise_wgrad_workspace bytes) */
 int rn_depthwise_bwd(const float* x, const float* dy, const float* wgt, float* dx, float* dw, int n, int h, int w, int c, int k,
-                     int stride, void* workspace, size_t workspace_bytes, rn_stream_t stream);
+                     int stride, void* workspace, size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer);
 int rn_depthwise_wgrad(const float* x, const float* dy, float* dw, int n, int h, int w, int c, int k, int stride,
-                       void* workspace, size_t workspace_bytes, rn_stream_t stream);
+                       void* workspace, size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer);
 
 /* ------------------------------------------------------------------ GroupNorm (+act, +dropout, +residual)
  * Replaces normalization.py:20-35 (reshape + tf.nn.moments + affine), the activation that
@@ -227,7 +243,7 @@ int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, co
 /* dgamma/dbeta [c] are OVERWRITTEN with the sum over all segments. */
 int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, const float* gamma,
                       const float* beta, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                      rn_stream_t stream);
+                      rn_stream_t stream, rn_reduce_list* defer);
 
 /* ------------------------------------------------------------------ small elementwise ops
  * activation alone (retinanet.py:180-181 `activation` before the P7 conv) */
@@ -300,8 +316,9 @@ typedef struct rn_loss_seg {
  * [8+3c]=I_c=sum l*sigmoid, [9+3c]=L_c=sum l, [10+3c]=P_c=sum sigmoid. */
 #define RN_LOSS_STATS_HEADER 8
 size_t rn_loss_workspace(const rn_loss_seg* segs, int nseg, int num_classes);
-int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, float* stats, void* workspace,
-                size_t workspace_bytes, rn_stream_t stream);
+/* class_loss_out / regr_loss_out (optional, one float each): the two losses also as stand-alone device scalars */
+int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, float* stats, float* class_loss_out,
+                float* regr_loss_out, void* workspace, size_t workspace_bytes, rn_stream_t stream);
 /* d(g_cls*class_loss + g_reg*regr_loss)/d(logits); g_* are device scalars (upstream grads). */
 int rn_loss_bwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, const float* stats,
                 const float* g_cls, const float* g_reg, rn_stream_t stream);
@@ -356,7 +373,7 @@ int rn_conv3x3_winograd_gn_bwd(const rn_conv_seg* segs, int nseg, int cin, int c
                                const float* urot_buf, rn_stream_t stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_r in[r * count + i], r < nrows, fixed order (bit-reproducible); joins the
  * deferred batch while rn_defer_reductions is on for the stream.  Finishes dgamma / dbeta from in_g_rows_chan. */
-int rn_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, rn_stream_t stream);
+int rn_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, rn_stream_t stream, rn_reduce_list* defer);
 
 /* ------------------------------------------------------------------ IoU
  * Replaces utils.iou (utils.py:62-97; known answers utils_test.py:99-118): boxes are corners [y1, x1, y2, x2].
@@ -455,10 +472,21 @@ size_t rn_optimizer_workspace(int64_t count);
 int rn_grad_norm_l2reg(const float* w, const float* grad, const float* wd_per_block, int64_t count,
                        float grad_scale, float* out2, void* workspace, size_t workspace_bytes, rn_stream_t stream);
 /* clip_norm <= 0 disables clipping; norm_sq is the device scalar from rn_grad_norm_l2reg.
- * step is 1-based (Adam bias correction). state1/state2: momentum-acc | rms,mom | m,v. */
+ * step is 1-based (Adam bias correction). state1/state2: momentum-acc | rms,mom | m,v.
+ * advance_counter (optional): a device word incremented by advance_by in the same launch -- the per-step counter the
+ * fused dropouts hash (rn_gn_params.drop_seed_dev), so that the next step (or hipGraph replay) draws fresh masks
+ * (tf.layers.Dropout draws new noise every session.run, mobilenet_v2.py:62). */
 int rn_optimizer_step(int kind, float* w, const float* grad, float* state1, float* state2,
                       const float* wd_per_block, int64_t count, float lr, float grad_scale, float clip_norm,
-                      const float* norm_sq, int64_t step, rn_stream_t stream);
+                      const float* norm_sq, int64_t step, uint64_t* advance_counter, uint64_t advance_by, rn_stream_t stream);
+/* *counter += inc on the stream (the same counter, for callers that run backward passes without an optimizer step) */
+int rn_counter_add(uint64_t* counter, uint64_t inc, rn_stream_t stream);
+
+/* out = a + b for up to RN_MAX_SEG tensors in one launch (count floats each, 16-byte aligned): the sum autograd forms when
+ * a tensor feeds two branches -- a bottleneck's input (expand conv + identity, mobilenet_v2.py:91-92), a pyramid level
+ * (class + box subnet, retinanet.py:283-291), C5 (P5 + P6, retinanet.py:214-216). */
+typedef struct rn_add_seg { const float* a; const float* b; float* out; int64_t count; } rn_add_seg;
+int rn_add_segs(const rn_add_seg* segs, int nseg, rn_stream_t stream);
 
 #ifdef __cplusplus
 }

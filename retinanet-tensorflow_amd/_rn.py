@@ -54,6 +54,26 @@ class WinoGnBwd(C.Structure):
                 ("out_groups", C.c_int32), ("out_eps", C.c_float)]
 
 
+class ReduceDesc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("count", C.c_int32), ("nrows", C.c_uint16), ("accumulate", C.c_uint16)]
+
+
+class ReduceList(C.Structure):
+    """rn_reduce_list: deferred row reductions recorded by the gradient entry points, owned by the caller (host memory)."""
+    _fields_ = [("desc", C.POINTER(ReduceDesc)), ("capacity", C.c_int32), ("count", C.c_int32)]
+
+    @classmethod
+    def make(cls, capacity=1024):
+        arr = (ReduceDesc * capacity)()
+        lst = cls(C.cast(arr, C.POINTER(ReduceDesc)), capacity, 0)
+        lst._keep = arr
+        return lst
+
+
+class AddSeg(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("count", C.c_int64)]
+
+
 class GnSeg(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("residual", C.c_void_p), ("dy", C.c_void_p),
                 ("dx", C.c_void_p), ("dresidual", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
@@ -92,7 +112,7 @@ SYMBOLS = [
     "rn_conv2d_fwd", "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad", "rn_conv2d_bwd",
     "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes",
-    "rn_conv3x3_winograd_bwd_workspace", "rn_conv3x3_winograd_bwd", "rn_defer_reductions", "rn_flush_reductions", "rn_gemm_batched",
+    "rn_conv3x3_winograd_bwd_workspace", "rn_conv3x3_winograd_bwd", "rn_flush_reductions", "rn_gemm_batched",
     "rn_wino_gn_rows", "rn_conv3x3_winograd_gn", "rn_conv3x3_winograd_gn_bwd", "rn_reduce_rows", "rn_resize_bilinear_normalize",
     "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad", "rn_depthwise_bwd",
     "rn_group_norm_sync_bytes", "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
@@ -102,7 +122,7 @@ SYMBOLS = [
     "rn_loss_workspace", "rn_loss_fwd", "rn_loss_bwd",
     "rn_iou", "rn_anchor_assign", "rn_anchor_assign_levels", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
     "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
-    "rn_optimizer_workspace", "rn_grad_norm_l2reg", "rn_optimizer_step",
+    "rn_optimizer_workspace", "rn_grad_norm_l2reg", "rn_optimizer_step", "rn_counter_add", "rn_add_segs",
 ]
 
 
@@ -125,24 +145,23 @@ def lib():
         L.rn_optimizer_workspace.argtypes = [C.c_int64]
         L.rn_depthwise_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_depthwise_dgrad.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
-        L.rn_depthwise_bwd.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rn_depthwise_bwd.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_depthwise_wgrad_workspace.argtypes = [C.c_int] * 6
-        L.rn_depthwise_wgrad.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rn_depthwise_wgrad.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_conv2d_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_conv2d_dgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_conv2d_fwd_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_conv2d_dgrad_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        L.rn_conv2d_bwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rn_conv2d_bwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_conv2d_wgrad_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_conv2d_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
-                                      C.c_size_t, C.c_void_p]
+                                      C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_conv2d_bias_grad_workspace.argtypes = [C.c_int]
         L.rn_conv3x3_winograd_workspace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.rn_resize_bilinear_normalize.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p,
                                                                                                          C.c_void_p]
         L.rn_gemm_batched.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]
-        L.rn_defer_reductions.argtypes = [C.c_void_p, C.c_int]
-        L.rn_flush_reductions.argtypes = [C.c_void_p]
+        L.rn_flush_reductions.argtypes = [C.c_void_p, C.c_void_p]
         L.rn_conv3x3_winograd_wgrad_workspace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.rn_conv3x3_winograd_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -157,14 +176,14 @@ def lib():
                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rn_conv3x3_winograd_gn_bwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.rn_reduce_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        L.rn_reduce_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.rn_conv2d_bias_grad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
-                                          C.c_void_p]
+                                          C.c_void_p, C.c_void_p]
         L.rn_group_norm_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_group_norm_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_size_t, C.c_void_p]
         L.rn_group_norm_bwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_act_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.rn_act_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.rn_upsample_add_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
@@ -184,7 +203,7 @@ def lib():
         L.rn_avgpool_fwd.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_avgpool_bwd.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_loss_workspace.argtypes = [C.c_void_p, C.c_int, C.c_int]
-        L.rn_loss_fwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+        L.rn_loss_fwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                   C.c_void_p]
         L.rn_loss_bwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]
@@ -205,7 +224,9 @@ def lib():
                                                              C.c_size_t, C.c_void_p]
         L.rn_optimizer_step.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int64, C.c_float, C.c_float,
                                                                        C.c_float, C.c_void_p, C.c_int64,
-                                                                       C.c_void_p]
+                                                                       C.c_void_p, C.c_uint64, C.c_void_p]
+        L.rn_counter_add.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.rn_add_segs.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_same_pad.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.rn_same_pad.restype = None
         _lib = L

@@ -17,10 +17,6 @@
 // panel) run on the same XCD and hit its L2.
 #include <stdlib.h>
 
-#include <map>
-#include <mutex>
-#include <vector>
-
 #include "rn_common.h"
 
 namespace {
@@ -721,7 +717,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
   reduce_rows_block(in, out, count, nrows, accumulate, blockIdx.x);
 }
 
-// Deferred mode (rn_defer_reductions): every row reduction recorded during a backward pass -- the split-K slabs of
+// Deferred mode (a `defer` list handed to the entry points): every row reduction recorded during a backward pass -- the split-K slabs of
 // ~70 weight gradients, the GroupNorm parameter-gradient rows -- runs as ONE launch instead of one
 // launch-latency-bound kernel each.
 constexpr int RN_MAX_REDUCE = 140;  // 24-byte descriptors + block starts: the whole step's ~135 reductions in one 4 KB kernarg
@@ -823,23 +819,28 @@ int validate_geom(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
 }  // namespace
 
 namespace {
-std::mutex g_defer_mu;
-std::map<hipStream_t, std::vector<ReduceDesc>> g_deferred;  // present key = deferring on that stream
+// the list the current entry point was handed (rn::DeferScope): valid only for the duration of that call, per thread --
+// nothing about a deferral outlives the call that records it
+thread_local rn_reduce_list* tl_defer = nullptr;
 }  // namespace
 
-bool rn::reduce_deferred(hipStream_t st) {
-  std::lock_guard<std::mutex> lk(g_defer_mu);
-  return g_deferred.count(st) != 0;
-}
+rn::DeferScope::DeferScope(rn_reduce_list* list) : prev_(tl_defer) { tl_defer = list; }
+rn::DeferScope::~DeferScope() { tl_defer = (rn_reduce_list*)prev_; }
+
+bool rn::reduce_deferred(hipStream_t) { return tl_defer != nullptr; }
 
 int rn::launch_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, hipStream_t st) {
-  {
-    std::lock_guard<std::mutex> lk(g_defer_mu);
-    auto it = g_deferred.find(st);
-    if (it != g_deferred.end() && count < (int64_t)1 << 31 && nrows < 65536) {
-      it->second.push_back(ReduceDesc{in, out, (int)count, (unsigned short)nrows, (unsigned short)(accumulate ? 1 : 0)});
-      return RN_OK;
+  if (tl_defer) {
+    rn_reduce_list* l = tl_defer;
+    RN_CHECK_ARG(l->desc && l->capacity > 0 && l->count >= 0, "deferred reduction: bad list");
+    RN_UNSUPPORTED(count >= ((int64_t)1 << 31) || nrows >= 65536, "deferred reduction: %lld x %d too large for a descriptor",
+                   (long long)count, nrows);
+    if (l->count >= l->capacity) {
+      rn::set_error("deferred reduction: list full (%d entries)", l->capacity);
+      return RN_EWORKSPACE;
     }
+    l->desc[l->count++] = rn_reduce_desc{in, out, (int32_t)count, (uint16_t)nrows, (uint16_t)(accumulate ? 1 : 0)};
+    return RN_OK;
   }
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)rn::ceil_div64(count, reduce_cols_per_block(nrows))), dim3(256), 0, st, in, out, count, nrows,
                      accumulate);
@@ -847,36 +848,16 @@ int rn::launch_reduce_rows(const float* in, float* out, int64_t count, int nrows
   return RN_OK;
 }
 
-// on != 0: row reductions issued on `stream` from now on are recorded, not launched; their inputs (the callers'
-// workspaces) must stay untouched until rn_flush_reductions.  on == 0: flush, then back to immediate mode.
-extern "C" int rn_defer_reductions(rn_stream_t stream, int on) {
+extern "C" int rn_flush_reductions(rn_reduce_list* list, rn_stream_t stream) {
+  RN_CHECK_ARG(list && (list->count == 0 || list->desc) && list->count >= 0 && list->count <= list->capacity, "flush_reductions: bad list");
   hipStream_t st = (hipStream_t)stream;
-  if (on) {
-    std::lock_guard<std::mutex> lk(g_defer_mu);
-    g_deferred[st];
-    return RN_OK;
-  }
-  if (int e = rn_flush_reductions(stream)) return e;
-  std::lock_guard<std::mutex> lk(g_defer_mu);
-  g_deferred.erase(st);
-  return RN_OK;
-}
-
-extern "C" int rn_flush_reductions(rn_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
-  std::vector<ReduceDesc> todo;
-  {
-    std::lock_guard<std::mutex> lk(g_defer_mu);
-    auto it = g_deferred.find(st);
-    if (it == g_deferred.end()) return RN_OK;
-    todo.swap(it->second);
-  }
-  for (size_t first = 0; first < todo.size(); first += RN_MAX_REDUCE) {
+  for (int first = 0; first < list->count; first += RN_MAX_REDUCE) {
     ReduceManyArgs a = {};
-    a.n = (int)(todo.size() - first < (size_t)RN_MAX_REDUCE ? todo.size() - first : (size_t)RN_MAX_REDUCE);
+    a.n = list->count - first < RN_MAX_REDUCE ? list->count - first : RN_MAX_REDUCE;
     int blocks = 0;
     for (int i = 0; i < a.n; ++i) {
-      a.d[i] = todo[first + i];
+      const rn_reduce_desc& d = list->desc[first + i];
+      a.d[i] = ReduceDesc{d.in, d.out, d.count, d.nrows, d.accumulate};
       a.block_start[i] = blocks;
       blocks += (int)rn::ceil_div64(a.d[i].count, reduce_cols_per_block(a.d[i].nrows));
     }
@@ -884,10 +865,12 @@ extern "C" int rn_flush_reductions(rn_stream_t stream) {
     if (blocks > 0) hipLaunchKernelGGL(reduce_rows_many_kernel, dim3(blocks), dim3(256), 0, st, a);
   }
   RN_LAUNCH_CHECK();
+  list->count = 0;
   return RN_OK;
 }
 
-extern "C" int rn_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, rn_stream_t stream) {
+extern "C" int rn_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, rn_stream_t stream, rn_reduce_list* defer) {
+  rn::DeferScope defer_scope_(defer);
   RN_CHECK_ARG(in && out && count >= 1 && nrows >= 1, "reduce_rows: bad argument");
   return rn::launch_reduce_rows(in, out, count, nrows, accumulate, (hipStream_t)stream);
 }
@@ -1224,7 +1207,8 @@ int conv_wgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, fl
                     Planned* plan = nullptr);
 }
 extern "C" int rn_conv2d_wgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, int accumulate,
-                               void* workspace, size_t workspace_bytes, rn_stream_t stream) {
+                               void* workspace, size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer) {
+  rn::DeferScope defer_scope_(defer);
   return conv_wgrad_impl(segs, nseg, g, dw, accumulate, workspace, workspace_bytes, Batch{1, 0, 0, 0}, stream);
 }
 
@@ -1322,7 +1306,8 @@ ConvArgs4 compact(const ConvArgs& a) {
 // decomposition) run as ONE launch of conv_bwd_kernel; everything else as rn_conv2d_dgrad followed by rn_conv2d_wgrad.
 // workspace: rn_conv2d_wgrad_workspace bytes.
 extern "C" int rn_conv2d_bwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dw, void* workspace,
-                             size_t workspace_bytes, rn_stream_t stream) {
+                             size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer) {
+  rn::DeferScope defer_scope_(defer);
   static const bool enabled = getenv("RN_NO_MERGED_BWD") == nullptr;
   Planned pd, pw;
   bool merge = enabled && nseg <= 4;
@@ -1438,7 +1423,8 @@ __global__ __launch_bounds__(256) void bias_partial_kernel(const BiasArgs a) {
 extern "C" size_t rn_conv2d_bias_grad_workspace(int cout) { return (size_t)BG_BLOCKS * (size_t)(cout > 0 ? cout : 0) * sizeof(float); }
 
 extern "C" int rn_conv2d_bias_grad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float* dbias, void* workspace,
-                                   size_t workspace_bytes, rn_stream_t stream) {
+                                   size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer) {
+  rn::DeferScope defer_scope_(defer);
   if (int e = validate_geom(segs, nseg, g)) return e;
   RN_CHECK_ARG(dbias && workspace, "bias grad: null pointer");
   BiasArgs a = {};

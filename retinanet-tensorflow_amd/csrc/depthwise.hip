@@ -264,7 +264,8 @@ extern "C" size_t rn_depthwise_wgrad_workspace(int n, int h, int w, int c, int k
 }
 
 extern "C" int rn_depthwise_wgrad(const float* x, const float* dy, float* dw, int n, int h, int w, int c, int k,
-                                  int stride, void* workspace, size_t workspace_bytes, rn_stream_t stream) {
+                                  int stride, void* workspace, size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer) {
+  rn::DeferScope defer_scope_(defer);
   DwArgs a = {};
   if (int e = fill(&a, n, h, w, c, k, stride)) return e;
   RN_CHECK_ARG(x && dy && dw && workspace, "depthwise wgrad: null pointer");
@@ -285,7 +286,8 @@ extern "C" int rn_depthwise_wgrad(const float* x, const float* dy, float* dw, in
 // dx and dw of a 3x3 depthwise conv from one launch (+ the fixed-order row reduction of the dw partials, which joins
 // the step's deferred reduction when that is active).  Workspace: rn_depthwise_wgrad_workspace bytes.
 extern "C" int rn_depthwise_bwd(const float* x, const float* dy, const float* wgt, float* dx, float* dw, int n, int h, int w, int c,
-                                int k, int stride, void* workspace, size_t workspace_bytes, rn_stream_t stream) {
+                                int k, int stride, void* workspace, size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer) {
+  rn::DeferScope defer_scope_(defer);
   DwBwdArgs b = {};
   if (int e = fill(&b.d, n, h, w, c, k, stride)) return e;
   RN_CHECK_ARG(x && dy && wgt && dx && dw && workspace, "depthwise bwd: null pointer");

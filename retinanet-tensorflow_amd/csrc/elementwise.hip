@@ -441,3 +441,44 @@ extern "C" int rn_flip_width(const void* x, void* y, int64_t outer, int w, int64
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
+
+// out_s = a_s + b_s for up to RN_MAX_SEG tensors in one launch: the sum of the two gradients of a tensor that two
+// branches consume (a bottleneck's input: expand conv + residual; a pyramid level: class + box subnet).
+namespace {
+struct AddArgs { rn_add_seg seg[RN_MAX_SEG]; int64_t start[RN_MAX_SEG + 1]; int nseg; };
+__global__ __launch_bounds__(256) void add_segs_kernel(const AddArgs a) {
+  const int64_t total = a.start[a.nseg];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int s = 0;
+    while (s + 1 < a.nseg && i >= a.start[s + 1]) ++s;
+    const int64_t q = i - a.start[s];            // quad index inside the segment
+    const rn_add_seg& g = a.seg[s];
+    if (q * 4 + 4 <= g.count) {
+      const float4 x = *reinterpret_cast<const float4*>(g.a + q * 4), y = *reinterpret_cast<const float4*>(g.b + q * 4);
+      *reinterpret_cast<float4*>(g.out + q * 4) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    } else {
+      for (int64_t j = q * 4; j < g.count; ++j) g.out[j] = g.a[j] + g.b[j];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int rn_add_segs(const rn_add_seg* segs, int nseg, rn_stream_t stream) {
+  RN_CHECK_ARG(segs && nseg >= 1 && nseg <= RN_MAX_SEG, "add_segs: nseg outside [1,%d]", RN_MAX_SEG);
+  AddArgs a = {};
+  a.nseg = nseg;
+  int64_t quads = 0;
+  for (int s = 0; s < nseg; ++s) {
+    RN_CHECK_ARG(segs[s].a && segs[s].b && segs[s].out && segs[s].count >= 1, "add_segs: bad segment %d", s);
+    RN_CHECK_ARG((((uintptr_t)segs[s].a | (uintptr_t)segs[s].b | (uintptr_t)segs[s].out) & 15) == 0, "add_segs: segment %d not 16-byte aligned", s);
+    a.seg[s] = segs[s];
+    a.start[s] = quads;
+    quads += (segs[s].count + 3) / 4;
+  }
+  a.start[nseg] = quads;
+  int64_t blocks = (quads + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_segs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}

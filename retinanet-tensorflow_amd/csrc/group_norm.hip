@@ -1163,7 +1163,8 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
 
 extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, const float* gamma,
                                  const float* beta, float* dgamma, float* dbeta, void* workspace,
-                                 size_t workspace_bytes, rn_stream_t stream) {
+                                 size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer) {
+  rn::DeferScope defer_scope_(defer);
   GnArgs a = {};
   if (int e = build_args(segs, nseg, p, &a, true)) return e;
   RN_CHECK_ARG(gamma && beta && dgamma && dbeta && workspace, "group_norm bwd: null argument");
@@ -1208,12 +1209,12 @@ extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(a.total_chunks), dim3(T), 0, st, a);
   // dbeta / dgamma = the column sums of the two partial planes: blocks appended to the finalize launch, or -- while
   // the step's reductions are deferred -- two rows of the single batched reduction
-  const bool defer = rn::reduce_deferred(st);
-  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(a.total_samples * a.groups + (defer ? 0 : rn::ceil_div(a.c, 16))), dim3(T), 0,
+  const bool deferring = rn::reduce_deferred(st);
+  hipLaunchKernelGGL(gn_finalize_kernel<true>, dim3(a.total_samples * a.groups + (deferring ? 0 : rn::ceil_div(a.c, 16))), dim3(T), 0,
                      st, a);
   hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(apply_blocks(a), a.total_samples), dim3(T), 0, st, a);
   RN_LAUNCH_CHECK();
-  if (defer) {
+  if (deferring) {
     if (int e = rn::launch_reduce_rows(a.partial, dbeta, a.c, a.total_chunks, 0, st)) return e;
     return rn::launch_reduce_rows(a.partial + (size_t)a.total_chunks * a.c, dgamma, a.c, a.total_chunks, 0, st);
   }

@@ -32,6 +32,7 @@ struct LossArgs {
   int64_t total_rows;
   float* partial;  // [BLOCKS][NSCAL + 3*C]
   float* stats;
+  float* cls_out; float* reg_out;  // optional separate scalars (forward)
   const float* g_cls; const float* g_reg;
 };
 
@@ -160,6 +161,8 @@ __global__ void loss_finalize_kernel(const LossArgs a, const double* __restrict_
     }
     const double reg = fg > 0.0 ? sh[4] / (4.0 * fg) : 0.0;
     a.stats[0] = (float)cls; a.stats[1] = (float)reg; a.stats[2] = (float)M; a.stats[3] = (float)fg;
+    if (a.cls_out) *a.cls_out = (float)cls;
+    if (a.reg_out) *a.reg_out = (float)reg;
     a.stats[4] = (float)sh[2]; a.stats[5] = (float)sh[3]; a.stats[6] = (float)sh[4]; a.stats[7] = 0.f;
   }
 }
@@ -264,8 +267,8 @@ extern "C" size_t rn_loss_workspace(const rn_loss_seg*, int, int num_classes) {
          (NSCAL + 3 * (size_t)num_classes) * sizeof(double);
 }
 
-extern "C" int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, float* stats, void* workspace,
-                           size_t workspace_bytes, rn_stream_t stream) {
+extern "C" int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, int mode, float* stats, float* class_loss_out,
+                           float* regr_loss_out, void* workspace, size_t workspace_bytes, rn_stream_t stream) {
   LossArgs a = {};
   if (int e = build(segs, nseg, num_classes, mode, &a, false)) return e;
   RN_CHECK_ARG(stats && workspace, "loss fwd: null stats/workspace");
@@ -273,7 +276,7 @@ extern "C" int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, i
     rn::set_error("loss fwd: workspace too small");
     return RN_EWORKSPACE;
   }
-  a.partial = (float*)workspace; a.stats = stats;
+  a.partial = (float*)workspace; a.stats = stats; a.cls_out = class_loss_out; a.reg_out = regr_loss_out;
   const int nb = nblocks_for(a.total_rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(nb), dim3(T), 0, st, a);

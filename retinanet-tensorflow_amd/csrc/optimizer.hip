@@ -46,7 +46,8 @@ template <int KIND>
 __global__ __launch_bounds__(T) void opt_step_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                      float* __restrict__ s1, float* __restrict__ s2,
                                                      const float* __restrict__ wd, int64_t count, float lr, float gs,
-                                                     float clip, const float* __restrict__ norm_sq) {
+                                                     float clip, const float* __restrict__ norm_sq, unsigned long long* advance, unsigned long long advance_by) {
+  if (advance && blockIdx.x == 0 && threadIdx.x == 0) *advance += advance_by;  // the step counter the dropout masks hash (fresh masks next step)
   float cs = 1.f;
   if (clip > 0.f) {
     const float gn = sqrtf(norm_sq[0]);
@@ -111,7 +112,7 @@ extern "C" int rn_grad_norm_l2reg(const float* w, const float* grad, const float
 
 extern "C" int rn_optimizer_step(int kind, float* w, const float* grad, float* state1, float* state2,
                                  const float* wd_per_block, int64_t count, float lr, float grad_scale, float clip_norm,
-                                 const float* norm_sq, int64_t step, rn_stream_t stream) {
+                                 const float* norm_sq, int64_t step, uint64_t* advance_counter, uint64_t advance_by, rn_stream_t stream) {
   RN_CHECK_ARG(w && grad && state1 && wd_per_block, "optimizer: null pointer");
   RN_CHECK_ARG(count > 0 && count % RN_OPT_BLOCK == 0, "optimizer: count %lld not a multiple of %d", (long long)count,
                RN_OPT_BLOCK);
@@ -121,19 +122,30 @@ extern "C" int rn_optimizer_step(int kind, float* w, const float* grad, float* s
   const unsigned nb = grid_for(count / 4);
   if (kind == RN_OPT_MOMENTUM) {
     hipLaunchKernelGGL(opt_step_kernel<RN_OPT_MOMENTUM>, dim3(nb), dim3(T), 0, st, w, grad, state1, state2, wd_per_block,
-                       count, lr, grad_scale, clip_norm, norm_sq);
+                       count, lr, grad_scale, clip_norm, norm_sq, (unsigned long long*)advance_counter, (unsigned long long)advance_by);
   } else if (kind == RN_OPT_RMSPROP) {
     hipLaunchKernelGGL(opt_step_kernel<RN_OPT_RMSPROP>, dim3(nb), dim3(T), 0, st, w, grad, state1, state2, wd_per_block,
-                       count, lr, grad_scale, clip_norm, norm_sq);
+                       count, lr, grad_scale, clip_norm, norm_sq, (unsigned long long*)advance_counter, (unsigned long long)advance_by);
   } else if (kind == RN_OPT_ADAM) {
     RN_CHECK_ARG(step >= 1, "optimizer: adam step must be >= 1");
     const double lr_t = (double)lr * sqrt(1.0 - pow(0.999, (double)step)) / (1.0 - pow(0.9, (double)step));
     hipLaunchKernelGGL(opt_step_kernel<RN_OPT_ADAM>, dim3(nb), dim3(T), 0, st, w, grad, state1, state2, wd_per_block,
-                       count, (float)lr_t, grad_scale, clip_norm, norm_sq);
+                       count, (float)lr_t, grad_scale, clip_norm, norm_sq, (unsigned long long*)advance_counter, (unsigned long long)advance_by);
   } else {
     rn::set_error("optimizer: unknown kind %d", kind);
     return RN_EINVAL;
   }
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+namespace {
+__global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) { *c += inc; }
+}  // namespace
+
+extern "C" int rn_counter_add(uint64_t* counter, uint64_t inc, rn_stream_t stream) {
+  RN_CHECK_ARG(counter, "counter_add: null pointer");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)counter, (unsigned long long)inc);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }

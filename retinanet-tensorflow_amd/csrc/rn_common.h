@@ -49,7 +49,14 @@ int launch_batched_gemm_tn(const float* A, const float* B, float* C, int M, int 
 int launch_winograd_bwd_products(const float* Ad, const float* Bd, float* Cd, int M, int Kd, int Nd, const float* Aw,
                                  const float* Bw, int Kw, int Nw, int nbatch, void* workspace, size_t workspace_bytes,
                                  hipStream_t st, int* nsplit_out);
-// true while row reductions on `st` are being recorded for rn_flush_reductions instead of launched
+// Entry points that end with a row reduction open one of these with their `defer` argument: while it is alive (this
+// call, this thread) launch_reduce_rows records into the caller's list instead of launching.
+struct DeferScope {
+  explicit DeferScope(rn_reduce_list* list);
+  ~DeferScope();
+  void* prev_;
+};
+// true while the current call records its row reductions for rn_flush_reductions instead of launching them
 bool reduce_deferred(hipStream_t st);
 // out[i] = (accumulate ? out[i] : 0) + sum_r in[r][i]  (r = 0..nrows-1, fixed order => reproducible).
 // 16 float4 columns x 16 row lanes per block; defined in conv_gemm.hip.

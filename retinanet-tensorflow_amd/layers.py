@@ -64,9 +64,10 @@ def activation_name(obj):
 
 
 def add(a, b):
-    if isinstance(a, (list, tuple)):
-        return [x + y for x, y in zip(a, b)]
-    return a + b
+    first = a[0] if isinstance(a, (list, tuple)) else a
+    if first.dtype == torch.float16:
+        return [x + y for x, y in zip(a, b)] if isinstance(a, (list, tuple)) else a + b
+    return ops.add(a, b)
 
 
 # ------------------------------------------------------------------ initialisers / regularisers

@@ -11,6 +11,7 @@ SURVEY Q8).  Each [conv, Normalization, activation, Dropout] run is conv kernel 
 GroupNorm kernel (the residual add rides in the same kernel).
 """
 import layers as L
+import ops
 from model import Model, Sequential
 from normalization import Normalization
 
@@ -60,7 +61,9 @@ class Bottleneck(Model):
         if self.expand_conv is None:
             self.build(input.shape[3])
             self.to(input.device)
-        identity = input if self._same_shape else None
+        identity = None
+        if self._same_shape:        # the input feeds the expand conv and the residual: their gradients are summed by our kernel
+            input, identity = ops.fanout(input, 2)
         input = self.expand_conv(input, training)
         input = self.depthwise_conv(input, training)
         return self.linear_conv(input, training, residual=identity)
@@ -98,7 +101,7 @@ class MobileNetV2(Model):
         input = self.input_conv(input, training)
         for name in self.block_names:
             input = getattr(self, name)(input, training)
-            if name in _TAP_AFTER:
-                out[_TAP_AFTER[name]] = input
+            if name in _TAP_AFTER:      # a tap feeds the next block and (C3, C4) the pyramid
+                out[_TAP_AFTER[name]], input = ops.fanout(input, 2)
         out['C5'] = self.output_conv(input, training)
         return out

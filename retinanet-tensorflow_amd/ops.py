@@ -134,13 +134,23 @@ def _grad_slot(p):
     return g, g
 
 
-# Deferred gradient reductions (rn_defer_reductions): between begin_deferred_reductions() and
-# end_deferred_reductions() the fixed-order row reductions that finish every weight / bias / GroupNorm-parameter
-# gradient are recorded by the library and run as ONE launch at the end instead of ~130 launch-latency-bound
-# kernels per step.  Their inputs (per-call workspaces) are kept alive here until the flush.
+# Deferred gradient reductions: between begin_deferred_reductions() and end_deferred_reductions() the fixed-order row
+# reductions that finish every weight / bias / GroupNorm-parameter gradient are recorded in a caller-owned rn_reduce_list
+# per stream (handed to each gradient entry point as its `defer` argument -- the library keeps nothing) and run as ONE
+# launch per stream at the end instead of ~130 launch-latency-bound kernels per step.  Their inputs (per-call workspaces)
+# are kept alive here until the flush.
 _deferring = False
 _deferred_keep = []
 _deferred_streams = []
+_defer_lists = {}          # raw stream handle -> _rn.ReduceList (allocated once, reused every step)
+
+
+def _defer_arg():
+    """The `defer` argument for an entry point launched on the current stream: this stream's list while deferring."""
+    if not _deferring:
+        return None
+    lst = _defer_lists.get(torch.cuda.current_stream().cuda_stream)
+    return C.byref(lst) if lst is not None else None
 
 
 def begin_deferred_reductions(extra_streams=()):
@@ -148,10 +158,11 @@ def begin_deferred_reductions(extra_streams=()):
     second head stream of retinanet.HEADS_TWO_STREAMS)."""
     global _deferring
     assert DIRECT_PARAM_GRADS, "deferred reductions write parameter gradients in place: set DIRECT_PARAM_GRADS"
-    L = _rn.lib()
-    _rn.check(L.rn_defer_reductions(_rn.stream(), 1), "rn_defer_reductions")
-    for st in extra_streams:
-        _rn.check(L.rn_defer_reductions(C.c_void_p(st.cuda_stream), 1), "rn_defer_reductions")
+    for h in [torch.cuda.current_stream().cuda_stream] + [st.cuda_stream for st in extra_streams]:
+        lst = _defer_lists.get(h)
+        if lst is None:
+            lst = _defer_lists[h] = _rn.ReduceList.make()
+        lst.count = 0
     _deferred_streams[:] = list(extra_streams)
     _deferring = True
 
@@ -161,16 +172,20 @@ def end_deferred_reductions():
     global _deferring
     if _deferring:
         L = _rn.lib()
-        _rn.check(L.rn_defer_reductions(_rn.stream(), 0), "rn_defer_reductions")
-        for st in _deferred_streams:
-            # fork again from the current stream first: after autograd's end-of-backward join a side stream is no
-            # longer part of an ongoing hipGraph capture, and its flush would run eagerly instead of being captured
-            st.wait_stream(torch.cuda.current_stream())
-            _rn.check(L.rn_defer_reductions(C.c_void_p(st.cuda_stream), 0), "rn_defer_reductions")
-            torch.cuda.current_stream().wait_stream(st)
         _deferring = False
-        del _deferred_keep[:]
-        del _deferred_streams[:]
+        cur = torch.cuda.current_stream()
+        try:
+            _rn.check(L.rn_flush_reductions(C.byref(_defer_lists[cur.cuda_stream]), _rn.stream()), "rn_flush_reductions")
+            for st in _deferred_streams:
+                # fork again from the current stream first: after autograd's end-of-backward join a side stream is no
+                # longer part of an ongoing hipGraph capture, and its flush would run eagerly instead of being captured
+                st.wait_stream(cur)
+                _rn.check(L.rn_flush_reductions(C.byref(_defer_lists[st.cuda_stream]), C.c_void_p(st.cuda_stream)),
+                          "rn_flush_reductions")
+                cur.wait_stream(st)
+        finally:
+            del _deferred_keep[:]
+            del _deferred_streams[:]
 
 
 def _grad_workspace(need, device):
@@ -268,7 +283,7 @@ class _Conv2dShared(torch.autograd.Function):
                 db_buf, db = _grad_slot(bias)
                 need = L.rn_conv2d_bias_grad_workspace(cout)
                 ws = _grad_workspace(need, w.device)
-                _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws.data_ptr(), ws.numel(), _rn.stream()),
+                _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws.data_ptr(), ws.numel(), _rn.stream(), _defer_arg()),
                           "rn_conv2d_bias_grad")
             return (None, dw, db) + tuple(outs)
         if (all(need_dx) and want_dw0 and not ctx.winograd and not WGRAD_SIDE_STREAM and n <= 4 and MERGED_CONV_BWD):
@@ -279,7 +294,7 @@ class _Conv2dShared(torch.autograd.Function):
                 dw_buf, dw = _grad_slot(w)
                 need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
                 ws = _grad_workspace(need, w.device)
-                _rn.check(L.rn_conv2d_bwd(segs, n, C.byref(geom), _rn.f32(dw_buf), ws.data_ptr(), ws.numel(), _rn.stream()),
+                _rn.check(L.rn_conv2d_bwd(segs, n, C.byref(geom), _rn.f32(dw_buf), ws.data_ptr(), ws.numel(), _rn.stream(), _defer_arg()),
                           "rn_conv2d_bwd")
                 db = None
                 if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -287,7 +302,7 @@ class _Conv2dShared(torch.autograd.Function):
                     need = L.rn_conv2d_bias_grad_workspace(cout)
                     ws = _grad_workspace(need, w.device)
                     _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws.data_ptr(), ws.numel(),
-                                                    _rn.stream()), "rn_conv2d_bias_grad")
+                                                    _rn.stream(), _defer_arg()), "rn_conv2d_bias_grad")
                 return (None, dw, db) + tuple(outs)
         if any(need_dx):
             idx = [i for i in range(n) if need_dx[i]]
@@ -320,12 +335,12 @@ class _Conv2dShared(torch.autograd.Function):
                     need = L.rn_conv2d_wgrad_workspace(segs, n, C.byref(geom))
                     ws = _grad_workspace(need, w.device)
                     _rn.check(L.rn_conv2d_wgrad(segs, n, C.byref(geom), _rn.f32(dw_buf), 0, ws.data_ptr(), ws.numel(),
-                                                _rn.stream()), "rn_conv2d_wgrad")
+                                                _rn.stream(), _defer_arg()), "rn_conv2d_wgrad")
                 if want_db:
                     need = L.rn_conv2d_bias_grad_workspace(cout)
                     ws = _grad_workspace(need, w.device)
                     _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws.data_ptr(), ws.numel(),
-                                                    _rn.stream()), "rn_conv2d_bias_grad")
+                                                    _rn.stream(), _defer_arg()), "rn_conv2d_bias_grad")
         return (None, dw, db) + tuple(dxs)
 
 
@@ -380,7 +395,7 @@ class _Conv2dChannelSplit(torch.autograd.Function):
             ws_buf = _grad_workspace(need, dev)
             dw_buf, dw = _grad_slot(w)
             _rn.check(L.rn_conv2d_wgrad(segs, n, C.byref(geom), _rn.f32(dw_buf), 0, ws_buf.data_ptr(), ws_buf.numel(),
-                                        _rn.stream()), "rn_conv2d_wgrad")
+                                        _rn.stream(), _defer_arg()), "rn_conv2d_wgrad")
             dws.append(dw)
             db = None
             if bs[j] is not None:
@@ -388,7 +403,7 @@ class _Conv2dChannelSplit(torch.autograd.Function):
                 ws_buf = _grad_workspace(need, dev)
                 db_buf, db = _grad_slot(bs[j])
                 _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), ws_buf.data_ptr(),
-                                                ws_buf.numel(), _rn.stream()), "rn_conv2d_bias_grad")
+                                                ws_buf.numel(), _rn.stream(), _defer_arg()), "rn_conv2d_bias_grad")
             dbs.append(db)
         return (None, None) + tuple(dws) + tuple(dbs) + tuple(dxs)
 
@@ -549,7 +564,7 @@ class _WinoTower(torch.autograd.Function):
                 geom = _rn.ConvGeom(3, 3, 1, cin, 1)
                 need = L.rn_conv2d_bias_grad_workspace(cout)
                 wsb = _grad_workspace(need, dev)
-                _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), wsb.data_ptr(), wsb.numel(), _rn.stream()),
+                _rn.check(L.rn_conv2d_bias_grad(segs, n, C.byref(geom), _rn.f32(db_buf), wsb.data_ptr(), wsb.numel(), _rn.stream(), _defer_arg()),
                           "rn_conv2d_bias_grad")
                 grads[3 * k + 1] = db
             if i > 0:                                    # dbeta / dgamma of GroupNorm i-1 from the per-channel rows
@@ -558,8 +573,8 @@ class _WinoTower(torch.autograd.Function):
                 db_buf, db = _grad_slot(beta)
                 if _deferring:
                     _deferred_keep.append(grc)
-                _rn.check(L.rn_reduce_rows(_rn.f32(grc[0]), _rn.f32(db_buf), cin, ctx.nrows, 0, _rn.stream()), "rn_reduce_rows")
-                _rn.check(L.rn_reduce_rows(_rn.f32(grc[1]), _rn.f32(dg_buf), cin, ctx.nrows, 0, _rn.stream()), "rn_reduce_rows")
+                _rn.check(L.rn_reduce_rows(_rn.f32(grc[0]), _rn.f32(db_buf), cin, ctx.nrows, 0, _rn.stream(), _defer_arg()), "rn_reduce_rows")
+                _rn.check(L.rn_reduce_rows(_rn.f32(grc[1]), _rn.f32(dg_buf), cin, ctx.nrows, 0, _rn.stream(), _defer_arg()), "rn_reduce_rows")
                 grads[3 * (i - 1) + 1], grads[3 * (i - 1) + 2] = dg, db
             cur_dy = dxs
             g_rows_group_next = grg
@@ -610,7 +625,7 @@ class _Depthwise(torch.autograd.Function):
             need = L.rn_depthwise_wgrad_workspace(n, h, wd, c, k, ctx.stride)
             ws = _grad_workspace(need, x.device)
             _rn.check(L.rn_depthwise_bwd(_rn.f32(x), _rn.f32(dy), _rn.f32(w), _rn.f32(dx), _rn.f32(dw_buf), n, h, wd, c, k,
-                                         ctx.stride, ws.data_ptr(), ws.numel(), _rn.stream()), "rn_depthwise_bwd")
+                                         ctx.stride, ws.data_ptr(), ws.numel(), _rn.stream(), _defer_arg()), "rn_depthwise_bwd")
             return dx, dw, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -622,7 +637,7 @@ class _Depthwise(torch.autograd.Function):
                 need = L.rn_depthwise_wgrad_workspace(n, h, wd, c, k, ctx.stride)
                 ws = _grad_workspace(need, x.device)
                 _rn.check(L.rn_depthwise_wgrad(_rn.f32(x), _rn.f32(dy), _rn.f32(dw_buf), n, h, wd, c, k, ctx.stride,
-                                               ws.data_ptr(), ws.numel(), _rn.stream()), "rn_depthwise_wgrad")
+                                               ws.data_ptr(), ws.numel(), _rn.stream(), _defer_arg()), "rn_depthwise_wgrad")
         return dx, dw, None
 
 
@@ -721,7 +736,7 @@ class _GroupNormAct(torch.autograd.Function):
         need = L.rn_group_norm_workspace(segs, n, C.byref(params))
         ws = _grad_workspace(need, dev)
         _rn.check(L.rn_group_norm_bwd(segs, n, C.byref(params), _rn.f32(gamma), _rn.f32(beta), _rn.f32(dgamma_buf),
-                                      _rn.f32(dbeta_buf), ws.data_ptr(), ws.numel(), _rn.stream()),
+                                      _rn.f32(dbeta_buf), ws.data_ptr(), ws.numel(), _rn.stream(), _defer_arg()),
                   "rn_group_norm_bwd")
         dres = [(dress[i] if dress[i] is not None else dys[i]) if ctx.has_res[i] else None for i in range(n)]
         return (None, dgamma, dbeta, None) + tuple(dxs) + tuple(dres)
@@ -835,13 +850,14 @@ class _DetectionLoss(torch.autograd.Function):
         segs = _loss_segs(cls_logits, cls_labels, reg_preds, reg_labels, masks, None, None)
         need = L.rn_loss_workspace(segs, n, num_classes)
         ws = _rn.workspace(need, dev)
-        _rn.check(L.rn_loss_fwd(segs, n, num_classes, _rn.LOSS_MODE[mode], _rn.f32(stats), ws.data_ptr(), ws.numel(),
-                                _rn.stream()), "rn_loss_fwd")
+        class_loss = torch.empty((), dtype=torch.float32, device=dev)     # stand-alone scalars written by the kernel itself
+        regr_loss = torch.empty((), dtype=torch.float32, device=dev)      # (no copies of stats[0], stats[1])
+        _rn.check(L.rn_loss_fwd(segs, n, num_classes, _rn.LOSS_MODE[mode], _rn.f32(stats), _rn.f32(class_loss), _rn.f32(regr_loss),
+                                ws.data_ptr(), ws.numel(), _rn.stream()), "rn_loss_fwd")
         ctx.mode, ctx.num_classes, ctx.n = mode, num_classes, n
         ctx.save_for_backward(stats, *cls_logits, *reg_preds, *cls_labels, *reg_labels, *masks)
         ctx.mark_non_differentiable(stats)
-        # separate scalars (not views of `stats`) so autograd sees plain outputs
-        return stats[0].clone(), stats[1].clone(), stats
+        return class_loss, regr_loss, stats
 
     @staticmethod
     def backward(ctx, g_cls, g_reg, _g_stats):
@@ -896,9 +912,88 @@ class _Dropout(torch.autograd.Function):
         return dx, None, None, None
 
 
+DROPOUT_COUNTER_STEP = 0x9E3779B9
+
+
 def advance_dropout_counter(counter):
-    """Next step's dropout masks: the device-side word every fused dropout hashes with (captured in the step's graph)."""
-    counter += 0x9E3779B9
+    """Next step's dropout masks: bump the device-side word every fused dropout hashes with.  train.Trainer.step does not
+    need this (its optimizer kernel bumps the counter, rn_optimizer_step); it is for backward passes without an update."""
+    _rn.check(_rn.lib().rn_counter_add(counter.data_ptr(), DROPOUT_COUNTER_STEP, _rn.stream()), "rn_counter_add")
+
+
+class _Fanout(torch.autograd.Function):
+    """k views of the same tensors for k consumers; backward sums the k gradients with ONE launch of our add kernel
+    (rn_add_segs) instead of leaving the sums to autograd's accumulation (PyTorch kernels inside the step)."""
+
+    @staticmethod
+    def forward(ctx, k, n, *xs):
+        ctx.k, ctx.n = k, n
+        return tuple(x.view_as(x) for _ in range(k) for x in xs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        k, n = ctx.k, ctx.n
+        acc = [gs[j] for j in range(n)]
+        for i in range(1, k):
+            nxt = [gs[i * n + j] for j in range(n)]
+            pairs = [(j, a, b) for j, (a, b) in enumerate(zip(acc, nxt)) if a is not None and b is not None]
+            for j, (a, b) in enumerate(zip(acc, nxt)):
+                if a is None:
+                    acc[j] = b
+            for c0 in range(0, len(pairs), _rn.MAX_SEG):
+                chunk = pairs[c0:c0 + _rn.MAX_SEG]
+                segs = (_rn.AddSeg * len(chunk))()
+                outs = []
+                for q, (j, a, b) in enumerate(chunk):
+                    a, b = a.contiguous(), b.contiguous()
+                    o = torch.empty_like(a)
+                    segs[q] = _rn.AddSeg(_rn.f32(a), _rn.f32(b), _rn.f32(o), a.numel())
+                    outs.append((j, o, a, b))
+                _rn.check(_rn.lib().rn_add_segs(segs, len(chunk), _rn.stream()), "rn_add_segs")
+                for j, o, _a, _b in outs:
+                    acc[j] = o
+        return (None, None) + tuple(acc)
+
+
+class _Add(torch.autograd.Function):
+    """a + b (lists: one launch for all pairs) by rn_add_segs; the gradient passes through to both."""
+
+    @staticmethod
+    def forward(ctx, n, *ts):
+        outs = []
+        for c0 in range(0, n, _rn.MAX_SEG):
+            m = min(_rn.MAX_SEG, n - c0)
+            segs = (_rn.AddSeg * m)()
+            for q in range(m):
+                a, b = ts[c0 + q].contiguous(), ts[n + c0 + q].contiguous()
+                assert a.shape == b.shape
+                o = torch.empty_like(a)
+                segs[q] = _rn.AddSeg(_rn.f32(a), _rn.f32(b), _rn.f32(o), a.numel())
+                outs.append(o)
+            _rn.check(_rn.lib().rn_add_segs(segs, m, _rn.stream()), "rn_add_segs")
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return (None,) + tuple(gs) + tuple(gs)
+
+
+def add(a, b):
+    if isinstance(a, (list, tuple)):
+        return list(_Add.apply(len(a), *a, *b))
+    return _Add.apply(1, a, b)[0]
+
+
+def fanout(xs, k=2):
+    """`xs` (tensor or list) for k consumers: returns k copies of the structure (views).  Gradients are summed by rn_add_segs."""
+    multi = isinstance(xs, (list, tuple))
+    lst = list(xs) if multi else [xs]
+    if not any(x.requires_grad for x in lst) or not torch.is_grad_enabled():
+        return [lst if multi else lst[0] for _ in range(k)]
+    out = _Fanout.apply(k, len(lst), *lst)
+    n = len(lst)
+    groups = [list(out[i * n:(i + 1) * n]) for i in range(k)]
+    return [g if multi else g[0] for g in groups]
 
 
 def dropout(x, rate, seed=0, seed_dev=None):

@@ -58,7 +58,8 @@ class ResNeXt_Bottleneck(Model):
         if not self._built:
             self.build(input.shape[3])
             self.to(input.device)
-        identity = input
+        import ops
+        input, identity = ops.fanout(input, 2) if input.dtype != L.torch.float16 else (input, input)   # two consumers: one summed gradient
         if self._identity_conv is not None:
             identity = self._identity_bn.fused(self._identity_conv(identity), training)
         x = self._bn_1.fused(self._conv_1(input), training, act='relu')

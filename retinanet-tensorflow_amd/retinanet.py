@@ -165,11 +165,13 @@ class FeaturePyramidNetwork(Model):
                                                                 name='upsample_merge_c3p4', in_channels=fc.get('C3'))
 
     def call(self, input, training):
-        P6 = self.p6_from_c5(input['C5'], training)
-        P7 = self.p7_from_p6(P6, training)
-        P5 = self.p5_from_c5(input['C5'], training)
-        P4 = self.p4_from_c4p5(input['C4'], P5, training)
-        P3 = self.p3_from_c3p4(input['C3'], P4, training)
+        # a tensor with two consumers goes through ops.fanout: its two gradients are summed by one launch of our add kernel
+        c5a, c5b = ops.fanout(input['C5'], 2)
+        P6, p6 = ops.fanout(self.p6_from_c5(c5a, training), 2)
+        P7 = self.p7_from_p6(p6, training)
+        P5, p5 = ops.fanout(self.p5_from_c5(c5b, training), 2)
+        P4, p4 = ops.fanout(self.p4_from_c4p5(input['C4'], p5, training), 2)
+        P3 = self.p3_from_c3p4(input['C3'], p4, training)
         return {'P3': P3, 'P4': P4, 'P5': P5, 'P6': P6, 'P7': P7}       # order matters
 
 
@@ -203,16 +205,18 @@ class RetinaNetBase(Model):
         maps = [top_down[k] for k in keys]
         if FUSE_HEAD_TOWERS and maps[0].is_cuda:
             cls_out, reg_out = self._fused_heads(maps, training)
-        elif HEADS_TWO_STREAMS and maps[0].is_cuda:
-            main, side = torch.cuda.current_stream(), side_stream(maps[0].device)
-            side.wait_stream(main)
-            cls_out = self.classification_subnet(maps, training)
-            with torch.cuda.stream(side):
-                reg_out = self.regression_subnet(maps, training)
-            main.wait_stream(side)
         else:
-            cls_out = self.classification_subnet(maps, training)
-            reg_out = self.regression_subnet(maps, training)
+            maps_c, maps_r = ops.fanout(maps, 2) if maps[0].is_cuda else (maps, maps)   # both subnets read every level
+            if HEADS_TWO_STREAMS and maps[0].is_cuda:
+                main, side = torch.cuda.current_stream(), side_stream(maps[0].device)
+                side.wait_stream(main)
+                cls_out = self.classification_subnet(maps_c, training)
+                with torch.cuda.stream(side):
+                    reg_out = self.regression_subnet(maps_r, training)
+                main.wait_stream(side)
+            else:
+                cls_out = self.classification_subnet(maps_c, training)
+                reg_out = self.regression_subnet(maps_r, training)
         classifications = dict(zip(keys, cls_out))
         regressions = dict(zip(keys, reg_out))
         return {'classifications': classifications, 'regressions': regressions}

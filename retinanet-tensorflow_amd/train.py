@@ -77,7 +77,8 @@ class Optimizer(object):
         self.norm_reg = torch.zeros(2, dtype=torch.float32, device=dev)   # [sum g'^2, L2 reg loss]
         self.step_count = 0
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, advance_counter=None):
+        """`advance_counter`: the device word the dropout masks hash; bumped by the optimizer kernel itself."""
         a = self.arena
         L_ = _rn.lib()
         ws = _rn.workspace(L_.rn_optimizer_workspace(a.count), a.weights.device)
@@ -88,7 +89,9 @@ class Optimizer(object):
         _rn.check(L_.rn_optimizer_step(_rn.OPT[self.kind], _rn.f32(a.weights), _rn.f32(a.grads), _rn.f32(self.state1),
                                        _rn.f32(self.state2) if self.state2 is not None else None,
                                        _rn.f32(a.wd_per_block), a.count, self.lr, grad_scale, self.clip,
-                                       _rn.f32(self.norm_reg), self.step_count, _rn.stream()), 'rn_optimizer_step')
+                                       _rn.f32(self.norm_reg), self.step_count,
+                                       advance_counter.data_ptr() if advance_counter is not None else None,
+                                       ops.DROPOUT_COUNTER_STEP, _rn.stream()), 'rn_optimizer_step')
 
     @property
     def regularization_loss(self):
@@ -264,11 +267,14 @@ class Trainer(object):
             src, leaves = self._cut_src, self._cut_leaves
             self._cut_src = self._cut_leaves = None
             self._backward(src, [l.grad for l in leaves])
-        ops.advance_dropout_counter(self.drop_counter)    # fresh dropout masks next step (device-side counter)
 
-    def forward_backward(self, features=None):
+    def forward_backward(self, features=None, advance_dropout=True):
+        """Both segments, no collective, no update.  The dropout counter is bumped here (one tiny launch); step() leaves
+        that to the optimizer kernel."""
         out = self.segment_a(features)
         self.segment_b()
+        if advance_dropout and self.device.type == 'cuda':
+            ops.advance_dropout_counter(self.drop_counter)
         return out
 
     def _capture(self, features):
@@ -279,7 +285,7 @@ class Trainer(object):
         with torch.cuda.stream(s):
             counter = self.drop_counter.clone()
             for _ in range(2):
-                self.forward_backward(self._static)
+                self.forward_backward(self._static, advance_dropout=False)
             self.drop_counter.copy_(counter)       # the warm-up passes do not count: replay i draws the masks eager step i draws
         torch.cuda.current_stream().wait_stream(s)
         ga = torch.cuda.CUDAGraph()
@@ -315,7 +321,7 @@ class Trainer(object):
             self.timing.setdefault('exposed_events', []).append((e0, e1))
         else:
             grad_scale = self.allreduce.wait()
-        self.opt.step(grad_scale)
+        self.opt.step(grad_scale, self.drop_counter)          # also bumps the dropout counter: fresh masks next step
         self.steps_done += 1
         if self.check_interval and self.steps_done % self.check_interval == 0:
             self.check_device_errors()

@@ -95,7 +95,7 @@ def _trainer_worker(rank, world, port, out_dir):
                for p in m.parameters())
     assert net.base.backward_cut is not None and tr.allreduce.active and tr.allreduce.world == world
 
-    def sgd(scale):
+    def sgd(scale, advance_counter=None):
         events.append("opt")
         tr.arena.weights.sub_(tr.opt.lr * scale * tr.arena.grads)
     tr.opt.step = sgd

@@ -143,7 +143,7 @@ def test_depthwise_fwd_bwd(dev, case):
     _rn.check(L.rn_depthwise_dgrad(_rn.f32(dyg), _rn.f32(wg.detach()), _rn.f32(dx2), n, h, w, c, 3, stride, _rn.stream()), "dgrad")
     ws = _rn.workspace(L.rn_depthwise_wgrad_workspace(n, h, w, c, 3, stride), dev)
     _rn.check(L.rn_depthwise_wgrad(_rn.f32(xg.detach()), _rn.f32(dyg), _rn.f32(dw2), n, h, w, c, 3, stride, ws.data_ptr(), ws.numel(),
-                                   _rn.stream()), "wgrad")
+                                   _rn.stream(), None), "wgrad")
     assert torch.equal(dx2, xg.grad) and torch.equal(dw2, wg.grad)
 
 
@@ -758,7 +758,7 @@ def test_batched_gemm_both_layouts(dev):
 
 
 def test_deferred_reductions_are_bitwise_identical(dev):
-    """rn_defer_reductions: the gradients after the single flushed launch equal the immediate ones bit for bit."""
+    """Deferred reductions (rn_reduce_list + rn_flush_reductions): the gradients after the single flushed launch equal the immediate ones bit for bit."""
     import ops
     rng = np.random.default_rng(5)
     x = _t(rng.standard_normal((2, 16, 16, 96)).astype(np.float32), dev)
@@ -927,10 +927,10 @@ def test_merged_conv_backward_equals_separate_calls(dev, case):
         segs = ops._conv_segs([x], wt, None, None, [dy], [dx])
         ws = torch.empty(max(int(L.rn_conv2d_wgrad_workspace(segs, 1, C.byref(geom))), 256), dtype=torch.uint8, device=dev)
         if merged:
-            _rn.check(L.rn_conv2d_bwd(segs, 1, C.byref(geom), _rn.f32(dw), ws.data_ptr(), ws.numel(), _rn.stream()), "bwd")
+            _rn.check(L.rn_conv2d_bwd(segs, 1, C.byref(geom), _rn.f32(dw), ws.data_ptr(), ws.numel(), _rn.stream(), None), "bwd")
         else:
             _rn.check(L.rn_conv2d_dgrad(segs, 1, C.byref(geom), None, 0, _rn.stream()), "dgrad")
-            _rn.check(L.rn_conv2d_wgrad(segs, 1, C.byref(geom), _rn.f32(dw), 0, ws.data_ptr(), ws.numel(), _rn.stream()), "wgrad")
+            _rn.check(L.rn_conv2d_wgrad(segs, 1, C.byref(geom), _rn.f32(dw), 0, ws.data_ptr(), ws.numel(), _rn.stream(), None), "wgrad")
         torch.cuda.synchronize()
         return dx, dw
 

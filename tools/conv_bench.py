@@ -47,7 +47,7 @@ def run_one():
         ws = _rn.workspace(need, dev)
         dw = torch.empty_like(w)
         t_w = timeit(lambda: L.rn_conv2d_wgrad(segs, len(xd), C.byref(geom), dw.data_ptr(), 0, ws.data_ptr(), ws.numel(),
-                                               _rn.stream()))
+                                               _rn.stream(), None))
         res[name] = tuple(round(flops / (t * 1e-3) / 1e12, 1) for t in (t_f, t_d, t_w)) + (round(t_f * 1e3), round(t_d * 1e3), round(t_w * 1e3))
     print(os.environ.get("RN_CONV_CFG", "auto"), res, flush=True)
 

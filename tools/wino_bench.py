@@ -55,7 +55,7 @@ def main():
     def direct_wgrad():
         need = L.rn_conv2d_wgrad_workspace(segs, len(xs), C.byref(geom))
         ws = _rn.workspace(need, dev)
-        L.rn_conv2d_wgrad(segs, len(xs), C.byref(geom), _rn.f32(dw), 0, ws.data_ptr(), ws.numel(), _rn.stream())
+        L.rn_conv2d_wgrad(segs, len(xs), C.byref(geom), _rn.f32(dw), 0, ws.data_ptr(), ws.numel(), _rn.stream(), None)
 
     print("wgrad direct: %.0f us" % timeit(direct_wgrad))
     for wcfg in ("", "0", "1", "2"):
