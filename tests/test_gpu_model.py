@@ -146,8 +146,10 @@ def test_fused_head_towers_equal_separate_subnets(dev):
         finally:
             retinanet.FUSE_HEAD_TOWERS = False
     for k in LEVELS:
-        assert_close(b["classifications"][k].cpu().numpy(), a["classifications"][k].cpu().numpy(), 1e-5, "cls " + k)
-        assert_close(b["regressions"][k].cpu().numpy(), a["regressions"][k].cpu().numpy(), 1e-5, "reg " + k)
+        # (the default path folds the GroupNorms into the Winograd transforms: statistics from chunk rows, box output conv as
+        # a Winograd layer -- rounding differs from the stand-alone kernels by a few 1e-6 of the output range)
+        assert_close(b["classifications"][k].cpu().numpy(), a["classifications"][k].cpu().numpy(), 5e-5, "cls " + k)
+        assert_close(b["regressions"][k].cpu().numpy(), a["regressions"][k].cpu().numpy(), 5e-5, "reg " + k)
 
 
 def test_gradient_average_equals_bigger_batch(dev):
