@@ -2,19 +2,22 @@
 """Headline benchmark: training images/sec of MobileNetV2-FPN RetinaNet, 512x512, batch 2 per GPU
 (BASELINE.json configs[1]), one process per GPU, gradients averaged with RCCL over xGMI.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = anchor assignment for the batch + forward + focal/smooth-L1 loss + backward +
-gradient all-reduce + momentum optimizer, fp32, dropout 0.2 (reference default), on a synthetic
-COCO-shaped batch [image, hflip(image)] that is resident in HBM before the timed region.
+A "step" = anchor assignment for the batch + forward + focal/smooth-L1 loss + backward + gradient all-reduce (the
+heads + FPN slice under the backbone's backward pass) + momentum optimizer, fp32, dropout 0.2 (reference default), on a
+synthetic COCO-shaped batch [image, hflip(image)] that is resident in HBM before the timed region.
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     : the dominant kernel (the batched fp32-MFMA product of the Winograd F(4x4,3x3) head-tower
-                 layer, 3x3 256->256 over P3..P7), timed live with HIP events on the launch stream, against
-                 the 157.3 TFLOP/s dense fp32 MFMA peak of MI355X_MICROARCH.md; executed (not direct-conv
-                 equivalent) FLOPs.  The whole layer's direct-conv-equivalent rate is reported beside it;
-  cpu_baseline : the CPU oracle (restatement of the reference's TF semantics, TF itself is not
-                 installable) timed on this host's cores on a bounded sample of the same workload.
+  roofline     : the largest kernel INSIDE the step -- the merged backward products of a Winograd F(4x4,3x3) head-tower
+                 layer (data-gradient products + weight-gradient partial products of 3x3 256->256 over P3..P7, one launch)
+                 -- timed from a replayed hipGraph with HIP events on the launch stream, against the 157.3 TFLOP/s dense
+                 fp32 MFMA peak of MI355X_MICROARCH.md; executed (not direct-conv equivalent) FLOPs.  `entries` holds the
+                 forward product and the largest GroupNorm beside it;
+  nms          : decode + candidate scan + hand-written segment sort + class-wise NMS at BASELINE configs[4]'s shape, fp16
+                 logits / box deltas as the fp16 net writes them (sigmoid inside the scan), ~1 % hot and the stress input;
+  cpu_baseline : the CPU oracle (restatement of the reference's TF semantics, TF itself is not installable) timed on
+                 this host's cores on bounded samples: the cfg-2 train step, the cfg-1 (shapes 256^2) step, decode + NMS.
 """
 import argparse
 import json
@@ -35,11 +38,10 @@ BATCH = 2
 NUM_CLASSES = 80
 MAX_OBJ = 32
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-# HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
-# --pmc WRITE_SIZE runs of tools/gemm_pmc.py, profiles/r01_gemm_pmc_fetch_write.csv):
-# FETCH_SIZE 17 567 KB x 2 (gfx950 reports 1/2 of wide 16-B/lane reads, MI355X_MICROARCH.md HBM section)
-# + WRITE_SIZE 24 552 KB = 61.1 MB.  Algorithmic bytes: 36 x (682x256 in + 256x256 weights + 682x256 out) x 4 = 59.7 MB.
-DOMINANT_KERNEL_HBM_BYTES = (2 * 17567 + 24552) * 1024
+HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# HBM bytes per launch of the roofline kernels, from THIS round's rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
+# --pmc WRITE_SIZE runs of tools/gemm_pmc.py, summarised by tools/pmc_traffic.py into this file); null when absent
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 TRAIN_GFLOP_PER_IMAGE = 239.2       # BASELINE.md section 3 (3 x forward conv FLOPs), cfg 2
 
 
@@ -107,116 +109,186 @@ class Step(object):
         return out['class_loss'], out['regr_loss']
 
 
-def time_dominant_kernel(device, iters=100):
-    """The kernel the training step spends most matrix-core time in: the batched product of the Winograd
-    F(4x4,3x3) head-tower layer (3x3, 256->256, the five pyramid levels of a 512^2 batch of 2 = 682 4x4 tiles):
-    36 x ([682 x 256] x [256 x 256]) in ONE launch of conv_fwd_kernel<64,64,...>.  Executed FLOPs per launch =
-    2 * 36 * 682 * 256 * 256 = 3.218 GFLOP (kernels table); average duration from HIP events on the
-    launch stream.  Also times the whole layer (weight / input transforms + product + output transform) and reports
-    its rate in direct-convolution FLOPs (12.87 GFLOP per layer)."""
+def _graph_time(fn, iters=100):
+    """Average device time of `fn` (launches on the current stream) from a replayed hipGraph, HIP events on the replay
+    stream, clocks warmed up first (an idle MI355X needs >= 10 ms of continuous work: 100 ms of replays)."""
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        fn()
+    t_end = time.perf_counter() + 0.1
+    while time.perf_counter() < t_end:
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        g.replay()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def roofline_kernels(device):
+    """The kernels the training step spends most time in, each timed alone from a replayed hipGraph:
+      bwd  merged backward products of a head-tower layer (conv_bwd_kernel, 36 x ([682x256] x [256x256]^T data gradient +
+           [256x682] x [682x256] weight-gradient partials) in ONE launch): 2 * 3.218 = 6.436 GFLOP executed -- the largest
+           (kernel, grid) of the step (8 launches);
+      fwd  forward products of the same layer (conv_fwd_kernel batched, 3.218 GFLOP);
+      gn   the largest stand-alone GroupNorm left in the step (MobileNetV2 bottleneck_2_1 expand: 2 x 256 x 256 x 96,
+           GroupNorm + ELU + dropout, forward): HBM-bound, 2 reads + 1 write of the tensor."""
+    import ctypes as C
     import _rn
     import ops
     sizes = [64, 32, 16, 8, 4]
     tiles = BATCH * sum(((s + 3) // 4) ** 2 for s in sizes)
+    L = _rn.lib()
     A = torch.randn(36, tiles, 256, device=device)
     B = torch.randn(36, 256, 256, device=device) * 0.01
     Cm = torch.empty(36, tiles, 256, device=device)
-    L = _rn.lib()
-
-    def timed(fn):
-        # steady state: the clocks of an idle MI355X take >= 10 ms of continuous work to come up (the same kernel measures
-        # 41 us in the first 50 launches after a pause and 35-36 us from then on), so warm up for 100 ms, not 5 launches
-        t_end = time.perf_counter() + 0.1
-        while time.perf_counter() < t_end:
-            for _ in range(20):
-                fn()
-            torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / iters
-
-    gemm_ms = timed(lambda: _rn.check(L.rn_gemm_batched(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, 36, 0,
-                                                        _rn.stream()), "rn_gemm_batched"))
+    fwd_ms = _graph_time(lambda: _rn.check(L.rn_gemm_batched(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, 36, 0,
+                                                             _rn.stream()), "rn_gemm_batched"))
+    dM = torch.randn(36, tiles, 256, device=device)
+    need = L.rn_winograd_bwd_products_workspace(tiles, 256, 256, 36)
+    ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=device)
+    nsplit = C.c_int(0)
+    bwd_ms = _graph_time(lambda: _rn.check(L.rn_winograd_bwd_products(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256,
+                                                                      _rn.f32(A), _rn.f32(dM), 256, 256, 36, ws.data_ptr(),
+                                                                      ws.numel(), C.byref(nsplit), _rn.stream()),
+                                           "rn_winograd_bwd_products"))
+    flops = 2.0 * 36 * tiles * 256 * 256
+    plane = 4.0 * 36 * tiles * 256
+    # algorithmic bytes: fwd reads V + U, writes M; bwd reads Vdy + Urot + V + dM, writes Mdx + the nsplit dU slabs
+    fwd_bytes = 2 * plane + 4.0 * 36 * 256 * 256
+    bwd_bytes = 4 * plane + 4.0 * 36 * 256 * 256 * (1 + max(nsplit.value, 1))
+    x = torch.randn(BATCH, 256, 256, 96, device=device)
+    gamma, beta = torch.ones(96, device=device), torch.zeros(96, device=device)
+    with torch.no_grad():
+        gn_ms = _graph_time(lambda: ops.group_norm_act(x, gamma, beta, groups=32, act="elu", drop_rate=0.2, seed=1))
+    gn_bytes = 3.0 * x.numel() * 4
     xs = [torch.randn(BATCH, s, s, 256, device=device) for s in sizes]
     w = torch.randn(3, 3, 256, 256, device=device) * 0.01
     with torch.no_grad():
-        layer_ms = timed(lambda: ops.conv2d(xs, w, None, 1))
+        layer_ms = _graph_time(lambda: ops.conv2d(xs, w, None, 1))
     pixels = BATCH * sum(s * s for s in sizes)
-    return {"gemm_ms": gemm_ms, "gemm_flops": 2.0 * 36 * tiles * 256 * 256, "layer_ms": layer_ms,
-            "layer_direct_flops": 2.0 * pixels * 2304 * 256,
-            "gemm_bytes": 4.0 * 36 * (2 * tiles * 256 + 256 * 256)}
+    traffic = {}
+    if os.path.exists(PMC_TRAFFIC_FILE):
+        traffic = json.load(open(PMC_TRAFFIC_FILE))
+
+    def entry(name, kernel, bound, work, ms, peak, unit, bytes_, tkey):
+        ach = work / (ms * 1e-3) / (1e12 if bound == "mfma" else 1e9)
+        return {"name": name, "kernel": kernel, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                "frac": round(ach / peak, 4), "kernel_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_,
+                "traffic": traffic.get(tkey)}
+
+    bwd = entry("head-tower layer, merged backward products (largest in-step kernel, 8 launches per step)",
+                "conv_bwd_kernel<64,64,2,2,true,64,64,2,2>: 36 x ([682x256]x[256x256]^T dgrad + [256x682]x[682x256] wgrad partials)",
+                "mfma", 2 * flops, bwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", bwd_bytes, "bwd_products")
+    bwd["flops_per_launch"] = 2 * flops
+    fwd = entry("head-tower layer, forward products", "conv_fwd_kernel<64,64,2,2,4,true>, batched: 36 x [682x256]x[256x256]",
+                "mfma", flops, fwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", fwd_bytes, "fwd_products")
+    fwd["flops_per_launch"] = flops
+    fwd["layer_ms"] = round(layer_ms, 4)
+    fwd["layer_direct_conv_equivalent_tflops"] = round(2.0 * pixels * 2304 * 256 / (layer_ms * 1e-3) / 1e12, 1)
+    gn = entry("largest stand-alone GroupNorm (+ELU+dropout) forward: 2x256x256x96", "gn_partial + gn_finalize + gn_apply", "hbm",
+               gn_bytes, gn_ms, HBM_PEAK_GBPS, "GB/s", gn_bytes, "group_norm")
+    return bwd, fwd, gn
 
 
-def nms_benchmark(device, batch=16, image_size=1024, hot=0.01, iters=5):
-    """Second half of BASELINE's metric ("NMS boxes/ms"): anchor decode + candidate extraction +
-    batched class-wise NMS at the shape of BASELINE configs[4] (1024x1024, batch 16, 80 classes,
-    196 416 anchors per image, 3.14 M per batch), synthetic class probabilities with ~1 % of the
-    anchors above the 0.5 threshold, fp32.  boxes/ms = candidates entering NMS per ms of
-    candidate scan + compaction + decode of the candidates + sort + NMS; anchors/ms = rows scanned per ms."""
+def _cfg5_inputs(device, batch, image_size, kind, seed=7):
+    """fp16 class LOGITS and box deltas in the layout the fp16 net writes them (BASELINE configs[4]).
+    hot1pct: ~1 % of the anchors carry one class above 0 (p > 0.5); stress: logits ~ N(-2, 2^2) i.i.d.."""
     import levels as levels_mod
-    import utils
     lv = levels_mod.build_levels()
-    g = torch.Generator(device=device).manual_seed(7)
-    probs, regs = {}, {}
-    size = image_size
+    g = torch.Generator(device=device).manual_seed(seed)
+    logits, regs = {}, {}
     for i, k in enumerate(lv):
-        s = -(-size // (2 ** (3 + i)))
-        p = torch.rand((batch, s, s, 9, NUM_CLASSES), generator=g, device=device) * 0.45
-        sel = torch.rand((batch, s, s, 9), generator=g, device=device) < hot
-        cls = torch.randint(0, NUM_CLASSES, (batch, s, s, 9), generator=g, device=device)
-        val = 0.5 + 0.5 * torch.rand((batch, s, s, 9), generator=g, device=device)
-        p.view(-1, NUM_CLASSES)[sel.view(-1).nonzero().squeeze(1), cls.view(-1)[sel.view(-1)]] = val.view(-1)[sel.view(-1)]
-        probs[k] = p
-        regs[k] = torch.randn((batch, s, s, 9, 4), generator=g, device=device) * 0.3
-    rows = sum(int(v.numel() // NUM_CLASSES) for v in probs.values())
+        s = -(-image_size // (2 ** (3 + i)))
+        shape = (batch, s, s, 9, NUM_CLASSES)
+        if kind == "stress":
+            z = torch.randn(shape, generator=g, device=device) * 2 - 2
+        else:
+            z = -1.0 - 3.0 * torch.rand(shape, generator=g, device=device)
+            sel = torch.rand(shape[:-1], generator=g, device=device) < 0.01
+            cls = torch.randint(0, NUM_CLASSES, shape[:-1], generator=g, device=device)
+            val = 4.0 * torch.rand(shape[:-1], generator=g, device=device) + 0.01
+            z.view(-1, NUM_CLASSES)[sel.view(-1).nonzero().squeeze(1), cls.view(-1)[sel.view(-1)]] = val.view(-1)[sel.view(-1)]
+        logits[k] = z.half()
+        regs[k] = (torch.randn((batch, s, s, 9, 4), generator=g, device=device) * 0.3).half()
     anchors = {k: lv[k].normalized_anchor_sizes((image_size, image_size)) for k in lv}
+    return logits, regs, anchors
 
-    def run():   # the raw regressions go in: only the rows that become candidates are decoded (utils.detect_raw)
-        return utils.detect_raw(probs, regs, anchors, NUM_CLASSES, capacity=int(rows * 0.05), return_raw=True)
 
-    out = run()
-    torch.cuda.synchronize()
-    counts = out[5].cpu().tolist()
-    # steady state, like the training step: clocks up (100 ms of warm-up runs), and the ~30 launches of one batch replayed
-    # as a hipGraph so that the number is device time, not the Python / ctypes launch path
-    t_end = time.perf_counter() + 0.1
-    while time.perf_counter() < t_end:
-        run()
+def nms_benchmark(device, batch=16, image_size=1024):
+    """Second half of BASELINE's metric ("NMS boxes/ms"): candidate scan (sigmoid inside) + compaction + decode of the
+    candidates + segment sort + batched class-wise NMS at BASELINE configs[4]'s shape (1024x1024, batch 16, 80 classes,
+    196 416 anchors per image, 3.14 M per batch), inputs in fp16 as the fp16 net writes them: 84 x 2 bytes per anchor.
+    boxes/ms = candidates entering NMS per ms of the whole pipeline; anchors/ms = rows scanned per ms.  Device time of
+    one batch: its launches replayed as a hipGraph, clocks warmed up."""
+    import utils
+    out = {}
+    for kind in ("hot1pct", "stress"):
+        logits, regs, anchors = _cfg5_inputs(device, batch, image_size, kind)
+        rows = sum(int(v.numel() // NUM_CLASSES) for v in logits.values())
+        cap = int(rows * (0.05 if kind == "hot1pct" else 1.0))
+
+        def run():
+            return utils.detect_raw(logits, regs, anchors, NUM_CLASSES, capacity=cap, return_raw=True, logits=True)
+
+        res = run()
         torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-        run()
-    graph.replay()
-    torch.cuda.synchronize()
-    iters = max(iters, 20)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        graph.replay()
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    read_bytes = rows * (NUM_CLASSES + 4) * 4
-    return {"boxes_per_ms": round(counts[0] / ms, 1), "anchors_per_ms": round(rows / ms, 1), "ms_per_batch": round(ms, 3),
-            "candidates": counts[0], "kept": counts[1], "anchors": rows, "scan_GBps": round(read_bytes / ms / 1e6, 1),
-            "config": "BASELINE configs[4] shape: 1024x1024, batch %d, 80 classes, fp32 probabilities, ~1%% of anchors > 0.5; "
-                      "device time of one batch (its launches replayed as a hipGraph, clocks warmed up)" % batch}
+        counts = res[5].cpu().tolist()
+        ms = _graph_time(run, iters=20)
+        read_bytes = rows * (NUM_CLASSES + 4) * 2
+        out[kind] = {"boxes_per_ms": round(counts[0] / ms, 1), "anchors_per_ms": round(rows / ms, 1), "ms_per_batch": round(ms, 3),
+                     "candidates": counts[0], "kept": counts[1], "anchors": rows,
+                     "algorithmic_read_GBps": round(read_bytes / ms / 1e6, 1)}
+        del logits, regs, res
+    out["config"] = ("BASELINE configs[4] shape: 1024x1024, batch %d, 80 classes, fp16 logits + fp16 box deltas (sigmoid inside "
+                     "the scan); hot1pct: ~1 %% of the anchors above 0.5, stress: logits ~ N(-2, 2^2); device time of one batch" % batch)
+    # the headline figure of the metric string is the ~1 % hot case (what a trained detector produces)
+    out.update({k: out["hot1pct"][k] for k in ("boxes_per_ms", "anchors_per_ms", "ms_per_batch")})
+    return out
 
 
-def cpu_baseline(max_seconds=30.0):
-    """Oracle (torch-CPU fp32 restatement of the reference graph) on this host: forward + loss +
-    backward + momentum step of the SAME workload (512^2, batch 2, 80 classes), bounded sample."""
-    from oracle import dataset_ref, model_ref, train_ref
+def _oracle_threads():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 32))      # more threads than that only adds contention on these small convs
     torch.set_num_threads(cores)
+    return cores
+
+
+def _oracle_step_rate(image_size, classes, boxes, cls, rng, max_steps, budget_s):
+    from oracle import dataset_ref, model_ref, train_ref
+    params = model_ref.init_params("mobilenet_v2", num_classes=classes, seed=0)
+    img = rng.standard_normal((1, image_size, image_size, 3)).astype(np.float32)
+    image = torch.from_numpy(np.concatenate([img, img[:, :, ::-1]], 0).copy())
+    c, r, m = dataset_ref.build_labels((image_size, image_size), cls, boxes, classes)
+    fc, fr, fm, _ = dataset_ref.flip(c, r, m)
+    labels = {"classifications": {k: torch.from_numpy(np.stack([c[k], fc[k]])) for k in c},
+              "regressions": {k: torch.from_numpy(np.stack([r[k], fr[k]])) for k in c},
+              "trainable_masks": {k: torch.from_numpy(np.stack([m[k], fm[k]])) for k in c}}
+    state, steps, t0 = {}, 0, time.perf_counter()
+    while True:
+        train_ref.train_step(params, image, labels, classes, state, lr=1e-2, step=steps + 1, loss_mode="focal")
+        steps += 1
+        if steps >= max_steps or time.perf_counter() - t0 > budget_s:
+            break
+    return 2 * steps / (time.perf_counter() - t0), steps
+
+
+def cpu_baseline(max_seconds=30.0):
+    """Oracle (torch-CPU fp32 restatement of the reference graph; numpy decode + NMS) on this host, bounded samples:
+      value : forward + loss + backward + momentum step of the SAME cfg-2 workload (512^2, batch 2, 80 classes)
+      cfg1  : the same step at BASELINE configs[0] (shapes-style 256^2, 3 classes, [image, hflip])
+      nms   : decode + class-wise NMS of one 1024^2 image of the cfg-5 ~1 % hot input (utils_ref.detect_image)."""
+    from oracle import model_ref, utils_ref
+    cores = _oracle_threads()
     rng = np.random.default_rng(1234)
     params = model_ref.init_params("mobilenet_v2", num_classes=NUM_CLASSES, seed=0)
     # calibration: backbone forward only (~2 % of the step's FLOPs); if the host is too slow for a
@@ -230,25 +302,58 @@ def cpu_baseline(max_seconds=30.0):
     if tc > 4.0:
         return {"value": None, "unit": "images/sec", "cores": cores, "kind": "port",
                 "sample": "skipped: backbone forward alone took %.1f s on this host (budget 30 s for the sample)" % tc}
-    img = rng.standard_normal((1, IMAGE_SIZE, IMAGE_SIZE, 3)).astype(np.float32)
-    image = torch.from_numpy(np.concatenate([img, img[:, :, ::-1]], 0).copy())
     boxes, cls, o = synthetic_objects(rng)
-    c, r, m = dataset_ref.build_labels((IMAGE_SIZE, IMAGE_SIZE), cls[:o], boxes[:o], NUM_CLASSES)
-    fc, fr, fm, _ = dataset_ref.flip(c, r, m)
-    labels = {"classifications": {k: torch.from_numpy(np.stack([c[k], fc[k]])) for k in c},
-              "regressions": {k: torch.from_numpy(np.stack([r[k], fr[k]])) for k in c},
-              "trainable_masks": {k: torch.from_numpy(np.stack([m[k], fm[k]])) for k in c}}
-    state, steps, t0 = {}, 0, time.perf_counter()
-    while True:
-        train_ref.train_step(params, image, labels, NUM_CLASSES, state, lr=1e-2, step=steps + 1, loss_mode="focal")
-        steps += 1
-        el = time.perf_counter() - t0
-        if steps >= 3 or el > max_seconds / 2:
-            break
+    rate, steps = _oracle_step_rate(IMAGE_SIZE, NUM_CLASSES, boxes[:o], cls[:o], rng, 3, max_seconds / 2)
+    res = {"value": round(rate, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": "%d full train steps (fwd+focal/huber loss+bwd+momentum) of the same 512x512 batch-2 workload, "
+                     "torch-CPU fp32 oracle restating the reference's TF graph (TensorFlow not installable)" % steps}
+    # cfg 1: shapes-style squares (data_loaders/shapes.py:143-176), 3 classes, 256x256
+    nsq = int(rng.integers(1, 5))
+    half = rng.integers(20, 64, nsq)
+    ctr = rng.integers(64, 192, (nsq, 2))
+    sb = np.stack([ctr[:, 0] - half, ctr[:, 1] - half, ctr[:, 0] + half, ctr[:, 1] + half], 1).astype(np.float32) / 256.0
+    rate1, steps1 = _oracle_step_rate(256, 3, sb, rng.integers(0, 3, nsq).astype(np.int32), rng, 5, 6.0)
+    res["cfg1"] = {"value": round(rate1, 3), "unit": "images/sec",
+                   "sample": "%d train steps, BASELINE configs[0]: shapes-style 256x256, 3 classes, [image, hflip]" % steps1}
+    # decode + NMS: one image of the cfg-5 ~1 % hot input, numpy oracle (single thread: the greedy loop is sequential)
+    prng = np.random.default_rng(8)
+    probs, regs = {}, {}
+    for i, k in enumerate(("P3", "P4", "P5", "P6", "P7")):
+        s = -(-1024 // 2 ** (3 + i))
+        p = prng.uniform(0, 0.45, (s, s, 9, NUM_CLASSES)).astype(np.float32)
+        sel = prng.uniform(size=(s, s, 9)) < 0.01
+        p[sel, prng.integers(0, NUM_CLASSES, int(sel.sum()))] = prng.uniform(0.5, 1.0, int(sel.sum())).astype(np.float32)
+        probs[k] = p
+        regs[k] = (prng.standard_normal((s, s, 9, 4)) * 0.3).astype(np.float32)
+    t0 = time.perf_counter()
+    det = utils_ref.detect_image(probs, regs, (1024, 1024), NUM_CLASSES)
     el = time.perf_counter() - t0
-    return {"value": round(BATCH * steps / el, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d full train steps (fwd+focal/huber loss+bwd+momentum) of the same 512x512 batch-2 workload, "
-                      "torch-CPU fp32 oracle restating the reference's TF graph (TensorFlow not installable)" % steps}
+    ncand = int(sum(int((probs[k].max(-1) > 0.5).sum()) for k in probs))
+    res["nms"] = {"boxes_per_ms": round(ncand / (el * 1e3), 2), "anchors_per_ms": round(196416 / (el * 1e3), 1), "cores": 1,
+                  "sample": "one 1024x1024 image (196 416 anchors, %d candidates, %d kept): numpy decode + class-wise greedy NMS"
+                            % (ncand, len(det.scores))}
+    return res
+
+
+def cfg1_gpu(device, steps=40):
+    """BASELINE configs[0] through the product path: the shapes loader -> device-side pipeline -> train step at 256x256."""
+    import dataset, layers, levels, retinanet, train
+    from data_loaders.shapes import Shapes
+    lv = levels.build_levels()
+    torch.manual_seed(0)
+    loader = Shapes(None, image_size=(320, 256))
+    net = retinanet.RetinaNet('mobilenet_v2', lv, loader.num_classes, layers.elu, 0.2).to(device)
+    tr = train.Trainer(net, lv, optimizer='momentum', learning_rate=1e-2, loss_mode='focal', device=device)
+    it = dataset.build_dataset(loader, lv, scale=256, device=device)
+    for _ in range(5):
+        tr.step(next(it))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(next(it))
+    torch.cuda.synchronize()
+    return {"value": round(2 * steps / (time.perf_counter() - t0), 1), "unit": "images/sec",
+            "sample": "%d eager steps incl. the host loader, rescale, label assignment (no hipGraph: every step is a new sample)" % steps}
 
 
 def _free_port():
@@ -352,8 +457,6 @@ def main():
     result = None
     if rank == 0:
         ips = world * BATCH * args.steps / elapsed
-        dk = time_dominant_kernel(device)
-        achieved = dk["gemm_flops"] / (dk["gemm_ms"] * 1e-3) / 1e12
         result = {
             "metric": "train images/sec (MobileNetV2-FPN RetinaNet 512x512, bs=2/GPU)",
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -374,18 +477,14 @@ def main():
                        "gn_barrier_timeouts": __import__("_rn").barrier_timeouts(),
                        "conv_roofline_frac_whole_step": round(ips / world * TRAIN_GFLOP_PER_IMAGE / 1e3 /
                                                               FP32_MFMA_PEAK_TFLOPS, 4)},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": DOMINANT_KERNEL_HBM_BYTES,
-                         "kernel": "conv_fwd_kernel<64,64,2,2,4,true>, batched: 36 x [682x256]x[256x256], the product stage of "
-                                   "the Winograd F(4x4,3x3) head-tower layer (3x3 256->256 over P3..P7)",
-                         "kernel_ms": round(dk["gemm_ms"], 4), "flops_per_launch": dk["gemm_flops"],
-                         "algorithmic_bytes_per_launch": dk["gemm_bytes"],
-                         "layer_ms": round(dk["layer_ms"], 4),
-                         "layer_direct_conv_equivalent_tflops": round(dk["layer_direct_flops"] / (dk["layer_ms"] * 1e-3) / 1e12, 1)},
         }
+        if not args.no_roofline:
+            bwd, fwd, gn = roofline_kernels(device)
+            result["roofline"] = dict(bwd, entries=[fwd, gn])
         if not args.no_nms:
             result["nms"] = nms_benchmark(device)
         if not args.no_cpu_baseline and world == 1:
+            result["config"]["cfg1_gpu"] = cfg1_gpu(device)
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -158,6 +158,15 @@ int rn_conv3x3_winograd(const rn_conv_seg* segs, int nseg, int cin, int cout, co
  *   C_b [M x N] = A_b [M x K] * B_b,  b = 0..nbatch-1, matrices of a batch stored back to back;
  *   b_nk == 0: B_b is [K x N];  b_nk != 0: B_b is [N x K] (the data-gradient layout).  K and N multiples of 4. */
 int rn_gemm_batched(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, int b_nk, rn_stream_t stream);
+/* The merged backward products of such a layer (what rn_conv3x3_winograd_bwd launches between its transforms), exposed
+ * for measurement (bench.py times the head-tower instance: the largest kernel of the training step): ONE launch with
+ * blocks of two kinds -- the data-gradient products Cd_b [M x Nd] = Ad_b [M x Kd] * Bd_b^T (Bd_b stored [Nd x Kd]) and
+ * the split partial products of the weight gradient Aw_b^T [Kw x M] * Bw_b [M x Nw], left in `workspace` as *nsplit
+ * slabs (rn_winograd_bwd_products_workspace bytes). */
+size_t rn_winograd_bwd_products_workspace(int M, int Kw, int Nw, int nbatch);
+int rn_winograd_bwd_products(const float* Ad, const float* Bd, float* Cd, int M, int Kd, int Nd, const float* Aw,
+                             const float* Bw, int Kw, int Nw, int nbatch, void* workspace, size_t workspace_bytes,
+                             int* nsplit, rn_stream_t stream);
 /* Weight gradient of the same convolution in the Winograd domain: dU_xi = sum over tiles of
  * (B^T d B)_xi^T (A dY A^T)_xi as (tile+2)^2 batched GEMMs with the reduction split across blocks (fixed-order
  * sum), then dw[3,3,cin,cout] (+)= G^T dU G.  Segments: x, dy, n, h, w. */
@@ -420,14 +429,22 @@ int rn_decode_boxes(const float* reg, const float* anchor_sizes, float* boxes, i
                     rn_stream_t stream);
 
 typedef struct rn_det_level {
-  const float* prob;  /* [n, rows_per_image, C] class probabilities (post-sigmoid) */
+  const void* prob;   /* [n, rows_per_image, C] class probabilities (post-sigmoid), fp32 or fp16 (prob_f16) */
   const float* boxes; /* [n, rows_per_image, 4] decoded corner boxes, or NULL: decode on the fly from the fields below */
   int64_t rows_per_image;
   /* boxes == NULL: only the rows that become candidates are decoded (utils.regression_postprocess arithmetic,
    * utils.py:100-117, same bits as rn_decode_boxes) -- ~1 % of the rows instead of a full pass over the level */
-  const float* regression;   /* [n, grid_h, grid_w, num_anchors, 4] raw network output */
+  const void* regression;    /* [n, grid_h, grid_w, num_anchors, 4] raw network output, fp32 or fp16 (regression_f16) */
   const float* anchor_sizes; /* [num_anchors, 2] normalised (h, w)                      */
   int32_t grid_h, grid_w, num_anchors;
+  /* BASELINE configs[4] (fp16 inference): the maps stay in the storage type the net wrote them in -- 2 bytes per
+   * element through the scan instead of 4; all arithmetic (max, threshold, decode, IoU) is fp32 on the exact values. */
+  int32_t prob_f16;        /* != 0: prob holds fp16                                                                */
+  int32_t regression_f16;  /* != 0: regression holds fp16                                                           */
+  /* != 0: prob holds the class LOGITS (classification.unscaled); the scan applies the sigmoid of train.py:74 /
+   * utils.py:246 element by element on the fly (same expression as rn_act_fwd(RN_ACT_SIGMOID), so fp32 results
+   * equal sigmoid-then-scan bit for bit) -- the probability map is never written or re-read */
+  int32_t prob_is_logit;
 } rn_det_level;
 
 typedef struct rn_det_params {

@@ -95,7 +95,8 @@ class LossSeg(C.Structure):
 class DetLevel(C.Structure):
     _fields_ = [("prob", C.c_void_p), ("boxes", C.c_void_p), ("rows_per_image", C.c_int64),
                 ("regression", C.c_void_p), ("anchor_sizes", C.c_void_p),
-                ("grid_h", C.c_int32), ("grid_w", C.c_int32), ("num_anchors", C.c_int32)]
+                ("grid_h", C.c_int32), ("grid_w", C.c_int32), ("num_anchors", C.c_int32),
+                ("prob_f16", C.c_int32), ("regression_f16", C.c_int32), ("prob_is_logit", C.c_int32)]
 
 
 class DetParams(C.Structure):
@@ -113,7 +114,7 @@ SYMBOLS = [
     "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes",
     "rn_conv3x3_winograd_bwd_workspace", "rn_conv3x3_winograd_bwd", "rn_flush_reductions", "rn_gemm_batched",
-    "rn_wino_gn_rows", "rn_conv3x3_winograd_gn", "rn_conv3x3_winograd_gn_bwd", "rn_reduce_rows", "rn_resize_bilinear_normalize",
+    "rn_winograd_bwd_products_workspace", "rn_winograd_bwd_products", "rn_wino_gn_rows", "rn_conv3x3_winograd_gn", "rn_conv3x3_winograd_gn_bwd", "rn_reduce_rows", "rn_resize_bilinear_normalize",
     "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad", "rn_depthwise_bwd",
     "rn_group_norm_sync_bytes", "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
@@ -140,7 +141,8 @@ def lib():
                      "rn_loss_workspace", "rn_detect_workspace", "rn_optimizer_workspace",
                      "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace", "rn_conv3x3_winograd_workspace", "rn_conv2d_fwd_workspace",
                      "rn_conv2d_dgrad_workspace",
-                     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_bwd_workspace", "rn_wino_gn_rows"):
+                     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_bwd_workspace", "rn_wino_gn_rows",
+                     "rn_winograd_bwd_products_workspace"):
             getattr(L, name).restype = C.c_size_t
         L.rn_optimizer_workspace.argtypes = [C.c_int64]
         L.rn_depthwise_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
@@ -172,6 +174,9 @@ def lib():
         L.rn_conv3x3_winograd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rn_wino_gn_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.rn_winograd_bwd_products_workspace.argtypes = [C.c_int] * 4
+        L.rn_winograd_bwd_products.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_int] * 3 + \
+                                              [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_conv3x3_winograd_gn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rn_conv3x3_winograd_gn_bwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -8,9 +8,12 @@
 //   1. scan   : one wave per anchor row: max / first-arg-max over the C class probabilities
 //               (coalesced row reads, HBM-bound: this is where the bytes are), per-wave counts
 //   2. offsets: exclusive scan of the per-wave counts (order-preserving compaction)
-//   3. emit   : candidates (box, score, class, image, anchor) + 64-bit key
-//               (image*C+class) << 32 | ~score_bits   in anchor order
-//   4. sort   : stable LSD radix sort of (key, index) pairs (rocPRIM device primitive)
+//   3. emit   : candidates (box, score, class, image, anchor) in anchor order, and a count per (image, class) segment
+//   4. sort   : hand-written, in two steps: (a) the candidates are dropped into their segment's slot range (exclusive scan
+//               of the segment counts; the slot inside the range comes from an atomic counter -- any order), as 64-bit
+//               keys ~score_bits << 32 | candidate position; (b) one block per segment sorts its keys with a bitonic
+//               network in LDS (all-ascending formulation, so ragged lengths need no padding values).  The key orders by
+//               score descending, then by lower anchor position: the result does not depend on the order of step (a)
 //               => segments (image, class), score descending, ties by lower anchor index
 //   5. nms    : one wave per (image, class) segment, exact greedy semantics: 64 candidates at
 //               a time are tested against the kept list (LDS) in parallel, then resolved in
@@ -18,8 +21,6 @@
 //   6. gather : kept boxes of all segments, (image, class)-major = the reference's output order
 #include <cstring>
 #include <string.h>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "rn_common.h"
 
@@ -29,8 +30,9 @@ constexpr int T = 256;
 constexpr int MAXL = 8;
 
 struct DetLevel {
-  const float* prob; const float* boxes; int64_t rows; int64_t row_off; int wave_off;
-  const float* reg; const float* anch; int h, w, A;  // boxes == nullptr: decode candidates from the raw regression
+  const void* prob; const float* boxes; int64_t rows; int64_t row_off; int wave_off;
+  const void* reg; const float* anch; int h, w, A;  // boxes == nullptr: decode candidates from the raw regression
+  int half_prob, half_reg, logit;
 };
 struct DetArgs {
   DetLevel lv[MAXL];
@@ -41,7 +43,7 @@ struct DetArgs {
   int waves_per_image;
   // workspace
   float* row_score; int32_t* row_class; int32_t* wave_count; int32_t* wave_off;
-  uint64_t* keys_in; uint64_t* keys_out; uint32_t* vals_in; uint32_t* vals_out;
+  uint64_t* keys; uint32_t* vals_out; int32_t* seg_count; int32_t* seg_fill;
   float* cand_box; float* cand_score; int32_t* cand_class; int32_t* cand_image; int64_t* cand_anchor;
   int32_t* seg_start; int32_t* seg_keep; int32_t* seg_off; int32_t* keep_idx;
   // outputs
@@ -62,19 +64,46 @@ __device__ __forceinline__ void locate_wave(const DetArgs& a, int64_t wid, int* 
 // pass, 2 shuffle steps to combine; first index wins ties (tf.argmax).  C % 4 == 0 fast path.
 // per-row (max, lowest arg-max) of the wave's (up to) 64 rows of C = 4 * C4 probabilities: 4 lanes per row, 16 rows per
 // pass, Q float4 chunks per lane; lane l ends up with row l's result
-template <int Q>
-__device__ __forceinline__ void scan_rows_unrolled(const float* __restrict__ base, int C, int nrow, int lane, float* out_s, int* out_c) {
-  const int sub = lane & 3, rsel = lane >> 2, C4 = C >> 2;
-  float4 v[4][Q];
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float to_prob(float z, bool logit) { return logit ? 1.f / (1.f + __expf(-z)) : z; }
+
+// V = elements per 16-byte load: 4 (fp32) or 8 (fp16)
+template <bool HALF>
+struct Chunk;
+template <>
+struct Chunk<false> {
+  static constexpr int V = 4;
+  float e[4];
+  __device__ __forceinline__ void load(const void* row, int ci) {
+    const float4 t = reinterpret_cast<const float4*>(row)[ci];
+    e[0] = t.x; e[1] = t.y; e[2] = t.z; e[3] = t.w;
+  }
+};
+template <>
+struct Chunk<true> {
+  static constexpr int V = 8;
+  float e[8];
+  __device__ __forceinline__ void load(const void* row, int ci) {
+    const half8 t = reinterpret_cast<const half8*>(row)[ci];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = (float)t[i];
+  }
+};
+
+template <int Q, bool HALF, bool LOGIT>
+__device__ __forceinline__ void scan_rows_unrolled(const void* __restrict__ base, int C, int nrow, int lane, float* out_s, int* out_c) {
+  constexpr int V = Chunk<HALF>::V, ESZ = HALF ? 2 : 4;
+  const int sub = lane & 3, rsel = lane >> 2, CV = C / V;
+  Chunk<HALF> v[4][Q];
   int cc[Q];
 #pragma unroll
-  for (int q = 0; q < Q; ++q) cc[q] = min(sub + 4 * q, C4 - 1);
+  for (int q = 0; q < Q; ++q) cc[q] = min(sub + 4 * q, CV - 1);
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int r = min(pass * 16 + rsel, nrow - 1);
-    const float4* row = reinterpret_cast<const float4*>(base + (size_t)r * C);
+    const void* row = reinterpret_cast<const char*>(base) + (size_t)r * C * ESZ;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) v[pass][q] = row[cc[q]];
+    for (int q = 0; q < Q; ++q) v[pass][q].load(row, cc[q]);
   }
   float my_s = 0.f; int my_c = 0;
 #pragma unroll
@@ -82,12 +111,12 @@ __device__ __forceinline__ void scan_rows_unrolled(const float* __restrict__ bas
     float best = -1e30f; int bi = 0x7fffffff;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {  // ascending chunk index per lane: strict > keeps the lowest index on ties
-      const int c = cc[q] * 4;
-      const float4 t = v[pass][q];
-      if (t.x > best) { best = t.x; bi = c; }
-      if (t.y > best) { best = t.y; bi = c + 1; }
-      if (t.z > best) { best = t.z; bi = c + 2; }
-      if (t.w > best) { best = t.w; bi = c + 3; }
+      const int c = cc[q] * V;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const float pv = to_prob(v[pass][q].e[i], LOGIT);
+        if (pv > best) { best = pv; bi = c + i; }
+      }
     }
 #pragma unroll
     for (int o = 1; o <= 2; o <<= 1) {
@@ -102,67 +131,34 @@ __device__ __forceinline__ void scan_rows_unrolled(const float* __restrict__ bas
   *out_s = my_s; *out_c = my_c;
 }
 
-__global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
-  const int64_t nw = (int64_t)a.n * a.waves_per_image;
-  if (wid >= nw) return;
-  int img, l; int64_t row0;
-  locate_wave(a, wid, &img, &l, &row0);
-  const DetLevel& lv = a.lv[l];
-  const int nrow = (int)((lv.rows - row0) < 64 ? (lv.rows - row0) : 64);
-  const float* base = lv.prob + ((size_t)img * lv.rows + row0) * a.C;
+template <bool HALF, bool LOGIT>
+__device__ __forceinline__ void scan_wave(const DetArgs& a, const DetLevel& lv, int img, int64_t row0, int nrow, int lane, float* out_s,
+                                          int* out_c) {
+  constexpr int V = Chunk<HALF>::V, ESZ = HALF ? 2 : 4;
+  const void* base = reinterpret_cast<const char*>(lv.prob) + ((size_t)img * lv.rows + row0) * a.C * ESZ;
   float my_s = 0.f; int my_c = 0;
-  const int q_per_lane = ((a.C >> 2) + 3) >> 2;  // float4 chunks per lane when 4 lanes share a row
-  if ((a.C & 3) == 0 && q_per_lane <= 8) {
+  const int q_per_lane = ((a.C / V) + 3) >> 2;  // 16-byte chunks per lane when 4 lanes share a row
+  if (a.C % V == 0 && q_per_lane <= 8) {
     // every load of the wave's 64 rows is issued before the first compare (clamped addresses: a duplicated chunk or row
     // cannot change a max / lowest-index arg-max), instead of one dependent load per loop iteration
     switch (q_per_lane) {
-      case 1: scan_rows_unrolled<1>(base, a.C, nrow, lane, &my_s, &my_c); break;
-      case 2: scan_rows_unrolled<2>(base, a.C, nrow, lane, &my_s, &my_c); break;
-      case 3: scan_rows_unrolled<3>(base, a.C, nrow, lane, &my_s, &my_c); break;
-      case 4: scan_rows_unrolled<4>(base, a.C, nrow, lane, &my_s, &my_c); break;
-      case 5: scan_rows_unrolled<5>(base, a.C, nrow, lane, &my_s, &my_c); break;
-      case 6: scan_rows_unrolled<6>(base, a.C, nrow, lane, &my_s, &my_c); break;
-      case 7: scan_rows_unrolled<7>(base, a.C, nrow, lane, &my_s, &my_c); break;
-      default: scan_rows_unrolled<8>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 1: scan_rows_unrolled<1, HALF, LOGIT>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 2: scan_rows_unrolled<2, HALF, LOGIT>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 3: scan_rows_unrolled<3, HALF, LOGIT>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 4: scan_rows_unrolled<4, HALF, LOGIT>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 5: scan_rows_unrolled<5, HALF, LOGIT>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 6: scan_rows_unrolled<6, HALF, LOGIT>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      case 7: scan_rows_unrolled<7, HALF, LOGIT>(base, a.C, nrow, lane, &my_s, &my_c); break;
+      default: scan_rows_unrolled<8, HALF, LOGIT>(base, a.C, nrow, lane, &my_s, &my_c); break;
     }
-  } else if ((a.C & 3) == 0) {
-    const int sub = lane & 3, rsel = lane >> 2;  // 4 lanes per row, 16 rows per pass
-    const int C4 = a.C >> 2;
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int r = pass * 16 + rsel;
-      float best = -1e30f; int bi = 0x7fffffff;
-      if (r < nrow) {
-        const float4* row = reinterpret_cast<const float4*>(base + (size_t)r * a.C);
-        for (int c4 = sub; c4 < C4; c4 += 4) {
-          const float4 v = row[c4];
-          const int c = c4 * 4;
-          if (v.x > best) { best = v.x; bi = c; }
-          if (v.y > best) { best = v.y; bi = c + 1; }
-          if (v.z > best) { best = v.z; bi = c + 2; }
-          if (v.w > best) { best = v.w; bi = c + 3; }
-        }
-      }
-#pragma unroll
-      for (int o = 1; o <= 2; o <<= 1) {
-        const float ob = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-      }
-      // row r's result sits in its 4 lanes; hand it to lane r
-      const float sv = __shfl(best, (lane & 15) * 4, 64);
-      const int sc = __shfl(bi, (lane & 15) * 4, 64);
-      if ((lane >> 4) == pass) { my_s = sv; my_c = sc; }
-    }
-  } else {
+  } else {   // any C: one row at a time, lanes stride over the classes
     for (int i = 0; i < nrow; ++i) {
-      const float* row = base + (size_t)i * a.C;
       float best = -1e30f; int bi = 0x7fffffff;
       for (int c = lane; c < a.C; c += 64) {
-        const float v = row[c];
-        if (v > best) { best = v; bi = c; }   // ascending c per lane: keeps the lowest index on ties
+        const size_t e = (size_t)i * a.C + c;
+        const float raw = HALF ? (float)reinterpret_cast<const _Float16*>(base)[e] : reinterpret_cast<const float*>(base)[e];
+        const float pv = to_prob(raw, LOGIT);
+        if (pv > best) { best = pv; bi = c; }   // ascending c per lane: keeps the lowest index on ties
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
@@ -172,6 +168,26 @@ __global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
       }
       if (lane == i) { my_s = best; my_c = bi; }
     }
+  }
+  *out_s = my_s; *out_c = my_c;
+}
+
+__global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
+  const int64_t nw = (int64_t)a.n * a.waves_per_image;
+  if (wid >= nw) return;
+  int img, l; int64_t row0;
+  locate_wave(a, wid, &img, &l, &row0);
+  const DetLevel& lv = a.lv[l];
+  const int nrow = (int)((lv.rows - row0) < 64 ? (lv.rows - row0) : 64);
+  float my_s = 0.f; int my_c = 0;
+  if (lv.half_prob) {
+    if (lv.logit) scan_wave<true, true>(a, lv, img, row0, nrow, lane, &my_s, &my_c);
+    else scan_wave<true, false>(a, lv, img, row0, nrow, lane, &my_s, &my_c);
+  } else {
+    if (lv.logit) scan_wave<false, true>(a, lv, img, row0, nrow, lane, &my_s, &my_c);
+    else scan_wave<false, false>(a, lv, img, row0, nrow, lane, &my_s, &my_c);
   }
   const bool flag = lane < nrow && my_s > a.score_thr;
   const int64_t g = (int64_t)img * a.rows_per_image + lv.row_off + row0 + lane;
@@ -230,6 +246,7 @@ __global__ __launch_bounds__(1024) void det_offsets_chunk_kernel(const DetArgs a
 
 __global__ __launch_bounds__(1024) void det_offsets_kernel(const DetArgs a) {
   __shared__ int base[1024];
+  for (int k = threadIdx.x; k < a.n * a.C; k += 1024) a.seg_count[k] = 0;   // the emit pass counts candidates per segment
   const int64_t nw = (int64_t)a.n * a.waves_per_image;
   const int nchunk = (int)((nw + 1023) / 1024);
   if (nchunk <= 1024) {
@@ -318,36 +335,101 @@ __global__ __launch_bounds__(T) void det_emit_kernel(const DetArgs a) {
     const int an = (int)(q % lv.A); q /= lv.A;
     const int x_ = (int)(q % lv.w);
     const int y_ = (int)(q / lv.w);
-    const float4 r = *reinterpret_cast<const float4*>(lv.reg + ((size_t)img * lv.rows + row0 + lane) * 4);
+    const size_t ri = ((size_t)img * lv.rows + row0 + lane) * 4;
+    float4 r;
+    if (lv.half_reg) {
+      const rn::rn_half4 h = *reinterpret_cast<const rn::rn_half4*>(reinterpret_cast<const _Float16*>(lv.reg) + ri);
+      r = make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+    } else {
+      r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(lv.reg) + ri);
+    }
     b = decode_one(r, lv.anch[an * 2], lv.anch[an * 2 + 1], y_, x_, lv.h, lv.w);
   }
   *reinterpret_cast<float4*>(a.cand_box + pos * 4) = b;
   a.cand_score[pos] = s; a.cand_class[pos] = c; a.cand_image[pos] = img; a.cand_anchor[pos] = in_img;
-  const uint32_t sb = __float_as_uint(s);  // s > 0: bit pattern is monotone in the value
-  a.keys_in[pos] = ((uint64_t)(uint32_t)(img * a.C + c) << 32) | (uint64_t)(0xFFFFFFFFu - sb);
-  a.vals_in[pos] = (uint32_t)pos;
+  atomicAdd(&a.seg_count[img * a.C + c], 1);   // integer count: the same whatever the order of arrival
 }
 
-__global__ void det_pad_kernel(const DetArgs a) {
-  const int64_t ncand = a.counts[0] < a.cap ? a.counts[0] : a.cap;
-  for (int64_t i = ncand + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.cap; i += (int64_t)gridDim.x * blockDim.x) {
-    a.keys_in[i] = ~0ull;
-    a.vals_in[i] = 0xFFFFFFFFu;
-  }
+// order-preserving map of ANY float onto unsigned integers (scores handed to rn_nms_classwise may be <= 0)
+__device__ __forceinline__ uint32_t float_order(float s) {
+  const uint32_t sb = __float_as_uint(s);
+  return (sb & 0x80000000u) ? ~sb : (sb | 0x80000000u);
 }
 
-// ---- segment starts: first sorted position whose segment id >= k, for k in [0, n*C]
-__global__ void det_segments_kernel(const DetArgs a) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- 4a. exclusive scan of the per-segment counts -> seg_start[0..nseg] (one 1024-thread block; nseg = n * C)
+__global__ __launch_bounds__(1024) void det_seg_scan_kernel(const DetArgs a) {
   const int nseg = a.n * a.C;
-  if (k > nseg) return;
-  const int64_t ncand = a.counts[0] < a.cap ? a.counts[0] : a.cap;
-  int64_t lo = 0, hi = ncand;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if ((uint32_t)(a.keys_out[mid] >> 32) < (uint32_t)k) lo = mid + 1; else hi = mid;
+  const int per = (nseg + 1023) / 1024;
+  const int b = threadIdx.x * per, e = min(b + per, nseg);
+  int local = 0;
+  for (int k = b; k < e; ++k) local += a.seg_count[k];
+  int total;
+  int run = block_exclusive_scan_1024(local, &total);
+  for (int k = b; k < e; ++k) {
+    a.seg_start[k] = run;
+    run += a.seg_count[k];
+    a.seg_fill[k] = 0;
   }
-  a.seg_start[k] = (int)lo;
+  if (threadIdx.x == 0) a.seg_start[nseg] = total;
+}
+
+// ---- 4b. every candidate takes a slot of its segment's range (the order inside the range is irrelevant: 4c sorts it)
+__global__ void det_seg_scatter_kernel(const DetArgs a) {
+  const int64_t ncand = a.counts[0] < a.cap ? a.counts[0] : a.cap;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncand; i += (int64_t)gridDim.x * blockDim.x) {
+    const int seg = a.cand_image[i] * a.C + a.cand_class[i];
+    const int slot = a.seg_start[seg] + atomicAdd(&a.seg_fill[seg], 1);
+    a.keys[slot] = ((uint64_t)(0xFFFFFFFFu - float_order(a.cand_score[i])) << 32) | (uint64_t)(uint32_t)i;
+  }
+}
+
+// ---- 4c. one block per segment: ascending bitonic sort of its 64-bit keys = score descending, then lower candidate
+// position (= lower anchor index) first.  All-ascending formulation (each merge starts with the "flip" step i <-> i^(k-1),
+// then half-cleaners i <-> i^j): elements only ever move towards the end when they are larger, so positions >= m behave as
+// +infinity without being stored -- ragged lengths need no padding.  Up to SORT_LDS keys are sorted in LDS, longer
+// segments in place in global memory (same network, block-wide barriers; a single-class NMS over a whole image).
+constexpr int SORT_T = 256, SORT_LDS = 8192;
+template <typename P>
+__device__ __forceinline__ void bitonic_ascending(P keys, int m) {
+  int p2 = 1;
+  while (p2 < m) p2 <<= 1;
+  for (int k = 2; k <= p2; k <<= 1) {
+    for (int i = threadIdx.x; i < p2; i += SORT_T) {
+      const int l = i ^ (k - 1);
+      if (l > i && l < m) {
+        const uint64_t x = keys[i], y = keys[l];
+        if (x > y) { keys[i] = y; keys[l] = x; }
+      }
+    }
+    __syncthreads();
+    for (int j = k >> 2; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < p2; i += SORT_T) {
+        const int l = i ^ j;
+        if (l > i && l < m) {
+          const uint64_t x = keys[i], y = keys[l];
+          if (x > y) { keys[i] = y; keys[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+__global__ __launch_bounds__(SORT_T) void det_seg_sort_kernel(const DetArgs a) {
+  __shared__ uint64_t sk[SORT_LDS];
+  const int k = blockIdx.x;
+  const int s0 = a.seg_start[k], m = a.seg_start[k + 1] - s0;
+  if (m <= 0) return;
+  uint64_t* g = a.keys + s0;
+  if (m <= SORT_LDS) {
+    for (int i = threadIdx.x; i < m; i += SORT_T) sk[i] = g[i];
+    __syncthreads();
+    bitonic_ascending(sk, m);
+    for (int i = threadIdx.x; i < m; i += SORT_T) a.vals_out[s0 + i] = (uint32_t)sk[i];
+  } else {
+    __syncthreads();
+    bitonic_ascending(g, m);   // same block wrote and reads these addresses: __syncthreads orders them
+    for (int i = threadIdx.x; i < m; i += SORT_T) a.vals_out[s0 + i] = (uint32_t)g[i];
+  }
 }
 
 // [TF-sem] IoU of TF's NonMaxSuppression kernel (corner normalisation, area<=0 -> 0, clamped extents)
@@ -452,7 +534,7 @@ __global__ void decode_kernel(const float* __restrict__ reg, const float* __rest
   }
 }
 
-struct WsLayout { size_t off[20]; size_t total; size_t sort_bytes; };
+struct WsLayout { size_t off[20]; size_t total; };
 
 int plan(const rn_det_level* levels, int nlevels, const rn_det_params* p, DetArgs* a, WsLayout* L) {
   RN_CHECK_ARG(levels && p && nlevels >= 1 && nlevels <= MAXL, "detect: bad levels");
@@ -467,6 +549,8 @@ int plan(const rn_det_level* levels, int nlevels, const rn_det_params* p, DetArg
     a->lv[l].prob = levels[l].prob; a->lv[l].boxes = levels[l].boxes; a->lv[l].rows = levels[l].rows_per_image;
     a->lv[l].reg = levels[l].regression; a->lv[l].anch = levels[l].anchor_sizes;
     a->lv[l].h = levels[l].grid_h; a->lv[l].w = levels[l].grid_w; a->lv[l].A = levels[l].num_anchors;
+    a->lv[l].half_prob = levels[l].prob_f16 ? 1 : 0; a->lv[l].half_reg = levels[l].regression_f16 ? 1 : 0;
+    a->lv[l].logit = levels[l].prob_is_logit ? 1 : 0;
     if (!levels[l].boxes && levels[l].regression)
       RN_CHECK_ARG(levels[l].anchor_sizes && levels[l].grid_h >= 1 && levels[l].grid_w >= 1 && levels[l].num_anchors >= 1 &&
                        (int64_t)levels[l].grid_h * levels[l].grid_w * levels[l].num_anchors == levels[l].rows_per_image,
@@ -479,18 +563,13 @@ int plan(const rn_det_level* levels, int nlevels, const rn_det_params* p, DetArg
   a->rows_per_image = rows; a->waves_per_image = waves;
   const int64_t nrows = rows * p->n, nw = (int64_t)waves * p->n, cap = p->max_candidates;
   const int64_t nseg = (int64_t)p->n * p->num_classes;
-  size_t sort_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                            (uint32_t*)nullptr, (size_t)cap, 0, 64, (hipStream_t)0);
-  L->sort_bytes = sort_bytes;
-  const size_t sizes[18] = {
+  const size_t sizes[17] = {
       (size_t)nrows * 4, (size_t)nrows * 4, (size_t)nw * 4, (size_t)nw * 4,            // row_score,row_class,wave_count,wave_off
-      (size_t)cap * 8, (size_t)cap * 8, (size_t)cap * 4, (size_t)cap * 4,              // keys in/out, vals in/out
+      (size_t)cap * 8, (size_t)cap * 4, (size_t)nseg * 4, (size_t)nseg * 4,            // keys, vals_out, seg_count, seg_fill
       (size_t)cap * 16, (size_t)cap * 4, (size_t)cap * 4, (size_t)cap * 4, (size_t)cap * 8,  // cand box,score,class,image,anchor
-      (size_t)(nseg + 1) * 4, (size_t)nseg * 4, (size_t)nseg * 4, (size_t)nseg * p->max_per_class * 4,  // seg_*, keep_idx
-      sort_bytes};
+      (size_t)(nseg + 1) * 4, (size_t)nseg * 4, (size_t)nseg * 4, (size_t)nseg * p->max_per_class * 4};  // seg_*, keep_idx
   size_t o = 0;
-  for (int i = 0; i < 18; ++i) { L->off[i] = o; o += rn::align_up(sizes[i], 256); }
+  for (int i = 0; i < 17; ++i) { L->off[i] = o; o += rn::align_up(sizes[i], 256); }
   L->total = o;
   return RN_OK;
 }
@@ -499,8 +578,8 @@ void bind(DetArgs* a, const WsLayout& L, void* ws) {
   char* b = (char*)ws;
   a->row_score = (float*)(b + L.off[0]); a->row_class = (int32_t*)(b + L.off[1]);
   a->wave_count = (int32_t*)(b + L.off[2]); a->wave_off = (int32_t*)(b + L.off[3]);
-  a->keys_in = (uint64_t*)(b + L.off[4]); a->keys_out = (uint64_t*)(b + L.off[5]);
-  a->vals_in = (uint32_t*)(b + L.off[6]); a->vals_out = (uint32_t*)(b + L.off[7]);
+  a->keys = (uint64_t*)(b + L.off[4]); a->vals_out = (uint32_t*)(b + L.off[5]);
+  a->seg_count = (int32_t*)(b + L.off[6]); a->seg_fill = (int32_t*)(b + L.off[7]);
   a->cand_box = (float*)(b + L.off[8]); a->cand_score = (float*)(b + L.off[9]);
   a->cand_class = (int32_t*)(b + L.off[10]); a->cand_image = (int32_t*)(b + L.off[11]);
   a->cand_anchor = (int64_t*)(b + L.off[12]);
@@ -540,39 +619,24 @@ __global__ void det_copy_candidates_kernel(const DetArgs a) {
   if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[1] = ncand;
 }
 
-// keys for candidates handed in as arrays (rn_nms_classwise)
-__global__ void det_keys_from_arrays_kernel(const DetArgs a, const int64_t* count_dev) {
+// candidates handed in as arrays (rn_nms_classwise): count them per segment
+__global__ void det_zero_seg_kernel(const DetArgs a) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < a.n * a.C; k += gridDim.x * blockDim.x) a.seg_count[k] = 0;
+}
+__global__ void det_count_arrays_kernel(const DetArgs a, const int64_t* count_dev) {
   const int64_t ncand = count_dev[0] < a.cap ? count_dev[0] : a.cap;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.cap; i += (int64_t)gridDim.x * blockDim.x) {
-    if (i < ncand) {
-      const uint32_t sb = __float_as_uint(a.cand_score[i]);
-      // order-preserving map of ANY float (scores may be <= 0 here): flip sign bit / all bits
-      const uint32_t ord = (sb & 0x80000000u) ? ~sb : (sb | 0x80000000u);
-      a.keys_in[i] = ((uint64_t)(uint32_t)(a.cand_image[i] * a.C + a.cand_class[i]) << 32) | (uint64_t)(0xFFFFFFFFu - ord);
-      a.vals_in[i] = (uint32_t)i;
-      a.cand_anchor[i] = i;
-    } else {
-      a.keys_in[i] = ~0ull;
-      a.vals_in[i] = 0xFFFFFFFFu;
-    }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncand; i += (int64_t)gridDim.x * blockDim.x) {
+    atomicAdd(&a.seg_count[a.cand_image[i] * a.C + a.cand_class[i]], 1);
+    a.cand_anchor[i] = i;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[0] = count_dev[0];
 }
 
 int sort_and_suppress(DetArgs& a, const WsLayout& L, void* workspace, hipStream_t st) {
-  size_t sort_bytes = L.sort_bytes;
-  // key = (image * C + class) << 32 | ~score bits: only the bits that can differ are sorted.  The padding keys are all
-  // ones, so with nb >= bits(n * C) their truncated segment id still exceeds every real one and they stay at the end.
-  int nb = 1;
-  while (((1ll << nb) - 1) < (long long)a.n * a.C) ++nb;
-  hipError_t e = rocprim::radix_sort_pairs((char*)workspace + L.off[17], sort_bytes, a.keys_in, a.keys_out, a.vals_in,
-                                           a.vals_out, (size_t)a.cap, 0, 32 + nb, st);
-  if (e != hipSuccess) {
-    rn::set_error("detect: radix sort failed: %s", hipGetErrorString(e));
-    return RN_EHIP;
-  }
   const int nseg = a.n * a.C;
-  hipLaunchKernelGGL(det_segments_kernel, dim3(rn::ceil_div(nseg + 1, 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(det_seg_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(det_seg_scatter_kernel, dim3(256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(det_seg_sort_kernel, dim3(nseg), dim3(SORT_T), 0, st, a);
   hipLaunchKernelGGL(det_nms_kernel, dim3(nseg), dim3(64), 0, st, a);
   hipLaunchKernelGGL(det_keep_offsets_kernel, dim3(1), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(det_gather_kernel, dim3(nseg), dim3(64), 0, st, a);
@@ -608,8 +672,6 @@ int run_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, 
     RN_LAUNCH_CHECK();
     return RN_OK;
   }
-  hipLaunchKernelGGL(det_pad_kernel, dim3(256), dim3(256), 0, st, a);
-  RN_LAUNCH_CHECK();
   return sort_and_suppress(a, L, workspace, st);
 }
 }  // namespace
@@ -658,7 +720,8 @@ extern "C" int rn_nms_classwise(const float* boxes, const float* scores, const i
   a.out_boxes = out_boxes; a.out_scores = out_scores; a.out_class = out_class; a.out_image = out_image;
   a.out_anchor = out_index; a.counts = counts;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(det_keys_from_arrays_kernel, dim3(256), dim3(256), 0, st, a, count_dev);
+  hipLaunchKernelGGL(det_zero_seg_kernel, dim3(16), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(det_count_arrays_kernel, dim3(256), dim3(256), 0, st, a, count_dev);
   RN_LAUNCH_CHECK();
   return sort_and_suppress(a, L, workspace, st);
 }

@@ -550,6 +550,21 @@ extern "C" int rn_gemm_batched(const float* A, const float* B, float* C, int M, 
   return rn::launch_batched_gemm(A, B, C, M, K, N, nbatch, b_nk, (hipStream_t)stream);
 }
 
+// The merged backward products of a Winograd layer, exposed for measurement like rn_gemm_batched: ONE launch whose blocks
+// are of two kinds -- dgrad products Cd_b [M x Nd] = Ad_b [M x Kd] * Bd_b^T (Bd_b is [Nd x Kd]) and the split partial
+// products of the weight gradient dU_b = Aw_b^T [Kw x M] * Bw_b [M x Nw] (left in `workspace`, *nsplit partial slabs).
+extern "C" size_t rn_winograd_bwd_products_workspace(int M, int Kw, int Nw, int nbatch) {
+  return rn::batched_gemm_tn_workspace(M, Kw, Nw, nbatch);
+}
+extern "C" int rn_winograd_bwd_products(const float* Ad, const float* Bd, float* Cd, int M, int Kd, int Nd, const float* Aw,
+                                        const float* Bw, int Kw, int Nw, int nbatch, void* workspace, size_t workspace_bytes,
+                                        int* nsplit, rn_stream_t stream) {
+  RN_CHECK_ARG(Ad && Bd && Cd && Aw && Bw && workspace && nsplit && M >= 1 && nbatch >= 1, "winograd_bwd_products: bad argument");
+  RN_UNSUPPORTED(Kd % 4 || Nd % 4 || Kw % 4 || Nw % 4, "winograd_bwd_products: K / N must be multiples of 4");
+  return rn::launch_winograd_bwd_products(Ad, Bd, Cd, M, Kd, Nd, Aw, Bw, Kw, Nw, nbatch, workspace, workspace_bytes, (hipStream_t)stream,
+                                          nsplit);
+}
+
 // bytes of the two optional buffers a forward call can fill for its backward pass: the transformed input V
 // ([P][tiles][cin], reused by the weight gradient) and the transformed rotated kernel ([P][cin][cout], reused by the
 // data gradient)

@@ -20,12 +20,16 @@ import ops_f16
 # matrix cores (fp32 accumulate), GroupNorm statistics stay fp32; layers that must emit fp32 (the subnets'
 # output convs) say so with `f16_out_f32`.  Training is always fp32.
 INFERENCE_F16 = False
+# ... and what the subnets' output convs emit then: fp16 (BASELINE configs[4] as stated: the logits / box deltas leave the
+# net in fp16 and utils.detect_raw reads them as stored, 2 bytes per element) or fp32 (outputs='f32')
+F16_OUTPUTS_F32 = False
 
 
-def set_inference_dtype(name):
-    global INFERENCE_F16
-    assert name in ('f32', 'f16')
+def set_inference_dtype(name, outputs='f16'):
+    global INFERENCE_F16, F16_OUTPUTS_F32
+    assert name in ('f32', 'f16') and outputs in ('f32', 'f16')
     INFERENCE_F16 = (name == 'f16')
+    F16_OUTPUTS_F32 = (outputs == 'f32')
 
 
 # ------------------------------------------------------------------ activations
@@ -122,7 +126,7 @@ class Conv2D(torch.nn.Module):
         assert padding == 'same', "the reference only uses padding='same'"
         self.filters, self.kernel_size, self.strides = filters, kernel_size, strides
         self.groups = groups        # > 1: the `groups` parallel convs of a ResNeXt bottleneck as ONE grouped conv
-        self.f16_out_f32 = False    # fp16 inference: emit fp32 (set on the subnets' output convs)
+        self.f16_out_f32 = False    # fp16 inference: may emit fp32 (set on the subnets' output convs; layers.F16_OUTPUTS_F32)
         self.use_bias = use_bias
         self.kernel_initializer = kernel_initializer or VarianceScaling(1.0)
         self.bias_initializer = bias_initializer or Constant(0.0)
@@ -147,7 +151,8 @@ class Conv2D(torch.nn.Module):
         if self.weight is None:
             self.build(first.shape[3], first.device)
         if first.dtype == torch.float16:
-            return ops_f16.conv2d(input, self.weight, self.bias, self.strides, self.groups, out_f32=self.f16_out_f32)
+            return ops_f16.conv2d(input, self.weight, self.bias, self.strides, self.groups,
+                                  out_f32=self.f16_out_f32 and F16_OUTPUTS_F32)
         return ops.conv2d(input, self.weight, self.bias, self.strides, self.groups)
 
 

@@ -88,7 +88,7 @@ class _Subnet(Model):
         self.out_conv = L.Conv2D(num_anchors * last_dim, 3, 1, padding='same', kernel_initializer=kernel_initializer,
                                  kernel_regularizer=kernel_regularizer, bias_initializer=bias_initializer,
                                  in_channels=256)
-        self.out_conv.f16_out_f32 = True     # fp16 inference: logits / box deltas leave the net in fp32
+        self.out_conv.f16_out_f32 = True     # fp16 inference: logits / box deltas leave the net in fp16, or fp32 on request
 
     def _reshape(self, t):
         return t.reshape(t.shape[0], t.shape[1], t.shape[2], self.num_anchors, self.last_dim)

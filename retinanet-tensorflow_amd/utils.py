@@ -88,16 +88,26 @@ def classmap_decode(classmap, name='classmap_decoder'):
     return ClassmapDecoded(fg_mask=classmap.max(-1).values > 0.5)
 
 
-def _det_call(fn_name, probs, boxes, num_classes, n, score_threshold, iou_threshold, max_per_class, capacity, raw=None):
+def _fp_ptr(t):
+    """(pointer, is_fp16) of an fp32 / fp16 device tensor."""
+    if t.dtype not in (torch.float32, torch.float16):
+        raise _rn.RnError("detect: fp32 or fp16 maps (got %s)" % t.dtype)
+    return _rn.ptr(t), 1 if t.dtype == torch.float16 else 0
+
+
+def _det_call(fn_name, probs, boxes, num_classes, n, score_threshold, iou_threshold, max_per_class, capacity, raw=None,
+              logits=False):
     """probs/boxes: lists over levels of [n, rows, C] / [n, rows, 4] tensors; or boxes=None and raw = list over levels of
-    (regression [n,H,W,A,4], anchor tensor [A,2]): candidates are decoded on the fly (see rn_det_level)."""
+    (regression [n,H,W,A,4], anchor tensor [A,2]): candidates are decoded on the fly (see rn_det_level).  probs and raw
+    regressions may be fp16 (read as stored); logits=True: `probs` are class logits, the sigmoid runs inside the scan."""
     L = _rn.lib()
     dev = probs[0].device
     levels = (_rn.DetLevel * len(probs))()
     total_rows = 0
     for i, p in enumerate(probs):
         assert p.shape[0] == n and p.shape[2] == num_classes
-        levels[i].prob = _rn.f32(p)
+        levels[i].prob, levels[i].prob_f16 = _fp_ptr(p)
+        levels[i].prob_is_logit = 1 if logits else 0
         levels[i].rows_per_image = p.shape[1]
         if raw is None:
             assert boxes[i].shape[0] == n and p.shape[1] == boxes[i].shape[1]
@@ -107,7 +117,7 @@ def _det_call(fn_name, probs, boxes, num_classes, n, score_threshold, iou_thresh
             assert reg.dim() == 5 and reg.shape[0] == n and reg.shape[4] == 4 and reg.shape[3] == anc.shape[0]
             assert reg.shape[1] * reg.shape[2] * reg.shape[3] == p.shape[1]
             levels[i].boxes = None
-            levels[i].regression = _rn.f32(reg)
+            levels[i].regression, levels[i].regression_f16 = _fp_ptr(reg)
             levels[i].anchor_sizes = _rn.f32(anc)
             levels[i].grid_h, levels[i].grid_w, levels[i].num_anchors = reg.shape[1], reg.shape[2], reg.shape[3]
         total_rows += p.shape[1]
@@ -210,17 +220,19 @@ def detect(class_probs, regressions_postprocessed, num_classes, score_threshold=
 
 
 def detect_raw(class_probs, regressions, anchor_sizes, num_classes, score_threshold=0.5, iou_threshold=0.5,
-               max_per_class=NMS_MAX_OUTPUT_SIZE, capacity=None, return_raw=False):
+               max_per_class=NMS_MAX_OUTPUT_SIZE, capacity=None, return_raw=False, logits=False):
     """`detect` without the full-map decode: dicts P3..P7 of [N,H,W,A,C] probabilities, RAW regressions [N,H,W,A,4] and
     normalised anchor sizes (`Level.normalized_anchor_sizes`).  Only the rows that pass the score threshold are decoded
-    (same arithmetic as `regression_postprocess`, same results as `detect(probs, regression_postprocess(...))`)."""
+    (same arithmetic as `regression_postprocess`, same results as `detect(probs, regression_postprocess(...))`).
+    The maps may be fp16 (BASELINE configs[4]: read as stored, 2 bytes per element).  logits=True: `class_probs` holds the
+    net's class LOGITS and the sigmoid (train.py:74) runs inside the scan -- no probability map is written."""
     keys = list(class_probs.keys())
     n = class_probs[keys[0]].shape[0]
     probs = [class_probs[k].reshape(n, -1, num_classes).contiguous() for k in keys]
     dev = probs[0].device
-    raw = [(regressions[k].contiguous().float(), _anchor_tensor(anchor_sizes[k], dev)) for k in keys]
+    raw = [(regressions[k].contiguous(), _anchor_tensor(anchor_sizes[k], dev)) for k in keys]
     ob, os_, oc, oi, oa, counts, cap = _det_call('rn_detect', probs, None, num_classes, n, score_threshold, iou_threshold,
-                                                 max_per_class, capacity, raw=raw)
+                                                 max_per_class, capacity, raw=raw, logits=logits)
     if return_raw:
         return ob, os_, oc, oi, oa, counts
     cnt = counts.cpu().tolist()

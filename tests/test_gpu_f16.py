@@ -108,6 +108,8 @@ def test_resnext_fpn_fp16_inference_matches_fp32(dev):
         try:
             out16 = net(x.to(dev), training=False)
             feats16 = net.base.backbone(x.to(dev), training=False)
+            layers.set_inference_dtype('f16', outputs='f32')
+            assert net(x.to(dev), training=False)["classifications"]["P5"].dtype == torch.float32
         finally:
             layers.set_inference_dtype('f32')
     def rel_l2(a, b):
@@ -121,8 +123,9 @@ def test_resnext_fpn_fp16_inference_matches_fp32(dev):
         print(k, "rel L2", rel_l2(feats16[k].float(), feats32[k]))
     for k in ("P3", "P4", "P5", "P6", "P7"):
         a, b = out16["classifications"][k], ref32["classifications"][k]
-        assert a.dtype == torch.float32 and a.shape == b.shape          # logits leave the net in fp32
-        e = max(rel_l2(a - a.mean(), b - b.mean()), rel_l2(out16["regressions"][k], ref32["regressions"][k]))
+        assert a.dtype == torch.float16 and a.shape == b.shape          # logits leave the net in fp16 (configs[4]); fp32 on request
+        a = a.float()
+        e = max(rel_l2(a - a.mean(), b - b.mean()), rel_l2(out16["regressions"][k].float(), ref32["regressions"][k]))
         print(k, "rel L2", e)
         if k in ("P6", "P7"):
             # 2x2 / 1x1 maps at this input size: GroupNorm over a handful of values amplifies the fp16 rounding

@@ -1025,3 +1025,70 @@ def test_winograd_forward_keeps_buffers_only_when_training(dev):
     assert y3.grad_fn.wino_v is None and y3.grad_fn.wino_urot is not None
     with torch.no_grad():
         assert torch.equal(ops.conv2d(x, w, None, 1), y)
+
+
+def test_detect_fp16_maps_and_logits_in_the_scan(dev):
+    """BASELINE configs[4]: the class / box maps stay fp16 (2 bytes per element through the scan) and the sigmoid runs
+    inside the scan.  fp16 storage == the same values handed over as fp32, bit for bit; logits + fused sigmoid == sigmoid
+    kernel then scan, bit for bit; and the result equals the oracle on those probabilities."""
+    import levels, ops, utils
+    rng = np.random.default_rng(31)
+    n, c = 2, 80
+    lv = levels.build_levels()
+    size = (128, 160)
+    logits, regs, anchors = {}, {}, {}
+    for k in lv:
+        f = 2 ** int(k[1])
+        gh, gw = -(-size[0] // f), -(-size[1] // f)
+        logits[k] = (rng.standard_normal((n, gh, gw, 9, c)) * 2 - 3.5).astype(np.float16)      # ~1 % of the anchors above 0
+        regs[k] = (rng.standard_normal((n, gh, gw, 9, 4)) * 0.3).astype(np.float16)
+        anchors[k] = lv[k].normalized_anchor_sizes(size)
+    l16 = {k: _t(v, dev) for k, v in logits.items()}
+    r16 = {k: _t(v, dev) for k, v in regs.items()}
+    l32 = {k: v.float() for k, v in l16.items()}
+    r32 = {k: v.float() for k, v in r16.items()}
+    p32 = {k: ops.activation(v, 'sigmoid') for k, v in l32.items()}                 # the stand-alone sigmoid kernel
+    want = utils.detect_raw(p32, r32, anchors, c)
+    for got in (utils.detect_raw(l16, r16, anchors, c, logits=True),                 # fp16 storage, sigmoid in the scan
+                utils.detect_raw(l32, r32, anchors, c, logits=True),                 # fp32 storage, sigmoid in the scan
+                utils.detect_raw(l16, r32, anchors, c, logits=True)):
+        for i in range(n):
+            assert torch.equal(got[i].boxes, want[i].boxes) and torch.equal(got[i].scores, want[i].scores)
+            assert torch.equal(got[i].class_ids, want[i].class_ids)
+    p16 = {k: v.half() for k, v in p32.items()}                                     # fp16 probabilities (no logits)
+    a = utils.detect_raw(p16, r16, anchors, c)
+    b = utils.detect_raw({k: v.float() for k, v in p16.items()}, r32, anchors, c)
+    kept = 0
+    for i in range(n):
+        assert torch.equal(a[i].boxes, b[i].boxes) and torch.equal(a[i].scores, b[i].scores) and torch.equal(a[i].class_ids, b[i].class_ids)
+        dec = {k: utils.regression_postprocess(r32[k], anchors[k])[i].cpu().numpy() for k in lv}
+        parts = [utils_ref.boxes_decode(p32[k][i].cpu().numpy(), dec[k]) for k in lv]
+        exp = utils_ref.nms_classwise(utils_ref.merge_boxes_decoded(parts), c)
+        assert np.array_equal(want[i].boxes.cpu().numpy(), exp.boxes) and np.array_equal(want[i].class_ids.cpu().numpy(), exp.class_ids)
+        assert np.array_equal(want[i].scores.cpu().numpy(), exp.scores)
+        kept += len(exp.scores)
+    assert kept > 20
+    # a class count that is not a multiple of 8 takes the generic fp16 path
+    c2 = 5
+    lg = {k: _t((rng.standard_normal((1, 4, 4, 9, c2)) * 2 - 1).astype(np.float16), dev) for k in ("P3",)}
+    rg = {k: _t((rng.standard_normal((1, 4, 4, 9, 4)) * 0.3).astype(np.float16), dev) for k in ("P3",)}
+    an = {"P3": lv["P3"].normalized_anchor_sizes((32, 32))}
+    g1 = utils.detect_raw(lg, rg, an, c2, logits=True)[0]
+    g2 = utils.detect_raw({k: ops.activation(v.float(), 'sigmoid') for k, v in lg.items()}, {k: v.float() for k, v in rg.items()}, an, c2)[0]
+    assert torch.equal(g1.boxes, g2.boxes) and torch.equal(g1.scores, g2.scores) and len(g1.scores) > 0
+
+
+def test_segment_sort_long_segment_and_ties(dev):
+    """The hand-written segment sort: a single segment longer than its LDS capacity (8192 keys: sorted in place in global
+    memory), many equal scores (ties resolve to the lower index), negative scores -- utils.nms vs the oracle."""
+    import utils
+    rng = np.random.default_rng(41)
+    for k, distinct in ((20000, 50), (9000, 0), (300, 3)):
+        c = rng.uniform(0.05, 0.95, (k, 2))
+        s_ = rng.uniform(0.01, 0.05, (k, 2))
+        boxes = np.concatenate([c - s_ / 2, c + s_ / 2], 1).astype(np.float32)
+        scores = (rng.integers(0, distinct, k) / max(distinct, 1) - 0.3).astype(np.float32) if distinct else rng.standard_normal(k).astype(np.float32)
+        dec = utils.BoxesDecoded(boxes=_t(boxes, dev), scores=_t(scores, dev), class_ids=torch.zeros(k, dtype=torch.int64, device=dev))
+        got = utils.nms(dec)
+        idx = utils_ref.nms_indices_vectorised(boxes, scores)
+        assert np.array_equal(got.boxes.cpu().numpy(), boxes[idx]) and np.array_equal(got.scores.cpu().numpy(), scores[idx])

@@ -1,4 +1,4 @@
-"""BASELINE configs[4] on one GPU: ResNeXt-50-FPN 1024x1024, batch 16, forward (training=False) + sigmoid +
+"""BASELINE configs[4] on one GPU: ResNeXt-50-FPN 1024x1024, batch 16, forward (training=False) + sigmoid (inside the candidate scan) +
 anchor decode + batched class-wise NMS, in fp32 and in fp16 storage (f16 matrix-core convs, fp32 accumulate)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,10 +19,11 @@ def main(backbone="resnet_50", size=1024, batch=16, iters=5):
     def run():
         with torch.no_grad():
             out = net(image, training=False)
-            probs = {k: ops.activation(v, "sigmoid") for k, v in out["classifications"].items()}
-            rows = sum(v.numel() // 80 for v in probs.values())
-            return utils.detect_raw(probs, out["regressions"], anchors, 80, score_threshold=0.0105, capacity=int(rows * 0.5),
-                                    return_raw=True)
+            rows = sum(v.numel() // 80 for v in out["classifications"].values())
+            # the class logits and box deltas go to the detector as the net wrote them (fp16 in fp16 mode); the sigmoid runs
+            # inside the candidate scan
+            return utils.detect_raw(out["classifications"], out["regressions"], anchors, 80, score_threshold=0.0105,
+                                    capacity=int(rows * 0.5), return_raw=True, logits=True)
 
     for dtype in ("f32", "f16"):
         layers.set_inference_dtype(dtype)

@@ -1,6 +1,12 @@
-"""rocprofv3 --pmc target: the dominant kernel of the training step in isolation (GPU box only).
-The batched product of the Winograd F(4x4,3x3) head-tower layer: 36 x [682 x 256] x [256 x 256], 30 launches.
-usage: rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python tools/gemm_pmc.py   (WRITE_SIZE in a second pass)"""
+"""rocprofv3 --pmc target: the roofline kernels of bench.py in isolation (GPU box only), 30 launches each:
+  fwd  batched forward products of the Winograd F(4x4,3x3) head-tower layer: 36 x [682 x 256] x [256 x 256]
+  bwd  the merged backward products of the same layer (the largest in-step kernel)
+  gn   the largest stand-alone GroupNorm (+ELU+dropout) forward: 2 x 256 x 256 x 96
+usage (separate passes: FETCH_SIZE and WRITE_SIZE do not fit one):
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python tools/gemm_pmc.py
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python tools/gemm_pmc.py
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r02_pmc_traffic.json"""
+import ctypes as C
 import os
 import sys
 
@@ -10,14 +16,25 @@ sys.path.insert(0, os.path.join(ROOT, "retinanet-tensorflow_amd"))
 import torch  # noqa: E402
 
 import _rn  # noqa: E402
+import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 tiles = 2 * sum(((s + 3) // 4) ** 2 for s in (64, 32, 16, 8, 4))
 A = torch.randn(36, tiles, 256, device=dev)
 B = torch.randn(36, 256, 256, device=dev) * 0.01
 Cm = torch.empty(36, tiles, 256, device=dev)
+dM = torch.randn(36, tiles, 256, device=dev)
 L = _rn.lib()
+need = L.rn_winograd_bwd_products_workspace(tiles, 256, 256, 36)
+ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=dev)
+nsplit = C.c_int(0)
+x = torch.randn(2, 256, 256, 96, device=dev)
+gamma, beta = torch.ones(96, device=dev), torch.zeros(96, device=dev)
 for _ in range(30):
     _rn.check(L.rn_gemm_batched(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, 36, 0, _rn.stream()), "rn_gemm_batched")
+    _rn.check(L.rn_winograd_bwd_products(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, _rn.f32(A), _rn.f32(dM), 256, 256, 36,
+                                         ws.data_ptr(), ws.numel(), C.byref(nsplit), _rn.stream()), "rn_winograd_bwd_products")
+    with torch.no_grad():
+        ops.group_norm_act(x, gamma, beta, groups=32, act="elu", drop_rate=0.2, seed=1)
 torch.cuda.synchronize()
-print("tiles", tiles, "algorithmic bytes", 4 * 36 * (2 * tiles * 256 + 256 * 256))
+print("tiles", tiles, "nsplit", nsplit.value)

@@ -1,0 +1,44 @@
+"""HBM-side bytes per launch of bench.py's roofline kernels from two rocprofv3 --pmc passes over tools/gemm_pmc.py
+(host-side): FETCH_SIZE (KB; x2 on gfx950 for wide 16-B/lane reads, MI355X_MICROARCH.md) + WRITE_SIZE (KB).
+usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> > profiles/r02_pmc_traffic.json"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+KERNELS = {"fwd_products": ("conv_fwd_kernel",), "bwd_products": ("conv_bwd_kernel",),
+           "group_norm": ("gn_partial_kernel", "gn_finalize_kernel", "gn_apply_kernel")}
+
+
+def per_kernel(directory, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == counter:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main(fetch_dir, write_dir):
+    fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    out, detail = {}, {}
+    for key, names in KERNELS.items():
+        total = 0.0
+        for n in names:
+            f = [v for k, vals in fetch.items() if n in k for v in vals]
+            w = [v for k, vals in write.items() if n in k for v in vals]
+            if not f or not w:
+                continue
+            fk, wk = sum(f) / len(f), sum(w) / len(w)
+            detail["%s/%s" % (key, n)] = {"FETCH_SIZE_KB_avg": round(fk, 1), "WRITE_SIZE_KB_avg": round(wk, 1), "dispatches": len(f)}
+            total += (2.0 * fk + wk) * 1024.0       # gfx950: FETCH_SIZE reports half of the bytes of wide streaming reads
+        out[key] = int(total) if total else None
+    out["_detail"] = detail
+    out["_note"] = "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), averaged over the dispatches of tools/gemm_pmc.py"
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
