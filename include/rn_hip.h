@@ -209,6 +209,36 @@ int rn_depthwise_bwd(const float* x, const float* dy, const float* wgt, float* d
 int rn_depthwise_wgrad(const float* x, const float* dy, float* dw, int n, int h, int w, int c, int k, int stride,
                        void* workspace, size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer);
 
+/* ------------------------------------------------------------------ fused GroupNorm -> depthwise 3x3 -> GroupNorm
+ * The middle of a MobileNetV2 bottleneck, mobilenet_v2.py:56-80 -- Sequential([.., Normalization(), activation, Dropout]),
+ * DepthwiseConv2D(3, strides), Normalization(), activation, Dropout --
+ *     y = drop2(act(GN2( depthwise3x3_same( drop1(act(GN1(x))) ) )))
+ * as ONE kernel forward and ONE backward instead of three each.  A depthwise conv keeps channels apart and both
+ * GroupNorms group the same channels, so one block owns a (sample, group) slice end to end, in LDS: exact two-pass
+ * statistics, no exchange between blocks, the two intermediate tensors are never written (backward recomputes them
+ * from x).  Applies when a slice fits a CU's LDS (rn_dwgn_supported: forward needs h*w*(c/groups)*4 bytes, backward the
+ * input and output slices together, <= 156 KB) -- MobileNetV2 at 1/8 resolution and below for a 512^2 image; otherwise
+ * the caller runs the three stand-alone kernels.  The dropouts hash (drop_seedK + *drop_seed_dev, element index) exactly
+ * like rn_group_norm_fwd, so fused and unfused results agree to rounding.
+ */
+typedef struct rn_dwgn_params {
+  int32_t n, h, w, c;      /* input [n,h,w,c]; output [n,ceil(h/stride),ceil(w/stride),c] */
+  int32_t stride;          /* 1 or 2 */
+  int32_t groups, act;     /* of both GroupNorms */
+  float eps, drop_rate;
+  uint64_t drop_seed1, drop_seed2;
+  const uint64_t* drop_seed_dev;
+} rn_dwgn_params;
+int rn_dwgn_supported(const rn_dwgn_params* p, int backward);
+/* stats [4][n][groups]: mean1, rstd1, mean2, rstd2 (kept for the backward pass) */
+int rn_dwgn_fwd(const float* x, const float* gamma1, const float* beta1, const float* wgt, const float* gamma2,
+                const float* beta2, float* y, float* stats, const rn_dwgn_params* p, rn_stream_t stream);
+/* dx [n,h,w,c]; rows: per-sample partial parameter gradients, to be summed over the n rows of each section with
+ * rn_reduce_rows: [dgamma1: n x c][dbeta1: n x c][dgamma2: n x c][dbeta2: n x c][dw: n x 9c] */
+int rn_dwgn_bwd(const float* x, const float* dy, const float* gamma1, const float* beta1, const float* wgt,
+                const float* gamma2, const float* beta2, const float* stats, float* dx, float* rows,
+                const rn_dwgn_params* p, rn_stream_t stream);
+
 /* ------------------------------------------------------------------ GroupNorm (+act, +dropout, +residual)
  * Replaces normalization.py:20-35 (reshape + tf.nn.moments + affine), the activation that
  * follows it in every reference Sequential (tf.nn.elu train.py:214 / tf.nn.relu resnet.py:85),

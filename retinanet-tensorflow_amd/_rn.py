@@ -74,6 +74,12 @@ class AddSeg(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("count", C.c_int64)]
 
 
+class DwGnParams(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("stride", C.c_int32),
+                ("groups", C.c_int32), ("act", C.c_int32), ("eps", C.c_float), ("drop_rate", C.c_float),
+                ("drop_seed1", C.c_uint64), ("drop_seed2", C.c_uint64), ("drop_seed_dev", C.c_void_p)]
+
+
 class GnSeg(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("residual", C.c_void_p), ("dy", C.c_void_p),
                 ("dx", C.c_void_p), ("dresidual", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
@@ -115,7 +121,7 @@ SYMBOLS = [
     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes",
     "rn_conv3x3_winograd_bwd_workspace", "rn_conv3x3_winograd_bwd", "rn_flush_reductions", "rn_gemm_batched",
     "rn_winograd_bwd_products_workspace", "rn_winograd_bwd_products", "rn_wino_gn_rows", "rn_conv3x3_winograd_gn", "rn_conv3x3_winograd_gn_bwd", "rn_reduce_rows", "rn_resize_bilinear_normalize",
-    "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad", "rn_depthwise_bwd",
+    "rn_dwgn_supported", "rn_dwgn_fwd", "rn_dwgn_bwd", "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad", "rn_depthwise_bwd",
     "rn_group_norm_sync_bytes", "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
     "rn_pack_weights_f16", "rn_cast_f32_to_f16", "rn_pad_cast_rgb_f16", "rn_conv2d_fwd_f16", "rn_maxpool_fwd_f16", "rn_upsample_add_fwd_f16",
@@ -145,6 +151,9 @@ def lib():
                      "rn_winograd_bwd_products_workspace"):
             getattr(L, name).restype = C.c_size_t
         L.rn_optimizer_workspace.argtypes = [C.c_int64]
+        L.rn_dwgn_supported.argtypes = [C.c_void_p, C.c_int]
+        L.rn_dwgn_fwd.argtypes = [C.c_void_p] * 10
+        L.rn_dwgn_bwd.argtypes = [C.c_void_p] * 12
         L.rn_depthwise_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_depthwise_dgrad.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_depthwise_bwd.argtypes = [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

@@ -10,6 +10,8 @@ each + GroupNorm, dropout; residual iff shapes match, :91-92); final 1x1 -> 32 c
 SURVEY Q8).  Each [conv, Normalization, activation, Dropout] run is conv kernel + ONE fused
 GroupNorm kernel (the residual add rides in the same kernel).
 """
+import torch
+
 import layers as L
 import ops
 from model import Model, Sequential
@@ -64,9 +66,31 @@ class Bottleneck(Model):
         identity = None
         if self._same_shape:        # the input feeds the expand conv and the residual: their gradients are summed by our kernel
             input, identity = ops.fanout(input, 2)
-        input = self.expand_conv(input, training)
-        input = self.depthwise_conv(input, training)
-        return self.linear_conv(input, training, residual=identity)
+        mid = self._fused_middle(input, training)
+        if mid is None:
+            mid = self.depthwise_conv(self.expand_conv(input, training), training)
+        return self.linear_conv(mid, training, residual=identity)
+
+    def _fused_middle(self, input, training):
+        """[GroupNorm, act, Dropout] -> depthwise 3x3 -> [GroupNorm, act, Dropout] as ONE kernel (ops.dw_gn_fused) when a
+        (sample, group) slice fits a CU's LDS; None otherwise (the layers then run one by one)."""
+        conv, norm1, act1, drop1 = self.expand_conv.layers
+        dw, norm2, act2, drop2 = self.depthwise_conv.layers
+        if not torch.is_tensor(input) or input.dtype != torch.float32 or (L.INFERENCE_F16 and not training):
+            return None
+        c = conv.filters
+        g = ops.gn_groups(c, norm1.groups)
+        act = L.activation_name(act1)
+        need_bwd = training and torch.is_grad_enabled()
+        shape = (input.shape[0], input.shape[1], input.shape[2], c)                 # the expand conv is 1x1 / stride 1
+        if (not input.is_cuda or dw.weight is None or norm1.gamma is None or norm2.gamma is None or
+                norm1.groups != norm2.groups or norm1.eps != norm2.eps or act != L.activation_name(act2) or
+                not ops.dw_gn_ok(shape, dw.weight, dw.strides, g, act, need_bwd)):
+            return None
+        rate = drop1.rate if (training and drop1.rate > 0.0) else 0.0
+        y1 = conv(input)
+        return ops.dw_gn_fused(y1, norm1.gamma, norm1.beta, dw.weight, norm2.gamma, norm2.beta, dw.strides, g, norm1.eps, act,
+                               rate, drop1.seed, drop2.seed, L.Dropout.seed_device_counter)
 
 
 class MobileNetV2(Model):

@@ -645,6 +645,74 @@ def depthwise_conv2d(x, w, stride=1):
     return _Depthwise.apply(x, w, stride)
 
 
+# GroupNorm -> depthwise 3x3 -> GroupNorm of a MobileNetV2 bottleneck as one kernel per direction (rn_dwgn_fwd / rn_dwgn_bwd)
+DW_GN_FUSED = os.environ.get("RN_DW_GN_FUSED", "1") == "1"
+
+
+def _dwgn_params(x, stride, groups, eps, act, rate, seed1, seed2, seed_dev):
+    n, h, w, c = x if isinstance(x, tuple) else x.shape
+    return _rn.DwGnParams(n, h, w, c, stride, groups, _rn.ACT[act], eps, rate, seed1, seed2,
+                          seed_dev.data_ptr() if seed_dev is not None else None)
+
+
+def dw_gn_ok(shape, w, stride, groups, act, need_backward):
+    """Can drop(act(GN(dw3x3(drop(act(GN(x))))))) run as the fused kernels for an fp32 device tensor x of `shape` [n,h,w,c]?"""
+    if not (DW_GN_FUSED and w.is_cuda and len(shape) == 4 and w.shape[0] == 3 and w.shape[1] == 3 and w.shape[2] == shape[3]
+            and stride in (1, 2) and act in (None, "none", "relu", "elu", "relu6")):
+        return False
+    p = _dwgn_params(tuple(int(v) for v in shape), stride, groups, 1e-5, act, 0.0, 0, 0, None)
+    return bool(_rn.lib().rn_dwgn_supported(C.byref(p), 1 if need_backward else 0))
+
+
+class _DwGnFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, x, g1, b1, w, g2, b2):
+        stride, groups, eps, act, rate, seed1, seed2, seed_dev = cfg
+        x = x.contiguous()
+        n, h, wd, c = x.shape
+        oh, _ = _rn.same_pad(h, 3, stride)
+        ow, _ = _rn.same_pad(wd, 3, stride)
+        y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
+        stats = torch.empty((4, n, groups), dtype=torch.float32, device=x.device)
+        p = _dwgn_params(x, stride, groups, eps, act, rate, seed1, seed2, seed_dev)
+        _rn.check(_rn.lib().rn_dwgn_fwd(_rn.f32(x), _rn.f32(g1), _rn.f32(b1), _rn.f32(w), _rn.f32(g2), _rn.f32(b2), _rn.f32(y),
+                                        _rn.f32(stats), C.byref(p), _rn.stream()), "rn_dwgn_fwd")
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, g1, b1, w, g2, b2, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, groups, eps, act, rate, seed1, seed2, seed_dev = ctx.cfg
+        x, g1, b1, w, g2, b2, stats = ctx.saved_tensors
+        n, h, wd, c = x.shape
+        L = _rn.lib()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        rows = torch.empty((13 * n * c,), dtype=torch.float32, device=x.device)
+        if _deferring:
+            _deferred_keep.append(rows)
+        p = _dwgn_params(x, stride, groups, eps, act, rate, seed1, seed2, seed_dev)
+        _rn.check(L.rn_dwgn_bwd(_rn.f32(x), _rn.f32(dy), _rn.f32(g1), _rn.f32(b1), _rn.f32(w), _rn.f32(g2), _rn.f32(b2),
+                                _rn.f32(stats), _rn.f32(dx), _rn.f32(rows), C.byref(p), _rn.stream()), "rn_dwgn_bwd")
+        grads = []
+        nc = n * c
+        for i, prm in enumerate((g1, b1, g2, b2, w)):
+            buf, ret = _grad_slot(prm)
+            count = 9 * c if i == 4 else c
+            sec = rows[i * nc:i * nc + n * count]
+            _rn.check(L.rn_reduce_rows(_rn.f32(sec), _rn.f32(buf), count, n, 0, _rn.stream(), _defer_arg()), "rn_reduce_rows")
+            grads.append(ret)
+        dg1, db1, dg2, db2, dw = grads                    # rows order; the inputs are (x, g1, b1, w, g2, b2)
+        return None, dx, dg1, db1, dw, dg2, db2
+
+
+def dw_gn_fused(x, gamma1, beta1, w, gamma2, beta2, stride, groups, eps, act, rate=0.0, seed1=0, seed2=0, seed_dev=None):
+    """drop2(act(GN2(depthwise3x3(drop1(act(GN1(x))))))): see rn_dwgn_fwd."""
+    cfg = (int(stride), int(groups), float(eps), act, float(rate), int(seed1), int(seed2), seed_dev)
+    return _DwGnFused.apply(cfg, x, gamma1, beta1, w, gamma2, beta2)
+
+
 def gn_groups(c, groups=32):
     """Largest divisor of c that is <= min(groups, c): the reference's min(32, C) rule
     (normalization.py:24) made total for C=144, where the reference itself cannot run

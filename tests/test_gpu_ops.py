@@ -1092,3 +1092,62 @@ def test_segment_sort_long_segment_and_ties(dev):
         got = utils.nms(dec)
         idx = utils_ref.nms_indices_vectorised(boxes, scores)
         assert np.array_equal(got.boxes.cpu().numpy(), boxes[idx]) and np.array_equal(got.scores.cpu().numpy(), scores[idx])
+
+
+DWGN_CASES = [  # n, h, w, c, stride, act, drop rate   (c / groups = 6, 12, 18, 30: the widths of MobileNetV2's bottlenecks)
+    (2, 32, 32, 192, 1, "elu", 0.0),
+    (2, 32, 32, 384, 1, "elu", 0.2),
+    (2, 32, 32, 576, 1, "relu6", 0.2),       # input + output slice: the largest that still fits the backward kernel
+    (2, 32, 32, 576, 2, "elu", 0.1),
+    (2, 16, 16, 960, 1, "elu", 0.2),
+    (3, 15, 13, 96, 2, "relu", 0.0),         # odd sizes, stride 2 (asymmetric SAME padding)
+    (1, 64, 64, 192, 2, "elu", 0.2),         # the 64 x 64 input slice (98 KB) with a 32 x 32 output
+    (2, 5, 7, 32, 1, None, 0.0),             # one channel per group
+]
+
+
+@pytest.mark.parametrize("case", DWGN_CASES, ids=[str(i) for i in range(len(DWGN_CASES))])
+def test_fused_groupnorm_depthwise_groupnorm(dev, case):
+    """rn_dwgn_fwd / rn_dwgn_bwd (one kernel per direction) == GroupNorm kernel + depthwise kernel + GroupNorm kernel, forward and
+    every gradient, with the same dropout masks; and == the oracle when there is no dropout."""
+    import ops
+    n, h, w, c, stride, act, rate = case
+    rng = np.random.default_rng(sum(case[:5]))
+    g = ops.gn_groups(c, 32)
+    x = _t((rng.standard_normal((n, h, w, c)) * 1.5 + 0.3).astype(np.float32), dev, True)
+    prm = [_t(v.astype(np.float32), dev, True) for v in (1 + 0.3 * rng.standard_normal(c), 0.2 * rng.standard_normal(c),
+                                                             rng.standard_normal((3, 3, c, 1)) / 3,
+                                                             1 + 0.3 * rng.standard_normal(c), 0.2 * rng.standard_normal(c))]
+    g1, b1, wd, g2, b2 = prm
+    assert ops.dw_gn_ok((n, h, w, c), wd, stride, g, act, True)
+    counter = torch.tensor([12345], dtype=torch.int64, device=dev)
+    got = ops.dw_gn_fused(x, g1, b1, wd, g2, b2, stride, g, 1e-5, act, rate, 111, 222, counter)
+    a1 = ops.group_norm_act(x, g1, b1, groups=32, eps=1e-5, act=act, drop_rate=rate, seed=111, seed_dev=counter)
+    ref = ops.group_norm_act(ops.depthwise_conv2d(a1, wd, stride), g2, b2, groups=32, eps=1e-5, act=act, drop_rate=rate, seed=222,
+                             seed_dev=counter)
+    assert got.shape == ref.shape
+    assert_close(got.detach().cpu().numpy(), ref.detach().cpu().numpy(), 2e-5, "fused forward")
+    if rate > 0:      # the same elements are dropped
+        assert torch.equal(got == 0, ref == 0) or float(((got == 0) != (ref == 0)).float().mean()) < 1e-5
+    dy = _t(rng.standard_normal(tuple(ref.shape)).astype(np.float32), dev)
+    leaves = [x] + prm
+    gg = torch.autograd.grad(got, leaves, dy)
+    gr = torch.autograd.grad(ref, leaves, dy)
+    for name, a, b in zip(("dx", "dgamma1", "dbeta1", "dw", "dgamma2", "dbeta2"), gg, gr):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4, name)
+    if rate == 0:
+        xc = x.detach().cpu().requires_grad_(True)
+        pc = [t.detach().cpu().requires_grad_(True) for t in prm]
+        o = tf_ops_ref.activation(tf_ops_ref.group_norm(xc, pc[0], pc[1], 32), act or "none")
+        o = tf_ops_ref.activation(tf_ops_ref.group_norm(tf_ops_ref.depthwise_conv2d_same(o, pc[2], stride), pc[3], pc[4], 32), act or "none")
+        assert_close(got.detach().cpu().numpy(), o.detach().numpy(), 1e-4, "fused forward vs oracle")
+        go = torch.autograd.grad(o, [xc] + pc, dy.cpu())
+        for name, a, b in zip(("dx", "dgamma1", "dbeta1", "dw", "dgamma2", "dbeta2"), gg, go):
+            assert_close(a.cpu().numpy(), b.numpy(), 1e-4, name + " vs oracle")
+
+
+def test_fused_dwgn_declines_what_does_not_fit(dev):
+    import ops
+    wd = torch.zeros((3, 3, 192, 1), device=dev)
+    assert not ops.dw_gn_ok((2, 128, 128, 192), wd, 1, 32, "elu", False)        # 393 KB slice
+    assert ops.dw_gn_ok((2, 64, 64, 192), wd, 1, 32, "elu", False) and not ops.dw_gn_ok((2, 64, 64, 192), wd, 1, 32, "elu", True)
