@@ -15,6 +15,7 @@
 
 namespace {
 constexpr int T = 1024;
+constexpr int U = 8;   // global loads a thread keeps in flight in the slice loops
 constexpr size_t LDS_LIMIT = 156 * 1024;   // dynamic LDS of the CU's 160 KB (the rest: ~3 KB of static reduction scratch)
 
 struct Args {
@@ -72,6 +73,11 @@ __device__ __forceinline__ void channel_sum(float v, int cpg, int plc, bool acti
   __syncthreads();
 }
 
+// floor(i / d) for 0 <= i < 2^20 and 1 <= d <= 2^12 without an integer division (a runtime-divisor division is ~40
+// instructions, and these loops did five per element): (i + 0.5) * (1 / d) is off by < 1e-6 * i / d, far inside the
+// 0.5 / d margin to the next integer
+__device__ __forceinline__ int fast_div(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
+
 __device__ __forceinline__ float drop_apply(float v, float rate, float keep_scale, uint64_t seed, uint64_t idx) {
   return (rn::uniform01(seed, idx) >= rate) ? v * keep_scale : 0.f;
 }
@@ -95,45 +101,52 @@ __device__ __forceinline__ float stencil(const Args& a, const float* a1, const f
   return acc;
 }
 
-// x slice -> LDS as a1 = drop1(act(GN1(x))); returns mean1 / rstd1 (computed when stats_known == false)
+// x slice -> LDS as a1 = drop1(act(GN1(x))); returns mean1 / rstd1 (computed when stats_known == false).
+// Thread t owns channel lane t % cpg and the pixels t / cpg + k * (T / cpg): no index arithmetic per element.
 template <int ACT>
 __device__ __forceinline__ void load_a1(const Args& a, float* a1, int n_, int g, bool stats_known, float* mean_io, float* rstd_io,
                                         float* sh) {
   const int tid = threadIdx.x, cpg = a.cpg, hw = a.h * a.w, C = a.c, cnt = hw * cpg;
-  const float* xg = a.x + (size_t)n_ * hw * C + g * cpg;
+  const int plc = T / cpg, ch = tid % cpg, pl = tid / cpg, cg = g * cpg + ch;
+  const int p0 = pl < plc ? pl : hw;           // idle lanes (T is not a multiple of cpg) skip every loop
+  const float* xg = a.x + (size_t)n_ * hw * C + cg;
   float mean = *mean_io, rstd = *rstd_io;
   if (!stats_known) {
     float s[1] = {0.f};
-    for (int e = tid; e < cnt; e += T) {
-      const int p = e / cpg, ch = e - p * cpg;
-      const float v = xg[(size_t)p * C + ch];
-      a1[e] = v;
-      s[0] += v;
+    for (int p = p0; p < hw; p += U * plc) {   // U loads in flight per thread (a one-load-per-iteration loop waits for each)
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = xg[(size_t)min(p + u * plc, hw - 1) * C];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (p + u * plc < hw) { a1[(p + u * plc) * cpg + ch] = v[u]; s[0] += v[u]; }
     }
     block_sum<1>(s, sh);
     mean = s[0] / (float)cnt;
     float q[1] = {0.f};
-    for (int e = tid; e < cnt; e += T) { const float d = a1[e] - mean; q[0] += d * d; }
+    for (int p = p0; p < hw; p += plc) { const float d = a1[p * cpg + ch] - mean; q[0] += d * d; }
     block_sum<1>(q, sh);
     rstd = 1.f / sqrtf(q[0] / (float)cnt + a.eps);
     *mean_io = mean; *rstd_io = rstd;
   } else {
-    for (int e = tid; e < cnt; e += T) {
-      const int p = e / cpg, ch = e - p * cpg;
-      a1[e] = xg[(size_t)p * C + ch];
+    for (int p = p0; p < hw; p += U * plc) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = xg[(size_t)min(p + u * plc, hw - 1) * C];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (p + u * plc < hw) a1[(p + u * plc) * cpg + ch] = v[u];
     }
-    __syncthreads();
   }
   const bool drop = a.drop_rate > 0.f;
   const float keep_scale = drop ? 1.f / (1.f - a.drop_rate) : 1.f;
   const uint64_t seed = a.seed1 + (a.seed_dev ? *a.seed_dev : 0ull);
-  const uint64_t samp = (uint64_t)n_ * (uint64_t)hw * (uint64_t)C;
-  for (int e = tid; e < cnt; e += T) {
-    const int p = e / cpg, ch = e - p * cpg, cg = g * cpg + ch;
-    const float sc = rstd * a.gamma1[cg], shf = a.beta1[cg] - mean * sc;
-    float v = rn::act_fwd(a1[e] * sc + shf, ACT);
-    if (drop) v = drop_apply(v, a.drop_rate, keep_scale, seed, samp + (uint64_t)p * C + cg);
-    a1[e] = v;
+  const uint64_t samp = (uint64_t)n_ * (uint64_t)hw * (uint64_t)C + (uint64_t)cg;
+  const float sc = rstd * a.gamma1[cg], shf = a.beta1[cg] - mean * sc;
+  for (int p = p0; p < hw; p += plc) {          // own elements only: no barrier needed before this loop
+    float v = rn::act_fwd(a1[p * cpg + ch] * sc + shf, ACT);
+    if (drop) v = drop_apply(v, a.drop_rate, keep_scale, seed, samp + (uint64_t)p * C);
+    a1[p * cpg + ch] = v;
   }
   __syncthreads();
 }
@@ -155,13 +168,14 @@ __global__ __launch_bounds__(T) void dwgn_fwd_kernel(const Args a) {
   float wt[9];
 #pragma unroll
   for (int t9 = 0; t9 < 9; ++t9) wt[t9] = a.wgt[(size_t)t9 * C + g * cpg + ch];
+  const float inv_ow = 1.f / (float)a.ow;
   float y2[R];
   float s[1] = {0.f};
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     const int op = pl + k * plc;
     const bool ok = active && op < ohw;
-    const int opc = min(op, ohw - 1), oy = opc / a.ow, ox = opc - oy * a.ow;
+    const int opc = min(op, ohw - 1), oy = fast_div(opc, inv_ow), ox = opc - oy * a.ow;
     const float v = stencil(a, a1, wt, oy, ox, ch);
     y2[k] = ok ? v : 0.f;
     s[0] += y2[k];
@@ -214,6 +228,8 @@ __global__ __launch_bounds__(T) void dwgn_bwd_kernel(const Args a) {
   load_a1<ACT>(a, a1, n_, g, true, &mean1, &rstd1, sh);
   const int plc = T / cpg, ch = tid % cpg, pl = tid / cpg, cg = g * cpg + ch;
   const bool active = pl < plc;
+  const float inv_ow = 1.f / (float)a.ow, inv_w = 1.f / (float)a.w;
+  const int sshift = a.stride - 1;             // stride 1 or 2
   const bool drop = a.drop_rate > 0.f;
   const float keep_scale = drop ? 1.f / (1.f - a.drop_rate) : 1.f;
   const uint64_t dev_seed = a.seed_dev ? *a.seed_dev : 0ull;
@@ -228,14 +244,23 @@ __global__ __launch_bounds__(T) void dwgn_bwd_kernel(const Args a) {
     const float* dyg = a.dy + (size_t)n_ * ohw * C;
     float s[2] = {0.f, 0.f};
     if (active)
-      for (int op = pl; op < ohw; op += plc) {
-        const int oy = op / a.ow, ox = op - oy * a.ow;
-        const float xh = (stencil(a, a1, wt, oy, ox, ch) - mean2) * rstd2;
-        float gg = dyg[(size_t)op * C + cg];
-        if (drop) gg = drop_apply(gg, a.drop_rate, keep_scale, seed2, samp2 + (uint64_t)op * C + cg);
-        gg *= rn::act_grad(xh * gam2 + bet2, ACT);
-        d2[op * cpg + ch] = gg;
-        s[0] += gg; s[1] += gg * xh;
+      for (int op0 = pl; op0 < ohw; op0 += U * plc) {
+        float dyv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dyv[u] = dyg[(size_t)min(op0 + u * plc, ohw - 1) * C + cg];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int op = op0 + u * plc;
+          if (op < ohw) {
+            const int oy = fast_div(op, inv_ow), ox = op - oy * a.ow;
+            const float xh = (stencil(a, a1, wt, oy, ox, ch) - mean2) * rstd2;
+            float gg = dyv[u];
+            if (drop) gg = drop_apply(gg, a.drop_rate, keep_scale, seed2, samp2 + (uint64_t)op * C + cg);
+            gg *= rn::act_grad(xh * gam2 + bet2, ACT);
+            d2[op * cpg + ch] = gg;
+            s[0] += gg; s[1] += gg * xh;
+          }
+        }
       }
     channel_sum(s[0], cpg, plc, active, red, red2, csum);
     channel_sum(s[1], cpg, plc, active, red, red2, csum2);
@@ -257,7 +282,7 @@ __global__ __launch_bounds__(T) void dwgn_bwd_kernel(const Args a) {
     for (int t9 = 0; t9 < 9; ++t9) wacc[t9] = 0.f;
     if (active)
       for (int op = pl; op < ohw; op += plc) {
-        const int oy = op / a.ow, ox = op - oy * a.ow;
+        const int oy = fast_div(op, inv_ow), ox = op - oy * a.ow;
         const float xh = (stencil(a, a1, wt, oy, ox, ch) - mean2) * rstd2;
         const float dv = rstd2 * (gam2 * d2[op * cpg + ch] - c1 - xh * c2);
         d2[op * cpg + ch] = dv;
@@ -288,30 +313,38 @@ __global__ __launch_bounds__(T) void dwgn_bwd_kernel(const Args a) {
     const uint64_t seed1 = a.seed1 + dev_seed, samp1 = (uint64_t)n_ * (uint64_t)hw * (uint64_t)C;
     float s[2] = {0.f, 0.f};
     if (active)
-      for (int ip = pl; ip < hw; ip += plc) {
-        const int ih = ip / a.w, iw = ip - ih * a.w;
+      for (int ip0 = pl; ip0 < hw; ip0 += U * plc) {
+       float xv[U];
+#pragma unroll
+       for (int u = 0; u < U; ++u) xv[u] = xg[(size_t)min(ip0 + u * plc, hw - 1) * C + cg];
+#pragma unroll
+       for (int u = 0; u < U; ++u) {
+        const int ip = ip0 + u * plc;
+        if (ip >= hw) break;
+        const int ih = fast_div(ip, inv_w), iw = ip - ih * a.w;
         float da = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {     // same visiting order as dw_dgrad_body's generic 3x3 branch
           const int ohs = ih + a.pad_t - kh;
-          const int oh_ = ohs / a.stride;
-          const bool rok = ohs >= 0 && oh_ * a.stride == ohs && oh_ < a.oh;
+          const int oh_ = ohs >> sshift;       // arithmetic shift: negative ohs stays negative and fails `ohs >= 0`
+          const bool rok = ohs >= 0 && (oh_ << sshift) == ohs && oh_ < a.oh;
           const int ohc = min(max(oh_, 0), a.oh - 1);
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
             const int ows = iw + a.pad_l - kw;
-            const int ow_ = ows / a.stride;
-            const float m = (rok && ows >= 0 && ow_ * a.stride == ows && ow_ < a.ow) ? 1.f : 0.f;
+            const int ow_ = ows >> sshift;
+            const float m = (rok && ows >= 0 && (ow_ << sshift) == ows && ow_ < a.ow) ? 1.f : 0.f;
             const int owc = min(max(ow_, 0), a.ow - 1);
             da = fmaf(d2[(ohc * a.ow + owc) * cpg + ch] * m, wt[kh * 3 + kw], da);
           }
         }
-        const float xh = (xg[(size_t)ip * C + cg] - mean1) * rstd1;
+        const float xh = (xv[u] - mean1) * rstd1;
         float gg = da;
         if (drop) gg = drop_apply(gg, a.drop_rate, keep_scale, seed1, samp1 + (uint64_t)ip * C + cg);
         gg *= rn::act_grad(xh * gam1 + bet1, ACT);
         a1[ip * cpg + ch] = gg;               // only this thread reads / writes (ip, ch) from here on
         s[0] += gg; s[1] += gg * xh;
+       }
       }
     channel_sum(s[0], cpg, plc, active, red, red2, csum);
     channel_sum(s[1], cpg, plc, active, red, red2, csum2);
@@ -329,9 +362,15 @@ __global__ __launch_bounds__(T) void dwgn_bwd_kernel(const Args a) {
     const float c1 = coef[0], c2 = coef[1];
     float* dxg = a.dx + (size_t)n_ * hw * C;
     if (active)
-      for (int ip = pl; ip < hw; ip += plc) {
-        const float xh = (xg[(size_t)ip * C + cg] - mean1) * rstd1;
-        dxg[(size_t)ip * C + cg] = rstd1 * (gam1 * a1[ip * cpg + ch] - c1 - xh * c2);
+      for (int ip0 = pl; ip0 < hw; ip0 += U * plc) {
+        float xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = xg[(size_t)min(ip0 + u * plc, hw - 1) * C + cg];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ip = ip0 + u * plc;
+          if (ip < hw) dxg[(size_t)ip * C + cg] = rstd1 * (gam1 * a1[ip * cpg + ch] - c1 - (xv[u] - mean1) * rstd1 * c2);
+        }
       }
   }
 }

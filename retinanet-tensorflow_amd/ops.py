@@ -645,8 +645,12 @@ def depthwise_conv2d(x, w, stride=1):
     return _Depthwise.apply(x, w, stride)
 
 
-# GroupNorm -> depthwise 3x3 -> GroupNorm of a MobileNetV2 bottleneck as one kernel per direction (rn_dwgn_fwd / rn_dwgn_bwd)
-DW_GN_FUSED = os.environ.get("RN_DW_GN_FUSED", "1") == "1"
+# GroupNorm -> depthwise 3x3 -> GroupNorm of a MobileNetV2 bottleneck as one kernel per direction (rn_dwgn_fwd / rn_dwgn_bwd).
+# Correct (tests/test_gpu_ops.py::test_fused_groupnorm_depthwise_groupnorm) but OFF by default: measured on the headline step it
+# is slower than the three kernels it replaces (347 vs 360 images/s; forward 19-40 us vs ~27, backward 58 vs ~41 per
+# bottleneck): one block per (sample, group) is 64 blocks on 256 CUs, and with one channel lane per thread the stencil's index
+# arithmetic (~100 VALU instructions per output) makes those 64 CUs ALU-bound.  See DESIGN.md section 9.
+DW_GN_FUSED = os.environ.get("RN_DW_GN_FUSED", "0") == "1"
 
 
 def _dwgn_params(x, stride, groups, eps, act, rate, seed1, seed2, seed_dev):

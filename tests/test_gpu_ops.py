@@ -1107,10 +1107,11 @@ DWGN_CASES = [  # n, h, w, c, stride, act, drop rate   (c / groups = 6, 12, 18, 
 
 
 @pytest.mark.parametrize("case", DWGN_CASES, ids=[str(i) for i in range(len(DWGN_CASES))])
-def test_fused_groupnorm_depthwise_groupnorm(dev, case):
+def test_fused_groupnorm_depthwise_groupnorm(dev, monkeypatch, case):
     """rn_dwgn_fwd / rn_dwgn_bwd (one kernel per direction) == GroupNorm kernel + depthwise kernel + GroupNorm kernel, forward and
     every gradient, with the same dropout masks; and == the oracle when there is no dropout."""
     import ops
+    monkeypatch.setattr(ops, "DW_GN_FUSED", True)
     n, h, w, c, stride, act, rate = case
     rng = np.random.default_rng(sum(case[:5]))
     g = ops.gn_groups(c, 32)
@@ -1146,8 +1147,9 @@ def test_fused_groupnorm_depthwise_groupnorm(dev, case):
             assert_close(a.cpu().numpy(), b.numpy(), 1e-4, name + " vs oracle")
 
 
-def test_fused_dwgn_declines_what_does_not_fit(dev):
+def test_fused_dwgn_declines_what_does_not_fit(dev, monkeypatch):
     import ops
+    monkeypatch.setattr(ops, "DW_GN_FUSED", True)
     wd = torch.zeros((3, 3, 192, 1), device=dev)
     assert not ops.dw_gn_ok((2, 128, 128, 192), wd, 1, 32, "elu", False)        # 393 KB slice
     assert ops.dw_gn_ok((2, 64, 64, 192), wd, 1, 32, "elu", False) and not ops.dw_gn_ok((2, 64, 64, 192), wd, 1, 32, "elu", True)

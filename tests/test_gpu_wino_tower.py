@@ -57,7 +57,7 @@ SHAPES = [  # (list of (n, h, w)), channels, out channels (0: no output conv), l
 def test_folded_tower_matches_layer_by_layer(dev, case):
     import ops
     shapes, c, cout, k, act, tile = case
-    rng = np.random.default_rng(hash(str(case)) % 1000)
+    rng = np.random.default_rng(SHAPES.index(case) + 17)      # (str hashes change from run to run)
     old = ops.WINOGRAD_TILE
     ops.WINOGRAD_TILE = tile
     try:
