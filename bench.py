@@ -428,31 +428,51 @@ def main():
     import _rn
     _rn.lib()
 
-    step = Step(device, use_graph=not args.no_graph, loss_mode=args.loss, dropout=args.dropout, rank=rank,
-                overlap=not args.no_overlap, force_collective=args.force_collective)
-    for _ in range(args.warmup):
-        step()
+    import ops
 
-    def barrier():
+    def run_once():
+        """Build the step, warm up, time exactly args.steps steps; returns (step, elapsed, exposed, losses, gn_timeouts)."""
+        step = Step(device, use_graph=not args.no_graph, loss_mode=args.loss, dropout=args.dropout, rank=rank,
+                    overlap=not args.no_overlap, force_collective=args.force_collective)
+        step.trainer.check_interval = 0            # checked explicitly below (a timeout switches the path, it does not abort)
+        for _ in range(args.warmup):
+            step()
+
+        def barrier():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        step.trainer.timing = {}
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        exposed = step.trainer.allreduce_exposed_ms()
+        timeouts = _rn.barrier_timeouts()
         if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+            t = torch.tensor([elapsed, exposed, float(timeouts)], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, exposed, timeouts = float(t[0].item()), float(t[1].item()), int(t[2].item())
+        return step, elapsed, exposed, [float(x) for x in out], timeouts
 
-    step.trainer.timing = {}
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    exposed = step.trainer.allreduce_exposed_ms()
-    if dist is not None:
-        t = torch.tensor([elapsed, exposed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, exposed = float(t[0].item()), float(t[1].item())
-    losses = [float(x) for x in out]
-    step.trainer.check_device_errors()
+    step, elapsed, exposed, losses, timeouts = run_once()
+    gn_fallback = False
+    if os.environ.get("RN_BENCH_FORCE_GN_FALLBACK") == "1":     # self-test of the fallback below
+        timeouts = 1
+    if timeouts:
+        # a grid-resident GroupNorm block waited for a peer that was not co-resident (other kernels held CUs: a collective
+        # under the backward pass, another process): its results are invalid.  Switch to the launch-ordered GroupNorm
+        # kernels on EVERY rank and measure again -- the number reported is then the one of the path that is correct here.
+        ops.GN_GRID_RESIDENT = False
+        _rn.reset_barrier_timeouts()
+        gn_fallback = True
+        del step
+        step, elapsed, exposed, losses, timeouts = run_once()
+        if timeouts:
+            raise SystemExit("bench.py: GroupNorm exchange timeouts with the grid-resident path off: invalid run")
 
     result = None
     if rank == 0:
@@ -474,7 +494,8 @@ def main():
                                      "allreduce_exposed_ms": round(exposed, 4)},
                        "final_class_loss": round(losses[0], 6),
                        "final_regr_loss": round(losses[1], 6),
-                       "gn_barrier_timeouts": __import__("_rn").barrier_timeouts(),
+                       "gn_barrier_timeouts": timeouts, "gn_grid_resident": bool(ops.GN_GRID_RESIDENT),
+                       "gn_fell_back_to_launch_ordered_kernels": gn_fallback,
                        "conv_roofline_frac_whole_step": round(ips / world * TRAIN_GFLOP_PER_IMAGE / 1e3 /
                                                               FP32_MFMA_PEAK_TFLOPS, 4)},
         }

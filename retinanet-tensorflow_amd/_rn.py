@@ -317,6 +317,12 @@ def barrier_timeouts():
     return sum(int(t[2].item()) for t in _sync_words.values())
 
 
+def reset_barrier_timeouts():
+    """Clear the error words (after the caller has dealt with a reported timeout, e.g. by switching the path off)."""
+    for t in _sync_words.values():
+        t[2] = 0
+
+
 def side_stream(device, index=0):
     """A stream (per device and index) for work that may overlap the main stream; it gets its own workspace."""
     key = (device.type, device.index, index)
