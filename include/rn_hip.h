@@ -257,6 +257,11 @@ typedef struct rn_gn_seg {
   float* mean;           /* [n, groups]                                     */
   float* rstd;           /* [n, groups]                                     */
   int32_t n, hw;
+  /* Channel-prefix views (concat-free DenseNet blocks, densenet.py:117-121: layer i normalises the first c channels of
+   * the block's one [n, hw, c_total] buffer instead of a concatenated copy).  0 = dense. */
+  int32_t x_ld;          /* floats between consecutive pixels of x (fwd and bwd reads)                     */
+  int32_t dx_ld;         /* the same for dx                                                                 */
+  int32_t dx_accumulate; /* != 0: dx += (every later layer of the block adds to the same gradient buffer)   */
 } rn_gn_seg;
 
 typedef struct rn_gn_params {
@@ -299,6 +304,12 @@ int rn_upsample_add_bwd_top(const float* dy, float* dtop, int n, int h, int w, i
  * the same counter-based mask in forward and backward: dx = rn_dropout(dy) with the same seed. */
 int rn_dropout(const float* x, float* y, int64_t count, float rate, uint64_t seed, const uint64_t* seed_dev,
                rn_stream_t stream);
+/* The same between channel slices: y[p, y_coff + ch] = dropout(x[p, x_coff + ch]), ch < c, rows x_ld / y_ld floats apart; the
+ * mask is that of the dense [pixels, c] tensor (element p * c + ch), so slice and dense forms agree.  rate 0 = a copy.
+ * Concat-free DenseNet blocks (densenet.py:117-121): a growth layer's output goes straight into its channel slice of the
+ * block's buffer; in the backward pass its gradient slice is read out of the block's gradient buffer. */
+int rn_dropout_strided(const float* x, float* y, int64_t pixels, int c, int x_ld, int x_coff, int y_ld, int y_coff, float rate,
+                       uint64_t seed, const uint64_t* seed_dev, rn_stream_t stream);
 /* tf.layers.MaxPooling2D(k, stride, 'same') (resnet.py:200, densenet.py:180): padded cells never win; the
  * gradient goes to the first maximum of each window.  tf.layers.AveragePooling2D(k, stride, 'same')
  * (densenet.py:144): divides by the number of valid cells. */

@@ -83,7 +83,7 @@ class DwGnParams(C.Structure):
 class GnSeg(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("residual", C.c_void_p), ("dy", C.c_void_p),
                 ("dx", C.c_void_p), ("dresidual", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
-                ("n", C.c_int32), ("hw", C.c_int32)]
+                ("n", C.c_int32), ("hw", C.c_int32), ("x_ld", C.c_int32), ("dx_ld", C.c_int32), ("dx_accumulate", C.c_int32)]
 
 
 class GnParams(C.Structure):
@@ -125,7 +125,7 @@ SYMBOLS = [
     "rn_group_norm_sync_bytes", "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
     "rn_pack_weights_f16", "rn_cast_f32_to_f16", "rn_pad_cast_rgb_f16", "rn_conv2d_fwd_f16", "rn_maxpool_fwd_f16", "rn_upsample_add_fwd_f16",
-    "rn_act_fwd_f16", "rn_flip_width", "rn_dropout", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_maxpool_bwd_arg", "rn_avgpool_fwd", "rn_avgpool_bwd",
+    "rn_act_fwd_f16", "rn_flip_width", "rn_dropout", "rn_dropout_strided", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_maxpool_bwd_arg", "rn_avgpool_fwd", "rn_avgpool_bwd",
     "rn_loss_workspace", "rn_loss_fwd", "rn_loss_bwd",
     "rn_iou", "rn_anchor_assign", "rn_anchor_assign_levels", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
     "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
@@ -210,6 +210,7 @@ def lib():
         L.rn_upsample_add_fwd_f16.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_act_fwd_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.rn_flip_width.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.rn_dropout_strided.argtypes = [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 5 + [C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]
         L.rn_dropout.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p]
         L.rn_maxpool_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_maxpool_bwd_arg.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]

@@ -482,3 +482,41 @@ extern "C" int rn_add_segs(const rn_add_seg* segs, int nseg, rn_stream_t stream)
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
+
+// Dropout (rate 0: a plain copy) between channel slices of wider buffers: the growth layers of a concat-free DenseNet
+// block write their k channels straight into the block's buffer, and read their gradient slice out of it.
+namespace {
+__global__ __launch_bounds__(256) void dropout_strided_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t pixels, int c,
+                                                              int x_ld, int x_coff, int y_ld, int y_coff, float rate, uint64_t seed,
+                                                              const uint64_t* __restrict__ seed_dev) {
+  const uint64_t sd = seed + (seed_dev ? *seed_dev : 0ull);
+  const float ks = rate > 0.f ? 1.f / (1.f - rate) : 1.f;
+  const int cq = c >> 2;
+  const int64_t total = pixels * cq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / cq;
+    const int q = (int)(i - p * cq);
+    float4 v = *reinterpret_cast<const float4*>(x + p * x_ld + x_coff + q * 4);
+    if (rate > 0.f) {
+      const uint64_t e = (uint64_t)p * (uint64_t)c + (uint64_t)q * 4;   // element index in the dense [pixels, c] tensor
+      v.x = rn::uniform01(sd, e) >= rate ? v.x * ks : 0.f;
+      v.y = rn::uniform01(sd, e + 1) >= rate ? v.y * ks : 0.f;
+      v.z = rn::uniform01(sd, e + 2) >= rate ? v.z * ks : 0.f;
+      v.w = rn::uniform01(sd, e + 3) >= rate ? v.w * ks : 0.f;
+    }
+    *reinterpret_cast<float4*>(y + p * y_ld + y_coff + q * 4) = v;
+  }
+}
+}  // namespace
+
+extern "C" int rn_dropout_strided(const float* x, float* y, int64_t pixels, int c, int x_ld, int x_coff, int y_ld, int y_coff,
+                                  float rate, uint64_t seed, const uint64_t* seed_dev, rn_stream_t stream) {
+  RN_CHECK_ARG(x && y && pixels >= 0 && c >= 4 && rate >= 0.f && rate < 1.f, "dropout_strided: bad argument");
+  RN_CHECK_ARG(c % 4 == 0 && x_ld % 4 == 0 && y_ld % 4 == 0 && x_coff % 4 == 0 && y_coff % 4 == 0 && x_coff >= 0 && y_coff >= 0 &&
+                   x_ld >= x_coff + c && y_ld >= y_coff + c, "dropout_strided: slices must be 16-byte aligned and inside their rows");
+  if (pixels == 0) return RN_OK;
+  hipLaunchKernelGGL(dropout_strided_kernel, dim3(grid_for(pixels * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, y, pixels, c, x_ld,
+                     x_coff, y_ld, y_coff, rate, seed, seed_dev);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}

@@ -20,6 +20,9 @@ struct GnSeg {
   int chunk_start;   // first partial row
   int chunks;        // chunks per sample
   int ppc;           // pixels per chunk
+  int x_ld;          // floats between consecutive pixels of x (c when dense): x may be the first c channels of a wider buffer
+  int dx_ld;         // the same for dx; dx_acc != 0: dx += (several layers of a DenseNet block feed one gradient buffer)
+  int dx_acc;
 };
 
 struct GnArgs {
@@ -38,6 +41,7 @@ struct GnArgs {
   unsigned long long* xchg;  // grid-resident path: [total_chunks][groups][2] tagged per-block group sums (inside the sync region)
   unsigned* sync;            // grid-resident path: leave counter, call counter, error word (caller-owned, zero-initialised)
   int coop_ppc, coop_r;  // grid-resident path: pixels per block, float4 values per thread
+  int strided;     // some segment reads a channel prefix of a wider buffer / accumulates dx: three-kernel path only
   int slice_wc;    // slice-resident path: channels per block (a whole number of groups), 0 = not used
   float* pgrad;    // slice-resident bwd: [2][total_samples][c] per-sample sum g (plane 0) and sum g*xhat (plane 1)
 };
@@ -70,7 +74,8 @@ __global__ __launch_bounds__(T) void gn_partial_kernel(const GnArgs a) {
   const int lanes = T / QP;
   const int p_begin = ck * sg.ppc, p_end = min(p_begin + sg.ppc, sg.hw);
   const size_t base = (size_t)nl * sg.hw * C;
-  const float* __restrict__ x = sg.x + base;
+  const size_t xbase = (size_t)nl * sg.hw * sg.x_ld;
+  const float* __restrict__ x = sg.x + xbase;
   const float* __restrict__ dy = BWD ? sg.dy + base : nullptr;
   const float* __restrict__ rs = (BWD && a.act_after_res && sg.res) ? sg.res + base : nullptr;
 
@@ -95,8 +100,8 @@ __global__ __launch_bounds__(T) void gn_partial_kernel(const GnArgs a) {
     if (pl < lanes && q4 < CQ) {
 #pragma unroll 4
       for (int p = p_begin + pl; p < p_end; p += lanes) {
-        const size_t off = (size_t)p * C + q4 * 4;
-        const float4 xv = BWD ? *reinterpret_cast<const float4*>(x + off) : rn::ld4(sg.x, base + off, a.in_half);
+        const size_t off = (size_t)p * C + q4 * 4, xoff = (size_t)p * sg.x_ld + q4 * 4;
+        const float4 xv = BWD ? *reinterpret_cast<const float4*>(x + xoff) : rn::ld4(sg.x, xbase + xoff, a.in_half);
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         if (!BWD) {
 #pragma unroll
@@ -238,17 +243,21 @@ __global__ __launch_bounds__(T) void gn_apply_kernel(const GnArgs a) {
   }
   __syncthreads();
   const size_t base = (size_t)nl * sg.hw * C;
-  const float* __restrict__ x = sg.x + base;
+  const size_t xbase = (size_t)nl * sg.hw * sg.x_ld;
+  const float* __restrict__ x = sg.x + xbase;
   const bool drop = a.drop_rate > 0.f;
   const float keep_scale = drop ? 1.f / (1.f - a.drop_rate) : 1.f;
   const uint64_t samp_off = (uint64_t)q * (uint64_t)sg.hw * (uint64_t)C;
   const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
   const int64_t total = (int64_t)sg.hw * CQ;
+  const bool strided = sg.x_ld != C || (BWD && sg.dx_ld != C);
 #pragma unroll 2
   for (int64_t i = (int64_t)blockIdx.x * T + tid; i < total; i += (int64_t)gridDim.x * T) {
     const int q4 = (int)(i % CQ);
     const size_t off = (size_t)i * 4;
-    const float4 xv = BWD ? *reinterpret_cast<const float4*>(x + off) : rn::ld4(sg.x, base + off, a.in_half);
+    const int64_t pix = strided ? i / CQ : 0;
+    const size_t xoff = strided ? (size_t)pix * sg.x_ld + q4 * 4 : off;
+    const float4 xv = BWD ? *reinterpret_cast<const float4*>(x + xoff) : rn::ld4(sg.x, xbase + xoff, a.in_half);
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
     float o[4];
     if (!BWD) {
@@ -286,7 +295,12 @@ __global__ __launch_bounds__(T) void gn_apply_kernel(const GnArgs a) {
         gr[j] = g;
         o[j] = tab[c][1] * (tab[c][2] * g - tab[c][4] - xh * tab[c][5]);
       }
-      *reinterpret_cast<float4*>(sg.dx + base + off) = make_float4(o[0], o[1], o[2], o[3]);
+      float* dxp = sg.dx + (strided ? (size_t)nl * sg.hw * sg.dx_ld + (size_t)pix * sg.dx_ld + q4 * 4 : base + off);
+      if (sg.dx_acc) {
+        const float4 old = *reinterpret_cast<const float4*>(dxp);
+        o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+      }
+      *reinterpret_cast<float4*>(dxp) = make_float4(o[0], o[1], o[2], o[3]);
       if (aar && sg.dres) *reinterpret_cast<float4*>(sg.dres + base + off) = make_float4(gr[0], gr[1], gr[2], gr[3]);
     }
   }
@@ -895,7 +909,7 @@ __global__ __launch_bounds__(CT) void gn_coop_bwd_kernel(const GnArgs a) {
 
 // chunking of the grid-resident path; false when the call does not qualify
 bool plan_coop(GnArgs* a) {
-  if (!a->sync || getenv("RN_GN_NO_COOP")) return false;
+  if (!a->sync || a->strided || getenv("RN_GN_NO_COOP")) return false;
   if (a->in_half || a->out_half || a->act == RN_ACT_SIGMOID) return false;
   const int CQ = a->c / 4;
   if (a->c > COOP_MAX_C || a->groups > COOP_MAX_C || CQ > CT) return false;
@@ -952,7 +966,7 @@ void launch_coop(const GnArgs& a, hipStream_t st) {
 // choose the block width of the slice-resident path; returns R (pixels per thread) or 0 when a slice does not fit
 int plan_slices(GnArgs* a) {
   a->slice_wc = 0;
-  if (getenv("RN_GN_NO_SLICE")) return 0;  // tuning aid: force the three-kernel path
+  if (a->strided || getenv("RN_GN_NO_SLICE")) return 0;  // (tuning aid: force the three-kernel path)
   if (a->in_half || a->out_half || a->cpg > SLICE_MAX_WC || a->act == RN_ACT_SIGMOID) return 0;
   int max_hw = 0;
   for (int s = 0; s < a->nseg; ++s) max_hw = max_hw > a->seg[s].hw ? max_hw : a->seg[s].hw;
@@ -1047,6 +1061,12 @@ int build_args(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, GnArgs* a
     d.x = segs[s].x; d.y = segs[s].y; d.res = segs[s].residual; d.dy = segs[s].dy; d.dx = segs[s].dx;
     d.dres = segs[s].dresidual;
     d.mean = segs[s].mean; d.rstd = segs[s].rstd; d.n = segs[s].n; d.hw = segs[s].hw;
+    d.x_ld = segs[s].x_ld > 0 ? segs[s].x_ld : p->c;
+    d.dx_ld = segs[s].dx_ld > 0 ? segs[s].dx_ld : p->c;
+    d.dx_acc = segs[s].dx_accumulate ? 1 : 0;
+    RN_CHECK_ARG(d.x_ld >= p->c && d.x_ld % 4 == 0 && d.dx_ld >= p->c && d.dx_ld % 4 == 0, "group_norm: bad x_ld / dx_ld in segment %d", s);
+    RN_UNSUPPORTED((d.x_ld != p->c || d.dx_ld != p->c || d.dx_acc) && (p->in_f16 || p->out_f16), "group_norm: strided views are fp32 only");
+    if (d.x_ld != p->c || d.dx_ld != p->c || d.dx_acc) a->strided = 1;
     d.sample_start = samples; d.chunk_start = chunks;
     long elems = (long)d.hw * p->c;
     const long per = elems >= (4L << 20) ? 16384 : 4096;  // small tensors are latency-bound: more, shorter blocks

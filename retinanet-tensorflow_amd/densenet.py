@@ -18,6 +18,7 @@ from model import Model, Sequential
 from normalization import Normalization
 
 Dropout = L.Dropout
+CONCAT_FREE = True      # dense blocks on one buffer per block (ops.dense_block) instead of a concat per layer
 
 
 class CompositeFunction(Sequential):
@@ -66,10 +67,33 @@ class DenseNet_Block(Model):
         self.out_channels = c
 
     def call(self, input, training):
-        for f in self.composite_functions:
+        out = self._concat_free(input, training)
+        if out is not None:
+            return out
+        for f in self.composite_functions:               # (fp16 inference / non-bottleneck blocks: layer by layer)
             output = f(input, training)
-            input = torch.cat([input, output], -1)       # growth concat (densenet.py:119); pure data movement
+            input = torch.cat([input, output], -1)       # growth concat (densenet.py:119)
         return input
+
+    def _concat_free(self, input, training):
+        """The block on ONE pre-allocated [n,h,w,c_total] buffer (ops.dense_block): every layer normalises a channel prefix of
+        it in place and writes its k channels into their slice -- no concat, no copy of the growing tensor."""
+        import ops
+        fns = self.composite_functions
+        if (not CONCAT_FREE or not fns or not isinstance(fns[0], BottleneckCompositeFunction) or not input.is_cuda or
+                input.dtype != torch.float32 or (L.INFERENCE_F16 and not training) or input.shape[3] % 4):
+            return None
+        layers, seeds = [], []
+        for f in fns:
+            n1, a1, c1, d1, n2, a2, c2, d2 = f.layers
+            if c1.weight is None or c2.weight is None or n1.gamma is None or n2.gamma is None:
+                return None
+            layers.append((n1.gamma, n1.beta, c1.weight, n2.gamma, n2.beta, c2.weight))
+            seeds.append((d1.seed, d2.seed))
+        n1, a1, _c1, d1 = fns[0].layers[:4]
+        rate = d1.rate if training else 0.0
+        return ops.dense_block(input, layers, fns[0].layers[6].filters, n1.groups, n1.eps, L.activation_name(a1), rate, seeds,
+                               L.Dropout.seed_device_counter if rate > 0.0 else None)
 
 
 class TransitionLayer(Sequential):
@@ -121,9 +145,13 @@ class DenseNetBC_ImageNet(Model):
         input = self.conv1(input, training)
         out['C1'] = input
         input = self.conv1_max_pool(input)
+        import ops
         for i in range(1, 5):
             input = getattr(self, 'dense_block_%d' % i)(input, training)
-            out['C%d' % (i + 1)] = input
+            if i in (2, 3) and input.dtype == torch.float32:        # C3, C4 feed the transition AND the pyramid: one summed gradient
+                out['C%d' % (i + 1)], input = ops.fanout(input, 2)
+            else:
+                out['C%d' % (i + 1)] = input
             if i < 4:
                 input = getattr(self, 'transition_layer_%d' % i)(input, training)
         return out

@@ -1074,6 +1074,148 @@ def dropout(x, rate, seed=0, seed_dev=None):
     return _Dropout.apply(x, float(rate), int(seed), seed_dev)
 
 
+# ---------------------------------------------------------------------------------------- concat-free DenseNet block
+def _gn_raw(fwd, x, x_ld, c, n, hw, gamma, beta, groups, eps, act, mean, rstd, y=None, dy=None, dx=None, dx_ld=0, dx_acc=False,
+            dgamma=None, dbeta=None):
+    """One rn_group_norm_fwd / _bwd call on raw buffers (x may be the first c channels of a buffer with x_ld channels)."""
+    L = _rn.lib()
+    dev = gamma.device
+    g = gn_groups(c, groups)
+    params = _gn_params(c, g, eps, act, 0.0, 0, None, False, dev)
+    segs = (_rn.GnSeg * 1)()
+    sg = segs[0]
+    sg.x, sg.mean, sg.rstd, sg.n, sg.hw, sg.x_ld = x.data_ptr(), _rn.f32(mean), _rn.f32(rstd), n, hw, x_ld
+    if fwd:
+        sg.y = _rn.f32(y)
+        ws = _rn.workspace(L.rn_group_norm_workspace(segs, 1, C.byref(params)), dev)
+        _rn.check(L.rn_group_norm_fwd(segs, 1, C.byref(params), _rn.f32(gamma), _rn.f32(beta), ws.data_ptr(), ws.numel(), _rn.stream()),
+                  "rn_group_norm_fwd")
+    else:
+        sg.dy, sg.dx, sg.dx_ld, sg.dx_accumulate = _rn.f32(dy), dx.data_ptr(), dx_ld, 1 if dx_acc else 0
+        ws = _grad_workspace(L.rn_group_norm_workspace(segs, 1, C.byref(params)), dev)
+        _rn.check(L.rn_group_norm_bwd(segs, 1, C.byref(params), _rn.f32(gamma), _rn.f32(beta), _rn.f32(dgamma), _rn.f32(dbeta),
+                                      ws.data_ptr(), ws.numel(), _rn.stream(), _defer_arg()), "rn_group_norm_bwd")
+
+
+def _conv_bwd_raw(x, w, dy, stride=1):
+    """dx and dw of a dense conv through the merged kernel when it applies (rn_conv2d_bwd), else dgrad + wgrad."""
+    L = _rn.lib()
+    kh, kw, cin, cout = w.shape
+    geom = _rn.ConvGeom(kh, kw, stride, cin, 1)
+    dx = torch.empty_like(x)
+    segs = _conv_segs([x], w, None, None, [dy], [dx])
+    dw_buf, dw = _grad_slot(w)
+    need = L.rn_conv2d_wgrad_workspace(segs, 1, C.byref(geom))
+    ws = _grad_workspace(need, w.device)
+    if MERGED_CONV_BWD and L.rn_conv2d_dgrad_workspace(segs, 1, C.byref(geom)) == 0:
+        _rn.check(L.rn_conv2d_bwd(segs, 1, C.byref(geom), _rn.f32(dw_buf), ws.data_ptr(), ws.numel(), _rn.stream(), _defer_arg()),
+                  "rn_conv2d_bwd")
+    else:
+        _conv_dgrad(segs, 1, geom, w.device)
+        _rn.check(L.rn_conv2d_wgrad(segs, 1, C.byref(geom), _rn.f32(dw_buf), 0, ws.data_ptr(), ws.numel(), _rn.stream(), _defer_arg()),
+                  "rn_conv2d_wgrad")
+    return dx, dw
+
+
+class _DenseBlock(torch.autograd.Function):
+    """A DenseNet-BC block (densenet.py:83-121) without the growth concat: ONE [n,h,w,c_total] buffer; layer i
+    (GN-act-1x1(4k)-drop-GN-act-3x3(k)-drop, densenet.py:50-80) normalises the first c_i channels in place (rn_gn_seg.x_ld) and
+    its k output channels are written straight into their slice (rn_dropout_strided).  Backward: one gradient buffer; each
+    layer reads its slice and ADDS the gradient of its input prefix (rn_gn_seg.dx_accumulate), last layer first."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, *params):
+        depth, k, groups, eps, act, rate, seeds, seed_dev = cfg
+        L = _rn.lib()
+        x = x.contiguous()
+        n, h, w, c_in = x.shape
+        dev = x.device
+        hw, px = h * w, n * h * w
+        ct = c_in + depth * k
+        sd = seed_dev.data_ptr() if seed_dev is not None else None
+        buf = torch.empty((n, h, w, ct), dtype=torch.float32, device=dev)
+        _rn.check(L.rn_dropout_strided(_rn.f32(x), _rn.f32(buf), px, c_in, c_in, 0, ct, 0, 0.0, 0, None, _rn.stream()), "rn_dropout_strided")
+        saved = []
+        for i in range(depth):
+            g1, b1, w1, g2, b2, w2 = params[6 * i:6 * i + 6]
+            ci, c4 = c_in + i * k, w1.shape[3]
+            gr1, gr2 = gn_groups(ci, groups), gn_groups(c4, groups)
+            a = torch.empty((n, h, w, ci), dtype=torch.float32, device=dev)
+            m1, r1 = torch.empty((n, gr1), device=dev), torch.empty((n, gr1), device=dev)
+            _gn_raw(True, buf, ct, ci, n, hw, g1, b1, groups, eps, act, m1, r1, y=a)
+            y1 = torch.empty((n, h, w, c4), dtype=torch.float32, device=dev)
+            _conv_fwd(_conv_segs([a], w1, None, [y1], None, None), 1, _rn.ConvGeom(1, 1, 1, ci, 1), dev)
+            d1 = y1
+            if rate > 0.0:
+                d1 = torch.empty_like(y1)
+                _rn.check(L.rn_dropout(_rn.f32(y1), _rn.f32(d1), y1.numel(), rate, seeds[i][0], sd, _rn.stream()), "rn_dropout")
+            a2 = torch.empty_like(d1)
+            m2, r2 = torch.empty((n, gr2), device=dev), torch.empty((n, gr2), device=dev)
+            _gn_raw(True, d1, 0, c4, n, hw, g2, b2, groups, eps, act, m2, r2, y=a2)
+            y2 = torch.empty((n, h, w, k), dtype=torch.float32, device=dev)
+            _conv_fwd(_conv_segs([a2], w2, None, [y2], None, None), 1, _rn.ConvGeom(3, 3, 1, c4, 1), dev)
+            _rn.check(L.rn_dropout_strided(_rn.f32(y2), _rn.f32(buf), px, k, k, 0, ct, ci, rate, seeds[i][1], sd, _rn.stream()),
+                      "rn_dropout_strided")
+            saved += [a, m1, r1, d1, a2, m2, r2]
+        ctx.cfg = cfg
+        ctx.nparams = len(params)
+        ctx.save_for_backward(buf, *params, *saved)
+        return buf
+
+    @staticmethod
+    def backward(ctx, dbuf_in):
+        depth, k, groups, eps, act, rate, seeds, seed_dev = ctx.cfg
+        L = _rn.lib()
+        tensors = ctx.saved_tensors
+        buf = tensors[0]
+        params = tensors[1:1 + ctx.nparams]
+        saved = tensors[1 + ctx.nparams:]
+        n, h, w, ct = buf.shape
+        dev = buf.device
+        hw, px = h * w, n * h * w
+        c_in = ct - depth * k
+        sd = seed_dev.data_ptr() if seed_dev is not None else None
+        dbuf_in = dbuf_in.contiguous()
+        dbuf = torch.empty_like(buf)                  # this node's own gradient buffer: the layers accumulate into it
+        _rn.check(L.rn_dropout_strided(_rn.f32(dbuf_in), _rn.f32(dbuf), px, ct, ct, 0, ct, 0, 0.0, 0, None, _rn.stream()), "rn_dropout_strided")
+        grads = [None] * ctx.nparams
+        for i in range(depth - 1, -1, -1):
+            g1, b1, w1, g2, b2, w2 = params[6 * i:6 * i + 6]
+            a, m1, r1, d1, a2, m2, r2 = saved[7 * i:7 * i + 7]
+            ci, c4 = c_in + i * k, w1.shape[3]
+            dy2 = torch.empty((n, h, w, k), dtype=torch.float32, device=dev)
+            _rn.check(L.rn_dropout_strided(_rn.f32(dbuf), _rn.f32(dy2), px, k, ct, ci, k, 0, rate, seeds[i][1], sd, _rn.stream()),
+                      "rn_dropout_strided")
+            da2, dw2 = _conv_bwd_raw(a2, w2, dy2)
+            dd1 = torch.empty_like(d1)
+            dg2_buf, dg2 = _grad_slot(g2)
+            db2_buf, db2 = _grad_slot(b2)
+            _gn_raw(False, d1, 0, c4, n, hw, g2, b2, groups, eps, act, m2, r2, dy=da2, dx=dd1, dgamma=dg2_buf, dbeta=db2_buf)
+            dy1 = dd1
+            if rate > 0.0:
+                dy1 = torch.empty_like(dd1)
+                _rn.check(L.rn_dropout(_rn.f32(dd1), _rn.f32(dy1), dd1.numel(), rate, seeds[i][0], sd, _rn.stream()), "rn_dropout")
+            da, dw1 = _conv_bwd_raw(a, w1, dy1)
+            dg1_buf, dg1 = _grad_slot(g1)
+            db1_buf, db1 = _grad_slot(b1)
+            _gn_raw(False, buf, ct, ci, n, hw, g1, b1, groups, eps, act, m1, r1, dy=da, dx=dbuf, dx_ld=ct, dx_acc=True, dgamma=dg1_buf,
+                    dbeta=db1_buf)
+            grads[6 * i:6 * i + 6] = [dg1, db1, dw1, dg2, db2, dw2]
+        dx = torch.empty((n, h, w, c_in), dtype=torch.float32, device=dev)
+        _rn.check(L.rn_dropout_strided(_rn.f32(dbuf), _rn.f32(dx), px, c_in, ct, 0, c_in, 0, 0.0, 0, None, _rn.stream()), "rn_dropout_strided")
+        return (None, dx) + tuple(grads)
+
+
+def dense_block(x, layers, k, groups=32, eps=1e-5, act=None, rate=0.0, seeds=None, seed_dev=None):
+    """`layers`: [(gamma1, beta1, w1 [1,1,c_i,4k], gamma2, beta2, w2 [3,3,4k,k])] -> the block's [n,h,w,c_in + len(layers) k]
+    output (input channels first, then every layer's k channels: the order of the reference's concat, densenet.py:119)."""
+    depth = len(layers)
+    seeds = tuple(seeds) if seeds is not None else tuple((0, 0) for _ in range(depth))
+    cfg = (depth, int(k), int(groups), float(eps), act, float(rate), seeds, seed_dev)
+    flat = [t for layer in layers for t in layer]
+    return _DenseBlock.apply(cfg, x, *flat)
+
+
 class _MaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, k, stride):

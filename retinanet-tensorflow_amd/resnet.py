@@ -113,9 +113,13 @@ class ResNeXt(Model):
         input = self._conv_1(input, training=training)
         out['C1'] = input
         input = self._conv_1_max_pool(input)
+        import ops
         for i, stage in enumerate((self._conv_2, self._conv_3, self._conv_4, self._conv_5)):
             input = stage(input, training=training)
-            out['C%d' % (i + 2)] = input
+            if i in (1, 2) and input.dtype == L.torch.float32:      # C3, C4 feed the next stage AND the pyramid: one summed gradient
+                out['C%d' % (i + 2)], input = ops.fanout(input, 2)
+            else:
+                out['C%d' % (i + 2)] = input
         return out
 
 

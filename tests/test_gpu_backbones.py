@@ -118,3 +118,38 @@ def test_retinanet_with_backbone_trains(dev, backbone):
         o = net(image, training=False)
     for k, s in zip(("P3", "P4", "P5", "P6", "P7"), (12, 6, 3, 2, 1)):
         assert o["classifications"][k].shape == (2, s, s, 9, 5) and o["regressions"][k].shape == (2, s, s, 9, 4)
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.2])
+def test_concat_free_dense_block_equals_concat_form(dev, rate):
+    """A DenseNet-BC block on one buffer (ops.dense_block: channel-prefix GroupNorm reads, slice writes, accumulated prefix
+    gradients) == the reference's literal form (a concat per layer, densenet.py:117-121), forward and every gradient, with the
+    same dropout masks."""
+    import densenet, layers
+    torch.manual_seed(3)
+    blk = densenet.DenseNet_Block(32, depth=4, bottleneck=True, activation=layers.elu, dropout_rate=rate,
+                                  kernel_initializer=layers.VarianceScaling(2.0), kernel_regularizer=layers.L2Regularizer(1e-4),
+                                  in_channels=64)
+    _randomize(blk, 5)
+    blk.to(dev)
+    counter = torch.tensor([99], dtype=torch.int64, device=dev)
+    layers.Dropout.seed_device_counter = counter
+    x = torch.randn(2, 12, 10, 64, device=dev, requires_grad=True)
+    outs, grads = [], []
+    try:
+        for free in (True, False):
+            densenet.CONCAT_FREE = free
+            y = blk(x, training=True)
+            assert y.shape == (2, 12, 10, 64 + 4 * 32)
+            g = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+            grads.append(torch.autograd.grad(y, [x] + list(blk.parameters()), g))
+            outs.append(y.detach())
+    finally:
+        densenet.CONCAT_FREE = True
+        layers.Dropout.seed_device_counter = None
+    assert_close(outs[0].cpu().numpy(), outs[1].cpu().numpy(), 1e-5, "dense block forward")
+    if rate > 0:
+        assert torch.equal(outs[0] == 0, outs[1] == 0)
+    names = ["dx"] + [n for n, _ in blk.named_parameters()]
+    for name, a, b in zip(names, grads[0], grads[1]):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4, "dense block " + name)

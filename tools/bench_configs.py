@@ -12,10 +12,10 @@ import bench
 def run(backbone, size, batch, steps=8, warmup=3, use_graph=True):
     import dataset, layers, levels, retinanet, train
     dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
     torch.manual_seed(0)
     lv = levels.build_levels()
     net = retinanet.RetinaNet(backbone, lv, 80, layers.elu, 0.2).to(dev)
-    trainer = train.Trainer(net, lv, loss_mode="focal", device=dev)
     rng = np.random.default_rng(0)
     image = torch.randn(batch, size, size, 3, device=dev)
     boxes = np.zeros((batch, 32, 4), np.float32); cls = np.zeros((batch, 32), np.int32); nobj = np.zeros(batch, np.int32)
@@ -24,33 +24,18 @@ def run(backbone, size, batch, steps=8, warmup=3, use_graph=True):
         boxes[i], cls[i], nobj[i] = b, c, o
     boxes, cls, nobj = (torch.from_numpy(a).to(dev) for a in (boxes, cls, nobj))
 
-    def local():
+    def features():
         c, r, m = dataset.build_labels((size, size), cls, boxes, lv, 80, num_obj=nobj)
-        return trainer.forward_backward({"image": image, "detection": {"classifications": c, "regressions": r},
-                                         "trainable_masks": m})
-    graph = None
-    if use_graph:
-        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                local()
-        torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = local()
+        return {"image": image, "detection": {"classifications": c, "regressions": r}, "trainable_masks": m}
 
-    def step():
-        if graph is not None:
-            graph.replay()
-        else:
-            local()
-        trainer.opt.step(1.0)
+    trainer = train.Trainer(net, lv, loss_mode="focal", device=dev, use_graph=use_graph, input_fn=features)
     for _ in range(warmup):
-        step()
+        trainer.step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        trainer.step()
     torch.cuda.synchronize(); el = time.perf_counter() - t0
+    trainer.check_device_errors()
     return {"backbone": backbone, "image_size": size, "batch": batch, "images_per_sec": round(batch * steps / el, 2),
             "ms_per_step": round(1e3 * el / steps, 2), "hip_graph": use_graph,
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
