@@ -1,11 +1,23 @@
 #!/bin/bash
-# Round-end evidence run (GPU box): full GPU test suite, smoke, the bench line, its rocprofv3 summary, the other configs.
+# Round-end evidence run (GPU box): full GPU test suite, smoke, the bench line, its rocprofv3 summary, PMC traffic of the
+# roofline kernels, the other configs.  Summaries are copied into profiles/ by hand afterwards (see profiles/README.md).
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > gpurun_out/final_tests.log
-timeout 300 python __graft_entry__.py smoke > gpurun_out/final_smoke.log 2>&1
-timeout 400 python bench.py > gpurun_out/final_bench.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_prof -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/final_prof.log 2>&1
-timeout 600 python tools/bench_configs.py > gpurun_out/final_cfgs.log 2>&1
-timeout 400 python tools/bench_inference.py > gpurun_out/final_inf.log 2>&1
+R=${ROUND:-r02}
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > gpurun_out/${R}_tests.log
+timeout 300 python __graft_entry__.py smoke > gpurun_out/${R}_smoke.log 2>&1
+timeout 600 python bench.py > gpurun_out/${R}_bench.log 2>&1
+rm -rf gpurun_out/${R}_prof gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_prof -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${R}_prof.log 2>&1
+TRACE=$(find gpurun_out/${R}_prof -name "bench_kernel_trace.csv" | head -1)
+python tools/timeline.py $TRACE > gpurun_out/${R}_bench_step_timeline.txt
+python tools/by_grid.py $TRACE > gpurun_out/${R}_bench_kernel_trace_by_grid.txt
+cp $(find gpurun_out/${R}_prof -name "bench_kernel_stats.csv" | head -1) gpurun_out/${R}_bench_kernel_stats.csv
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${R}_pmc_fetch -- python tools/gemm_pmc.py > gpurun_out/${R}_pmc_f.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${R}_pmc_write -- python tools/gemm_pmc.py > gpurun_out/${R}_pmc_w.log 2>&1
+python tools/pmc_traffic.py gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write > gpurun_out/${R}_pmc_traffic.json
+timeout 600 python tools/bench_configs.py > gpurun_out/${R}_cfgs.log 2>&1
+timeout 400 python tools/bench_inference.py > gpurun_out/${R}_inf.log 2>&1
+timeout 200 python tools/tower_bench.py 720 > gpurun_out/${R}_tower.log 2>&1
+tail -3 gpurun_out/${R}_tests.log; tail -1 gpurun_out/${R}_smoke.log; tail -1 gpurun_out/${R}_bench.log | cut -c1-400
