@@ -5,16 +5,23 @@ import json
 import os
 
 import torch
-from safetensors.torch import load_file, save_file
+from safetensors import safe_open
+from safetensors.torch import save_file
 
 
 def save(path, net, trainer=None, step=0, extra=None):
+    """Weights under "model/<name>"; optimizer slots PER PARAMETER under "optimizer/state{1,2}/<name>" (independent of the
+    arena's layout); the dropout step counter, so that a resumed run does not replay the masks of step 0."""
     tensors = {"model/" + k: v.detach().cpu().contiguous().clone() for k, v in net.named_parameters()}
-    meta = {"step": str(int(step)), "format": "retinanet-amd-v1"}
+    meta = {"step": str(int(step)), "format": "retinanet-amd-v2"}
     if trainer is not None:
-        tensors["optimizer/state1"] = trainer.opt.state1.detach().cpu().clone()
-        if trainer.opt.state2 is not None:
-            tensors["optimizer/state2"] = trainer.opt.state2.detach().cpu().clone()
+        names = {id(p): k for k, p in net.named_parameters()}
+        for p, (off, size) in zip(trainer.arena.params, trainer.arena.offsets):
+            name = names[id(p)]
+            tensors["optimizer/state1/" + name] = trainer.opt.state1[off:off + size].detach().cpu().clone().view(p.shape)
+            if trainer.opt.state2 is not None:
+                tensors["optimizer/state2/" + name] = trainer.opt.state2[off:off + size].detach().cpu().clone().view(p.shape)
+        tensors["trainer/drop_counter"] = trainer.drop_counter.detach().cpu().clone()
         meta.update(optimizer=trainer.opt.kind, step_count=str(trainer.opt.step_count))
     if extra:
         meta["extra"] = json.dumps(extra)
@@ -25,18 +32,35 @@ def save(path, net, trainer=None, step=0, extra=None):
 
 
 def load(path, net, trainer=None):
-    """Restores in place (the parameters keep pointing into the trainer's arena).  Returns the saved step."""
-    from safetensors import safe_open
-    tensors = load_file(path)
+    """Restores in place (the parameters keep pointing into the trainer's arena).  Returns the saved step.
+    Missing keys and shape mismatches raise a ValueError that names the parameter."""
     with safe_open(path, framework="pt") as f:
         meta = f.metadata() or {}
-    with torch.no_grad():
-        for k, p in net.named_parameters():
-            p.copy_(tensors["model/" + k].to(p.device))
-        if trainer is not None and "optimizer/state1" in tensors:
-            assert meta.get("optimizer") == trainer.opt.kind, "checkpoint optimizer %s != %s" % (meta.get("optimizer"), trainer.opt.kind)
-            trainer.opt.state1.copy_(tensors["optimizer/state1"].to(trainer.opt.state1.device))
-            if trainer.opt.state2 is not None:
-                trainer.opt.state2.copy_(tensors["optimizer/state2"].to(trainer.opt.state2.device))
-            trainer.opt.step_count = int(meta.get("step_count", 0))
+        keys = set(f.keys())
+
+        def get(key, like):
+            if key not in keys:
+                raise ValueError("checkpoint %s has no tensor %r" % (path, key))
+            t = f.get_tensor(key)
+            if tuple(t.shape) != tuple(like.shape):
+                raise ValueError("checkpoint %s: %r has shape %s, the model expects %s" % (path, key, tuple(t.shape), tuple(like.shape)))
+            return t
+
+        with torch.no_grad():
+            for k, p in net.named_parameters():
+                p.copy_(get("model/" + k, p).to(p.device))
+            if trainer is not None and meta.get("optimizer") is not None:
+                if meta.get("optimizer") != trainer.opt.kind:
+                    raise ValueError("checkpoint optimizer %s != %s" % (meta.get("optimizer"), trainer.opt.kind))
+                names = {id(p): k for k, p in net.named_parameters()}
+                for p, (off, size) in zip(trainer.arena.params, trainer.arena.offsets):
+                    name = names[id(p)]
+                    trainer.opt.state1[off:off + size].copy_(get("optimizer/state1/" + name, p).reshape(-1).to(trainer.opt.state1.device))
+                    if trainer.opt.state2 is not None:
+                        trainer.opt.state2[off:off + size].copy_(get("optimizer/state2/" + name, p).reshape(-1).to(trainer.opt.state2.device))
+                if "trainer/drop_counter" in keys:
+                    trainer.drop_counter.copy_(f.get_tensor("trainer/drop_counter").to(trainer.drop_counter.device))
+                trainer.opt.step_count = int(meta.get("step_count", 0))
+    import ops_f16
+    ops_f16.weights_changed()
     return int(meta.get("step", 0))

@@ -929,6 +929,7 @@ class _DetectionLoss(torch.autograd.Function):
         ctx.mode, ctx.num_classes, ctx.n = mode, num_classes, n
         ctx.save_for_backward(stats, *cls_logits, *reg_preds, *cls_labels, *reg_labels, *masks)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)       # no zero tensor for the non-differentiable `stats` output
         return class_loss, regr_loss, stats
 
     @staticmethod
@@ -1000,6 +1001,7 @@ class _Fanout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, k, n, *xs):
         ctx.k, ctx.n = k, n
+        ctx.set_materialize_grads(False)       # a branch without a gradient stays None (no zero tensors to add)
         return tuple(x.view_as(x) for _ in range(k) for x in xs)
 
     @staticmethod
@@ -1032,6 +1034,7 @@ class _Add(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, n, *ts):
+        ctx.set_materialize_grads(False)
         outs = []
         for c0 in range(0, n, _rn.MAX_SEG):
             m = min(_rn.MAX_SEG, n - c0)

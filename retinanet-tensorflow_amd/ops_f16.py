@@ -8,7 +8,15 @@ import torch
 import _rn
 from ops import gn_groups
 
-_packed = {}    # (data_ptr, version, shape) -> packed fp16 kernel Wt[cout][K]
+# Packed fp16 kernels are cached ON the weight tensor object (attribute `_rn_f16_cache`), keyed by the tensor's version and
+# WEIGHTS_EPOCH: the optimizer kernel and checkpoint.load write weights through raw pointers (no version bump), so they
+# advance the epoch.  (A cache keyed by data_ptr served another model's kernel once the allocator reused an address.)
+WEIGHTS_EPOCH = 0
+
+
+def weights_changed():
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
 
 
 SUPER_GROUP = 32    # narrow groups are merged into block-diagonal groups of this many input channels
@@ -31,10 +39,11 @@ def packed_weight(w, groups=1, pad_cin_to=None):
       multiplies by zero are free compared with the tile overhead they remove;
     * pad_cin_to: zero-pad the input-channel axis (the RGB stem reads an image padded to 4 channels).
     """
-    key = (w.data_ptr(), w._version, tuple(w.shape), groups, pad_cin_to)
-    hit = _packed.get(key)
-    if hit is not None:
-        return hit
+    key = (WEIGHTS_EPOCH, w._version, w.data_ptr(), groups, pad_cin_to)
+    owner = w
+    cache = getattr(owner, '_rn_f16_cache', None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
     w = w.detach()
     kh, kw, cin_g, cout = w.shape
     g2 = groups
@@ -51,7 +60,7 @@ def packed_weight(w, groups=1, pad_cin_to=None):
             wide[:, :, j * cin_g:(j + 1) * cin_g, cols] = w[:, :, :, cols]
         w, cin_g, g2 = wide, SUPER_GROUP, groups // per
     hit = (_pack(w), g2, cin_g * g2)
-    _packed[key] = hit
+    owner._rn_f16_cache = (key, hit)
     return hit
 
 

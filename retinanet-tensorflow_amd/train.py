@@ -92,6 +92,8 @@ class Optimizer(object):
                                        _rn.f32(self.norm_reg), self.step_count,
                                        advance_counter.data_ptr() if advance_counter is not None else None,
                                        ops.DROPOUT_COUNTER_STEP, _rn.stream()), 'rn_optimizer_step')
+        import ops_f16
+        ops_f16.weights_changed()      # fp16-packed copies of the kernels (inference path) are stale now
 
     @property
     def regularization_loss(self):

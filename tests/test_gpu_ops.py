@@ -728,16 +728,22 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     net = retinanet.RetinaNet('mobilenet_v2', lv, 3, layers.elu, 0.0).to(dev)
     tr = train.Trainer(net, lv, optimizer="rmsprop", device=dev)
     tr.opt.state2.normal_(); tr.opt.step_count = 7
+    tr.drop_counter.fill_(424242)
     ref = {k: v.detach().clone() for k, v in net.named_parameters()}
     s1, s2 = tr.opt.state1.clone(), tr.opt.state2.clone()
     path = str(tmp_path / "ckpt" / "model.safetensors")
     checkpoint.save(path, net, tr, step=123)
     with torch.no_grad():
-        tr.arena.weights.zero_(); tr.opt.state1.zero_(); tr.opt.state2.zero_()
-    assert checkpoint.load(path, net, tr) == 123 and tr.opt.step_count == 7
+        tr.arena.weights.zero_(); tr.opt.state1.zero_(); tr.opt.state2.zero_(); tr.drop_counter.zero_()
+    assert checkpoint.load(path, net, tr) == 123 and tr.opt.step_count == 7 and int(tr.drop_counter.item()) == 424242
     for k, v in net.named_parameters():
         assert torch.equal(v, ref[k]) and v.data_ptr() >= tr.arena.weights.data_ptr()      # still views of the arena
-    assert torch.equal(tr.opt.state1, s1) and torch.equal(tr.opt.state2, s2)
+    for off, size in tr.arena.offsets:       # optimizer slots are stored per parameter (the padding between them is not state)
+        assert torch.equal(tr.opt.state1[off:off + size], s1[off:off + size]) and torch.equal(tr.opt.state2[off:off + size], s2[off:off + size])
+    # a model the file does not fit says which tensor
+    other = retinanet.RetinaNet('mobilenet_v2', lv, 5, layers.elu, 0.0).to(dev)
+    with pytest.raises(ValueError, match="out_conv"):
+        checkpoint.load(path, other)
 
 
 def test_batched_gemm_both_layouts(dev):
