@@ -78,18 +78,24 @@ struct Chunk<false> {
     const float4 t = reinterpret_cast<const float4*>(row)[ci];
     e[0] = t.x; e[1] = t.y; e[2] = t.z; e[3] = t.w;
   }
+  __device__ __forceinline__ float get(int i) const { return e[i]; }
 };
 template <>
-struct Chunk<true> {
+struct Chunk<true> {   // stays packed in registers (4 VGPRs per chunk, not 8): the scan's occupancy is set by its registers
   static constexpr int V = 8;
-  float e[8];
-  __device__ __forceinline__ void load(const void* row, int ci) {
-    const half8 t = reinterpret_cast<const half8*>(row)[ci];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) e[i] = (float)t[i];
-  }
+  half8 t;
+  __device__ __forceinline__ void load(const void* row, int ci) { t = reinterpret_cast<const half8*>(row)[ci]; }
+  __device__ __forceinline__ float get(int i) const { return (float)t[i]; }
 };
 
+// LOGIT: the rows hold logits and the result must be that of "sigmoid every element, then max / first arg-max of the
+// probabilities".  Evaluating 80 exponentials per anchor made the scan ALU-bound (184 us for 528 MB); instead:
+//   1. max logit m of the row and its first index (compares only);
+//   2. p = sigmoid(m); an element can tie with or (through the last-ulp wobble of the hardware exponential) exceed p only
+//      if its logit lies within margin(m) = 5e-7 (1 + e^m) + 1e-6 |m| below m -- that is >= 8 ulp(p) / sigmoid'(m) -- or
+//      both are in the saturated range (> 16: p == 1.0f); only those elements (normally none) get their own sigmoid and
+//      the (greater probability, lower index) rule.
+// Bit-identical to the element-wise form for every input the margin covers, two exponentials per row instead of C.
 template <int Q, bool HALF, bool LOGIT>
 __device__ __forceinline__ void scan_rows_unrolled(const void* __restrict__ base, int C, int nrow, int lane, float* out_s, int* out_c) {
   constexpr int V = Chunk<HALF>::V, ESZ = HALF ? 2 : 4;
@@ -114,7 +120,7 @@ __device__ __forceinline__ void scan_rows_unrolled(const void* __restrict__ base
       const int c = cc[q] * V;
 #pragma unroll
       for (int i = 0; i < V; ++i) {
-        const float pv = to_prob(v[pass][q].e[i], LOGIT);
+        const float pv = v[pass][q].get(i);
         if (pv > best) { best = pv; bi = c + i; }
       }
     }
@@ -123,6 +129,32 @@ __device__ __forceinline__ void scan_rows_unrolled(const void* __restrict__ base
       const float ob = __shfl_xor(best, o, 64);
       const int oi = __shfl_xor(bi, o, 64);
       if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (LOGIT) {   // best / bi: the row's max LOGIT and its first index, the same in the row's 4 lanes
+      const float m = best;
+      float pb = to_prob(m, true);
+      int pi = bi;
+      float zlo = m - (5e-7f * (1.f + __expf(m)) + 1e-6f * fabsf(m));
+      zlo = fminf(zlo, 16.f);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int c = cc[q] * V;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float z = v[pass][q].get(i);
+          if (z >= zlo && c + i != bi) {            // rare: a possible tie / inversion in probability space
+            const float pz = to_prob(z, true);
+            if (pz > pb || (pz == pb && c + i < pi)) { pb = pz; pi = c + i; }
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 1; o <= 2; o <<= 1) {
+        const float ob = __shfl_xor(pb, o, 64);
+        const int oi = __shfl_xor(pi, o, 64);
+        if (ob > pb || (ob == pb && oi < pi)) { pb = ob; pi = oi; }
+      }
+      best = pb; bi = pi;
     }
     const float sv = __shfl(best, (lane & 15) * 4, 64);
     const int sc = __shfl(bi, (lane & 15) * 4, 64);
@@ -170,6 +202,128 @@ __device__ __forceinline__ void scan_wave(const DetArgs& a, const DetLevel& lv, 
     }
   }
   *out_s = my_s; *out_c = my_c;
+}
+
+// ---- 1'. the same scan with the wave's rows staged through LDS: the wave's (up to) 64 rows are ONE contiguous range of
+// memory, fetched with fully coalesced 16-byte lane loads (lane l takes chunks l, l + 64, ...: 1 KB per instruction), parked
+// in LDS with a row stride of an odd number of 16-byte units (conflict-free ds_read_b128 when every lane then walks its own
+// row), and lane l reduces row l sequentially -- no shuffles, ascending class order, so strict > keeps the first maximum.
+// The four-lanes-per-row variant above touches ~20 cache lines per load instruction (16 rows x 64 bytes) and ran at
+// 2.8 TB/s whatever the element size; this one is bound by HBM.  Needs row bytes % 16 == 0 and 64 rows <= SCAN_LDS_WAVE.
+constexpr int SCAN_LDS_WAVE = 24 * 1024;   // most LDS bytes a wave may take (4 waves per block)
+template <bool HALF, bool LOGIT>
+__device__ __forceinline__ void scan_wave_lds(const DetArgs& a, const DetLevel& lv, int img, int64_t row0, int nrow, int lane, char* lds,
+                                              float* out_s, int* out_c) {
+  constexpr int V = Chunk<HALF>::V, ESZ = HALF ? 2 : 4;
+  const int CV = a.C / V;                              // 16-byte chunks per row
+  const int RS = (CV | 1) * 16;                        // row stride in LDS: an odd number of chunks
+  const char* base = reinterpret_cast<const char*>(lv.prob) + ((size_t)img * lv.rows + row0) * a.C * ESZ;
+  const int total = nrow * CV;
+  const float inv_cv = 1.f / (float)CV;
+  for (int g0 = 0; g0 < total; g0 += 64 * 8) {         // 8 loads in flight per lane
+    uint4 t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = reinterpret_cast<const uint4*>(base)[min(g0 + j * 64 + lane, total - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = g0 + j * 64 + lane;
+      if (g < total) {
+        const int r = (int)(((float)g + 0.5f) * inv_cv), ch = g - r * CV;     // exact for these sizes (see dw_gn.hip fast_div)
+        *reinterpret_cast<uint4*>(lds + r * RS + ch * 16) = t[j];
+      }
+    }
+  }
+  // (one wave owns this LDS region: no block barrier needed, only the wave's own LDS writes must have landed)
+  __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  const char* row = lds + min(lane, nrow - 1) * RS;
+  float best = -1e30f; int bi = 0;
+  for (int c4 = 0; c4 < CV; ++c4) {
+    Chunk<HALF> ck;
+    ck.load(row, c4);
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+      if (ck.get(i) > best) { best = ck.get(i); bi = c4 * V + i; }
+  }
+  if (LOGIT) {   // see scan_rows_unrolled: sigmoid of the max logit, exact handling of possible ties in probability space
+    const float m = best;
+    float pb = to_prob(m, true);
+    int pi = bi;
+    const float zlo = fminf(m - (5e-7f * (1.f + __expf(m)) + 1e-6f * fabsf(m)), 16.f);
+    bool any = false;
+    for (int c4 = 0; c4 < CV; ++c4) {
+      Chunk<HALF> ck;
+      ck.load(row, c4);
+#pragma unroll
+      for (int i = 0; i < V; ++i) any = any || (ck.get(i) >= zlo && c4 * V + i != bi);
+    }
+    if (any) {   // rare
+      for (int c4 = 0; c4 < CV; ++c4) {
+        Chunk<HALF> ck;
+        ck.load(row, c4);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float z = ck.get(i);
+          if (z >= zlo && c4 * V + i != bi) {
+            const float pz = to_prob(z, true);
+            if (pz > pb || (pz == pb && c4 * V + i < pi)) { pb = pz; pi = c4 * V + i; }
+          }
+        }
+      }
+    }
+    best = pb; bi = pi;
+  }
+  *out_s = best; *out_c = bi;
+}
+
+__global__ __launch_bounds__(T) void det_scan_lds_kernel(const DetArgs a, int lds_per_wave) {
+  extern __shared__ char scan_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
+  const int64_t nw = (int64_t)a.n * a.waves_per_image;
+  if (wid >= nw) return;
+  int img, l; int64_t row0;
+  locate_wave(a, wid, &img, &l, &row0);
+  const DetLevel& lv = a.lv[l];
+  const int nrow = (int)((lv.rows - row0) < 64 ? (lv.rows - row0) : 64);
+  char* lds = scan_lds + (size_t)wave * lds_per_wave;
+  float my_s = 0.f; int my_c = 0;
+  if (lv.half_prob) {
+    if (lv.logit) scan_wave_lds<true, true>(a, lv, img, row0, nrow, lane, lds, &my_s, &my_c);
+    else scan_wave_lds<true, false>(a, lv, img, row0, nrow, lane, lds, &my_s, &my_c);
+  } else {
+    if (lv.logit) scan_wave_lds<false, true>(a, lv, img, row0, nrow, lane, lds, &my_s, &my_c);
+    else scan_wave_lds<false, false>(a, lv, img, row0, nrow, lane, lds, &my_s, &my_c);
+  }
+  const bool flag = lane < nrow && my_s > a.score_thr;
+  const int64_t g = (int64_t)img * a.rows_per_image + lv.row_off + row0 + lane;
+  if (lane < nrow) { a.row_score[g] = my_s; a.row_class[g] = my_c; }
+  const unsigned long long m = __ballot(flag);
+  if (lane == 0) a.wave_count[wid] = __popcll(m);
+}
+
+// the unrolled scan for ONE (storage type, logit mode, chunks per lane): registers sized for this case only.  (The
+// catch-all kernel below contains every Q up to 8 and is allocated 250 VGPRs -- two waves per SIMD, which made the scan
+// latency-bound at 2.8 TB/s whatever the element size.)
+template <bool HALF, bool LOGIT, int Q>
+__global__ __launch_bounds__(T) void det_scan_q_kernel(const DetArgs a) {
+  constexpr int ESZ = HALF ? 2 : 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
+  const int64_t nw = (int64_t)a.n * a.waves_per_image;
+  if (wid >= nw) return;
+  int img, l; int64_t row0;
+  locate_wave(a, wid, &img, &l, &row0);
+  const DetLevel& lv = a.lv[l];
+  const int nrow = (int)((lv.rows - row0) < 64 ? (lv.rows - row0) : 64);
+  const void* base = reinterpret_cast<const char*>(lv.prob) + ((size_t)img * lv.rows + row0) * a.C * ESZ;
+  float my_s = 0.f; int my_c = 0;
+  scan_rows_unrolled<Q, HALF, LOGIT>(base, a.C, nrow, lane, &my_s, &my_c);
+  const bool flag = lane < nrow && my_s > a.score_thr;
+  const int64_t g = (int64_t)img * a.rows_per_image + lv.row_off + row0 + lane;
+  if (lane < nrow) { a.row_score[g] = my_s; a.row_class[g] = my_c; }
+  const unsigned long long m = __ballot(flag);
+  if (lane == 0) a.wave_count[wid] = __popcll(m);
 }
 
 __global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
@@ -663,7 +817,49 @@ int run_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, 
   hipStream_t st = (hipStream_t)stream;
   const int64_t nw = (int64_t)a.n * a.waves_per_image;
   const unsigned wblocks = (unsigned)((nw * 64 + T - 1) / T);
-  hipLaunchKernelGGL(det_scan_kernel, dim3(wblocks), dim3(T), 0, st, a);
+  {
+    // LDS-staged scan when every level's rows are whole 16-byte chunks and 64 of them (padded) fit a wave's LDS share
+    bool lds_ok = getenv("RN_SCAN_NO_LDS") == nullptr;
+    for (int l = 0; l < a.nlv; ++l) {
+      const int esz = a.lv[l].half_prob ? 2 : 4, v = 16 / esz;
+      lds_ok = lds_ok && a.C % v == 0 && 64 * (((a.C / v) | 1) * 16) <= SCAN_LDS_WAVE;
+    }
+    // all levels in one storage type / logit mode with whole 16-byte chunks: the kernel specialised for that case
+    bool uniform = true;
+    for (int l = 1; l < a.nlv; ++l) uniform = uniform && a.lv[l].half_prob == a.lv[0].half_prob && a.lv[l].logit == a.lv[0].logit;
+    const int v0 = a.lv[0].half_prob ? 8 : 4;
+    const int qpl = a.C % v0 == 0 ? (a.C / v0 + 3) / 4 : 0;
+    lds_ok = lds_ok && getenv("RN_SCAN_LDS") != nullptr;   // measured slower than the specialised kernels: opt-in only
+    if (uniform && qpl >= 1 && qpl <= 8 && !lds_ok) {
+#define RN_SCAN_Q(H_, L_)                                                                                         \
+      switch (qpl) {                                                                                              \
+        case 1: hipLaunchKernelGGL((det_scan_q_kernel<H_, L_, 1>), dim3(wblocks), dim3(T), 0, st, a); break;      \
+        case 2: hipLaunchKernelGGL((det_scan_q_kernel<H_, L_, 2>), dim3(wblocks), dim3(T), 0, st, a); break;      \
+        case 3: hipLaunchKernelGGL((det_scan_q_kernel<H_, L_, 3>), dim3(wblocks), dim3(T), 0, st, a); break;      \
+        case 4: hipLaunchKernelGGL((det_scan_q_kernel<H_, L_, 4>), dim3(wblocks), dim3(T), 0, st, a); break;      \
+        case 5: hipLaunchKernelGGL((det_scan_q_kernel<H_, L_, 5>), dim3(wblocks), dim3(T), 0, st, a); break;      \
+        case 6: hipLaunchKernelGGL((det_scan_q_kernel<H_, L_, 6>), dim3(wblocks), dim3(T), 0, st, a); break;      \
+        case 7: hipLaunchKernelGGL((det_scan_q_kernel<H_, L_, 7>), dim3(wblocks), dim3(T), 0, st, a); break;      \
+        default: hipLaunchKernelGGL((det_scan_q_kernel<H_, L_, 8>), dim3(wblocks), dim3(T), 0, st, a); break;     \
+      }
+      if (a.lv[0].half_prob) { if (a.lv[0].logit) { RN_SCAN_Q(true, true) } else { RN_SCAN_Q(true, false) } }
+      else { if (a.lv[0].logit) { RN_SCAN_Q(false, true) } else { RN_SCAN_Q(false, false) } }
+#undef RN_SCAN_Q
+    } else if (lds_ok) {
+      static const hipError_t attr_ = hipFuncSetAttribute((const void*)det_scan_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                          (T / 64) * SCAN_LDS_WAVE);
+      (void)attr_;
+      size_t need = 0;
+      for (int l = 0; l < a.nlv; ++l) {
+        const int esz = a.lv[l].half_prob ? 2 : 4, v = 16 / esz;
+        const size_t w = (size_t)64 * (((a.C / v) | 1) * 16);
+        need = need > w ? need : w;
+      }
+      hipLaunchKernelGGL(det_scan_lds_kernel, dim3(wblocks), dim3(T), (size_t)(T / 64) * need, st, a, (int)need);
+    } else {
+      hipLaunchKernelGGL(det_scan_kernel, dim3(wblocks), dim3(T), 0, st, a);
+    }
+  }
   hipLaunchKernelGGL(det_offsets_chunk_kernel, dim3((unsigned)((nw + 1023) / 1024)), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(det_offsets_kernel, dim3(1), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(det_emit_kernel, dim3(wblocks), dim3(T), 0, st, a);

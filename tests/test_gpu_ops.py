@@ -1074,6 +1074,24 @@ def test_detect_fp16_maps_and_logits_in_the_scan(dev):
         assert np.array_equal(want[i].scores.cpu().numpy(), exp.scores)
         kept += len(exp.scores)
     assert kept > 20
+    # adversarial rows for the max-logit shortcut of the scan: saturated logits (sigmoid == 1.0f for several classes: the
+    # FIRST of them must win, not the largest logit), equal logits, logits one ulp apart, huge negative rows
+    z = (rng.standard_normal((1, 8, 8, 9, c)) * 2 - 3.5).astype(np.float32)
+    rows = z.reshape(-1, c)
+    rows[0, [7, 30, 60]] = [18.0, 25.0, 40.0]
+    rows[1, [5, 6]] = [2.5, 2.5]
+    rows[2, [40, 3]] = [1.0, np.nextafter(np.float32(1.0), np.float32(2.0))]
+    rows[3, [70, 11]] = [np.nextafter(np.float32(9.0), np.float32(10.0)), 9.0]
+    rows[4, :] = -80.0
+    rows[5, [9, 8]] = [16.7, 16.6]
+    rows[6, [1, 0]] = [12.0, np.nextafter(np.float32(12.0), np.float32(0.0))]
+    adv = {"P5": _t(z, dev)}
+    radv = {"P5": _t((rng.standard_normal((1, 8, 8, 9, 4)) * 0.3).astype(np.float32), dev)}
+    aadv = {"P5": lv["P5"].normalized_anchor_sizes((256, 256))}
+    w1 = utils.detect_raw({"P5": ops.activation(adv["P5"], 'sigmoid')}, radv, aadv, c)[0]
+    g1 = utils.detect_raw(adv, radv, aadv, c, logits=True)[0]
+    assert torch.equal(g1.boxes, w1.boxes) and torch.equal(g1.scores, w1.scores) and torch.equal(g1.class_ids, w1.class_ids)
+    assert 7 in g1.class_ids.tolist() and 5 in g1.class_ids.tolist()
     # a class count that is not a multiple of 8 takes the generic fp16 path
     c2 = 5
     lg = {k: _t((rng.standard_normal((1, 4, 4, 9, c2)) * 2 - 1).astype(np.float16), dev) for k in ("P3",)}
