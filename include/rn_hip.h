@@ -422,7 +422,7 @@ int rn_conv3x3_winograd_gn_bwd(const rn_conv_seg* segs, int nseg, int cin, int c
                                int tile, const rn_wino_gn_bwd* gn, void* workspace, size_t workspace_bytes, const float* v_buf,
                                const float* urot_buf, rn_stream_t stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_r in[r * count + i], r < nrows, fixed order (bit-reproducible); joins the
- * deferred batch while rn_defer_reductions is on for the stream.  Finishes dgamma / dbeta from in_g_rows_chan. */
+ * caller's deferred batch when `defer` is given.  Finishes dgamma / dbeta from in_g_rows_chan. */
 int rn_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, rn_stream_t stream, rn_reduce_list* defer);
 
 /* ------------------------------------------------------------------ IoU
