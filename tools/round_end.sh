@@ -20,4 +20,7 @@ python tools/pmc_traffic.py gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write 
 timeout 600 python tools/bench_configs.py > gpurun_out/${R}_cfgs.log 2>&1
 timeout 400 python tools/bench_inference.py > gpurun_out/${R}_inf.log 2>&1
 timeout 200 python tools/tower_bench.py 720 > gpurun_out/${R}_tower.log 2>&1
+rm -rf gpurun_out/${R}_nms_prof
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_nms_prof -o nms -- python tools/nms_prof.py > gpurun_out/${R}_nms.log 2>&1
+python tools/by_grid.py $(find gpurun_out/${R}_nms_prof -name "nms_kernel_trace.csv" | head -1) > gpurun_out/${R}_nms_kernels_by_grid.txt
 tail -3 gpurun_out/${R}_tests.log; tail -1 gpurun_out/${R}_smoke.log; tail -1 gpurun_out/${R}_bench.log | cut -c1-400
