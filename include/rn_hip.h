@@ -90,6 +90,29 @@ int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, void
                   rn_stream_t stream);
 int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, void* workspace, size_t workspace_bytes,
                     rn_stream_t stream);
+/* ------------------------------------------------------------------ GroupNorm statistics from the producer
+ * normalization.py:30 takes the moments of a conv output that this library has just had in registers: the conv /
+ * depthwise forward can emit partial sums as a by-product -- per block, a row of (sum, sum of squares) pairs -- and the
+ * GroupNorm that follows (rn_gn_params.stat_rows) merges the rows of its sample in a fixed order (fp64) while its
+ * activations are in flight, then applies: one elementwise pass instead of a reduction + exchange + apply.  No block
+ * waits for another, no atomics, bitwise reproducible.
+ *   rows            : [n][rows_per_sample][width] pairs of floats, written by the producer, read by the GroupNorm
+ *   rows_per_sample : m-tiles of a sample (conv) / pixel chunks of a sample (depthwise)
+ *   per_group       : 0: width = channels (the conv's tiles cut through groups); 1: width = groups (a depthwise block owns
+ *                     all channels of its pixels and folds them into groups itself)
+ * The *_stats_rows functions return the bytes of `rows` and fill the layout fields, or return 0 when the shape cannot
+ * produce rows (several segments, grouped conv, bias, split-K plan, a sample's pixels not a multiple of the tile height)
+ * or the GroupNorm could not merge them cheaply (rn_group_norm_rows_ok): use the stand-alone GroupNorm then. */
+typedef struct rn_gn_rows {
+  void* rows;
+  int32_t rows_per_sample, per_group, groups;
+} rn_gn_rows;
+size_t rn_conv2d_stats_rows(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, size_t workspace_bytes, int groups,
+                            rn_gn_rows* layout);
+/* rn_conv2d_fwd + the rows of y (one dense segment, no bias) */
+int rn_conv2d_fwd_stats(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, void* workspace, size_t workspace_bytes,
+                        const rn_gn_rows* rows, rn_stream_t stream);
+
 /* dw[kh,kw,cin,cout] = sum over all segments (they share the kernel: shared heads);
  * split-K partial slabs go to `workspace`, reduced in fixed order (bitwise reproducible).
  * If accumulate != 0 the result is added to dw instead of overwriting it. */
@@ -200,6 +223,10 @@ int rn_conv2d_fwd_f16(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, 
  */
 int rn_depthwise_fwd(const float* x, const float* wgt, float* y, int n, int h, int w, int c, int k, int stride,
                      rn_stream_t stream);
+/* the same with the GroupNorm partial-sum rows of y (rn_gn_rows above); k == 3, c % 4 == 0, c <= 1024 */
+size_t rn_depthwise_stats_rows(int n, int h, int w, int c, int k, int stride, int groups, rn_gn_rows* layout);
+int rn_depthwise_fwd_stats(const float* x, const float* wgt, float* y, int n, int h, int w, int c, int k, int stride,
+                           const rn_gn_rows* rows, rn_stream_t stream);
 int rn_depthwise_dgrad(const float* dy, const float* wgt, float* dx, int n, int h, int w, int c, int k,
                        int stride, rn_stream_t stream);
 size_t rn_depthwise_wgrad_workspace(int n, int h, int w, int c, int k, int stride);
@@ -278,9 +305,15 @@ typedef struct rn_gn_params {
                  stream, written by these kernels only; enables the single-kernel path for mid-sized maps (<= 128 blocks
                  exchange tagged per-group sums through it, bounded polling).  Word 0 is left at zero, word 1 counts the
                  calls, word 2 becomes 1 if a wait ever timed out.  NULL = not used. */
+  const rn_gn_rows* stat_rows; /* forward, one dense fp32 segment: the partial-sum rows its producer wrote for x
+                                  (rn_conv2d_fwd_stats / rn_depthwise_fwd_stats): merged here instead of reading x twice.
+                                  Ignored (statistics computed from x) where rn_group_norm_rows_ok says no.  NULL = none. */
 } rn_gn_params;
 
 size_t rn_group_norm_sync_bytes(void);
+/* can rn_group_norm_fwd merge rows of this layout for c channels in `groups` groups? (channel slabs of whole groups must
+ * tile c, and a block's share of the rows must stay small) */
+int rn_group_norm_rows_ok(int c, int groups, int rows_per_sample, int per_group);
 size_t rn_group_norm_workspace(const rn_gn_seg* segs, int nseg, const rn_gn_params* p);
 int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, const float* gamma,
                       const float* beta, void* workspace, size_t workspace_bytes, rn_stream_t stream);

@@ -89,7 +89,13 @@ class GnSeg(C.Structure):
 class GnParams(C.Structure):
     _fields_ = [("c", C.c_int32), ("groups", C.c_int32), ("act", C.c_int32), ("act_after_residual", C.c_int32),
                 ("in_f16", C.c_int32), ("out_f16", C.c_int32), ("eps", C.c_float),
-                ("drop_rate", C.c_float), ("drop_seed", C.c_uint64), ("drop_seed_dev", C.c_void_p), ("sync", C.c_void_p)]
+                ("drop_rate", C.c_float), ("drop_seed", C.c_uint64), ("drop_seed_dev", C.c_void_p), ("sync", C.c_void_p),
+                ("stat_rows", C.c_void_p)]
+
+
+class GnRows(C.Structure):
+    """rn_gn_rows: partial (sum, sum of squares) rows a conv / depthwise forward wrote for the GroupNorm that follows"""
+    _fields_ = [("rows", C.c_void_p), ("rows_per_sample", C.c_int32), ("per_group", C.c_int32), ("groups", C.c_int32)]
 
 
 class LossSeg(C.Structure):
@@ -116,7 +122,8 @@ _lib = None
 SYMBOLS = [
     "rn_version", "rn_last_error", "rn_same_pad",
     "rn_conv2d_fwd_workspace", "rn_conv2d_dgrad_workspace",
-    "rn_conv2d_fwd", "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad", "rn_conv2d_bwd",
+    "rn_conv2d_fwd", "rn_conv2d_stats_rows", "rn_conv2d_fwd_stats", "rn_depthwise_stats_rows", "rn_depthwise_fwd_stats", "rn_group_norm_rows_ok",
+    "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad", "rn_conv2d_bwd",
     "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes",
     "rn_conv3x3_winograd_bwd_workspace", "rn_conv3x3_winograd_bwd", "rn_flush_reductions", "rn_gemm_batched",
@@ -148,7 +155,7 @@ def lib():
                      "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace", "rn_conv3x3_winograd_workspace", "rn_conv2d_fwd_workspace",
                      "rn_conv2d_dgrad_workspace",
                      "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_bwd_workspace", "rn_wino_gn_rows",
-                     "rn_winograd_bwd_products_workspace"):
+                     "rn_winograd_bwd_products_workspace", "rn_conv2d_stats_rows", "rn_depthwise_stats_rows"):
             getattr(L, name).restype = C.c_size_t
         L.rn_optimizer_workspace.argtypes = [C.c_int64]
         L.rn_dwgn_supported.argtypes = [C.c_void_p, C.c_int]
@@ -161,6 +168,11 @@ def lib():
         L.rn_depthwise_wgrad.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_conv2d_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_conv2d_dgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rn_conv2d_stats_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        L.rn_conv2d_fwd_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.rn_depthwise_stats_rows.argtypes = [C.c_int] * 7 + [C.c_void_p]
+        L.rn_group_norm_rows_ok.argtypes = [C.c_int] * 4
+        L.rn_depthwise_fwd_stats.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]
         L.rn_conv2d_fwd_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_conv2d_dgrad_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_conv2d_bwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

@@ -63,6 +63,8 @@ struct ConvArgsT {
   // split-K mode (fwd / dgrad of tiny grids, e.g. the 4x4 P7 map: 4 tiles x 72 K-tiles): the "batches" are K ranges of
   // `ksplit` K-tiles each (bs_a = bs_b = 0), written to slab rows bs_out apart and summed by reduce_rows
   int ksplit;
+  // forward only: GroupNorm partial-sum rows of the output as a by-product (rn_conv2d_fwd_stats); rows == nullptr: off
+  rn::StatDev st;
 };
 typedef ConvArgsT<RN_MAX_SEG> ConvArgs;
 typedef ConvArgsT<4> ConvArgs4;  // compact copy (<= 4 segments) so that TWO argument blocks fit one 4 KB kernarg
@@ -184,6 +186,39 @@ __device__ __forceinline__ int find_seg(const A& args, int id) {
   return s;
 }
 
+// GroupNorm partial sums of the tile a block has just computed (rn::StatDev): per-channel (sum, sum of squares) over the
+// tile's BM rows -> row `tile_m` of the rows tensor.  A tile never straddles two samples (the host checks that a sample's
+// pixels are a multiple of BM), rows past the end do not exist (m % BM == 0), there is no bias.  `smem` = the dead operand tiles.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_stats_epilogue(const f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const rn::StatDev& st,
+                                                    float* smem, int tile_m, int n0, int nmax, int cout, int wm, int wn, int lane) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  const int tid = threadIdx.x, l31 = lane & 31;
+  float* red = smem;                                        // [WM][BN][2]
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float v = acc[tm][tn][r]; s1 += v; s2 = fmaf(v, v, s2); }
+    s1 += __shfl_xor(s1, 32, 64);                           // the other 16 rows of each 32-row slab
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lane < 32) {
+      const int col = wn * (BN / WN) + tn * 32 + l31;
+      red[(wm * BN + col) * 2 + 0] = s1;
+      red[(wm * BN + col) * 2 + 1] = s2;
+    }
+  }
+  __syncthreads();
+  if (tid < BN && n0 + tid < nmax) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2 + 0]; t2 += red[(w * BN + tid) * 2 + 1]; }
+    st.rows[(size_t)tile_m * cout + n0 + tid] = make_float2(t1, t2);
+  }
+}
+
 // =============================================================================================
 // forward.  TAPU: cin % BK == 0, so every K-tile lies inside ONE filter tap and (kh, kw, ci0) are
 // block-uniform scalars advanced incrementally -- no per-thread division in the K loop.
@@ -299,6 +334,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs ar
   }
   store_tile<BM, BN, WM, WN>(acc, sg.out + batch * args.bs_out, (args.ksplit && batch) ? nullptr : sg.bias, m0, n0, M, nmax, cout,
                              wm, wn, lane);
+  if (args.st.rows) conv_stats_epilogue<BM, BN, WM, WN>(acc, args.st, smem, tile_m, n0, nmax, cout, wm, wn, lane);
 }
 
 // =============================================================================================
@@ -889,8 +925,10 @@ struct Planned {
 };
 // split-K scratch: ws == nullptr -> never split; need_out != nullptr -> dry run, only report the bytes split-K wants
 struct Scratch { void* ws; size_t bytes; size_t* need_out; };
+// rows request of rn_conv2d_fwd_stats: `rows` the caller's buffer, or (dry run) layout_out = the layout + bytes_out (0: cannot)
+struct StatReq { const rn_gn_rows* rows; int groups; rn_gn_rows* layout_out; size_t* bytes_out; };
 int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
-                  const Scratch& sc = Scratch{nullptr, 0, nullptr});
+                  const Scratch& sc = Scratch{nullptr, 0, nullptr}, const StatReq& sr = StatReq{nullptr, 0, nullptr, nullptr});
 int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
                     const Scratch& sc = Scratch{nullptr, 0, nullptr}, Planned* plan = nullptr);
 
@@ -923,6 +961,20 @@ extern "C" int rn_conv2d_fwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
                              rn_stream_t stream) {
   return conv_fwd_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream, Scratch{workspace, workspace_bytes, nullptr});
 }
+extern "C" size_t rn_conv2d_stats_rows(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, size_t workspace_bytes, int groups,
+                                       rn_gn_rows* layout) {
+  size_t bytes = 0;
+  // (a non-null scratch pointer of the caller's size, never dereferenced in a dry run: the split-K decision depends on it)
+  if (conv_fwd_impl(segs, nseg, g, Batch{1, 0, 0, 0}, nullptr, Scratch{workspace_bytes ? (void*)segs : nullptr, workspace_bytes, nullptr},
+                    StatReq{nullptr, groups, layout, &bytes}))
+    return 0;
+  return bytes;
+}
+extern "C" int rn_conv2d_fwd_stats(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, void* workspace, size_t workspace_bytes,
+                                   const rn_gn_rows* rows, rn_stream_t stream) {
+  RN_CHECK_ARG(rows, "conv fwd stats: null rows");
+  return conv_fwd_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream, Scratch{workspace, workspace_bytes, nullptr}, StatReq{rows, 0, nullptr, nullptr});
+}
 extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, void* workspace, size_t workspace_bytes,
                                rn_stream_t stream) {
   return conv_dgrad_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream, Scratch{workspace, workspace_bytes, nullptr});
@@ -946,7 +998,7 @@ int rn::launch_batched_gemm(const float* A, const float* B, float* C, int M, int
 
 namespace {
 int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
-                  const Scratch& sc) {
+                  const Scratch& sc, const StatReq& sr) {
   if (int e = validate_geom(segs, nseg, g)) return e;
   RN_CHECK_ARG(bt.n == 1 || nseg == 1, "conv: batched mode takes one segment");
   ConvArgs a = {};
@@ -997,6 +1049,24 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
     tiles *= nsplit;
   } else {
     nsplit = 1;
+  }
+  if (sr.rows || sr.bytes_out) {
+    // rows ride on the plain single-segment kernel only, and the tile rows of a sample must be whole m-tiles
+    const SegDev& d = a.seg[0];
+    const int ohw = d.oh * d.ow, bm = kCfgs[c].bm;
+    const int groups = sr.rows ? sr.rows->groups : sr.groups;
+    const bool ok = nseg == 1 && bt.n == 1 && G == 1 && nsplit == 1 && !d.bias && ohw % bm == 0 && groups >= 1 && d.cout % groups == 0 &&
+                    (double)ohw * (d.cout / groups) < 16777216.0 &&
+                    rn_group_norm_rows_ok(d.cout, groups, ohw / bm, 0);
+    if (sr.bytes_out) {
+      *sr.bytes_out = ok ? (size_t)(d.m / bm) * d.cout * 8 : 0;
+      if (ok && sr.layout_out) { sr.layout_out->rows_per_sample = ohw / bm; sr.layout_out->per_group = 0; sr.layout_out->groups = groups; }
+      return RN_OK;
+    }
+    RN_UNSUPPORTED(!ok || sr.rows->rows_per_sample != ohw / bm || sr.rows->per_group != 0,
+                   "conv fwd stats: this shape / layout cannot produce GroupNorm rows (rn_conv2d_stats_rows)");
+    RN_CHECK_ARG(sr.rows->rows, "conv fwd stats: null rows");
+    a.st.rows = (float2*)sr.rows->rows; a.st.groups = groups; a.st.cpg = d.cout / groups;
   }
 #define RN_FWD(BM_, BN_, WM_, WN_)                                                                   \
   do {                                                                                               \

@@ -204,6 +204,80 @@ __global__ __launch_bounds__(T) void dw_bwd_kernel(const DwBwdArgs b) {
   else dw_wgrad_partial_body(b.w, (int)blockIdx.x - b.dgrad_blocks);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 forward that also emits the GroupNorm partial sums of its output (rn_depthwise_fwd_stats, rn::StatDev): a block owns
+// a run of `ppc` output pixels of ONE sample and all channels -- thread = (channel quad, pixel lane), R pixels each, the
+// nine weights in registers -- so its per-channel sums fold into one row of per-group (sum, sum of squares) inside the
+// block; the GroupNorm that follows merges the sample's rows.  Same fmaf order as dw_fwd_kernel: the same output bits.
+constexpr int ST = 512;
+struct DwStatArgs { DwArgs a; rn::StatDev st; int chunks_ps, ppc; };
+
+template <int R>
+__global__ __launch_bounds__(ST) void dw_fwd_stats_kernel(const DwStatArgs b) {
+  __shared__ float red[ST][8];
+  __shared__ float chan[1024][2];
+  const DwArgs& a = b.a;
+  const rn::StatDev& st = b.st;
+  const int tid = threadIdx.x, C = a.c, CQ = C >> 2, lanes = ST / CQ;
+  const int q4 = tid % CQ, pl = tid / CQ;
+  const bool active = pl < lanes;
+  const int sample = blockIdx.x / b.chunks_ps, ck = blockIdx.x - sample * b.chunks_ps;
+  const int ohw = a.oh * a.ow;
+  const int p_begin = ck * b.ppc, p_end = min(p_begin + b.ppc, ohw);
+  float4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(a.w + (size_t)t * C + q4 * 4);
+  const float inv_ow = 1.f / (float)a.ow;
+  const float* __restrict__ xs = a.x + (size_t)sample * a.h * a.wd * C + q4 * 4;
+  float* __restrict__ ys = a.out + (size_t)sample * ohw * C + q4 * 4;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int p = p_begin + pl + k * lanes;
+    const bool ok = active && p < p_end;
+    const int pc = min(p, ohw - 1);
+    const int oh_ = (int)(((float)pc + 0.5f) * inv_ow);   // floor(pc / ow): exact for pc < 2^20, ow <= 2^12 (host-checked)
+    const int ow_ = pc - oh_ * a.ow;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh_ * a.stride - a.pad_t + kh;
+      const int ihc = min(max(ih, 0), a.h - 1);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow_ * a.stride - a.pad_l + kw;
+        const int iwc = min(max(iw, 0), a.wd - 1);
+        const float m = ((unsigned)ih < (unsigned)a.h && (unsigned)iw < (unsigned)a.wd) ? 1.f : 0.f;
+        const float4 xv = *reinterpret_cast<const float4*>(xs + ((size_t)ihc * a.wd + iwc) * C);
+        const float4 w4 = wv[kh * 3 + kw];
+        acc.x = fmaf(xv.x * m, w4.x, acc.x); acc.y = fmaf(xv.y * m, w4.y, acc.y);
+        acc.z = fmaf(xv.z * m, w4.z, acc.z); acc.w = fmaf(xv.w * m, w4.w, acc.w);
+      }
+    }
+    if (ok) {
+      *reinterpret_cast<float4*>(ys + (size_t)p * C) = acc;
+      s1[0] += acc.x; s1[1] += acc.y; s1[2] += acc.z; s1[3] += acc.w;
+      s2[0] = fmaf(acc.x, acc.x, s2[0]); s2[1] = fmaf(acc.y, acc.y, s2[1]);
+      s2[2] = fmaf(acc.z, acc.z, s2[2]); s2[3] = fmaf(acc.w, acc.w, s2[3]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[tid][j] = s1[j]; red[tid][4 + j] = s2[j]; }
+  __syncthreads();
+  for (int e = tid; e < CQ * 8; e += ST) {      // pixel lanes in order
+    const int q = e >> 3, comp = e & 7;
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += red[l * CQ + q][comp];
+    chan[q * 4 + (comp & 3)][comp >> 2] = t;
+  }
+  __syncthreads();
+  for (int g = tid; g < st.groups; g += ST) {   // channels of a group in order
+    float t1 = 0.f, t2 = 0.f;
+    for (int j = 0; j < st.cpg; ++j) { t1 += chan[g * st.cpg + j][0]; t2 += chan[g * st.cpg + j][1]; }
+    st.rows[(size_t)blockIdx.x * st.groups + g] = make_float2(t1, t2);
+  }
+}
+
 int fill(DwArgs* a, int n, int h, int w, int c, int k, int stride) {
   RN_CHECK_ARG(n >= 1 && h >= 1 && w >= 1 && c >= 1 && k >= 1 && stride >= 1, "depthwise: bad shape");
   RN_UNSUPPORTED(c % 4 != 0 || c > 1024, "depthwise: c=%d must be a multiple of 4 and <= 1024", c);
@@ -239,6 +313,48 @@ extern "C" int rn_depthwise_fwd(const float* x, const float* wgt, float* y, int 
   a.x = x; a.w = wgt; a.out = y;
   if (k == 3) hipLaunchKernelGGL(dw_fwd_kernel<true>, dim3(grid_for((int64_t)n * a.oh * a.ow * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(dw_fwd_kernel<false>, dim3(grid_for((int64_t)n * a.oh * a.ow * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+namespace {
+// plan of the statistics kernel: pixels per thread R (4, or 8 / 16 where that keeps a sample at <= 256 rows)
+bool stats_plan(const DwArgs& a, int groups, int* R, int* ppc, int* chunks_ps) {
+  if (a.k != 3 || groups < 1 || a.c % groups) return false;
+  const long ohw = (long)a.oh * a.ow;
+  if (ohw >= (1 << 20) || a.ow > 4096 || (double)ohw * (a.c / groups) >= 16777216.0) return false;
+  const int lanes = ST / (a.c / 4);
+  int r = 4;
+  while (r < 16 && rn::ceil_div((int)ohw, lanes * r) > 256) r *= 2;   // (per-group rows: a few hundred are cheap to merge)
+  *R = r; *ppc = lanes * r; *chunks_ps = rn::ceil_div((int)ohw, lanes * r);
+  return rn_group_norm_rows_ok(a.c, groups, *chunks_ps, 1) != 0;
+}
+}  // namespace
+
+extern "C" size_t rn_depthwise_stats_rows(int n, int h, int w, int c, int k, int stride, int groups, rn_gn_rows* layout) {
+  DwArgs a = {};
+  if (n < 1 || h < 1 || w < 1 || c < 4 || c % 4 || c > 1024 || k < 1 || stride < 1) return 0;
+  if (fill(&a, n, h, w, c, k, stride)) return 0;
+  int R, ppc, cps;
+  if (!stats_plan(a, groups, &R, &ppc, &cps)) return 0;
+  if (layout) { layout->rows_per_sample = cps; layout->per_group = 1; layout->groups = groups; }
+  return (size_t)n * cps * groups * 8;
+}
+
+extern "C" int rn_depthwise_fwd_stats(const float* x, const float* wgt, float* y, int n, int h, int w, int c, int k, int stride,
+                                      const rn_gn_rows* rows, rn_stream_t stream) {
+  DwStatArgs b = {};
+  if (int e = fill(&b.a, n, h, w, c, k, stride)) return e;
+  RN_CHECK_ARG(x && wgt && y && rows && rows->rows, "depthwise fwd stats: null pointer");
+  int R;
+  RN_UNSUPPORTED(!stats_plan(b.a, rows->groups, &R, &b.ppc, &b.chunks_ps) || rows->rows_per_sample != b.chunks_ps || rows->per_group != 1,
+                 "depthwise fwd stats: unsupported shape / layout (rn_depthwise_stats_rows)");
+  b.a.x = x; b.a.w = wgt; b.a.out = y;
+  b.st.rows = (float2*)rows->rows; b.st.groups = rows->groups; b.st.cpg = c / rows->groups;
+  const dim3 grid((unsigned)(n * b.chunks_ps));
+  if (R == 4) hipLaunchKernelGGL(dw_fwd_stats_kernel<4>, grid, dim3(ST), 0, (hipStream_t)stream, b);
+  else if (R == 8) hipLaunchKernelGGL(dw_fwd_stats_kernel<8>, grid, dim3(ST), 0, (hipStream_t)stream, b);
+  else hipLaunchKernelGGL(dw_fwd_stats_kernel<16>, grid, dim3(ST), 0, (hipStream_t)stream, b);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }

@@ -153,4 +153,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// GroupNorm partial sums as a by-product of the PRODUCING kernel (rn_gn_rows, rn_hip.h): every block of a conv / depthwise
+// forward stores one row of (sum, sum of squares) pairs for the outputs it has just computed; the GroupNorm kernel that
+// follows merges the rows of its sample (fixed order, fp64).  Plain stores, read by the next kernel on the stream.
+struct StatDev {
+  float2* rows;     // conv: [m-tile][channel]; depthwise: [pixel chunk][group]
+  int groups, cpg;  // depthwise: the block folds its channels into groups
+};
+
 }  // namespace rn

@@ -146,14 +146,17 @@ class Conv2D(torch.nn.Module):
             b = self.bias_initializer((self.filters,))
             self.bias = torch.nn.Parameter(b.to(device) if device is not None else b)
 
-    def forward(self, input):
+    def forward(self, input, norm=None):
+        """`norm`: the GroupNormalization layer applied to the output next (model.Sequential passes it): the conv kernel then
+        also emits that layer's statistics where it can, and the GroupNorm only applies them."""
         first = input[0] if isinstance(input, (list, tuple)) else input
         if self.weight is None:
             self.build(first.shape[3], first.device)
         if first.dtype == torch.float16:
             return ops_f16.conv2d(input, self.weight, self.bias, self.strides, self.groups,
                                   out_f32=self.f16_out_f32 and F16_OUTPUTS_F32)
-        return ops.conv2d(input, self.weight, self.bias, self.strides, self.groups)
+        gn = (norm.groups, norm.eps) if (norm is not None and self.bias is None and self.groups == 1) else None
+        return ops.conv2d(input, self.weight, self.bias, self.strides, self.groups, gn=gn)
 
 
 class DepthwiseConv2D(torch.nn.Module):
@@ -176,10 +179,10 @@ class DepthwiseConv2D(torch.nn.Module):
         self.weight = torch.nn.Parameter(w.to(device) if device is not None else w)
         self.weight.l2_scale = self.l2_scale
 
-    def forward(self, input):
+    def forward(self, input, norm=None):
         if self.weight is None:
             self.build(input.shape[3], input.device)
-        return ops.depthwise_conv2d(input, self.weight, self.strides)
+        return ops.depthwise_conv2d(input, self.weight, self.strides, gn=(norm.groups, norm.eps) if norm is not None else None)
 
 
 class Dropout(torch.nn.Module):

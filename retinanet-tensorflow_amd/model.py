@@ -59,6 +59,11 @@ class Sequential(Model):
                     residual = None
                 i = j
                 continue
+            if (isinstance(layer, (L.Conv2D, L.DepthwiseConv2D)) and i + 1 < n and isinstance(self.layers[i + 1], L.GroupNormalization)
+                    and torch.is_tensor(input) and input.dtype == torch.float32 and not (L.INFERENCE_F16 and not training)):
+                input = layer(input, norm=self.layers[i + 1])    # the conv also emits the GroupNorm's statistics where it can
+                i += 1
+                continue
             target = layer.call if isinstance(layer, Model) else layer
             if isinstance(layer, torch.nn.Module) and not isinstance(layer, Model):
                 target = layer.forward

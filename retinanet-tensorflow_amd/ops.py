@@ -105,12 +105,31 @@ def _winograd_keep_buffers(segs, n, w, want_v, want_urot):
     return v, u
 
 
-def _conv_fwd(segs, n, geom, device):
+# GroupNorm partial sums as a by-product of the producing conv / depthwise kernel (rn_conv2d_fwd_stats, rn_depthwise_fwd_stats):
+# the GroupNorm that follows merges the rows while its activations load, and reads x once.  model.Sequential announces
+# the GroupNorm to the conv in front of it; the rows travel on the conv's output tensor (`_gn_rows`).
+GN_PRODUCER_STATS = os.environ.get("RN_GN_PRODUCER_STATS", "1") == "1"
+_LAST_ROWS_LAYOUT = [None]      # (rows_per_sample, per_group, groups) of the rows the last producer call returned
+
+
+def _conv_fwd(segs, n, geom, device, gn=None, samples=0):
+    """The forward conv; with `gn` = (groups, eps) of a GroupNorm that follows, and a shape whose kernel can emit them, also the
+    partial-sum rows of the output: returns (rows tensor, rows_per_sample, per_group, groups) or None."""
     L = _rn.lib()
     need = L.rn_conv2d_fwd_workspace(segs, n, C.byref(geom))           # split-K scratch for tiny grids (0 otherwise)
+    if gn is not None and GN_PRODUCER_STATS and device.type == 'cuda':
+        g = gn_groups(segs[0].cout, gn[0])
+        lay = _rn.GnRows(None, 0, 0, g)
+        nbytes = L.rn_conv2d_stats_rows(segs, n, C.byref(geom), need, g, C.byref(lay))
+        if nbytes:
+            rows = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+            lay.rows = rows.data_ptr()
+            _rn.check(L.rn_conv2d_fwd_stats(segs, n, C.byref(geom), None, 0, C.byref(lay), _rn.stream()), "rn_conv2d_fwd_stats")
+            return rows, lay.rows_per_sample, lay.per_group, g
     ws = _rn.workspace(need, device) if need else None
     _rn.check(L.rn_conv2d_fwd(segs, n, C.byref(geom), ws.data_ptr() if need else None, ws.numel() if need else 0,
                               _rn.stream()), "rn_conv2d_fwd")
+    return None
 
 
 def _conv_dgrad(segs, n, geom, device):
@@ -219,7 +238,8 @@ class _Conv2dShared(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, stride_groups, w, bias, *xs):
-        stride, groups = stride_groups
+        stride, groups = stride_groups[:2]
+        gn = stride_groups[2] if len(stride_groups) > 2 else None      # (groups, eps) of the GroupNorm that follows
         kh, kw, cin_g, cout = w.shape
         cin = cin_g * groups
         L = _rn.lib()
@@ -240,13 +260,19 @@ class _Conv2dShared(torch.autograd.Function):
                 ctx.wino_v, ctx.wino_urot = _winograd_keep_buffers(
                     segs, len(xs), w, ctx.needs_input_grad[1] and WINOGRAD_WGRAD, any(ctx.needs_input_grad[3:]))
             _winograd(segs, len(xs), w, bias, False, ctx.wino_v, ctx.wino_urot)
+            stats = None
         else:
-            _conv_fwd(segs, len(xs), geom, xs[0].device)
+            stats = _conv_fwd(segs, len(xs), geom, xs[0].device, gn if (gn and len(xs) == 1 and bias is None) else None, xs[0].shape[0])
         ctx.stride = stride
         ctx.groups = groups
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
         ctx.save_for_backward(w, *xs)
+        ctx.set_materialize_grads(False)
+        if stats is not None:      # the partial-sum rows of y came with it: one more (non-differentiable) output
+            _LAST_ROWS_LAYOUT[0] = tuple(stats[1:])
+            ctx.mark_non_differentiable(stats[0])
+            return tuple(ys) + (stats[0],)
         return tuple(ys)
 
     @staticmethod
@@ -258,7 +284,7 @@ class _Conv2dShared(torch.autograd.Function):
         L = _rn.lib()
         geom = _rn.ConvGeom(kh, kw, ctx.stride, cin, ctx.groups)
         n = len(xs)
-        dys = [dy.contiguous() if dy is not None else None for dy in dys]
+        dys = [dy.contiguous() if dy is not None else None for dy in dys[:n]]
         for i in range(n):
             if dys[i] is None:
                 oh, _ = _rn.same_pad(xs[i].shape[1], kh, ctx.stride)
@@ -415,11 +441,18 @@ def conv2d_channel_split(xs, weights, biases, stride=1):
     return [list(out[j * n:(j + 1) * n]) for j in range(k)]
 
 
-def conv2d(x, w, bias=None, stride=1, groups=1):
+def conv2d(x, w, bias=None, stride=1, groups=1, gn=None):
     """NHWC conv, HWIO kernel [kh,kw,cin/groups,cout], TF SAME padding.  `x` may be a list (shared
-    kernel, one launch).  groups > 1: grouped conv (ResNeXt cardinality)."""
+    kernel, one launch).  groups > 1: grouped conv (ResNeXt cardinality).  gn = (groups, eps) announces the GroupNorm that
+    follows: where the kernel can, it also emits that GroupNorm's statistics (they travel on the returned tensor)."""
     if isinstance(x, (list, tuple)):
         return list(_Conv2dShared.apply((stride, groups), w, bias, *x))
+    if gn is not None and GN_PRODUCER_STATS and x.is_cuda and x.dtype == torch.float32:
+        outs = _Conv2dShared.apply((stride, groups, (int(gn[0]), float(gn[1]))), w, bias, x)
+        y = outs[0]
+        if len(outs) == 2:         # group_norm_act finds the rows on the tensor it is handed
+            y._gn_rows = (outs[1],) + _LAST_ROWS_LAYOUT[0]
+        return y
     return _Conv2dShared.apply((stride, groups), w, bias, x)[0]
 
 
@@ -597,7 +630,7 @@ class _Depthwise(torch.autograd.Function):
     """tf.nn.depthwise_conv2d(padding='SAME'), kernel [k,k,C,1] (mobilenet_v2.py:35-36)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride):
+    def forward(ctx, x, w, stride, gn=None):
         k = w.shape[0]
         n, h, wd, c = x.shape
         assert w.shape[2] == c and w.shape[3] == 1
@@ -605,14 +638,29 @@ class _Depthwise(torch.autograd.Function):
         oh, _ = _rn.same_pad(h, k, stride)
         ow, _ = _rn.same_pad(wd, k, stride)
         y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
-        _rn.check(_rn.lib().rn_depthwise_fwd(_rn.f32(x), _rn.f32(w), _rn.f32(y), n, h, wd, c, k, stride,
-                                             _rn.stream()), "rn_depthwise_fwd")
+        L = _rn.lib()
         ctx.stride = stride
         ctx.save_for_backward(x, w)
+        ctx.set_materialize_grads(False)
+        if gn is not None:
+            g = gn_groups(c, gn[0])
+            lay = _rn.GnRows(None, 0, 0, g)
+            nbytes = L.rn_depthwise_stats_rows(n, h, wd, c, k, stride, g, C.byref(lay))
+            if nbytes:
+                rows = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+                lay.rows = rows.data_ptr()
+                _rn.check(L.rn_depthwise_fwd_stats(_rn.f32(x), _rn.f32(w), _rn.f32(y), n, h, wd, c, k, stride, C.byref(lay),
+                                                   _rn.stream()), "rn_depthwise_fwd_stats")
+                _LAST_ROWS_LAYOUT[0] = (lay.rows_per_sample, lay.per_group, g)
+                ctx.mark_non_differentiable(rows)
+                return y, rows
+        _rn.check(L.rn_depthwise_fwd(_rn.f32(x), _rn.f32(w), _rn.f32(y), n, h, wd, c, k, stride, _rn.stream()), "rn_depthwise_fwd")
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
+        if dy is None:
+            return None, None, None, None
         x, w = ctx.saved_tensors
         k = w.shape[0]
         n, h, wd, c = x.shape
@@ -626,7 +674,7 @@ class _Depthwise(torch.autograd.Function):
             ws = _grad_workspace(need, x.device)
             _rn.check(L.rn_depthwise_bwd(_rn.f32(x), _rn.f32(dy), _rn.f32(w), _rn.f32(dx), _rn.f32(dw_buf), n, h, wd, c, k,
                                          ctx.stride, ws.data_ptr(), ws.numel(), _rn.stream(), _defer_arg()), "rn_depthwise_bwd")
-            return dx, dw, None
+            return dx, dw, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _rn.check(L.rn_depthwise_dgrad(_rn.f32(dy), _rn.f32(w), _rn.f32(dx), n, h, wd, c, k, ctx.stride,
@@ -638,10 +686,18 @@ class _Depthwise(torch.autograd.Function):
                 ws = _grad_workspace(need, x.device)
                 _rn.check(L.rn_depthwise_wgrad(_rn.f32(x), _rn.f32(dy), _rn.f32(dw_buf), n, h, wd, c, k, ctx.stride,
                                                ws.data_ptr(), ws.numel(), _rn.stream(), _defer_arg()), "rn_depthwise_wgrad")
-        return dx, dw, None
+        return dx, dw, None, None
 
 
-def depthwise_conv2d(x, w, stride=1):
+def depthwise_conv2d(x, w, stride=1, gn=None):
+    """gn = (groups, eps) of the GroupNorm that follows: its statistics come out of the same kernel (see conv2d)."""
+    if gn is not None and GN_PRODUCER_STATS and x.is_cuda and x.dtype == torch.float32:
+        outs = _Depthwise.apply(x, w, stride, (int(gn[0]), float(gn[1])))
+        if isinstance(outs, tuple):
+            y = outs[0]
+            y._gn_rows = (outs[1],) + _LAST_ROWS_LAYOUT[0]
+            return y
+        return outs
     return _Depthwise.apply(x, w, stride)
 
 
@@ -760,7 +816,9 @@ class _GroupNormAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, gamma, beta, n, *tensors):
-        groups, eps, act, drop_rate, seed, seed_dev, aar = cfg
+        groups, eps, act, drop_rate, seed, seed_dev, aar = cfg[:7]
+        rows_layout = cfg[7] if len(cfg) > 7 else None   # tensors end with the producer's partial-sum rows of the single x
+        have_stats = rows_layout is not None
         xs = [t.contiguous() for t in tensors[:n]]
         ress = [t.contiguous() if t is not None else None for t in tensors[n:2 * n]]
         c = xs[0].shape[3]
@@ -773,6 +831,10 @@ class _GroupNormAct(torch.autograd.Function):
         for x, r in zip(xs, ress):
             assert x.shape[3] == c and (r is None or r.shape == x.shape)
         params = _gn_params(c, g, eps, act, drop_rate, seed, seed_dev, aar, dev)
+        if have_stats:
+            lay = _rn.GnRows(tensors[2 * n].data_ptr(), rows_layout[0], rows_layout[1], rows_layout[2])
+            params.stat_rows = C.addressof(lay)
+        ctx.extra = 1 if have_stats else 0
         segs = _gn_segs(xs, ys, ress, None, None, means, rstds)
         need = L.rn_group_norm_workspace(segs, n, C.byref(params))
         ws = _rn.workspace(need, dev)
@@ -811,7 +873,7 @@ class _GroupNormAct(torch.autograd.Function):
                                       _rn.f32(dbeta_buf), ws.data_ptr(), ws.numel(), _rn.stream(), _defer_arg()),
                   "rn_group_norm_bwd")
         dres = [(dress[i] if dress[i] is not None else dys[i]) if ctx.has_res[i] else None for i in range(n)]
-        return (None, dgamma, dbeta, None) + tuple(dxs) + tuple(dres)
+        return (None, dgamma, dbeta, None) + tuple(dxs) + tuple(dres) + (None,) * ctx.extra
 
 
 def group_norm_act(x, gamma, beta, groups=32, eps=1e-5, act=None, residual=None, drop_rate=0.0, seed=0,
@@ -822,7 +884,12 @@ def group_norm_act(x, gamma, beta, groups=32, eps=1e-5, act=None, residual=None,
     xs = _as_list(x)
     ress = _as_list(residual) if residual is not None else [None] * len(xs)
     cfg = (groups, float(eps), act, float(drop_rate), int(seed), seed_dev, bool(act_after_residual))
-    ys = _GroupNormAct.apply(cfg, gamma, beta, len(xs), *xs, *ress)
+    rows = getattr(xs[0], '_gn_rows', None) if len(xs) == 1 else None
+    if rows is not None and rows[3] == gn_groups(xs[0].shape[3], groups) and xs[0].is_contiguous():
+        # the conv / depthwise kernel that produced x also wrote its partial sums: merge + apply in one pass over x
+        ys = _GroupNormAct.apply(cfg + (tuple(rows[1:]),), gamma, beta, 1, xs[0], ress[0], rows[0])
+    else:
+        ys = _GroupNormAct.apply(cfg, gamma, beta, len(xs), *xs, *ress)
     return list(ys) if multi else ys[0]
 
 

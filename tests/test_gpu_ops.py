@@ -873,15 +873,17 @@ def test_build_dataset_pipeline(dev):
         assert torch.equal(b['detection']['classifications'][k][1], c2[k][0])
 
 
-@pytest.mark.parametrize("mode", ["default", "grid_resident", "three_kernel"])
-@pytest.mark.parametrize("c,act,res", [(96, "relu6", False), (256, "elu", True), (24, None, False)])
+@pytest.mark.parametrize("mode", ["default", "rows", "grid_resident", "three_kernel"])
+@pytest.mark.parametrize("c,act,res", [(96, "relu6", False), (256, "elu", True), (24, None, False), (144, "elu", False)])
 def test_group_norm_all_kernel_paths(dev, monkeypatch, mode, c, act, res):
-    """The three GroupNorm implementations (slice-resident, grid-resident with the in-kernel barrier, partial + finalize +
-    apply) on mid-sized multi-segment inputs, each against the oracle; no barrier may time out."""
+    """The GroupNorm implementations (slice-resident; partial-sum rows + merging apply; grid-resident with the in-kernel
+    barrier; partial + finalize + apply) on mid-sized multi-segment inputs, each against the oracle; no barrier may time out."""
     import _rn
     import ops
     if mode != "default":
         monkeypatch.setenv("RN_GN_NO_SLICE", "1")
+    if mode in ("grid_resident", "three_kernel"):
+        monkeypatch.setenv("RN_GN_NO_ROWS", "1")
     if mode == "three_kernel":
         monkeypatch.setenv("RN_GN_NO_COOP", "1")
     rng = np.random.default_rng(c + len(mode))
@@ -1177,3 +1179,96 @@ def test_fused_dwgn_declines_what_does_not_fit(dev, monkeypatch):
     wd = torch.zeros((3, 3, 192, 1), device=dev)
     assert not ops.dw_gn_ok((2, 128, 128, 192), wd, 1, 32, "elu", False)        # 393 KB slice
     assert ops.dw_gn_ok((2, 64, 64, 192), wd, 1, 32, "elu", False) and not ops.dw_gn_ok((2, 64, 64, 192), wd, 1, 32, "elu", True)
+
+
+# ------------------------------------------------------------------ GroupNorm statistics from the producing kernel
+def _moments_ref(y, g, eps):
+    n, h, w, c = y.shape
+    v = y.detach().double().cpu().reshape(n, h * w, g, c // g)
+    mean = v.mean(dim=(1, 3))
+    var = v.var(dim=(1, 3), unbiased=False)
+    return mean.numpy(), (1.0 / torch.sqrt(var + eps)).numpy()
+
+
+PRODUCER_STATS_CASES = [
+    # kind, x shape, cout, k, stride, act, residual, drop   (MobileNetV2-FPN shapes of BASELINE configs[1], and odd ones)
+    ("conv", (2, 32, 32, 64), 384, 1, 1, "elu", False, 0.2),      # expand conv at 1/16 (tile 64x64)
+    ("conv", (2, 64, 64, 24), 144, 1, 1, "elu", False, 0.0),      # C = 144: 24 groups of 6, groups straddle tiles
+    ("conv", (2, 64, 64, 144), 32, 1, 1, None, False, 0.2),       # linear bottleneck conv, per-channel groups
+    ("conv", (2, 64, 64, 192), 32, 1, 1, None, True, 0.0),        # ... with the residual added by the GroupNorm
+    ("conv", (2, 128, 128, 3), 32, 3, 2, "relu6", False, 0.0),    # stem: scalar (cin = 3) kernel, 128 x 32 tiles
+    ("conv", (3, 16, 16, 160), 960, 1, 1, "relu", False, 0.0),    # three samples, 960 channels
+    ("dw", (2, 32, 32, 384), 384, 3, 1, "elu", False, 0.2),
+    ("dw", (2, 64, 64, 144), 144, 3, 2, "elu", False, 0.0),       # stride 2, C = 144
+    ("dw", (2, 33, 29, 96), 96, 3, 1, "relu6", False, 0.0),       # odd map: ragged last chunk
+    ("dw", (1, 128, 128, 32), 32, 3, 1, "elu", False, 0.0),       # 64 pixel lanes per block
+]
+
+
+@pytest.mark.parametrize("case", PRODUCER_STATS_CASES, ids=lambda c: "%s-%s-%d" % (c[0], "x".join(map(str, c[1])), c[2]))
+def test_group_norm_statistics_from_the_producer(dev, monkeypatch, case):
+    """conv / depthwise forward that also emits partial-sum rows for the GroupNorm that follows (rn_conv2d_fwd_stats,
+    rn_depthwise_fwd_stats) + the rows-merging GroupNorm == conv, then the stand-alone GroupNorm (normalization.py:20-35):
+    same conv output bits, moments vs an fp64 restatement, same output, dropout mask and gradients."""
+    import ops
+    kind, xs, cout, k, stride, act, use_res, rate = case
+    rng = np.random.default_rng(17)
+    n, h, w, cin = xs
+    x = _t((rng.standard_normal(xs) * 1.5 + 0.3).astype(np.float32), dev, True)
+    if kind == "conv":
+        wt = _t((rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32), dev, True)
+    else:
+        wt = _t((rng.standard_normal((3, 3, cin, 1)) / 3).astype(np.float32), dev, True)
+    gamma = _t((1 + 0.2 * rng.standard_normal(cout)).astype(np.float32), dev, True)
+    beta = _t((0.1 * rng.standard_normal(cout)).astype(np.float32), dev, True)
+    counter = torch.tensor([5], dtype=torch.int64, device=dev)
+
+    def run(producer):
+        monkeypatch.setattr(ops, "GN_PRODUCER_STATS", producer)
+        gn = (32, 1e-5)
+        y = ops.conv2d(x, wt, None, stride, 1, gn=gn) if kind == "conv" else ops.depthwise_conv2d(x, wt, stride, gn=gn)
+        res = None
+        if use_res:
+            res = torch.from_numpy(np.random.default_rng(3).standard_normal(tuple(y.shape)).astype(np.float32)).to(dev)
+        z = ops.group_norm_act(y, gamma, beta, 32, 1e-5, act, res, rate, 1234, counter)
+        dz = torch.from_numpy(np.random.default_rng(4).standard_normal(tuple(z.shape)).astype(np.float32)).to(dev)
+        grads = torch.autograd.grad(z, [x, wt, gamma, beta], dz)
+        return y, z, grads
+
+    y0, z0, g0 = run(False)
+    assert not hasattr(y0, "_gn_rows")
+    y1, z1, g1 = run(True)
+    assert hasattr(y1, "_gn_rows"), "this shape is expected to take the producer-rows path"
+    rows, rows_ps, per_group, g = y1._gn_rows
+    assert torch.equal(y0, y1)                                   # the conv output itself: the same kernel arithmetic
+    # the rows add up to the moments of y (fp64 restatement of normalization.py:30)
+    cpg = cout // g
+    r = rows.double().cpu().reshape(n, rows_ps, -1, 2).sum(1)    # [n, width, 2]
+    if not per_group:
+        r = r.reshape(n, g, cpg, 2).sum(2)
+    cnt = y1.shape[1] * y1.shape[2] * cpg
+    mean = (r[..., 0] / cnt).numpy()
+    var = (r[..., 1] / cnt).numpy() - mean * mean
+    mref, rref = _moments_ref(y1, g, 1e-5)
+    assert_close(mean, mref, 1e-5, "mean from rows")
+    assert np.max(np.abs(1.0 / np.sqrt(np.maximum(var, 0) + 1e-5) / rref - 1)) < 1e-5
+    assert_close(z1.detach().cpu().numpy(), z0.detach().cpu().numpy(), 1e-5, "GroupNorm output")
+    if rate > 0:
+        assert torch.equal(z0 == 0, z1 == 0)                     # the same dropout mask
+    for name, a, b in zip(("dx", "dw", "dgamma", "dbeta"), g1, g0):
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 2e-5, name)
+    y2, z2, _ = run(True)                                        # replay: same bits (fixed-order combination)
+    assert torch.equal(z1, z2) and torch.equal(y2._gn_rows[0], rows)
+
+
+def test_producer_statistics_decline_what_they_cannot_do(dev):
+    """Shapes whose conv plan cannot emit statistics (a sample's pixels not whole tiles, split-K plans, a bias) fall back to the
+    stand-alone GroupNorm: no statistics on the tensor, same result."""
+    import ops
+    rng = np.random.default_rng(2)
+    for xs, cout, k in (((2, 15, 15, 64), 128, 1), ((2, 16, 16, 960), 160, 1)):
+        x = _t(rng.standard_normal(xs).astype(np.float32), dev)
+        wt = _t((rng.standard_normal((k, k, xs[3], cout)) / np.sqrt(xs[3])).astype(np.float32), dev)
+        y = ops.conv2d(x, wt, None, 1, 1, gn=(32, 1e-5))
+        assert not hasattr(y, "_gn_rows")
+        assert torch.equal(y, ops.conv2d(x, wt))
