@@ -317,7 +317,8 @@ __global__ __launch_bounds__(T) void gn_apply_kernel(const GnArgs a) {
 //   merge    every block of the apply kernel owns a channel slab (a whole number of groups and of float4 quads, ~32-64
 //            channels) of a pixel chunk; it first issues the loads of its activations, then adds up its slab's share of the
 //            sample's rows -- row lanes in fp64, fixed order -- while those loads are in flight, and applies.
-// Dense fp32 tensors.  Replaces the grid-resident (spinning) kernels wherever a slice does not fit one block.
+// fp32 tensors; x / dx may be channel prefixes of a wider buffer (concat-free DenseNet blocks).  The path for whatever
+// neither a slice-resident block nor the grid-resident kernel takes, and the configuration without any spinning kernel.
 constexpr int AT = 256, RT = 512, ROWS_MAX_SLAB = 128, ROWS_MAX_ENTRIES = 8192;
 
 // the slab's per-group totals (S, Q) of sample-local index nl -> gsum[group of slab][2] (fp64)
@@ -367,11 +368,11 @@ __global__ __launch_bounds__(AT) void gn_apply_rows_kernel(const GnArgs a) {
   const int q4 = tid % SQ, pl = tid / SQ, c0 = slab * SW;
   const int p0 = (int)blockIdx.x * lanes * R + pl;
   const size_t base = (size_t)nl * sg.hw * C + c0 + q4 * 4;
-  const float* __restrict__ x = sg.x + base;
+  const float* __restrict__ x = sg.x + (size_t)nl * sg.hw * sg.x_ld + c0 + q4 * 4;   // (x may be a channel prefix of a wider buffer)
   const float* __restrict__ res = sg.res ? sg.res + base : nullptr;
   float4 v[R], rv[R];
 #pragma unroll
-  for (int k = 0; k < R; ++k) v[k] = *reinterpret_cast<const float4*>(x + (size_t)min(p0 + k * lanes, sg.hw - 1) * C);
+  for (int k = 0; k < R; ++k) v[k] = *reinterpret_cast<const float4*>(x + (size_t)min(p0 + k * lanes, sg.hw - 1) * sg.x_ld);
   if (res) {
 #pragma unroll
     for (int k = 0; k < R; ++k) rv[k] = *reinterpret_cast<const float4*>(res + (size_t)min(p0 + k * lanes, sg.hw - 1) * C);
@@ -441,16 +442,16 @@ __global__ __launch_bounds__(AT) void gn_bwd_apply_rows_kernel(const GnArgs a) {
   const int q4 = tid % SQ, pl = tid / SQ, c0 = slab * SW;
   const int p0 = (int)blockIdx.x * lanes * R + pl;
   const size_t base = (size_t)nl * sg.hw * C + c0 + q4 * 4;
-  const float* __restrict__ x = sg.x + base;
+  const float* __restrict__ x = sg.x + (size_t)nl * sg.hw * sg.x_ld + c0 + q4 * 4;
   const float* __restrict__ dy = sg.dy + base;
   const bool aar = a.act_after_res && sg.res;
   const float* __restrict__ res = aar ? sg.res + base : nullptr;
   float4 xv[R], dv[R], rv[R];
 #pragma unroll
   for (int k = 0; k < R; ++k) {
-    const size_t off = (size_t)min(p0 + k * lanes, sg.hw - 1) * C;
-    xv[k] = *reinterpret_cast<const float4*>(x + off);
-    dv[k] = *reinterpret_cast<const float4*>(dy + off);
+    const size_t pc = (size_t)min(p0 + k * lanes, sg.hw - 1);
+    xv[k] = *reinterpret_cast<const float4*>(x + pc * sg.x_ld);
+    dv[k] = *reinterpret_cast<const float4*>(dy + pc * C);
   }
   if (res) {
 #pragma unroll
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(AT) void gn_bwd_apply_rows_kernel(const GnArgs a) {
   const bool drop = a.drop_rate > 0.f;
   const float keep_scale = drop ? 1.f / (1.f - a.drop_rate) : 1.f;
   const uint64_t samp_off = (uint64_t)q * (uint64_t)sg.hw * (uint64_t)C;
-  float* __restrict__ dx = sg.dx + base;
+  float* __restrict__ dx = sg.dx + (size_t)nl * sg.hw * sg.dx_ld + c0 + q4 * 4;   // (dx may be a channel prefix too, and accumulate)
   float* __restrict__ dres = (aar && sg.dres) ? sg.dres + base : nullptr;
 #pragma unroll
   for (int k = 0; k < R; ++k) {
@@ -502,7 +503,12 @@ __global__ __launch_bounds__(AT) void gn_bwd_apply_rows_kernel(const GnArgs a) {
         g[j] = t * rn::act_grad(z, ACT);
         o[j] = rstd[j] * (gam[j] * g[j] - c1[j] - h * c2[j]);
       }
-      *reinterpret_cast<float4*>(dx + (size_t)p * C) = make_float4(o[0], o[1], o[2], o[3]);
+      float* dxp = dx + (size_t)p * sg.dx_ld;
+      if (sg.dx_acc) {
+        const float4 old = *reinterpret_cast<const float4*>(dxp);
+        o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+      }
+      *reinterpret_cast<float4*>(dxp) = make_float4(o[0], o[1], o[2], o[3]);
       if (dres) *reinterpret_cast<float4*>(dres + (size_t)p * C) = make_float4(g[0], g[1], g[2], g[3]);
     }
   }
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(RT) void gn_rows_partial_kernel(const GnArgs a) {
   const int p_begin = ck * sg.ppc, p_end = min(p_begin + sg.ppc, sg.hw);
   const size_t base = (size_t)nl * sg.hw * C;
   const int q4 = tid % CQ, pl = tid / CQ;
-  const float* __restrict__ x = sg.x + base + q4 * 4;
+  const float* __restrict__ x = sg.x + (size_t)nl * sg.hw * sg.x_ld + q4 * 4;
   const float* __restrict__ dy = BWD ? sg.dy + base + q4 * 4 : nullptr;
   const float* __restrict__ res = (BWD && a.act_after_res && sg.res) ? sg.res + base + q4 * 4 : nullptr;
   float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {1.f, 1.f, 1.f, 1.f}, gam[4], bet[4];
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(RT) void gn_rows_partial_kernel(const GnArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const size_t off = (size_t)min(pb + k * lanes, sg.hw - 1) * C;
-        xv[k] = *reinterpret_cast<const float4*>(x + off);
+        xv[k] = *reinterpret_cast<const float4*>(x + (size_t)min(pb + k * lanes, sg.hw - 1) * sg.x_ld);
         if (BWD) dv[k] = *reinterpret_cast<const float4*>(dy + off);
         rv[k] = (BWD && res) ? *reinterpret_cast<const float4*>(res + off) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -1457,7 +1463,7 @@ namespace {
 // chunk rows mergeable
 bool rows_path_ok(const GnArgs& a) {
   if (getenv("RN_GN_NO_ROWS")) return false;   // (tuning aid)
-  if (a.in_half || a.out_half || a.strided || a.act == RN_ACT_SIGMOID || a.c / 4 > RT) return false;
+  if (a.in_half || a.out_half || a.act == RN_ACT_SIGMOID || a.c / 4 > RT) return false;   // (channel-prefix views are fine)
   for (int s = 0; s < a.nseg; ++s)
     if (!rn_group_norm_rows_ok(a.c, a.groups, a.seg[s].chunks, 1)) return false;
   return true;

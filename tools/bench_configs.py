@@ -42,5 +42,8 @@ def run(backbone, size, batch, steps=8, warmup=3, use_graph=True):
 
 
 if __name__ == "__main__":
-    for cfg in (("resnet_50", 800, 2), ("densenet_121", 640, 4), ("mobilenet_v2", 512, 2)):
-        print(json.dumps(run(*cfg)), flush=True)
+    cfgs = (("resnet_50", 800, 2), ("densenet_121", 640, 4), ("mobilenet_v2", 512, 2))
+    only = sys.argv[1] if len(sys.argv) > 1 else None        # e.g. `densenet_121`: that config alone (for a rocprofv3 run)
+    for cfg in cfgs:
+        if only is None or cfg[0] == only:
+            print(json.dumps(run(*cfg)), flush=True)
