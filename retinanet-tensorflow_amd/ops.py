@@ -144,9 +144,23 @@ def _as_list(x):
     return list(x) if isinstance(x, (list, tuple)) else [x]
 
 
+_direct_written = set()      # ids of the parameters whose gradient slot has been written since begin_direct_grad_step()
+
+
+def begin_direct_grad_step():
+    """Start of a training step under DIRECT_PARAM_GRADS (train.Trainer calls it): forget which slots were written."""
+    _direct_written.clear()
+
+
 def _grad_slot(p):
-    """(buffer to write the gradient of parameter p into, value to return to autograd)."""
+    """(buffer to write the gradient of parameter p into, value to return to autograd).  Under DIRECT_PARAM_GRADS the kernels
+    OVERWRITE p.grad in place and autograd gets None: that is only right while every parameter is used by exactly one op
+    call per step, so a second write within a step is refused instead of silently dropping the first contribution."""
     if DIRECT_PARAM_GRADS and p.grad is not None and p.grad.is_contiguous():
+        if id(p) in _direct_written:
+            raise RuntimeError("DIRECT_PARAM_GRADS: a parameter of shape %s is used by two op calls in one step (shared weights must "
+                               "go through ONE call, e.g. a list of inputs); its first gradient would be overwritten" % (tuple(p.shape),))
+        _direct_written.add(id(p))
         return p.grad, None
     assert not _deferring, "deferred reductions need every parameter gradient written in place (DIRECT_PARAM_GRADS)"
     g = torch.empty_like(p)

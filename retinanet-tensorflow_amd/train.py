@@ -14,6 +14,7 @@ single kernel, the gradient all-reduce is a few large contiguous messages sized 
 xGMI bandwidth, and the whole step (forward, loss, backward, optimizer) can be captured into one
 hipGraph -- the launch-bound small kernels of the pyramid's coarse levels then cost no host time.
 """
+import contextlib
 import os
 
 import numpy as np
@@ -191,12 +192,14 @@ class Trainer(object):
         self.input_fn = input_fn       # optional: features = input_fn(), run INSIDE segment A (e.g. device-side label assignment)
         self.defer_reductions = (bool(defer_reductions) and bool(direct_param_grads) and
                                  os.environ.get("RN_DEFER_REDUCTIONS", "1") == "1")
-        # kernels write parameter gradients straight into the arena (every parameter of this network
-        # is used by exactly one op call per step); see ops.DIRECT_PARAM_GRADS
-        ops.DIRECT_PARAM_GRADS = bool(direct_param_grads)
+        # kernels write parameter gradients straight into the arena (every parameter of this network is used by exactly one
+        # op call per step; ops._grad_slot refuses a second write); see ops.DIRECT_PARAM_GRADS.  These switches and the dropout
+        # counter are process-wide in ops / layers: they are set only while THIS trainer's segments run (_scoped) and restored
+        # afterwards, so trainers and plain autograd users in one process do not see each other's settings
+        self.direct_param_grads = bool(direct_param_grads)
         # ... which would let the weight-gradient kernels run on a side stream under the dgrad / GroupNorm chain;
         # measured on MI355X: 162 vs 170 img/s (fork/join edges + CU contention cost more than the overlap buys), so off
-        ops.WGRAD_SIDE_STREAM = bool(direct_param_grads) and bool(wgrad_side_stream)
+        self.wgrad_side_stream = bool(direct_param_grads) and bool(wgrad_side_stream)
         # backward segments: arena offset where the FPN's parameters start (arena order = registration order =
         # backbone, fpn, classification_subnet, regression_subnet)
         self.cut_offset = 0
@@ -213,11 +216,22 @@ class Trainer(object):
         self._static = None
         self.drop_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
-        L.Dropout.seed_device_counter = self.drop_counter
         self.check_interval = int(check_interval)
         self.steps_done = 0
         self.timing = None             # set to {} to collect 'allreduce_exposed_ms' (events around the final wait)
         self.last = {}
+
+    @contextlib.contextmanager
+    def _scoped(self):
+        """This trainer's process-wide switches (direct parameter gradients, weight-gradient side stream, dropout counter) for
+        the duration of one of its segments."""
+        saved = (ops.DIRECT_PARAM_GRADS, ops.WGRAD_SIDE_STREAM, L.Dropout.seed_device_counter)
+        ops.DIRECT_PARAM_GRADS, ops.WGRAD_SIDE_STREAM = self.direct_param_grads, self.wgrad_side_stream
+        L.Dropout.seed_device_counter = self.drop_counter
+        try:
+            yield
+        finally:
+            ops.DIRECT_PARAM_GRADS, ops.WGRAD_SIDE_STREAM, L.Dropout.seed_device_counter = saved
 
     # -- replica-local work (capturable)
     def _cut(self, taps):
@@ -249,26 +263,29 @@ class Trainer(object):
 
     def segment_a(self, features=None):
         """forward + loss + backward of the heads and the FPN (the whole backward pass when there is no cut)."""
-        if features is None:
-            features = self.input_fn()
-        self._cut_src = self._cut_leaves = None
-        logits = {'detection': self.net(features['image'], training=True)}
-        inp, logits = utils.process_labels_and_logits(labels=features, logits=logits, levels=self.levels)
-        class_loss, regr_loss = losses.loss(labels=inp['detection_trainable'], logits=logits['detection_trainable'],
-                                            mode=self.loss_mode)
-        # kernels that write a parameter's gradient directly overwrite it; gradients that reach a parameter
-        # through autograd (e.g. the concatenated head kernels) are accumulated -> the arena starts at zero
-        self.arena.zero_grad()
-        # d(class_loss + regr_loss): both roots seeded with the same pre-allocated 1 (no add / fill kernels in the step)
-        self._backward([class_loss, regr_loss], [self._one, self._one])
-        return class_loss.detach(), regr_loss.detach()
+        with self._scoped():
+            if features is None:
+                features = self.input_fn()
+            self._cut_src = self._cut_leaves = None
+            ops.begin_direct_grad_step()       # a parameter's gradient slot may be written once per step from here on
+            logits = {'detection': self.net(features['image'], training=True)}
+            inp, logits = utils.process_labels_and_logits(labels=features, logits=logits, levels=self.levels)
+            class_loss, regr_loss = losses.loss(labels=inp['detection_trainable'], logits=logits['detection_trainable'],
+                                                mode=self.loss_mode)
+            # kernels that write a parameter's gradient directly overwrite it; gradients that reach a parameter
+            # through autograd (e.g. the concatenated head kernels) are accumulated -> the arena starts at zero
+            self.arena.zero_grad()
+            # d(class_loss + regr_loss): both roots seeded with the same pre-allocated 1 (no add / fill kernels in the step)
+            self._backward([class_loss, regr_loss], [self._one, self._one])
+            return class_loss.detach(), regr_loss.detach()
 
     def segment_b(self):
         """backward of the backbone from the gradients segment A left at the cut."""
         if self._cut_src is not None:
-            src, leaves = self._cut_src, self._cut_leaves
-            self._cut_src = self._cut_leaves = None
-            self._backward(src, [l.grad for l in leaves])
+            with self._scoped():
+                src, leaves = self._cut_src, self._cut_leaves
+                self._cut_src = self._cut_leaves = None
+                self._backward(src, [l.grad for l in leaves])
 
     def forward_backward(self, features=None, advance_dropout=True):
         """Both segments, no collective, no update.  The dropout counter is bumped here (one tiny launch); step() leaves

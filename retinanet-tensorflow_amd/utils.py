@@ -330,12 +330,19 @@ def postprocess_and_mask(input, trainable_masks, image_size, levels, name='postp
             'trainable_masks': trainable_masks}
 
 
+def _sigmoid(t):
+    import ops                      # (ops imports nothing from here; kept local so that utils stays importable without it)
+    return ops.activation(t.detach(), 'sigmoid')
+
+
 def process_labels_and_logits(labels, logits, levels, name='process_labels_and_logits'):
     """utils.py:240-255.  `labels`: features dict (image, detection{classifications, regressions},
     trainable_masks); `logits`: {'detection': net output}."""
     labels = dict_update(labels, ['detection', 'classifications'], lambda c: Classification(unscaled=None, prob=c))
+    # utils.py:245-247 sets prob = sigmoid(unscaled); the loss kernel takes the logits (the sigmoid is fused there), so the
+    # probabilities are computed only if somebody reads them (summaries / metrics in the reference): the step pays nothing
     logits = dict_update(logits, ['detection', 'classifications'],
-                         lambda c: Classification(unscaled=c, prob=None))   # sigmoid is fused into the loss kernel
+                         lambda c: Classification(unscaled=c, prob=_LazyLevels(c.keys(), lambda k: _sigmoid(c[k]))))
     image_size = tuple(labels['image'].shape[1:3])
     labels = postprocess_and_mask(labels, labels['trainable_masks'], image_size=image_size, levels=levels)
     logits = postprocess_and_mask(logits, labels['trainable_masks'], image_size=image_size, levels=levels)

@@ -95,6 +95,10 @@ def test_loss_and_gradients_match_oracle(dev, mode):
     size = tuple(feats["image"].shape[1:3])
     want = utils.regression_postprocess(logits["detection"].regression["P3"], lv["P3"].normalized_anchor_sizes(size, utils.ANCHOR_SIZE_MODE))
     assert torch.equal(p3, want) and list(dict.keys(rp)) == ["P3"] and len(rp.items()) == len(list(lv))
+    # Classification.prob = sigmoid(unscaled) (reference utils.py:245-247), also on first access only
+    cls = logits["detection"].classification
+    assert len(dict.keys(cls.prob)) == 0
+    assert_close(cls.prob["P4"].cpu().numpy(), torch.sigmoid(cls.unscaled["P4"].detach()).cpu().numpy(), 1e-6, "prob")
     assert_close(gcl.item(), cl.item(), TOL, "class loss")
     assert_close(grl.item(), rl.item(), TOL, "regr loss")
     # Error is measured against max(|grad of this tensor|, 1e-3 * largest gradient in the net): some

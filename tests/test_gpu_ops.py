@@ -780,6 +780,7 @@ def test_deferred_reductions_are_bitwise_identical(dev):
             p.grad = torch.zeros_like(p)
         old = ops.DIRECT_PARAM_GRADS
         ops.DIRECT_PARAM_GRADS = True
+        ops.begin_direct_grad_step()
         try:
             h = ops.depthwise_conv2d(x, dww, 1)
             h = ops.group_norm_act(h, gamma, beta, groups=32, act="relu6")

@@ -162,3 +162,26 @@ def test_metrics_known_answers_and_oracle():
     # tf.metrics.mean_iou, 2 classes: labels 1 1 0 0, predictions 1 0 0 0 -> IoU(1) = 1/2, IoU(0) = 2/3
     assert abs(metrics.class_iou([1, 1, 0, 0], [0.9, 0.2, 0.1, 0.3]) - (0.5 + 2 / 3) / 2) < 1e-12
     assert abs(metrics.regr_iou([[0, 0, 1, 1]], [[0, 0, 1, 0.5]]) - 0.5) < 1e-12
+
+
+def test_trainer_scopes_its_process_wide_switches():
+    """A Trainer sets ops.DIRECT_PARAM_GRADS / the dropout counter only while one of its segments runs, and a parameter's
+    in-place gradient slot can be written once per step (a second op call on the same weights is refused, not dropped)."""
+    import torch
+    import layers, levels, ops, retinanet, train
+    lv = levels.build_levels()
+    net = retinanet.RetinaNet('mobilenet_v2', lv, 3, layers.elu, 0.0)
+    before = (ops.DIRECT_PARAM_GRADS, ops.WGRAD_SIDE_STREAM, layers.Dropout.seed_device_counter)
+    tr = train.Trainer(net, lv, device=torch.device("cpu"), use_graph=False)
+    assert (ops.DIRECT_PARAM_GRADS, ops.WGRAD_SIDE_STREAM, layers.Dropout.seed_device_counter) == before
+    with tr._scoped():
+        assert ops.DIRECT_PARAM_GRADS is True and layers.Dropout.seed_device_counter is tr.drop_counter
+        p = tr.arena.params[0]
+        ops.begin_direct_grad_step()
+        buf, ret = ops._grad_slot(p)
+        assert buf is p.grad and ret is None
+        with pytest.raises(RuntimeError, match="two op calls"):
+            ops._grad_slot(p)
+        ops.begin_direct_grad_step()
+        assert ops._grad_slot(p)[0] is p.grad
+    assert (ops.DIRECT_PARAM_GRADS, ops.WGRAD_SIDE_STREAM, layers.Dropout.seed_device_counter) == before
