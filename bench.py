@@ -192,7 +192,7 @@ def roofline_kernels(device):
     fwd["flops_per_launch"] = flops
     fwd["layer_ms"] = round(layer_ms, 4)
     fwd["layer_direct_conv_equivalent_tflops"] = round(2.0 * pixels * 2304 * 256 / (layer_ms * 1e-3) / 1e12, 1)
-    gn = entry("largest stand-alone GroupNorm (+ELU+dropout) forward: 2x256x256x96", "gn_partial + gn_finalize + gn_apply", "hbm",
+    gn = entry("largest stand-alone GroupNorm (+ELU+dropout) forward: 2x256x256x96", "gn_rows_partial_kernel + gn_apply_rows_kernel", "hbm",
                gn_bytes, gn_ms, HBM_PEAK_GBPS, "GB/s", gn_bytes, "group_norm")
     return bwd, fwd, gn
 

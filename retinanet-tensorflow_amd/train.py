@@ -181,9 +181,8 @@ class Trainer(object):
             # the kernels are launched on the CURRENT device's current stream with raw pointers
             assert torch.cuda.current_device() == self.device.index, \
                 "call torch.cuda.set_device(%d) before building the Trainer" % self.device.index
-        if optimizer == 'adam' and use_graph:
-            raise ValueError("optimizer='adam' cannot run with use_graph=True: its bias-corrected learning rate changes "
-                             "every step and is a launch argument of the optimizer kernel")
+        # (the optimizer kernel is launched per step, outside the captured segments, with the host's step count: Adam's
+        # bias-corrected learning rate is a fresh launch argument every step, also with use_graph=True)
         self.loss_mode = loss_mode
         self.arena = ParamArena(net, self.device)
         self.opt = Optimizer(self.arena, optimizer, learning_rate, grad_clip_norm)

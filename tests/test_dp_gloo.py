@@ -139,15 +139,6 @@ def test_real_trainer_schedule_and_arena_world2(tmp_path):
     assert all(os.path.exists(os.path.join(str(tmp_path), "ok_%d.npy" % r)) for r in range(world))
 
 
-def test_adam_with_graph_replay_is_refused():
-    sys.path.insert(0, os.path.join(ROOT, "retinanet-tensorflow_amd"))
-    import train
-    m = torch.nn.Module()
-    m.a = torch.nn.Parameter(torch.randn(10))
-    with pytest.raises(ValueError):
-        train.Trainer(m, device='cpu', optimizer='adam', use_graph=True)
-
-
 def test_bucketed_gradient_allreduce_world2(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)

@@ -115,18 +115,37 @@ def test_loss_and_gradients_match_oracle(dev, mode):
     print("worst gradient error", worst)
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_train_steps_match_oracle(dev, use_graph):
-    """Three optimizer steps (momentum, L2 regulariser, global-norm clip) == the oracle's."""
+def test_adam_under_graph_replay_equals_eager(dev):
+    """Adam's bias-corrected learning rate changes every step; the optimizer kernel is launched per step outside the
+    captured segments, so three steps through the replayed hipGraphs give the weights of three eager steps (the update
+    rule itself is checked against the oracle in test_gpu_ops.py::test_optimizer_matches_tf_semantics)."""
+    import levels as levels_mod, train
+    weights = []
+    for use_graph in (False, True):
+        net, params, image, labels = _tiny_problem(dev, seed=3)
+        trainer = train.Trainer(net, levels_mod.build_levels(), optimizer="adam", learning_rate=1e-3, grad_clip_norm=5.0,
+                                loss_mode="bce_dice", device=dev, use_graph=use_graph)
+        feats = _features(image, labels, dev)
+        for _ in range(3):
+            trainer.step(feats)
+        torch.cuda.synchronize()
+        weights.append(trainer.arena.weights.clone())
+    assert torch.equal(weights[0], weights[1])
+
+
+@pytest.mark.parametrize("use_graph,optimizer,lr", [(False, "momentum", 1e-2), (True, "momentum", 1e-2)])
+def test_train_steps_match_oracle(dev, use_graph, optimizer, lr):
+    """Three optimizer steps (momentum, L2 regulariser, global-norm clip) == the oracle's (reference train.py:111-134),
+    eager and through the replayed hipGraph segments."""
     import levels as levels_mod, train
     net, params, image, labels = _tiny_problem(dev, seed=3)
-    trainer = train.Trainer(net, levels_mod.build_levels(), optimizer="momentum", learning_rate=1e-2,
+    trainer = train.Trainer(net, levels_mod.build_levels(), optimizer=optimizer, learning_rate=lr,
                             grad_clip_norm=5.0, loss_mode="bce_dice", device=dev, use_graph=use_graph)
     feats = _features(image, labels, dev)
     state = {}
     for step in range(1, 4):
         out = trainer.step(feats)
-        first, _ = train_ref.train_step(params, image, labels, 3, state, lr=1e-2, optimizer="momentum", step=step,
+        first, _ = train_ref.train_step(params, image, labels, 3, state, lr=lr, optimizer=optimizer, step=step,
                                         loss_mode="bce_dice", grad_clip_norm=5.0)
         torch.cuda.synchronize()
         assert_close(out["class_loss"].item(), first[1], 2e-4, "class loss step %d" % step)
