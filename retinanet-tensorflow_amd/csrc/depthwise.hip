@@ -17,14 +17,19 @@ struct DwArgs {
 
 template <bool K3>
 __global__ __launch_bounds__(T) void dw_fwd_kernel(const DwArgs a) {
-  const int CQ = a.c >> 2;
-  const int64_t total = (int64_t)a.n * a.oh * a.ow * CQ;
-  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < total; i += (int64_t)gridDim.x * T) {
+  // 32-bit index arithmetic: a tensor has < 2^31 bytes (fill), and a 64-bit division by a runtime divisor is ~150
+  // instructions -- three of them per element were several times the nine taps' work
+  const unsigned CQ = (unsigned)a.c >> 2;
+  const unsigned total = (unsigned)a.n * a.oh * a.ow * CQ;
+  // consecutive blocks (neighbouring pixels: shared taps) on ONE XCD's L2 -- dealt round-robin over the eight XCDs, every
+  // XCD fetched the three input rows of each output row itself (measured: 3x the algorithmic fetch traffic)
+  const unsigned bid = (unsigned)rn::xcd_remap(blockIdx.x, gridDim.x);
+  for (unsigned i = bid * T + threadIdx.x; i < total; i += gridDim.x * T) {
     const int q4 = (int)(i % CQ);
-    int64_t p = i / CQ;
-    const int ow_ = (int)(p % a.ow); p /= a.ow;
-    const int oh_ = (int)(p % a.oh);
-    const int n_ = (int)(p / a.oh);
+    unsigned p = i / CQ;
+    const int ow_ = (int)(p % (unsigned)a.ow); p /= (unsigned)a.ow;
+    const int oh_ = (int)(p % (unsigned)a.oh);
+    const int n_ = (int)(p / (unsigned)a.oh);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (K3) {
       // branch-free 3x3: every tap is loaded from a clamped address and multiplied by a 0/1 mask -- loads under
@@ -65,14 +70,14 @@ __global__ __launch_bounds__(T) void dw_fwd_kernel(const DwArgs a) {
 // dx[n,ih,iw,c] = sum_{kh,kw} dy[n,oh,ow,c]*w[kh,kw,c] with oh*s + kh - pad_t == ih
 template <bool K3>
 __device__ __forceinline__ void dw_dgrad_body(const DwArgs& a, int bid, int nblk) {
-  const int CQ = a.c >> 2;
-  const int64_t total = (int64_t)a.n * a.h * a.wd * CQ;
-  for (int64_t i = (int64_t)bid * T + threadIdx.x; i < total; i += (int64_t)nblk * T) {
+  const unsigned CQ = (unsigned)a.c >> 2;           // (32-bit index arithmetic: see dw_fwd_kernel)
+  const unsigned total = (unsigned)a.n * a.h * a.wd * CQ;
+  for (unsigned i = (unsigned)rn::xcd_remap(bid, nblk) * T + threadIdx.x; i < total; i += (unsigned)nblk * T) {   // (XCD locality: see dw_fwd_kernel)
     const int q4 = (int)(i % CQ);
-    int64_t p = i / CQ;
-    const int iw = (int)(p % a.wd); p /= a.wd;
-    const int ih = (int)(p % a.h);
-    const int n_ = (int)(p / a.h);
+    unsigned p = i / CQ;
+    const int iw = (int)(p % (unsigned)a.wd); p /= (unsigned)a.wd;
+    const int ih = (int)(p % (unsigned)a.h);
+    const int n_ = (int)(p / (unsigned)a.h);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (K3 && a.stride == 2) {
       // stride 2: only the taps whose parity matches the input pixel's reach an output (<= 2 x 2 of the 3 x 3): visit
@@ -150,18 +155,18 @@ __device__ __forceinline__ void dw_wgrad_partial_body(const DwArgs& a, int chunk
   const int tid = threadIdx.x;
   const int CQ = a.c >> 2, lanes = T / CQ;
   const int q4 = tid % CQ, pl = tid / CQ;
-  const int64_t npix = (int64_t)a.n * a.oh * a.ow;
-  const int64_t p_begin = (int64_t)chunk * a.ppc;
-  const int64_t p_end = p_begin + a.ppc < npix ? p_begin + a.ppc : npix;
+  const unsigned npix = (unsigned)a.n * a.oh * a.ow;
+  const unsigned p_begin = (unsigned)chunk * a.ppc;
+  const unsigned p_end = p_begin + a.ppc < npix ? p_begin + a.ppc : npix;
   float4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (pl < lanes) {
-    for (int64_t p = p_begin + pl; p < p_end; p += lanes) {
-      const int ow_ = (int)(p % a.ow);
-      const int64_t r = p / a.ow;
-      const int oh_ = (int)(r % a.oh);
-      const int n_ = (int)(r / a.oh);
+    for (unsigned p = p_begin + pl; p < p_end; p += lanes) {
+      const int ow_ = (int)(p % (unsigned)a.ow);
+      const unsigned r = p / (unsigned)a.ow;
+      const int oh_ = (int)(r % (unsigned)a.oh);
+      const int n_ = (int)(r / (unsigned)a.oh);
       const float4 dv = *reinterpret_cast<const float4*>(a.dy + (size_t)p * a.c + q4 * 4);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
@@ -194,14 +199,14 @@ __device__ __forceinline__ void dw_wgrad_partial_body(const DwArgs& a, int chunk
   }
 }
 
-__global__ __launch_bounds__(T) void dw_wgrad_partial_kernel(const DwArgs a) { dw_wgrad_partial_body(a, blockIdx.x); }
+__global__ __launch_bounds__(T) void dw_wgrad_partial_kernel(const DwArgs a) { dw_wgrad_partial_body(a, rn::xcd_remap(blockIdx.x, gridDim.x)); }
 
 // both gradients of a 3x3 depthwise conv in ONE launch: blocks [0, dgrad_blocks) compute dx, the rest the weight-gradient
 // partials (independent work on the same dy; two launch-latency-bound kernels otherwise)
 struct DwBwdArgs { DwArgs d, w; int dgrad_blocks; };
 __global__ __launch_bounds__(T) void dw_bwd_kernel(const DwBwdArgs b) {
   if ((int)blockIdx.x < b.dgrad_blocks) dw_dgrad_body<true>(b.d, blockIdx.x, b.dgrad_blocks);
-  else dw_wgrad_partial_body(b.w, (int)blockIdx.x - b.dgrad_blocks);
+  else dw_wgrad_partial_body(b.w, rn::xcd_remap((int)blockIdx.x - b.dgrad_blocks, (int)gridDim.x - b.dgrad_blocks));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -221,7 +226,8 @@ __global__ __launch_bounds__(ST) void dw_fwd_stats_kernel(const DwStatArgs b) {
   const int tid = threadIdx.x, C = a.c, CQ = C >> 2, lanes = ST / CQ;
   const int q4 = tid % CQ, pl = tid / CQ;
   const bool active = pl < lanes;
-  const int sample = blockIdx.x / b.chunks_ps, ck = blockIdx.x - sample * b.chunks_ps;
+  const int chunk = rn::xcd_remap(blockIdx.x, gridDim.x);      // neighbouring pixel chunks share taps: one XCD's L2
+  const int sample = chunk / b.chunks_ps, ck = chunk - sample * b.chunks_ps;
   const int ohw = a.oh * a.ow;
   const int p_begin = ck * b.ppc, p_end = min(p_begin + b.ppc, ohw);
   float4 wv[9];
@@ -274,13 +280,14 @@ __global__ __launch_bounds__(ST) void dw_fwd_stats_kernel(const DwStatArgs b) {
   for (int g = tid; g < st.groups; g += ST) {   // channels of a group in order
     float t1 = 0.f, t2 = 0.f;
     for (int j = 0; j < st.cpg; ++j) { t1 += chan[g * st.cpg + j][0]; t2 += chan[g * st.cpg + j][1]; }
-    st.rows[(size_t)blockIdx.x * st.groups + g] = make_float2(t1, t2);
+    st.rows[(size_t)chunk * st.groups + g] = make_float2(t1, t2);
   }
 }
 
 int fill(DwArgs* a, int n, int h, int w, int c, int k, int stride) {
   RN_CHECK_ARG(n >= 1 && h >= 1 && w >= 1 && c >= 1 && k >= 1 && stride >= 1, "depthwise: bad shape");
   RN_UNSUPPORTED(c % 4 != 0 || c > 1024, "depthwise: c=%d must be a multiple of 4 and <= 1024", c);
+  RN_UNSUPPORTED((double)n * h * w * c >= 536870912.0, "depthwise: tensors of 2 GiB and more are not supported");   // 32-bit indices
   a->n = n; a->h = h; a->wd = w; a->c = c; a->k = k; a->stride = stride;
   rn::same_pad(h, k, stride, &a->oh, &a->pad_t);
   rn::same_pad(w, k, stride, &a->ow, &a->pad_l);
@@ -318,14 +325,14 @@ extern "C" int rn_depthwise_fwd(const float* x, const float* wgt, float* y, int 
 }
 
 namespace {
-// plan of the statistics kernel: pixels per thread R (4, or 8 / 16 where that keeps a sample at <= 256 rows)
+// plan of the statistics kernel: pixels per thread R (4, or 8 / 16 where that keeps a sample at <= 1024 rows)
 bool stats_plan(const DwArgs& a, int groups, int* R, int* ppc, int* chunks_ps) {
   if (a.k != 3 || groups < 1 || a.c % groups) return false;
   const long ohw = (long)a.oh * a.ow;
   if (ohw >= (1 << 20) || a.ow > 4096 || (double)ohw * (a.c / groups) >= 16777216.0) return false;
   const int lanes = ST / (a.c / 4);
   int r = 4;
-  while (r < 16 && rn::ceil_div((int)ohw, lanes * r) > 256) r *= 2;   // (per-group rows: a few hundred are cheap to merge)
+  while (r < 16 && rn::ceil_div((int)ohw, lanes * r) > 1024) r *= 2;  // (per-group rows: a thousand are still cheap to merge; short blocks: a thread's pixels are a serial chain)
   *R = r; *ppc = lanes * r; *chunks_ps = rn::ceil_div((int)ohw, lanes * r);
   return rn_group_norm_rows_ok(a.c, groups, *chunks_ps, 1) != 0;
 }

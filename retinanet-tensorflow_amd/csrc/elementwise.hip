@@ -493,8 +493,9 @@ __global__ __launch_bounds__(256) void dropout_strided_kernel(const float* __res
   const float ks = rate > 0.f ? 1.f / (1.f - rate) : 1.f;
   const int cq = c >> 2;
   const int64_t total = pixels * cq;
+  const bool small = total < (1ll << 31);   // a 64-bit division by a runtime divisor is ~150 instructions per element
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t p = i / cq;
+    const int64_t p = small ? (int64_t)((unsigned)i / (unsigned)cq) : i / cq;
     const int q = (int)(i - p * cq);
     float4 v = *reinterpret_cast<const float4*>(x + p * x_ld + x_coff + q * 4);
     if (rate > 0.f) {
