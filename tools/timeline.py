@@ -1,6 +1,6 @@
 """Where a step's time goes, from a rocprofv3 kernel trace of `bench.py` (host-side analysis, no GPU needed):
 usage: python tools/timeline.py gpurun_out/final_prof/bench_kernel_trace.csv
-Takes the last full step (from one anchor-assignment kernel to the next), and reports: wall time, time with >= 1 kernel
+Takes the step of median wall time among the last ten (from one anchor-assignment kernel to the next), and reports: wall time, time with >= 1 kernel
 running, idle time, time with two kernels overlapping, kernels per step, and the per-kernel-family totals."""
 import csv
 import re
@@ -17,9 +17,11 @@ def main(path):
     rows = [r for r in csv.DictReader(open(path))]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     marks = [i for i, r in enumerate(rows) if 'assign_kernel' in r['Kernel_Name']]
-    # steps = spans between consecutive assign kernels; use the median-length one among the last ten
+    # steps = spans between consecutive assign kernels; of the last ten, the one of median WALL time (the profiler's buffer
+    # flushes put multi-millisecond holes into some steps)
     spans = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1)]
     spans = [s for s in spans if 300 < s[1] - s[0] < 700][-10:]
+    spans.sort(key=lambda s: int(rows[s[1]]['Start_Timestamp']) - int(rows[s[0]]['Start_Timestamp']))
     lo, hi = spans[len(spans) // 2]
     step = rows[lo:hi]
     t0 = int(step[0]['Start_Timestamp'])
