@@ -572,6 +572,9 @@ int rn_optimizer_step(int kind, float* w, const float* grad, float* state1, floa
                       const float* norm_sq, int64_t step, uint64_t* advance_counter, uint64_t advance_by, rn_stream_t stream);
 /* *counter += inc on the stream (the same counter, for callers that run backward passes without an optimizer step) */
 int rn_counter_add(uint64_t* counter, uint64_t inc, rn_stream_t stream);
+/* p[0..count) = 0 (16-byte aligned): the gradient arena before a backward pass (the reference's graph zero-initialises
+ * its gradient accumulators, train.py:121-123) */
+int rn_zero(float* p, int64_t count, rn_stream_t stream);
 
 /* out = a + b for up to RN_MAX_SEG tensors in one launch (count floats each, 16-byte aligned): the sum autograd forms when
  * a tensor feeds two branches -- a bottleneck's input (expand conv + identity, mobilenet_v2.py:91-92), a pyramid level

@@ -122,7 +122,7 @@ _lib = None
 SYMBOLS = [
     "rn_version", "rn_last_error", "rn_same_pad",
     "rn_conv2d_fwd_workspace", "rn_conv2d_dgrad_workspace",
-    "rn_conv2d_fwd", "rn_conv2d_stats_rows", "rn_conv2d_fwd_stats", "rn_depthwise_stats_rows", "rn_depthwise_fwd_stats", "rn_group_norm_rows_ok",
+    "rn_zero", "rn_conv2d_fwd", "rn_conv2d_stats_rows", "rn_conv2d_fwd_stats", "rn_depthwise_stats_rows", "rn_depthwise_fwd_stats", "rn_group_norm_rows_ok",
     "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad", "rn_conv2d_bwd",
     "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes",
@@ -168,6 +168,7 @@ def lib():
         L.rn_depthwise_wgrad.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_conv2d_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_conv2d_dgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.rn_zero.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.rn_conv2d_stats_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.rn_conv2d_fwd_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_depthwise_stats_rows.argtypes = [C.c_int] * 7 + [C.c_void_p]

@@ -149,3 +149,20 @@ extern "C" int rn_counter_add(uint64_t* counter, uint64_t inc, rn_stream_t strea
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
+
+namespace {
+__global__ __launch_bounds__(T) void zero_kernel(float* __restrict__ p, int64_t count) {
+  const int64_t nquad = count / 4;
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < nquad; i += (int64_t)gridDim.x * T)
+    *reinterpret_cast<float4*>(p + i * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x == 0 && threadIdx.x < (int)(count - nquad * 4)) p[nquad * 4 + threadIdx.x] = 0.f;
+}
+}  // namespace
+
+extern "C" int rn_zero(float* p, int64_t count, rn_stream_t stream) {
+  RN_CHECK_ARG(p && count >= 0 && ((uintptr_t)p & 15) == 0, "zero: null / unaligned pointer");
+  if (count == 0) return RN_OK;
+  hipLaunchKernelGGL(zero_kernel, dim3(grid_for(count / 4 + 1)), dim3(T), 0, (hipStream_t)stream, p, count);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}

@@ -61,7 +61,10 @@ class ParamArena(object):
         self.wd_per_block = torch.from_numpy(wd).to(device)
 
     def zero_grad(self):
-        self.grads.zero_()
+        if self.grads.is_cuda:          # our own kernel: no PyTorch kernel inside the step
+            _rn.check(_rn.lib().rn_zero(_rn.f32(self.grads), self.grads.numel(), _rn.stream()), "rn_zero")
+        else:
+            self.grads.zero_()
 
 
 class Optimizer(object):
