@@ -130,7 +130,8 @@ def _det_call(fn_name, probs, boxes, num_classes, n, score_threshold, iou_thresh
     out_class = torch.empty((cap,), dtype=torch.int32, device=dev)
     out_image = torch.empty((cap,), dtype=torch.int32, device=dev)
     out_anchor = torch.empty((cap,), dtype=torch.int64, device=dev)
-    counts = torch.zeros((2 + n,), dtype=torch.int64, device=dev)
+    counts = torch.empty((2 + n,), dtype=torch.int64, device=dev)
+    _rn.check(L.rn_zero(_rn.ptr(counts), 2 * (2 + n), _rn.stream()), "rn_zero")     # (our kernel: no PyTorch fill on the detection path)
     _rn.check(getattr(L, fn_name)(levels, len(probs), C.byref(params), _rn.f32(out_boxes), _rn.f32(out_scores),
                                   _rn.ptr(out_class), _rn.ptr(out_image), _rn.ptr(out_anchor), _rn.ptr(counts),
                                   ws.data_ptr(), ws.numel(), _rn.stream()), fn_name)
