@@ -1273,3 +1273,13 @@ def test_producer_statistics_decline_what_they_cannot_do(dev):
         y = ops.conv2d(x, wt, None, 1, 1, gn=(32, 1e-5))
         assert not hasattr(y, "_gn_rows")
         assert torch.equal(y, ops.conv2d(x, wt))
+
+
+def test_zero_kernel_clears_exactly_the_range(dev):
+    """rn_zero (the gradient arena before a backward pass, the detector's counters): every float of the range, none beyond."""
+    import _rn
+    for count in (1, 3, 4, 1023, 1024 * 1024 + 5):
+        t = torch.full((count + 8,), 7.0, device=dev)
+        _rn.check(_rn.lib().rn_zero(_rn.f32(t), count, _rn.stream()), "rn_zero")
+        torch.cuda.synchronize()
+        assert float(t[:count].abs().sum()) == 0.0 and bool((t[count:] == 7.0).all())
