@@ -71,12 +71,12 @@ def make_batch(rank, device):
     img = torch.randn((1, IMAGE_SIZE, IMAGE_SIZE, 3), generator=g)
     image = torch.cat([img, torch.flip(img, [2])], 0).to(device).contiguous()
     boxes, cls, o = synthetic_objects(rng)
-    b = torch.from_numpy(boxes)
-    boxes2 = torch.stack([b, dataset.flip_boxes(b)], 0).to(device).contiguous()
-    boxes2[1, o:] = 0
-    cls2 = torch.from_numpy(np.stack([cls, cls])).to(device).contiguous()
-    nobj = torch.tensor([o, o], dtype=torch.int32, device=device)
-    return image, boxes2, cls2, nobj
+    # the objects of the SAMPLE only: the mirror image's labels are the sample's label maps flipped (augmentation.py:5-22),
+    # written by the same assignment launch (dataset.build_labels(flip_pair=True))
+    boxes1 = torch.from_numpy(boxes)[None].to(device).contiguous()
+    cls1 = torch.from_numpy(cls)[None].to(device).contiguous()
+    nobj = torch.tensor([o], dtype=torch.int32, device=device)
+    return image, boxes1, cls1, nobj
 
 
 class Step(object):
@@ -99,9 +99,11 @@ class Step(object):
         train.broadcast_initial_state(self.trainer)
 
     def features(self):
-        """Device-side anchor assignment of the batch (inside the timed step, inside segment A's graph)."""
+        """Device-side anchor assignment of the batch (inside the timed step, inside segment A's graph): the sample is
+        assigned once, its maps and their flipped copies fill the two batch slots -- the reference's [labels, flip(labels)]
+        (dataset.py:182-204), bit for bit."""
         c, r, m = self.dataset.build_labels((IMAGE_SIZE, IMAGE_SIZE), self.cls, self.boxes, self.levels, NUM_CLASSES,
-                                            num_obj=self.nobj)
+                                            num_obj=self.nobj, flip_pair=True)
         return {'image': self.image, 'detection': {'classifications': c, 'regressions': r}, 'trainable_masks': m}
 
     def __call__(self):

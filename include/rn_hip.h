@@ -46,6 +46,9 @@ enum rn_opt { RN_OPT_MOMENTUM = 0, RN_OPT_RMSPROP = 1, RN_OPT_ADAM = 2 };
 /* caller-owned list that collects deferred row reductions (see "deferred gradient reductions" below) */
 typedef struct rn_reduce_list rn_reduce_list;
 
+/* Version of this header's ABI: bumped whenever an entry point's arguments or a struct layout change.  rn_version() returns
+ * the value the library was built with; a caller built against another value must not call anything else. */
+#define RN_API_VERSION 300
 int rn_version(void);
 const char* rn_last_error(void);
 
@@ -472,6 +475,8 @@ int rn_iou(const float* a, int64_t na, const float* b, int64_t nb, int pairwise,
  * Replaces dataset.level_labels / build_labels (dataset.py:43-142) for a batch of images:
  * IoU of every anchor with every object -> arg-max/max -> one-hot class (zero where IoU<0.5),
  * log-space regression target of the arg-max object, trainable = IoU<0.4 || IoU>=0.5.
+ * Degenerate objects (zero / negative extent) behave as in the reference's reduce_sum(regression * one_hot, 0)
+ * (dataset.py:118-121): the log-size component of every anchor NOT assigned to such an object is NaN (-inf * 0).
  * boxes [nimg, max_obj, 4] normalised corners, class_ids [nimg, max_obj], num_obj [nimg] (>=1).
  * anchor_sizes [A,2] already divided by the image size (levels.py:38-44, dataset.py:53).
  */
@@ -492,6 +497,13 @@ typedef struct rn_assign_level {
 int rn_anchor_assign_levels(const float* boxes, const int32_t* class_ids, const int32_t* num_obj, int nimg, int max_obj,
                             const rn_assign_level* levels, int nlevel, int num_anchors, int num_classes,
                             rn_stream_t stream);
+/* The reference's batch of two (dataset.py:182-204: [sample, augmentation.flip(sample)], augmentation.py:5-22) straight from
+ * the assignment: every source image i is assigned ONCE and written to two batch slots -- [2i] as is, [2i+1] with every
+ * map reversed along W and the x shift (regression component 1) negated -- so the mirror image's labels are the flipped
+ * MAPS bit for bit (assigning mirrored boxes rounds 1 - x differently).  Outputs hold 2 * nimg images. */
+int rn_anchor_assign_levels_pair(const float* boxes, const int32_t* class_ids, const int32_t* num_obj, int nimg, int max_obj,
+                                 const rn_assign_level* levels, int nlevel, int num_anchors, int num_classes,
+                                 rn_stream_t stream);
 
 /* ------------------------------------------------------------------ decode + NMS
  * rn_decode_boxes: utils.regression_postprocess (utils.py:108-117): exp, anchor scale, add

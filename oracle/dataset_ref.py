@@ -73,7 +73,12 @@ def level_labels(image_size, class_id, true_box, anchor_sizes_px, factor, num_cl
     with np.errstate(divide="ignore"):
         scales = np.log((t_size / size).astype(f32)).astype(f32)
     regr_all = np.concatenate([shifts, scales], -1)
-    regression = np.take_along_axis(regr_all, iou_index[None, ..., None], 0)[0]
+    # dataset.py:118-121: reduce_sum(regression * one_hot(iou_index, num_objects, axis=0), 0) -- a product with the
+    # one-hot, not a gather: a non-finite entry (log of a zero / negative extent) of an object that is NOT the arg-max
+    # still poisons the sum (-inf * 0 = NaN).  With finite entries the sum is the arg-max object's row exactly.
+    sel = (np.arange(o).reshape(o, 1, 1, 1) == iou_index[None]).astype(f32)[..., None]
+    with np.errstate(invalid="ignore"):
+        regression = (regr_all * sel).sum(0, dtype=f32)
     return onehot, regression.astype(f32), trainable, iou_index
 
 

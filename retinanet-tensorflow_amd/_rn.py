@@ -19,6 +19,7 @@ LOSS_MODE = {"bce_dice": 0, "focal": 1}
 OPT = {"momentum": 0, "rmsprop": 1, "adam": 2}
 OPT_BLOCK = 1024
 LOSS_STATS_HEADER = 8
+API_VERSION = 300        # RN_API_VERSION of include/rn_hip.h these bindings were written against
 
 
 class RnError(RuntimeError):
@@ -134,7 +135,7 @@ SYMBOLS = [
     "rn_pack_weights_f16", "rn_cast_f32_to_f16", "rn_pad_cast_rgb_f16", "rn_conv2d_fwd_f16", "rn_maxpool_fwd_f16", "rn_upsample_add_fwd_f16",
     "rn_act_fwd_f16", "rn_flip_width", "rn_dropout", "rn_dropout_strided", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_maxpool_bwd_arg", "rn_avgpool_fwd", "rn_avgpool_bwd",
     "rn_loss_workspace", "rn_loss_fwd", "rn_loss_bwd",
-    "rn_iou", "rn_anchor_assign", "rn_anchor_assign_levels", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
+    "rn_iou", "rn_anchor_assign", "rn_anchor_assign_levels", "rn_anchor_assign_levels_pair", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
     "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
     "rn_optimizer_workspace", "rn_grad_norm_l2reg", "rn_optimizer_step", "rn_counter_add", "rn_add_segs",
 ]
@@ -148,6 +149,9 @@ def lib():
             raise RnError("librn_hip.so not found at %s: build it with "
                           "`make -C retinanet-tensorflow_amd/csrc` (there is no fallback path)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
+        if not hasattr(L, "rn_version") or L.rn_version() != API_VERSION:
+            raise RnError("%s reports ABI version %s, these bindings need %d: rebuild it (make -C retinanet-tensorflow_amd/csrc)"
+                          % (LIB_PATH, L.rn_version() if hasattr(L, "rn_version") else "none", API_VERSION))
         L.rn_last_error.restype = C.c_char_p
         L.rn_group_norm_sync_bytes.argtypes = []
         for name in ("rn_conv2d_wgrad_workspace", "rn_depthwise_wgrad_workspace", "rn_group_norm_workspace", "rn_group_norm_sync_bytes",
@@ -240,6 +244,7 @@ def lib():
                                       [C.c_void_p] * 4 + [C.c_void_p]
         L.rn_anchor_assign_levels.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p]
+        L.rn_anchor_assign_levels_pair.argtypes = L.rn_anchor_assign_levels.argtypes
         L.rn_decode_boxes.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
         L.rn_detect_workspace.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_detect.argtypes = [C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 6 + [C.c_void_p, C.c_size_t,
@@ -315,25 +320,31 @@ _sync_words = {}
 def sync_counters(device):
     """The zeroed region (rn_group_norm_sync_bytes()) per (device, current stream) for rn_gn_params.sync: counters and
     exchange rows of the grid-resident GroupNorm path.  Word 2 is set if a wait ever timed out."""
-    # like workspace(): one region for the main stream (default, warm-up or graph-capture stream -- never concurrent
-    # with each other) and one per registered side stream, so nothing is allocated (and zero-filled) inside a capture
-    h = stream().value
-    key = (device.type, device.index, h if h in SIDE_STREAMS else 0)
+    # one region per stream HANDLE (two grid-resident kernels that run concurrently on different streams must not share
+    # tags / exchange rows).  Nothing may be allocated (and zero-filled) inside a graph capture: a capturing stream without
+    # a region of its own takes the region of key 0 -- the one the warm-up pass before the capture sized -- which it shares
+    # with nobody while the capture (and later the replay, on the stream that replays it) is the only user.
+    h = stream().value or 0
+    capturing = torch.cuda.is_current_stream_capturing() if device.type == 'cuda' else False
+    key = (device.type, device.index, 0 if (capturing and (device.type, device.index, h) not in _sync_words) else h)
     t = _sync_words.get(key)
     if t is None:
+        if capturing:
+            raise RnError("the grid-resident GroupNorm's exchange region must exist before graph capture (run the step once eagerly)")
         t = torch.zeros(lib().rn_group_norm_sync_bytes() // 4, dtype=torch.int32, device=device)
         _sync_words[key] = t
+        _sync_words.setdefault((device.type, device.index, 0), t)
     return t
 
 
 def barrier_timeouts():
     """Number of (device, stream) counter sets whose error word is set (should always be 0)."""
-    return sum(int(t[2].item()) for t in _sync_words.values())
+    return sum(int(t[2].item()) for t in {id(t): t for t in _sync_words.values()}.values())
 
 
 def reset_barrier_timeouts():
     """Clear the error words (after the caller has dealt with a reported timeout, e.g. by switching the path off)."""
-    for t in _sync_words.values():
+    for t in {id(t): t for t in _sync_words.values()}.values():
         t[2] = 0
 
 

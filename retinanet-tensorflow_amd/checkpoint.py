@@ -21,7 +21,8 @@ def save(path, net, trainer=None, step=0, extra=None):
             tensors["optimizer/state1/" + name] = trainer.opt.state1[off:off + size].detach().cpu().clone().view(p.shape)
             if trainer.opt.state2 is not None:
                 tensors["optimizer/state2/" + name] = trainer.opt.state2[off:off + size].detach().cpu().clone().view(p.shape)
-        tensors["trainer/drop_counter"] = trainer.drop_counter.detach().cpu().clone()
+        # (stored without this replica's offset: every rank adds its own back on load, replicas keep distinct dropout streams)
+        tensors["trainer/drop_counter"] = trainer.drop_counter.detach().cpu().clone() - int(getattr(trainer, "drop_rank_offset", 0))
         meta.update(optimizer=trainer.opt.kind, step_count=str(trainer.opt.step_count))
     if extra:
         meta["extra"] = json.dumps(extra)
@@ -31,12 +32,36 @@ def save(path, net, trainer=None, step=0, extra=None):
     os.replace(tmp, path)
 
 
+def load_extra(path):
+    """The `extra` dict a checkpoint was saved with (train.py main(): epochs done, samples drawn per rank); {} if none."""
+    with safe_open(path, framework="pt") as f:
+        meta = f.metadata() or {}
+    return json.loads(meta["extra"]) if "extra" in meta else {}
+
+
 def load(path, net, trainer=None):
     """Restores in place (the parameters keep pointing into the trainer's arena).  Returns the saved step.
     Missing keys and shape mismatches raise a ValueError that names the parameter."""
     with safe_open(path, framework="pt") as f:
         meta = f.metadata() or {}
         keys = set(f.keys())
+        fmt = meta.get("format")
+        if fmt != "retinanet-amd-v2":       # checked BEFORE any weight is overwritten in place
+            raise ValueError("checkpoint %s has format %r; this build reads 'retinanet-amd-v2' (per-parameter optimizer slots)" % (path, fmt))
+        if trainer is not None and meta.get("optimizer") is not None:
+            if meta.get("optimizer") != trainer.opt.kind:
+                raise ValueError("checkpoint optimizer %s != %s" % (meta.get("optimizer"), trainer.opt.kind))
+            need = ["optimizer/state1/"] + (["optimizer/state2/"] if trainer.opt.state2 is not None else [])
+            for k, _ in net.named_parameters():
+                for pre in need:
+                    if pre + k not in keys:
+                        raise ValueError("checkpoint %s has no tensor %r" % (path, pre + k))
+        for k, p in net.named_parameters():
+            if "model/" + k not in keys:
+                raise ValueError("checkpoint %s has no tensor %r" % (path, "model/" + k))
+            shape = tuple(f.get_slice("model/" + k).get_shape())
+            if shape != tuple(p.shape):
+                raise ValueError("checkpoint %s: %r has shape %s, the model expects %s" % (path, "model/" + k, shape, tuple(p.shape)))
 
         def get(key, like):
             if key not in keys:
@@ -59,7 +84,8 @@ def load(path, net, trainer=None):
                     if trainer.opt.state2 is not None:
                         trainer.opt.state2[off:off + size].copy_(get("optimizer/state2/" + name, p).reshape(-1).to(trainer.opt.state2.device))
                 if "trainer/drop_counter" in keys:
-                    trainer.drop_counter.copy_(f.get_tensor("trainer/drop_counter").to(trainer.drop_counter.device))
+                    trainer.drop_counter.copy_((f.get_tensor("trainer/drop_counter") + int(getattr(trainer, "drop_rank_offset", 0)))
+                                               .to(trainer.drop_counter.device))
                 trainer.opt.step_count = int(meta.get("step_count", 0))
     import ops_f16
     ops_f16.weights_changed()

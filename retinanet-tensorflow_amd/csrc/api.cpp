@@ -14,5 +14,5 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace rn
 
-extern "C" int rn_version(void) { return 100; }
+extern "C" int rn_version(void) { return RN_API_VERSION; }
 extern "C" const char* rn_last_error(void) { return rn::g_err; }

@@ -23,6 +23,12 @@ class Shapes(Base):
     def num_classes(self):
         return len(self._class_names)
 
+    def skip(self, n):
+        """Advance the sample stream by n samples (resuming a run: the checkpoint stores how many were drawn)."""
+        it = iter(self)
+        for _ in range(int(n)):
+            next(it)
+
     def __iter__(self):
         h, w = self._image_size
         yy, xx = np.mgrid[0:h, 0:w]

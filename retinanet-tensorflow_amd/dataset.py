@@ -49,15 +49,19 @@ def level_labels(image_size, class_id, true_box, level, factor, num_classes, num
     return cls, reg, msk
 
 
-def build_labels(image_size, class_ids, boxes, levels, num_classes, num_obj=None):
+def build_labels(image_size, class_ids, boxes, levels, num_classes, num_obj=None, flip_pair=False):
     """dataset.py:126-142 for a batch: every level's maps from one launch (rn_anchor_assign_levels); the per-level
-    results are the ones `level_labels` gives."""
+    results are the ones `level_labels` gives.
+    flip_pair=True: the reference's batch of two per sample (dataset.py:182-204) from the same launch -- image i is assigned
+    once and fills batch slots 2i (as is) and 2i+1 (= augmentation.flip of its maps: W reversed, x shift negated), so the
+    mirror image's labels are bit for bit the flipped maps, and the assignment runs once per sample."""
     dev = boxes.device
-    n, o = boxes.shape[0], boxes.shape[1]
+    n_src, o = boxes.shape[0], boxes.shape[1]
+    n = 2 * n_src if flip_pair else n_src
     boxes = boxes.contiguous().float()
     class_ids = class_ids.to(torch.int32).contiguous()
     if num_obj is None:
-        num_obj = torch.full((n,), o, dtype=torch.int32, device=dev)
+        num_obj = torch.full((n_src,), o, dtype=torch.int32, device=dev)
     num_obj = num_obj.to(torch.int32).contiguous()
     names = list(levels)
     lv = (_rn.AssignLevel * len(names))()
@@ -75,8 +79,9 @@ def build_labels(image_size, class_ids, boxes, levels, num_classes, num_obj=None
         keep.append(anchors)
         lv[i] = _rn.AssignLevel(anchors.data_ptr(), gh, gw, classifications[pn].data_ptr(), regressions[pn].data_ptr(),
                                 trainable_masks[pn].data_ptr(), None)
-    _rn.check(_rn.lib().rn_anchor_assign_levels(_rn.f32(boxes), _rn.ptr(class_ids), _rn.ptr(num_obj), n, o, lv, len(names),
-                                                a, num_classes, _rn.stream()), 'rn_anchor_assign_levels')
+    fn = _rn.lib().rn_anchor_assign_levels_pair if flip_pair else _rn.lib().rn_anchor_assign_levels
+    _rn.check(fn(_rn.f32(boxes), _rn.ptr(class_ids), _rn.ptr(num_obj), n_src, o, lv, len(names), a, num_classes, _rn.stream()),
+              'rn_anchor_assign_levels')
     return classifications, regressions, trainable_masks
 
 
@@ -137,12 +142,10 @@ def build_dataset(data_loader, levels, scale=None, shuffle=None, augment=False, 
             image = rescale_image(image, size=(h, w))
         size = (int(image.shape[0]), int(image.shape[1]))
         ids = torch.from_numpy(np.asarray(sample['class_ids'], np.int32)).to(dev)[None]
-        c, r, m = build_labels(size, ids, torch.from_numpy(boxes).to(dev)[None], levels, data_loader.num_classes)
-        one = {'image': image, 'image_size': size, 'boxes': boxes, 'class_ids': sample['class_ids'],
-               'detection': {'classifications': {k: v[0] for k, v in c.items()},
-                             'regressions': {k: v[0] for k, v in r.items()}},
-               'trainable_masks': {k: v[0] for k, v in m.items()}}
-        batch = augmentation.make_pair(one)
+        # the labels of [sample, hflip(sample)] from ONE assignment launch (flip_pair: no stack / flip kernels for the maps)
+        c, r, m = build_labels(size, ids, torch.from_numpy(boxes).to(dev)[None], levels, data_loader.num_classes, flip_pair=True)
+        batch = {'image': torch.stack([image, augmentation._flip(image, 1)], 0), 'image_size': size, 'boxes': boxes,
+                 'class_ids': sample['class_ids'], 'detection': {'classifications': c, 'regressions': r}, 'trainable_masks': m}
         if normalize:
             batch['image'] = preprocess_image(batch['image'])
         yield batch

@@ -797,8 +797,10 @@ def gn_groups(c, groups=32):
     return g
 
 
-# single-kernel GroupNorm for mid-sized maps (<= 128 co-resident blocks meeting at a bounded in-kernel barrier)
-GN_GRID_RESIDENT = os.environ.get("RN_GN_GRID_RESIDENT", "1") == "1"
+# single-kernel GroupNorm for mid-sized maps (<= 128 co-resident blocks exchanging tagged sums, bounded polls).  OFF by
+# default: its blocks wait for each other, which is only safe while nothing else holds CUs (a collective under the backward
+# pass does) -- the default configuration contains no kernel that waits for another block.  RN_GN_GRID_RESIDENT=1 opts in.
+GN_GRID_RESIDENT = os.environ.get("RN_GN_GRID_RESIDENT", "0") == "1"
 
 
 def _gn_params(c, g, eps, act, drop_rate, seed, seed_dev, act_after_residual, device=None):

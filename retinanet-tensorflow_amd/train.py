@@ -120,6 +120,7 @@ class GradientAllReduce(object):
         import torch.distributed as dist
         self.dist, self.group, self.arena = dist, process_group, arena
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         # force: issue the collectives even with one rank (self-tests of the RCCL path on a 1-GPU box)
         self.active = self.world > 1 or (bool(force) and dist.is_initialized())
         self.per = max(OPT_BLOCK, (int(bucket_bytes) // 4) // OPT_BLOCK * OPT_BLOCK)
@@ -211,12 +212,15 @@ class Trainer(object):
             for p, (off, _) in zip(self.arena.params, self.arena.offsets):
                 if p is first:
                     self.cut_offset = off
-            if self.cut_offset:
-                base.backward_cut = self._cut
+        # (the hook itself -- base.backward_cut -- is installed only while one of this trainer's segments runs: _scoped)
+        self._cut_base = base if self.cut_offset else None
         self._cut_src = self._cut_leaves = None
         self._graphs = None
         self._static = None
-        self.drop_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        # the device word every fused dropout hashes (bumped by the optimizer kernel); replicas start it at different values
+        # so that they draw different masks (each tower of the reference's MirroredStrategy has its own dropout stream)
+        self.drop_rank_offset = self.allreduce.rank * 0x632BE59BD9B4E019 % (1 << 62)      # (checkpoints store counter - offset)
+        self.drop_counter = torch.full((1,), self.drop_rank_offset, dtype=torch.int64, device=self.device)
         self._one = torch.ones((), dtype=torch.float32, device=self.device)
         self.check_interval = int(check_interval)
         self.steps_done = 0
@@ -230,10 +234,16 @@ class Trainer(object):
         saved = (ops.DIRECT_PARAM_GRADS, ops.WGRAD_SIDE_STREAM, L.Dropout.seed_device_counter)
         ops.DIRECT_PARAM_GRADS, ops.WGRAD_SIDE_STREAM = self.direct_param_grads, self.wgrad_side_stream
         L.Dropout.seed_device_counter = self.drop_counter
+        base = self._cut_base
+        saved_cut = base.backward_cut if base is not None else None
+        if base is not None:        # plain autograd users of the same net (and other trainers) never see this trainer's cut
+            base.backward_cut = self._cut
         try:
             yield
         finally:
             ops.DIRECT_PARAM_GRADS, ops.WGRAD_SIDE_STREAM, L.Dropout.seed_device_counter = saved
+            if base is not None:
+                base.backward_cut = saved_cut
 
     # -- replica-local work (capturable)
     def _cut(self, taps):
@@ -344,7 +354,9 @@ class Trainer(object):
             grad_scale = self.allreduce.wait()
         self.opt.step(grad_scale, self.drop_counter)          # also bumps the dropout counter: fresh masks next step
         self.steps_done += 1
-        if self.check_interval and self.steps_done % self.check_interval == 0:
+        # (only the opt-in grid-resident GroupNorm can flag anything; checked after the first steps too, not only every
+        # check_interval: a poisoned update must not be trained on for long)
+        if self.check_interval and ops.GN_GRID_RESIDENT and (self.steps_done in (1, 2, 4, 8) or self.steps_done % self.check_interval == 0):
             self.check_device_errors()
         self.last = {'class_loss': class_loss, 'regr_loss': regr_loss,
                      'regularization_loss': self.opt.regularization_loss}
@@ -361,9 +373,17 @@ class Trainer(object):
     def check_device_errors(self):
         """Raise if any kernel of this process has flagged an error on the device (synchronises)."""
         n = _rn.barrier_timeouts()
+        if self.allreduce.active:       # every rank must take the same decision, or the others hang in the next all-reduce
+            t = torch.tensor([float(n)], device=self.device)
+            self.allreduce.dist.all_reduce(t, op=self.allreduce.dist.ReduceOp.MAX, group=self.allreduce.group)
+            n = int(t.item())
         if n:
-            raise _rn.RnError("%d GroupNorm exchange wait(s) timed out: the results of this run are invalid "
-                              "(set RN_GN_GRID_RESIDENT=0 on a shared / partitioned GPU)" % n)
+            ops.GN_GRID_RESIDENT = False        # the launch-ordered kernels from here on (on every rank: n is the max over ranks)
+            _rn.reset_barrier_timeouts()
+            self._graphs = None                 # the captured segments contain the grid-resident kernels: capture again
+            raise _rn.RnError("%d GroupNorm exchange wait(s) timed out on some rank: the updates since the last check are invalid; "
+                              "the grid-resident path is now off (ops.GN_GRID_RESIDENT = False) -- reload the last checkpoint "
+                              "and continue" % n)
 
 
 def _copy_tree(dst, src):
@@ -487,15 +507,18 @@ def main(argv=None):
                               dropout_rate=args.dropout).to(dev)
     trainer = Trainer(net, levels, optimizer=args.optimizer, learning_rate=args.learning_rate,
                       grad_clip_norm=args.grad_clip_norm, loss_mode=args.loss, device=dev)
-    step = 0
+    step, first_epoch = 0, 0
     path = None if args.experiment is None else os.path.join(args.experiment, 'model.safetensors')
     if path is not None and os.path.exists(path):
         step = checkpoint.load(path, net, trainer)                                 # every rank reads the same file
+        extra = checkpoint.load_extra(path)
+        first_epoch = int(extra.get('epochs_done', 0))
+        loader.skip(int(extra.get('samples_drawn', 0)))                            # the sample stream goes on where it stopped
         if rank == 0:
-            print('restored step', step)
+            print('restored step', step, 'epochs done', first_epoch)
     broadcast_initial_state(trainer)
     it = dataset.build_dataset(loader, levels, scale=args.scale, device=dev)       # train.py:192-203 train_input_fn
-    for epoch in range(args.epochs):
+    for epoch in range(first_epoch, args.epochs):
         for _ in range(args.steps_per_epoch):
             out = trainer.step(next(it))                                           # batch = [image, hflip]
             step += 1
@@ -505,7 +528,7 @@ def main(argv=None):
                     flush=True)
         trainer.check_device_errors()
         if path is not None and rank == 0:                                         # replicas are identical: rank 0 writes
-            checkpoint.save(path, net, trainer, step=step)
+            checkpoint.save(path, net, trainer, step=step, extra={'epochs_done': epoch + 1, 'samples_drawn': step})
     if args.eval_images and rank == 0:
         res = evaluate(net, Shapes(None, image_size=(args.scale + args.scale // 4, args.scale), seed=12345), levels,
                        args.eval_images, scale=args.scale, device=dev)

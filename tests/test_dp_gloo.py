@@ -93,7 +93,11 @@ def _trainer_worker(rank, world, port, out_dir):
     assert all(offs[id(p)] < tr.cut_offset for p in net.base.backbone.parameters())
     assert all(offs[id(p)] >= tr.cut_offset for m in (net.base.fpn, net.base.classification_subnet, net.base.regression_subnet)
                for p in m.parameters())
-    assert net.base.backward_cut is not None and tr.allreduce.active and tr.allreduce.world == world
+    # the cut hook is installed only while one of the trainer's segments runs (plain autograd users of the net never see it)
+    assert net.base.backward_cut is None and tr._cut_base is net.base and tr.allreduce.active and tr.allreduce.world == world
+    with tr._scoped():
+        assert net.base.backward_cut is not None
+    assert net.base.backward_cut is None
 
     def sgd(scale, advance_counter=None):
         events.append("opt")

@@ -200,3 +200,37 @@ def test_no_group_norm_barrier_timeouts(dev):
     (eager, hipGraph, two head streams) no barrier may have given up."""
     import _rn
     assert _rn.barrier_timeouts() == 0
+
+
+def test_plain_autograd_after_a_trainer_exists(dev):
+    """The trainer's backward cut (detached leaves at the backbone taps) is installed only while one of ITS segments runs:
+    a plain `net(x, training=True)` + backward on the same net -- before, between and after trainer steps, and with a
+    second trainer built on it -- still reaches the backbone."""
+    import losses, train, utils, levels as levels_mod
+    net, params, image, labels = _tiny_problem(dev)
+    lv = levels_mod.build_levels()
+    feats = _features(image, labels, dev)
+
+    def plain_backward():
+        for p in net.parameters():
+            p.grad = None
+        out = {'detection': net(feats['image'], training=True)}
+        inp, logits = utils.process_labels_and_logits(labels=feats, logits=out, levels=lv)
+        cl, rl = losses.loss(labels=inp['detection_trainable'], logits=logits['detection_trainable'], mode='focal')
+        (cl + rl).backward()
+        g = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+        assert all(n in g for n, _ in net.named_parameters()), "a parameter got no gradient"
+        return g
+
+    before = plain_backward()
+    assert float(before['base.backbone.input_conv._mods.0.weight'].abs().max()) > 0
+    tr1 = train.Trainer(net, lv, loss_mode='focal', device=dev)
+    assert net.base.backward_cut is None
+    tr1.forward_backward(feats)
+    with_trainer = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+    tr2 = train.Trainer(net, lv, loss_mode='focal', device=dev)        # re-points the parameters into ITS arena
+    tr2.forward_backward(feats)
+    after = plain_backward()
+    for n in before:
+        assert_close(after[n].cpu().numpy(), before[n].cpu().numpy(), 1e-5, "plain backward after trainers: " + n)
+        assert_close(with_trainer[n].cpu().numpy(), before[n].cpu().numpy(), 1e-5, "trainer segments vs plain backward: " + n)

@@ -334,6 +334,61 @@ def test_anchor_assignment_bit_exact(dev, mode):
         dataset.ANCHOR_SIZE_MODE = "trunc_int"
 
 
+def test_assignment_flip_pair_is_the_flipped_maps(dev):
+    """dataset.py:182-204 / augmentation.py:5-22: build_labels(flip_pair=True) writes [labels, flip(labels)] from ONE assignment:
+    slot 2i is the plain assignment of image i, slot 2i+1 the oracle's flip of those maps (W reversed, x shift negated), bit
+    for bit -- and equal to what augmentation.flip (the flip kernel) makes of the plain maps."""
+    import augmentation, dataset, levels
+    lv = levels.build_levels()
+    rng = np.random.default_rng(11)
+    size, c, nimg, max_obj = (192, 160), 7, 3, 9
+    boxes = np.zeros((nimg, max_obj, 4), np.float32)
+    cids = np.zeros((nimg, max_obj), np.int32)
+    nobj = np.zeros(nimg, np.int32)
+    for i in range(nimg):
+        b, k = coco_like_objects(rng, 160, max_obj)
+        nobj[i] = len(b)
+        boxes[i, :len(b)], cids[i, :len(b)] = b, k % c
+    pc, pr, pm = dataset.build_labels(size, _t(cids, dev), _t(boxes, dev), lv, c, num_obj=_t(nobj, dev), flip_pair=True)
+    ac, ar, am = dataset.build_labels(size, _t(cids, dev), _t(boxes, dev), lv, c, num_obj=_t(nobj, dev))
+    for i in range(nimg):
+        oc, orr, om = dataset_ref.build_labels(size, cids[i, :nobj[i]], boxes[i, :nobj[i]], c)
+        fc, fr, fm, _ = dataset_ref.flip(oc, orr, om)
+        one = {'image': torch.zeros((size[0], size[1], 3), device=dev),
+               'detection': {'classifications': {k: ac[k][i] for k in lv}, 'regressions': {k: ar[k][i] for k in lv}},
+               'trainable_masks': {k: am[k][i] for k in lv}}
+        fl = augmentation.flip(one)
+        for k in lv:
+            assert pc[k].shape[0] == 2 * nimg
+            assert torch.equal(pc[k][2 * i], ac[k][i]) and torch.equal(pr[k][2 * i], ar[k][i]) and torch.equal(pm[k][2 * i], am[k][i]), k
+            assert np.array_equal(pc[k][2 * i + 1].cpu().numpy(), fc[k]), k
+            assert np.array_equal(pm[k][2 * i + 1].cpu().numpy().astype(bool), fm[k]), k
+            assert_close(pr[k][2 * i + 1].cpu().numpy(), fr[k], TOL, "flipped regression targets " + k)
+            assert torch.equal(pc[k][2 * i + 1], fl['detection']['classifications'][k]), k
+            assert torch.equal(pr[k][2 * i + 1], fl['detection']['regressions'][k]), k
+            assert torch.equal(pm[k][2 * i + 1], fl['trainable_masks'][k]), k
+
+
+def test_assignment_degenerate_box_is_the_references_nan(dev):
+    """dataset.py:118-121 picks the arg-max object's target with reduce_sum(regression * one_hot, 0): a zero-extent box
+    (log 0 = -inf) makes the log-size component NaN for every anchor NOT assigned to it (-inf * 0).  Kernel == oracle,
+    NaN for NaN; the finite components and the masks / class maps are untouched."""
+    import dataset, levels
+    lv = levels.build_levels()
+    size, c = (128, 128), 4
+    boxes = np.array([[[0.1, 0.1, 0.5, 0.6], [0.3, 0.7, 0.3, 0.9], [0.55, 0.2, 0.95, 0.6]]], np.float32)   # object 1: zero height
+    cids = np.array([[0, 1, 2]], np.int32)
+    ac, ar, am = dataset.build_labels(size, _t(cids, dev), _t(boxes, dev), lv, c)
+    oc, orr, om = dataset_ref.build_labels(size, cids[0], boxes[0], c)
+    for k in lv:
+        got, want = ar[k][0].cpu().numpy(), orr[k]
+        assert np.array_equal(np.isnan(got), np.isnan(want)), k
+        assert np.isnan(want[..., 2]).any() and not np.isnan(want[..., :2]).any() and not np.isnan(want[..., 3]).any(), k
+        ok = ~np.isnan(want)
+        assert_close(got[ok], want[ok], TOL, "finite regression targets " + k)
+        assert np.array_equal(ac[k][0].cpu().numpy(), oc[k]) and np.array_equal(am[k][0].cpu().numpy().astype(bool), om[k]), k
+
+
 def test_assignment_reference_kat(dev):
     """dataset_test.py:8-45 class map through the HIP kernel."""
     import dataset

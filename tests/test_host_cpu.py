@@ -27,7 +27,9 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), "librn_hip.so does not export %s" % sym
     assert sorted(_rn.SYMBOLS) == declared
-    assert lib.rn_version() == 100
+    # the ABI version of the header the library was built from == the one the ctypes bindings were written against
+    hdr = open(os.path.join(ROOT, "include", "rn_hip.h")).read()
+    assert lib.rn_version() == _rn.API_VERSION == int(re.search(r"#define RN_API_VERSION (\d+)", hdr).group(1))
 
 
 def test_same_pad_c_matches_python():
@@ -185,3 +187,43 @@ def test_trainer_scopes_its_process_wide_switches():
         ops.begin_direct_grad_step()
         assert ops._grad_slot(p)[0] is p.grad
     assert (ops.DIRECT_PARAM_GRADS, ops.WGRAD_SIDE_STREAM, layers.Dropout.seed_device_counter) == before
+
+
+def test_checkpoint_is_validated_before_any_weight_is_touched(tmp_path):
+    """A checkpoint of another format / with a missing or mis-shaped tensor raises BEFORE load() overwrites anything in place."""
+    import checkpoint
+    from safetensors.torch import save_file
+    net = torch.nn.Sequential(torch.nn.Linear(3, 2), torch.nn.Linear(2, 2))
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    good = {"model/" + k: torch.full_like(v, 7.0) for k, v in net.named_parameters()}
+    old = str(tmp_path / "v1.safetensors")
+    save_file(good, old, metadata={"format": "retinanet-amd-v1", "step": "3"})
+    with pytest.raises(ValueError, match="format"):
+        checkpoint.load(old, net)
+    bad = dict(good)
+    bad["model/1.weight"] = torch.zeros(5, 5)
+    p2 = str(tmp_path / "shape.safetensors")
+    save_file(bad, p2, metadata={"format": "retinanet-amd-v2", "step": "3"})
+    with pytest.raises(ValueError, match="1.weight"):
+        checkpoint.load(p2, net)
+    for k, v in net.named_parameters():
+        assert torch.equal(v, before[k]), k
+    ok = str(tmp_path / "ok.safetensors")
+    checkpoint.save(ok, net, step=5, extra={"epochs_done": 2, "samples_drawn": 40})
+    with torch.no_grad():
+        for v in net.parameters():
+            v.zero_()
+    assert checkpoint.load(ok, net) == 5 and checkpoint.load_extra(ok) == {"epochs_done": 2, "samples_drawn": 40}
+    for k, v in net.named_parameters():
+        assert torch.equal(v, before[k]), k
+
+
+def test_shapes_loader_skip_resumes_the_stream():
+    from data_loaders.shapes import Shapes
+    a = Shapes(None, image_size=(64, 64), seed=5)
+    it = iter(a)
+    first = [next(it) for _ in range(4)]
+    b = Shapes(None, image_size=(64, 64), seed=5)
+    b.skip(3)
+    nxt = next(iter(b))
+    assert np.array_equal(nxt['image'], first[3]['image']) and np.array_equal(nxt['boxes'], first[3]['boxes'])
