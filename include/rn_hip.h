@@ -461,6 +461,87 @@ int rn_conv3x3_winograd_gn_bwd(const rn_conv_seg* segs, int nseg, int cin, int c
  * caller's deferred batch when `defer` is given.  Finishes dgamma / dbeta from in_g_rows_chan. */
 int rn_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, rn_stream_t stream, rn_reduce_list* defer);
 
+/* ------------------------------------------------------------------ MobileNetV2 bottleneck chain
+ * Replaces the chain  [conv1x1, Normalization, act, Dropout] -> [DepthwiseConv2D 3x3, Normalization, act, Dropout] ->
+ * [conv1x1, Normalization, Dropout] (+ input)  of mobilenet_v2.py:41-94 (GroupNorm variant: normalization.py:20-35),
+ * forward and backward, with every GroupNorm applied by its CONSUMER while it loads:
+ *   - a conv / depthwise kernel writes its RAW output y and, as a by-product, rows of per-group (sum, sum of squares);
+ *   - the next kernel merges the rows of its sample (fixed order, fp64) and computes dropout(act(GN(y))) [+ residual] on the
+ *     fly in its operand load -- the normalised tensor is never written (a pointwise conv can also write it out once,
+ *     `materialise`: the bottleneck's output is needed again as the next bottleneck's residual / as a pyramid tap);
+ *   - backward: a data-gradient kernel turns its result into g = d * act'(z) * dropout mask of the GroupNorm block it enters
+ *     from behind, stores it, and emits rows of (sum gamma g, sum gamma g xhat) + per-channel planes (sum g, sum g xhat);
+ *     the kernel that needs dy = rstd (gamma g - c1 - xhat c2) of that GroupNorm computes it while loading g and y.
+ * One bottleneck = 3 launches forward, 3 backward (13 through the layer-by-layer path).  No kernel waits for another
+ * block, no atomics; results are bitwise reproducible.  fp32, NHWC; channels % 4 == 0; a sample's pixels are a multiple
+ * of the pointwise kernels' tile height (RN_EUNSUPPORTED otherwise: use the layer-by-layer entry points).
+ *
+ * rn_mb_rows: [n][rows_per_sample][width] pairs of floats.  Entry (group g, producer N-tile t) of a row sits at position
+ * g + t: a pointwise conv's N-tiles (bn channels each) cut through groups, consecutive tiles share at most one group, so
+ * the positions are unique; a depthwise block owns whole groups (bn >= channels: t = 0).  Group g's total is the sum over
+ * the rows and over t = (g cpg) / bn .. ((g + 1) cpg - 1) / bn.  The *_rows functions fill the layout and return the bytes. */
+typedef struct rn_mb_rows {
+  float* rows;
+  int32_t rows_per_sample, width, bn;
+} rn_mb_rows;
+
+/* one GroupNorm (+ activation + dropout) block, described for the kernels on either side of it */
+typedef struct rn_mb_norm {
+  const float* y;             /* the raw conv output it normalises, [n, hw, c] */
+  rn_mb_rows stat;            /* forward: y's (sum, sum sq) rows; stat.rows == NULL: mean / rstd below are READ, not written */
+  float* mean; float* rstd;   /* [n, groups]; the forward consumer writes them, every backward kernel reads them */
+  const float* gamma; const float* beta;   /* [c] */
+  int32_t c, groups, act;     /* act: rn_act applied after the normalisation */
+  float eps, drop_rate;       /* dropout after the activation: keep iff hash(seed, element index of y) >= rate (rn_gn_params) */
+  uint64_t drop_seed; const uint64_t* drop_seed_dev;
+} rn_mb_norm;
+
+/* y[n,hw,cout] = A w, w [cin, cout] (a 1x1 Conv2D kernel, HWIO), A = x (plain) or dropout(act(GN(in->y))) [+ residual];
+ * `materialise` (optional, with `in`): A is also written out, [n,hw,cin].  stat_out (optional): y's rows (layout from
+ * rn_mb_pointwise_rows with the GroupNorm's `groups` that follows y). */
+size_t rn_mb_pointwise_rows(int n, int hw, int cin, int cout, int groups, rn_mb_rows* layout);
+int rn_mb_pointwise_fwd(const float* x, const rn_mb_norm* in, const float* residual, float* materialise, const float* w, float* y,
+                        int n, int hw, int cin, int cout, const rn_mb_rows* stat_out, int stat_groups, rn_stream_t stream);
+/* y = depthwise3x3(dropout(act(GN(in->y)))), TF SAME padding, stride 1 or 2; w [3,3,c]; stat_out: y's rows */
+size_t rn_mb_depthwise_rows(int n, int h, int w, int c, int stride, int groups, rn_mb_rows* layout);
+int rn_mb_depthwise_fwd(const rn_mb_norm* in, const float* w, float* y, int n, int h, int wd, int stride, const rn_mb_rows* stat_out,
+                        int stat_groups, rn_stream_t stream);
+/* out = dropout(act(GN(in->y))) [+ residual]: writes a normalised tensor out (the end of a chain; tests) */
+int rn_mb_apply(const rn_mb_norm* in, const float* residual, float* out, int n, int hw, rn_stream_t stream);
+
+/* the gradient of a conv output y, as a backward kernel loads it */
+typedef struct rn_mb_dy {
+  const float* dy;            /* plain gradient [n,hw,c]; or NULL: computed from the fields below while loading */
+  const rn_mb_norm* norm;     /* the GroupNorm block behind y (mean / rstd as the forward pass wrote them) */
+  const float* g;             /* [n,hw,c] the gradient entering that block from behind */
+  int32_t g_plain;            /* 0: g already carries act' and the dropout mask (a data-gradient epilogue wrote it);
+                                 1: g is the gradient of the block's OUTPUT: the dropout mask is applied while loading
+                                    (the block's activation must be RN_ACT_NONE) */
+  rn_mb_rows grows;           /* the rows (sum gamma g, sum gamma g xhat) g's producer wrote */
+} rn_mb_dy;
+/* what a data-gradient kernel does with its result d = dL/d(input of the conv) */
+typedef struct rn_mb_gout {
+  float* out;                 /* [n,hw,c] */
+  const float* add1; const float* add2;   /* optional, d += add1 + add2 (the residual path's gradient, a pyramid tap's gradient) */
+  const rn_mb_norm* norm;     /* NULL: out = d.  Else the conv's input was norm's block output: g = d act'(z) mask */
+  int32_t store_plain;        /* with norm: 1: out = d (its loader applies the mask: rn_mb_dy.g_plain), 0: out = g */
+  rn_mb_rows grows;           /* out: rows of (sum gamma g, sum gamma g xhat) */
+  float* planes;              /* out: [2][n * grows.rows_per_sample][c] per-channel (sum g | sum g xhat) of every row;
+                                 rn_reduce_rows over the rows gives dbeta | dgamma */
+} rn_mb_gout;
+/* both gradients of rn_mb_pointwise_fwd in one launch: gout->out = dy w^T (+ ...), dw = A^T dy (A = x or the block of `in`).
+ * workspace: rn_mb_pointwise_bwd_workspace bytes (weight-gradient partial sums, summed by the deferred reduction). */
+size_t rn_mb_pointwise_bwd_rows(int n, int hw, int cin, int cout, int groups, rn_mb_rows* layout);   /* layout of gout->grows */
+size_t rn_mb_pointwise_bwd_workspace(int n, int hw, int cin, int cout);
+int rn_mb_pointwise_bwd(const float* x, const rn_mb_norm* in, const rn_mb_dy* dy, const float* w, float* dw, const rn_mb_gout* gout,
+                        int n, int hw, int cin, int cout, void* workspace, size_t workspace_bytes, rn_stream_t stream,
+                        rn_reduce_list* defer);
+/* both gradients of rn_mb_depthwise_fwd in one launch: gout (norm = in) receives the data gradient, dw [3,3,c] */
+size_t rn_mb_depthwise_bwd_rows(int n, int h, int w, int c, int stride, int groups, rn_mb_rows* layout);
+size_t rn_mb_depthwise_bwd_workspace(int n, int h, int w, int c, int stride);
+int rn_mb_depthwise_bwd(const rn_mb_norm* in, const rn_mb_dy* dy, const float* w, float* dw, const rn_mb_gout* gout, int n, int h,
+                        int wd, int stride, void* workspace, size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer);
+
 /* ------------------------------------------------------------------ IoU
  * Replaces utils.iou (utils.py:62-97; known answers utils_test.py:99-118): boxes are corners [y1, x1, y2, x2].
  * pairwise != 0: out[i * nb + j] = IoU(a[i], b[j]) -- the [O,1,1,1,4] x [1,H,W,A,4] -> [O,H,W,A] broadcast of

@@ -99,6 +99,29 @@ class GnRows(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("rows_per_sample", C.c_int32), ("per_group", C.c_int32), ("groups", C.c_int32)]
 
 
+class MbRows(C.Structure):
+    """rn_mb_rows"""
+    _fields_ = [("rows", C.c_void_p), ("rows_per_sample", C.c_int32), ("width", C.c_int32), ("bn", C.c_int32)]
+
+
+class MbNorm(C.Structure):
+    """rn_mb_norm: one GroupNorm (+ activation + dropout) block, applied by the kernels on either side of it"""
+    _fields_ = [("y", C.c_void_p), ("stat", MbRows), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("c", C.c_int32), ("groups", C.c_int32), ("act", C.c_int32), ("eps", C.c_float),
+                ("drop_rate", C.c_float), ("drop_seed", C.c_uint64), ("drop_seed_dev", C.c_void_p)]
+
+
+class MbDy(C.Structure):
+    """rn_mb_dy"""
+    _fields_ = [("dy", C.c_void_p), ("norm", C.POINTER(MbNorm)), ("g", C.c_void_p), ("g_plain", C.c_int32), ("grows", MbRows)]
+
+
+class MbGout(C.Structure):
+    """rn_mb_gout"""
+    _fields_ = [("out", C.c_void_p), ("add1", C.c_void_p), ("add2", C.c_void_p), ("norm", C.POINTER(MbNorm)),
+                ("store_plain", C.c_int32), ("grows", MbRows), ("planes", C.c_void_p)]
+
+
 class LossSeg(C.Structure):
     _fields_ = [("cls_logit", C.c_void_p), ("cls_label", C.c_void_p), ("reg_pred", C.c_void_p),
                 ("reg_label", C.c_void_p), ("trainable", C.c_void_p), ("d_cls_logit", C.c_void_p),
@@ -138,6 +161,9 @@ SYMBOLS = [
     "rn_iou", "rn_anchor_assign", "rn_anchor_assign_levels", "rn_anchor_assign_levels_pair", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
     "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
     "rn_optimizer_workspace", "rn_grad_norm_l2reg", "rn_optimizer_step", "rn_counter_add", "rn_add_segs",
+    "rn_mb_pointwise_rows", "rn_mb_pointwise_fwd", "rn_mb_depthwise_rows", "rn_mb_depthwise_fwd", "rn_mb_apply",
+    "rn_mb_pointwise_bwd_rows", "rn_mb_pointwise_bwd_workspace", "rn_mb_pointwise_bwd",
+    "rn_mb_depthwise_bwd_rows", "rn_mb_depthwise_bwd_workspace", "rn_mb_depthwise_bwd",
 ]
 
 
@@ -260,6 +286,20 @@ def lib():
                                                                        C.c_void_p, C.c_uint64, C.c_void_p]
         L.rn_counter_add.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         L.rn_add_segs.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        for name in ("rn_mb_pointwise_rows", "rn_mb_depthwise_rows", "rn_mb_pointwise_bwd_rows", "rn_mb_pointwise_bwd_workspace",
+                     "rn_mb_depthwise_bwd_rows", "rn_mb_depthwise_bwd_workspace"):
+            getattr(L, name).restype = C.c_size_t
+        L.rn_mb_pointwise_rows.argtypes = [C.c_int] * 5 + [C.c_void_p]
+        L.rn_mb_pointwise_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p]
+        L.rn_mb_depthwise_rows.argtypes = [C.c_int] * 6 + [C.c_void_p]
+        L.rn_mb_depthwise_fwd.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p]
+        L.rn_mb_apply.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]
+        L.rn_mb_pointwise_bwd_rows.argtypes = [C.c_int] * 5 + [C.c_void_p]
+        L.rn_mb_pointwise_bwd_workspace.argtypes = [C.c_int] * 4
+        L.rn_mb_pointwise_bwd.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.rn_mb_depthwise_bwd_rows.argtypes = [C.c_int] * 6 + [C.c_void_p]
+        L.rn_mb_depthwise_bwd_workspace.argtypes = [C.c_int] * 5
+        L.rn_mb_depthwise_bwd.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_same_pad.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.rn_same_pad.restype = None
         _lib = L

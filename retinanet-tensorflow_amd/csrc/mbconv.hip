@@ -1,0 +1,1345 @@
+// MobileNetV2 bottleneck chain (mobilenet_v2.py:41-94, GroupNorm variant normalization.py:20-35) with every GroupNorm
+// applied by its CONSUMER (rn_hip.h, "MobileNetV2 bottleneck chain"):
+//
+//   forward   y1 = A W1            A  = x, or drop(GN3'(y3')) + x' of the previous bottleneck, normalised WHILE LOADING the
+//                                  A tile (and written out once: the bottleneck's materialised input / a pyramid tap)
+//             y2 = dw3x3(a1)       a1 = drop(act(GN1(y1))) formed once per input-patch element on its way into LDS
+//             y3 = a2 W3           a2 = drop(act(GN2(y2))) normalised while loading the A tile
+//   every kernel emits the per-group (sum, sum sq) rows of its raw output from its epilogue; the consumer merges the rows
+//   of its sample (fixed order, fp64) before its first operand store.
+//   backward  the data-gradient epilogues form g = d act'(z) mask of the GroupNorm block they enter, with its rows
+//             (sum gamma g, sum gamma g xhat); the next kernel computes dy = rstd (gamma g - c1 - xhat c2) while loading.
+//
+// Pointwise convs run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, conv_tiles.h); the depthwise kernels stage their
+// input patch through LDS (one transform per element instead of one per tap).  HBM-bound layers: what this file removes is
+// the write + re-read of every normalised tensor and 7 of 13 kernel boundaries per bottleneck.
+#include <stdlib.h>
+
+#include "conv_tiles.h"
+#include "rn_common.h"
+
+namespace {
+using namespace rn_tiles;
+
+constexpr int T = 256;
+constexpr int KMAX = 1024;     // widest channel count (tables of per-channel coefficients live in LDS)
+constexpr int GMAX = 32;       // GroupNorm groups (normalization.py:24: min(32, c))
+constexpr int RMAX = 256;      // rows of a sample a consumer block is willing to merge
+
+struct RowsDev { float2* rows; int R, W, bn; };
+struct NormDev {
+  const float* y; RowsDev st; float* mean; float* rstd; const float* gamma; const float* beta;
+  int c, groups, cpg, act;
+  float eps, drop_rate, keep_scale;
+  uint64_t seed; const uint64_t* seed_dev;
+};
+
+// Totals (a, b) of the groups [g0, g0 + ng) over the rows of `sample` -> tot[ng][2] (fp64, fixed order).  Every thread of
+// the block calls it; ng <= T.  A group's entries of a row: position g + t for the producer N-tiles t that cut it (<= 2,
+// the host checks cpg <= bn): both are loaded unconditionally (the second weighted 0 when there is none).
+__device__ __forceinline__ void merge_rows(const RowsDev& st, int sample, int cpg, int C, int g0, int ng, double (*part)[2],
+                                           double (*tot)[2]) {
+  const int tid = threadIdx.x;
+  const int RL = T / ng, gl = tid % ng, rl = tid / ng;
+  double S = 0.0, Q = 0.0;
+  if (rl < RL) {
+    const int g = g0 + gl;
+    const int t0 = (g * cpg) / st.bn, t1 = (min((g + 1) * cpg, C) - 1) / st.bn;
+    const double w1 = t1 > t0 ? 1.0 : 0.0;
+    const float2* __restrict__ base = st.rows + (size_t)sample * st.R * st.W + g;
+    for (int r0 = rl; r0 < st.R; r0 += 4 * RL) {
+      float2 a[4], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const size_t rr = (size_t)min(r0 + j * RL, st.R - 1) * st.W;
+        a[j] = base[rr + t0];
+        b[j] = base[rr + t1];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (r0 + j * RL < st.R) {
+          S += (double)a[j].x + w1 * (double)b[j].x;
+          Q += (double)a[j].y + w1 * (double)b[j].y;
+        }
+    }
+  }
+  part[tid][0] = S; part[tid][1] = Q;
+  __syncthreads();
+  if (tid < ng) {
+    S = 0.0; Q = 0.0;
+    for (int l = 0; l < RL; ++l) { S += part[l * ng + tid][0]; Q += part[l * ng + tid][1]; }
+    tot[tid][0] = S; tot[tid][1] = Q;
+  }
+  __syncthreads();
+}
+
+// (mean, rstd) of the groups [g0, g0 + ng) of `sample` -> gstat[ng][2]: merged from the rows (and written to nd.mean /
+// nd.rstd when `publish`), or read back (nd.st.rows == nullptr: the backward kernels).  `scratch` >= (T + GMAX) * 16 bytes.
+__device__ __forceinline__ void group_stats(const NormDev& nd, int sample, int hw, int g0, int ng, bool publish, void* scratch,
+                                            float (*gstat)[2]) {
+  const int tid = threadIdx.x;
+  if (nd.st.rows) {
+    double (*part)[2] = reinterpret_cast<double (*)[2]>(scratch);
+    double (*tot)[2] = part + T;
+    merge_rows(nd.st, sample, nd.cpg, nd.c, g0, ng, part, tot);
+    if (tid < ng) {
+      const double m = (double)hw * (double)nd.cpg;
+      const double mean = tot[tid][0] / m;
+      double var = tot[tid][1] / m - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)nd.eps));
+      gstat[tid][0] = (float)mean; gstat[tid][1] = rstd;
+      if (publish) { nd.mean[sample * nd.groups + g0 + tid] = (float)mean; nd.rstd[sample * nd.groups + g0 + tid] = rstd; }
+    }
+  } else if (tid < ng) {
+    gstat[tid][0] = nd.mean[sample * nd.groups + g0 + tid];
+    gstat[tid][1] = nd.rstd[sample * nd.groups + g0 + tid];
+  }
+  __syncthreads();
+}
+
+// per-channel z = x * sc + sh  (sc = rstd gamma, sh = beta - mean sc) of the channels [c0, c0 + nc) -> tab[0..nc) | tab[nc..2nc)
+__device__ __forceinline__ void scale_shift_table(const NormDev& nd, int c0, int nc, int g0, const float (*gstat)[2], float* sc, float* sh) {
+  for (int i = threadIdx.x; i < nc; i += T) {
+    const int c = c0 + i, g = c / nd.cpg - g0;
+    const float s = gstat[g][1] * nd.gamma[c];
+    sc[i] = s;
+    sh[i] = nd.beta[c] - gstat[g][0] * s;
+  }
+  __syncthreads();
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_of(float z, int act_rt) { return ACT >= 0 ? rn::act_fwd(z, ACT) : rn::act_fwd(z, act_rt); }
+template <int ACT>
+__device__ __forceinline__ float actgrad_of(float z, int act_rt) { return ACT >= 0 ? rn::act_grad(z, ACT) : rn::act_grad(z, act_rt); }
+
+// drop(act(z)) of 4 consecutive channels of one pixel; `eidx` = element index of the first one in the GroupNorm's tensor
+template <int ACT>
+__device__ __forceinline__ float4 norm_act_drop(float4 v, float4 sc, float4 sh, int act_rt, bool drop, float rate, float keep,
+                                                uint64_t seed, uint64_t eidx) {
+  float o[4] = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float t = act_of<ACT>(o[j], act_rt);
+    if (drop) t = (rn::uniform01(seed, eidx + (uint64_t)j) >= rate) ? t * keep : 0.f;
+    o[j] = t;
+  }
+  return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-group rows from per-lane column sums of an accumulator tile.  A lane holds 16 rows x TN columns of each 32-row slab:
+// the caller has summed its (v1, v2) over those rows into s1[tn], s2[tn]; here: one cross-half shuffle, the WM waves
+// through LDS, then the channels of every group the N-tile touches, in channel order -> row[g + tile_n].  Optionally the
+// per-channel sums go to plane1 / plane2 (the parameter-gradient planes) and the group sums are weighted by wgt[c]
+// (gamma).  `smem`: dead operand tiles, >= (WM + 1) * BN * 2 floats.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void reduce_group_rows(const float (&s1)[BN / WN / 32], const float (&s2)[BN / WN / 32], float* smem, float2* row,
+                                                  int n0, int C, int cpg, int tile_n, int wm, int wn, int lane, const float* wgt,
+                                                  float* plane1, float* plane2) {
+  constexpr int TN = BN / WN / 32;
+  const int tid = threadIdx.x, l31 = lane & 31;
+  float* red = smem;                 // [WM][BN][2]
+  float* chan = smem + WM * BN * 2;  // [BN][2]
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    float a = s1[tn], b = s2[tn];
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 32, 64);
+    if (lane < 32) {
+      const int col = wn * (BN / WN) + tn * 32 + l31;
+      red[(wm * BN + col) * 2 + 0] = a;
+      red[(wm * BN + col) * 2 + 1] = b;
+    }
+  }
+  __syncthreads();
+  if (tid < BN) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2 + 0]; t2 += red[(w * BN + tid) * 2 + 1]; }
+    chan[tid * 2 + 0] = t1; chan[tid * 2 + 1] = t2;
+    if (plane1 && n0 + tid < C) { plane1[n0 + tid] = t1; plane2[n0 + tid] = t2; }
+  }
+  __syncthreads();
+  const int cend = min(n0 + BN, C);
+  const int g_lo = n0 / cpg, g_hi = (cend - 1) / cpg;
+  if (tid <= g_hi - g_lo) {
+    const int g = g_lo + tid;
+    const int c_lo = max(g * cpg, n0), c_hi = min((g + 1) * cpg, cend);
+    float t1 = 0.f, t2 = 0.f;
+    for (int c = c_lo; c < c_hi; ++c) {
+      const float w = wgt ? wgt[c] : 1.f;
+      t1 += w * chan[(c - n0) * 2 + 0]; t2 += w * chan[(c - n0) * 2 + 1];
+    }
+    row[g + tile_n] = make_float2(t1, t2);
+  }
+}
+
+// =====================================================================================================================
+// pointwise forward:  y[M, N] = A[M, K] W[K, N],  A plain or normalised while loading
+// =====================================================================================================================
+struct PwFwdArgs {
+  const float* x; const float* res; float* mat; const float* w; float* y;
+  NormDev in;
+  int n, hw, cin, cout, tiles_n;
+  RowsDev ost; int ocpg;
+};
+
+template <int BM, int BN, int WM, int WN, bool NORM, int ACT>
+__global__ __launch_bounds__(WM* WN * 64) void mb_pw_fwd_kernel(const PwFwdArgs a) {
+  static_assert(WM * WN * 64 == T, "256-thread blocks");
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int KQ = BK / 4, A_RPP = T / KQ, A_PASS = BM / A_RPP;
+  constexpr int NQ = BN / 4, B_RPP = T / NQ, B_PASS = BK / B_RPP;
+  static_assert(A_PASS >= 1 && B_PASS >= 1 && BM % A_RPP == 0 && BK % B_RPP == 0, "tile/threads mismatch");
+  constexpr int OPF = BM * LDK + BK * BN;
+  static_assert(OPF * 4 >= (T + GMAX) * 16 && OPF >= (WM + 1) * BN * 2, "operand tiles double as scratch");
+  __shared__ __attribute__((aligned(16))) float smem[OPF];
+  __shared__ __attribute__((aligned(16))) float tab[NORM ? 2 * KMAX : 4];
+  __shared__ float gstat[NORM ? GMAX : 1][2];
+  float* As = smem;
+  float* Bs = smem + BM * LDK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+  const int K = a.cin, N = a.cout, M = a.n * a.hw;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int sample = m0 / a.hw;                       // a tile never straddles samples (hw % BM == 0, host-checked)
+  const float* asrc = NORM ? a.in.y : a.x;
+  const __amdgpu_buffer_rsrc_t xa = make_rsrc(asrc, (unsigned)M * K * 4u);
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.res ? a.res : asrc, (unsigned)M * K * 4u);
+  const __amdgpu_buffer_rsrc_t wb = make_rsrc(a.w, (unsigned)K * N * 4u);
+  const bool has_res = NORM && a.res != nullptr;
+
+  const int kq = tid % KQ, arow = tid / KQ;
+  const int nq = tid % NQ;
+  const int bcol = n0 + nq * 4;
+  const unsigned boff0 = bcol < N ? ((unsigned)(tid / NQ) * N + bcol) * 4u : OOB;
+  const int nk = (K + BK - 1) / BK;
+  float4 ra[A_PASS], rr[A_PASS], rb[B_PASS];
+  auto load_tiles = [&](int kt) {
+    const int k = kt * BK + kq * 4;
+    const bool kok = k < K;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      const unsigned off = kok ? ((unsigned)(m0 + arow + i * A_RPP) * K + k) * 4u : OOB;
+      ra[i] = Vec<4>::load(xa, off);
+      if (NORM) rr[i] = Vec<4>::load(xr, has_res ? off : OOB);
+    }
+    const unsigned bo = boff0 + (unsigned)kt * BK * N * 4u;
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j) rb[j] = Vec<4>::load(wb, bo + (unsigned)j * B_RPP * N * 4u);
+  };
+  load_tiles(0);
+  uint64_t seed = 0;
+  bool drop = false;
+  if (NORM) {
+    // the sample's statistics while the first tiles are in flight; the first block of a sample publishes them
+    group_stats(a.in, sample, a.hw, 0, a.in.groups, tile_n == 0 && m0 == sample * a.hw, smem, gstat);
+    scale_shift_table(a.in, 0, K, 0, gstat, tab, tab + KMAX);
+    drop = a.in.drop_rate > 0.f;
+    seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
+  }
+  const bool write_mat = NORM && a.mat != nullptr && tile_n == 0;
+  auto store_tiles = [&](int kt) {
+    const int k = kt * BK + kq * 4;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      float4 v = ra[i];
+      if (NORM) {
+        if (k < K) {
+          const int m = m0 + arow + i * A_RPP;
+          const float4 sc = *reinterpret_cast<const float4*>(&tab[k]);
+          const float4 sh = *reinterpret_cast<const float4*>(&tab[KMAX + k]);
+          v = norm_act_drop<ACT>(v, sc, sh, a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed, (uint64_t)m * K + k);
+          v.x += rr[i].x; v.y += rr[i].y; v.z += rr[i].z; v.w += rr[i].w;
+          if (write_mat) *reinterpret_cast<float4*>(a.mat + (size_t)m * K + k) = v;
+        } else {
+          v = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      *reinterpret_cast<float4*>(&As[(arow + i * A_RPP) * LDK + kq * 4]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j) *reinterpret_cast<float4*>(&Bs[(tid / NQ + j * B_RPP) * BN + nq * 4]) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tiles(kt);
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    mma_ktile<BM, BN, WM, WN, false, false>(As, Bs, acc, wm, wn, lane);
+    __syncthreads();
+  }
+  store_tile<BM, BN, WM, WN>(acc, a.y, nullptr, m0, n0, M, N, N, wm, wn, lane);
+  if (a.ost.rows) {
+    float2* row = a.ost.rows + ((size_t)sample * a.ost.R + (m0 - sample * a.hw) / BM) * a.ost.W;
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      s1[tn] = 0.f; s2[tn] = 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = acc[tm][tn][r]; s1[tn] += v; s2[tn] = fmaf(v, v, s2[tn]); }
+    }
+    reduce_group_rows<BM, BN, WM, WN>(s1, s2, smem, row, n0, N, a.ocpg, tile_n, wm, wn, lane, nullptr, nullptr, nullptr);
+  }
+}
+
+// =====================================================================================================================
+// depthwise 3x3 forward on the normalised input: block = (sample, TH x TW output tile, channel slab of whole groups)
+// =====================================================================================================================
+struct DwFwdArgs {
+  NormDev in; const float* w; float* y;
+  int n, h, wd, c, stride, oh, ow, pad_t, pad_l;
+  int th, tw, tiles_h, tiles_w, sw, nslab, ph, pw;
+  RowsDev ost; int ocpg;
+};
+
+template <int ACT>
+__global__ __launch_bounds__(T) void mb_dw_fwd_kernel(const DwFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];   // patch [ph * pw][sw]; before / after: merge and reduction scratch
+  __shared__ __attribute__((aligned(16))) float tab[2 * 128];    // scale | shift of the slab's channels
+  __shared__ float gstat[GMAX][2];
+  const int tid = threadIdx.x;
+  const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  const int slab = bid % a.nslab;
+  const int tt = bid / a.nslab;
+  const int ntile = a.tiles_h * a.tiles_w;
+  const int tile = tt % ntile, sample = tt / ntile;
+  const int oh0 = (tile / a.tiles_w) * a.th, ow0 = (tile % a.tiles_w) * a.tw;
+  const int C = a.c, SW = a.sw, SQ = SW >> 2, c0 = slab * SW;
+  const int g0 = c0 / a.in.cpg, ng = SW / a.in.cpg;
+  group_stats(a.in, sample, a.h * a.wd, g0, ng, tile == 0, dsm, gstat);
+  scale_shift_table(a.in, c0, SW, g0, gstat, tab, tab + 128);
+  const bool drop = a.in.drop_rate > 0.f;
+  const uint64_t seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
+  // input patch -> LDS, normalised once per element; zero outside the image (SAME padding pads the ACTIVATED tensor)
+  const int ih0 = oh0 * a.stride - a.pad_t, iw0 = ow0 * a.stride - a.pad_l;
+  const int total = a.ph * a.pw * SQ;
+  const float* __restrict__ xs = a.in.y + (size_t)sample * a.h * a.wd * C + c0;
+  const uint64_t samp_off = (uint64_t)sample * a.h * a.wd * C;
+  for (int base = tid; base < total; base += 4 * T) {
+    float4 v[4];
+    int pix[4], q[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = min(base + j * T, total - 1);
+      const int pp = idx / SQ;
+      q[j] = idx - pp * SQ;
+      const int py = pp / a.pw, px = pp - py * a.pw;
+      const int ih = ih0 + py, iw = iw0 + px;
+      ok[j] = (unsigned)ih < (unsigned)a.h && (unsigned)iw < (unsigned)a.wd;
+      pix[j] = min(max(ih, 0), a.h - 1) * a.wd + min(max(iw, 0), a.wd - 1);
+      v[j] = *reinterpret_cast<const float4*>(xs + (size_t)pix[j] * C + q[j] * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = base + j * T;
+      if (idx < total) {
+        const float4 sc = *reinterpret_cast<const float4*>(&tab[q[j] * 4]);
+        const float4 sh = *reinterpret_cast<const float4*>(&tab[128 + q[j] * 4]);
+        float4 o = norm_act_drop<ACT>(v[j], sc, sh, a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed,
+                                      samp_off + (uint64_t)pix[j] * C + c0 + q[j] * 4);
+        if (!ok[j]) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&dsm[(size_t)idx * 4]) = o;     // idx = pp * SQ + q: [pp][sw] rows
+      }
+    }
+  }
+  __syncthreads();
+  // stencil from LDS: thread = (channel quad, pixel lane)
+  const int lanes = T / SQ, q4 = tid % SQ, pl = tid / SQ;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (pl < lanes) {
+    float4 wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(a.w + (size_t)t * C + c0 + q4 * 4);
+    float* __restrict__ ys = a.y + (size_t)sample * a.oh * a.ow * C + c0 + q4 * 4;
+    for (int p = pl; p < a.th * a.tw; p += lanes) {
+      const int oy = p / a.tw, ox = p - oy * a.tw;
+      const int oh_ = oh0 + oy, ow_ = ow0 + ox;
+      if (oh_ < a.oh && ow_ < a.ow) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const float4 xv = *reinterpret_cast<const float4*>(&dsm[((size_t)(oy * a.stride + kh) * a.pw + ox * a.stride + kw) * SW + q4 * 4]);
+            const float4 w4 = wv[kh * 3 + kw];
+            acc.x = fmaf(xv.x, w4.x, acc.x); acc.y = fmaf(xv.y, w4.y, acc.y);
+            acc.z = fmaf(xv.z, w4.z, acc.z); acc.w = fmaf(xv.w, w4.w, acc.w);
+          }
+        *reinterpret_cast<float4*>(ys + (size_t)(oh_ * a.ow + ow_) * C) = acc;
+        s1[0] += acc.x; s1[1] += acc.y; s1[2] += acc.z; s1[3] += acc.w;
+        s2[0] = fmaf(acc.x, acc.x, s2[0]); s2[1] = fmaf(acc.y, acc.y, s2[1]);
+        s2[2] = fmaf(acc.z, acc.z, s2[2]); s2[3] = fmaf(acc.w, acc.w, s2[3]);
+      }
+    }
+  }
+  if (!a.ost.rows) return;
+  __syncthreads();                                 // the patch is dead: its LDS becomes the reduction scratch
+  float (*red)[8] = reinterpret_cast<float (*)[8]>(dsm);
+  float (*chan)[2] = reinterpret_cast<float (*)[2]>(dsm + T * 8);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[tid][j] = s1[j]; red[tid][4 + j] = s2[j]; }
+  __syncthreads();
+  for (int e = tid; e < SQ * 8; e += T) {          // pixel lanes in order
+    const int qd = e >> 3, comp = e & 7;
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += red[l * SQ + qd][comp];
+    chan[qd * 4 + (comp & 3)][comp >> 2] = t;
+  }
+  __syncthreads();
+  const int ong = SW / a.ocpg, og0 = c0 / a.ocpg;
+  if (tid < ong) {                                 // channels of a group in order
+    float t1 = 0.f, t2 = 0.f;
+    for (int j = 0; j < a.ocpg; ++j) { t1 += chan[tid * a.ocpg + j][0]; t2 += chan[tid * a.ocpg + j][1]; }
+    a.ost.rows[((size_t)sample * a.ost.R + tile) * a.ost.W + og0 + tid] = make_float2(t1, t2);
+  }
+}
+
+// =====================================================================================================================
+// out = drop(act(GN(y))) [+ residual]: the end of a chain.  grid (pixel chunks, samples); thread = (channel quad, pixel lane)
+// =====================================================================================================================
+struct ApplyArgs { NormDev in; const float* res; float* out; int n, hw, ppb; };
+
+__global__ __launch_bounds__(T) void mb_apply_kernel(const ApplyArgs a) {
+  __shared__ __attribute__((aligned(16))) double scratch[(T + GMAX) * 2];
+  __shared__ __attribute__((aligned(16))) float tab[2 * KMAX];
+  __shared__ float gstat[GMAX][2];
+  const int tid = threadIdx.x, sample = blockIdx.y, C = a.in.c, CQ = C >> 2;
+  group_stats(a.in, sample, a.hw, 0, a.in.groups, blockIdx.x == 0, scratch, gstat);
+  scale_shift_table(a.in, 0, C, 0, gstat, tab, tab + KMAX);
+  const bool drop = a.in.drop_rate > 0.f;
+  const uint64_t seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
+  const int p_begin = blockIdx.x * a.ppb, p_end = min(p_begin + a.ppb, a.hw);
+  const size_t base = (size_t)sample * a.hw * C;
+  for (int i = tid; i < (p_end - p_begin) * CQ; i += T) {
+    const int p = p_begin + i / CQ, q = i % CQ;
+    const size_t e = base + (size_t)p * C + q * 4;
+    const float4 v = *reinterpret_cast<const float4*>(a.in.y + e);
+    float4 o = norm_act_drop<-1>(v, *reinterpret_cast<const float4*>(&tab[q * 4]), *reinterpret_cast<const float4*>(&tab[KMAX + q * 4]),
+                                 a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed, (uint64_t)e);
+    if (a.res) {
+      const float4 r = *reinterpret_cast<const float4*>(a.res + e);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    *reinterpret_cast<float4*>(a.out + e) = o;
+  }
+}
+
+// =====================================================================================================================
+// backward
+// =====================================================================================================================
+struct DyDev {            // the gradient of a raw conv output y as a kernel loads it (rn_mb_dy)
+  const float* dy;        // plain, or nullptr:
+  const float* g; int g_plain; NormDev nd; RowsDev grows;   // dy = rstd (gamma g' - c1 - xhat c2), g' = g (* dropout mask when g_plain)
+};
+struct GoutDev {          // rn_mb_gout
+  float* out; const float* add1; const float* add2;
+  int has_norm; NormDev nd; int store_plain; RowsDev grows; float* planes; long plane_stride;   // planes: [2][plane rows][c]
+};
+
+// per-channel coefficients of dy = P g' + Q + R y for the channels [c0, c0 + nc) of `sample`: the GroupNorm's statistics
+// (read back) and the merged rows c1 = sum(gamma g) / m, c2 = sum(gamma g xhat) / m.  tab: P | Q | R, each `stride` apart.
+__device__ __forceinline__ void dy_table(const DyDev& d, int sample, int hw, int c0, int nc, void* scratch, float (*gstat)[2], float (*gc)[2],
+                                         float* tab, int stride) {
+  const int tid = threadIdx.x;
+  const int g0 = c0 / d.nd.cpg, ng = (c0 + nc - 1) / d.nd.cpg - g0 + 1;
+  double (*part)[2] = reinterpret_cast<double (*)[2]>(scratch);
+  double (*tot)[2] = part + T;
+  merge_rows(d.grows, sample, d.nd.cpg, d.nd.c, g0, ng, part, tot);
+  if (tid < ng) {
+    const double m = (double)hw * (double)d.nd.cpg;
+    gc[tid][0] = (float)(tot[tid][0] / m); gc[tid][1] = (float)(tot[tid][1] / m);
+    gstat[tid][0] = d.nd.mean[sample * d.nd.groups + g0 + tid];
+    gstat[tid][1] = d.nd.rstd[sample * d.nd.groups + g0 + tid];
+  }
+  __syncthreads();
+  for (int i = tid; i < nc; i += T) {
+    const int c = c0 + i, g = c / d.nd.cpg - g0;
+    const float mean = gstat[g][0], rstd = gstat[g][1], c1 = gc[g][0], c2 = gc[g][1];
+    tab[i] = rstd * d.nd.gamma[c];
+    tab[stride + i] = rstd * (rstd * c2 * mean - c1);
+    tab[2 * stride + i] = -rstd * rstd * c2;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float4 dy_of(float4 g, float4 y, const float* tab, int stride, int i, bool mask, float rate, float keep, uint64_t seed,
+                                        uint64_t eidx) {
+  const float4 P = *reinterpret_cast<const float4*>(&tab[i]);
+  const float4 Q = *reinterpret_cast<const float4*>(&tab[stride + i]);
+  const float4 R = *reinterpret_cast<const float4*>(&tab[2 * stride + i]);
+  if (mask) {
+    g.x = (rn::uniform01(seed, eidx) >= rate) ? g.x * keep : 0.f;
+    g.y = (rn::uniform01(seed, eidx + 1) >= rate) ? g.y * keep : 0.f;
+    g.z = (rn::uniform01(seed, eidx + 2) >= rate) ? g.z * keep : 0.f;
+    g.w = (rn::uniform01(seed, eidx + 3) >= rate) ? g.w * keep : 0.f;
+  }
+  return make_float4(fmaf(P.x, g.x, fmaf(R.x, y.x, Q.x)), fmaf(P.y, g.y, fmaf(R.y, y.y, Q.y)), fmaf(P.z, g.z, fmaf(R.z, y.z, Q.z)),
+                     fmaf(P.w, g.w, fmaf(R.w, y.w, Q.w)));
+}
+
+struct PwBwdArgs {
+  const float* x; NormDev in; int has_in;     // A operand of the weight gradient: x, or the block of `in`
+  DyDev dy; const float* w; GoutDev go;
+  int n, hw, cin, cout;
+  int d_tiles_n, dblocks;                     // data gradient: N-tiles over cin; blocks
+  int w_tiles_m, w_tiles_n, chunk, sps;       // weight gradient: tiles over (cin, cout), pixels per split, splits per sample
+  float* slab;                                // [n * sps][cin][cout]
+};
+constexpr int PB = 64;                        // both halves use 64x64 tiles, 2 x 2 waves
+constexpr int PW_LDS = 2 * PB * LDK;          // operand floats (dgrad: two k-contiguous tiles; wgrad needs 2 * BK * PB, less)
+
+// data gradient  d[M, cin] = dy[M, cout] W^T  and what rn_mb_gout asks for
+template <int ACT_OUT>
+__device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem, float* tabD, float (*gstat)[2], float (*gc)[2], int blk) {
+  constexpr int BM = PB, BN = PB, WM = 2, WN = 2, TM = 1, TN = 1;
+  constexpr int KQ = BK / 4, RPP = T / KQ, A_PASS = BM / RPP, B_PASS = BN / RPP;
+  float* As = smem;
+  float* Bs = smem + BM * LDK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = rn::xcd_remap(blk, a.dblocks);
+  const int tile_n = bid % a.d_tiles_n, tile_m = bid / a.d_tiles_n;
+  const int KD = a.cout, ND = a.cin, M = a.n * a.hw;      // reduction over cout, output columns = cin
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int sample = m0 / a.hw;
+  const bool plain = a.dy.dy != nullptr;
+  const __amdgpu_buffer_rsrc_t ga = make_rsrc(plain ? a.dy.dy : a.dy.g, (unsigned)M * KD * 4u);
+  const __amdgpu_buffer_rsrc_t ya = make_rsrc(plain ? a.dy.dy : a.dy.nd.y, (unsigned)M * KD * 4u);
+  const __amdgpu_buffer_rsrc_t wb = make_rsrc(a.w, (unsigned)ND * KD * 4u);
+  const int kq = tid % KQ, r0 = tid / KQ;
+  unsigned browoff[B_PASS];
+#pragma unroll
+  for (int j = 0; j < B_PASS; ++j) {
+    const int ci = n0 + r0 + j * RPP;
+    browoff[j] = ci < ND ? (unsigned)ci * KD * 4u : OOB;
+  }
+  const int nk = (KD + BK - 1) / BK;
+  float4 ra[A_PASS], ry[A_PASS], rb[B_PASS];
+  auto load_tiles = [&](int kt) {
+    const int k = kt * BK + kq * 4;
+    const bool kok = k < KD;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      const unsigned off = kok ? ((unsigned)(m0 + r0 + i * RPP) * KD + k) * 4u : OOB;
+      ra[i] = Vec<4>::load(ga, off);
+      ry[i] = Vec<4>::load(ya, plain ? OOB : off);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j) rb[j] = Vec<4>::load(wb, (kok && browoff[j] != OOB) ? browoff[j] + (unsigned)k * 4u : OOB);
+  };
+  load_tiles(0);
+  bool mask = false;
+  uint64_t seed = 0;
+  if (!plain) {
+    dy_table(a.dy, sample, a.hw, 0, KD, smem, gstat, gc, tabD, KMAX);
+    mask = a.dy.g_plain && a.dy.nd.drop_rate > 0.f;
+    seed = a.dy.nd.seed + (a.dy.nd.seed_dev ? *a.dy.nd.seed_dev : 0ull);
+  }
+  auto store_tiles = [&](int kt) {
+    const int k = kt * BK + kq * 4;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      float4 v = ra[i];
+      if (!plain) {
+        if (k < KD) v = dy_of(v, ry[i], tabD, KMAX, k, mask, a.dy.nd.drop_rate, a.dy.nd.keep_scale, seed,
+                              (uint64_t)(m0 + r0 + i * RPP) * KD + k);
+        else v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      *reinterpret_cast<float4*>(&As[(r0 + i * RPP) * LDK + kq * 4]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j) *reinterpret_cast<float4*>(&Bs[(r0 + j * RPP) * LDK + kq * 4]) = rb[j];
+  };
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tiles(kt);
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    mma_ktile<BM, BN, WM, WN, false, true>(As, Bs, acc, wm, wn, lane);
+    __syncthreads();
+  }
+  // ---- epilogue: d (+ addends) -> out; with a GroupNorm block behind the conv's input: g, its rows and planes
+  const GoutDev& go = a.go;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int col = n0 + wn * 32 + l31;
+  const bool cok = col < ND;
+  const int rbase = m0 + wm * 32 + 4 * half;
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(go.out, (unsigned)M * ND * 4u);
+  float d[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) d[r] = acc[0][0][r];
+  if (go.add1) {
+    const __amdgpu_buffer_rsrc_t r1 = make_rsrc(go.add1, (unsigned)M * ND * 4u);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = Vec<1>::load(r1, cok ? ((unsigned)(rbase + (r & 3) + 8 * (r >> 2)) * ND + col) * 4u : OOB);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] += t[r];
+  }
+  if (go.add2) {
+    const __amdgpu_buffer_rsrc_t r2 = make_rsrc(go.add2, (unsigned)M * ND * 4u);
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = Vec<1>::load(r2, cok ? ((unsigned)(rbase + (r & 3) + 8 * (r >> 2)) * ND + col) * 4u : OOB);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] += t[r];
+  }
+  if (!go.has_norm) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[r]), ro, cok ? ((unsigned)(rbase + (r & 3) + 8 * (r >> 2)) * ND + col) * 4u : OOB, 0, 0);
+    return;
+  }
+  const NormDev& nd = go.nd;
+  const __amdgpu_buffer_rsrc_t ry2 = make_rsrc(nd.y, (unsigned)M * ND * 4u);
+  float yv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) yv[r] = Vec<1>::load(ry2, cok ? ((unsigned)(rbase + (r & 3) + 8 * (r >> 2)) * ND + col) * 4u : OOB);
+  const int cc = cok ? col : 0, grp = cc / nd.cpg;
+  const float mean = nd.mean[sample * nd.groups + grp], rstd = nd.rstd[sample * nd.groups + grp];
+  const float gam = nd.gamma[cc], bet = nd.beta[cc];
+  const bool drop = nd.drop_rate > 0.f;
+  const uint64_t oseed = nd.seed + (nd.seed_dev ? *nd.seed_dev : 0ull);
+  float s1[1] = {0.f}, s2[1] = {0.f};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = rbase + (r & 3) + 8 * (r >> 2);
+    const float xh = (yv[r] - mean) * rstd;
+    const float z = fmaf(xh, gam, bet);
+    float g = d[r] * actgrad_of<ACT_OUT>(z, nd.act);
+    if (drop) g = (rn::uniform01(oseed, (uint64_t)row * ND + col) >= nd.drop_rate) ? g * nd.keep_scale : 0.f;
+    if (!cok) g = 0.f;
+    s1[0] += g; s2[0] = fmaf(g, xh, s2[0]);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(go.store_plain ? d[r] : g), ro, cok ? ((unsigned)row * ND + col) * 4u : OOB, 0, 0);
+  }
+  const int prow = sample * go.grows.R + (m0 - sample * a.hw) / BM;
+  reduce_group_rows<BM, BN, WM, WN>(s1, s2, smem, go.grows.rows + (size_t)prow * go.grows.W, n0, ND, nd.cpg, tile_n, wm, wn, lane, nd.gamma,
+                                    go.planes + (size_t)prow * ND, go.planes + go.plane_stride + (size_t)prow * ND);
+}
+
+// weight gradient  dW[cin, cout] = A^T dy over one split's pixels (inside one sample) -> slab[split]
+template <int ACT_IN>
+__device__ __forceinline__ void mb_pw_wgrad_body(const PwBwdArgs& a, float* smem, float* tabA, float* tabD, float (*gstat)[2], float (*gc)[2],
+                                                 int blk, int nblk) {
+  constexpr int BM = PB, BN = PB, WM = 2, WN = 2, TM = 1, TN = 1;
+  constexpr int MQ = BM / 4, A_RPP = T / MQ, A_PASS = BK / A_RPP;
+  constexpr int NQ = BN / 4, B_RPP = T / NQ, B_PASS = BK / B_RPP;
+  float* As = smem;              // [BK][BM]  (pixel rows, cin contiguous)
+  float* Bs = smem + BK * BM;    // [BK][BN]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = rn::xcd_remap(blk, nblk);
+  const int tiles_mn = a.w_tiles_m * a.w_tiles_n;
+  const int split = bid / tiles_mn, t = bid - split * tiles_mn;
+  const int tile_n = t % a.w_tiles_n, tile_m = t / a.w_tiles_n;
+  const int sample = split / a.sps;
+  const int p0 = sample * a.hw + (split - sample * a.sps) * a.chunk, p1 = p0 + a.chunk;   // chunk divides hw (host)
+  const int KI = a.cin, NO = a.cout, M = a.n * a.hw;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const bool plain = a.dy.dy != nullptr;
+  const float* asrc = a.has_in ? a.in.y : a.x;
+  const __amdgpu_buffer_rsrc_t xa = make_rsrc(asrc, (unsigned)M * KI * 4u);
+  const __amdgpu_buffer_rsrc_t ga = make_rsrc(plain ? a.dy.dy : a.dy.g, (unsigned)M * NO * 4u);
+  const __amdgpu_buffer_rsrc_t ya = make_rsrc(plain ? a.dy.dy : a.dy.nd.y, (unsigned)M * NO * 4u);
+  const int mq = tid % MQ, acol = m0 + mq * 4;
+  const bool aok = acol < KI;
+  const int nq = tid % NQ, bcol = n0 + nq * 4;
+  const bool bok = bcol < NO;
+  const int nk = a.chunk / BK;
+  float4 ra[A_PASS], rg[B_PASS], ry[B_PASS];
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < A_PASS; ++j) {
+      const int p = p0 + kt * BK + tid / MQ + j * A_RPP;
+      ra[j] = Vec<4>::load(xa, aok ? ((unsigned)p * KI + acol) * 4u : OOB);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j) {
+      const int p = p0 + kt * BK + tid / NQ + j * B_RPP;
+      const unsigned off = bok ? ((unsigned)p * NO + bcol) * 4u : OOB;
+      rg[j] = Vec<4>::load(ga, off);
+      ry[j] = Vec<4>::load(ya, plain ? OOB : off);
+    }
+  };
+  load_tiles(0);
+  bool mask = false, drop_in = false;
+  uint64_t seed = 0, seed_in = 0;
+  const int na = min(BM, KI - m0), nb = min(BN, NO - n0);
+  if (!plain) {
+    dy_table(a.dy, sample, a.hw, n0, nb, smem, gstat, gc, tabD, BN);
+    mask = a.dy.g_plain && a.dy.nd.drop_rate > 0.f;
+    seed = a.dy.nd.seed + (a.dy.nd.seed_dev ? *a.dy.nd.seed_dev : 0ull);
+  }
+  if (a.has_in) {
+    const int g0 = m0 / a.in.cpg, ng = (m0 + na - 1) / a.in.cpg - g0 + 1;
+    group_stats(a.in, sample, a.hw, g0, ng, false, smem, gstat);
+    scale_shift_table(a.in, m0, na, g0, gstat, tabA, tabA + BM);
+    drop_in = a.in.drop_rate > 0.f;
+    seed_in = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
+  }
+  auto store_tiles = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < A_PASS; ++j) {
+      float4 v = ra[j];
+      if (a.has_in) {
+        if (aok) {
+          const int p = p0 + kt * BK + tid / MQ + j * A_RPP;
+          v = norm_act_drop<ACT_IN>(v, *reinterpret_cast<const float4*>(&tabA[mq * 4]), *reinterpret_cast<const float4*>(&tabA[BM + mq * 4]),
+                                    a.in.act, drop_in, a.in.drop_rate, a.in.keep_scale, seed_in, (uint64_t)p * KI + acol);
+        } else {
+          v = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      *reinterpret_cast<float4*>(&As[(tid / MQ + j * A_RPP) * BM + mq * 4]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASS; ++j) {
+      float4 v = rg[j];
+      if (!plain) {
+        if (bok) {
+          const int p = p0 + kt * BK + tid / NQ + j * B_RPP;
+          v = dy_of(v, ry[j], tabD, BN, nq * 4, mask, a.dy.nd.drop_rate, a.dy.nd.keep_scale, seed, (uint64_t)p * NO + bcol);
+        } else {
+          v = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      *reinterpret_cast<float4*>(&Bs[(tid / NQ + j * B_RPP) * BN + nq * 4]) = v;
+    }
+  };
+  (void)p1;
+  f32x16 acc[TM][TN];
+  zero_acc<TM, TN>(acc);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tiles(kt);
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    mma_ktile<BM, BN, WM, WN, true, false>(As, Bs, acc, wm, wn, lane);
+    __syncthreads();
+  }
+  store_tile<BM, BN, WM, WN>(acc, a.slab + (size_t)split * KI * NO, nullptr, m0, n0, KI, NO, NO, wm, wn, lane);
+}
+
+// ACT_IN: activation of the weight gradient's A block (-2: plain x); ACT_OUT: activation of the block the data gradient enters
+template <int ACT_IN, int ACT_OUT>
+__global__ __launch_bounds__(T) void mb_pw_bwd_kernel(const PwBwdArgs a) {
+  static_assert(PW_LDS * 4 >= (T + GMAX) * 16 && PW_LDS >= 3 * PB * 2 && PW_LDS >= 2 * BK * PB, "operand tiles double as scratch");
+  __shared__ __attribute__((aligned(16))) float smem[PW_LDS];
+  __shared__ __attribute__((aligned(16))) float tabD[3 * KMAX];
+  __shared__ __attribute__((aligned(16))) float tabA[2 * PB];
+  __shared__ float gstat[GMAX][2];
+  __shared__ float gc[GMAX][2];
+  if ((int)blockIdx.x < a.dblocks) mb_pw_dgrad_body<ACT_OUT>(a, smem, tabD, gstat, gc, blockIdx.x);
+  else mb_pw_wgrad_body<(ACT_IN == -2 ? 0 : ACT_IN)>(a, smem, tabA, tabD, gstat, gc, (int)blockIdx.x - a.dblocks, (int)gridDim.x - a.dblocks);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// depthwise 3x3 backward: block = (sample, TH x TW INPUT tile, channel slab).  LDS: the dy patch (dy = rstd (gamma g - c1
+// - xhat c2) formed once per element) and the a1 patch (drop(act(GN(y1))), formed once per element).  Data gradient of the
+// tile's pixels -> g1 = d act'(z1) mask with its rows / planes; weight-gradient partial sums over the outputs whose window
+// origin lies in the tile (a disjoint cover of the outputs) -> partial[block row][9][c].
+struct DwBwdArgs {
+  NormDev in; DyDev dy; const float* w; float* partial; GoutDev go;
+  int n, h, wd, c, stride, oh, ow, pad_t, pad_l;
+  int th, tw, tiles_h, tiles_w, sw, nslab;
+  int oph, opw;      // dy patch (output pixels)
+};
+
+__device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+template <int ACT>
+__global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];   // a1 patch [(th+2)(tw+2)][sw] | dy patch [oph*opw][sw]
+  __shared__ __attribute__((aligned(16))) float tabA[4 * 128];   // scale | shift | mean | rstd of the slab's channels (GN1)
+  __shared__ __attribute__((aligned(16))) float tabD[3 * 128];   // P | Q | R (GN2)
+  __shared__ float gstat[GMAX][2];
+  __shared__ float gc[GMAX][2];
+  const int tid = threadIdx.x;
+  const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  const int slab = bid % a.nslab;
+  const int tt = bid / a.nslab;
+  const int ntile = a.tiles_h * a.tiles_w;
+  const int tile = tt % ntile, sample = tt / ntile;
+  const int ih0 = (tile / a.tiles_w) * a.th, iw0 = (tile % a.tiles_w) * a.tw;
+  const int C = a.c, SW = a.sw, SQ = SW >> 2, c0 = slab * SW, s = a.stride;
+  const int aph = a.th + 2, apw = a.tw + 2;
+  float* a1p = dsm;
+  float* dyp = dsm + (size_t)aph * apw * SW;
+  // coefficient tables (the patches' LDS is the merge scratch until they are filled)
+  dy_table(a.dy, sample, a.oh * a.ow, c0, SW, dsm, gstat, gc, tabD, 128);
+  {
+    const int g0 = c0 / a.in.cpg, ng = SW / a.in.cpg;
+    group_stats(a.in, sample, a.h * a.wd, g0, ng, false, dsm, gstat);
+    scale_shift_table(a.in, c0, SW, g0, gstat, tabA, tabA + 128);
+    for (int i = tid; i < SW; i += T) {
+      const int g = (c0 + i) / a.in.cpg - g0;
+      tabA[256 + i] = gstat[g][0]; tabA[384 + i] = gstat[g][1];
+    }
+    __syncthreads();
+  }
+  const bool drop = a.in.drop_rate > 0.f;
+  const uint64_t seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
+  // a1 patch: input rows [ih0 - pad_t, +th+2), cols [iw0 - pad_l, +tw+2)
+  {
+    const int ay0 = ih0 - a.pad_t, ax0 = iw0 - a.pad_l;
+    const int total = aph * apw * SQ;
+    const float* __restrict__ xs = a.in.y + (size_t)sample * a.h * a.wd * C + c0;
+    const uint64_t samp_off = (uint64_t)sample * a.h * a.wd * C;
+    for (int base = tid; base < total; base += 4 * T) {
+      float4 v[4];
+      int pix[4], q[4];
+      bool ok[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = min(base + j * T, total - 1);
+        const int pp = idx / SQ;
+        q[j] = idx - pp * SQ;
+        const int py = pp / apw, px = pp - py * apw;
+        const int ih = ay0 + py, iw = ax0 + px;
+        ok[j] = (unsigned)ih < (unsigned)a.h && (unsigned)iw < (unsigned)a.wd;
+        pix[j] = min(max(ih, 0), a.h - 1) * a.wd + min(max(iw, 0), a.wd - 1);
+        v[j] = *reinterpret_cast<const float4*>(xs + (size_t)pix[j] * C + q[j] * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = base + j * T;
+        if (idx < total) {
+          float4 o = norm_act_drop<ACT>(v[j], *reinterpret_cast<const float4*>(&tabA[q[j] * 4]), *reinterpret_cast<const float4*>(&tabA[128 + q[j] * 4]),
+                                        a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed, samp_off + (uint64_t)pix[j] * C + c0 + q[j] * 4);
+          if (!ok[j]) o = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(&a1p[(size_t)idx * 4]) = o;
+        }
+      }
+    }
+  }
+  // dy patch: output rows [oy0, +oph), cols [ox0, +opw): every output that touches the tile
+  const int oy0 = floor_div(ih0 + a.pad_t - 2 + (s - 1), s), ox0 = floor_div(iw0 + a.pad_l - 2 + (s - 1), s);
+  {
+    const int total = a.oph * a.opw * SQ;
+    const float* __restrict__ gs = a.dy.g + (size_t)sample * a.oh * a.ow * C + c0;
+    const float* __restrict__ ys = a.dy.nd.y + (size_t)sample * a.oh * a.ow * C + c0;
+    for (int base = tid; base < total; base += 4 * T) {
+      float4 g[4], y[4];
+      int q[4];
+      bool ok[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = min(base + j * T, total - 1);
+        const int pp = idx / SQ;
+        q[j] = idx - pp * SQ;
+        const int py = pp / a.opw, px = pp - py * a.opw;
+        const int oh_ = oy0 + py, ow_ = ox0 + px;
+        ok[j] = (unsigned)oh_ < (unsigned)a.oh && (unsigned)ow_ < (unsigned)a.ow;
+        const size_t off = (size_t)(min(max(oh_, 0), a.oh - 1) * a.ow + min(max(ow_, 0), a.ow - 1)) * C + q[j] * 4;
+        g[j] = *reinterpret_cast<const float4*>(gs + off);
+        y[j] = *reinterpret_cast<const float4*>(ys + off);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = base + j * T;
+        if (idx < total) {
+          float4 o = dy_of(g[j], y[j], tabD, 128, q[j] * 4, false, 0.f, 1.f, 0ull, 0ull);
+          if (!ok[j]) o = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(&dyp[(size_t)idx * 4]) = o;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int lanes = T / SQ, q4 = tid % SQ, pl = tid / SQ;
+  const bool active = pl < lanes;
+  float4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = active ? *reinterpret_cast<const float4*>(a.w + (size_t)t * C + c0 + q4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- data gradient of the tile's pixels, then g1 and its sums
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const float4 sc = *reinterpret_cast<const float4*>(&tabA[q4 * 4]), sh = *reinterpret_cast<const float4*>(&tabA[128 + q4 * 4]);
+    const float4 mn = *reinterpret_cast<const float4*>(&tabA[256 + q4 * 4]), rs = *reinterpret_cast<const float4*>(&tabA[384 + q4 * 4]);
+    const float* __restrict__ y1 = a.in.y + (size_t)sample * a.h * a.wd * C + c0 + q4 * 4;
+    float* __restrict__ go = a.go.out + (size_t)sample * a.h * a.wd * C + c0 + q4 * 4;
+    const uint64_t samp_off = (uint64_t)sample * a.h * a.wd * C;
+    for (int p = pl; p < a.th * a.tw; p += lanes) {
+      const int ty = p / a.tw, tx = p - ty * a.tw;
+      const int ih = ih0 + ty, iw = iw0 + tx;
+      if (ih < a.h && iw < a.wd) {
+        const float4 yv = *reinterpret_cast<const float4*>(y1 + (size_t)(ih * a.wd + iw) * C);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int ohs = ih + a.pad_t - kh;
+          const int oh_ = ohs / s;                         // (ohs < 0 only with a 0 weight: see m below)
+          const bool rok = ohs >= 0 && oh_ * s == ohs && oh_ < a.oh;
+          const int py = min(max(oh_ - oy0, 0), a.oph - 1);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int ows = iw + a.pad_l - kw;
+            const int ow_ = ows / s;
+            const float m = (rok && ows >= 0 && ow_ * s == ows && ow_ < a.ow) ? 1.f : 0.f;
+            const int px = min(max(ow_ - ox0, 0), a.opw - 1);
+            const float4 dv = *reinterpret_cast<const float4*>(&dyp[((size_t)py * a.opw + px) * SW + q4 * 4]);
+            const float4 w4 = wv[kh * 3 + kw];
+            acc.x = fmaf(dv.x * m, w4.x, acc.x); acc.y = fmaf(dv.y * m, w4.y, acc.y);
+            acc.z = fmaf(dv.z * m, w4.z, acc.z); acc.w = fmaf(dv.w * m, w4.w, acc.w);
+          }
+        }
+        const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, dd[4] = {acc.x, acc.y, acc.z, acc.w};
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+        const float mnv[4] = {mn.x, mn.y, mn.z, mn.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+        float g[4];
+        const uint64_t e0 = samp_off + (uint64_t)(ih * a.wd + iw) * C + c0 + q4 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float z = fmaf(yy[j], scv[j], shv[j]);
+          const float xh = (yy[j] - mnv[j]) * rsv[j];
+          float t = dd[j] * actgrad_of<ACT>(z, a.in.act);
+          if (drop) t = (rn::uniform01(seed, e0 + (uint64_t)j) >= a.in.drop_rate) ? t * a.in.keep_scale : 0.f;
+          g[j] = t;
+          s1[j] += t; s2[j] = fmaf(t, xh, s2[j]);
+        }
+        *reinterpret_cast<float4*>(go + (size_t)(ih * a.wd + iw) * C) = make_float4(g[0], g[1], g[2], g[3]);
+      }
+    }
+  }
+  // ---- weight-gradient partial sums over the owned outputs (window origin inside the tile)
+  float4 wacc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wacc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    const int noy = (a.th + s - 1) / s, nox = (a.tw + s - 1) / s;      // tiles are aligned to the stride (host)
+    const int oyb = ih0 / s, oxb = iw0 / s;
+    for (int p = pl; p < noy * nox; p += lanes) {
+      const int ty = p / nox, tx = p - ty * nox;
+      const int oh_ = oyb + ty, ow_ = oxb + tx;
+      if (oh_ < a.oh && ow_ < a.ow) {
+        const float4 dv = *reinterpret_cast<const float4*>(&dyp[((size_t)(oh_ - oy0) * a.opw + (ow_ - ox0)) * SW + q4 * 4]);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            // input pixel (oh s - pad_t + kh, ..) in a1-patch coordinates (origin ih0 - pad_t)
+            const float4 xv = *reinterpret_cast<const float4*>(&a1p[((size_t)(ty * s + kh) * apw + tx * s + kw) * SW + q4 * 4]);
+            float4& t = wacc[kh * 3 + kw];
+            t.x = fmaf(xv.x, dv.x, t.x); t.y = fmaf(xv.y, dv.y, t.y); t.z = fmaf(xv.z, dv.z, t.z); t.w = fmaf(xv.w, dv.w, t.w);
+          }
+      }
+    }
+  }
+  __syncthreads();                                 // the patches are dead: their LDS becomes the reduction scratch
+  float (*red)[4] = reinterpret_cast<float (*)[4]>(dsm);
+  const int brow = sample * ntile + tile;
+  for (int t = 0; t < 9; ++t) {
+    red[tid][0] = wacc[t].x; red[tid][1] = wacc[t].y; red[tid][2] = wacc[t].z; red[tid][3] = wacc[t].w;
+    __syncthreads();
+    if (tid < SQ) {
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      for (int l = 0; l < lanes; ++l) { b0 += red[l * SQ + tid][0]; b1 += red[l * SQ + tid][1]; b2 += red[l * SQ + tid][2]; b3 += red[l * SQ + tid][3]; }
+      *reinterpret_cast<float4*>(a.partial + ((size_t)brow * 9 + t) * C + c0 + tid * 4) = make_float4(b0, b1, b2, b3);
+    }
+    __syncthreads();
+  }
+  // g1's sums: per channel -> planes, gamma-weighted per group -> rows
+  float (*red8)[8] = reinterpret_cast<float (*)[8]>(dsm);
+  float (*chan)[2] = reinterpret_cast<float (*)[2]>(dsm + T * 8);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red8[tid][j] = s1[j]; red8[tid][4 + j] = s2[j]; }
+  __syncthreads();
+  for (int e = tid; e < SQ * 8; e += T) {
+    const int qd = e >> 3, comp = e & 7;
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += red8[l * SQ + qd][comp];
+    const int ch = qd * 4 + (comp & 3);
+    chan[ch][comp >> 2] = t;
+    a.go.planes[(size_t)(comp >> 2) * a.go.plane_stride + (size_t)brow * C + c0 + ch] = t;
+  }
+  __syncthreads();
+  const int cpg = a.in.cpg, ng = SW / cpg, g0 = c0 / cpg;
+  if (tid < ng) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int j = 0; j < cpg; ++j) {
+      const float w = a.in.gamma[c0 + tid * cpg + j];
+      t1 += w * chan[tid * cpg + j][0]; t2 += w * chan[tid * cpg + j][1];
+    }
+    a.go.grows.rows[(size_t)brow * a.go.grows.W + g0 + tid] = make_float2(t1, t2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+int fill_norm(const rn_mb_norm* s, NormDev* d, int n, bool need_rows, const char* what) {
+  RN_CHECK_ARG(s && s->y && s->mean && s->rstd && s->gamma && s->beta, "%s: null pointer in rn_mb_norm", what);
+  RN_CHECK_ARG(s->c >= 4 && s->groups >= 1 && s->c % s->groups == 0, "%s: c=%d groups=%d", what, s->c, s->groups);
+  RN_UNSUPPORTED(s->c % 4 != 0 || s->c > KMAX || s->groups > GMAX, "%s: c=%d (multiple of 4, <= %d), groups=%d (<= %d)", what, s->c, KMAX,
+                 s->groups, GMAX);
+  RN_CHECK_ARG(s->drop_rate >= 0.f && s->drop_rate < 1.f, "%s: drop_rate %f", what, s->drop_rate);
+  d->y = s->y; d->mean = s->mean; d->rstd = s->rstd; d->gamma = s->gamma; d->beta = s->beta;
+  d->c = s->c; d->groups = s->groups; d->cpg = s->c / s->groups; d->act = s->act;
+  d->eps = s->eps; d->drop_rate = s->drop_rate; d->keep_scale = s->drop_rate > 0.f ? 1.f / (1.f - s->drop_rate) : 1.f;
+  d->seed = s->drop_seed; d->seed_dev = s->drop_seed_dev;
+  d->st.rows = (float2*)s->stat.rows; d->st.R = s->stat.rows_per_sample; d->st.W = s->stat.width; d->st.bn = s->stat.bn;
+  if (need_rows) RN_CHECK_ARG(s->stat.rows, "%s: the forward pass needs the statistic rows", what);
+  if (s->stat.rows) {
+    RN_CHECK_ARG(d->st.R >= 1 && d->st.W >= d->groups && d->st.bn >= 1, "%s: bad row layout", what);
+    RN_UNSUPPORTED(d->st.R > RMAX || d->cpg > d->st.bn, "%s: %d rows per sample (<= %d) / groups wider than an N-tile", what, d->st.R, RMAX);
+  }
+  (void)n;
+  return RN_OK;
+}
+
+// tile shape of the pointwise kernels: 0 = 64x64, 1 = 128x32, 2 = 128x64
+struct PwCfg { int id, bm, bn; };
+PwCfg pw_cfg(int n, int hw, int ncols) {
+  if (const char* f = getenv("RN_MB_PW_CFG")) {  // tuning aid
+    const int c = atoi(f);
+    if (c == 1 && hw % 128 == 0) return {1, 128, 32};
+    if (c == 2 && hw % 128 == 0) return {2, 128, 64};
+    if (c == 0) return {0, 64, 64};
+  }
+  const long m = (long)n * hw;
+  if (hw % 128 == 0 && ncols <= 32 && m / 128 >= 128) return {1, 128, 32};
+  if (hw % 128 == 0 && hw > 4096) return {2, 128, 64};       // large maps: fewer rows for the consumers to merge
+  return {0, 64, 64};
+}
+
+// channel slab of the depthwise kernels: whole groups (of both GroupNorms around it: same channel count, same rule) and
+// whole float4 quads, the narrowest one of >= 32 channels that tiles c (or all of c), at most 128
+int dw_slab(int c, int cpg) {
+  int unit = cpg;
+  while (unit % 4) unit += cpg;
+  for (int sw = unit; sw <= c; sw += unit)
+    if (c % sw == 0 && sw >= 32) return sw <= 128 ? sw : 0;
+  return c <= 128 ? c : 0;
+}
+
+struct DwPlan { int th, tw, tiles_h, tiles_w, sw, nslab, ph, pw; };
+bool dw_plan(int n, int oh, int ow, int c, int stride, int cpg, DwPlan* p) {
+  p->sw = dw_slab(c, cpg);
+  if (!p->sw) return false;
+  p->nslab = c / p->sw;
+  int th = stride == 1 ? 8 : 4, tw = 8;
+  if (th > oh) th = oh;
+  if (tw > ow) tw = ow;
+  auto blocks = [&]() { return (long)n * rn::ceil_div(oh, th) * rn::ceil_div(ow, tw) * p->nslab; };
+  while (blocks() < 384 && th * tw > 16) {
+    if (th >= tw) th = (th + 1) / 2; else tw = (tw + 1) / 2;
+  }
+  p->th = th; p->tw = tw;
+  p->tiles_h = rn::ceil_div(oh, th); p->tiles_w = rn::ceil_div(ow, tw);
+  p->ph = (th - 1) * stride + 3; p->pw = (tw - 1) * stride + 3;
+  return true;
+}
+size_t dw_lds_bytes(const DwPlan& p) {
+  size_t patch = (size_t)p.ph * p.pw * p.sw * 4;
+  size_t scratch = (size_t)(T + GMAX) * 16;
+  size_t red = (size_t)(T * 8 + 2 * p.sw) * 4;
+  size_t m = patch > scratch ? patch : scratch;
+  return m > red ? m : red;
+}
+
+}  // namespace
+
+extern "C" size_t rn_mb_pointwise_rows(int n, int hw, int cin, int cout, int groups, rn_mb_rows* layout) {
+  if (n < 1 || hw < 1 || cin < 4 || cout < 4 || groups < 1 || cout % groups) return 0;
+  const PwCfg c = pw_cfg(n, hw, cout);
+  if (hw % c.bm) return 0;
+  const int R = hw / c.bm, W = groups + rn::ceil_div(cout, c.bn);
+  if (R > RMAX || cout / groups > c.bn) return 0;
+  if (layout) { layout->rows_per_sample = R; layout->width = W; layout->bn = c.bn; }
+  return (size_t)n * R * W * 8;
+}
+
+extern "C" int rn_mb_pointwise_fwd(const float* x, const rn_mb_norm* in, const float* residual, float* materialise, const float* w, float* y,
+                                   int n, int hw, int cin, int cout, const rn_mb_rows* stat_out, int stat_groups, rn_stream_t stream) {
+  RN_CHECK_ARG((x != nullptr) != (in != nullptr), "mb pointwise fwd: exactly one of x / in");
+  RN_CHECK_ARG(w && y && n >= 1 && hw >= 1, "mb pointwise fwd: bad argument");
+  RN_UNSUPPORTED(cin % 4 || cout % 4 || cin > KMAX || cout > KMAX, "mb pointwise fwd: cin=%d cout=%d (multiples of 4, <= %d)", cin, cout, KMAX);
+  RN_UNSUPPORTED((double)n * hw * cin >= 536870912.0 || (double)n * hw * cout >= 536870912.0, "mb pointwise fwd: tensor >= 2 GiB");
+  RN_CHECK_ARG(in || (!residual && !materialise), "mb pointwise fwd: residual / materialise come with `in`");
+  PwFwdArgs a = {};
+  a.x = x; a.res = residual; a.mat = materialise; a.w = w; a.y = y;
+  a.n = n; a.hw = hw; a.cin = cin; a.cout = cout;
+  if (in) {
+    if (int e = fill_norm(in, &a.in, n, true, "mb pointwise fwd")) return e;
+    RN_CHECK_ARG(in->c == cin, "mb pointwise fwd: in->c %d != cin %d", in->c, cin);
+  }
+  const PwCfg c = pw_cfg(n, hw, cout);
+  RN_UNSUPPORTED(hw % c.bm, "mb pointwise fwd: %d pixels per sample, tile height %d", hw, c.bm);
+  a.tiles_n = rn::ceil_div(cout, c.bn);
+  if (stat_out) {
+    RN_CHECK_ARG(stat_out->rows && stat_groups >= 1 && cout % stat_groups == 0, "mb pointwise fwd: bad stat_out");
+    rn_mb_rows want = {};
+    RN_UNSUPPORTED(!rn_mb_pointwise_rows(n, hw, cin, cout, stat_groups, &want), "mb pointwise fwd: this shape cannot emit rows");
+    RN_CHECK_ARG(want.rows_per_sample == stat_out->rows_per_sample && want.width == stat_out->width && want.bn == stat_out->bn,
+                 "mb pointwise fwd: stat_out layout differs from rn_mb_pointwise_rows");
+    a.ost.rows = (float2*)stat_out->rows; a.ost.R = want.rows_per_sample; a.ost.W = want.width; a.ost.bn = want.bn;
+    a.ocpg = cout / stat_groups;
+  }
+  const dim3 grid((unsigned)((long)n * hw / c.bm * a.tiles_n));
+  hipStream_t st = (hipStream_t)stream;
+#define RN_PW(BM_, BN_, WM_, WN_)                                                                                     \
+  do {                                                                                                                \
+    if (!in) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, false, 0>), grid, dim3(T), 0, st, a);            \
+    else if (in->act == RN_ACT_NONE) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_NONE>), grid, dim3(T), 0, st, a); \
+    else if (in->act == RN_ACT_ELU) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_ELU>), grid, dim3(T), 0, st, a);   \
+    else hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, -1>), grid, dim3(T), 0, st, a);                \
+  } while (0)
+  switch (c.id) {
+    case 1: RN_PW(128, 32, 4, 1); break;
+    case 2: RN_PW(128, 64, 2, 2); break;
+    default: RN_PW(64, 64, 2, 2); break;
+  }
+#undef RN_PW
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" size_t rn_mb_depthwise_rows(int n, int h, int w, int c, int stride, int groups, rn_mb_rows* layout) {
+  if (n < 1 || h < 1 || w < 1 || c < 4 || c % 4 || groups < 1 || c % groups || (stride != 1 && stride != 2)) return 0;
+  int oh, ow, pt, pl;
+  rn::same_pad(h, 3, stride, &oh, &pt);
+  rn::same_pad(w, 3, stride, &ow, &pl);
+  DwPlan p;
+  if (!dw_plan(n, oh, ow, c, stride, c / groups, &p)) return 0;
+  const int R = p.tiles_h * p.tiles_w;
+  if (R > RMAX) return 0;
+  if (layout) { layout->rows_per_sample = R; layout->width = groups; layout->bn = c; }
+  return (size_t)n * R * groups * 8;
+}
+
+extern "C" int rn_mb_depthwise_fwd(const rn_mb_norm* in, const float* w, float* y, int n, int h, int wd, int stride, const rn_mb_rows* stat_out,
+                                   int stat_groups, rn_stream_t stream) {
+  RN_CHECK_ARG(in && w && y && n >= 1 && h >= 1 && wd >= 1 && (stride == 1 || stride == 2), "mb depthwise fwd: bad argument");
+  DwFwdArgs a = {};
+  if (int e = fill_norm(in, &a.in, n, true, "mb depthwise fwd")) return e;
+  const int c = in->c;
+  RN_UNSUPPORTED((double)n * h * wd * c >= 536870912.0, "mb depthwise fwd: tensor >= 2 GiB");
+  a.w = w; a.y = y; a.n = n; a.h = h; a.wd = wd; a.c = c; a.stride = stride;
+  rn::same_pad(h, 3, stride, &a.oh, &a.pad_t);
+  rn::same_pad(wd, 3, stride, &a.ow, &a.pad_l);
+  DwPlan p;
+  // the slab must hold whole groups of the input GroupNorm and of the one that follows y (same c: stat_groups == in->groups here)
+  RN_UNSUPPORTED(stat_out && stat_groups != in->groups, "mb depthwise fwd: the GroupNorms around a depthwise conv share their grouping");
+  RN_UNSUPPORTED(!dw_plan(n, a.oh, a.ow, c, stride, a.in.cpg, &p), "mb depthwise fwd: no channel slab for c=%d groups=%d", c, in->groups);
+  a.th = p.th; a.tw = p.tw; a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.sw = p.sw; a.nslab = p.nslab; a.ph = p.ph; a.pw = p.pw;
+  if (stat_out) {
+    rn_mb_rows want = {};
+    RN_UNSUPPORTED(!rn_mb_depthwise_rows(n, h, wd, c, stride, stat_groups, &want), "mb depthwise fwd: this shape cannot emit rows");
+    RN_CHECK_ARG(stat_out->rows && want.rows_per_sample == stat_out->rows_per_sample && want.width == stat_out->width && want.bn == stat_out->bn,
+                 "mb depthwise fwd: stat_out layout differs from rn_mb_depthwise_rows");
+    a.ost.rows = (float2*)stat_out->rows; a.ost.R = want.rows_per_sample; a.ost.W = want.width; a.ost.bn = want.bn;
+    a.ocpg = c / stat_groups;
+  }
+  const size_t lds = dw_lds_bytes(p);
+  RN_UNSUPPORTED(lds > 64 * 1024, "mb depthwise fwd: patch of %zu bytes", lds);
+  const dim3 grid((unsigned)((long)n * p.tiles_h * p.tiles_w * p.nslab));
+  hipStream_t st = (hipStream_t)stream;
+  if (in->act == RN_ACT_ELU) hipLaunchKernelGGL(mb_dw_fwd_kernel<RN_ACT_ELU>, grid, dim3(T), lds, st, a);
+  else if (in->act == RN_ACT_RELU6) hipLaunchKernelGGL(mb_dw_fwd_kernel<RN_ACT_RELU6>, grid, dim3(T), lds, st, a);
+  else hipLaunchKernelGGL(mb_dw_fwd_kernel<-1>, grid, dim3(T), lds, st, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_mb_apply(const rn_mb_norm* in, const float* residual, float* out, int n, int hw, rn_stream_t stream) {
+  RN_CHECK_ARG(in && out && n >= 1 && hw >= 1, "mb apply: bad argument");
+  ApplyArgs a = {};
+  if (int e = fill_norm(in, &a.in, n, false, "mb apply")) return e;
+  RN_UNSUPPORTED((double)n * hw * in->c >= 536870912.0, "mb apply: tensor >= 2 GiB");
+  a.res = residual; a.out = out; a.n = n; a.hw = hw;
+  const long elems = (long)hw * (in->c / 4);
+  int chunks = (int)((elems + 4 * T - 1) / (4 * T));   // ~4 quads per thread
+  if (chunks > hw) chunks = hw;
+  if (chunks < 1) chunks = 1;
+  a.ppb = rn::ceil_div(hw, chunks);
+  hipLaunchKernelGGL(mb_apply_kernel, dim3((unsigned)rn::ceil_div(hw, a.ppb), (unsigned)n), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward entry points
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+int fill_dy(const rn_mb_dy* s, DyDev* d, int n, int channels, const char* what) {
+  RN_CHECK_ARG(s, "%s: null rn_mb_dy", what);
+  if (s->dy) { d->dy = s->dy; return RN_OK; }
+  RN_CHECK_ARG(s->norm && s->g && s->grows.rows, "%s: rn_mb_dy needs dy, or norm + g + grows", what);
+  if (int e = fill_norm(s->norm, &d->nd, n, false, what)) return e;
+  RN_CHECK_ARG(s->norm->c == channels, "%s: rn_mb_dy.norm->c %d != %d", what, s->norm->c, channels);
+  RN_CHECK_ARG(!s->g_plain || s->norm->act == RN_ACT_NONE, "%s: g_plain needs a block without activation", what);
+  d->nd.st.rows = nullptr;                       // backward kernels read mean / rstd back
+  d->g = s->g; d->g_plain = s->g_plain ? 1 : 0;
+  d->grows.rows = (float2*)s->grows.rows; d->grows.R = s->grows.rows_per_sample; d->grows.W = s->grows.width; d->grows.bn = s->grows.bn;
+  RN_CHECK_ARG(d->grows.R >= 1 && d->grows.W >= d->nd.groups && d->grows.bn >= 1, "%s: bad grows layout", what);
+  RN_UNSUPPORTED(d->grows.R > RMAX || d->nd.cpg > d->grows.bn, "%s: %d gradient rows per sample (<= %d)", what, d->grows.R, RMAX);
+  return RN_OK;
+}
+int fill_gout(const rn_mb_gout* s, GoutDev* d, int n, int channels, const rn_mb_rows& want, const char* what) {
+  RN_CHECK_ARG(s && s->out, "%s: null rn_mb_gout", what);
+  d->out = s->out; d->add1 = s->add1; d->add2 = s->add2; d->store_plain = s->store_plain ? 1 : 0;
+  if (!s->norm) return RN_OK;
+  if (int e = fill_norm(s->norm, &d->nd, n, false, what)) return e;
+  RN_CHECK_ARG(s->norm->c == channels, "%s: rn_mb_gout.norm->c %d != %d", what, s->norm->c, channels);
+  d->nd.st.rows = nullptr;
+  d->has_norm = 1;
+  RN_CHECK_ARG(s->grows.rows && s->planes, "%s: rn_mb_gout with a norm needs grows + planes", what);
+  RN_CHECK_ARG(s->grows.rows_per_sample == want.rows_per_sample && s->grows.width == want.width && s->grows.bn == want.bn,
+               "%s: gout->grows layout differs from the *_bwd_rows query", what);
+  d->grows.rows = (float2*)s->grows.rows; d->grows.R = want.rows_per_sample; d->grows.W = want.width; d->grows.bn = want.bn;
+  d->planes = s->planes; d->plane_stride = (long)n * want.rows_per_sample * channels;
+  return RN_OK;
+}
+// weight-gradient split of the pointwise backward: pixels per split (divides hw, multiple of BK) and splits per sample
+void pw_wgrad_plan(int n, int hw, int cin, int cout, int* chunk, int* sps) {
+  const int tiles = rn::ceil_div(cin, PB) * rn::ceil_div(cout, PB);
+  int want = rn::ceil_div(768, tiles * n);             // splits per sample for ~768 blocks
+  if (const char* f = getenv("RN_MB_WGRAD_SPS")) { if (atoi(f) > 0) want = atoi(f); }   // tuning aid
+  const int units = hw / 64;                           // a split reduces >= 64 pixels
+  int best = 1;
+  for (int d = 1; d <= units && d <= want; ++d)
+    if (units % d == 0) best = d;
+  *sps = best; *chunk = hw / best;
+}
+struct DwBwdPlan { int th, tw, tiles_h, tiles_w, sw, nslab, oph, opw; };
+bool dw_bwd_plan(int n, int h, int w, int c, int stride, int cpg, DwBwdPlan* p) {
+  p->sw = dw_slab(c, cpg);
+  if (!p->sw) return false;
+  p->nslab = c / p->sw;
+  int th = 8, tw = 8;
+  auto blocks = [&]() { return (long)n * rn::ceil_div(h, th) * rn::ceil_div(w, tw) * p->nslab; };
+  while (blocks() < 384 && th * tw > 16) {
+    if (th >= tw) th /= 2; else tw /= 2;
+  }
+  p->th = th; p->tw = tw;                              // powers of two >= 2: aligned to stride 1 / 2
+  p->tiles_h = rn::ceil_div(h, th); p->tiles_w = rn::ceil_div(w, tw);
+  p->oph = th / stride + 2; p->opw = tw / stride + 2;
+  return true;
+}
+size_t dw_bwd_lds_bytes(const DwBwdPlan& p) {
+  size_t patches = ((size_t)(p.th + 2) * (p.tw + 2) + (size_t)p.oph * p.opw) * p.sw * 4;
+  size_t scratch = (size_t)(T + GMAX) * 16;
+  size_t red = (size_t)(T * 8 + 2 * p.sw) * 4;
+  size_t m = patches > scratch ? patches : scratch;
+  return m > red ? m : red;
+}
+}  // namespace
+
+extern "C" size_t rn_mb_pointwise_bwd_rows(int n, int hw, int cin, int cout, int groups, rn_mb_rows* layout) {
+  if (n < 1 || hw < 1 || cin < 4 || cout < 4 || groups < 1 || cin % groups || hw % PB) return 0;
+  const int R = hw / PB, W = groups + rn::ceil_div(cin, PB);
+  if (R > RMAX || cin / groups > PB) return 0;
+  if (layout) { layout->rows_per_sample = R; layout->width = W; layout->bn = PB; }
+  return (size_t)n * R * W * 8;
+}
+extern "C" size_t rn_mb_pointwise_bwd_workspace(int n, int hw, int cin, int cout) {
+  if (n < 1 || hw < 64 || hw % 64 || cin < 4 || cout < 4) return 0;
+  int chunk, sps;
+  pw_wgrad_plan(n, hw, cin, cout, &chunk, &sps);
+  return (size_t)n * sps * cin * cout * sizeof(float);
+}
+
+extern "C" int rn_mb_pointwise_bwd(const float* x, const rn_mb_norm* in, const rn_mb_dy* dy, const float* w, float* dw, const rn_mb_gout* gout,
+                                   int n, int hw, int cin, int cout, void* workspace, size_t workspace_bytes, rn_stream_t stream,
+                                   rn_reduce_list* defer) {
+  rn::DeferScope defer_scope_(defer);
+  RN_CHECK_ARG((x != nullptr) != (in != nullptr), "mb pointwise bwd: exactly one of x / in");
+  RN_CHECK_ARG(w && dw && dy && gout && workspace && n >= 1 && hw >= 1, "mb pointwise bwd: bad argument");
+  RN_UNSUPPORTED(cin % 4 || cout % 4 || cin > KMAX || cout > KMAX, "mb pointwise bwd: cin=%d cout=%d (multiples of 4, <= %d)", cin, cout, KMAX);
+  RN_UNSUPPORTED(hw % PB, "mb pointwise bwd: %d pixels per sample, tile height %d", hw, PB);
+  RN_UNSUPPORTED((double)n * hw * cin >= 536870912.0 || (double)n * hw * cout >= 536870912.0, "mb pointwise bwd: tensor >= 2 GiB");
+  PwBwdArgs a = {};
+  a.x = x; a.w = w; a.n = n; a.hw = hw; a.cin = cin; a.cout = cout;
+  if (in) {
+    if (int e = fill_norm(in, &a.in, n, false, "mb pointwise bwd")) return e;
+    RN_CHECK_ARG(in->c == cin, "mb pointwise bwd: in->c %d != cin %d", in->c, cin);
+    a.in.st.rows = nullptr;
+    a.has_in = 1;
+  }
+  if (int e = fill_dy(dy, &a.dy, n, cout, "mb pointwise bwd")) return e;
+  rn_mb_rows want = {};
+  if (gout->norm) RN_UNSUPPORTED(!rn_mb_pointwise_bwd_rows(n, hw, cin, cout, gout->norm->groups, &want), "mb pointwise bwd: this shape cannot emit gradient rows");
+  if (int e = fill_gout(gout, &a.go, n, cin, want, "mb pointwise bwd")) return e;
+  a.d_tiles_n = rn::ceil_div(cin, PB);
+  a.dblocks = n * hw / PB * a.d_tiles_n;
+  a.w_tiles_m = rn::ceil_div(cin, PB); a.w_tiles_n = rn::ceil_div(cout, PB);
+  pw_wgrad_plan(n, hw, cin, cout, &a.chunk, &a.sps);
+  const int nsplit = n * a.sps;
+  const size_t need = (size_t)nsplit * cin * cout * sizeof(float);
+  if (workspace_bytes < need) { rn::set_error("mb pointwise bwd: workspace %zu < %zu bytes", workspace_bytes, need); return RN_EWORKSPACE; }
+  a.slab = nsplit == 1 ? dw : (float*)workspace;
+  const dim3 grid((unsigned)(a.dblocks + nsplit * a.w_tiles_m * a.w_tiles_n));
+  hipStream_t st = (hipStream_t)stream;
+  const int act_in = in ? in->act : -2, act_out = gout->norm ? gout->norm->act : RN_ACT_NONE;
+  if (act_in == -2 && act_out == RN_ACT_NONE) hipLaunchKernelGGL((mb_pw_bwd_kernel<-2, RN_ACT_NONE>), grid, dim3(T), 0, st, a);
+  else if (act_in == -2) hipLaunchKernelGGL((mb_pw_bwd_kernel<-2, -1>), grid, dim3(T), 0, st, a);
+  else if (act_in == RN_ACT_ELU && act_out == RN_ACT_ELU) hipLaunchKernelGGL((mb_pw_bwd_kernel<RN_ACT_ELU, RN_ACT_ELU>), grid, dim3(T), 0, st, a);
+  else hipLaunchKernelGGL((mb_pw_bwd_kernel<-1, -1>), grid, dim3(T), 0, st, a);
+  RN_LAUNCH_CHECK();
+  if (nsplit == 1) return RN_OK;
+  return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)cin * cout, nsplit, 0, st);
+}
+
+extern "C" size_t rn_mb_depthwise_bwd_rows(int n, int h, int w, int c, int stride, int groups, rn_mb_rows* layout) {
+  if (n < 1 || h < 1 || w < 1 || c < 4 || c % 4 || groups < 1 || c % groups || (stride != 1 && stride != 2)) return 0;
+  DwBwdPlan p;
+  if (!dw_bwd_plan(n, h, w, c, stride, c / groups, &p)) return 0;
+  const int R = p.tiles_h * p.tiles_w;
+  if (R > RMAX) return 0;
+  if (layout) { layout->rows_per_sample = R; layout->width = groups; layout->bn = c; }
+  return (size_t)n * R * groups * 8;
+}
+extern "C" size_t rn_mb_depthwise_bwd_workspace(int n, int h, int w, int c, int stride) {
+  if (n < 1 || h < 1 || w < 1 || c < 4 || c % 4 || (stride != 1 && stride != 2)) return 0;
+  // weight-gradient partial sums, one row per (sample, input tile): the planner's tiles are never smaller than 4 x 4
+  return (size_t)n * rn::ceil_div(h, 4) * rn::ceil_div(w, 4) * 9 * c * sizeof(float);
+}
+
+extern "C" int rn_mb_depthwise_bwd(const rn_mb_norm* in, const rn_mb_dy* dy, const float* w, float* dw, const rn_mb_gout* gout, int n, int h,
+                                   int wd, int stride, void* workspace, size_t workspace_bytes, rn_stream_t stream, rn_reduce_list* defer) {
+  rn::DeferScope defer_scope_(defer);
+  RN_CHECK_ARG(in && dy && w && dw && gout && gout->norm && workspace && n >= 1 && h >= 1 && wd >= 1 && (stride == 1 || stride == 2),
+               "mb depthwise bwd: bad argument");
+  RN_CHECK_ARG(!dy->dy && !gout->store_plain && !gout->add1 && !gout->add2, "mb depthwise bwd: dy comes as (g, norm, grows); gout stores g");
+  DwBwdArgs a = {};
+  if (int e = fill_norm(in, &a.in, n, false, "mb depthwise bwd")) return e;
+  a.in.st.rows = nullptr;
+  const int c = in->c;
+  RN_UNSUPPORTED((double)n * h * wd * c >= 536870912.0, "mb depthwise bwd: tensor >= 2 GiB");
+  if (int e = fill_dy(dy, &a.dy, n, c, "mb depthwise bwd")) return e;
+  RN_CHECK_ARG(!a.dy.g_plain && dy->norm->groups == in->groups, "mb depthwise bwd: the GroupNorms around a depthwise conv share their grouping");
+  a.w = w; a.n = n; a.h = h; a.wd = wd; a.c = c; a.stride = stride;
+  rn::same_pad(h, 3, stride, &a.oh, &a.pad_t);
+  rn::same_pad(wd, 3, stride, &a.ow, &a.pad_l);
+  DwBwdPlan p;
+  RN_UNSUPPORTED(!dw_bwd_plan(n, h, wd, c, stride, a.in.cpg, &p), "mb depthwise bwd: no channel slab for c=%d groups=%d", c, in->groups);
+  a.th = p.th; a.tw = p.tw; a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.sw = p.sw; a.nslab = p.nslab; a.oph = p.oph; a.opw = p.opw;
+  rn_mb_rows want = {};
+  RN_UNSUPPORTED(!rn_mb_depthwise_bwd_rows(n, h, wd, c, stride, in->groups, &want), "mb depthwise bwd: this shape cannot emit gradient rows");
+  if (int e = fill_gout(gout, &a.go, n, c, want, "mb depthwise bwd")) return e;
+  RN_CHECK_ARG(gout->norm->y == in->y, "mb depthwise bwd: gout->norm is the block of `in`");
+  const int nrows = n * p.tiles_h * p.tiles_w;
+  const size_t need = (size_t)nrows * 9 * c * sizeof(float);
+  if (workspace_bytes < need) { rn::set_error("mb depthwise bwd: workspace %zu < %zu bytes", workspace_bytes, need); return RN_EWORKSPACE; }
+  a.partial = (float*)workspace;
+  const size_t lds = dw_bwd_lds_bytes(p);
+  RN_UNSUPPORTED(lds > 64 * 1024, "mb depthwise bwd: patches of %zu bytes", lds);
+  const dim3 grid((unsigned)((long)nrows * p.nslab));
+  hipStream_t st = (hipStream_t)stream;
+  if (in->act == RN_ACT_ELU) hipLaunchKernelGGL(mb_dw_bwd_kernel<RN_ACT_ELU>, grid, dim3(T), lds, st, a);
+  else if (in->act == RN_ACT_RELU6) hipLaunchKernelGGL(mb_dw_bwd_kernel<RN_ACT_RELU6>, grid, dim3(T), lds, st, a);
+  else hipLaunchKernelGGL(mb_dw_bwd_kernel<-1>, grid, dim3(T), lds, st, a);
+  RN_LAUNCH_CHECK();
+  return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)9 * c, nrows, 0, st);
+}

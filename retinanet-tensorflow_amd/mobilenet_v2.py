@@ -10,10 +10,13 @@ each + GroupNorm, dropout; residual iff shapes match, :91-92); final 1x1 -> 32 c
 SURVEY Q8).  Each [conv, Normalization, activation, Dropout] run is conv kernel + ONE fused
 GroupNorm kernel (the residual add rides in the same kernel).
 """
+import os
+
 import torch
 
 import layers as L
 import ops
+import ops_mb
 from model import Model, Sequential
 from normalization import Normalization
 
@@ -28,6 +31,12 @@ _STAGES = (
     (7, 320, 6, (1,)),
 )
 _TAP_AFTER = {'bottleneck_1_1': 'C1', 'bottleneck_2_2': 'C2', 'bottleneck_3_3': 'C3', 'bottleneck_5_3': 'C4'}
+
+# The bottlenecks as ONE autograd node over the rn_mb_* kernels (ops_mb.mb_chain): every GroupNorm applied by its consumer,
+# 3 launches per bottleneck forward and 3 backward instead of 6 + 7.  It starts at the first bottleneck from which on every
+# layer's shape qualifies (maps whose statistic rows a consumer block can merge: <= 128 x 128 at the headline size); the
+# bottlenecks in front of it run layer by layer.  RN_MB_CHAIN=0: layer by layer everywhere.
+MB_CHAIN = os.environ.get("RN_MB_CHAIN", "1") == "1"
 
 
 class DepthwiseConv2D(L.DepthwiseConv2D):
@@ -120,12 +129,60 @@ class MobileNetV2(Model):
         self.output_conv = conv_block(32, 1, 1, channels)
         self.out_channels = {'C3': 32, 'C4': 96, 'C5': 32}
 
+    def _chain_blocks(self, first):
+        blocks = []
+        for name in self.block_names[first:]:
+            b = getattr(self, name)
+            conv1, norm1, act1, drop1 = b.expand_conv.layers
+            dw, norm2, act2, drop2 = b.depthwise_conv.layers
+            conv3, norm3, drop3 = b.linear_conv.layers
+            blocks.append(ops_mb.Block(
+                conv1.weight, ops_mb.Norm(norm1.gamma, norm1.beta, norm1.groups, norm1.eps, L.activation_name(act1), drop1.rate, drop1.seed),
+                dw.weight, ops_mb.Norm(norm2.gamma, norm2.beta, norm2.groups, norm2.eps, L.activation_name(act2), drop2.rate, drop2.seed),
+                conv3.weight, ops_mb.Norm(norm3.gamma, norm3.beta, norm3.groups, norm3.eps, None, drop3.rate, drop3.seed),
+                dw.strides, b._same_shape))
+        return blocks
+
+    def _chain_start(self, x, training):
+        """Index of the first bottleneck the fused chain runs (None: no chain) for the stem output x."""
+        if not (MB_CHAIN and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32) or (L.INFERENCE_F16 and not training):
+            return None
+        key = tuple(x.shape)
+        cache = self.__dict__.setdefault('_chain_cache', {})
+        if key not in cache:
+            n, h, w, c = key
+            shapes = []
+            for name in self.block_names:
+                b = getattr(self, name)
+                shapes.append((n, h, w, c))
+                s = b.depthwise_conv.layers[0].strides
+                h, w, c = -(-h // s), -(-w // s), b.linear_conv.layers[0].filters
+            start = None
+            for i in range(len(self.block_names) - 1):
+                if ops_mb.chain_supported(shapes[i], self._chain_blocks(i)):
+                    start = i
+                    break
+            cache[key] = start
+        return cache[key]
+
     def call(self, input, training):
         out = {}
         input = self.input_conv(input, training)
-        for name in self.block_names:
+        start = self._chain_start(input, training)
+        for name in (self.block_names if start is None else self.block_names[:start]):
             input = getattr(self, name)(input, training)
             if name in _TAP_AFTER:      # a tap feeds the next block and (C3, C4) the pyramid
                 out[_TAP_AFTER[name]], input = ops.fanout(input, 2)
-        out['C5'] = self.output_conv(input, training)
+        conv_o, norm_o, act_o, drop_o = self.output_conv.layers
+        if start is None:
+            out['C5'] = self.output_conv(input, training)
+            return out
+        names = self.block_names[start:]
+        tap_after = [i for i, name in enumerate(names) if name in _TAP_AFTER]
+        taps, y_tail = ops_mb.mb_chain(input, self._chain_blocks(start), conv_o.weight, tap_after, training=training,
+                                       seed_dev=L.Dropout.seed_device_counter)
+        for i, t in zip(tap_after, taps):
+            out[_TAP_AFTER[names[i]]] = t
+        # the output block's own GroupNorm + activation + dropout (its 1x1 conv ran as the chain's tail)
+        out['C5'] = norm_o.fused(y_tail, training, act=L.activation_name(act_o), dropout=drop_o)
         return out
