@@ -34,36 +34,63 @@ struct NormDev {
   uint64_t seed; const uint64_t* seed_dev;
 };
 
-// Totals (a, b) of the groups [g0, g0 + ng) over the rows of `sample` -> tot[ng][2] (fp64, fixed order).  Every thread of
-// the block calls it; ng <= T.  A group's entries of a row: position g + t for the producer N-tiles t that cut it (<= 2,
-// the host checks cpg <= bn): both are loaded unconditionally (the second weighted 0 when there is none).
+// ---------------------------------------------------------------------------------------------------------------------
+// Prologue helpers.  A block may have more than T threads (intra-block split-K: KS groups of T); the first T ("leaders")
+// do the work, every thread of the block calls (the helpers contain block-wide barriers).  Everything a prologue needs
+// from global memory that does not depend on another load -- gamma / beta of its channels, mean / rstd when they are read
+// back -- is fetched into registers FIRST (prefetch_*), together with the kernel's first operand loads: the merge of the
+// rows, the tables and the first tile then cost one round trip to memory, not one each.
+template <int NJ>
+struct ChanPre { float g[NJ], b[NJ]; };             // gamma / beta of the channels c0 + tid + j T
+template <int NJ>
+__device__ __forceinline__ void prefetch_chan(const float* gamma, const float* beta, int c0, int nc, int tid, ChanPre<NJ>& p) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = min(tid % T + j * T, nc - 1);
+    p.g[j] = (tid < T) ? gamma[c0 + i] : 0.f;
+    p.b[j] = (tid < T && beta) ? beta[c0 + i] : 0.f;
+  }
+}
+struct GroupPre { float mean, rstd; };             // read-back statistics of group g0 + tid (tid < ng)
+__device__ __forceinline__ GroupPre prefetch_groups(const NormDev& nd, int sample, int g0, int ng, int tid) {
+  GroupPre p = {0.f, 1.f};
+  if (nd.st.rows == nullptr && tid < T) {
+    const int g = g0 + min(tid, ng - 1);
+    p.mean = nd.mean[sample * nd.groups + g];
+    p.rstd = nd.rstd[sample * nd.groups + g];
+  }
+  return p;
+}
+
+// Totals (a, b) of the groups [g0, g0 + ng) over the rows of `sample` -> tot[ng][2] (fp64, fixed order); ng <= T.  A group's
+// entries of a row: position g + t for the producer N-tiles t that cut it (<= 2, the host checks cpg <= bn): both are loaded
+// unconditionally (the second weighted 0 when there is none), eight rows in flight per lane.
 __device__ __forceinline__ void merge_rows(const RowsDev& st, int sample, int cpg, int C, int g0, int ng, double (*part)[2],
-                                           double (*tot)[2]) {
-  const int tid = threadIdx.x;
+                                           double (*tot)[2], int tid) {
   const int RL = T / ng, gl = tid % ng, rl = tid / ng;
   double S = 0.0, Q = 0.0;
-  if (rl < RL) {
+  if (tid < T && rl < RL) {
     const int g = g0 + gl;
     const int t0 = (g * cpg) / st.bn, t1 = (min((g + 1) * cpg, C) - 1) / st.bn;
     const double w1 = t1 > t0 ? 1.0 : 0.0;
     const float2* __restrict__ base = st.rows + (size_t)sample * st.R * st.W + g;
-    for (int r0 = rl; r0 < st.R; r0 += 4 * RL) {
-      float2 a[4], b[4];
+    for (int r0 = rl; r0 < st.R; r0 += 8 * RL) {
+      float2 a[8], b[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 8; ++j) {
         const size_t rr = (size_t)min(r0 + j * RL, st.R - 1) * st.W;
         a[j] = base[rr + t0];
         b[j] = base[rr + t1];
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 8; ++j)
         if (r0 + j * RL < st.R) {
           S += (double)a[j].x + w1 * (double)b[j].x;
           Q += (double)a[j].y + w1 * (double)b[j].y;
         }
     }
   }
-  part[tid][0] = S; part[tid][1] = Q;
+  if (tid < T) { part[tid][0] = S; part[tid][1] = Q; }
   __syncthreads();
   if (tid < ng) {
     S = 0.0; Q = 0.0;
@@ -74,14 +101,14 @@ __device__ __forceinline__ void merge_rows(const RowsDev& st, int sample, int cp
 }
 
 // (mean, rstd) of the groups [g0, g0 + ng) of `sample` -> gstat[ng][2]: merged from the rows (and written to nd.mean /
-// nd.rstd when `publish`), or read back (nd.st.rows == nullptr: the backward kernels).  `scratch` >= (T + GMAX) * 16 bytes.
+// nd.rstd when `publish`), or the prefetched read-back values (nd.st.rows == nullptr: the backward kernels).
+// `scratch` >= (T + GMAX) * 16 bytes.
 __device__ __forceinline__ void group_stats(const NormDev& nd, int sample, int hw, int g0, int ng, bool publish, void* scratch,
-                                            float (*gstat)[2]) {
-  const int tid = threadIdx.x;
+                                            float (*gstat)[2], const GroupPre& pre, int tid) {
   if (nd.st.rows) {
     double (*part)[2] = reinterpret_cast<double (*)[2]>(scratch);
     double (*tot)[2] = part + T;
-    merge_rows(nd.st, sample, nd.cpg, nd.c, g0, ng, part, tot);
+    merge_rows(nd.st, sample, nd.cpg, nd.c, g0, ng, part, tot, tid);
     if (tid < ng) {
       const double m = (double)hw * (double)nd.cpg;
       const double mean = tot[tid][0] / m;
@@ -92,19 +119,26 @@ __device__ __forceinline__ void group_stats(const NormDev& nd, int sample, int h
       if (publish) { nd.mean[sample * nd.groups + g0 + tid] = (float)mean; nd.rstd[sample * nd.groups + g0 + tid] = rstd; }
     }
   } else if (tid < ng) {
-    gstat[tid][0] = nd.mean[sample * nd.groups + g0 + tid];
-    gstat[tid][1] = nd.rstd[sample * nd.groups + g0 + tid];
+    gstat[tid][0] = pre.mean; gstat[tid][1] = pre.rstd;
   }
   __syncthreads();
 }
 
-// per-channel z = x * sc + sh  (sc = rstd gamma, sh = beta - mean sc) of the channels [c0, c0 + nc) -> tab[0..nc) | tab[nc..2nc)
-__device__ __forceinline__ void scale_shift_table(const NormDev& nd, int c0, int nc, int g0, const float (*gstat)[2], float* sc, float* sh) {
-  for (int i = threadIdx.x; i < nc; i += T) {
-    const int c = c0 + i, g = c / nd.cpg - g0;
-    const float s = gstat[g][1] * nd.gamma[c];
-    sc[i] = s;
-    sh[i] = nd.beta[c] - gstat[g][0] * s;
+// per-channel z = x * sc + sh  (sc = rstd gamma, sh = beta - mean sc) of the channels [c0, c0 + nc) -> sc[0..nc) | sh[0..nc)
+template <int NJ>
+__device__ __forceinline__ void scale_shift_table(const NormDev& nd, int c0, int nc, int g0, const float (*gstat)[2], float* sc, float* sh,
+                                                  const ChanPre<NJ>& p, int tid) {
+  if (tid < T) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int i = tid + j * T;
+      if (i < nc) {
+        const int g = (c0 + i) / nd.cpg - g0;
+        const float s = gstat[g][1] * p.g[j];
+        sc[i] = s;
+        sh[i] = p.b[j] - gstat[g][0] * s;
+      }
+    }
   }
   __syncthreads();
 }
@@ -133,13 +167,13 @@ __device__ __forceinline__ float4 norm_act_drop(float4 v, float4 sc, float4 sh, 
 // the caller has summed its (v1, v2) over those rows into s1[tn], s2[tn]; here: one cross-half shuffle, the WM waves
 // through LDS, then the channels of every group the N-tile touches, in channel order -> row[g + tile_n].  Optionally the
 // per-channel sums go to plane1 / plane2 (the parameter-gradient planes) and the group sums are weighted by wgt[c]
-// (gamma).  `smem`: dead operand tiles, >= (WM + 1) * BN * 2 floats.
+// (gamma).  `smem`: dead operand tiles, >= (WM + 1) * BN * 2 floats.  Every thread of the block calls; `tid` < T works.
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void reduce_group_rows(const float (&s1)[BN / WN / 32], const float (&s2)[BN / WN / 32], float* smem, float2* row,
-                                                  int n0, int C, int cpg, int tile_n, int wm, int wn, int lane, const float* wgt,
-                                                  float* plane1, float* plane2) {
+                                                  int n0, int C, int cpg, int tile_n, int tid, const float* wgt, float* plane1, float* plane2) {
   constexpr int TN = BN / WN / 32;
-  const int tid = threadIdx.x, l31 = lane & 31;
+  const bool on = tid < T;
+  const int lane = tid & 63, wave = (tid >> 6) & 3, wm = wave / WN, wn = wave % WN, l31 = lane & 31;
   float* red = smem;                 // [WM][BN][2]
   float* chan = smem + WM * BN * 2;  // [BN][2]
 #pragma unroll
@@ -147,7 +181,7 @@ __device__ __forceinline__ void reduce_group_rows(const float (&s1)[BN / WN / 32
     float a = s1[tn], b = s2[tn];
     a += __shfl_xor(a, 32, 64);
     b += __shfl_xor(b, 32, 64);
-    if (lane < 32) {
+    if (on && lane < 32) {
       const int col = wn * (BN / WN) + tn * 32 + l31;
       red[(wm * BN + col) * 2 + 0] = a;
       red[(wm * BN + col) * 2 + 1] = b;
@@ -176,6 +210,28 @@ __device__ __forceinline__ void reduce_group_rows(const float (&s1)[BN / WN / 32
   }
 }
 
+// Intra-block split-K: the accumulators of the groups 1 .. KS-1 are added to group 0's, in group order, through LDS
+// (`red` >= (KS - 1) * NACC * T floats; the operand tiles are dead).  Afterwards group 0 holds the tile.
+template <int KS, int NACC>
+__device__ __forceinline__ void sum_groups(f32x16* acc, float* red, int grp, int lt) {
+  if (KS == 1) return;
+  if (grp > 0) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((size_t)((grp - 1) * NACC + i) * 16 + r) * T + lt] = acc[i][r];
+  }
+  __syncthreads();
+  if (grp == 0) {
+    for (int g = 1; g < KS; ++g)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] += red[((size_t)((g - 1) * NACC + i) * 16 + r) * T + lt];
+  }
+  __syncthreads();
+}
+
 // =====================================================================================================================
 // pointwise forward:  y[M, N] = A[M, K] W[K, N],  A plain or normalised while loading
 // =====================================================================================================================
@@ -186,22 +242,24 @@ struct PwFwdArgs {
   RowsDev ost; int ocpg;
 };
 
-template <int BM, int BN, int WM, int WN, bool NORM, int ACT>
-__global__ __launch_bounds__(WM* WN * 64) void mb_pw_fwd_kernel(const PwFwdArgs a) {
-  static_assert(WM * WN * 64 == T, "256-thread blocks");
+// KS > 1: the K-tiles are dealt round-robin to KS groups of T threads (few output tiles, long K: the small maps' linear
+// convs), each with its own operand tiles; the groups' accumulators are summed at the end.
+template <int BM, int BN, int WM, int WN, bool NORM, int ACT, int KS>
+__global__ __launch_bounds__(T* KS) void mb_pw_fwd_kernel(const PwFwdArgs a) {
+  static_assert(WM * WN * 64 == T, "groups of 256 threads");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int KQ = BK / 4, A_RPP = T / KQ, A_PASS = BM / A_RPP;
   constexpr int NQ = BN / 4, B_RPP = T / NQ, B_PASS = BK / B_RPP;
   static_assert(A_PASS >= 1 && B_PASS >= 1 && BM % A_RPP == 0 && BK % B_RPP == 0, "tile/threads mismatch");
   constexpr int OPF = BM * LDK + BK * BN;
   static_assert(OPF * 4 >= (T + GMAX) * 16 && OPF >= (WM + 1) * BN * 2, "operand tiles double as scratch");
-  __shared__ __attribute__((aligned(16))) float smem[OPF];
+  static_assert(KS == 1 || KS * OPF >= (KS - 1) * TM * TN * 16 * T, "operand tiles double as the split-K exchange");
+  __shared__ __attribute__((aligned(16))) float smem[KS * OPF];
   __shared__ __attribute__((aligned(16))) float tab[NORM ? 2 * KMAX : 4];
   __shared__ float gstat[NORM ? GMAX : 1][2];
-  float* As = smem;
-  float* Bs = smem + BM * LDK;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, grp = tid / T, lt = tid % T, lane = lt & 63, wave = lt >> 6;
+  float* As = smem + grp * OPF;
+  float* Bs = As + BM * LDK;
   const int wm = wave / WN, wn = wave % WN;
   const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
@@ -214,13 +272,14 @@ __global__ __launch_bounds__(WM* WN * 64) void mb_pw_fwd_kernel(const PwFwdArgs 
   const __amdgpu_buffer_rsrc_t wb = make_rsrc(a.w, (unsigned)K * N * 4u);
   const bool has_res = NORM && a.res != nullptr;
 
-  const int kq = tid % KQ, arow = tid / KQ;
-  const int nq = tid % NQ;
+  const int kq = lt % KQ, arow = lt / KQ;
+  const int nq = lt % NQ;
   const int bcol = n0 + nq * 4;
-  const unsigned boff0 = bcol < N ? ((unsigned)(tid / NQ) * N + bcol) * 4u : OOB;
-  const int nk = (K + BK - 1) / BK;
+  const unsigned boff0 = bcol < N ? ((unsigned)(lt / NQ) * N + bcol) * 4u : OOB;
+  const int nk = (K + BK - 1) / BK, nit = (nk + KS - 1) / KS;
   float4 ra[A_PASS], rr[A_PASS], rb[B_PASS];
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](int it) {
+    const int kt = it * KS + grp;
     const int k = kt * BK + kq * 4;
     const bool kok = k < K;
 #pragma unroll
@@ -229,23 +288,29 @@ __global__ __launch_bounds__(WM* WN * 64) void mb_pw_fwd_kernel(const PwFwdArgs 
       ra[i] = Vec<4>::load(xa, off);
       if (NORM) rr[i] = Vec<4>::load(xr, has_res ? off : OOB);
     }
-    const unsigned bo = boff0 + (unsigned)kt * BK * N * 4u;
+    const unsigned bo = (kt < nk && boff0 != OOB) ? boff0 + (unsigned)kt * BK * N * 4u : OOB;
 #pragma unroll
-    for (int j = 0; j < B_PASS; ++j) rb[j] = Vec<4>::load(wb, bo + (unsigned)j * B_RPP * N * 4u);
+    for (int j = 0; j < B_PASS; ++j) rb[j] = Vec<4>::load(wb, bo == OOB ? OOB : bo + (unsigned)j * B_RPP * N * 4u);
   };
+  ChanPre<NORM ? KMAX / T : 1> pre;
+  GroupPre gpre = {0.f, 1.f};
+  if (NORM) {
+    prefetch_chan(a.in.gamma, a.in.beta, 0, K, tid, pre);
+    gpre = prefetch_groups(a.in, sample, 0, a.in.groups, tid);
+  }
   load_tiles(0);
   uint64_t seed = 0;
   bool drop = false;
   if (NORM) {
     // the sample's statistics while the first tiles are in flight; the first block of a sample publishes them
-    group_stats(a.in, sample, a.hw, 0, a.in.groups, tile_n == 0 && m0 == sample * a.hw, smem, gstat);
-    scale_shift_table(a.in, 0, K, 0, gstat, tab, tab + KMAX);
+    group_stats(a.in, sample, a.hw, 0, a.in.groups, tile_n == 0 && m0 == sample * a.hw, smem, gstat, gpre, tid);
+    scale_shift_table(a.in, 0, K, 0, gstat, tab, tab + KMAX, pre, tid);
     drop = a.in.drop_rate > 0.f;
     seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
   }
   const bool write_mat = NORM && a.mat != nullptr && tile_n == 0;
-  auto store_tiles = [&](int kt) {
-    const int k = kt * BK + kq * 4;
+  auto store_tiles = [&](int it) {
+    const int k = (it * KS + grp) * BK + kq * 4;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       float4 v = ra[i];
@@ -264,19 +329,20 @@ __global__ __launch_bounds__(WM* WN * 64) void mb_pw_fwd_kernel(const PwFwdArgs 
       *reinterpret_cast<float4*>(&As[(arow + i * A_RPP) * LDK + kq * 4]) = v;
     }
 #pragma unroll
-    for (int j = 0; j < B_PASS; ++j) *reinterpret_cast<float4*>(&Bs[(tid / NQ + j * B_RPP) * BN + nq * 4]) = rb[j];
+    for (int j = 0; j < B_PASS; ++j) *reinterpret_cast<float4*>(&Bs[(lt / NQ + j * B_RPP) * BN + nq * 4]) = rb[j];
   };
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  for (int kt = 0; kt < nk; ++kt) {
-    store_tiles(kt);
+  for (int it = 0; it < nit; ++it) {
+    store_tiles(it);
     __syncthreads();
-    if (kt + 1 < nk) load_tiles(kt + 1);
-    mma_ktile<BM, BN, WM, WN, false, false>(As, Bs, acc, wm, wn, lane);
+    if (it + 1 < nit) load_tiles(it + 1);
+    if (it * KS + grp < nk) mma_ktile<BM, BN, WM, WN, false, false>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
-  store_tile<BM, BN, WM, WN>(acc, a.y, nullptr, m0, n0, M, N, N, wm, wn, lane);
+  sum_groups<KS, TM * TN>(&acc[0][0], smem, grp, lt);
+  if (grp == 0) store_tile<BM, BN, WM, WN>(acc, a.y, nullptr, m0, n0, M, N, N, wm, wn, lane);
   if (a.ost.rows) {
     float2* row = a.ost.rows + ((size_t)sample * a.ost.R + (m0 - sample * a.hw) / BM) * a.ost.W;
     float s1[TN], s2[TN];
@@ -288,7 +354,7 @@ __global__ __launch_bounds__(WM* WN * 64) void mb_pw_fwd_kernel(const PwFwdArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const float v = acc[tm][tn][r]; s1[tn] += v; s2[tn] = fmaf(v, v, s2[tn]); }
     }
-    reduce_group_rows<BM, BN, WM, WN>(s1, s2, smem, row, n0, N, a.ocpg, tile_n, wm, wn, lane, nullptr, nullptr, nullptr);
+    reduce_group_rows<BM, BN, WM, WN>(s1, s2, smem, row, n0, N, a.ocpg, tile_n, tid, nullptr, nullptr, nullptr);
   }
 }
 
@@ -301,6 +367,22 @@ struct DwFwdArgs {
   int th, tw, tiles_h, tiles_w, sw, nslab, ph, pw;
   RowsDev ost; int ocpg;
 };
+constexpr int NP = 8;            // patch loads in flight per thread (the host keeps a patch at <= NP * T float4)
+
+// one patch element of thread `tid`: its LDS slot idx = tid + j T = pp * SQ + q, pixel, validity
+struct PatchElem { int q, pix; bool inside, live; };
+__device__ __forceinline__ PatchElem patch_elem(int idx, int total, int SQ, int pw, int y0, int x0, int h, int w) {
+  PatchElem e;
+  e.live = idx < total;
+  const int i = min(idx, total - 1);
+  const int pp = i / SQ;
+  e.q = i - pp * SQ;
+  const int py = pp / pw, px = pp - py * pw;
+  const int yy = y0 + py, xx = x0 + px;
+  e.inside = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
+  e.pix = min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1);
+  return e;
+}
 
 template <int ACT>
 __global__ __launch_bounds__(T) void mb_dw_fwd_kernel(const DwFwdArgs a) {
@@ -316,51 +398,43 @@ __global__ __launch_bounds__(T) void mb_dw_fwd_kernel(const DwFwdArgs a) {
   const int oh0 = (tile / a.tiles_w) * a.th, ow0 = (tile % a.tiles_w) * a.tw;
   const int C = a.c, SW = a.sw, SQ = SW >> 2, c0 = slab * SW;
   const int g0 = c0 / a.in.cpg, ng = SW / a.in.cpg;
-  group_stats(a.in, sample, a.h * a.wd, g0, ng, tile == 0, dsm, gstat);
-  scale_shift_table(a.in, c0, SW, g0, gstat, tab, tab + 128);
-  const bool drop = a.in.drop_rate > 0.f;
-  const uint64_t seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
-  // input patch -> LDS, normalised once per element; zero outside the image (SAME padding pads the ACTIVATED tensor)
+  // everything from memory first: the slab's gamma / beta, the raw patch, the stencil weights
+  ChanPre<1> pre;
+  prefetch_chan(a.in.gamma, a.in.beta, c0, SW, tid, pre);
+  const GroupPre gpre = prefetch_groups(a.in, sample, g0, ng, tid);
   const int ih0 = oh0 * a.stride - a.pad_t, iw0 = ow0 * a.stride - a.pad_l;
   const int total = a.ph * a.pw * SQ;
   const float* __restrict__ xs = a.in.y + (size_t)sample * a.h * a.wd * C + c0;
+  float4 pv[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const PatchElem e = patch_elem(tid + j * T, total, SQ, a.pw, ih0, iw0, a.h, a.wd);
+    pv[j] = *reinterpret_cast<const float4*>(xs + (size_t)e.pix * C + e.q * 4);
+  }
+  const int lanes = T / SQ, q4 = tid % SQ, pl = tid / SQ;
+  float4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(a.w + (size_t)t * C + c0 + min(q4, SQ - 1) * 4);
+  group_stats(a.in, sample, a.h * a.wd, g0, ng, tile == 0, dsm, gstat, gpre, tid);
+  scale_shift_table(a.in, c0, SW, g0, gstat, tab, tab + 128, pre, tid);
+  const bool drop = a.in.drop_rate > 0.f;
+  const uint64_t seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
+  // patch -> LDS, normalised once per element; zero outside the image (SAME padding pads the ACTIVATED tensor)
   const uint64_t samp_off = (uint64_t)sample * a.h * a.wd * C;
-  for (int base = tid; base < total; base += 4 * T) {
-    float4 v[4];
-    int pix[4], q[4];
-    bool ok[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = min(base + j * T, total - 1);
-      const int pp = idx / SQ;
-      q[j] = idx - pp * SQ;
-      const int py = pp / a.pw, px = pp - py * a.pw;
-      const int ih = ih0 + py, iw = iw0 + px;
-      ok[j] = (unsigned)ih < (unsigned)a.h && (unsigned)iw < (unsigned)a.wd;
-      pix[j] = min(max(ih, 0), a.h - 1) * a.wd + min(max(iw, 0), a.wd - 1);
-      v[j] = *reinterpret_cast<const float4*>(xs + (size_t)pix[j] * C + q[j] * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = base + j * T;
-      if (idx < total) {
-        const float4 sc = *reinterpret_cast<const float4*>(&tab[q[j] * 4]);
-        const float4 sh = *reinterpret_cast<const float4*>(&tab[128 + q[j] * 4]);
-        float4 o = norm_act_drop<ACT>(v[j], sc, sh, a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed,
-                                      samp_off + (uint64_t)pix[j] * C + c0 + q[j] * 4);
-        if (!ok[j]) o = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&dsm[(size_t)idx * 4]) = o;     // idx = pp * SQ + q: [pp][sw] rows
-      }
+  for (int j = 0; j < NP; ++j) {
+    const PatchElem e = patch_elem(tid + j * T, total, SQ, a.pw, ih0, iw0, a.h, a.wd);
+    if (e.live) {
+      float4 o = norm_act_drop<ACT>(pv[j], *reinterpret_cast<const float4*>(&tab[e.q * 4]), *reinterpret_cast<const float4*>(&tab[128 + e.q * 4]),
+                                    a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed, samp_off + (uint64_t)e.pix * C + c0 + e.q * 4);
+      if (!e.inside) o = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&dsm[(size_t)(tid + j * T) * 4]) = o;     // slot = pp * SQ + q: [pp][sw] rows
     }
   }
   __syncthreads();
   // stencil from LDS: thread = (channel quad, pixel lane)
-  const int lanes = T / SQ, q4 = tid % SQ, pl = tid / SQ;
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (pl < lanes) {
-    float4 wv[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(a.w + (size_t)t * C + c0 + q4 * 4);
     float* __restrict__ ys = a.y + (size_t)sample * a.oh * a.ow * C + c0 + q4 * 4;
     for (int p = pl; p < a.th * a.tw; p += lanes) {
       const int oy = p / a.tw, ox = p - oy * a.tw;
@@ -415,8 +489,11 @@ __global__ __launch_bounds__(T) void mb_apply_kernel(const ApplyArgs a) {
   __shared__ __attribute__((aligned(16))) float tab[2 * KMAX];
   __shared__ float gstat[GMAX][2];
   const int tid = threadIdx.x, sample = blockIdx.y, C = a.in.c, CQ = C >> 2;
-  group_stats(a.in, sample, a.hw, 0, a.in.groups, blockIdx.x == 0, scratch, gstat);
-  scale_shift_table(a.in, 0, C, 0, gstat, tab, tab + KMAX);
+  ChanPre<KMAX / T> pre;
+  prefetch_chan(a.in.gamma, a.in.beta, 0, C, tid, pre);
+  const GroupPre gpre = prefetch_groups(a.in, sample, 0, a.in.groups, tid);
+  group_stats(a.in, sample, a.hw, 0, a.in.groups, blockIdx.x == 0, scratch, gstat, gpre, tid);
+  scale_shift_table(a.in, 0, C, 0, gstat, tab, tab + KMAX, pre, tid);
   const bool drop = a.in.drop_rate > 0.f;
   const uint64_t seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
   const int p_begin = blockIdx.x * a.ppb, p_end = min(p_begin + a.ppb, a.hw);
@@ -448,27 +525,32 @@ struct GoutDev {          // rn_mb_gout
 };
 
 // per-channel coefficients of dy = P g' + Q + R y for the channels [c0, c0 + nc) of `sample`: the GroupNorm's statistics
-// (read back) and the merged rows c1 = sum(gamma g) / m, c2 = sum(gamma g xhat) / m.  tab: P | Q | R, each `stride` apart.
+// (read back: `gp`) and the merged rows c1 = sum(gamma g) / m, c2 = sum(gamma g xhat) / m.  tab: P | Q | R, `stride` apart.
+template <int NJ>
 __device__ __forceinline__ void dy_table(const DyDev& d, int sample, int hw, int c0, int nc, void* scratch, float (*gstat)[2], float (*gc)[2],
-                                         float* tab, int stride) {
-  const int tid = threadIdx.x;
+                                         float* tab, int stride, const GroupPre& gp, const ChanPre<NJ>& p, int tid) {
   const int g0 = c0 / d.nd.cpg, ng = (c0 + nc - 1) / d.nd.cpg - g0 + 1;
   double (*part)[2] = reinterpret_cast<double (*)[2]>(scratch);
   double (*tot)[2] = part + T;
-  merge_rows(d.grows, sample, d.nd.cpg, d.nd.c, g0, ng, part, tot);
+  merge_rows(d.grows, sample, d.nd.cpg, d.nd.c, g0, ng, part, tot, tid);
   if (tid < ng) {
     const double m = (double)hw * (double)d.nd.cpg;
     gc[tid][0] = (float)(tot[tid][0] / m); gc[tid][1] = (float)(tot[tid][1] / m);
-    gstat[tid][0] = d.nd.mean[sample * d.nd.groups + g0 + tid];
-    gstat[tid][1] = d.nd.rstd[sample * d.nd.groups + g0 + tid];
+    gstat[tid][0] = gp.mean; gstat[tid][1] = gp.rstd;
   }
   __syncthreads();
-  for (int i = tid; i < nc; i += T) {
-    const int c = c0 + i, g = c / d.nd.cpg - g0;
-    const float mean = gstat[g][0], rstd = gstat[g][1], c1 = gc[g][0], c2 = gc[g][1];
-    tab[i] = rstd * d.nd.gamma[c];
-    tab[stride + i] = rstd * (rstd * c2 * mean - c1);
-    tab[2 * stride + i] = -rstd * rstd * c2;
+  if (tid < T) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int i = tid + j * T;
+      if (i < nc) {
+        const int g = (c0 + i) / d.nd.cpg - g0;
+        const float mean = gstat[g][0], rstd = gstat[g][1], c1 = gc[g][0], c2 = gc[g][1];
+        tab[i] = rstd * p.g[j];
+        tab[stride + i] = rstd * (rstd * c2 * mean - c1);
+        tab[2 * stride + i] = -rstd * rstd * c2;
+      }
+    }
   }
   __syncthreads();
 }
@@ -496,17 +578,17 @@ struct PwBwdArgs {
   int w_tiles_m, w_tiles_n, chunk, sps;       // weight gradient: tiles over (cin, cout), pixels per split, splits per sample
   float* slab;                                // [n * sps][cin][cout]
 };
-constexpr int PB = 64;                        // both halves use 64x64 tiles, 2 x 2 waves
-constexpr int PW_LDS = 2 * PB * LDK;          // operand floats (dgrad: two k-contiguous tiles; wgrad needs 2 * BK * PB, less)
+constexpr int PB = 64;                        // both halves use 64x64 tiles, 2 x 2 waves (x KS groups)
+constexpr int PW_LDS = 2 * PB * LDK;          // operand floats per group (dgrad: two k-contiguous tiles; wgrad needs 2 * BK * PB, less)
 
 // data gradient  d[M, cin] = dy[M, cout] W^T  and what rn_mb_gout asks for
-template <int ACT_OUT>
-__device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem, float* tabD, float (*gstat)[2], float (*gc)[2], int blk) {
+template <int ACT_OUT, int KS>
+__device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem_all, float* tabD, float (*gstat)[2], float (*gc)[2], int blk) {
   constexpr int BM = PB, BN = PB, WM = 2, WN = 2, TM = 1, TN = 1;
   constexpr int KQ = BK / 4, RPP = T / KQ, A_PASS = BM / RPP, B_PASS = BN / RPP;
-  float* As = smem;
-  float* Bs = smem + BM * LDK;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, grp = tid / T, lt = tid % T, lane = lt & 63, wave = lt >> 6;
+  float* As = smem_all + grp * PW_LDS;
+  float* Bs = As + BM * LDK;
   const int wm = wave / WN, wn = wave % WN;
   const int bid = rn::xcd_remap(blk, a.dblocks);
   const int tile_n = bid % a.d_tiles_n, tile_m = bid / a.d_tiles_n;
@@ -517,17 +599,17 @@ __device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem
   const __amdgpu_buffer_rsrc_t ga = make_rsrc(plain ? a.dy.dy : a.dy.g, (unsigned)M * KD * 4u);
   const __amdgpu_buffer_rsrc_t ya = make_rsrc(plain ? a.dy.dy : a.dy.nd.y, (unsigned)M * KD * 4u);
   const __amdgpu_buffer_rsrc_t wb = make_rsrc(a.w, (unsigned)ND * KD * 4u);
-  const int kq = tid % KQ, r0 = tid / KQ;
+  const int kq = lt % KQ, r0 = lt / KQ;
   unsigned browoff[B_PASS];
 #pragma unroll
   for (int j = 0; j < B_PASS; ++j) {
     const int ci = n0 + r0 + j * RPP;
     browoff[j] = ci < ND ? (unsigned)ci * KD * 4u : OOB;
   }
-  const int nk = (KD + BK - 1) / BK;
+  const int nk = (KD + BK - 1) / BK, nit = (nk + KS - 1) / KS;
   float4 ra[A_PASS], ry[A_PASS], rb[B_PASS];
-  auto load_tiles = [&](int kt) {
-    const int k = kt * BK + kq * 4;
+  auto load_tiles = [&](int it) {
+    const int k = (it * KS + grp) * BK + kq * 4;
     const bool kok = k < KD;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
@@ -538,16 +620,33 @@ __device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem
 #pragma unroll
     for (int j = 0; j < B_PASS; ++j) rb[j] = Vec<4>::load(wb, (kok && browoff[j] != OOB) ? browoff[j] + (unsigned)k * 4u : OOB);
   };
+  // everything from memory first: the dy table's gamma and statistics, the epilogue's per-column constants, the first tiles
+  ChanPre<KMAX / T> pre;
+  GroupPre gpre = {0.f, 1.f};
+  if (!plain) {
+    prefetch_chan<KMAX / T>(a.dy.nd.gamma, nullptr, 0, KD, tid, pre);
+    gpre = prefetch_groups(a.dy.nd, sample, 0, a.dy.nd.groups, tid);
+  }
+  const GoutDev& go = a.go;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int col = n0 + wn * 32 + l31;
+  const bool cok = col < ND;
+  float o_mean = 0.f, o_rstd = 1.f, o_gam = 1.f, o_bet = 0.f;
+  if (go.has_norm && grp == 0) {
+    const int cc = cok ? col : 0, og = cc / go.nd.cpg;
+    o_mean = go.nd.mean[sample * go.nd.groups + og]; o_rstd = go.nd.rstd[sample * go.nd.groups + og];
+    o_gam = go.nd.gamma[cc]; o_bet = go.nd.beta[cc];
+  }
   load_tiles(0);
   bool mask = false;
   uint64_t seed = 0;
   if (!plain) {
-    dy_table(a.dy, sample, a.hw, 0, KD, smem, gstat, gc, tabD, KMAX);
+    dy_table(a.dy, sample, a.hw, 0, KD, smem_all, gstat, gc, tabD, KMAX, gpre, pre, tid);
     mask = a.dy.g_plain && a.dy.nd.drop_rate > 0.f;
     seed = a.dy.nd.seed + (a.dy.nd.seed_dev ? *a.dy.nd.seed_dev : 0ull);
   }
-  auto store_tiles = [&](int kt) {
-    const int k = kt * BK + kq * 4;
+  auto store_tiles = [&](int it) {
+    const int k = (it * KS + grp) * BK + kq * 4;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       float4 v = ra[i];
@@ -563,89 +662,83 @@ __device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem
   };
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  for (int kt = 0; kt < nk; ++kt) {
-    store_tiles(kt);
+  for (int it = 0; it < nit; ++it) {
+    store_tiles(it);
     __syncthreads();
-    if (kt + 1 < nk) load_tiles(kt + 1);
-    mma_ktile<BM, BN, WM, WN, false, true>(As, Bs, acc, wm, wn, lane);
+    if (it + 1 < nit) load_tiles(it + 1);
+    if (it * KS + grp < nk) mma_ktile<BM, BN, WM, WN, false, true>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
-  // ---- epilogue: d (+ addends) -> out; with a GroupNorm block behind the conv's input: g, its rows and planes
-  const GoutDev& go = a.go;
-  const int l31 = lane & 31, half = lane >> 5;
-  const int col = n0 + wn * 32 + l31;
-  const bool cok = col < ND;
+  sum_groups<KS, 1>(&acc[0][0], smem_all, grp, lt);
+  // ---- epilogue (group 0): d (+ addends) -> out; with a GroupNorm block behind the conv's input: g, its rows and planes
   const int rbase = m0 + wm * 32 + 4 * half;
   const __amdgpu_buffer_rsrc_t ro = make_rsrc(go.out, (unsigned)M * ND * 4u);
+  const bool on = grp == 0;
   float d[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) d[r] = acc[0][0][r];
-  if (go.add1) {
-    const __amdgpu_buffer_rsrc_t r1 = make_rsrc(go.add1, (unsigned)M * ND * 4u);
-    float t[16];
+  float t1[16], t2[16], yv[16];
+  {
+    const __amdgpu_buffer_rsrc_t r1 = make_rsrc(go.add1 ? go.add1 : go.out, (unsigned)M * ND * 4u);
+    const __amdgpu_buffer_rsrc_t r2 = make_rsrc(go.add2 ? go.add2 : go.out, (unsigned)M * ND * 4u);
+    const __amdgpu_buffer_rsrc_t ry2 = make_rsrc(go.has_norm ? go.nd.y : go.out, (unsigned)M * ND * 4u);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = Vec<1>::load(r1, cok ? ((unsigned)(rbase + (r & 3) + 8 * (r >> 2)) * ND + col) * 4u : OOB);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) d[r] += t[r];
+    for (int r = 0; r < 16; ++r) {
+      const unsigned off = (cok && on) ? ((unsigned)(rbase + (r & 3) + 8 * (r >> 2)) * ND + col) * 4u : OOB;
+      t1[r] = Vec<1>::load(r1, go.add1 ? off : OOB);
+      t2[r] = Vec<1>::load(r2, go.add2 ? off : OOB);
+      yv[r] = Vec<1>::load(ry2, go.has_norm ? off : OOB);
+    }
   }
-  if (go.add2) {
-    const __amdgpu_buffer_rsrc_t r2 = make_rsrc(go.add2, (unsigned)M * ND * 4u);
-    float t[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = Vec<1>::load(r2, cok ? ((unsigned)(rbase + (r & 3) + 8 * (r >> 2)) * ND + col) * 4u : OOB);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) d[r] += t[r];
-  }
+  for (int r = 0; r < 16; ++r) d[r] += t1[r] + t2[r];
   if (!go.has_norm) {
+    if (on) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[r]), ro, cok ? ((unsigned)(rbase + (r & 3) + 8 * (r >> 2)) * ND + col) * 4u : OOB, 0, 0);
+      for (int r = 0; r < 16; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[r]), ro, cok ? ((unsigned)(rbase + (r & 3) + 8 * (r >> 2)) * ND + col) * 4u : OOB, 0, 0);
+    }
     return;
   }
   const NormDev& nd = go.nd;
-  const __amdgpu_buffer_rsrc_t ry2 = make_rsrc(nd.y, (unsigned)M * ND * 4u);
-  float yv[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) yv[r] = Vec<1>::load(ry2, cok ? ((unsigned)(rbase + (r & 3) + 8 * (r >> 2)) * ND + col) * 4u : OOB);
-  const int cc = cok ? col : 0, grp = cc / nd.cpg;
-  const float mean = nd.mean[sample * nd.groups + grp], rstd = nd.rstd[sample * nd.groups + grp];
-  const float gam = nd.gamma[cc], bet = nd.beta[cc];
   const bool drop = nd.drop_rate > 0.f;
   const uint64_t oseed = nd.seed + (nd.seed_dev ? *nd.seed_dev : 0ull);
   float s1[1] = {0.f}, s2[1] = {0.f};
+  if (on) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = rbase + (r & 3) + 8 * (r >> 2);
-    const float xh = (yv[r] - mean) * rstd;
-    const float z = fmaf(xh, gam, bet);
-    float g = d[r] * actgrad_of<ACT_OUT>(z, nd.act);
-    if (drop) g = (rn::uniform01(oseed, (uint64_t)row * ND + col) >= nd.drop_rate) ? g * nd.keep_scale : 0.f;
-    if (!cok) g = 0.f;
-    s1[0] += g; s2[0] = fmaf(g, xh, s2[0]);
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(go.store_plain ? d[r] : g), ro, cok ? ((unsigned)row * ND + col) * 4u : OOB, 0, 0);
+    for (int r = 0; r < 16; ++r) {
+      const int row = rbase + (r & 3) + 8 * (r >> 2);
+      const float xh = (yv[r] - o_mean) * o_rstd;
+      const float z = fmaf(xh, o_gam, o_bet);
+      float g = d[r] * actgrad_of<ACT_OUT>(z, nd.act);
+      if (drop) g = (rn::uniform01(oseed, (uint64_t)row * ND + col) >= nd.drop_rate) ? g * nd.keep_scale : 0.f;
+      if (!cok) g = 0.f;
+      s1[0] += g; s2[0] = fmaf(g, xh, s2[0]);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(go.store_plain ? d[r] : g), ro, cok ? ((unsigned)row * ND + col) * 4u : OOB, 0, 0);
+    }
   }
   const int prow = sample * go.grows.R + (m0 - sample * a.hw) / BM;
-  reduce_group_rows<BM, BN, WM, WN>(s1, s2, smem, go.grows.rows + (size_t)prow * go.grows.W, n0, ND, nd.cpg, tile_n, wm, wn, lane, nd.gamma,
+  reduce_group_rows<BM, BN, WM, WN>(s1, s2, smem_all, go.grows.rows + (size_t)prow * go.grows.W, n0, ND, nd.cpg, tile_n, tid, nd.gamma,
                                     go.planes + (size_t)prow * ND, go.planes + go.plane_stride + (size_t)prow * ND);
 }
 
 // weight gradient  dW[cin, cout] = A^T dy over one split's pixels (inside one sample) -> slab[split]
-template <int ACT_IN>
-__device__ __forceinline__ void mb_pw_wgrad_body(const PwBwdArgs& a, float* smem, float* tabA, float* tabD, float (*gstat)[2], float (*gc)[2],
+template <int ACT_IN, int KS>
+__device__ __forceinline__ void mb_pw_wgrad_body(const PwBwdArgs& a, float* smem_all, float* tabA, float* tabD, float (*gstat)[2], float (*gc)[2],
                                                  int blk, int nblk) {
   constexpr int BM = PB, BN = PB, WM = 2, WN = 2, TM = 1, TN = 1;
   constexpr int MQ = BM / 4, A_RPP = T / MQ, A_PASS = BK / A_RPP;
   constexpr int NQ = BN / 4, B_RPP = T / NQ, B_PASS = BK / B_RPP;
-  float* As = smem;              // [BK][BM]  (pixel rows, cin contiguous)
-  float* Bs = smem + BK * BM;    // [BK][BN]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, grp = tid / T, lt = tid % T, lane = lt & 63, wave = lt >> 6;
+  float* As = smem_all + grp * PW_LDS;   // [BK][BM]  (pixel rows, cin contiguous)
+  float* Bs = As + BK * BM;              // [BK][BN]
   const int wm = wave / WN, wn = wave % WN;
   const int bid = rn::xcd_remap(blk, nblk);
   const int tiles_mn = a.w_tiles_m * a.w_tiles_n;
   const int split = bid / tiles_mn, t = bid - split * tiles_mn;
   const int tile_n = t % a.w_tiles_n, tile_m = t / a.w_tiles_n;
   const int sample = split / a.sps;
-  const int p0 = sample * a.hw + (split - sample * a.sps) * a.chunk, p1 = p0 + a.chunk;   // chunk divides hw (host)
+  const int p0 = sample * a.hw + (split - sample * a.sps) * a.chunk;   // chunk divides hw (host)
   const int KI = a.cin, NO = a.cout, M = a.n * a.hw;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const bool plain = a.dy.dy != nullptr;
@@ -653,95 +746,111 @@ __device__ __forceinline__ void mb_pw_wgrad_body(const PwBwdArgs& a, float* smem
   const __amdgpu_buffer_rsrc_t xa = make_rsrc(asrc, (unsigned)M * KI * 4u);
   const __amdgpu_buffer_rsrc_t ga = make_rsrc(plain ? a.dy.dy : a.dy.g, (unsigned)M * NO * 4u);
   const __amdgpu_buffer_rsrc_t ya = make_rsrc(plain ? a.dy.dy : a.dy.nd.y, (unsigned)M * NO * 4u);
-  const int mq = tid % MQ, acol = m0 + mq * 4;
+  const int mq = lt % MQ, acol = m0 + mq * 4;
   const bool aok = acol < KI;
-  const int nq = tid % NQ, bcol = n0 + nq * 4;
+  const int nq = lt % NQ, bcol = n0 + nq * 4;
   const bool bok = bcol < NO;
-  const int nk = a.chunk / BK;
+  const int nk = a.chunk / BK, nit = (nk + KS - 1) / KS;
   float4 ra[A_PASS], rg[B_PASS], ry[B_PASS];
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](int it) {
+    const int kt = it * KS + grp;
+    const bool tok = kt < nk;
 #pragma unroll
     for (int j = 0; j < A_PASS; ++j) {
-      const int p = p0 + kt * BK + tid / MQ + j * A_RPP;
-      ra[j] = Vec<4>::load(xa, aok ? ((unsigned)p * KI + acol) * 4u : OOB);
+      const int p = p0 + kt * BK + lt / MQ + j * A_RPP;
+      ra[j] = Vec<4>::load(xa, (aok && tok) ? ((unsigned)p * KI + acol) * 4u : OOB);
     }
 #pragma unroll
     for (int j = 0; j < B_PASS; ++j) {
-      const int p = p0 + kt * BK + tid / NQ + j * B_RPP;
-      const unsigned off = bok ? ((unsigned)p * NO + bcol) * 4u : OOB;
+      const int p = p0 + kt * BK + lt / NQ + j * B_RPP;
+      const unsigned off = (bok && tok) ? ((unsigned)p * NO + bcol) * 4u : OOB;
       rg[j] = Vec<4>::load(ga, off);
       ry[j] = Vec<4>::load(ya, plain ? OOB : off);
     }
   };
+  const int na = min(BM, KI - m0), nb = min(BN, NO - n0);
+  ChanPre<1> pre_d, pre_a;
+  GroupPre gp_d = {0.f, 1.f}, gp_a = {0.f, 1.f};
+  int ga0 = 0, nga = 1;
+  if (!plain) {
+    prefetch_chan<1>(a.dy.nd.gamma, nullptr, n0, nb, tid, pre_d);
+    const int g0 = n0 / a.dy.nd.cpg, ng = (n0 + nb - 1) / a.dy.nd.cpg - g0 + 1;
+    gp_d = prefetch_groups(a.dy.nd, sample, g0, ng, tid);
+  }
+  if (a.has_in) {
+    prefetch_chan<1>(a.in.gamma, a.in.beta, m0, na, tid, pre_a);
+    ga0 = m0 / a.in.cpg; nga = (m0 + na - 1) / a.in.cpg - ga0 + 1;
+    gp_a = prefetch_groups(a.in, sample, ga0, nga, tid);
+  }
   load_tiles(0);
   bool mask = false, drop_in = false;
   uint64_t seed = 0, seed_in = 0;
-  const int na = min(BM, KI - m0), nb = min(BN, NO - n0);
   if (!plain) {
-    dy_table(a.dy, sample, a.hw, n0, nb, smem, gstat, gc, tabD, BN);
+    dy_table(a.dy, sample, a.hw, n0, nb, smem_all, gstat, gc, tabD, BN, gp_d, pre_d, tid);
     mask = a.dy.g_plain && a.dy.nd.drop_rate > 0.f;
     seed = a.dy.nd.seed + (a.dy.nd.seed_dev ? *a.dy.nd.seed_dev : 0ull);
   }
   if (a.has_in) {
-    const int g0 = m0 / a.in.cpg, ng = (m0 + na - 1) / a.in.cpg - g0 + 1;
-    group_stats(a.in, sample, a.hw, g0, ng, false, smem, gstat);
-    scale_shift_table(a.in, m0, na, g0, gstat, tabA, tabA + BM);
+    group_stats(a.in, sample, a.hw, ga0, nga, false, smem_all, gstat, gp_a, tid);
+    scale_shift_table(a.in, m0, na, ga0, gstat, tabA, tabA + BM, pre_a, tid);
     drop_in = a.in.drop_rate > 0.f;
     seed_in = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
   }
-  auto store_tiles = [&](int kt) {
+  auto store_tiles = [&](int it) {
+    const int kt = it * KS + grp;
 #pragma unroll
     for (int j = 0; j < A_PASS; ++j) {
       float4 v = ra[j];
       if (a.has_in) {
-        if (aok) {
-          const int p = p0 + kt * BK + tid / MQ + j * A_RPP;
+        if (aok && kt < nk) {
+          const int p = p0 + kt * BK + lt / MQ + j * A_RPP;
           v = norm_act_drop<ACT_IN>(v, *reinterpret_cast<const float4*>(&tabA[mq * 4]), *reinterpret_cast<const float4*>(&tabA[BM + mq * 4]),
                                     a.in.act, drop_in, a.in.drop_rate, a.in.keep_scale, seed_in, (uint64_t)p * KI + acol);
         } else {
           v = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
-      *reinterpret_cast<float4*>(&As[(tid / MQ + j * A_RPP) * BM + mq * 4]) = v;
+      *reinterpret_cast<float4*>(&As[(lt / MQ + j * A_RPP) * BM + mq * 4]) = v;
     }
 #pragma unroll
     for (int j = 0; j < B_PASS; ++j) {
       float4 v = rg[j];
       if (!plain) {
-        if (bok) {
-          const int p = p0 + kt * BK + tid / NQ + j * B_RPP;
+        if (bok && kt < nk) {
+          const int p = p0 + kt * BK + lt / NQ + j * B_RPP;
           v = dy_of(v, ry[j], tabD, BN, nq * 4, mask, a.dy.nd.drop_rate, a.dy.nd.keep_scale, seed, (uint64_t)p * NO + bcol);
         } else {
           v = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
-      *reinterpret_cast<float4*>(&Bs[(tid / NQ + j * B_RPP) * BN + nq * 4]) = v;
+      *reinterpret_cast<float4*>(&Bs[(lt / NQ + j * B_RPP) * BN + nq * 4]) = v;
     }
   };
-  (void)p1;
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  for (int kt = 0; kt < nk; ++kt) {
-    store_tiles(kt);
+  for (int it = 0; it < nit; ++it) {
+    store_tiles(it);
     __syncthreads();
-    if (kt + 1 < nk) load_tiles(kt + 1);
-    mma_ktile<BM, BN, WM, WN, true, false>(As, Bs, acc, wm, wn, lane);
+    if (it + 1 < nit) load_tiles(it + 1);
+    if (it * KS + grp < nk) mma_ktile<BM, BN, WM, WN, true, false>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
-  store_tile<BM, BN, WM, WN>(acc, a.slab + (size_t)split * KI * NO, nullptr, m0, n0, KI, NO, NO, wm, wn, lane);
+  sum_groups<KS, 1>(&acc[0][0], smem_all, grp, lt);
+  if (grp == 0) store_tile<BM, BN, WM, WN>(acc, a.slab + (size_t)split * KI * NO, nullptr, m0, n0, KI, NO, NO, wm, wn, lane);
 }
 
 // ACT_IN: activation of the weight gradient's A block (-2: plain x); ACT_OUT: activation of the block the data gradient enters
-template <int ACT_IN, int ACT_OUT>
-__global__ __launch_bounds__(T) void mb_pw_bwd_kernel(const PwBwdArgs a) {
+template <int ACT_IN, int ACT_OUT, int KS>
+__global__ __launch_bounds__(T* KS) void mb_pw_bwd_kernel(const PwBwdArgs a) {
   static_assert(PW_LDS * 4 >= (T + GMAX) * 16 && PW_LDS >= 3 * PB * 2 && PW_LDS >= 2 * BK * PB, "operand tiles double as scratch");
-  __shared__ __attribute__((aligned(16))) float smem[PW_LDS];
+  static_assert(KS == 1 || KS * PW_LDS >= (KS - 1) * 16 * T, "operand tiles double as the split-K exchange");
+  __shared__ __attribute__((aligned(16))) float smem[KS * PW_LDS];
   __shared__ __attribute__((aligned(16))) float tabD[3 * KMAX];
   __shared__ __attribute__((aligned(16))) float tabA[2 * PB];
   __shared__ float gstat[GMAX][2];
   __shared__ float gc[GMAX][2];
-  if ((int)blockIdx.x < a.dblocks) mb_pw_dgrad_body<ACT_OUT>(a, smem, tabD, gstat, gc, blockIdx.x);
-  else mb_pw_wgrad_body<(ACT_IN == -2 ? 0 : ACT_IN)>(a, smem, tabA, tabD, gstat, gc, (int)blockIdx.x - a.dblocks, (int)gridDim.x - a.dblocks);
+  if ((int)blockIdx.x < a.dblocks) mb_pw_dgrad_body<ACT_OUT, KS>(a, smem, tabD, gstat, gc, blockIdx.x);
+  else mb_pw_wgrad_body<(ACT_IN == -2 ? 0 : ACT_IN), KS>(a, smem, tabA, tabD, gstat, gc, (int)blockIdx.x - a.dblocks, (int)gridDim.x - a.dblocks);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -776,92 +885,71 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
   const int aph = a.th + 2, apw = a.tw + 2;
   float* a1p = dsm;
   float* dyp = dsm + (size_t)aph * apw * SW;
-  // coefficient tables (the patches' LDS is the merge scratch until they are filled)
-  dy_table(a.dy, sample, a.oh * a.ow, c0, SW, dsm, gstat, gc, tabD, 128);
-  {
-    const int g0 = c0 / a.in.cpg, ng = SW / a.in.cpg;
-    group_stats(a.in, sample, a.h * a.wd, g0, ng, false, dsm, gstat);
-    scale_shift_table(a.in, c0, SW, g0, gstat, tabA, tabA + 128);
-    for (int i = tid; i < SW; i += T) {
-      const int g = (c0 + i) / a.in.cpg - g0;
-      tabA[256 + i] = gstat[g][0]; tabA[384 + i] = gstat[g][1];
-    }
-    __syncthreads();
-  }
-  const bool drop = a.in.drop_rate > 0.f;
-  const uint64_t seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
-  // a1 patch: input rows [ih0 - pad_t, +th+2), cols [iw0 - pad_l, +tw+2)
-  {
-    const int ay0 = ih0 - a.pad_t, ax0 = iw0 - a.pad_l;
-    const int total = aph * apw * SQ;
-    const float* __restrict__ xs = a.in.y + (size_t)sample * a.h * a.wd * C + c0;
-    const uint64_t samp_off = (uint64_t)sample * a.h * a.wd * C;
-    for (int base = tid; base < total; base += 4 * T) {
-      float4 v[4];
-      int pix[4], q[4];
-      bool ok[4];
+  const int g0 = c0 / a.in.cpg, ng = SW / a.in.cpg;
+  // ---- everything from memory first: channel constants, statistics, both raw patches, the stencil weights
+  ChanPre<1> pre_a, pre_d;
+  prefetch_chan<1>(a.in.gamma, a.in.beta, c0, SW, tid, pre_a);
+  prefetch_chan<1>(a.dy.nd.gamma, nullptr, c0, SW, tid, pre_d);
+  const GroupPre gp_a = prefetch_groups(a.in, sample, g0, ng, tid);
+  const GroupPre gp_d = prefetch_groups(a.dy.nd, sample, g0, ng, tid);
+  const int ay0 = ih0 - a.pad_t, ax0 = iw0 - a.pad_l;
+  const int atotal = aph * apw * SQ;
+  const float* __restrict__ xs = a.in.y + (size_t)sample * a.h * a.wd * C + c0;
+  float4 av[NP];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = min(base + j * T, total - 1);
-        const int pp = idx / SQ;
-        q[j] = idx - pp * SQ;
-        const int py = pp / apw, px = pp - py * apw;
-        const int ih = ay0 + py, iw = ax0 + px;
-        ok[j] = (unsigned)ih < (unsigned)a.h && (unsigned)iw < (unsigned)a.wd;
-        pix[j] = min(max(ih, 0), a.h - 1) * a.wd + min(max(iw, 0), a.wd - 1);
-        v[j] = *reinterpret_cast<const float4*>(xs + (size_t)pix[j] * C + q[j] * 4);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = base + j * T;
-        if (idx < total) {
-          float4 o = norm_act_drop<ACT>(v[j], *reinterpret_cast<const float4*>(&tabA[q[j] * 4]), *reinterpret_cast<const float4*>(&tabA[128 + q[j] * 4]),
-                                        a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed, samp_off + (uint64_t)pix[j] * C + c0 + q[j] * 4);
-          if (!ok[j]) o = make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(&a1p[(size_t)idx * 4]) = o;
-        }
-      }
-    }
+  for (int j = 0; j < NP; ++j) {
+    const PatchElem e = patch_elem(tid + j * T, atotal, SQ, apw, ay0, ax0, a.h, a.wd);
+    av[j] = *reinterpret_cast<const float4*>(xs + (size_t)e.pix * C + e.q * 4);
   }
   // dy patch: output rows [oy0, +oph), cols [ox0, +opw): every output that touches the tile
   const int oy0 = floor_div(ih0 + a.pad_t - 2 + (s - 1), s), ox0 = floor_div(iw0 + a.pad_l - 2 + (s - 1), s);
-  {
-    const int total = a.oph * a.opw * SQ;
-    const float* __restrict__ gs = a.dy.g + (size_t)sample * a.oh * a.ow * C + c0;
-    const float* __restrict__ ys = a.dy.nd.y + (size_t)sample * a.oh * a.ow * C + c0;
-    for (int base = tid; base < total; base += 4 * T) {
-      float4 g[4], y[4];
-      int q[4];
-      bool ok[4];
+  const int dtotal = a.oph * a.opw * SQ;
+  const float* __restrict__ gs = a.dy.g + (size_t)sample * a.oh * a.ow * C + c0;
+  const float* __restrict__ ys = a.dy.nd.y + (size_t)sample * a.oh * a.ow * C + c0;
+  float4 gv[NP], yv2[NP];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = min(base + j * T, total - 1);
-        const int pp = idx / SQ;
-        q[j] = idx - pp * SQ;
-        const int py = pp / a.opw, px = pp - py * a.opw;
-        const int oh_ = oy0 + py, ow_ = ox0 + px;
-        ok[j] = (unsigned)oh_ < (unsigned)a.oh && (unsigned)ow_ < (unsigned)a.ow;
-        const size_t off = (size_t)(min(max(oh_, 0), a.oh - 1) * a.ow + min(max(ow_, 0), a.ow - 1)) * C + q[j] * 4;
-        g[j] = *reinterpret_cast<const float4*>(gs + off);
-        y[j] = *reinterpret_cast<const float4*>(ys + off);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = base + j * T;
-        if (idx < total) {
-          float4 o = dy_of(g[j], y[j], tabD, 128, q[j] * 4, false, 0.f, 1.f, 0ull, 0ull);
-          if (!ok[j]) o = make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(&dyp[(size_t)idx * 4]) = o;
-        }
-      }
-    }
+  for (int j = 0; j < NP; ++j) {
+    const PatchElem e = patch_elem(tid + j * T, dtotal, SQ, a.opw, oy0, ox0, a.oh, a.ow);
+    gv[j] = *reinterpret_cast<const float4*>(gs + (size_t)e.pix * C + e.q * 4);
+    yv2[j] = *reinterpret_cast<const float4*>(ys + (size_t)e.pix * C + e.q * 4);
   }
-  __syncthreads();
   const int lanes = T / SQ, q4 = tid % SQ, pl = tid / SQ;
   const bool active = pl < lanes;
   float4 wv[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) wv[t] = active ? *reinterpret_cast<const float4*>(a.w + (size_t)t * C + c0 + q4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(a.w + (size_t)t * C + c0 + min(q4, SQ - 1) * 4);
+  // ---- coefficient tables (the patches' LDS is the merge scratch until they are filled)
+  dy_table(a.dy, sample, a.oh * a.ow, c0, SW, dsm, gstat, gc, tabD, 128, gp_d, pre_d, tid);
+  group_stats(a.in, sample, a.h * a.wd, g0, ng, false, dsm, gstat, gp_a, tid);
+  scale_shift_table(a.in, c0, SW, g0, gstat, tabA, tabA + 128, pre_a, tid);
+  for (int i = tid; i < SW; i += T) {
+    const int g = (c0 + i) / a.in.cpg - g0;
+    tabA[256 + i] = gstat[g][0]; tabA[384 + i] = gstat[g][1];
+  }
+  __syncthreads();
+  const bool drop = a.in.drop_rate > 0.f;
+  const uint64_t seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
+  const uint64_t samp_off = (uint64_t)sample * a.h * a.wd * C;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const PatchElem e = patch_elem(tid + j * T, atotal, SQ, apw, ay0, ax0, a.h, a.wd);
+    if (e.live) {
+      float4 o = norm_act_drop<ACT>(av[j], *reinterpret_cast<const float4*>(&tabA[e.q * 4]), *reinterpret_cast<const float4*>(&tabA[128 + e.q * 4]),
+                                    a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed, samp_off + (uint64_t)e.pix * C + c0 + e.q * 4);
+      if (!e.inside) o = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&a1p[(size_t)(tid + j * T) * 4]) = o;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const PatchElem e = patch_elem(tid + j * T, dtotal, SQ, a.opw, oy0, ox0, a.oh, a.ow);
+    if (e.live) {
+      float4 o = dy_of(gv[j], yv2[j], tabD, 128, e.q * 4, false, 0.f, 1.f, 0ull, 0ull);
+      if (!e.inside) o = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&dyp[(size_t)(tid + j * T) * 4]) = o;
+    }
+  }
+  __syncthreads();
   // ---- data gradient of the tile's pixels, then g1 and its sums
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (active) {
@@ -869,7 +957,6 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
     const float4 mn = *reinterpret_cast<const float4*>(&tabA[256 + q4 * 4]), rs = *reinterpret_cast<const float4*>(&tabA[384 + q4 * 4]);
     const float* __restrict__ y1 = a.in.y + (size_t)sample * a.h * a.wd * C + c0 + q4 * 4;
     float* __restrict__ go = a.go.out + (size_t)sample * a.h * a.wd * C + c0 + q4 * 4;
-    const uint64_t samp_off = (uint64_t)sample * a.h * a.wd * C;
     for (int p = pl; p < a.th * a.tw; p += lanes) {
       const int ty = p / a.tw, tx = p - ty * a.tw;
       const int ih = ih0 + ty, iw = iw0 + tx;
@@ -937,39 +1024,38 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
     }
   }
   __syncthreads();                                 // the patches are dead: their LDS becomes the reduction scratch
-  float (*red)[4] = reinterpret_cast<float (*)[4]>(dsm);
-  const int brow = sample * ntile + tile;
-  for (int t = 0; t < 9; ++t) {
-    red[tid][0] = wacc[t].x; red[tid][1] = wacc[t].y; red[tid][2] = wacc[t].z; red[tid][3] = wacc[t].w;
-    __syncthreads();
-    if (tid < SQ) {
-      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-      for (int l = 0; l < lanes; ++l) { b0 += red[l * SQ + tid][0]; b1 += red[l * SQ + tid][1]; b2 += red[l * SQ + tid][2]; b3 += red[l * SQ + tid][3]; }
-      *reinterpret_cast<float4*>(a.partial + ((size_t)brow * 9 + t) * C + c0 + tid * 4) = make_float4(b0, b1, b2, b3);
-    }
-    __syncthreads();
-  }
-  // g1's sums: per channel -> planes, gamma-weighted per group -> rows
-  float (*red8)[8] = reinterpret_cast<float (*)[8]>(dsm);
-  float (*chan)[2] = reinterpret_cast<float (*)[2]>(dsm + T * 8);
+  // one exchange for all nine taps and both statistics: red[thread][36 + 8], then (tap, channel) outputs over the pixel lanes
+  constexpr int RW = 44;
+  float* red = dsm;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { red8[tid][j] = s1[j]; red8[tid][4 + j] = s2[j]; }
+  for (int t = 0; t < 9; ++t) {
+    red[tid * RW + t * 4 + 0] = wacc[t].x; red[tid * RW + t * 4 + 1] = wacc[t].y;
+    red[tid * RW + t * 4 + 2] = wacc[t].z; red[tid * RW + t * 4 + 3] = wacc[t].w;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[tid * RW + 36 + j] = s1[j]; red[tid * RW + 40 + j] = s2[j]; }
   __syncthreads();
-  for (int e = tid; e < SQ * 8; e += T) {
-    const int qd = e >> 3, comp = e & 7;
+  float* chan = dsm + T * RW;                       // [sw][2]
+  const int brow = sample * ntile + tile;
+  for (int e = tid; e < 11 * SW; e += T) {          // 9 taps + 2 statistics, channel fastest; pixel lanes in order
+    const int k = e / SW, ch = e - k * SW;
+    const int qd = ch >> 2, comp = ch & 3;
     float t = 0.f;
-    for (int l = 0; l < lanes; ++l) t += red8[l * SQ + qd][comp];
-    const int ch = qd * 4 + (comp & 3);
-    chan[ch][comp >> 2] = t;
-    a.go.planes[(size_t)(comp >> 2) * a.go.plane_stride + (size_t)brow * C + c0 + ch] = t;
+    for (int l = 0; l < lanes; ++l) t += red[(l * SQ + qd) * RW + k * 4 + comp];
+    if (k < 9) {
+      a.partial[((size_t)brow * 9 + k) * C + c0 + ch] = t;
+    } else {
+      chan[ch * 2 + (k - 9)] = t;
+      a.go.planes[(size_t)(k - 9) * a.go.plane_stride + (size_t)brow * C + c0 + ch] = t;
+    }
   }
   __syncthreads();
-  const int cpg = a.in.cpg, ng = SW / cpg, g0 = c0 / cpg;
+  const int cpg = a.in.cpg;
   if (tid < ng) {
     float t1 = 0.f, t2 = 0.f;
     for (int j = 0; j < cpg; ++j) {
       const float w = a.in.gamma[c0 + tid * cpg + j];
-      t1 += w * chan[tid * cpg + j][0]; t2 += w * chan[tid * cpg + j][1];
+      t1 += w * chan[(tid * cpg + j) * 2 + 0]; t2 += w * chan[(tid * cpg + j) * 2 + 1];
     }
     a.go.grows.rows[(size_t)brow * a.go.grows.W + g0 + tid] = make_float2(t1, t2);
   }
@@ -1032,9 +1118,11 @@ bool dw_plan(int n, int oh, int ow, int c, int stride, int cpg, DwPlan* p) {
   if (th > oh) th = oh;
   if (tw > ow) tw = ow;
   auto blocks = [&]() { return (long)n * rn::ceil_div(oh, th) * rn::ceil_div(ow, tw) * p->nslab; };
-  while (blocks() < 384 && th * tw > 16) {
+  auto patch = [&]() { return (long)((th - 1) * stride + 3) * ((tw - 1) * stride + 3) * (p->sw / 4); };
+  while ((blocks() < 384 && th * tw > 16) || (patch() > NP * T && th * tw > 1)) {   // (a thread holds <= NP patch loads)
     if (th >= tw) th = (th + 1) / 2; else tw = (tw + 1) / 2;
   }
+  if (patch() > NP * T) return false;
   p->th = th; p->tw = tw;
   p->tiles_h = rn::ceil_div(oh, th); p->tiles_w = rn::ceil_div(ow, tw);
   p->ph = (th - 1) * stride + 3; p->pw = (tw - 1) * stride + 3;
@@ -1086,19 +1174,26 @@ extern "C" int rn_mb_pointwise_fwd(const float* x, const rn_mb_norm* in, const f
     a.ost.rows = (float2*)stat_out->rows; a.ost.R = want.rows_per_sample; a.ost.W = want.width; a.ost.bn = want.bn;
     a.ocpg = cout / stat_groups;
   }
-  const dim3 grid((unsigned)((long)n * hw / c.bm * a.tiles_n));
+  const long blocks = (long)n * hw / c.bm * a.tiles_n;
+  const dim3 grid((unsigned)blocks);
   hipStream_t st = (hipStream_t)stream;
-#define RN_PW(BM_, BN_, WM_, WN_)                                                                                     \
+  // few output tiles with a long K (the small maps' linear convs): four groups of waves share the K-tiles of a block
+  static const bool no_ks = getenv("RN_MB_NO_SPLITK") != nullptr;
+  const bool ks4 = in && c.id == 0 && blocks <= 96 && rn::ceil_div(cin, BK) >= 4 && !no_ks;
+#define RN_PW(BM_, BN_, WM_, WN_, KS_)                                                                                \
   do {                                                                                                                \
-    if (!in) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, false, 0>), grid, dim3(T), 0, st, a);            \
-    else if (in->act == RN_ACT_NONE) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_NONE>), grid, dim3(T), 0, st, a); \
-    else if (in->act == RN_ACT_ELU) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_ELU>), grid, dim3(T), 0, st, a);   \
-    else hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, -1>), grid, dim3(T), 0, st, a);                \
+    if (!in) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, false, 0, 1>), grid, dim3(T), 0, st, a);         \
+    else if (in->act == RN_ACT_NONE) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_NONE, KS_>), grid, dim3(T * KS_), 0, st, a); \
+    else if (in->act == RN_ACT_ELU) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_ELU, KS_>), grid, dim3(T * KS_), 0, st, a);   \
+    else hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, -1, KS_>), grid, dim3(T * KS_), 0, st, a);     \
   } while (0)
   switch (c.id) {
-    case 1: RN_PW(128, 32, 4, 1); break;
-    case 2: RN_PW(128, 64, 2, 2); break;
-    default: RN_PW(64, 64, 2, 2); break;
+    case 1: RN_PW(128, 32, 4, 1, 1); break;
+    case 2: RN_PW(128, 64, 2, 2, 1); break;
+    default:
+      if (ks4) RN_PW(64, 64, 2, 2, 4);
+      else RN_PW(64, 64, 2, 2, 1);
+      break;
   }
 #undef RN_PW
   RN_LAUNCH_CHECK();
@@ -1201,12 +1296,20 @@ int fill_gout(const rn_mb_gout* s, GoutDev* d, int n, int channels, const rn_mb_
   d->planes = s->planes; d->plane_stride = (long)n * want.rows_per_sample * channels;
   return RN_OK;
 }
-// weight-gradient split of the pointwise backward: pixels per split (divides hw, multiple of BK) and splits per sample
-void pw_wgrad_plan(int n, int hw, int cin, int cout, int* chunk, int* sps) {
+// intra-block split-K of the pointwise backward: few data-gradient tiles with a long reduction (the small maps)
+int pw_bwd_ks(int n, int hw, int cin, int cout) {
+  static const bool no_ks = getenv("RN_MB_NO_SPLITK") != nullptr;
+  const long dblocks = (long)n * hw / PB * rn::ceil_div(cin, PB);
+  return (!no_ks && dblocks <= 96 && rn::ceil_div(cout, BK) >= 4) ? 4 : 1;
+}
+// weight-gradient split of the pointwise backward: pixels per split (divides hw, multiple of BK) and splits per sample;
+// a block (ks groups) reduces >= 128 ks pixels -- every block pays for its coefficient tables once
+void pw_wgrad_plan(int n, int hw, int cin, int cout, int ks, int* chunk, int* sps) {
   const int tiles = rn::ceil_div(cin, PB) * rn::ceil_div(cout, PB);
-  int want = rn::ceil_div(768, tiles * n);             // splits per sample for ~768 blocks
+  int want = rn::ceil_div(384, tiles * n);             // splits per sample for ~384 blocks
   if (const char* f = getenv("RN_MB_WGRAD_SPS")) { if (atoi(f) > 0) want = atoi(f); }   // tuning aid
-  const int units = hw / 64;                           // a split reduces >= 64 pixels
+  const int unit = 128 * ks;
+  const int units = hw % unit == 0 ? hw / unit : 1;    // (hw is a multiple of 64; odd multiples: one split per sample)
   int best = 1;
   for (int d = 1; d <= units && d <= want; ++d)
     if (units % d == 0) best = d;
@@ -1225,12 +1328,13 @@ bool dw_bwd_plan(int n, int h, int w, int c, int stride, int cpg, DwBwdPlan* p) 
   p->th = th; p->tw = tw;                              // powers of two >= 2: aligned to stride 1 / 2
   p->tiles_h = rn::ceil_div(h, th); p->tiles_w = rn::ceil_div(w, tw);
   p->oph = th / stride + 2; p->opw = tw / stride + 2;
+  if ((long)(th + 2) * (tw + 2) * (p->sw / 4) > NP * T || (long)p->oph * p->opw * (p->sw / 4) > NP * T) return false;
   return true;
 }
 size_t dw_bwd_lds_bytes(const DwBwdPlan& p) {
   size_t patches = ((size_t)(p.th + 2) * (p.tw + 2) + (size_t)p.oph * p.opw) * p.sw * 4;
   size_t scratch = (size_t)(T + GMAX) * 16;
-  size_t red = (size_t)(T * 8 + 2 * p.sw) * 4;
+  size_t red = (size_t)(T * 44 + 2 * p.sw) * 4;
   size_t m = patches > scratch ? patches : scratch;
   return m > red ? m : red;
 }
@@ -1246,7 +1350,7 @@ extern "C" size_t rn_mb_pointwise_bwd_rows(int n, int hw, int cin, int cout, int
 extern "C" size_t rn_mb_pointwise_bwd_workspace(int n, int hw, int cin, int cout) {
   if (n < 1 || hw < 64 || hw % 64 || cin < 4 || cout < 4) return 0;
   int chunk, sps;
-  pw_wgrad_plan(n, hw, cin, cout, &chunk, &sps);
+  pw_wgrad_plan(n, hw, cin, cout, pw_bwd_ks(n, hw, cin, cout), &chunk, &sps);
   return (size_t)n * sps * cin * cout * sizeof(float);
 }
 
@@ -1274,7 +1378,8 @@ extern "C" int rn_mb_pointwise_bwd(const float* x, const rn_mb_norm* in, const r
   a.d_tiles_n = rn::ceil_div(cin, PB);
   a.dblocks = n * hw / PB * a.d_tiles_n;
   a.w_tiles_m = rn::ceil_div(cin, PB); a.w_tiles_n = rn::ceil_div(cout, PB);
-  pw_wgrad_plan(n, hw, cin, cout, &a.chunk, &a.sps);
+  const int ks = pw_bwd_ks(n, hw, cin, cout);
+  pw_wgrad_plan(n, hw, cin, cout, ks, &a.chunk, &a.sps);
   const int nsplit = n * a.sps;
   const size_t need = (size_t)nsplit * cin * cout * sizeof(float);
   if (workspace_bytes < need) { rn::set_error("mb pointwise bwd: workspace %zu < %zu bytes", workspace_bytes, need); return RN_EWORKSPACE; }
@@ -1282,10 +1387,15 @@ extern "C" int rn_mb_pointwise_bwd(const float* x, const rn_mb_norm* in, const r
   const dim3 grid((unsigned)(a.dblocks + nsplit * a.w_tiles_m * a.w_tiles_n));
   hipStream_t st = (hipStream_t)stream;
   const int act_in = in ? in->act : -2, act_out = gout->norm ? gout->norm->act : RN_ACT_NONE;
-  if (act_in == -2 && act_out == RN_ACT_NONE) hipLaunchKernelGGL((mb_pw_bwd_kernel<-2, RN_ACT_NONE>), grid, dim3(T), 0, st, a);
-  else if (act_in == -2) hipLaunchKernelGGL((mb_pw_bwd_kernel<-2, -1>), grid, dim3(T), 0, st, a);
-  else if (act_in == RN_ACT_ELU && act_out == RN_ACT_ELU) hipLaunchKernelGGL((mb_pw_bwd_kernel<RN_ACT_ELU, RN_ACT_ELU>), grid, dim3(T), 0, st, a);
-  else hipLaunchKernelGGL((mb_pw_bwd_kernel<-1, -1>), grid, dim3(T), 0, st, a);
+#define RN_PWB(KS_)                                                                                                                  \
+  do {                                                                                                                               \
+    if (act_in == -2 && act_out == RN_ACT_NONE) hipLaunchKernelGGL((mb_pw_bwd_kernel<-2, RN_ACT_NONE, KS_>), grid, dim3(T * KS_), 0, st, a); \
+    else if (act_in == -2) hipLaunchKernelGGL((mb_pw_bwd_kernel<-2, -1, KS_>), grid, dim3(T * KS_), 0, st, a);                         \
+    else if (act_in == RN_ACT_ELU && act_out == RN_ACT_ELU) hipLaunchKernelGGL((mb_pw_bwd_kernel<RN_ACT_ELU, RN_ACT_ELU, KS_>), grid, dim3(T * KS_), 0, st, a); \
+    else hipLaunchKernelGGL((mb_pw_bwd_kernel<-1, -1, KS_>), grid, dim3(T * KS_), 0, st, a);                                           \
+  } while (0)
+  if (ks == 4) RN_PWB(4); else RN_PWB(1);
+#undef RN_PWB
   RN_LAUNCH_CHECK();
   if (nsplit == 1) return RN_OK;
   return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)cin * cout, nsplit, 0, st);

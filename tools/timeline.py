@@ -20,7 +20,7 @@ def main(path):
     # steps = spans between consecutive assign kernels; of the last ten, the one of median WALL time (the profiler's buffer
     # flushes put multi-millisecond holes into some steps)
     spans = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1)]
-    spans = [s for s in spans if 300 < s[1] - s[0] < 700][-10:]
+    spans = [s for s in spans if 100 < s[1] - s[0] < 700][-10:]
     spans.sort(key=lambda s: int(rows[s[1]]['Start_Timestamp']) - int(rows[s[0]]['Start_Timestamp']))
     lo, hi = spans[len(spans) // 2]
     step = rows[lo:hi]
