@@ -14,6 +14,7 @@
 // input patch through LDS (one transform per element instead of one per tap).  HBM-bound layers: what this file removes is
 // the write + re-read of every normalised tensor and 7 of 13 kernel boundaries per bottleneck.
 #include <stdlib.h>
+#include <string.h>
 
 #include "conv_tiles.h"
 #include "rn_common.h"
@@ -148,16 +149,43 @@ __device__ __forceinline__ float act_of(float z, int act_rt) { return ACT >= 0 ?
 template <int ACT>
 __device__ __forceinline__ float actgrad_of(float z, int act_rt) { return ACT >= 0 ? rn::act_grad(z, ACT) : rn::act_grad(z, act_rt); }
 
+// rn::uniform01(seed, idx .. idx + 3) >= rate for four consecutive element indices, the same bits as the per-element
+// function: every tensor here has < 2^32 elements (host-checked: < 2 GiB), so the index's high word contributes only the
+// seed's high word; the first multiply is shared (idx + j) * C = idx * C + j * C.  (The two avalanche multiplies per element
+// stay: v_mul_lo_u32 is quarter rate, this is what an element's mask costs.)
+__device__ __forceinline__ void keep4(uint64_t seed, uint64_t eidx, float rate, float keep, float (&m)[4]) {
+  const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
+  uint32_t h0 = (uint32_t)eidx * 0x9E3779B1u + s_lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t h = h0 ^ s_hi;
+    h0 += 0x9E3779B1u;
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    m[j] = ((float)(h >> 8) * (1.0f / 16777216.0f) >= rate) ? keep : 0.f;
+  }
+}
+__device__ __forceinline__ float keep1(uint64_t seed, uint64_t eidx, float rate, float keep) {
+  uint32_t h = ((uint32_t)eidx * 0x9E3779B1u + (uint32_t)seed) ^ (uint32_t)(seed >> 32);
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return ((float)(h >> 8) * (1.0f / 16777216.0f) >= rate) ? keep : 0.f;
+}
+
 // drop(act(z)) of 4 consecutive channels of one pixel; `eidx` = element index of the first one in the GroupNorm's tensor
 template <int ACT>
 __device__ __forceinline__ float4 norm_act_drop(float4 v, float4 sc, float4 sh, int act_rt, bool drop, float rate, float keep,
                                                 uint64_t seed, uint64_t eidx) {
   float o[4] = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)};
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float t = act_of<ACT>(o[j], act_rt);
-    if (drop) t = (rn::uniform01(seed, eidx + (uint64_t)j) >= rate) ? t * keep : 0.f;
-    o[j] = t;
+  for (int j = 0; j < 4; ++j) o[j] = act_of<ACT>(o[j], act_rt);
+  if (drop) {
+    float m[4];
+    keep4(seed, eidx, rate, keep, m);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] *= m[j];
   }
   return make_float4(o[0], o[1], o[2], o[3]);
 }
@@ -172,8 +200,8 @@ template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void reduce_group_rows(const float (&s1)[BN / WN / 32], const float (&s2)[BN / WN / 32], float* smem, float2* row,
                                                   int n0, int C, int cpg, int tile_n, int tid, const float* wgt, float* plane1, float* plane2) {
   constexpr int TN = BN / WN / 32;
-  const bool on = tid < T;
-  const int lane = tid & 63, wave = (tid >> 6) & 3, wm = wave / WN, wn = wave % WN, l31 = lane & 31;
+  const bool on = tid < WM * WN * 64;                 // group 0
+  const int lane = tid & 63, wave = (tid >> 6) % (WM * WN), wm = wave / WN, wn = wave % WN, l31 = lane & 31;
   float* red = smem;                 // [WM][BN][2]
   float* chan = smem + WM * BN * 2;  // [BN][2]
 #pragma unroll
@@ -212,14 +240,14 @@ __device__ __forceinline__ void reduce_group_rows(const float (&s1)[BN / WN / 32
 
 // Intra-block split-K: the accumulators of the groups 1 .. KS-1 are added to group 0's, in group order, through LDS
 // (`red` >= (KS - 1) * NACC * T floats; the operand tiles are dead).  Afterwards group 0 holds the tile.
-template <int KS, int NACC>
+template <int KS, int NACC, int TG = T>
 __device__ __forceinline__ void sum_groups(f32x16* acc, float* red, int grp, int lt) {
   if (KS == 1) return;
   if (grp > 0) {
 #pragma unroll
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[((size_t)((grp - 1) * NACC + i) * 16 + r) * T + lt] = acc[i][r];
+      for (int r = 0; r < 16; ++r) red[((size_t)((grp - 1) * NACC + i) * 16 + r) * TG + lt] = acc[i][r];
   }
   __syncthreads();
   if (grp == 0) {
@@ -227,7 +255,7 @@ __device__ __forceinline__ void sum_groups(f32x16* acc, float* red, int grp, int
 #pragma unroll
       for (int i = 0; i < NACC; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] += red[((size_t)((g - 1) * NACC + i) * 16 + r) * T + lt];
+        for (int r = 0; r < 16; ++r) acc[i][r] += red[((size_t)((g - 1) * NACC + i) * 16 + r) * TG + lt];
   }
   __syncthreads();
 }
@@ -236,28 +264,32 @@ __device__ __forceinline__ void sum_groups(f32x16* acc, float* red, int grp, int
 // pointwise forward:  y[M, N] = A[M, K] W[K, N],  A plain or normalised while loading
 // =====================================================================================================================
 struct PwFwdArgs {
+  int dbg;   // tuning aid (RN_MB_DBG): stop after a phase
   const float* x; const float* res; float* mat; const float* w; float* y;
   NormDev in;
   int n, hw, cin, cout, tiles_n;
   RowsDev ost; int ocpg;
 };
 
-// KS > 1: the K-tiles are dealt round-robin to KS groups of T threads (few output tiles, long K: the small maps' linear
-// convs), each with its own operand tiles; the groups' accumulators are summed at the end.
+// KS > 1: the K-tiles are dealt round-robin to KS groups of TG = WM WN 64 threads (few output tiles, long K: the small
+// maps' linear convs), each with its own operand tiles; the groups' accumulators are summed at the end.  The smallest maps
+// take 32 x 32 tiles with one wave per group: more blocks -- the operand transform (ELU, dropout mask: VALU work) and the
+// fp32 MFMAs of a 64 x 64 x 960 tile would keep ONE compute unit busy for 13 us while 230 others idle.
 template <int BM, int BN, int WM, int WN, bool NORM, int ACT, int KS>
-__global__ __launch_bounds__(T* KS) void mb_pw_fwd_kernel(const PwFwdArgs a) {
-  static_assert(WM * WN * 64 == T, "groups of 256 threads");
+__global__ __launch_bounds__(WM* WN * 64 * KS) void mb_pw_fwd_kernel(const PwFwdArgs a) {
+  constexpr int TG = WM * WN * 64;
+  static_assert(TG * KS >= T || !NORM, "the prologue needs 256 threads");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int KQ = BK / 4, A_RPP = T / KQ, A_PASS = BM / A_RPP;
-  constexpr int NQ = BN / 4, B_RPP = T / NQ, B_PASS = BK / B_RPP;
+  constexpr int KQ = BK / 4, A_RPP = TG / KQ, A_PASS = BM / A_RPP;
+  constexpr int NQ = BN / 4, B_RPP = TG / NQ, B_PASS = BK / B_RPP;
   static_assert(A_PASS >= 1 && B_PASS >= 1 && BM % A_RPP == 0 && BK % B_RPP == 0, "tile/threads mismatch");
   constexpr int OPF = BM * LDK + BK * BN;
-  static_assert(OPF * 4 >= (T + GMAX) * 16 && OPF >= (WM + 1) * BN * 2, "operand tiles double as scratch");
-  static_assert(KS == 1 || KS * OPF >= (KS - 1) * TM * TN * 16 * T, "operand tiles double as the split-K exchange");
+  static_assert(KS * OPF * 4 >= (T + GMAX) * 16 && OPF >= (WM + 1) * BN * 2, "operand tiles double as scratch");
+  static_assert(KS == 1 || KS * OPF >= (KS - 1) * TM * TN * 16 * TG, "operand tiles double as the split-K exchange");
   __shared__ __attribute__((aligned(16))) float smem[KS * OPF];
   __shared__ __attribute__((aligned(16))) float tab[NORM ? 2 * KMAX : 4];
   __shared__ float gstat[NORM ? GMAX : 1][2];
-  const int tid = threadIdx.x, grp = tid / T, lt = tid % T, lane = lt & 63, wave = lt >> 6;
+  const int tid = threadIdx.x, grp = tid / TG, lt = tid % TG, lane = lt & 63, wave = lt >> 6;
   float* As = smem + grp * OPF;
   float* Bs = As + BM * LDK;
   const int wm = wave / WN, wn = wave % WN;
@@ -308,6 +340,7 @@ __global__ __launch_bounds__(T* KS) void mb_pw_fwd_kernel(const PwFwdArgs a) {
     drop = a.in.drop_rate > 0.f;
     seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
   }
+  if (a.dbg == 1) return;
   const bool write_mat = NORM && a.mat != nullptr && tile_n == 0;
   auto store_tiles = [&](int it) {
     const int k = (it * KS + grp) * BK + kq * 4;
@@ -341,8 +374,10 @@ __global__ __launch_bounds__(T* KS) void mb_pw_fwd_kernel(const PwFwdArgs a) {
     if (it * KS + grp < nk) mma_ktile<BM, BN, WM, WN, false, false>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
-  sum_groups<KS, TM * TN>(&acc[0][0], smem, grp, lt);
+  if (a.dbg == 2) { if (acc[0][0][0] == 123.456f) a.y[0] = 0.f; return; }
+  sum_groups<KS, TM * TN, TG>(&acc[0][0], smem, grp, lt);
   if (grp == 0) store_tile<BM, BN, WM, WN>(acc, a.y, nullptr, m0, n0, M, N, N, wm, wn, lane);
+  if (a.dbg == 3) return;
   if (a.ost.rows) {
     float2* row = a.ost.rows + ((size_t)sample * a.ost.R + (m0 - sample * a.hw) / BM) * a.ost.W;
     float s1[TN], s2[TN];
@@ -362,6 +397,7 @@ __global__ __launch_bounds__(T* KS) void mb_pw_fwd_kernel(const PwFwdArgs a) {
 // depthwise 3x3 forward on the normalised input: block = (sample, TH x TW output tile, channel slab of whole groups)
 // =====================================================================================================================
 struct DwFwdArgs {
+  int dbg;
   NormDev in; const float* w; float* y;
   int n, h, wd, c, stride, oh, ow, pad_t, pad_l;
   int th, tw, tiles_h, tiles_w, sw, nslab, ph, pw;
@@ -404,12 +440,13 @@ __global__ __launch_bounds__(T) void mb_dw_fwd_kernel(const DwFwdArgs a) {
   const GroupPre gpre = prefetch_groups(a.in, sample, g0, ng, tid);
   const int ih0 = oh0 * a.stride - a.pad_t, iw0 = ow0 * a.stride - a.pad_l;
   const int total = a.ph * a.pw * SQ;
-  const float* __restrict__ xs = a.in.y + (size_t)sample * a.h * a.wd * C + c0;
+  // (raw buffer loads: a slot that is not part of the patch, or lies outside the image, costs no memory access)
+  const __amdgpu_buffer_rsrc_t xs = make_rsrc(a.in.y + (size_t)sample * a.h * a.wd * C + c0, (unsigned)(a.h * a.wd * C - c0) * 4u);
   float4 pv[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
     const PatchElem e = patch_elem(tid + j * T, total, SQ, a.pw, ih0, iw0, a.h, a.wd);
-    pv[j] = *reinterpret_cast<const float4*>(xs + (size_t)e.pix * C + e.q * 4);
+    pv[j] = Vec<4>::load(xs, (e.live && e.inside) ? ((unsigned)e.pix * C + e.q * 4) * 4u : OOB);
   }
   const int lanes = T / SQ, q4 = tid % SQ, pl = tid / SQ;
   float4 wv[9];
@@ -417,6 +454,7 @@ __global__ __launch_bounds__(T) void mb_dw_fwd_kernel(const DwFwdArgs a) {
   for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(a.w + (size_t)t * C + c0 + min(q4, SQ - 1) * 4);
   group_stats(a.in, sample, a.h * a.wd, g0, ng, tile == 0, dsm, gstat, gpre, tid);
   scale_shift_table(a.in, c0, SW, g0, gstat, tab, tab + 128, pre, tid);
+  if (a.dbg == 1) { if (pv[0].x == 123.456f && wv[0].x == 1.f) a.y[0] = 0.f; return; }
   const bool drop = a.in.drop_rate > 0.f;
   const uint64_t seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
   // patch -> LDS, normalised once per element; zero outside the image (SAME padding pads the ACTIVATED tensor)
@@ -432,6 +470,7 @@ __global__ __launch_bounds__(T) void mb_dw_fwd_kernel(const DwFwdArgs a) {
     }
   }
   __syncthreads();
+  if (a.dbg == 2) { if (dsm[tid] == 123.456f) a.y[0] = 0.f; return; }
   // stencil from LDS: thread = (channel quad, pixel lane)
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (pl < lanes) {
@@ -457,7 +496,7 @@ __global__ __launch_bounds__(T) void mb_dw_fwd_kernel(const DwFwdArgs a) {
       }
     }
   }
-  if (!a.ost.rows) return;
+  if (!a.ost.rows || a.dbg == 3) return;
   __syncthreads();                                 // the patch is dead: its LDS becomes the reduction scratch
   float (*red)[8] = reinterpret_cast<float (*)[8]>(dsm);
   float (*chan)[2] = reinterpret_cast<float (*)[2]>(dsm + T * 8);
@@ -561,16 +600,16 @@ __device__ __forceinline__ float4 dy_of(float4 g, float4 y, const float* tab, in
   const float4 Q = *reinterpret_cast<const float4*>(&tab[stride + i]);
   const float4 R = *reinterpret_cast<const float4*>(&tab[2 * stride + i]);
   if (mask) {
-    g.x = (rn::uniform01(seed, eidx) >= rate) ? g.x * keep : 0.f;
-    g.y = (rn::uniform01(seed, eidx + 1) >= rate) ? g.y * keep : 0.f;
-    g.z = (rn::uniform01(seed, eidx + 2) >= rate) ? g.z * keep : 0.f;
-    g.w = (rn::uniform01(seed, eidx + 3) >= rate) ? g.w * keep : 0.f;
+    float m[4];
+    keep4(seed, eidx, rate, keep, m);
+    g.x *= m[0]; g.y *= m[1]; g.z *= m[2]; g.w *= m[3];
   }
   return make_float4(fmaf(P.x, g.x, fmaf(R.x, y.x, Q.x)), fmaf(P.y, g.y, fmaf(R.y, y.y, Q.y)), fmaf(P.z, g.z, fmaf(R.z, y.z, Q.z)),
                      fmaf(P.w, g.w, fmaf(R.w, y.w, Q.w)));
 }
 
 struct PwBwdArgs {
+  int dbg;
   const float* x; NormDev in; int has_in;     // A operand of the weight gradient: x, or the block of `in`
   DyDev dy; const float* w; GoutDev go;
   int n, hw, cin, cout;
@@ -645,6 +684,7 @@ __device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem
     mask = a.dy.g_plain && a.dy.nd.drop_rate > 0.f;
     seed = a.dy.nd.seed + (a.dy.nd.seed_dev ? *a.dy.nd.seed_dev : 0ull);
   }
+  if (a.dbg == 1) return;
   auto store_tiles = [&](int it) {
     const int k = (it * KS + grp) * BK + kq * 4;
 #pragma unroll
@@ -669,6 +709,7 @@ __device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem
     if (it * KS + grp < nk) mma_ktile<BM, BN, WM, WN, false, true>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
+  if (a.dbg == 2) { if (acc[0][0][0] == 123.456f) a.go.out[0] = 0.f; return; }
   sum_groups<KS, 1>(&acc[0][0], smem_all, grp, lt);
   // ---- epilogue (group 0): d (+ addends) -> out; with a GroupNorm block behind the conv's input: g, its rows and planes
   const int rbase = m0 + wm * 32 + 4 * half;
@@ -711,7 +752,7 @@ __device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem
       const float xh = (yv[r] - o_mean) * o_rstd;
       const float z = fmaf(xh, o_gam, o_bet);
       float g = d[r] * actgrad_of<ACT_OUT>(z, nd.act);
-      if (drop) g = (rn::uniform01(oseed, (uint64_t)row * ND + col) >= nd.drop_rate) ? g * nd.keep_scale : 0.f;
+      if (drop) g *= keep1(oseed, (uint64_t)row * ND + col, nd.drop_rate, nd.keep_scale);
       if (!cok) g = 0.f;
       s1[0] += g; s2[0] = fmaf(g, xh, s2[0]);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(go.store_plain ? d[r] : g), ro, cok ? ((unsigned)row * ND + col) * 4u : OOB, 0, 0);
@@ -796,6 +837,7 @@ __device__ __forceinline__ void mb_pw_wgrad_body(const PwBwdArgs& a, float* smem
     drop_in = a.in.drop_rate > 0.f;
     seed_in = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
   }
+  if (a.dbg == 1) return;
   auto store_tiles = [&](int it) {
     const int kt = it * KS + grp;
 #pragma unroll
@@ -835,6 +877,7 @@ __device__ __forceinline__ void mb_pw_wgrad_body(const PwBwdArgs& a, float* smem
     if (it * KS + grp < nk) mma_ktile<BM, BN, WM, WN, true, false>(As, Bs, acc, wm, wn, lane);
     __syncthreads();
   }
+  if (a.dbg == 2) { if (acc[0][0][0] == 123.456f) a.slab[0] = 0.f; return; }
   sum_groups<KS, 1>(&acc[0][0], smem_all, grp, lt);
   if (grp == 0) store_tile<BM, BN, WM, WN>(acc, a.slab + (size_t)split * KI * NO, nullptr, m0, n0, KI, NO, NO, wm, wn, lane);
 }
@@ -859,6 +902,7 @@ __global__ __launch_bounds__(T* KS) void mb_pw_bwd_kernel(const PwBwdArgs a) {
 // tile's pixels -> g1 = d act'(z1) mask with its rows / planes; weight-gradient partial sums over the outputs whose window
 // origin lies in the tile (a disjoint cover of the outputs) -> partial[block row][9][c].
 struct DwBwdArgs {
+  int dbg;
   NormDev in; DyDev dy; const float* w; float* partial; GoutDev go;
   int n, h, wd, c, stride, oh, ow, pad_t, pad_l;
   int th, tw, tiles_h, tiles_w, sw, nslab;
@@ -894,24 +938,25 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
   const GroupPre gp_d = prefetch_groups(a.dy.nd, sample, g0, ng, tid);
   const int ay0 = ih0 - a.pad_t, ax0 = iw0 - a.pad_l;
   const int atotal = aph * apw * SQ;
-  const float* __restrict__ xs = a.in.y + (size_t)sample * a.h * a.wd * C + c0;
+  const __amdgpu_buffer_rsrc_t xs = make_rsrc(a.in.y + (size_t)sample * a.h * a.wd * C + c0, (unsigned)(a.h * a.wd * C - c0) * 4u);
   float4 av[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
     const PatchElem e = patch_elem(tid + j * T, atotal, SQ, apw, ay0, ax0, a.h, a.wd);
-    av[j] = *reinterpret_cast<const float4*>(xs + (size_t)e.pix * C + e.q * 4);
+    av[j] = Vec<4>::load(xs, (e.live && e.inside) ? ((unsigned)e.pix * C + e.q * 4) * 4u : OOB);
   }
   // dy patch: output rows [oy0, +oph), cols [ox0, +opw): every output that touches the tile
   const int oy0 = floor_div(ih0 + a.pad_t - 2 + (s - 1), s), ox0 = floor_div(iw0 + a.pad_l - 2 + (s - 1), s);
   const int dtotal = a.oph * a.opw * SQ;
-  const float* __restrict__ gs = a.dy.g + (size_t)sample * a.oh * a.ow * C + c0;
-  const float* __restrict__ ys = a.dy.nd.y + (size_t)sample * a.oh * a.ow * C + c0;
+  const __amdgpu_buffer_rsrc_t gs = make_rsrc(a.dy.g + (size_t)sample * a.oh * a.ow * C + c0, (unsigned)(a.oh * a.ow * C - c0) * 4u);
+  const __amdgpu_buffer_rsrc_t ys = make_rsrc(a.dy.nd.y + (size_t)sample * a.oh * a.ow * C + c0, (unsigned)(a.oh * a.ow * C - c0) * 4u);
   float4 gv[NP], yv2[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
     const PatchElem e = patch_elem(tid + j * T, dtotal, SQ, a.opw, oy0, ox0, a.oh, a.ow);
-    gv[j] = *reinterpret_cast<const float4*>(gs + (size_t)e.pix * C + e.q * 4);
-    yv2[j] = *reinterpret_cast<const float4*>(ys + (size_t)e.pix * C + e.q * 4);
+    const unsigned off = (e.live && e.inside) ? ((unsigned)e.pix * C + e.q * 4) * 4u : OOB;
+    gv[j] = Vec<4>::load(gs, off);
+    yv2[j] = Vec<4>::load(ys, off);
   }
   const int lanes = T / SQ, q4 = tid % SQ, pl = tid / SQ;
   const bool active = pl < lanes;
@@ -927,6 +972,7 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
     tabA[256 + i] = gstat[g][0]; tabA[384 + i] = gstat[g][1];
   }
   __syncthreads();
+  if (a.dbg == 1) { if (av[0].x == 123.456f && gv[0].x == 1.f && yv2[0].x == 1.f && wv[0].x == 1.f) a.go.out[0] = 0.f; return; }
   const bool drop = a.in.drop_rate > 0.f;
   const uint64_t seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
   const uint64_t samp_off = (uint64_t)sample * a.h * a.wd * C;
@@ -950,6 +996,7 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
     }
   }
   __syncthreads();
+  if (a.dbg == 2) { if (dsm[tid] == 123.456f) a.go.out[0] = 0.f; return; }
   // ---- data gradient of the tile's pixels, then g1 and its sums
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (active) {
@@ -984,14 +1031,13 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
         const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, dd[4] = {acc.x, acc.y, acc.z, acc.w};
         const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
         const float mnv[4] = {mn.x, mn.y, mn.z, mn.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
-        float g[4];
-        const uint64_t e0 = samp_off + (uint64_t)(ih * a.wd + iw) * C + c0 + q4 * 4;
+        float g[4], mk[4] = {1.f, 1.f, 1.f, 1.f};
+        if (drop) keep4(seed, samp_off + (uint64_t)(ih * a.wd + iw) * C + c0 + q4 * 4, a.in.drop_rate, a.in.keep_scale, mk);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float z = fmaf(yy[j], scv[j], shv[j]);
           const float xh = (yy[j] - mnv[j]) * rsv[j];
-          float t = dd[j] * actgrad_of<ACT>(z, a.in.act);
-          if (drop) t = (rn::uniform01(seed, e0 + (uint64_t)j) >= a.in.drop_rate) ? t * a.in.keep_scale : 0.f;
+          const float t = dd[j] * actgrad_of<ACT>(z, a.in.act) * mk[j];
           g[j] = t;
           s1[j] += t; s2[j] = fmaf(t, xh, s2[j]);
         }
@@ -999,6 +1045,7 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
       }
     }
   }
+  if (a.dbg == 3) return;
   // ---- weight-gradient partial sums over the owned outputs (window origin inside the tile)
   float4 wacc[9];
 #pragma unroll
@@ -1023,6 +1070,7 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
       }
     }
   }
+  if (a.dbg == 4) { if (wacc[0].x == 123.456f && s1[0] == 1.f) a.go.out[0] = 0.f; return; }
   __syncthreads();                                 // the patches are dead: their LDS becomes the reduction scratch
   // one exchange for all nine taps and both statistics: red[thread][36 + 8], then (tap, channel) outputs over the pixel lanes
   constexpr int RW = 44;
@@ -1064,6 +1112,11 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
+int dbg_word(const char* kernel) {      // RN_MB_DBG="<kernel>:<phase>" (pwf, dwf, pwb, dwb): stop that kernel after a phase (timing aid; results invalid)
+  const char* e = getenv("RN_MB_DBG");
+  if (!e || strncmp(e, kernel, 3) != 0 || e[3] != ':') return 0;
+  return atoi(e + 4);
+}
 int fill_norm(const rn_mb_norm* s, NormDev* d, int n, bool need_rows, const char* what) {
   RN_CHECK_ARG(s && s->y && s->mean && s->rstd && s->gamma && s->beta, "%s: null pointer in rn_mb_norm", what);
   RN_CHECK_ARG(s->c >= 4 && s->groups >= 1 && s->c % s->groups == 0, "%s: c=%d groups=%d", what, s->c, s->groups);
@@ -1084,19 +1137,29 @@ int fill_norm(const rn_mb_norm* s, NormDev* d, int n, bool need_rows, const char
   return RN_OK;
 }
 
-// tile shape of the pointwise kernels: 0 = 64x64, 1 = 128x32, 2 = 128x64
-struct PwCfg { int id, bm, bn; };
-PwCfg pw_cfg(int n, int hw, int ncols) {
+// tile shape of the pointwise forward: 0 = 64x64, 1 = 128x32, 2 = 128x64, 3 = 32x32 (one wave per split-K group); ks = groups
+// of waves that share a block's K-tiles.  A function of the shape alone: the row layout (rn_mb_pointwise_rows) follows it.
+struct PwCfg { int id, bm, bn, ks; };
+PwCfg pw_cfg(int n, int hw, int kdim, int ncols) {
+  static const bool no_ks = getenv("RN_MB_NO_SPLITK") != nullptr;
+  static const bool no_t32 = getenv("RN_MB_NO_TILE32") != nullptr;
   if (const char* f = getenv("RN_MB_PW_CFG")) {  // tuning aid
     const int c = atoi(f);
-    if (c == 1 && hw % 128 == 0) return {1, 128, 32};
-    if (c == 2 && hw % 128 == 0) return {2, 128, 64};
-    if (c == 0) return {0, 64, 64};
+    if (c == 1 && hw % 128 == 0) return {1, 128, 32, 1};
+    if (c == 2 && hw % 128 == 0) return {2, 128, 64, 1};
+    if (c == 0) return {0, 64, 64, 1};
   }
   const long m = (long)n * hw;
-  if (hw % 128 == 0 && ncols <= 32 && m / 128 >= 128) return {1, 128, 32};
-  if (hw % 128 == 0 && hw > 4096) return {2, 128, 64};       // large maps: fewer rows for the consumers to merge
-  return {0, 64, 64};
+  if (hw % 128 == 0 && ncols <= 32 && m / 128 >= 128) return {1, 128, 32, 1};
+  if (hw % 128 == 0 && hw > 4096) return {2, 128, 64, 1};       // large maps: fewer rows for the consumers to merge
+  // few output tiles with a long K (the small maps): groups of waves share the K-tiles, 32 x 32 tiles give more blocks
+  const long blocks64 = m / 64 * rn::ceil_div(ncols, 64);
+  const int nkt = rn::ceil_div(kdim, BK);
+  if (blocks64 <= 96 && nkt >= 4 && !no_ks) {
+    if (!no_t32) return {3, 32, 32, nkt >= 16 ? 8 : 4};
+    return {0, 64, 64, 4};
+  }
+  return {0, 64, 64, 1};
 }
 
 // channel slab of the depthwise kernels: whole groups (of both GroupNorms around it: same channel count, same rule) and
@@ -1140,7 +1203,7 @@ size_t dw_lds_bytes(const DwPlan& p) {
 
 extern "C" size_t rn_mb_pointwise_rows(int n, int hw, int cin, int cout, int groups, rn_mb_rows* layout) {
   if (n < 1 || hw < 1 || cin < 4 || cout < 4 || groups < 1 || cout % groups) return 0;
-  const PwCfg c = pw_cfg(n, hw, cout);
+  const PwCfg c = pw_cfg(n, hw, cin, cout);
   if (hw % c.bm) return 0;
   const int R = hw / c.bm, W = groups + rn::ceil_div(cout, c.bn);
   if (R > RMAX || cout / groups > c.bn) return 0;
@@ -1156,13 +1219,14 @@ extern "C" int rn_mb_pointwise_fwd(const float* x, const rn_mb_norm* in, const f
   RN_UNSUPPORTED((double)n * hw * cin >= 536870912.0 || (double)n * hw * cout >= 536870912.0, "mb pointwise fwd: tensor >= 2 GiB");
   RN_CHECK_ARG(in || (!residual && !materialise), "mb pointwise fwd: residual / materialise come with `in`");
   PwFwdArgs a = {};
+  a.dbg = dbg_word("pwf");
   a.x = x; a.res = residual; a.mat = materialise; a.w = w; a.y = y;
   a.n = n; a.hw = hw; a.cin = cin; a.cout = cout;
   if (in) {
     if (int e = fill_norm(in, &a.in, n, true, "mb pointwise fwd")) return e;
     RN_CHECK_ARG(in->c == cin, "mb pointwise fwd: in->c %d != cin %d", in->c, cin);
   }
-  const PwCfg c = pw_cfg(n, hw, cout);
+  const PwCfg c = pw_cfg(n, hw, cin, cout);
   RN_UNSUPPORTED(hw % c.bm, "mb pointwise fwd: %d pixels per sample, tile height %d", hw, c.bm);
   a.tiles_n = rn::ceil_div(cout, c.bn);
   if (stat_out) {
@@ -1177,21 +1241,23 @@ extern "C" int rn_mb_pointwise_fwd(const float* x, const rn_mb_norm* in, const f
   const long blocks = (long)n * hw / c.bm * a.tiles_n;
   const dim3 grid((unsigned)blocks);
   hipStream_t st = (hipStream_t)stream;
-  // few output tiles with a long K (the small maps' linear convs): four groups of waves share the K-tiles of a block
-  static const bool no_ks = getenv("RN_MB_NO_SPLITK") != nullptr;
-  const bool ks4 = in && c.id == 0 && blocks <= 96 && rn::ceil_div(cin, BK) >= 4 && !no_ks;
 #define RN_PW(BM_, BN_, WM_, WN_, KS_)                                                                                \
   do {                                                                                                                \
-    if (!in) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, false, 0, 1>), grid, dim3(T), 0, st, a);         \
-    else if (in->act == RN_ACT_NONE) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_NONE, KS_>), grid, dim3(T * KS_), 0, st, a); \
-    else if (in->act == RN_ACT_ELU) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_ELU, KS_>), grid, dim3(T * KS_), 0, st, a);   \
-    else hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, -1, KS_>), grid, dim3(T * KS_), 0, st, a);     \
+    constexpr int TB = WM_ * WN_ * 64 * KS_;                                                                          \
+    if (!in) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, false, 0, KS_>), grid, dim3(TB), 0, st, a);      \
+    else if (in->act == RN_ACT_NONE) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_NONE, KS_>), grid, dim3(TB), 0, st, a); \
+    else if (in->act == RN_ACT_ELU) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_ELU, KS_>), grid, dim3(TB), 0, st, a);   \
+    else hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, -1, KS_>), grid, dim3(TB), 0, st, a);          \
   } while (0)
   switch (c.id) {
     case 1: RN_PW(128, 32, 4, 1, 1); break;
     case 2: RN_PW(128, 64, 2, 2, 1); break;
+    case 3:
+      if (c.ks == 8) RN_PW(32, 32, 1, 1, 8);
+      else RN_PW(32, 32, 1, 1, 4);
+      break;
     default:
-      if (ks4) RN_PW(64, 64, 2, 2, 4);
+      if (c.ks == 4) RN_PW(64, 64, 2, 2, 4);
       else RN_PW(64, 64, 2, 2, 1);
       break;
   }
@@ -1217,6 +1283,7 @@ extern "C" int rn_mb_depthwise_fwd(const rn_mb_norm* in, const float* w, float* 
                                    int stat_groups, rn_stream_t stream) {
   RN_CHECK_ARG(in && w && y && n >= 1 && h >= 1 && wd >= 1 && (stride == 1 || stride == 2), "mb depthwise fwd: bad argument");
   DwFwdArgs a = {};
+  a.dbg = dbg_word("dwf");
   if (int e = fill_norm(in, &a.in, n, true, "mb depthwise fwd")) return e;
   const int c = in->c;
   RN_UNSUPPORTED((double)n * h * wd * c >= 536870912.0, "mb depthwise fwd: tensor >= 2 GiB");
@@ -1364,6 +1431,7 @@ extern "C" int rn_mb_pointwise_bwd(const float* x, const rn_mb_norm* in, const r
   RN_UNSUPPORTED(hw % PB, "mb pointwise bwd: %d pixels per sample, tile height %d", hw, PB);
   RN_UNSUPPORTED((double)n * hw * cin >= 536870912.0 || (double)n * hw * cout >= 536870912.0, "mb pointwise bwd: tensor >= 2 GiB");
   PwBwdArgs a = {};
+  a.dbg = dbg_word("pwb");
   a.x = x; a.w = w; a.n = n; a.hw = hw; a.cin = cin; a.cout = cout;
   if (in) {
     if (int e = fill_norm(in, &a.in, n, false, "mb pointwise bwd")) return e;
@@ -1423,6 +1491,7 @@ extern "C" int rn_mb_depthwise_bwd(const rn_mb_norm* in, const rn_mb_dy* dy, con
                "mb depthwise bwd: bad argument");
   RN_CHECK_ARG(!dy->dy && !gout->store_plain && !gout->add1 && !gout->add2, "mb depthwise bwd: dy comes as (g, norm, grows); gout stores g");
   DwBwdArgs a = {};
+  a.dbg = dbg_word("dwb");
   if (int e = fill_norm(in, &a.in, n, false, "mb depthwise bwd")) return e;
   a.in.st.rows = nullptr;
   const int c = in->c;
