@@ -275,9 +275,12 @@ struct PwFwdArgs {
 // maps' linear convs), each with its own operand tiles; the groups' accumulators are summed at the end.  The smallest maps
 // take 32 x 32 tiles with one wave per group: more blocks -- the operand transform (ELU, dropout mask: VALU work) and the
 // fp32 MFMAs of a 64 x 64 x 960 tile would keep ONE compute unit busy for 13 us while 230 others idle.
-template <int BM, int BN, int WM, int WN, bool NORM, int ACT, int KS>
+// NST register stages: the operand tiles of NST K-steps are in flight at once (a dependent round trip to memory costs
+// ~3 us here -- L2 is per XCD, data written by the previous kernel sits in another one -- an MFMA step 0.4 us).
+template <int BM, int BN, int WM, int WN, bool NORM, int ACT, int KS, int NST>
 __global__ __launch_bounds__(WM* WN * 64 * KS) void mb_pw_fwd_kernel(const PwFwdArgs a) {
   constexpr int TG = WM * WN * 64;
+  constexpr bool RES = NORM && ACT != RN_ACT_ELU && ACT != RN_ACT_RELU6 && ACT != RN_ACT_RELU;   // a residual comes with a linear block only
   static_assert(TG * KS >= T || !NORM, "the prologue needs 256 threads");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int KQ = BK / 4, A_RPP = TG / KQ, A_PASS = BM / A_RPP;
@@ -302,27 +305,27 @@ __global__ __launch_bounds__(WM* WN * 64 * KS) void mb_pw_fwd_kernel(const PwFwd
   const __amdgpu_buffer_rsrc_t xa = make_rsrc(asrc, (unsigned)M * K * 4u);
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.res ? a.res : asrc, (unsigned)M * K * 4u);
   const __amdgpu_buffer_rsrc_t wb = make_rsrc(a.w, (unsigned)K * N * 4u);
-  const bool has_res = NORM && a.res != nullptr;
+  const bool has_res = RES && a.res != nullptr;
 
   const int kq = lt % KQ, arow = lt / KQ;
   const int nq = lt % NQ;
   const int bcol = n0 + nq * 4;
   const unsigned boff0 = bcol < N ? ((unsigned)(lt / NQ) * N + bcol) * 4u : OOB;
   const int nk = (K + BK - 1) / BK, nit = (nk + KS - 1) / KS;
-  float4 ra[A_PASS], rr[A_PASS], rb[B_PASS];
-  auto load_tiles = [&](int it) {
+  float4 ra[NST][A_PASS], rr[RES ? NST : 1][A_PASS], rb[NST][B_PASS];
+  auto load_tiles = [&](int it, const int st) {
     const int kt = it * KS + grp;
     const int k = kt * BK + kq * 4;
     const bool kok = k < K;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       const unsigned off = kok ? ((unsigned)(m0 + arow + i * A_RPP) * K + k) * 4u : OOB;
-      ra[i] = Vec<4>::load(xa, off);
-      if (NORM) rr[i] = Vec<4>::load(xr, has_res ? off : OOB);
+      ra[st][i] = Vec<4>::load(xa, off);
+      if (RES) rr[st][i] = Vec<4>::load(xr, has_res ? off : OOB);
     }
     const unsigned bo = (kt < nk && boff0 != OOB) ? boff0 + (unsigned)kt * BK * N * 4u : OOB;
 #pragma unroll
-    for (int j = 0; j < B_PASS; ++j) rb[j] = Vec<4>::load(wb, bo == OOB ? OOB : bo + (unsigned)j * B_RPP * N * 4u);
+    for (int j = 0; j < B_PASS; ++j) rb[st][j] = Vec<4>::load(wb, bo == OOB ? OOB : bo + (unsigned)j * B_RPP * N * 4u);
   };
   ChanPre<NORM ? KMAX / T : 1> pre;
   GroupPre gpre = {0.f, 1.f};
@@ -330,7 +333,9 @@ __global__ __launch_bounds__(WM* WN * 64 * KS) void mb_pw_fwd_kernel(const PwFwd
     prefetch_chan(a.in.gamma, a.in.beta, 0, K, tid, pre);
     gpre = prefetch_groups(a.in, sample, 0, a.in.groups, tid);
   }
-  load_tiles(0);
+#pragma unroll
+  for (int st = 0; st < NST; ++st)
+    if (st < nit) load_tiles(st, st);
   uint64_t seed = 0;
   bool drop = false;
   if (NORM) {
@@ -342,18 +347,18 @@ __global__ __launch_bounds__(WM* WN * 64 * KS) void mb_pw_fwd_kernel(const PwFwd
   }
   if (a.dbg == 1) return;
   const bool write_mat = NORM && a.mat != nullptr && tile_n == 0;
-  auto store_tiles = [&](int it) {
+  auto store_tiles = [&](int it, const int st) {
     const int k = (it * KS + grp) * BK + kq * 4;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
-      float4 v = ra[i];
+      float4 v = ra[st][i];
       if (NORM) {
         if (k < K) {
           const int m = m0 + arow + i * A_RPP;
           const float4 sc = *reinterpret_cast<const float4*>(&tab[k]);
           const float4 sh = *reinterpret_cast<const float4*>(&tab[KMAX + k]);
           v = norm_act_drop<ACT>(v, sc, sh, a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed, (uint64_t)m * K + k);
-          v.x += rr[i].x; v.y += rr[i].y; v.z += rr[i].z; v.w += rr[i].w;
+          if (RES) { v.x += rr[st][i].x; v.y += rr[st][i].y; v.z += rr[st][i].z; v.w += rr[st][i].w; }
           if (write_mat) *reinterpret_cast<float4*>(a.mat + (size_t)m * K + k) = v;
         } else {
           v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -362,17 +367,23 @@ __global__ __launch_bounds__(WM* WN * 64 * KS) void mb_pw_fwd_kernel(const PwFwd
       *reinterpret_cast<float4*>(&As[(arow + i * A_RPP) * LDK + kq * 4]) = v;
     }
 #pragma unroll
-    for (int j = 0; j < B_PASS; ++j) *reinterpret_cast<float4*>(&Bs[(lt / NQ + j * B_RPP) * BN + nq * 4]) = rb[j];
+    for (int j = 0; j < B_PASS; ++j) *reinterpret_cast<float4*>(&Bs[(lt / NQ + j * B_RPP) * BN + nq * 4]) = rb[st][j];
   };
 
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  for (int it = 0; it < nit; ++it) {
-    store_tiles(it);
-    __syncthreads();
-    if (it + 1 < nit) load_tiles(it + 1);
-    if (it * KS + grp < nk) mma_ktile<BM, BN, WM, WN, false, false>(As, Bs, acc, wm, wn, lane);
-    __syncthreads();
+  for (int it0 = 0; it0 < nit; it0 += NST) {
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int it = it0 + st;
+      if (it < nit) {                       // (block-uniform)
+        store_tiles(it, st);
+        __syncthreads();
+        if (it + NST < nit) load_tiles(it + NST, st);
+        if (it * KS + grp < nk) mma_ktile<BM, BN, WM, WN, false, false>(As, Bs, acc, wm, wn, lane);
+        __syncthreads();
+      }
+    }
   }
   if (a.dbg == 2) { if (acc[0][0][0] == 123.456f) a.y[0] = 0.f; return; }
   sum_groups<KS, TM * TN, TG>(&acc[0][0], smem, grp, lt);
@@ -617,16 +628,16 @@ struct PwBwdArgs {
   int w_tiles_m, w_tiles_n, chunk, sps;       // weight gradient: tiles over (cin, cout), pixels per split, splits per sample
   float* slab;                                // [n * sps][cin][cout]
 };
-constexpr int PB = 64;                        // both halves use 64x64 tiles, 2 x 2 waves (x KS groups)
-constexpr int PW_LDS = 2 * PB * LDK;          // operand floats per group (dgrad: two k-contiguous tiles; wgrad needs 2 * BK * PB, less)
+// both halves use PB x PB tiles: 64 (2 x 2 waves per group) or, on the smallest maps, 32 (one wave per group; more blocks)
+constexpr int pw_lds(int pb) { return 2 * pb * LDK; }   // operand floats per group (dgrad: two k-contiguous tiles; wgrad needs 2 * BK * pb, less)
 
 // data gradient  d[M, cin] = dy[M, cout] W^T  and what rn_mb_gout asks for
-template <int ACT_OUT, int KS>
+template <int ACT_OUT, int PB, int KS, int NST>
 __device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem_all, float* tabD, float (*gstat)[2], float (*gc)[2], int blk) {
-  constexpr int BM = PB, BN = PB, WM = 2, WN = 2, TM = 1, TN = 1;
-  constexpr int KQ = BK / 4, RPP = T / KQ, A_PASS = BM / RPP, B_PASS = BN / RPP;
-  const int tid = threadIdx.x, grp = tid / T, lt = tid % T, lane = lt & 63, wave = lt >> 6;
-  float* As = smem_all + grp * PW_LDS;
+  constexpr int BM = PB, BN = PB, WM = PB / 32, WN = PB / 32, TM = 1, TN = 1, TG = WM * WN * 64;
+  constexpr int KQ = BK / 4, RPP = TG / KQ, A_PASS = BM / RPP, B_PASS = BN / RPP;
+  const int tid = threadIdx.x, grp = tid / TG, lt = tid % TG, lane = lt & 63, wave = lt >> 6;
+  float* As = smem_all + grp * pw_lds(PB);
   float* Bs = As + BM * LDK;
   const int wm = wave / WN, wn = wave % WN;
   const int bid = rn::xcd_remap(blk, a.dblocks);
@@ -646,18 +657,18 @@ __device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem
     browoff[j] = ci < ND ? (unsigned)ci * KD * 4u : OOB;
   }
   const int nk = (KD + BK - 1) / BK, nit = (nk + KS - 1) / KS;
-  float4 ra[A_PASS], ry[A_PASS], rb[B_PASS];
-  auto load_tiles = [&](int it) {
+  float4 ra[NST][A_PASS], ry[NST][A_PASS], rb[NST][B_PASS];
+  auto load_tiles = [&](int it, const int st) {
     const int k = (it * KS + grp) * BK + kq * 4;
     const bool kok = k < KD;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       const unsigned off = kok ? ((unsigned)(m0 + r0 + i * RPP) * KD + k) * 4u : OOB;
-      ra[i] = Vec<4>::load(ga, off);
-      ry[i] = Vec<4>::load(ya, plain ? OOB : off);
+      ra[st][i] = Vec<4>::load(ga, off);
+      ry[st][i] = Vec<4>::load(ya, plain ? OOB : off);
     }
 #pragma unroll
-    for (int j = 0; j < B_PASS; ++j) rb[j] = Vec<4>::load(wb, (kok && browoff[j] != OOB) ? browoff[j] + (unsigned)k * 4u : OOB);
+    for (int j = 0; j < B_PASS; ++j) rb[st][j] = Vec<4>::load(wb, (kok && browoff[j] != OOB) ? browoff[j] + (unsigned)k * 4u : OOB);
   };
   // everything from memory first: the dy table's gamma and statistics, the epilogue's per-column constants, the first tiles
   ChanPre<KMAX / T> pre;
@@ -676,7 +687,9 @@ __device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem
     o_mean = go.nd.mean[sample * go.nd.groups + og]; o_rstd = go.nd.rstd[sample * go.nd.groups + og];
     o_gam = go.nd.gamma[cc]; o_bet = go.nd.beta[cc];
   }
-  load_tiles(0);
+#pragma unroll
+  for (int st = 0; st < NST; ++st)
+    if (st < nit) load_tiles(st, st);
   bool mask = false;
   uint64_t seed = 0;
   if (!plain) {
@@ -685,32 +698,38 @@ __device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem
     seed = a.dy.nd.seed + (a.dy.nd.seed_dev ? *a.dy.nd.seed_dev : 0ull);
   }
   if (a.dbg == 1) return;
-  auto store_tiles = [&](int it) {
+  auto store_tiles = [&](int it, const int st) {
     const int k = (it * KS + grp) * BK + kq * 4;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
-      float4 v = ra[i];
+      float4 v = ra[st][i];
       if (!plain) {
-        if (k < KD) v = dy_of(v, ry[i], tabD, KMAX, k, mask, a.dy.nd.drop_rate, a.dy.nd.keep_scale, seed,
+        if (k < KD) v = dy_of(v, ry[st][i], tabD, KMAX, k, mask, a.dy.nd.drop_rate, a.dy.nd.keep_scale, seed,
                               (uint64_t)(m0 + r0 + i * RPP) * KD + k);
         else v = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       *reinterpret_cast<float4*>(&As[(r0 + i * RPP) * LDK + kq * 4]) = v;
     }
 #pragma unroll
-    for (int j = 0; j < B_PASS; ++j) *reinterpret_cast<float4*>(&Bs[(r0 + j * RPP) * LDK + kq * 4]) = rb[j];
+    for (int j = 0; j < B_PASS; ++j) *reinterpret_cast<float4*>(&Bs[(r0 + j * RPP) * LDK + kq * 4]) = rb[st][j];
   };
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  for (int it = 0; it < nit; ++it) {
-    store_tiles(it);
-    __syncthreads();
-    if (it + 1 < nit) load_tiles(it + 1);
-    if (it * KS + grp < nk) mma_ktile<BM, BN, WM, WN, false, true>(As, Bs, acc, wm, wn, lane);
-    __syncthreads();
+  for (int it0 = 0; it0 < nit; it0 += NST) {
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int it = it0 + st;
+      if (it < nit) {
+        store_tiles(it, st);
+        __syncthreads();
+        if (it + NST < nit) load_tiles(it + NST, st);
+        if (it * KS + grp < nk) mma_ktile<BM, BN, WM, WN, false, true>(As, Bs, acc, wm, wn, lane);
+        __syncthreads();
+      }
+    }
   }
   if (a.dbg == 2) { if (acc[0][0][0] == 123.456f) a.go.out[0] = 0.f; return; }
-  sum_groups<KS, 1>(&acc[0][0], smem_all, grp, lt);
+  sum_groups<KS, 1, TG>(&acc[0][0], smem_all, grp, lt);
   // ---- epilogue (group 0): d (+ addends) -> out; with a GroupNorm block behind the conv's input: g, its rows and planes
   const int rbase = m0 + wm * 32 + 4 * half;
   const __amdgpu_buffer_rsrc_t ro = make_rsrc(go.out, (unsigned)M * ND * 4u);
@@ -764,14 +783,14 @@ __device__ __forceinline__ void mb_pw_dgrad_body(const PwBwdArgs& a, float* smem
 }
 
 // weight gradient  dW[cin, cout] = A^T dy over one split's pixels (inside one sample) -> slab[split]
-template <int ACT_IN, int KS>
+template <int ACT_IN, int PB, int KS, int NST>
 __device__ __forceinline__ void mb_pw_wgrad_body(const PwBwdArgs& a, float* smem_all, float* tabA, float* tabD, float (*gstat)[2], float (*gc)[2],
                                                  int blk, int nblk) {
-  constexpr int BM = PB, BN = PB, WM = 2, WN = 2, TM = 1, TN = 1;
-  constexpr int MQ = BM / 4, A_RPP = T / MQ, A_PASS = BK / A_RPP;
-  constexpr int NQ = BN / 4, B_RPP = T / NQ, B_PASS = BK / B_RPP;
-  const int tid = threadIdx.x, grp = tid / T, lt = tid % T, lane = lt & 63, wave = lt >> 6;
-  float* As = smem_all + grp * PW_LDS;   // [BK][BM]  (pixel rows, cin contiguous)
+  constexpr int BM = PB, BN = PB, WM = PB / 32, WN = PB / 32, TM = 1, TN = 1, TG = WM * WN * 64;
+  constexpr int MQ = BM / 4, A_RPP = TG / MQ, A_PASS = BK / A_RPP;
+  constexpr int NQ = BN / 4, B_RPP = TG / NQ, B_PASS = BK / B_RPP;
+  const int tid = threadIdx.x, grp = tid / TG, lt = tid % TG, lane = lt & 63, wave = lt >> 6;
+  float* As = smem_all + grp * pw_lds(PB);   // [BK][BM]  (pixel rows, cin contiguous)
   float* Bs = As + BK * BM;              // [BK][BN]
   const int wm = wave / WN, wn = wave % WN;
   const int bid = rn::xcd_remap(blk, nblk);
@@ -792,21 +811,21 @@ __device__ __forceinline__ void mb_pw_wgrad_body(const PwBwdArgs& a, float* smem
   const int nq = lt % NQ, bcol = n0 + nq * 4;
   const bool bok = bcol < NO;
   const int nk = a.chunk / BK, nit = (nk + KS - 1) / KS;
-  float4 ra[A_PASS], rg[B_PASS], ry[B_PASS];
-  auto load_tiles = [&](int it) {
+  float4 ra[NST][A_PASS], rg[NST][B_PASS], ry[NST][B_PASS];
+  auto load_tiles = [&](int it, const int st) {
     const int kt = it * KS + grp;
     const bool tok = kt < nk;
 #pragma unroll
     for (int j = 0; j < A_PASS; ++j) {
       const int p = p0 + kt * BK + lt / MQ + j * A_RPP;
-      ra[j] = Vec<4>::load(xa, (aok && tok) ? ((unsigned)p * KI + acol) * 4u : OOB);
+      ra[st][j] = Vec<4>::load(xa, (aok && tok) ? ((unsigned)p * KI + acol) * 4u : OOB);
     }
 #pragma unroll
     for (int j = 0; j < B_PASS; ++j) {
       const int p = p0 + kt * BK + lt / NQ + j * B_RPP;
       const unsigned off = (bok && tok) ? ((unsigned)p * NO + bcol) * 4u : OOB;
-      rg[j] = Vec<4>::load(ga, off);
-      ry[j] = Vec<4>::load(ya, plain ? OOB : off);
+      rg[st][j] = Vec<4>::load(ga, off);
+      ry[st][j] = Vec<4>::load(ya, plain ? OOB : off);
     }
   };
   const int na = min(BM, KI - m0), nb = min(BN, NO - n0);
@@ -823,7 +842,9 @@ __device__ __forceinline__ void mb_pw_wgrad_body(const PwBwdArgs& a, float* smem
     ga0 = m0 / a.in.cpg; nga = (m0 + na - 1) / a.in.cpg - ga0 + 1;
     gp_a = prefetch_groups(a.in, sample, ga0, nga, tid);
   }
-  load_tiles(0);
+#pragma unroll
+  for (int st = 0; st < NST; ++st)
+    if (st < nit) load_tiles(st, st);
   bool mask = false, drop_in = false;
   uint64_t seed = 0, seed_in = 0;
   if (!plain) {
@@ -838,11 +859,11 @@ __device__ __forceinline__ void mb_pw_wgrad_body(const PwBwdArgs& a, float* smem
     seed_in = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
   }
   if (a.dbg == 1) return;
-  auto store_tiles = [&](int it) {
+  auto store_tiles = [&](int it, const int st) {
     const int kt = it * KS + grp;
 #pragma unroll
     for (int j = 0; j < A_PASS; ++j) {
-      float4 v = ra[j];
+      float4 v = ra[st][j];
       if (a.has_in) {
         if (aok && kt < nk) {
           const int p = p0 + kt * BK + lt / MQ + j * A_RPP;
@@ -856,11 +877,11 @@ __device__ __forceinline__ void mb_pw_wgrad_body(const PwBwdArgs& a, float* smem
     }
 #pragma unroll
     for (int j = 0; j < B_PASS; ++j) {
-      float4 v = rg[j];
+      float4 v = rg[st][j];
       if (!plain) {
         if (bok && kt < nk) {
           const int p = p0 + kt * BK + lt / NQ + j * B_RPP;
-          v = dy_of(v, ry[j], tabD, BN, nq * 4, mask, a.dy.nd.drop_rate, a.dy.nd.keep_scale, seed, (uint64_t)p * NO + bcol);
+          v = dy_of(v, ry[st][j], tabD, BN, nq * 4, mask, a.dy.nd.drop_rate, a.dy.nd.keep_scale, seed, (uint64_t)p * NO + bcol);
         } else {
           v = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -870,30 +891,43 @@ __device__ __forceinline__ void mb_pw_wgrad_body(const PwBwdArgs& a, float* smem
   };
   f32x16 acc[TM][TN];
   zero_acc<TM, TN>(acc);
-  for (int it = 0; it < nit; ++it) {
-    store_tiles(it);
-    __syncthreads();
-    if (it + 1 < nit) load_tiles(it + 1);
-    if (it * KS + grp < nk) mma_ktile<BM, BN, WM, WN, true, false>(As, Bs, acc, wm, wn, lane);
-    __syncthreads();
+  for (int it0 = 0; it0 < nit; it0 += NST) {
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int it = it0 + st;
+      if (it < nit) {
+        store_tiles(it, st);
+        __syncthreads();
+        if (it + NST < nit) load_tiles(it + NST, st);
+        if (it * KS + grp < nk) mma_ktile<BM, BN, WM, WN, true, false>(As, Bs, acc, wm, wn, lane);
+        __syncthreads();
+      }
+    }
   }
   if (a.dbg == 2) { if (acc[0][0][0] == 123.456f) a.slab[0] = 0.f; return; }
-  sum_groups<KS, 1>(&acc[0][0], smem_all, grp, lt);
+  sum_groups<KS, 1, TG>(&acc[0][0], smem_all, grp, lt);
   if (grp == 0) store_tile<BM, BN, WM, WN>(acc, a.slab + (size_t)split * KI * NO, nullptr, m0, n0, KI, NO, NO, wm, wn, lane);
 }
 
-// ACT_IN: activation of the weight gradient's A block (-2: plain x); ACT_OUT: activation of the block the data gradient enters
-template <int ACT_IN, int ACT_OUT, int KS>
-__global__ __launch_bounds__(T* KS) void mb_pw_bwd_kernel(const PwBwdArgs a) {
-  static_assert(PW_LDS * 4 >= (T + GMAX) * 16 && PW_LDS >= 3 * PB * 2 && PW_LDS >= 2 * BK * PB, "operand tiles double as scratch");
-  static_assert(KS == 1 || KS * PW_LDS >= (KS - 1) * 16 * T, "operand tiles double as the split-K exchange");
-  __shared__ __attribute__((aligned(16))) float smem[KS * PW_LDS];
+// ACT_IN: activation of the weight gradient's A block (-2: plain x); ACT_OUT: activation of the block the data gradient enters.
+// The two halves have their own tile size and split-K group count (same number of threads): on the smallest maps the data
+// gradient takes 32 x 32 tiles (more blocks: its reduction is long), the weight gradient keeps 64 x 64 (its output is large).
+template <int ACT_IN, int ACT_OUT, int DPB, int DKS, int WPB, int WKS>
+__global__ __launch_bounds__((DPB / 32) * (DPB / 32) * 64 * DKS) void mb_pw_bwd_kernel(const PwBwdArgs a) {
+  constexpr int DTG = (DPB / 32) * (DPB / 32) * 64, WTG = (WPB / 32) * (WPB / 32) * 64;
+  static_assert(DTG * DKS == WTG * WKS && DTG * DKS >= T, "both halves run in the same block size; the prologues need 256 threads");
+  constexpr int LDSF = DKS * pw_lds(DPB) > WKS * pw_lds(WPB) ? DKS * pw_lds(DPB) : WKS * pw_lds(WPB);
+  static_assert(LDSF * 4 >= (T + GMAX) * 16 && pw_lds(DPB) >= 3 * DPB * 2 && pw_lds(WPB) >= 2 * BK * WPB, "operand tiles double as scratch");
+  static_assert((DKS == 1 || DKS * pw_lds(DPB) >= (DKS - 1) * 16 * DTG) && (WKS == 1 || WKS * pw_lds(WPB) >= (WKS - 1) * 16 * WTG),
+                "operand tiles double as the split-K exchange");
+  __shared__ __attribute__((aligned(16))) float smem[LDSF];
   __shared__ __attribute__((aligned(16))) float tabD[3 * KMAX];
-  __shared__ __attribute__((aligned(16))) float tabA[2 * PB];
+  __shared__ __attribute__((aligned(16))) float tabA[2 * 64];
   __shared__ float gstat[GMAX][2];
   __shared__ float gc[GMAX][2];
-  if ((int)blockIdx.x < a.dblocks) mb_pw_dgrad_body<ACT_OUT, KS>(a, smem, tabD, gstat, gc, blockIdx.x);
-  else mb_pw_wgrad_body<(ACT_IN == -2 ? 0 : ACT_IN), KS>(a, smem, tabA, tabD, gstat, gc, (int)blockIdx.x - a.dblocks, (int)gridDim.x - a.dblocks);
+  constexpr int NST = 1;      // operand tiles in flight per thread (measured: 4 stages cost occupancy on the big maps and buy nothing on the small)
+  if ((int)blockIdx.x < a.dblocks) mb_pw_dgrad_body<ACT_OUT, DPB, DKS, NST>(a, smem, tabD, gstat, gc, blockIdx.x);
+  else mb_pw_wgrad_body<(ACT_IN == -2 ? 0 : ACT_IN), WPB, WKS, NST>(a, smem, tabA, tabD, gstat, gc, (int)blockIdx.x - a.dblocks, (int)gridDim.x - a.dblocks);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1241,24 +1275,25 @@ extern "C" int rn_mb_pointwise_fwd(const float* x, const rn_mb_norm* in, const f
   const long blocks = (long)n * hw / c.bm * a.tiles_n;
   const dim3 grid((unsigned)blocks);
   hipStream_t st = (hipStream_t)stream;
-#define RN_PW(BM_, BN_, WM_, WN_, KS_)                                                                                \
+#define RN_PW(BM_, BN_, WM_, WN_, KS_, NST_)                                                                              \
   do {                                                                                                                \
     constexpr int TB = WM_ * WN_ * 64 * KS_;                                                                          \
-    if (!in) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, false, 0, KS_>), grid, dim3(TB), 0, st, a);      \
-    else if (in->act == RN_ACT_NONE) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_NONE, KS_>), grid, dim3(TB), 0, st, a); \
-    else if (in->act == RN_ACT_ELU) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_ELU, KS_>), grid, dim3(TB), 0, st, a);   \
-    else hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, -1, KS_>), grid, dim3(TB), 0, st, a);          \
+    if (!in) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, false, 0, KS_, NST_>), grid, dim3(TB), 0, st, a);      \
+    else if (in->act == RN_ACT_NONE) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_NONE, KS_, NST_>), grid, dim3(TB), 0, st, a); \
+    else if (in->act == RN_ACT_ELU) hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, RN_ACT_ELU, KS_, NST_>), grid, dim3(TB), 0, st, a);   \
+    else hipLaunchKernelGGL((mb_pw_fwd_kernel<BM_, BN_, WM_, WN_, true, -1, KS_, NST_>), grid, dim3(TB), 0, st, a);          \
   } while (0)
   switch (c.id) {
-    case 1: RN_PW(128, 32, 4, 1, 1); break;
-    case 2: RN_PW(128, 64, 2, 2, 1); break;
+    // (register stages: measured, more than one tile in flight per thread buys nothing here and costs occupancy on the big maps)
+    case 1: RN_PW(128, 32, 4, 1, 1, 1); break;
+    case 2: RN_PW(128, 64, 2, 2, 1, 1); break;
     case 3:
-      if (c.ks == 8) RN_PW(32, 32, 1, 1, 8);
-      else RN_PW(32, 32, 1, 1, 4);
+      if (c.ks == 8) RN_PW(32, 32, 1, 1, 8, 2);
+      else RN_PW(32, 32, 1, 1, 4, 2);
       break;
     default:
-      if (c.ks == 4) RN_PW(64, 64, 2, 2, 4);
-      else RN_PW(64, 64, 2, 2, 1);
+      if (c.ks == 4) RN_PW(64, 64, 2, 2, 4, 1);
+      else RN_PW(64, 64, 2, 2, 1, 1);
       break;
   }
 #undef RN_PW
@@ -1363,16 +1398,25 @@ int fill_gout(const rn_mb_gout* s, GoutDev* d, int n, int channels, const rn_mb_
   d->planes = s->planes; d->plane_stride = (long)n * want.rows_per_sample * channels;
   return RN_OK;
 }
-// intra-block split-K of the pointwise backward: few data-gradient tiles with a long reduction (the small maps)
-int pw_bwd_ks(int n, int hw, int cin, int cout) {
+// tile sizes and intra-block split-K of the pointwise backward's two halves: few data-gradient tiles with a long reduction
+// (the small maps) take 32 x 32 tiles and several groups of waves per block.  A function of the shape alone (the row
+// layout follows the data gradient's tile).
+struct PwBwdCfg { int dpb, dks, wpb, wks; };
+PwBwdCfg pw_bwd_cfg(int n, int hw, int cin, int cout) {
   static const bool no_ks = getenv("RN_MB_NO_SPLITK") != nullptr;
-  const long dblocks = (long)n * hw / PB * rn::ceil_div(cin, PB);
-  return (!no_ks && dblocks <= 96 && rn::ceil_div(cout, BK) >= 4) ? 4 : 1;
+  static const bool no_t32 = getenv("RN_MB_NO_TILE32") != nullptr;
+  const long dblocks = (long)n * hw / 64 * rn::ceil_div(cin, 64);
+  const int nkt = rn::ceil_div(cout, BK);
+  if (!no_ks && dblocks <= 96 && nkt >= 4) {
+    if (no_t32) return {64, 4, 64, 4};
+    return nkt >= 16 ? PwBwdCfg{32, 8, 64, 2} : PwBwdCfg{32, 4, 64, 1};
+  }
+  return {64, 1, 64, 1};
 }
 // weight-gradient split of the pointwise backward: pixels per split (divides hw, multiple of BK) and splits per sample;
 // a block (ks groups) reduces >= 128 ks pixels -- every block pays for its coefficient tables once
-void pw_wgrad_plan(int n, int hw, int cin, int cout, int ks, int* chunk, int* sps) {
-  const int tiles = rn::ceil_div(cin, PB) * rn::ceil_div(cout, PB);
+void pw_wgrad_plan(int n, int hw, int cin, int cout, int pb, int ks, int* chunk, int* sps) {
+  const int tiles = rn::ceil_div(cin, pb) * rn::ceil_div(cout, pb);
   int want = rn::ceil_div(384, tiles * n);             // splits per sample for ~384 blocks
   if (const char* f = getenv("RN_MB_WGRAD_SPS")) { if (atoi(f) > 0) want = atoi(f); }   // tuning aid
   const int unit = 128 * ks;
@@ -1408,16 +1452,18 @@ size_t dw_bwd_lds_bytes(const DwBwdPlan& p) {
 }  // namespace
 
 extern "C" size_t rn_mb_pointwise_bwd_rows(int n, int hw, int cin, int cout, int groups, rn_mb_rows* layout) {
-  if (n < 1 || hw < 1 || cin < 4 || cout < 4 || groups < 1 || cin % groups || hw % PB) return 0;
-  const int R = hw / PB, W = groups + rn::ceil_div(cin, PB);
-  if (R > RMAX || cin / groups > PB) return 0;
-  if (layout) { layout->rows_per_sample = R; layout->width = W; layout->bn = PB; }
+  if (n < 1 || hw < 1 || cin < 4 || cout < 4 || groups < 1 || cin % groups || hw % 64) return 0;
+  const int pb = pw_bwd_cfg(n, hw, cin, cout).dpb;
+  const int R = hw / pb, W = groups + rn::ceil_div(cin, pb);
+  if (R > RMAX || cin / groups > pb) return 0;
+  if (layout) { layout->rows_per_sample = R; layout->width = W; layout->bn = pb; }
   return (size_t)n * R * W * 8;
 }
 extern "C" size_t rn_mb_pointwise_bwd_workspace(int n, int hw, int cin, int cout) {
   if (n < 1 || hw < 64 || hw % 64 || cin < 4 || cout < 4) return 0;
   int chunk, sps;
-  pw_wgrad_plan(n, hw, cin, cout, pw_bwd_ks(n, hw, cin, cout), &chunk, &sps);
+  const PwBwdCfg c = pw_bwd_cfg(n, hw, cin, cout);
+  pw_wgrad_plan(n, hw, cin, cout, c.wpb, c.wks, &chunk, &sps);
   return (size_t)n * sps * cin * cout * sizeof(float);
 }
 
@@ -1428,7 +1474,7 @@ extern "C" int rn_mb_pointwise_bwd(const float* x, const rn_mb_norm* in, const r
   RN_CHECK_ARG((x != nullptr) != (in != nullptr), "mb pointwise bwd: exactly one of x / in");
   RN_CHECK_ARG(w && dw && dy && gout && workspace && n >= 1 && hw >= 1, "mb pointwise bwd: bad argument");
   RN_UNSUPPORTED(cin % 4 || cout % 4 || cin > KMAX || cout > KMAX, "mb pointwise bwd: cin=%d cout=%d (multiples of 4, <= %d)", cin, cout, KMAX);
-  RN_UNSUPPORTED(hw % PB, "mb pointwise bwd: %d pixels per sample, tile height %d", hw, PB);
+  RN_UNSUPPORTED(hw % 64, "mb pointwise bwd: %d pixels per sample, tile height 64", hw);
   RN_UNSUPPORTED((double)n * hw * cin >= 536870912.0 || (double)n * hw * cout >= 536870912.0, "mb pointwise bwd: tensor >= 2 GiB");
   PwBwdArgs a = {};
   a.dbg = dbg_word("pwb");
@@ -1443,11 +1489,11 @@ extern "C" int rn_mb_pointwise_bwd(const float* x, const rn_mb_norm* in, const r
   rn_mb_rows want = {};
   if (gout->norm) RN_UNSUPPORTED(!rn_mb_pointwise_bwd_rows(n, hw, cin, cout, gout->norm->groups, &want), "mb pointwise bwd: this shape cannot emit gradient rows");
   if (int e = fill_gout(gout, &a.go, n, cin, want, "mb pointwise bwd")) return e;
-  a.d_tiles_n = rn::ceil_div(cin, PB);
-  a.dblocks = n * hw / PB * a.d_tiles_n;
-  a.w_tiles_m = rn::ceil_div(cin, PB); a.w_tiles_n = rn::ceil_div(cout, PB);
-  const int ks = pw_bwd_ks(n, hw, cin, cout);
-  pw_wgrad_plan(n, hw, cin, cout, ks, &a.chunk, &a.sps);
+  const PwBwdCfg cfg = pw_bwd_cfg(n, hw, cin, cout);
+  a.d_tiles_n = rn::ceil_div(cin, cfg.dpb);
+  a.dblocks = n * hw / cfg.dpb * a.d_tiles_n;
+  a.w_tiles_m = rn::ceil_div(cin, cfg.wpb); a.w_tiles_n = rn::ceil_div(cout, cfg.wpb);
+  pw_wgrad_plan(n, hw, cin, cout, cfg.wpb, cfg.wks, &a.chunk, &a.sps);
   const int nsplit = n * a.sps;
   const size_t need = (size_t)nsplit * cin * cout * sizeof(float);
   if (workspace_bytes < need) { rn::set_error("mb pointwise bwd: workspace %zu < %zu bytes", workspace_bytes, need); return RN_EWORKSPACE; }
@@ -1455,14 +1501,18 @@ extern "C" int rn_mb_pointwise_bwd(const float* x, const rn_mb_norm* in, const r
   const dim3 grid((unsigned)(a.dblocks + nsplit * a.w_tiles_m * a.w_tiles_n));
   hipStream_t st = (hipStream_t)stream;
   const int act_in = in ? in->act : -2, act_out = gout->norm ? gout->norm->act : RN_ACT_NONE;
-#define RN_PWB(KS_)                                                                                                                  \
+#define RN_PWB(DPB_, DKS_, WPB_, WKS_)                                                                                               \
   do {                                                                                                                               \
-    if (act_in == -2 && act_out == RN_ACT_NONE) hipLaunchKernelGGL((mb_pw_bwd_kernel<-2, RN_ACT_NONE, KS_>), grid, dim3(T * KS_), 0, st, a); \
-    else if (act_in == -2) hipLaunchKernelGGL((mb_pw_bwd_kernel<-2, -1, KS_>), grid, dim3(T * KS_), 0, st, a);                         \
-    else if (act_in == RN_ACT_ELU && act_out == RN_ACT_ELU) hipLaunchKernelGGL((mb_pw_bwd_kernel<RN_ACT_ELU, RN_ACT_ELU, KS_>), grid, dim3(T * KS_), 0, st, a); \
-    else hipLaunchKernelGGL((mb_pw_bwd_kernel<-1, -1, KS_>), grid, dim3(T * KS_), 0, st, a);                                           \
+    constexpr int TB = (DPB_ / 32) * (DPB_ / 32) * 64 * DKS_;                                                                        \
+    if (act_in == -2 && act_out == RN_ACT_NONE) hipLaunchKernelGGL((mb_pw_bwd_kernel<-2, RN_ACT_NONE, DPB_, DKS_, WPB_, WKS_>), grid, dim3(TB), 0, st, a); \
+    else if (act_in == -2) hipLaunchKernelGGL((mb_pw_bwd_kernel<-2, -1, DPB_, DKS_, WPB_, WKS_>), grid, dim3(TB), 0, st, a);          \
+    else if (act_in == RN_ACT_ELU && act_out == RN_ACT_ELU) hipLaunchKernelGGL((mb_pw_bwd_kernel<RN_ACT_ELU, RN_ACT_ELU, DPB_, DKS_, WPB_, WKS_>), grid, dim3(TB), 0, st, a); \
+    else hipLaunchKernelGGL((mb_pw_bwd_kernel<-1, -1, DPB_, DKS_, WPB_, WKS_>), grid, dim3(TB), 0, st, a);                            \
   } while (0)
-  if (ks == 4) RN_PWB(4); else RN_PWB(1);
+  if (cfg.dpb == 32 && cfg.dks == 8) RN_PWB(32, 8, 64, 2);
+  else if (cfg.dpb == 32) RN_PWB(32, 4, 64, 1);
+  else if (cfg.dks == 4) RN_PWB(64, 4, 64, 4);
+  else RN_PWB(64, 1, 64, 1);
 #undef RN_PWB
   RN_LAUNCH_CHECK();
   if (nsplit == 1) return RN_OK;
