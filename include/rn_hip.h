@@ -496,6 +496,12 @@ typedef struct rn_mb_norm {
   uint64_t drop_seed; const uint64_t* drop_seed_dev;
 } rn_mb_norm;
 
+/* A consumer block merges at most rn_mb_rows_max() rows of its sample.  The largest maps produce more (one row per tile):
+ * rn_mb_compact_rows sums consecutive rows (fp64, fixed order) into <= 8 per sample first -- one small launch. */
+int rn_mb_rows_max(void);
+size_t rn_mb_compact_rows_layout(int n, const rn_mb_rows* in, rn_mb_rows* out);   /* fills `out`'s layout, returns its bytes */
+int rn_mb_compact_rows(const rn_mb_rows* in, const rn_mb_rows* out, int n, rn_stream_t stream);
+
 /* y[n,hw,cout] = A w, w [cin, cout] (a 1x1 Conv2D kernel, HWIO), A = x (plain) or dropout(act(GN(in->y))) [+ residual];
  * `materialise` (optional, with `in`): A is also written out, [n,hw,cin].  stat_out (optional): y's rows (layout from
  * rn_mb_pointwise_rows with the GroupNorm's `groups` that follows y). */

@@ -161,7 +161,7 @@ SYMBOLS = [
     "rn_iou", "rn_anchor_assign", "rn_anchor_assign_levels", "rn_anchor_assign_levels_pair", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
     "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
     "rn_optimizer_workspace", "rn_grad_norm_l2reg", "rn_optimizer_step", "rn_counter_add", "rn_add_segs",
-    "rn_mb_pointwise_rows", "rn_mb_pointwise_fwd", "rn_mb_depthwise_rows", "rn_mb_depthwise_fwd", "rn_mb_apply",
+    "rn_mb_rows_max", "rn_mb_compact_rows_layout", "rn_mb_compact_rows", "rn_mb_pointwise_rows", "rn_mb_pointwise_fwd", "rn_mb_depthwise_rows", "rn_mb_depthwise_fwd", "rn_mb_apply",
     "rn_mb_pointwise_bwd_rows", "rn_mb_pointwise_bwd_workspace", "rn_mb_pointwise_bwd",
     "rn_mb_depthwise_bwd_rows", "rn_mb_depthwise_bwd_workspace", "rn_mb_depthwise_bwd",
 ]
@@ -289,6 +289,9 @@ def lib():
         for name in ("rn_mb_pointwise_rows", "rn_mb_depthwise_rows", "rn_mb_pointwise_bwd_rows", "rn_mb_pointwise_bwd_workspace",
                      "rn_mb_depthwise_bwd_rows", "rn_mb_depthwise_bwd_workspace"):
             getattr(L, name).restype = C.c_size_t
+        L.rn_mb_compact_rows_layout.restype = C.c_size_t
+        L.rn_mb_compact_rows_layout.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.rn_mb_compact_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.rn_mb_pointwise_rows.argtypes = [C.c_int] * 5 + [C.c_void_p]
         L.rn_mb_pointwise_fwd.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p]
         L.rn_mb_depthwise_rows.argtypes = [C.c_int] * 6 + [C.c_void_p]

@@ -563,6 +563,37 @@ __global__ __launch_bounds__(T) void mb_apply_kernel(const ApplyArgs a) {
 }
 
 // =====================================================================================================================
+// Row compaction: the 256 x 256 maps produce more rows per sample (one per tile) than a consumer block wants to merge;
+// F consecutive rows are summed into one (fp64, fixed order).  grid (out rows, samples), thread = (entry, row lane).
+// =====================================================================================================================
+struct CompactArgs { const float2* in; float2* out; int R, W, F, Rout; };
+__global__ __launch_bounds__(T) void mb_compact_rows_kernel(const CompactArgs a) {
+  __shared__ double part[T][2];
+  const int tid = threadIdx.x, ro = blockIdx.x, sample = blockIdx.y;
+  const int RL = T / a.W, e = tid % a.W, rl = tid / a.W;
+  const int r_begin = ro * a.F, r_end = min(r_begin + a.F, a.R);
+  double S = 0.0, Q = 0.0;
+  if (rl < RL) {
+    const float2* __restrict__ base = a.in + (size_t)sample * a.R * a.W + e;
+    for (int r0 = r_begin + rl; r0 < r_end; r0 += 8 * RL) {
+      float2 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = base[(size_t)min(r0 + j * RL, r_end - 1) * a.W];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (r0 + j * RL < r_end) { S += (double)v[j].x; Q += (double)v[j].y; }
+    }
+  }
+  part[tid][0] = S; part[tid][1] = Q;
+  __syncthreads();
+  if (tid < a.W) {
+    S = 0.0; Q = 0.0;
+    for (int l = 0; l < RL; ++l) { S += part[l * a.W + tid][0]; Q += part[l * a.W + tid][1]; }
+    a.out[((size_t)sample * a.Rout + ro) * a.W + tid] = make_float2((float)S, (float)Q);
+  }
+}
+
+// =====================================================================================================================
 // backward
 // =====================================================================================================================
 struct DyDev {            // the gradient of a raw conv output y as a kernel loads it (rn_mb_dy)
@@ -1240,7 +1271,7 @@ extern "C" size_t rn_mb_pointwise_rows(int n, int hw, int cin, int cout, int gro
   const PwCfg c = pw_cfg(n, hw, cin, cout);
   if (hw % c.bm) return 0;
   const int R = hw / c.bm, W = groups + rn::ceil_div(cout, c.bn);
-  if (R > RMAX || cout / groups > c.bn) return 0;
+  if (cout / groups > c.bn) return 0;      // (R > rn_mb_rows_max(): rn_mb_compact_rows before a consumer reads them)
   if (layout) { layout->rows_per_sample = R; layout->width = W; layout->bn = c.bn; }
   return (size_t)n * R * W * 8;
 }
@@ -1309,7 +1340,6 @@ extern "C" size_t rn_mb_depthwise_rows(int n, int h, int w, int c, int stride, i
   DwPlan p;
   if (!dw_plan(n, oh, ow, c, stride, c / groups, &p)) return 0;
   const int R = p.tiles_h * p.tiles_w;
-  if (R > RMAX) return 0;
   if (layout) { layout->rows_per_sample = R; layout->width = groups; layout->bn = c; }
   return (size_t)n * R * groups * 8;
 }
@@ -1455,7 +1485,7 @@ extern "C" size_t rn_mb_pointwise_bwd_rows(int n, int hw, int cin, int cout, int
   if (n < 1 || hw < 1 || cin < 4 || cout < 4 || groups < 1 || cin % groups || hw % 64) return 0;
   const int pb = pw_bwd_cfg(n, hw, cin, cout).dpb;
   const int R = hw / pb, W = groups + rn::ceil_div(cin, pb);
-  if (R > RMAX || cin / groups > pb) return 0;
+  if (cin / groups > pb) return 0;
   if (layout) { layout->rows_per_sample = R; layout->width = W; layout->bn = pb; }
   return (size_t)n * R * W * 8;
 }
@@ -1524,7 +1554,6 @@ extern "C" size_t rn_mb_depthwise_bwd_rows(int n, int h, int w, int c, int strid
   DwBwdPlan p;
   if (!dw_bwd_plan(n, h, w, c, stride, c / groups, &p)) return 0;
   const int R = p.tiles_h * p.tiles_w;
-  if (R > RMAX) return 0;
   if (layout) { layout->rows_per_sample = R; layout->width = groups; layout->bn = c; }
   return (size_t)n * R * groups * 8;
 }
@@ -1571,4 +1600,27 @@ extern "C" int rn_mb_depthwise_bwd(const rn_mb_norm* in, const rn_mb_dy* dy, con
   else hipLaunchKernelGGL(mb_dw_bwd_kernel<-1>, grid, dim3(T), lds, st, a);
   RN_LAUNCH_CHECK();
   return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)9 * c, nrows, 0, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// row compaction
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int rn_mb_rows_max(void) { return RMAX; }
+
+extern "C" size_t rn_mb_compact_rows_layout(int n, const rn_mb_rows* in, rn_mb_rows* out) {
+  if (!in || !out || n < 1 || in->rows_per_sample < 1 || in->width < 1 || in->width > T) return 0;
+  const int F = rn::ceil_div(in->rows_per_sample, 8);
+  out->rows_per_sample = rn::ceil_div(in->rows_per_sample, F); out->width = in->width; out->bn = in->bn;
+  return (size_t)n * out->rows_per_sample * out->width * 8;
+}
+
+extern "C" int rn_mb_compact_rows(const rn_mb_rows* in, const rn_mb_rows* out, int n, rn_stream_t stream) {
+  RN_CHECK_ARG(in && out && in->rows && out->rows && n >= 1, "mb compact rows: bad argument");
+  rn_mb_rows want = {};
+  RN_CHECK_ARG(rn_mb_compact_rows_layout(n, in, &want) && want.rows_per_sample == out->rows_per_sample && want.width == out->width && want.bn == out->bn,
+               "mb compact rows: `out` layout differs from rn_mb_compact_rows_layout");
+  CompactArgs a = {(const float2*)in->rows, (float2*)out->rows, in->rows_per_sample, in->width, rn::ceil_div(in->rows_per_sample, 8), want.rows_per_sample};
+  hipLaunchKernelGGL(mb_compact_rows_kernel, dim3((unsigned)a.Rout, (unsigned)n), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
 }

@@ -37,6 +37,10 @@ _TAP_AFTER = {'bottleneck_1_1': 'C1', 'bottleneck_2_2': 'C2', 'bottleneck_3_3': 
 # layer's shape qualifies (maps whose statistic rows a consumer block can merge: <= 128 x 128 at the headline size); the
 # bottlenecks in front of it run layer by layer.  RN_MB_CHAIN=0: layer by layer everywhere.
 MB_CHAIN = os.environ.get("RN_MB_CHAIN", "1") == "1"
+# Maps of more than this many pixels per sample stay on the layer-by-layer path.  The chain CAN take them (their statistic
+# rows go through rn_mb_compact_rows first; RN_MB_CHAIN_MAX_HW=0 lifts the limit, tests/test_gpu_mbchain.py runs it), but
+# measured on the headline step its 256 x 256 kernels are no faster than the layer-by-layer ones (420 vs 421 images/s).
+MB_CHAIN_MAX_HW = int(os.environ.get("RN_MB_CHAIN_MAX_HW", 16384))
 
 
 class DepthwiseConv2D(L.DepthwiseConv2D):
@@ -159,6 +163,8 @@ class MobileNetV2(Model):
                 h, w, c = -(-h // s), -(-w // s), b.linear_conv.layers[0].filters
             start = None
             for i in range(len(self.block_names) - 1):
+                if MB_CHAIN_MAX_HW and shapes[i][1] * shapes[i][2] > MB_CHAIN_MAX_HW:
+                    continue
                 if ops_mb.chain_supported(shapes[i], self._chain_blocks(i)):
                     start = i
                     break

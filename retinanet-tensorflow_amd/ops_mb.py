@@ -38,6 +38,22 @@ def _rows(query, *args):
     return lay, int(nbytes)
 
 
+def _compact(rows, lay, n, dev):
+    """(rows, layout) a consumer can merge: the producer's, or -- more rows per sample than rn_mb_rows_max() (the largest maps) --
+    their sums over runs of consecutive rows (rn_mb_compact_rows, one small launch)."""
+    L = _rn.lib()
+    if lay.rows_per_sample <= L.rn_mb_rows_max():
+        return rows, lay
+    src = _rn.MbRows(rows.data_ptr(), lay.rows_per_sample, lay.width, lay.bn)
+    out = _rn.MbRows()
+    nbytes = L.rn_mb_compact_rows_layout(n, C.byref(src), C.byref(out))
+    assert nbytes
+    small = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    out.rows = small.data_ptr()
+    _rn.check(L.rn_mb_compact_rows(C.byref(src), C.byref(out), n, _rn.stream()), "rn_mb_compact_rows")
+    return small, out
+
+
 class _Stage(object):
     """Buffers of one GroupNorm block inside the chain: raw tensor, statistic rows (forward), mean / rstd."""
     __slots__ = ("y", "rows", "lay", "mean", "rstd", "norm", "c", "groups", "hw")
@@ -132,17 +148,20 @@ class _MbChain(torch.autograd.Function):
                                                 _rn.f32(w1), _rn.f32(y1), n, h * w, c, wide, rows_arg(s1), gr1, st_), "rn_mb_pointwise_fwd")
                 if (i - 1) in tap_after:
                     taps.append(x_in)
+            s1.rows, s1.lay = _compact(s1.rows, s1.lay, n, dev)
             # depthwise 3x3 on drop(act(GN1(y1)))
             y2 = torch.empty((n, oh, ow, wide), dtype=torch.float32, device=dev)
             s2 = new_stage(y2, (n, h, w, wide, stride, gr1), L.rn_mb_depthwise_rows, gr1, n2)
             nm = _mb_norm(s1, training, seed_dev, True)
             _rn.check(L.rn_mb_depthwise_fwd(C.byref(nm), _rn.f32(wd), _rn.f32(y2), n, h, w, stride, rows_arg(s2), gr1, st_), "rn_mb_depthwise_fwd")
+            s2.rows, s2.lay = _compact(s2.rows, s2.lay, n, dev)
             # linear 1x1 on drop(act(GN2(y2)))
             y3 = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=dev)
             s3 = new_stage(y3, (n, oh * ow, wide, cout, gr3), L.rn_mb_pointwise_rows, gr3, n3)
             nm = _mb_norm(s2, training, seed_dev, True)
             _rn.check(L.rn_mb_pointwise_fwd(None, C.byref(nm), None, None, _rn.f32(w3), _rn.f32(y3), n, oh * ow, wide, cout, rows_arg(s3), gr3, st_),
                       "rn_mb_pointwise_fwd")
+            s3.rows, s3.lay = _compact(s3.rows, s3.lay, n, dev)
             saved.append((x_in, s1, s2, s3))
             pend, pend_res = s3, (x_in if residual else None)
             h, w, c = oh, ow, cout
@@ -226,6 +245,7 @@ class _MbChain(torch.autograd.Function):
                           _rn.MbRows(rows3.data_ptr(), lay3.rows_per_sample, lay3.width, lay3.bn), planes3.data_ptr())
         dyd = _rn.MbDy(dy_t.data_ptr(), None, None, 0, _rn.MbRows())
         pgrads[9 * nb] = pw_bwd(x_last, None, dyd, tail_w, gout, hl * wl, cl, ct)
+        rows3, lay3 = _compact(rows3, lay3, n, dev)
         keep = [tg]
 
         dx0 = None
@@ -247,6 +267,7 @@ class _MbChain(torch.autograd.Function):
             gout = _rn.MbGout(g2.data_ptr(), None, None, C.pointer(nm2), 0,
                               _rn.MbRows(rows2.data_ptr(), lay2.rows_per_sample, lay2.width, lay2.bn), planes2.data_ptr())
             pgrads[9 * i + 6] = pw_bwd(None, s2, dy3, w3, gout, oh * ow, wide, cout)
+            rows2, lay2 = _compact(rows2, lay2, n, dev)
             norm_param_grads(planes2, n2, 9 * i + 4, 9 * i + 5)
             # depthwise backward: dy2 from g2; data gradient -> g1 of GroupNorm 1
             nm1 = _mb_norm(s1, training, seed_dev, False)
@@ -261,6 +282,7 @@ class _MbChain(torch.autograd.Function):
             _rn.check(L.rn_mb_depthwise_bwd(C.byref(nm1), C.byref(dy2), _rn.f32(wd), _rn.f32(dwd_buf), C.byref(gout), n, h, w, stride,
                                             ws.data_ptr(), ws.numel(), st_, ops._defer_arg()), "rn_mb_depthwise_bwd")
             pgrads[9 * i + 3] = dwd
+            rows1, lay1 = _compact(rows1, lay1, n, dev)
             norm_param_grads(planes1, n1, 9 * i + 1, 9 * i + 2)
             # expand conv backward: dy1 from g1; data gradient (+ the residual path's D, + a tap's gradient) enters the previous
             # bottleneck's GroupNorm 3 -- or leaves the chain
@@ -280,6 +302,7 @@ class _MbChain(torch.autograd.Function):
                 gout = _rn.MbGout(Dn.data_ptr(), add1, None, None, 1, _rn.MbRows(), None)
             pgrads[9 * i] = pw_bwd(x_in, None, dy1, w1, gout, h * w, c, wide)
             if i > 0:
+                rows3n, lay3n = _compact(rows3n, lay3n, n, dev)
                 lay3, rows3, planes3 = lay3n, rows3n, planes3n
             else:
                 dx0 = Dn

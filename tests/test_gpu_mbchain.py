@@ -81,17 +81,20 @@ def _run(bb, x, cot, training=True):
     return {k: out[k].detach() for k in ("C3", "C4", "C5")}, grads, xin.grad.detach()
 
 
-@pytest.mark.parametrize("size,batch", [(256, 2), (512, 1)])
-def test_chain_matches_oracle(dev, size, batch):
+@pytest.mark.parametrize("size,batch,big", [(256, 2, False), (512, 1, False), (512, 1, True)])
+def test_chain_matches_oracle(dev, size, batch, big, monkeypatch):
     """Backbone forward (C3 / C4 / C5) and the gradients of every backbone parameter and of the image through the fused chain
-    vs the oracle (dropout 0): outputs 1e-4, gradients 5e-4 of max(|g|, 1e-3 x the largest gradient)."""
+    vs the oracle (dropout 0): outputs 1e-4, gradients 5e-4 of max(|g|, 1e-3 x the largest gradient).  big: the chain also
+    takes the 256 x 256 maps (their statistic rows go through rn_mb_compact_rows)."""
     import mobilenet_v2
+    if big:
+        monkeypatch.setattr(mobilenet_v2, "MB_CHAIN_MAX_HW", 0)
     bb, params = _backbone(dev, 0.0)
     rng = np.random.default_rng(size)
     x = torch.from_numpy(rng.standard_normal((batch, size, size, 3)).astype(np.float32))
     stem = bb.input_conv(x.to(dev), training=True)
     start = bb._chain_start(stem, True)
-    assert start is not None and start <= 2, "the fused chain must run here (starts at bottleneck %s)" % start
+    assert start is not None and start <= (0 if big else 2), "the fused chain must run here (starts at bottleneck %s)" % start
     shapes = {"C3": (batch, size // 8, size // 8, 32), "C4": (batch, size // 16, size // 16, 96), "C5": (batch, size // 32, size // 32, 32)}
     cot = {k: torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for k, s in shapes.items()}
     out, grads, dx = _run(bb, x.to(dev), {k: v.to(dev) for k, v in cot.items()})
