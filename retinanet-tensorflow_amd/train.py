@@ -507,18 +507,19 @@ def main(argv=None):
                               dropout_rate=args.dropout).to(dev)
     trainer = Trainer(net, levels, optimizer=args.optimizer, learning_rate=args.learning_rate,
                       grad_clip_norm=args.grad_clip_norm, loss_mode=args.loss, device=dev)
-    step, first_epoch = 0, 0
+    step = 0
     path = None if args.experiment is None else os.path.join(args.experiment, 'model.safetensors')
     if path is not None and os.path.exists(path):
         step = checkpoint.load(path, net, trainer)                                 # every rank reads the same file
-        extra = checkpoint.load_extra(path)
-        first_epoch = int(extra.get('epochs_done', 0))
-        loader.skip(int(extra.get('samples_drawn', 0)))                            # the sample stream goes on where it stopped
+        # like the reference (train.py:271-273: `for epoch in range(args.epochs): estimator.train(...)` on a restored global
+        # step) a rerun trains args.epochs MORE epochs; what is carried over besides the weights: the step count, the
+        # optimizer slots, the dropout counter and the position in the sample stream
+        loader.skip(int(checkpoint.load_extra(path).get('samples_drawn', 0)))
         if rank == 0:
-            print('restored step', step, 'epochs done', first_epoch)
+            print('restored step', step)
     broadcast_initial_state(trainer)
     it = dataset.build_dataset(loader, levels, scale=args.scale, device=dev)       # train.py:192-203 train_input_fn
-    for epoch in range(first_epoch, args.epochs):
+    for epoch in range(args.epochs):
         for _ in range(args.steps_per_epoch):
             out = trainer.step(next(it))                                           # batch = [image, hflip]
             step += 1
