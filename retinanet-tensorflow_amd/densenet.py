@@ -120,6 +120,7 @@ class DenseNetBC_ImageNet(Model):
     def __init__(self, blocks, growth_rate, compression_factor, bottleneck, activation, dropout_rate,
                  kernel_initializer, kernel_regularizer, name='densenet_bc_imagenet'):
         super().__init__(name=name)
+        self.stage_cut = None       # installed by train.Trainer (see resnet.ResNeXt.stage_cut)
         act = L.get_activation(activation)
         common = dict(kernel_initializer=kernel_initializer, kernel_regularizer=kernel_regularizer)
         self.conv1 = Sequential([
@@ -147,7 +148,10 @@ class DenseNetBC_ImageNet(Model):
         input = self.conv1_max_pool(input)
         import ops
         for i in range(1, 5):
-            input = getattr(self, 'dense_block_%d' % i)(input, training)
+            block = getattr(self, 'dense_block_%d' % i)
+            if i > 2 and getattr(self, 'stage_cut', None) is not None and training and torch.is_grad_enabled():
+                input = self.stage_cut(block, input, tuple(out.keys()))    # (see resnet.ResNeXt.stage_cut)
+            input = block(input, training)
             if i in (2, 3) and input.dtype == torch.float32:        # C3, C4 feed the transition AND the pyramid: one summed gradient
                 out['C%d' % (i + 1)], input = ops.fanout(input, 2)
             else:

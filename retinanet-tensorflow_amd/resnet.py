@@ -107,6 +107,10 @@ class ResNeXt(Model):
         super().__init__(name=name)
         self._kernel_initializer = kernel_initializer
         self._kernel_regularizer = kernel_regularizer
+        # train.Trainer installs a callable here: stage_cut(stage module, its input, names of the taps made so far) -> the
+        # tensor the stage reads (a detached leaf: the backward pass then runs stage by stage, each stage's gradient
+        # all-reduce underneath the stages below it)
+        self.stage_cut = None
 
     def call(self, input, training):
         out = {}
@@ -115,6 +119,8 @@ class ResNeXt(Model):
         input = self._conv_1_max_pool(input)
         import ops
         for i, stage in enumerate((self._conv_2, self._conv_3, self._conv_4, self._conv_5)):
+            if i > 0 and self.stage_cut is not None and training and L.torch.is_grad_enabled():
+                input = self.stage_cut(stage, input, tuple(out.keys()))
             input = stage(input, training=training)
             if i in (1, 2) and input.dtype == L.torch.float32:      # C3, C4 feed the next stage AND the pyramid: one summed gradient
                 out['C%d' % (i + 2)], input = ops.fanout(input, 2)

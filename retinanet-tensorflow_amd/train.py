@@ -215,6 +215,14 @@ class Trainer(object):
         # (the hook itself -- base.backward_cut -- is installed only while one of this trainer's segments runs: _scoped)
         self._cut_base = base if self.cut_offset else None
         self._cut_src = self._cut_leaves = None
+        # ... and the backbone's own backward pass in one part per stage where the backbone offers the cut points (`stage_cut`:
+        # ResNeXt / DenseNet, whose 200 / 50 MB of backbone gradients would otherwise all wait for the last backward kernel):
+        # part j's slice of the gradient arena is reduced underneath the parts that follow it
+        bb = getattr(base, 'backbone', None) if self._cut_base is not None else None
+        self._stage_bb = bb if (bb is not None and hasattr(bb, 'stage_cut') and os.environ.get("RN_STAGE_CUTS", "1") == "1") else None
+        self._stage_cuts = []          # per step: (arena offset, source tensor, detached leaf, names of the taps made before it)
+        self._param_offset = {id(p): off for p, (off, _) in zip(self.arena.params, self.arena.offsets)}
+        self._parts = []               # per step: (roots, grads-of-leaves getter, arena range) of segment B's parts
         self._graphs = None
         self._static = None
         # the device word every fused dropout hashes (bumped by the optimizer kernel); replicas start it at different values
@@ -236,22 +244,57 @@ class Trainer(object):
         L.Dropout.seed_device_counter = self.drop_counter
         base = self._cut_base
         saved_cut = base.backward_cut if base is not None else None
+        saved_stage = self._stage_bb.stage_cut if self._stage_bb is not None else None
         if base is not None:        # plain autograd users of the same net (and other trainers) never see this trainer's cut
             base.backward_cut = self._cut
+        if self._stage_bb is not None:
+            self._stage_bb.stage_cut = self._stage_cut
         try:
             yield
         finally:
             ops.DIRECT_PARAM_GRADS, ops.WGRAD_SIDE_STREAM, L.Dropout.seed_device_counter = saved
             if base is not None:
                 base.backward_cut = saved_cut
+            if self._stage_bb is not None:
+                self._stage_bb.stage_cut = saved_stage
 
     # -- replica-local work (capturable)
     def _cut(self, taps):
         """RetinaNetBase.backward_cut: the FPN reads detached leaves; segment B feeds their gradients back."""
         keys = [k for k in ('C3', 'C4', 'C5') if k in taps]
+        self._cut_keys = keys
         self._cut_src = [taps[k] for k in keys]
         self._cut_leaves = [t.detach().requires_grad_(True) for t in self._cut_src]
         return {**taps, **dict(zip(keys, self._cut_leaves))}
+
+    def _stage_cut(self, module, x, taps_before=()):
+        """<backbone>.stage_cut: the stage that starts with `module` reads a detached leaf (see __init__)."""
+        first = next(iter(module.parameters()), None)
+        off = self._param_offset.get(id(first)) if first is not None else None
+        if off is None or not x.requires_grad or not (0 < off < self.cut_offset):
+            return x
+        leaf = x.detach().requires_grad_(True)
+        self._stage_cuts.append((off, x, leaf, frozenset(taps_before)))
+        return leaf
+
+    def _plan_parts(self):
+        """Segment B as parts, last stage first: [(roots, leaves whose .grad seeds them, (start, end) of the arena slice complete after it)]."""
+        keys, srcs, leaves = self._cut_keys, self._cut_src, self._cut_leaves
+        cuts = sorted(self._stage_cuts, key=lambda c: c[0])
+        parts, done, hi = [], set(), self.cut_offset
+        nxt = None                                     # (source, leaf) of the cut above the part being built
+        for off, x, leaf, before in reversed(cuts):
+            idx = [i for i, k in enumerate(keys) if k not in before and k not in done]
+            done.update(keys[i] for i in idx)
+            roots = [srcs[i] for i in idx] + ([nxt[0]] if nxt is not None else [])
+            seeds = [leaves[i] for i in idx] + ([nxt[1]] if nxt is not None else [])
+            parts.append((roots, seeds, (off, hi)))
+            nxt, hi = (x, leaf), off
+        idx = [i for i, k in enumerate(keys) if k not in done]
+        roots = [srcs[i] for i in idx] + ([nxt[0]] if nxt is not None else [])
+        seeds = [leaves[i] for i in idx] + ([nxt[1]] if nxt is not None else [])
+        parts.append((roots, seeds, (0, hi)))
+        return parts
 
     def _backward(self, roots, grads):
         defer = self.defer_reductions and self.device.type == 'cuda' and ops.DIRECT_PARAM_GRADS
@@ -276,11 +319,27 @@ class Trainer(object):
     def segment_a(self, features=None):
         """forward + loss + backward of the heads and the FPN (the whole backward pass when there is no cut)."""
         with self._scoped():
+            label_stream = None
             if features is None:
-                features = self.input_fn()
+                # input_fn builds the step's labels on the device (anchor assignment); only the loss reads them: their
+                # kernels run on a side stream underneath the backbone's forward pass (the image itself -- written before
+                # the step, not by input_fn -- is read at once).  input_fn.concurrent = False keeps it on the main stream.
+                if self.device.type == 'cuda' and getattr(self.input_fn, 'concurrent', True):
+                    label_stream = _rn.side_stream(self.device, 2)
+                    label_stream.wait_stream(torch.cuda.current_stream())
+                    main_stream = torch.cuda.current_stream()
+                    with torch.cuda.stream(label_stream):
+                        features = self.input_fn()
+                    _for_each_tensor(features, lambda t: t.record_stream(main_stream) if t.is_cuda else None)   # (allocated on the side stream, read on this one)
+                else:
+                    features = self.input_fn()
             self._cut_src = self._cut_leaves = None
+            self._stage_cuts = []
+            self._parts = []
             ops.begin_direct_grad_step()       # a parameter's gradient slot may be written once per step from here on
             logits = {'detection': self.net(features['image'], training=True)}
+            if label_stream is not None:
+                torch.cuda.current_stream().wait_stream(label_stream)
             inp, logits = utils.process_labels_and_logits(labels=features, logits=logits, levels=self.levels)
             class_loss, regr_loss = losses.loss(labels=inp['detection_trainable'], logits=logits['detection_trainable'],
                                                 mode=self.loss_mode)
@@ -289,15 +348,30 @@ class Trainer(object):
             self.arena.zero_grad()
             # d(class_loss + regr_loss): both roots seeded with the same pre-allocated 1 (no add / fill kernels in the step)
             self._backward([class_loss, regr_loss], [self._one, self._one])
+            if self._cut_src is not None:
+                self._parts = self._plan_parts()
+                self._cut_src = self._cut_leaves = None
+                self._stage_cuts = []
             return class_loss.detach(), regr_loss.detach()
 
-    def segment_b(self):
-        """backward of the backbone from the gradients segment A left at the cut."""
-        if self._cut_src is not None:
+    def num_parts(self):
+        """Parts of segment B planned by the last segment_a (1 without stage cuts, 0 without any cut)."""
+        return len(self._parts)
+
+    def segment_b(self, part=None):
+        """backward of the backbone from the gradients segment A left at the cut: every part (part=None), or part j of
+        num_parts() (last stage first).  Returns the (start, end) arena slice that is complete after it."""
+        if not self._parts:
+            return None
+        rng = None
+        for j in (range(len(self._parts)) if part is None else [part]):
+            roots, seeds, rng = self._parts[j]
             with self._scoped():
-                src, leaves = self._cut_src, self._cut_leaves
-                self._cut_src = self._cut_leaves = None
-                self._backward(src, [l.grad for l in leaves])
+                self._backward(roots, [l.grad for l in seeds])
+        if part is None:
+            self._parts = []
+            return (0, self.cut_offset)
+        return rng
 
     def forward_backward(self, features=None, advance_dropout=True):
         """Both segments, no collective, no update.  The dropout counter is bumped here (one tiny launch); step() leaves
@@ -323,10 +397,14 @@ class Trainer(object):
         # thread_local: RCCL's watchdog thread may poll events while the capture is open
         with torch.cuda.graph(ga, capture_error_mode="thread_local"):
             self._graph_out = self.segment_a(self._static)
-        gb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
-            self.segment_b()
-        self._graphs = (ga, gb)
+        gbs, ranges = [], []
+        for j in range(self.num_parts()):          # one graph per part of segment B: the collectives go between the replays
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+                ranges.append(self.segment_b(j))
+            gbs.append(gb)
+        self._parts = []
+        self._graphs = (ga, gbs, ranges)
 
     def step(self, features=None):
         if self.use_graph:
@@ -340,10 +418,15 @@ class Trainer(object):
             class_loss, regr_loss = self.segment_a(features)
         self.allreduce.launch(self.cut_offset, self.arena.count)      # heads + FPN: under the backbone's backward pass
         if self.use_graph:
-            self._graphs[1].replay()
+            for gb, (lo, hi) in zip(self._graphs[1], self._graphs[2]):
+                gb.replay()
+                self.allreduce.launch(lo, hi)                         # this part's slice: under the parts that follow
         else:
-            self.segment_b()
-        self.allreduce.launch(0, self.cut_offset)
+            n = self.num_parts()
+            for j in range(n if n else (1 if self.cut_offset else 0)):
+                rng = self.segment_b(j) if n else self.segment_b()
+                self.allreduce.launch(*(rng or (0, self.cut_offset)))
+            self._parts = []
         if self.timing is not None and self.device.type == 'cuda':
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -384,6 +467,17 @@ class Trainer(object):
             raise _rn.RnError("%d GroupNorm exchange wait(s) timed out on some rank: the updates since the last check are invalid; "
                               "the grid-resident path is now off (ops.GN_GRID_RESIDENT = False) -- reload the last checkpoint "
                               "and continue" % n)
+
+
+def _for_each_tensor(tree, fn):
+    if torch.is_tensor(tree):
+        fn(tree)
+    elif isinstance(tree, dict):
+        for v in tree.values():
+            _for_each_tensor(v, fn)
+    elif isinstance(tree, (list, tuple)):
+        for v in tree:
+            _for_each_tensor(v, fn)
 
 
 def _copy_tree(dst, src):

@@ -234,3 +234,37 @@ def test_plain_autograd_after_a_trainer_exists(dev):
     for n in before:
         assert_close(after[n].cpu().numpy(), before[n].cpu().numpy(), 1e-5, "plain backward after trainers: " + n)
         assert_close(with_trainer[n].cpu().numpy(), before[n].cpu().numpy(), 1e-5, "trainer segments vs plain backward: " + n)
+
+
+@pytest.mark.parametrize("backbone,use_graph", [("resnet_50", False), ("resnet_50", True), ("densenet_121", False)])
+def test_stage_cut_backward_parts_bit_equal_to_single_segment(dev, backbone, use_graph):
+    """ResNeXt / DenseNet: the backbone's backward pass in one part per stage (Trainer stage cuts: each stage's slice of the
+    gradient arena can be all-reduced underneath the stages below it, reference train.py:261-267) changes no bit: same losses
+    and weights after two steps as the single-segment step; the parts' arena slices tile [0, cut_offset) from the top down."""
+    import copy
+    import dataset, layers, levels as levels_mod, retinanet, train
+    lv = levels_mod.build_levels()
+    torch.manual_seed(3)
+    net_a = retinanet.RetinaNet(backbone, lv, 4, layers.elu, 0.1).to(dev)
+    net_b = copy.deepcopy(net_a)
+    rng = np.random.default_rng(1)
+    size = 96
+    image = torch.from_numpy(rng.standard_normal((2, size, size, 3)).astype(np.float32)).to(dev)
+    boxes = torch.tensor([[[0.1, 0.2, 0.7, 0.8], [0.4, 0.1, 0.9, 0.5]]], device=dev)
+    cids = torch.tensor([[1, 3]], dtype=torch.int32, device=dev)
+    c, r, m = dataset.build_labels((size, size), cids, boxes, lv, 4, flip_pair=True)
+    feats = {"image": image, "detection": {"classifications": c, "regressions": r}, "trainable_masks": m}
+    ta = train.Trainer(net_a, lv, loss_mode="focal", device=dev, use_graph=use_graph)
+    tb = train.Trainer(net_b, lv, loss_mode="focal", device=dev, use_graph=use_graph, overlap=False)
+    assert ta._stage_bb is not None and tb.cut_offset == 0
+    seen = []
+    orig = ta.allreduce.launch
+    ta.allreduce.launch = lambda start=0, end=None: (seen.append((start, ta.arena.count if end is None else end)), orig(start, end))[1]
+    for _ in range(2):
+        del seen[:]
+        oa, ob = ta.step(feats), tb.step(feats)
+        assert oa["class_loss"].item() == ob["class_loss"].item() and oa["regr_loss"].item() == ob["regr_loss"].item()
+        # heads + FPN first, then the backbone's parts from the last stage down to the stem, tiling the arena exactly
+        assert seen[0] == (ta.cut_offset, ta.arena.count) and len(seen) >= 4, seen
+        assert all(a[0] == b[1] for a, b in zip(seen, seen[1:])) and seen[-1][0] == 0, seen
+    assert torch.equal(ta.arena.weights, tb.arena.weights)

@@ -227,3 +227,48 @@ def test_shapes_loader_skip_resumes_the_stream():
     b.skip(3)
     nxt = next(iter(b))
     assert np.array_equal(nxt['image'], first[3]['image']) and np.array_equal(nxt['boxes'], first[3]['boxes'])
+
+
+def test_map_hand_computed_coco_known_answer():
+    """An independent pin for metrics.mean_average_precision: a COCO-style known-answer set worked out BY HAND
+    from the published evaluation procedure (pycocotools COCOeval.evaluateImg / accumulate: detections of a class sorted by score
+    over all images; each takes the still-unmatched ground truth of its image with the largest IoU >= t; precision made
+    non-increasing from the right; precision sampled at the 101 recall points k/100 by searchsorted(recall, r, 'left'), 0 past
+    the last recall; mean over classes and t = 0.50:0.05:0.95).  Three images, two classes, a duplicate, two low-IoU hits, a
+    missed object, a detection in an image without that class.
+
+    Class 0, 3 objects (A: g1, B: g2, C: g3 undetected).  Detections by score: d1 0.9 (A, IoU 1.0 with g1) TP;
+      d2 0.8 (A, IoU 0.80 with g1, which d1 holds) duplicate -> FP; d3 0.7 (B, IoU 0.62 with g2) TP for t <= 0.60, FP above.
+      t in {.50,.55,.60}: tp 1,0,1 -> recall 1/3,1/3,2/3, precision 1,1/2,2/3 -> envelope 1,2/3,2/3: 34 points (r <= .33) at 1,
+        33 points (.34...66) at 2/3, 34 points at 0 -> AP = (34 + 22)/101 = 56/101.
+      t in {.65 ... .95}: tp 1,0,0 -> recall 1/3 throughout, envelope 1,1/2,1/3: 34 points at 1 -> AP = 34/101.
+    Class 1, 2 objects (A: h1, C: h2).  e1 0.95 (C, IoU 0.78 with h2) TP for t <= 0.75; e2 0.6 (A, IoU 1 with h1) TP;
+      e3 0.5 (B, no class-1 object there) FP.
+      t <= .75 (6 thresholds): tp 1,1,0 -> recall 1/2,1,1, envelope 1,1,2/3 -> AP = 1.
+      t >= .80 (4): tp 0,1,0 -> recall 0,1/2,1/2, precision 0,1/2,1/3 -> envelope 1/2,1/2,1/3: r = 0 and r <= .50 -> 51 points
+        at 1/2 -> AP = 25.5/101.
+    mAP = (3*56/101 + 7*34/101 + 6 + 4*25.5/101) / 20 = (406/101 + 6 + 102/101) / 20;  AP50 = (56/101 + 1)/2;  AP75 = (34/101 + 1)/2."""
+    import metrics
+    from oracle import metrics_ref
+    A_det = (np.array([[0, 0, 10, 10], [0, 0, 10, 8], [50, 50, 60, 60]], np.float64), np.array([0.9, 0.8, 0.6]), np.array([0, 0, 1]))
+    B_det = (np.array([[0, 0, 10, 6.2], [0, 0, 5, 5]], np.float64), np.array([0.7, 0.5]), np.array([0, 1]))
+    C_det = (np.array([[50, 50, 70, 65.6]], np.float64), np.array([0.95]), np.array([1]))
+    A_gt = (np.array([[0, 0, 10, 10], [50, 50, 60, 60]], np.float64), np.array([0, 1]))
+    B_gt = (np.array([[0, 0, 10, 10]], np.float64), np.array([0]))
+    C_gt = (np.array([[20, 20, 30, 30], [50, 50, 70, 70]], np.float64), np.array([0, 1]))
+    dets, gts = [A_det, B_det, C_det], [A_gt, B_gt, C_gt]
+    r = metrics.mean_average_precision(dets, gts, 2)
+    want_map = (406.0 / 101 + 6 + 102.0 / 101) / 20
+    assert abs(r['mAP'] - want_map) < 1e-12, (r['mAP'], want_map)
+    assert abs(r['AP50'] - (56.0 / 101 + 1) / 2) < 1e-12 and abs(r['AP75'] - (34.0 / 101 + 1) / 2) < 1e-12
+    assert abs(r['per_class'][0] - 406.0 / 1010) < 1e-12 and abs(r['per_class'][1] - (6 + 102.0 / 101) / 10) < 1e-12
+    # single thresholds, as derived above
+    assert abs(metrics.mean_average_precision(dets, gts, 2, iou_thresholds=[0.6])['per_class'][0] - 56.0 / 101) < 1e-12
+    assert abs(metrics.mean_average_precision(dets, gts, 2, iou_thresholds=[0.65])['per_class'][0] - 34.0 / 101) < 1e-12
+    assert abs(metrics.mean_average_precision(dets, gts, 2, iou_thresholds=[0.8])['per_class'][1] - 25.5 / 101) < 1e-12
+    # the second opinion (the naive loop of oracle/metrics_ref.py) agrees with the hand-derived number too
+    assert abs(metrics_ref.mean_ap(dets, gts, 2, np.arange(0.5, 0.96, 0.05)) - want_map) < 1e-9
+    # the order of the images and of the detections inside an image does not matter
+    perm = [2, 0, 1]
+    shuf = [(d[0][::-1], d[1][::-1], d[2][::-1]) for d in (dets[i] for i in perm)]
+    assert abs(metrics.mean_average_precision(shuf, [gts[i] for i in perm], 2)['mAP'] - want_map) < 1e-12
