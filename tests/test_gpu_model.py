@@ -241,12 +241,15 @@ def test_stage_cut_backward_parts_bit_equal_to_single_segment(dev, backbone, use
     """ResNeXt / DenseNet: the backbone's backward pass in one part per stage (Trainer stage cuts: each stage's slice of the
     gradient arena can be all-reduced underneath the stages below it, reference train.py:261-267) changes no bit: same losses
     and weights after two steps as the single-segment step; the parts' arena slices tile [0, cut_offset) from the top down."""
-    import copy
     import dataset, layers, levels as levels_mod, retinanet, train
     lv = levels_mod.build_levels()
-    torch.manual_seed(3)
-    net_a = retinanet.RetinaNet(backbone, lv, 4, layers.elu, 0.1).to(dev)
-    net_b = copy.deepcopy(net_a)
+
+    def build():        # (twice from the same seeds; copy.deepcopy would drop the kernels' l2_scale attribute)
+        layers.Dropout._next_seed[0] = 0x5EED
+        torch.manual_seed(3)
+        return retinanet.RetinaNet(backbone, lv, 4, layers.elu, 0.1).to(dev)
+
+    net_a, net_b = build(), build()
     rng = np.random.default_rng(1)
     size = 96
     image = torch.from_numpy(rng.standard_normal((2, size, size, 3)).astype(np.float32)).to(dev)
