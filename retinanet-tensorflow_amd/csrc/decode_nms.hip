@@ -42,7 +42,7 @@ struct DetArgs {
   int64_t rows_per_image; // sum over levels
   int waves_per_image;
   // workspace
-  float* row_score; int32_t* row_class; int32_t* wave_count; int32_t* wave_off;
+  float* row_score; int32_t* row_class; int32_t* wave_count; int32_t* wave_off; unsigned long long* wave_mask;
   uint64_t* keys; uint32_t* vals_out; int32_t* seg_count; int32_t* seg_fill;
   float* cand_box; float* cand_score; int32_t* cand_class; int32_t* cand_image; int64_t* cand_anchor;
   int32_t* seg_start; int32_t* seg_keep; int32_t* seg_off; int32_t* keep_idx;
@@ -295,11 +295,13 @@ __global__ __launch_bounds__(T) void det_scan_lds_kernel(const DetArgs a, int ld
     if (lv.logit) scan_wave_lds<false, true>(a, lv, img, row0, nrow, lane, lds, &my_s, &my_c);
     else scan_wave_lds<false, false>(a, lv, img, row0, nrow, lane, lds, &my_s, &my_c);
   }
+  // only the candidates' (score, class) are kept (~1 % of the rows: sparse stores instead of 8 bytes for every row), with the
+  // wave's candidate mask: the emit pass reads 12 bytes per wave and returns at once where the mask is empty
   const bool flag = lane < nrow && my_s > a.score_thr;
   const int64_t g = (int64_t)img * a.rows_per_image + lv.row_off + row0 + lane;
-  if (lane < nrow) { a.row_score[g] = my_s; a.row_class[g] = my_c; }
+  if (flag) { a.row_score[g] = my_s; a.row_class[g] = my_c; }
   const unsigned long long m = __ballot(flag);
-  if (lane == 0) a.wave_count[wid] = __popcll(m);
+  if (lane == 0) { a.wave_count[wid] = __popcll(m); a.wave_mask[wid] = m; }
 }
 
 // the unrolled scan for ONE (storage type, logit mode, chunks per lane): registers sized for this case only.  (The
@@ -319,11 +321,13 @@ __global__ __launch_bounds__(T) void det_scan_q_kernel(const DetArgs a) {
   const void* base = reinterpret_cast<const char*>(lv.prob) + ((size_t)img * lv.rows + row0) * a.C * ESZ;
   float my_s = 0.f; int my_c = 0;
   scan_rows_unrolled<Q, HALF, LOGIT>(base, a.C, nrow, lane, &my_s, &my_c);
+  // only the candidates' (score, class) are kept (~1 % of the rows: sparse stores instead of 8 bytes for every row), with the
+  // wave's candidate mask: the emit pass reads 12 bytes per wave and returns at once where the mask is empty
   const bool flag = lane < nrow && my_s > a.score_thr;
   const int64_t g = (int64_t)img * a.rows_per_image + lv.row_off + row0 + lane;
-  if (lane < nrow) { a.row_score[g] = my_s; a.row_class[g] = my_c; }
+  if (flag) { a.row_score[g] = my_s; a.row_class[g] = my_c; }
   const unsigned long long m = __ballot(flag);
-  if (lane == 0) a.wave_count[wid] = __popcll(m);
+  if (lane == 0) { a.wave_count[wid] = __popcll(m); a.wave_mask[wid] = m; }
 }
 
 __global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
@@ -343,11 +347,13 @@ __global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
     if (lv.logit) scan_wave<false, true>(a, lv, img, row0, nrow, lane, &my_s, &my_c);
     else scan_wave<false, false>(a, lv, img, row0, nrow, lane, &my_s, &my_c);
   }
+  // only the candidates' (score, class) are kept (~1 % of the rows: sparse stores instead of 8 bytes for every row), with the
+  // wave's candidate mask: the emit pass reads 12 bytes per wave and returns at once where the mask is empty
   const bool flag = lane < nrow && my_s > a.score_thr;
   const int64_t g = (int64_t)img * a.rows_per_image + lv.row_off + row0 + lane;
-  if (lane < nrow) { a.row_score[g] = my_s; a.row_class[g] = my_c; }
+  if (flag) { a.row_score[g] = my_s; a.row_class[g] = my_c; }
   const unsigned long long m = __ballot(flag);
-  if (lane == 0) a.wave_count[wid] = __popcll(m);
+  if (lane == 0) { a.wave_count[wid] = __popcll(m); a.wave_mask[wid] = m; }
 }
 
 // exclusive scan of one int per thread across a 1024-thread block (wave shuffles + one LDS hop); returns the
@@ -464,44 +470,45 @@ __device__ __forceinline__ float4 decode_one(const float4 r, float ah, float aw,
 
 // ---- 3. emit candidates in anchor order; pad the key array with sentinels
 __global__ __launch_bounds__(T) void det_emit_kernel(const DetArgs a) {
+  // a few thousand blocks walk the waves' masks (most are empty: 12 bytes read, nothing to do) instead of one block per four
+  // waves -- 12 276 blocks of almost no work each took 37 us at the 1024^2 x 16 shape, bound by the block dispatch rate
   const int lane = threadIdx.x & 63;
-  const int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
   const int64_t nw = (int64_t)a.n * a.waves_per_image;
-  if (wid >= nw) return;
-  int img, l; int64_t row0;
-  locate_wave(a, wid, &img, &l, &row0);
-  const DetLevel& lv = a.lv[l];
-  const int nrow = (int)((lv.rows - row0) < 64 ? (lv.rows - row0) : 64);
-  const int64_t in_img = lv.row_off + row0 + lane;
-  const int64_t g = (int64_t)img * a.rows_per_image + in_img;
-  float s = 0.f; int c = 0;
-  if (lane < nrow) { s = a.row_score[g]; c = a.row_class[g]; }
-  const bool flag = lane < nrow && s > a.score_thr;
-  const unsigned long long m = __ballot(flag);
-  if (!flag) return;
-  const int64_t pos = (int64_t)a.wave_off[wid] + __popcll(m & ((1ull << lane) - 1ull));
-  if (pos >= a.cap) return;  // overflow is reported through counts[0] > capacity
-  float4 b;
-  if (lv.boxes) {
-    b = *reinterpret_cast<const float4*>(lv.boxes + ((size_t)img * lv.rows + row0 + lane) * 4);
-  } else {  // decode this candidate only
-    int64_t q = row0 + lane;
-    const int an = (int)(q % lv.A); q /= lv.A;
-    const int x_ = (int)(q % lv.w);
-    const int y_ = (int)(q / lv.w);
-    const size_t ri = ((size_t)img * lv.rows + row0 + lane) * 4;
-    float4 r;
-    if (lv.half_reg) {
-      const rn::rn_half4 h = *reinterpret_cast<const rn::rn_half4*>(reinterpret_cast<const _Float16*>(lv.reg) + ri);
-      r = make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
-    } else {
-      r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(lv.reg) + ri);
+  const int64_t stride = ((int64_t)gridDim.x * T) >> 6;
+  for (int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6; wid < nw; wid += stride) {
+    const unsigned long long m = a.wave_mask[wid];       // (wave-uniform)
+    if (m == 0ull || !((m >> lane) & 1ull)) continue;
+    int img, l; int64_t row0;
+    locate_wave(a, wid, &img, &l, &row0);
+    const DetLevel& lv = a.lv[l];
+    const int64_t in_img = lv.row_off + row0 + lane;
+    const int64_t g = (int64_t)img * a.rows_per_image + in_img;
+    const float s = a.row_score[g];
+    const int c = a.row_class[g];
+    const int64_t pos = (int64_t)a.wave_off[wid] + __popcll(m & ((1ull << lane) - 1ull));
+    if (pos >= a.cap) continue;  // overflow is reported through counts[0] > capacity
+    float4 b;
+    if (lv.boxes) {
+      b = *reinterpret_cast<const float4*>(lv.boxes + ((size_t)img * lv.rows + row0 + lane) * 4);
+    } else {  // decode this candidate only
+      int64_t q = row0 + lane;
+      const int an = (int)(q % lv.A); q /= lv.A;
+      const int x_ = (int)(q % lv.w);
+      const int y_ = (int)(q / lv.w);
+      const size_t ri = ((size_t)img * lv.rows + row0 + lane) * 4;
+      float4 r;
+      if (lv.half_reg) {
+        const rn::rn_half4 h = *reinterpret_cast<const rn::rn_half4*>(reinterpret_cast<const _Float16*>(lv.reg) + ri);
+        r = make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+      } else {
+        r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(lv.reg) + ri);
+      }
+      b = decode_one(r, lv.anch[an * 2], lv.anch[an * 2 + 1], y_, x_, lv.h, lv.w);
     }
-    b = decode_one(r, lv.anch[an * 2], lv.anch[an * 2 + 1], y_, x_, lv.h, lv.w);
+    *reinterpret_cast<float4*>(a.cand_box + pos * 4) = b;
+    a.cand_score[pos] = s; a.cand_class[pos] = c; a.cand_image[pos] = img; a.cand_anchor[pos] = in_img;
+    atomicAdd(&a.seg_count[img * a.C + c], 1);   // integer count: the same whatever the order of arrival
   }
-  *reinterpret_cast<float4*>(a.cand_box + pos * 4) = b;
-  a.cand_score[pos] = s; a.cand_class[pos] = c; a.cand_image[pos] = img; a.cand_anchor[pos] = in_img;
-  atomicAdd(&a.seg_count[img * a.C + c], 1);   // integer count: the same whatever the order of arrival
 }
 
 // order-preserving map of ANY float onto unsigned integers (scores handed to rn_nms_classwise may be <= 0)
@@ -717,13 +724,14 @@ int plan(const rn_det_level* levels, int nlevels, const rn_det_params* p, DetArg
   a->rows_per_image = rows; a->waves_per_image = waves;
   const int64_t nrows = rows * p->n, nw = (int64_t)waves * p->n, cap = p->max_candidates;
   const int64_t nseg = (int64_t)p->n * p->num_classes;
-  const size_t sizes[17] = {
+  const size_t sizes[18] = {
       (size_t)nrows * 4, (size_t)nrows * 4, (size_t)nw * 4, (size_t)nw * 4,            // row_score,row_class,wave_count,wave_off
       (size_t)cap * 8, (size_t)cap * 4, (size_t)nseg * 4, (size_t)nseg * 4,            // keys, vals_out, seg_count, seg_fill
       (size_t)cap * 16, (size_t)cap * 4, (size_t)cap * 4, (size_t)cap * 4, (size_t)cap * 8,  // cand box,score,class,image,anchor
-      (size_t)(nseg + 1) * 4, (size_t)nseg * 4, (size_t)nseg * 4, (size_t)nseg * p->max_per_class * 4};  // seg_*, keep_idx
+      (size_t)(nseg + 1) * 4, (size_t)nseg * 4, (size_t)nseg * 4, (size_t)nseg * p->max_per_class * 4,   // seg_*, keep_idx
+      (size_t)nw * 8};                                                                                    // wave_mask
   size_t o = 0;
-  for (int i = 0; i < 17; ++i) { L->off[i] = o; o += rn::align_up(sizes[i], 256); }
+  for (int i = 0; i < 18; ++i) { L->off[i] = o; o += rn::align_up(sizes[i], 256); }
   L->total = o;
   return RN_OK;
 }
@@ -739,6 +747,7 @@ void bind(DetArgs* a, const WsLayout& L, void* ws) {
   a->cand_anchor = (int64_t*)(b + L.off[12]);
   a->seg_start = (int32_t*)(b + L.off[13]); a->seg_keep = (int32_t*)(b + L.off[14]);
   a->seg_off = (int32_t*)(b + L.off[15]); a->keep_idx = (int32_t*)(b + L.off[16]);
+  a->wave_mask = (unsigned long long*)(b + L.off[17]);
 }
 }  // namespace
 
@@ -862,7 +871,7 @@ int run_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, 
   }
   hipLaunchKernelGGL(det_offsets_chunk_kernel, dim3((unsigned)((nw + 1023) / 1024)), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(det_offsets_kernel, dim3(1), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(det_emit_kernel, dim3(wblocks), dim3(T), 0, st, a);
+  hipLaunchKernelGGL(det_emit_kernel, dim3(wblocks < 2048u ? wblocks : 2048u), dim3(T), 0, st, a);
   if (decode_only) {
     hipLaunchKernelGGL(det_copy_candidates_kernel, dim3(256), dim3(256), 0, st, a);
     RN_LAUNCH_CHECK();
