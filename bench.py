@@ -41,7 +41,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # HBM bytes per launch of the roofline kernels, from THIS round's rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
 # --pmc WRITE_SIZE runs of tools/gemm_pmc.py, summarised by tools/pmc_traffic.py into this file); null when absent
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 TRAIN_GFLOP_PER_IMAGE = 239.2       # BASELINE.md section 3 (3 x forward conv FLOPs), cfg 2
 
 
@@ -183,7 +183,10 @@ def roofline_kernels(device):
         ach = work / (ms * 1e-3) / (1e12 if bound == "mfma" else 1e9)
         return {"name": name, "kernel": kernel, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                 "frac": round(ach / peak, 4), "kernel_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_,
-                "traffic": traffic.get(tkey)}
+                "traffic": traffic.get(tkey),
+                # `traffic` is NOT counted in this run: it is the PMC measurement of the same kernel and shape kept in
+                # profiles/ (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE)
+                "traffic_source": ("stored: " + os.path.basename(PMC_TRAFFIC_FILE)) if traffic.get(tkey) is not None else None}
 
     bwd = entry("head-tower layer, merged backward products (largest in-step kernel, 8 launches per step)",
                 "conv_bwd_kernel<64,64,2,2,true,64,64,2,2>: 36 x ([682x256]x[256x256]^T dgrad + [256x682]x[682x256] wgrad partials)",
@@ -496,6 +499,7 @@ def main():
                                      "allreduce_exposed_ms": round(exposed, 4)},
                        "final_class_loss": round(losses[0], 6),
                        "final_regr_loss": round(losses[1], 6),
+                       "mobilenet_chain": "rn_mb_* kernels (every GroupNorm applied by its consumer) from bottleneck_2_2 on",
                        "gn_barrier_timeouts": timeouts, "gn_grid_resident": bool(ops.GN_GRID_RESIDENT),
                        "gn_fell_back_to_launch_ordered_kernels": gn_fallback,
                        "conv_roofline_frac_whole_step": round(ips / world * TRAIN_GFLOP_PER_IMAGE / 1e3 /

@@ -27,6 +27,7 @@ def run(backbone, size, batch, steps=8, warmup=3, use_graph=True):
     def features():
         c, r, m = dataset.build_labels((size, size), cls, boxes, lv, 80, num_obj=nobj)
         return {"image": image, "detection": {"classifications": c, "regressions": r}, "trainable_masks": m}
+    features.concurrent = False        # (the assignment of `batch` independent images on the main stream, as before)
 
     trainer = train.Trainer(net, lv, loss_mode="focal", device=dev, use_graph=use_graph, input_fn=features)
     for _ in range(warmup):
@@ -36,9 +37,17 @@ def run(backbone, size, batch, steps=8, warmup=3, use_graph=True):
         trainer.step()
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     trainer.check_device_errors()
+    # the gradient all-reduce schedule a multi-GPU run would follow: heads + FPN after segment A, then one slice per backbone
+    # part (last stage first); only the LAST part's slice is reduced after the last backward kernel
+    ranges = list(trainer._graphs[2]) if (use_graph and trainer._graphs) else []
+    total = 4 * trainer.arena.count
+    after = 4 * (ranges[-1][1] - ranges[-1][0]) if ranges else 4 * trainer.cut_offset
     return {"backbone": backbone, "image_size": size, "batch": batch, "images_per_sec": round(batch * steps / el, 2),
             "ms_per_step": round(1e3 * el / steps, 2), "hip_graph": use_graph,
-            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            "backward_parts": 1 + len(ranges), "gradient_bytes": total, "bytes_after_backward": after,
+            "bytes_after_backward_frac": round(after / total, 4),
+            "allreduce_slices_MB": [round(4 * (trainer.arena.count - trainer.cut_offset) / 1e6, 1)] + [round(4 * (hi - lo) / 1e6, 1) for lo, hi in ranges]}
 
 
 if __name__ == "__main__":

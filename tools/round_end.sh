@@ -4,7 +4,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > gpurun_out/${R}_tests.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/${R}_smoke.log 2>&1
 timeout 600 python bench.py > gpurun_out/${R}_bench.log 2>&1
@@ -17,6 +17,7 @@ cp $(find gpurun_out/${R}_prof -name "bench_kernel_stats.csv" | head -1) gpurun_
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${R}_pmc_fetch -- python tools/gemm_pmc.py > gpurun_out/${R}_pmc_f.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${R}_pmc_write -- python tools/gemm_pmc.py > gpurun_out/${R}_pmc_w.log 2>&1
 python tools/pmc_traffic.py gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write > gpurun_out/${R}_pmc_traffic.json
+ROUND=$R bash tools/pmc_step.sh > gpurun_out/${R}_pmc_step.log 2>&1
 timeout 600 python tools/bench_configs.py > gpurun_out/${R}_cfgs.log 2>&1
 timeout 400 python tools/bench_inference.py > gpurun_out/${R}_inf.log 2>&1
 timeout 200 python tools/tower_bench.py 720 > gpurun_out/${R}_tower.log 2>&1
