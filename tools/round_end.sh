@@ -1,11 +1,11 @@
 #!/bin/bash
 # Round-end evidence run (GPU box): full GPU test suite, smoke, the bench line, its rocprofv3 summary, PMC traffic of the
-# roofline kernels, the other configs.  Summaries are copied into profiles/ by hand afterwards (see profiles/README.md).
+# roofline kernels, the other configs (QUICK=1: bench, profile and PMC passes only).  Summaries are copied into profiles/ by hand afterwards (see profiles/README.md).
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${ROUND:-r03}
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > gpurun_out/${R}_tests.log
+[ -z "$QUICK" ] && timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > gpurun_out/${R}_tests.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/${R}_smoke.log 2>&1
 timeout 600 python bench.py > gpurun_out/${R}_bench.log 2>&1
 rm -rf gpurun_out/${R}_prof gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write
@@ -18,9 +18,9 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpu
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${R}_pmc_write -- python tools/gemm_pmc.py > gpurun_out/${R}_pmc_w.log 2>&1
 python tools/pmc_traffic.py gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write > gpurun_out/${R}_pmc_traffic.json
 ROUND=$R bash tools/pmc_step.sh > gpurun_out/${R}_pmc_step.log 2>&1
-timeout 600 python tools/bench_configs.py > gpurun_out/${R}_cfgs.log 2>&1
-timeout 400 python tools/bench_inference.py > gpurun_out/${R}_inf.log 2>&1
-timeout 200 python tools/tower_bench.py 720 > gpurun_out/${R}_tower.log 2>&1
+[ -z "$QUICK" ] && timeout 600 python tools/bench_configs.py > gpurun_out/${R}_cfgs.log 2>&1
+[ -z "$QUICK" ] && timeout 400 python tools/bench_inference.py > gpurun_out/${R}_inf.log 2>&1
+[ -z "$QUICK" ] && timeout 200 python tools/tower_bench.py 720 > gpurun_out/${R}_tower.log 2>&1
 rm -rf gpurun_out/${R}_nms_prof
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_nms_prof -o nms -- python tools/nms_prof.py > gpurun_out/${R}_nms.log 2>&1
 python tools/by_grid.py $(find gpurun_out/${R}_nms_prof -name "nms_kernel_trace.csv" | head -1) > gpurun_out/${R}_nms_kernels_by_grid.txt
