@@ -784,6 +784,11 @@ extern "C" int rn_flush_reductions(rn_reduce_list* list, rn_stream_t stream) {
       blocks += (int)rn::ceil_div64(a.d[i].count, reduce_cols_per_block(a.d[i].nrows));
     }
     a.block_start[a.n] = blocks;
+    static const bool dump = getenv("RN_REDUCE_DBG") != nullptr;      // measurement aid: what a flush is made of
+    if (dump)
+      for (int i = 0; i < a.n; ++i)
+        fprintf(stderr, "reduce[%d] cols %lld rows %d MB %.2f blocks %d\n", first + i, (long long)a.d[i].count, a.d[i].nrows,
+                (double)a.d[i].count * a.d[i].nrows * 4e-6, a.block_start[i + 1 < a.n ? i + 1 : a.n] - a.block_start[i]);
     if (blocks > 0) hipLaunchKernelGGL(reduce_rows_many_kernel, dim3(blocks), dim3(256), 0, st, a);
   }
   RN_LAUNCH_CHECK();

@@ -412,6 +412,7 @@ struct DwFwdArgs {
   NormDev in; const float* w; float* y;
   int n, h, wd, c, stride, oh, ow, pad_t, pad_l;
   int th, tw, tiles_h, tiles_w, sw, nslab, ph, pw;
+  int tpb, nblk;     // tiles per block, blocks per (sample, slab)
   RowsDev ost; int ocpg;
 };
 constexpr int NP = 8;            // patch loads in flight per thread (the host keeps a patch at <= NP * T float4)
@@ -430,8 +431,25 @@ __device__ __forceinline__ PatchElem patch_elem(int idx, int total, int SQ, int 
   e.pix = min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1);
   return e;
 }
+// the tile-independent half of patch_elem, packed into one register per slot (the tile loops keep NP of them alive instead of
+// letting the compiler hoist three or four values per slot): q | py << 8 | px << 16 | live << 24
+__device__ __forceinline__ int patch_pack(int idx, int total, int SQ, int pw) {
+  const int i = min(idx, total - 1);
+  const int pp = i / SQ, q = i - pp * SQ;
+  const int py = pp / pw, px = pp - py * pw;
+  return q | (py << 8) | (px << 16) | (idx < total ? (1 << 24) : 0);
+}
+__device__ __forceinline__ PatchElem patch_at(int pk, int y0, int x0, int h, int w) {
+  PatchElem e;
+  e.live = (pk >> 24) != 0;
+  e.q = pk & 255;
+  const int yy = y0 + ((pk >> 8) & 255), xx = x0 + ((pk >> 16) & 255);
+  e.inside = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
+  e.pix = min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1);
+  return e;
+}
 
-template <int ACT>
+template <int ACT, bool PF>
 __global__ __launch_bounds__(T) void mb_dw_fwd_kernel(const DwFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];   // patch [ph * pw][sw]; before / after: merge and reduction scratch
   __shared__ __attribute__((aligned(16))) float tab[2 * 128];    // scale | shift of the slab's channels
@@ -441,74 +459,97 @@ __global__ __launch_bounds__(T) void mb_dw_fwd_kernel(const DwFwdArgs a) {
   const int slab = bid % a.nslab;
   const int tt = bid / a.nslab;
   const int ntile = a.tiles_h * a.tiles_w;
-  const int tile = tt % ntile, sample = tt / ntile;
-  const int oh0 = (tile / a.tiles_w) * a.th, ow0 = (tile % a.tiles_w) * a.tw;
+  // a block walks `tpb` consecutive tiles of one sample: the prologue (rows merge, tables, weights) and the final reduction
+  // are paid once, the raw patch of tile t + 1 is in flight while tile t's stencil runs
+  const int blk = tt % a.nblk, sample = tt / a.nblk;
+  const int tile_lo = blk * a.tpb, tile_hi = min(tile_lo + a.tpb, ntile);
   const int C = a.c, SW = a.sw, SQ = SW >> 2, c0 = slab * SW;
   const int g0 = c0 / a.in.cpg, ng = SW / a.in.cpg;
-  // everything from memory first: the slab's gamma / beta, the raw patch, the stencil weights
+  // everything from memory first: the slab's gamma / beta, the first raw patch, the stencil weights
   ChanPre<1> pre;
   prefetch_chan(a.in.gamma, a.in.beta, c0, SW, tid, pre);
   const GroupPre gpre = prefetch_groups(a.in, sample, g0, ng, tid);
-  const int ih0 = oh0 * a.stride - a.pad_t, iw0 = ow0 * a.stride - a.pad_l;
   const int total = a.ph * a.pw * SQ;
   // (raw buffer loads: a slot that is not part of the patch, or lies outside the image, costs no memory access)
   const __amdgpu_buffer_rsrc_t xs = make_rsrc(a.in.y + (size_t)sample * a.h * a.wd * C + c0, (unsigned)(a.h * a.wd * C - c0) * 4u);
   float4 pv[NP];
+  int pk[NP];
 #pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    const PatchElem e = patch_elem(tid + j * T, total, SQ, a.pw, ih0, iw0, a.h, a.wd);
-    pv[j] = Vec<4>::load(xs, (e.live && e.inside) ? ((unsigned)e.pix * C + e.q * 4) * 4u : OOB);
-  }
+  for (int j = 0; j < NP; ++j) pk[j] = patch_pack(tid + j * T, total, SQ, a.pw);
+  auto load_patch = [&](int tile) {
+    const int ih0 = (tile / a.tiles_w) * a.th * a.stride - a.pad_t, iw0 = (tile % a.tiles_w) * a.tw * a.stride - a.pad_l;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const PatchElem e = patch_at(pk[j], ih0, iw0, a.h, a.wd);
+      pv[j] = Vec<4>::load(xs, (e.live && e.inside) ? ((unsigned)e.pix * C + e.q * 4) * 4u : OOB);
+    }
+  };
+  load_patch(tile_lo);
   const int lanes = T / SQ, q4 = tid % SQ, pl = tid / SQ;
   float4 wv[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(a.w + (size_t)t * C + c0 + min(q4, SQ - 1) * 4);
-  group_stats(a.in, sample, a.h * a.wd, g0, ng, tile == 0, dsm, gstat, gpre, tid);
+  group_stats(a.in, sample, a.h * a.wd, g0, ng, blk == 0, dsm, gstat, gpre, tid);
   scale_shift_table(a.in, c0, SW, g0, gstat, tab, tab + 128, pre, tid);
   if (a.dbg == 1) { if (pv[0].x == 123.456f && wv[0].x == 1.f) a.y[0] = 0.f; return; }
   const bool drop = a.in.drop_rate > 0.f;
   const uint64_t seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
-  // patch -> LDS, normalised once per element; zero outside the image (SAME padding pads the ACTIVATED tensor)
   const uint64_t samp_off = (uint64_t)sample * a.h * a.wd * C;
-#pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    const PatchElem e = patch_elem(tid + j * T, total, SQ, a.pw, ih0, iw0, a.h, a.wd);
-    if (e.live) {
-      float4 o = norm_act_drop<ACT>(pv[j], *reinterpret_cast<const float4*>(&tab[e.q * 4]), *reinterpret_cast<const float4*>(&tab[128 + e.q * 4]),
-                                    a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed, samp_off + (uint64_t)e.pix * C + c0 + e.q * 4);
-      if (!e.inside) o = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(&dsm[(size_t)(tid + j * T) * 4]) = o;     // slot = pp * SQ + q: [pp][sw] rows
-    }
-  }
-  __syncthreads();
-  if (a.dbg == 2) { if (dsm[tid] == 123.456f) a.y[0] = 0.f; return; }
-  // stencil from LDS: thread = (channel quad, pixel lane)
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (pl < lanes) {
-    float* __restrict__ ys = a.y + (size_t)sample * a.oh * a.ow * C + c0 + q4 * 4;
-    for (int p = pl; p < a.th * a.tw; p += lanes) {
-      const int oy = p / a.tw, ox = p - oy * a.tw;
-      const int oh_ = oh0 + oy, ow_ = ow0 + ox;
-      if (oh_ < a.oh && ow_ < a.ow) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float* __restrict__ ys = a.y + (size_t)sample * a.oh * a.ow * C + c0 + q4 * 4;
+  auto process_tile = [&](int tile) {
+    const int oh0 = (tile / a.tiles_w) * a.th, ow0 = (tile % a.tiles_w) * a.tw;
+    const int ih0 = oh0 * a.stride - a.pad_t, iw0 = ow0 * a.stride - a.pad_l;
+    // patch -> LDS, normalised once per element; zero outside the image (SAME padding pads the ACTIVATED tensor)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const float4 xv = *reinterpret_cast<const float4*>(&dsm[((size_t)(oy * a.stride + kh) * a.pw + ox * a.stride + kw) * SW + q4 * 4]);
-            const float4 w4 = wv[kh * 3 + kw];
-            acc.x = fmaf(xv.x, w4.x, acc.x); acc.y = fmaf(xv.y, w4.y, acc.y);
-            acc.z = fmaf(xv.z, w4.z, acc.z); acc.w = fmaf(xv.w, w4.w, acc.w);
-          }
-        *reinterpret_cast<float4*>(ys + (size_t)(oh_ * a.ow + ow_) * C) = acc;
-        s1[0] += acc.x; s1[1] += acc.y; s1[2] += acc.z; s1[3] += acc.w;
-        s2[0] = fmaf(acc.x, acc.x, s2[0]); s2[1] = fmaf(acc.y, acc.y, s2[1]);
-        s2[2] = fmaf(acc.z, acc.z, s2[2]); s2[3] = fmaf(acc.w, acc.w, s2[3]);
+    for (int j = 0; j < NP; ++j) {
+      const PatchElem e = patch_at(pk[j], ih0, iw0, a.h, a.wd);
+      if (e.live) {
+        float4 o = norm_act_drop<ACT>(pv[j], *reinterpret_cast<const float4*>(&tab[e.q * 4]), *reinterpret_cast<const float4*>(&tab[128 + e.q * 4]),
+                                      a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed, samp_off + (uint64_t)e.pix * C + c0 + e.q * 4);
+        if (!e.inside) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&dsm[(size_t)(tid + j * T) * 4]) = o;     // slot = pp * SQ + q: [pp][sw] rows
       }
+    }
+    __syncthreads();
+    if (PF && tile + 1 < tile_hi) load_patch(tile + 1);
+    // stencil from LDS: thread = (channel quad, pixel lane)
+    if (pl < lanes) {
+      for (int p = pl; p < a.th * a.tw; p += lanes) {
+        const int oy = p / a.tw, ox = p - oy * a.tw;
+        const int oh_ = oh0 + oy, ow_ = ow0 + ox;
+        if (oh_ < a.oh && ow_ < a.ow) {
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const float4 xv = *reinterpret_cast<const float4*>(&dsm[((size_t)(oy * a.stride + kh) * a.pw + ox * a.stride + kw) * SW + q4 * 4]);
+              const float4 w4 = wv[kh * 3 + kw];
+              acc.x = fmaf(xv.x, w4.x, acc.x); acc.y = fmaf(xv.y, w4.y, acc.y);
+              acc.z = fmaf(xv.z, w4.z, acc.z); acc.w = fmaf(xv.w, w4.w, acc.w);
+            }
+          *reinterpret_cast<float4*>(ys + (size_t)(oh_ * a.ow + ow_) * C) = acc;
+          s1[0] += acc.x; s1[1] += acc.y; s1[2] += acc.z; s1[3] += acc.w;
+          s2[0] = fmaf(acc.x, acc.x, s2[0]); s2[1] = fmaf(acc.y, acc.y, s2[1]);
+          s2[2] = fmaf(acc.z, acc.z, s2[2]); s2[3] = fmaf(acc.w, acc.w, s2[3]);
+        }
+      }
+    }
+    __syncthreads();                               // the patch is dead: the next tile's, or the reduction scratch
+  };
+  if (PF) {
+#pragma nounroll
+    for (int tile = tile_lo; tile < tile_hi; ++tile) process_tile(tile);
+  } else {                                         // (nothing carried around the loop)
+    process_tile(tile_lo);
+#pragma nounroll
+    for (int tile = tile_lo + 1; tile < tile_hi; ++tile) {
+      load_patch(tile);
+      process_tile(tile);
     }
   }
   if (!a.ost.rows || a.dbg == 3) return;
-  __syncthreads();                                 // the patch is dead: its LDS becomes the reduction scratch
   float (*red)[8] = reinterpret_cast<float (*)[8]>(dsm);
   float (*chan)[2] = reinterpret_cast<float (*)[2]>(dsm + T * 8);
 #pragma unroll
@@ -525,7 +566,7 @@ __global__ __launch_bounds__(T) void mb_dw_fwd_kernel(const DwFwdArgs a) {
   if (tid < ong) {                                 // channels of a group in order
     float t1 = 0.f, t2 = 0.f;
     for (int j = 0; j < a.ocpg; ++j) { t1 += chan[tid * a.ocpg + j][0]; t2 += chan[tid * a.ocpg + j][1]; }
-    a.ost.rows[((size_t)sample * a.ost.R + tile) * a.ost.W + og0 + tid] = make_float2(t1, t2);
+    a.ost.rows[((size_t)sample * a.ost.R + blk) * a.ost.W + og0 + tid] = make_float2(t1, t2);
   }
 }
 
@@ -972,15 +1013,17 @@ struct DwBwdArgs {
   int n, h, wd, c, stride, oh, ow, pad_t, pad_l;
   int th, tw, tiles_h, tiles_w, sw, nslab;
   int oph, opw;      // dy patch (output pixels)
+  int tpb, nblk;     // tiles per block, blocks per (sample, slab)
 };
 
 __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
-template <int ACT>
-__global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
+template <int ACT, bool MULTI>
+__global__ __launch_bounds__(T, 2) void mb_dw_bwd_kernel(const DwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];   // a1 patch [(th+2)(tw+2)][sw] | dy patch [oph*opw][sw]
   __shared__ __attribute__((aligned(16))) float tabA[4 * 128];   // scale | shift | mean | rstd of the slab's channels (GN1)
   __shared__ __attribute__((aligned(16))) float tabD[3 * 128];   // P | Q | R (GN2)
+  __shared__ __attribute__((aligned(16))) float wtab[9 * 128];   // the slab's stencil weights [tap][sw] (registers are short here)
   __shared__ float gstat[GMAX][2];
   __shared__ float gc[GMAX][2];
   const int tid = threadIdx.x;
@@ -988,8 +1031,10 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
   const int slab = bid % a.nslab;
   const int tt = bid / a.nslab;
   const int ntile = a.tiles_h * a.tiles_w;
-  const int tile = tt % ntile, sample = tt / ntile;
-  const int ih0 = (tile / a.tiles_w) * a.th, iw0 = (tile % a.tiles_w) * a.tw;
+  // MULTI: a block walks `tpb` consecutive tiles of one sample: prologue and final reduction once (the weight-gradient sums
+  // then live across the loop, so the stencil weights move from registers to LDS)
+  const int blk = tt % a.nblk, sample = tt / a.nblk;
+  const int tile_lo = MULTI ? blk * a.tpb : blk, tile_hi = MULTI ? min(tile_lo + a.tpb, ntile) : tile_lo + 1;
   const int C = a.c, SW = a.sw, SQ = SW >> 2, c0 = slab * SW, s = a.stride;
   const int aph = a.th + 2, apw = a.tw + 2;
   float* a1p = dsm;
@@ -1001,33 +1046,44 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
   prefetch_chan<1>(a.dy.nd.gamma, nullptr, c0, SW, tid, pre_d);
   const GroupPre gp_a = prefetch_groups(a.in, sample, g0, ng, tid);
   const GroupPre gp_d = prefetch_groups(a.dy.nd, sample, g0, ng, tid);
-  const int ay0 = ih0 - a.pad_t, ax0 = iw0 - a.pad_l;
   const int atotal = aph * apw * SQ;
-  const __amdgpu_buffer_rsrc_t xs = make_rsrc(a.in.y + (size_t)sample * a.h * a.wd * C + c0, (unsigned)(a.h * a.wd * C - c0) * 4u);
-  float4 av[NP];
-#pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    const PatchElem e = patch_elem(tid + j * T, atotal, SQ, apw, ay0, ax0, a.h, a.wd);
-    av[j] = Vec<4>::load(xs, (e.live && e.inside) ? ((unsigned)e.pix * C + e.q * 4) * 4u : OOB);
-  }
-  // dy patch: output rows [oy0, +oph), cols [ox0, +opw): every output that touches the tile
-  const int oy0 = floor_div(ih0 + a.pad_t - 2 + (s - 1), s), ox0 = floor_div(iw0 + a.pad_l - 2 + (s - 1), s);
   const int dtotal = a.oph * a.opw * SQ;
+  const __amdgpu_buffer_rsrc_t xs = make_rsrc(a.in.y + (size_t)sample * a.h * a.wd * C + c0, (unsigned)(a.h * a.wd * C - c0) * 4u);
   const __amdgpu_buffer_rsrc_t gs = make_rsrc(a.dy.g + (size_t)sample * a.oh * a.ow * C + c0, (unsigned)(a.oh * a.ow * C - c0) * 4u);
   const __amdgpu_buffer_rsrc_t ys = make_rsrc(a.dy.nd.y + (size_t)sample * a.oh * a.ow * C + c0, (unsigned)(a.oh * a.ow * C - c0) * 4u);
-  float4 gv[NP], yv2[NP];
+  float4 av[NP], gv[NP], yv2[NP];
+  int pka[NP], pkd[NP];
 #pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    const PatchElem e = patch_elem(tid + j * T, dtotal, SQ, a.opw, oy0, ox0, a.oh, a.ow);
-    const unsigned off = (e.live && e.inside) ? ((unsigned)e.pix * C + e.q * 4) * 4u : OOB;
-    gv[j] = Vec<4>::load(gs, off);
-    yv2[j] = Vec<4>::load(ys, off);
-  }
+  for (int j = 0; j < NP; ++j) { pka[j] = patch_pack(tid + j * T, atotal, SQ, apw); pkd[j] = patch_pack(tid + j * T, dtotal, SQ, a.opw); }
+  auto load_patches = [&](int tile) {
+    const int ih0 = (tile / a.tiles_w) * a.th, iw0 = (tile % a.tiles_w) * a.tw;
+    const int ay0 = ih0 - a.pad_t, ax0 = iw0 - a.pad_l;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const PatchElem e = patch_at(pka[j], ay0, ax0, a.h, a.wd);
+      av[j] = Vec<4>::load(xs, (e.live && e.inside) ? ((unsigned)e.pix * C + e.q * 4) * 4u : OOB);
+    }
+    // dy patch: output rows [oy0, +oph), cols [ox0, +opw): every output that touches the tile
+    const int oy0 = floor_div(ih0 + a.pad_t - 2 + (s - 1), s), ox0 = floor_div(iw0 + a.pad_l - 2 + (s - 1), s);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const PatchElem e = patch_at(pkd[j], oy0, ox0, a.oh, a.ow);
+      const unsigned off = (e.live && e.inside) ? ((unsigned)e.pix * C + e.q * 4) * 4u : OOB;
+      gv[j] = Vec<4>::load(gs, off);
+      yv2[j] = Vec<4>::load(ys, off);
+    }
+  };
+  load_patches(tile_lo);
   const int lanes = T / SQ, q4 = tid % SQ, pl = tid / SQ;
   const bool active = pl < lanes;
   float4 wv[9];
+  if (MULTI) {
+    for (int e = tid; e < 9 * SQ; e += T)
+      *reinterpret_cast<float4*>(&wtab[(e / SQ) * 128 + (e % SQ) * 4]) = *reinterpret_cast<const float4*>(a.w + (size_t)(e / SQ) * C + c0 + (e % SQ) * 4);
+  } else {
 #pragma unroll
-  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(a.w + (size_t)t * C + c0 + min(q4, SQ - 1) * 4);
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(a.w + (size_t)t * C + c0 + q4 * 4);
+  }
   // ---- coefficient tables (the patches' LDS is the merge scratch until they are filled)
   dy_table(a.dy, sample, a.oh * a.ow, c0, SW, dsm, gstat, gc, tabD, 128, gp_d, pre_d, tid);
   group_stats(a.in, sample, a.h * a.wd, g0, ng, false, dsm, gstat, gp_a, tid);
@@ -1037,106 +1093,118 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
     tabA[256 + i] = gstat[g][0]; tabA[384 + i] = gstat[g][1];
   }
   __syncthreads();
-  if (a.dbg == 1) { if (av[0].x == 123.456f && gv[0].x == 1.f && yv2[0].x == 1.f && wv[0].x == 1.f) a.go.out[0] = 0.f; return; }
+  if (a.dbg == 1) { if (av[0].x == 123.456f && gv[0].x == 1.f && yv2[0].x == 1.f) a.go.out[0] = 0.f; return; }
   const bool drop = a.in.drop_rate > 0.f;
   const uint64_t seed = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
   const uint64_t samp_off = (uint64_t)sample * a.h * a.wd * C;
-#pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    const PatchElem e = patch_elem(tid + j * T, atotal, SQ, apw, ay0, ax0, a.h, a.wd);
-    if (e.live) {
-      float4 o = norm_act_drop<ACT>(av[j], *reinterpret_cast<const float4*>(&tabA[e.q * 4]), *reinterpret_cast<const float4*>(&tabA[128 + e.q * 4]),
-                                    a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed, samp_off + (uint64_t)e.pix * C + c0 + e.q * 4);
-      if (!e.inside) o = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(&a1p[(size_t)(tid + j * T) * 4]) = o;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    const PatchElem e = patch_elem(tid + j * T, dtotal, SQ, a.opw, oy0, ox0, a.oh, a.ow);
-    if (e.live) {
-      float4 o = dy_of(gv[j], yv2[j], tabD, 128, e.q * 4, false, 0.f, 1.f, 0ull, 0ull);
-      if (!e.inside) o = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(&dyp[(size_t)(tid + j * T) * 4]) = o;
-    }
-  }
-  __syncthreads();
-  if (a.dbg == 2) { if (dsm[tid] == 123.456f) a.go.out[0] = 0.f; return; }
-  // ---- data gradient of the tile's pixels, then g1 and its sums
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (active) {
-    const float4 sc = *reinterpret_cast<const float4*>(&tabA[q4 * 4]), sh = *reinterpret_cast<const float4*>(&tabA[128 + q4 * 4]);
-    const float4 mn = *reinterpret_cast<const float4*>(&tabA[256 + q4 * 4]), rs = *reinterpret_cast<const float4*>(&tabA[384 + q4 * 4]);
-    const float* __restrict__ y1 = a.in.y + (size_t)sample * a.h * a.wd * C + c0 + q4 * 4;
-    float* __restrict__ go = a.go.out + (size_t)sample * a.h * a.wd * C + c0 + q4 * 4;
-    for (int p = pl; p < a.th * a.tw; p += lanes) {
-      const int ty = p / a.tw, tx = p - ty * a.tw;
-      const int ih = ih0 + ty, iw = iw0 + tx;
-      if (ih < a.h && iw < a.wd) {
-        const float4 yv = *reinterpret_cast<const float4*>(y1 + (size_t)(ih * a.wd + iw) * C);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int ohs = ih + a.pad_t - kh;
-          const int oh_ = ohs / s;                         // (ohs < 0 only with a 0 weight: see m below)
-          const bool rok = ohs >= 0 && oh_ * s == ohs && oh_ < a.oh;
-          const int py = min(max(oh_ - oy0, 0), a.oph - 1);
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int ows = iw + a.pad_l - kw;
-            const int ow_ = ows / s;
-            const float m = (rok && ows >= 0 && ow_ * s == ows && ow_ < a.ow) ? 1.f : 0.f;
-            const int px = min(max(ow_ - ox0, 0), a.opw - 1);
-            const float4 dv = *reinterpret_cast<const float4*>(&dyp[((size_t)py * a.opw + px) * SW + q4 * 4]);
-            const float4 w4 = wv[kh * 3 + kw];
-            acc.x = fmaf(dv.x * m, w4.x, acc.x); acc.y = fmaf(dv.y * m, w4.y, acc.y);
-            acc.z = fmaf(dv.z * m, w4.z, acc.z); acc.w = fmaf(dv.w * m, w4.w, acc.w);
-          }
-        }
-        const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, dd[4] = {acc.x, acc.y, acc.z, acc.w};
-        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-        const float mnv[4] = {mn.x, mn.y, mn.z, mn.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
-        float g[4], mk[4] = {1.f, 1.f, 1.f, 1.f};
-        if (drop) keep4(seed, samp_off + (uint64_t)(ih * a.wd + iw) * C + c0 + q4 * 4, a.in.drop_rate, a.in.keep_scale, mk);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float z = fmaf(yy[j], scv[j], shv[j]);
-          const float xh = (yy[j] - mnv[j]) * rsv[j];
-          const float t = dd[j] * actgrad_of<ACT>(z, a.in.act) * mk[j];
-          g[j] = t;
-          s1[j] += t; s2[j] = fmaf(t, xh, s2[j]);
-        }
-        *reinterpret_cast<float4*>(go + (size_t)(ih * a.wd + iw) * C) = make_float4(g[0], g[1], g[2], g[3]);
-      }
-    }
-  }
-  if (a.dbg == 3) return;
-  // ---- weight-gradient partial sums over the owned outputs (window origin inside the tile)
   float4 wacc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wacc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (active) {
-    const int noy = (a.th + s - 1) / s, nox = (a.tw + s - 1) / s;      // tiles are aligned to the stride (host)
-    const int oyb = ih0 / s, oxb = iw0 / s;
-    for (int p = pl; p < noy * nox; p += lanes) {
-      const int ty = p / nox, tx = p - ty * nox;
-      const int oh_ = oyb + ty, ow_ = oxb + tx;
-      if (oh_ < a.oh && ow_ < a.ow) {
-        const float4 dv = *reinterpret_cast<const float4*>(&dyp[((size_t)(oh_ - oy0) * a.opw + (ow_ - ox0)) * SW + q4 * 4]);
+  const float* __restrict__ y1 = a.in.y + (size_t)sample * a.h * a.wd * C + c0 + q4 * 4;
+  float* __restrict__ go = a.go.out + (size_t)sample * a.h * a.wd * C + c0 + q4 * 4;
+  auto process_tile = [&](int tile) {
+    const int ih0 = (tile / a.tiles_w) * a.th, iw0 = (tile % a.tiles_w) * a.tw;
+    const int ay0 = ih0 - a.pad_t, ax0 = iw0 - a.pad_l;
+    const int oy0 = floor_div(ih0 + a.pad_t - 2 + (s - 1), s), ox0 = floor_div(iw0 + a.pad_l - 2 + (s - 1), s);
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            // input pixel (oh s - pad_t + kh, ..) in a1-patch coordinates (origin ih0 - pad_t)
-            const float4 xv = *reinterpret_cast<const float4*>(&a1p[((size_t)(ty * s + kh) * apw + tx * s + kw) * SW + q4 * 4]);
-            float4& t = wacc[kh * 3 + kw];
-            t.x = fmaf(xv.x, dv.x, t.x); t.y = fmaf(xv.y, dv.y, t.y); t.z = fmaf(xv.z, dv.z, t.z); t.w = fmaf(xv.w, dv.w, t.w);
-          }
+    for (int j = 0; j < NP; ++j) {
+      const PatchElem e = patch_at(pka[j], ay0, ax0, a.h, a.wd);
+      if (e.live) {
+        float4 o = norm_act_drop<ACT>(av[j], *reinterpret_cast<const float4*>(&tabA[e.q * 4]), *reinterpret_cast<const float4*>(&tabA[128 + e.q * 4]),
+                                      a.in.act, drop, a.in.drop_rate, a.in.keep_scale, seed, samp_off + (uint64_t)e.pix * C + c0 + e.q * 4);
+        if (!e.inside) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&a1p[(size_t)(tid + j * T) * 4]) = o;
       }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const PatchElem e = patch_at(pkd[j], oy0, ox0, a.oh, a.ow);
+      if (e.live) {
+        float4 o = dy_of(gv[j], yv2[j], tabD, 128, e.q * 4, false, 0.f, 1.f, 0ull, 0ull);
+        if (!e.inside) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&dyp[(size_t)(tid + j * T) * 4]) = o;
+      }
+    }
+    __syncthreads();
+    // ---- data gradient of the tile's pixels, then g1 and its sums
+    if (active) {
+      const float4 sc = *reinterpret_cast<const float4*>(&tabA[q4 * 4]), sh = *reinterpret_cast<const float4*>(&tabA[128 + q4 * 4]);
+      const float4 mn = *reinterpret_cast<const float4*>(&tabA[256 + q4 * 4]), rs = *reinterpret_cast<const float4*>(&tabA[384 + q4 * 4]);
+      for (int p = pl; p < a.th * a.tw; p += lanes) {
+        const int ty = p / a.tw, tx = p - ty * a.tw;
+        const int ih = ih0 + ty, iw = iw0 + tx;
+        if (ih < a.h && iw < a.wd) {
+          const float4 yv = *reinterpret_cast<const float4*>(y1 + (size_t)(ih * a.wd + iw) * C);
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const int ohs = ih + a.pad_t - kh;
+            const int oh_ = ohs / s;                         // (ohs < 0 only with a 0 weight: see m below)
+            const bool rok = ohs >= 0 && oh_ * s == ohs && oh_ < a.oh;
+            const int py = min(max(oh_ - oy0, 0), a.oph - 1);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const int ows = iw + a.pad_l - kw;
+              const int ow_ = ows / s;
+              const float m = (rok && ows >= 0 && ow_ * s == ows && ow_ < a.ow) ? 1.f : 0.f;
+              const int px = min(max(ow_ - ox0, 0), a.opw - 1);
+              const float4 dv = *reinterpret_cast<const float4*>(&dyp[((size_t)py * a.opw + px) * SW + q4 * 4]);
+              const float4 w4 = MULTI ? *reinterpret_cast<const float4*>(&wtab[(kh * 3 + kw) * 128 + q4 * 4]) : wv[kh * 3 + kw];
+              acc.x = fmaf(dv.x * m, w4.x, acc.x); acc.y = fmaf(dv.y * m, w4.y, acc.y);
+              acc.z = fmaf(dv.z * m, w4.z, acc.z); acc.w = fmaf(dv.w * m, w4.w, acc.w);
+            }
+          }
+          const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, dd[4] = {acc.x, acc.y, acc.z, acc.w};
+          const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+          const float mnv[4] = {mn.x, mn.y, mn.z, mn.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+          float g[4], mk[4] = {1.f, 1.f, 1.f, 1.f};
+          if (drop) keep4(seed, samp_off + (uint64_t)(ih * a.wd + iw) * C + c0 + q4 * 4, a.in.drop_rate, a.in.keep_scale, mk);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float z = fmaf(yy[j], scv[j], shv[j]);
+            const float xh = (yy[j] - mnv[j]) * rsv[j];
+            const float t = dd[j] * actgrad_of<ACT>(z, a.in.act) * mk[j];
+            g[j] = t;
+            s1[j] += t; s2[j] = fmaf(t, xh, s2[j]);
+          }
+          *reinterpret_cast<float4*>(go + (size_t)(ih * a.wd + iw) * C) = make_float4(g[0], g[1], g[2], g[3]);
+        }
+      }
+    }
+    // ---- weight-gradient partial sums over the owned outputs (window origin inside the tile)
+    if (active) {
+      const int noy = (a.th + s - 1) / s, nox = (a.tw + s - 1) / s;      // tiles are aligned to the stride (host)
+      const int oyb = ih0 / s, oxb = iw0 / s;
+      for (int p = pl; p < noy * nox; p += lanes) {
+        const int ty = p / nox, tx = p - ty * nox;
+        const int oh_ = oyb + ty, ow_ = oxb + tx;
+        if (oh_ < a.oh && ow_ < a.ow) {
+          const float4 dv = *reinterpret_cast<const float4*>(&dyp[((size_t)(oh_ - oy0) * a.opw + (ow_ - ox0)) * SW + q4 * 4]);
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              // input pixel (oh s - pad_t + kh, ..) in a1-patch coordinates (origin ih0 - pad_t)
+              const float4 xv = *reinterpret_cast<const float4*>(&a1p[((size_t)(ty * s + kh) * apw + tx * s + kw) * SW + q4 * 4]);
+              float4& t = wacc[kh * 3 + kw];
+              t.x = fmaf(xv.x, dv.x, t.x); t.y = fmaf(xv.y, dv.y, t.y); t.z = fmaf(xv.z, dv.z, t.z); t.w = fmaf(xv.w, dv.w, t.w);
+            }
+        }
+      }
+    }
+    __syncthreads();                               // the patches are dead: the next tile's, or the reduction scratch
+  };
+  // (no loads carried around the loop: ~100 loop-carried registers are copied at the back edge, which doubled them)
+  process_tile(tile_lo);
+  if (MULTI) {
+#pragma nounroll
+    for (int tile = tile_lo + 1; tile < tile_hi; ++tile) {
+      load_patches(tile);
+      process_tile(tile);
     }
   }
   if (a.dbg == 4) { if (wacc[0].x == 123.456f && s1[0] == 1.f) a.go.out[0] = 0.f; return; }
-  __syncthreads();                                 // the patches are dead: their LDS becomes the reduction scratch
   // one exchange for all nine taps and both statistics: red[thread][36 + 8], then (tap, channel) outputs over the pixel lanes
   constexpr int RW = 44;
   float* red = dsm;
@@ -1149,7 +1217,7 @@ __global__ __launch_bounds__(T) void mb_dw_bwd_kernel(const DwBwdArgs a) {
   for (int j = 0; j < 4; ++j) { red[tid * RW + 36 + j] = s1[j]; red[tid * RW + 40 + j] = s2[j]; }
   __syncthreads();
   float* chan = dsm + T * RW;                       // [sw][2]
-  const int brow = sample * ntile + tile;
+  const int brow = sample * a.nblk + blk;
   for (int e = tid; e < 11 * SW; e += T) {          // 9 taps + 2 statistics, channel fastest; pixel lanes in order
     const int k = e / SW, ch = e - k * SW;
     const int qd = ch >> 2, comp = ch & 3;
@@ -1237,7 +1305,15 @@ int dw_slab(int c, int cpg) {
   return c <= 128 ? c : 0;
 }
 
-struct DwPlan { int th, tw, tiles_h, tiles_w, sw, nslab, ph, pw; };
+struct DwPlan { int th, tw, tiles_h, tiles_w, sw, nslab, ph, pw, tpb, nblk; };
+// tiles per block of the depthwise kernels: about two blocks per CU (RN_MB_DW_TPB overrides: measurements)
+int dw_tiles_per_block(long blocks, int ntile) {
+  static const int forced = getenv("RN_MB_DW_TPB") ? atoi(getenv("RN_MB_DW_TPB")) : 0;
+  int tpb = forced > 0 ? forced : (int)(blocks / 512);
+  if (tpb < 1) tpb = 1;
+  if (tpb > ntile) tpb = ntile;
+  return tpb;
+}
 bool dw_plan(int n, int oh, int ow, int c, int stride, int cpg, DwPlan* p) {
   p->sw = dw_slab(c, cpg);
   if (!p->sw) return false;
@@ -1254,6 +1330,8 @@ bool dw_plan(int n, int oh, int ow, int c, int stride, int cpg, DwPlan* p) {
   p->th = th; p->tw = tw;
   p->tiles_h = rn::ceil_div(oh, th); p->tiles_w = rn::ceil_div(ow, tw);
   p->ph = (th - 1) * stride + 3; p->pw = (tw - 1) * stride + 3;
+  p->tpb = dw_tiles_per_block(blocks(), p->tiles_h * p->tiles_w);
+  p->nblk = rn::ceil_div(p->tiles_h * p->tiles_w, p->tpb);
   return true;
 }
 size_t dw_lds_bytes(const DwPlan& p) {
@@ -1339,7 +1417,7 @@ extern "C" size_t rn_mb_depthwise_rows(int n, int h, int w, int c, int stride, i
   rn::same_pad(w, 3, stride, &ow, &pl);
   DwPlan p;
   if (!dw_plan(n, oh, ow, c, stride, c / groups, &p)) return 0;
-  const int R = p.tiles_h * p.tiles_w;
+  const int R = p.nblk;
   if (layout) { layout->rows_per_sample = R; layout->width = groups; layout->bn = c; }
   return (size_t)n * R * groups * 8;
 }
@@ -1360,6 +1438,7 @@ extern "C" int rn_mb_depthwise_fwd(const rn_mb_norm* in, const float* w, float* 
   RN_UNSUPPORTED(stat_out && stat_groups != in->groups, "mb depthwise fwd: the GroupNorms around a depthwise conv share their grouping");
   RN_UNSUPPORTED(!dw_plan(n, a.oh, a.ow, c, stride, a.in.cpg, &p), "mb depthwise fwd: no channel slab for c=%d groups=%d", c, in->groups);
   a.th = p.th; a.tw = p.tw; a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.sw = p.sw; a.nslab = p.nslab; a.ph = p.ph; a.pw = p.pw;
+  a.tpb = p.tpb; a.nblk = p.nblk;
   if (stat_out) {
     rn_mb_rows want = {};
     RN_UNSUPPORTED(!rn_mb_depthwise_rows(n, h, wd, c, stride, stat_groups, &want), "mb depthwise fwd: this shape cannot emit rows");
@@ -1370,11 +1449,13 @@ extern "C" int rn_mb_depthwise_fwd(const rn_mb_norm* in, const float* w, float* 
   }
   const size_t lds = dw_lds_bytes(p);
   RN_UNSUPPORTED(lds > 64 * 1024, "mb depthwise fwd: patch of %zu bytes", lds);
-  const dim3 grid((unsigned)((long)n * p.tiles_h * p.tiles_w * p.nslab));
+  const dim3 grid((unsigned)((long)n * p.nblk * p.nslab));
   hipStream_t st = (hipStream_t)stream;
-  if (in->act == RN_ACT_ELU) hipLaunchKernelGGL(mb_dw_fwd_kernel<RN_ACT_ELU>, grid, dim3(T), lds, st, a);
-  else if (in->act == RN_ACT_RELU6) hipLaunchKernelGGL(mb_dw_fwd_kernel<RN_ACT_RELU6>, grid, dim3(T), lds, st, a);
-  else hipLaunchKernelGGL(mb_dw_fwd_kernel<-1>, grid, dim3(T), lds, st, a);
+  static const bool pf = !(getenv("RN_MB_DW_NO_PF") && atoi(getenv("RN_MB_DW_NO_PF")));
+  if (in->act == RN_ACT_ELU && pf && p.tpb > 1) hipLaunchKernelGGL((mb_dw_fwd_kernel<RN_ACT_ELU, true>), grid, dim3(T), lds, st, a);
+  else if (in->act == RN_ACT_ELU) hipLaunchKernelGGL((mb_dw_fwd_kernel<RN_ACT_ELU, false>), grid, dim3(T), lds, st, a);
+  else if (in->act == RN_ACT_RELU6) hipLaunchKernelGGL((mb_dw_fwd_kernel<RN_ACT_RELU6, false>), grid, dim3(T), lds, st, a);
+  else hipLaunchKernelGGL((mb_dw_fwd_kernel<-1, false>), grid, dim3(T), lds, st, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
@@ -1456,7 +1537,7 @@ void pw_wgrad_plan(int n, int hw, int cin, int cout, int pb, int ks, int* chunk,
     if (units % d == 0) best = d;
   *sps = best; *chunk = hw / best;
 }
-struct DwBwdPlan { int th, tw, tiles_h, tiles_w, sw, nslab, oph, opw; };
+struct DwBwdPlan { int th, tw, tiles_h, tiles_w, sw, nslab, oph, opw, tpb, nblk; };
 bool dw_bwd_plan(int n, int h, int w, int c, int stride, int cpg, DwBwdPlan* p) {
   p->sw = dw_slab(c, cpg);
   if (!p->sw) return false;
@@ -1470,6 +1551,8 @@ bool dw_bwd_plan(int n, int h, int w, int c, int stride, int cpg, DwBwdPlan* p) 
   p->tiles_h = rn::ceil_div(h, th); p->tiles_w = rn::ceil_div(w, tw);
   p->oph = th / stride + 2; p->opw = tw / stride + 2;
   if ((long)(th + 2) * (tw + 2) * (p->sw / 4) > NP * T || (long)p->oph * p->opw * (p->sw / 4) > NP * T) return false;
+  p->tpb = dw_tiles_per_block(blocks(), p->tiles_h * p->tiles_w);
+  p->nblk = rn::ceil_div(p->tiles_h * p->tiles_w, p->tpb);
   return true;
 }
 size_t dw_bwd_lds_bytes(const DwBwdPlan& p) {
@@ -1553,7 +1636,7 @@ extern "C" size_t rn_mb_depthwise_bwd_rows(int n, int h, int w, int c, int strid
   if (n < 1 || h < 1 || w < 1 || c < 4 || c % 4 || groups < 1 || c % groups || (stride != 1 && stride != 2)) return 0;
   DwBwdPlan p;
   if (!dw_bwd_plan(n, h, w, c, stride, c / groups, &p)) return 0;
-  const int R = p.tiles_h * p.tiles_w;
+  const int R = p.nblk;
   if (layout) { layout->rows_per_sample = R; layout->width = groups; layout->bn = c; }
   return (size_t)n * R * groups * 8;
 }
@@ -1583,11 +1666,12 @@ extern "C" int rn_mb_depthwise_bwd(const rn_mb_norm* in, const rn_mb_dy* dy, con
   DwBwdPlan p;
   RN_UNSUPPORTED(!dw_bwd_plan(n, h, wd, c, stride, a.in.cpg, &p), "mb depthwise bwd: no channel slab for c=%d groups=%d", c, in->groups);
   a.th = p.th; a.tw = p.tw; a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.sw = p.sw; a.nslab = p.nslab; a.oph = p.oph; a.opw = p.opw;
+  a.tpb = p.tpb; a.nblk = p.nblk;
   rn_mb_rows want = {};
   RN_UNSUPPORTED(!rn_mb_depthwise_bwd_rows(n, h, wd, c, stride, in->groups, &want), "mb depthwise bwd: this shape cannot emit gradient rows");
   if (int e = fill_gout(gout, &a.go, n, c, want, "mb depthwise bwd")) return e;
   RN_CHECK_ARG(gout->norm->y == in->y, "mb depthwise bwd: gout->norm is the block of `in`");
-  const int nrows = n * p.tiles_h * p.tiles_w;
+  const int nrows = n * p.nblk;
   const size_t need = (size_t)nrows * 9 * c * sizeof(float);
   if (workspace_bytes < need) { rn::set_error("mb depthwise bwd: workspace %zu < %zu bytes", workspace_bytes, need); return RN_EWORKSPACE; }
   a.partial = (float*)workspace;
@@ -1595,9 +1679,10 @@ extern "C" int rn_mb_depthwise_bwd(const rn_mb_norm* in, const rn_mb_dy* dy, con
   RN_UNSUPPORTED(lds > 64 * 1024, "mb depthwise bwd: patches of %zu bytes", lds);
   const dim3 grid((unsigned)((long)nrows * p.nslab));
   hipStream_t st = (hipStream_t)stream;
-  if (in->act == RN_ACT_ELU) hipLaunchKernelGGL(mb_dw_bwd_kernel<RN_ACT_ELU>, grid, dim3(T), lds, st, a);
-  else if (in->act == RN_ACT_RELU6) hipLaunchKernelGGL(mb_dw_bwd_kernel<RN_ACT_RELU6>, grid, dim3(T), lds, st, a);
-  else hipLaunchKernelGGL(mb_dw_bwd_kernel<-1>, grid, dim3(T), lds, st, a);
+  if (in->act == RN_ACT_ELU && p.tpb == 1) hipLaunchKernelGGL((mb_dw_bwd_kernel<RN_ACT_ELU, false>), grid, dim3(T), lds, st, a);
+  else if (in->act == RN_ACT_ELU) hipLaunchKernelGGL((mb_dw_bwd_kernel<RN_ACT_ELU, true>), grid, dim3(T), lds, st, a);
+  else if (in->act == RN_ACT_RELU6) hipLaunchKernelGGL((mb_dw_bwd_kernel<RN_ACT_RELU6, true>), grid, dim3(T), lds, st, a);
+  else hipLaunchKernelGGL((mb_dw_bwd_kernel<-1, true>), grid, dim3(T), lds, st, a);
   RN_LAUNCH_CHECK();
   return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)9 * c, nrows, 0, st);
 }
