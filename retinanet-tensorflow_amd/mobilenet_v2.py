@@ -37,10 +37,11 @@ _TAP_AFTER = {'bottleneck_1_1': 'C1', 'bottleneck_2_2': 'C2', 'bottleneck_3_3': 
 # layer's shape qualifies (maps whose statistic rows a consumer block can merge: <= 128 x 128 at the headline size); the
 # bottlenecks in front of it run layer by layer.  RN_MB_CHAIN=0: layer by layer everywhere.
 MB_CHAIN = os.environ.get("RN_MB_CHAIN", "1") == "1"
-# Maps of more than this many pixels per sample stay on the layer-by-layer path.  The chain CAN take them (their statistic
-# rows go through rn_mb_compact_rows first; RN_MB_CHAIN_MAX_HW=0 lifts the limit, tests/test_gpu_mbchain.py runs it), but
-# measured on the headline step its 256 x 256 kernels are no faster than the layer-by-layer ones (420 vs 421 images/s).
-MB_CHAIN_MAX_HW = int(os.environ.get("RN_MB_CHAIN_MAX_HW", 16384))
+# Maps of more than this many pixels per sample stay on the layer-by-layer path; 0 = no limit (the default since the
+# depthwise kernels walk several tiles per block on big maps: 427 vs 423 images/s with the 256 x 256 maps in the chain; their
+# statistic rows go through rn_mb_compact_rows first).  RN_MB_CHAIN_MAX_HW=16384: the round-3 first version (chain from
+# bottleneck_2_2 on).
+MB_CHAIN_MAX_HW = int(os.environ.get("RN_MB_CHAIN_MAX_HW", 0))
 
 
 class DepthwiseConv2D(L.DepthwiseConv2D):

@@ -87,8 +87,7 @@ def test_chain_matches_oracle(dev, size, batch, big, monkeypatch):
     vs the oracle (dropout 0): outputs 1e-4, gradients 5e-4 of max(|g|, 1e-3 x the largest gradient).  big: the chain also
     takes the 256 x 256 maps (their statistic rows go through rn_mb_compact_rows)."""
     import mobilenet_v2
-    if big:
-        monkeypatch.setattr(mobilenet_v2, "MB_CHAIN_MAX_HW", 0)
+    monkeypatch.setattr(mobilenet_v2, "MB_CHAIN_MAX_HW", 0 if big else 16384)   # (0 = the default: the whole backbone)
     bb, params = _backbone(dev, 0.0)
     rng = np.random.default_rng(size)
     x = torch.from_numpy(rng.standard_normal((batch, size, size, 3)).astype(np.float32))
