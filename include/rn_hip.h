@@ -399,7 +399,8 @@ typedef struct rn_loss_seg {
 
 /* stats layout (float32, device): [0]=class_loss [1]=regr_loss [2]=M (trainable rows)
  * [3]=#fg [4]=sum bce [5]=sum focal [6]=sum huber [7]=reserved, then per class c:
- * [8+3c]=I_c=sum l*sigmoid, [9+3c]=L_c=sum l, [10+3c]=P_c=sum sigmoid. */
+ * [8+3c]=I_c=sum l*sigmoid, [9+3c]=L_c=sum l, [10+3c]=P_c=sum sigmoid (the dice term's sums: RN_LOSS_BCE_DICE; in
+ * RN_LOSS_FOCAL mode, which does not use them, they may be zero). */
 #define RN_LOSS_STATS_HEADER 8
 size_t rn_loss_workspace(const rn_loss_seg* segs, int nseg, int num_classes);
 /* class_loss_out / regr_loss_out (optional, one float each): the two losses also as stand-alone device scalars */

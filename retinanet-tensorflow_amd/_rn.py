@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librn_hip.so")
+LIB_PATH = os.environ.get("RN_LIB_PATH") or os.path.join(_HERE, "librn_hip.so")   # (RN_LIB_PATH: A/B measurements of two builds on one box)
 
 MAX_SEG = 16
 ACT = {None: 0, "none": 0, "linear": 0, "relu": 1, "elu": 2, "relu6": 3, "sigmoid": 4}

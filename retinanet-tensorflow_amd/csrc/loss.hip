@@ -110,6 +110,186 @@ __global__ __launch_bounds__(T) void loss_reduce_kernel(const LossArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// C % 4 == 0, C <= 128 (the COCO / VOC class counts): FOUR lanes per row, 16 rows per wave and pass.  Lane (row, j) owns the
+// class quads j, j + 4, ..: NK 16-byte loads of the logits and NK of the labels, all issued before the first is used, two
+// row groups per pass (4 NK loads in flight per lane); the row's four lanes also are the four box coordinates.  The
+// wave-per-row kernels above read 4 bytes per lane with one row in flight per wave: 44 us for 63 MB at the headline shape.
+// Same sums (other order), same `partial` layout.
+constexpr int RPW = 16;          // rows per wave and pass
+template <int NK, int MODE>
+__global__ __launch_bounds__(T) void loss_reduce4_kernel(const LossArgs a) {
+  __shared__ float red[WAVES][NSCAL + 3 * 16 * NK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = a.C, CQ = C >> 2, j = lane & 3, r16 = lane >> 2;
+  float I[NK][4], L[NK][4], P[NK][4];
+#pragma unroll
+  for (int k = 0; k < NK; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) I[k][e] = L[k][e] = P[k][e] = 0.f;
+  float s_m = 0.f, s_fg = 0.f, s_cls = 0.f, s_hub = 0.f;
+  const int64_t ngroups = (a.total_rows + RPW - 1) / RPW;
+  const int64_t wave_id = (int64_t)blockIdx.x * WAVES + wave, nwaves = (int64_t)gridDim.x * WAVES;
+  for (int64_t g0 = wave_id * 2; g0 < ngroups; g0 += nwaves * 2) {
+    float4 z[2][NK], l[2][NK];
+    float rl[2], rp[2], tmv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = min((g0 + u) * RPW + r16, a.total_rows - 1);
+      const bool live = (g0 + u) * RPW + r16 < a.total_rows;
+      const LossSeg& sg = a.seg[seg_of_row(a, r)];
+      const int64_t lr = r - sg.row_start;
+      tmv[u] = (live && sg.tm[lr]) ? 1.f : 0.f;
+      rl[u] = sg.rl[lr * 4 + j]; rp[u] = sg.rp[lr * 4 + j];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int q = min(j + 4 * k, CQ - 1);
+        z[u][k] = *reinterpret_cast<const float4*>(sg.zl + lr * C + q * 4);
+        l[u][k] = *reinterpret_cast<const float4*>(sg.ll + lr * C + q * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float lmax = -1e30f, cls = 0.f;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const float w = (j + 4 * k < CQ) ? tmv[u] : 0.f;        // 0: the quad does not exist, or the row is not trainable
+        const float zz[4] = {z[u][k].x, z[u][k].y, z[u][k].z, z[u][k].w}, ll[4] = {l[u][k].x, l[u][k].y, l[u][k].z, l[u][k].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float zv = zz[e], lv = ll[e];
+          const float p = sigmoidf(zv);
+          if (j + 4 * k < CQ) lmax = fmaxf(lmax, lv);
+          if (MODE == RN_LOSS_BCE_DICE) {
+            I[k][e] = fmaf(w, lv * p, I[k][e]); L[k][e] = fmaf(w, lv, L[k][e]); P[k][e] = fmaf(w, p, P[k][e]);
+            cls = fmaf(w, fmaxf(zv, 0.f) - zv * lv + log1pf(expf(-fabsf(zv))), cls);
+          } else {
+            const bool pos = (lv == 1.f);
+            const float pt = pos ? p : 1.f - p;
+            const float al = pos ? 0.25f : 0.75f;
+            const float om = 1.f - pt;
+            cls = fmaf(w, -al * om * om * logf(pt + 1e-7f), cls);
+          }
+        }
+      }
+      lmax = fmaxf(lmax, __shfl_xor(lmax, 1, 64));
+      lmax = fmaxf(lmax, __shfl_xor(lmax, 2, 64));
+      const float fg = (lmax > 0.5f) ? tmv[u] : 0.f;
+      s_cls += cls;
+      if (j == 0) { s_m += tmv[u]; s_fg += fg; }
+      s_hub = fmaf(fg, huber1(rl[u] - rp[u]), s_hub);
+    }
+  }
+  s_m = rn::wave_sum(s_m); s_fg = rn::wave_sum(s_fg); s_cls = rn::wave_sum(s_cls); s_hub = rn::wave_sum(s_hub);
+  if (lane == 0) {
+    red[wave][0] = s_m; red[wave][1] = s_fg;
+    red[wave][2] = MODE == RN_LOSS_BCE_DICE ? s_cls : 0.f; red[wave][3] = MODE == RN_LOSS_BCE_DICE ? 0.f : s_cls;
+    red[wave][4] = s_hub;
+  }
+  // per-class sums (the dice term's; the focal mode neither needs nor forms them: zeros): over the 16 row lanes that share j
+#pragma unroll
+  for (int k = 0; k < NK; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float vi = I[k][e], vl = L[k][e], vp = P[k][e];
+      if (MODE == RN_LOSS_BCE_DICE) {
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) { vi += __shfl_xor(vi, m, 64); vl += __shfl_xor(vl, m, 64); vp += __shfl_xor(vp, m, 64); }
+      }
+      const int c = 4 * (j + 4 * k) + e;
+      if (lane < 4 && j + 4 * k < CQ) { red[wave][NSCAL + 3 * c + 0] = vi; red[wave][NSCAL + 3 * c + 1] = vl; red[wave][NSCAL + 3 * c + 2] = vp; }
+    }
+  __syncthreads();
+  const int n = NSCAL + 3 * C;
+  for (int i = tid; i < n; i += T) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += red[w][i];
+    a.partial[(size_t)blockIdx.x * n + i] = v;
+  }
+}
+
+template <int NK, int MODE>
+__global__ __launch_bounds__(T) void loss_grad4_kernel(const LossArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = a.C, CQ = C >> 2, j = lane & 3, r16 = lane >> 2;
+  const float M = a.stats[2], nfg = a.stats[3];
+  const float gc = a.g_cls[0], gr = a.g_reg[0];
+  const float k_bce = gc / (M * (float)C);
+  const float k_dice = gc * 2.f / (float)C;
+  const float k_focal = gc / fmaxf(nfg, 1.f);
+  const float k_reg = nfg > 0.f ? gr / (4.f * nfg) : 0.f;
+  float Ic[NK][4], Uc[NK][4];
+  if (MODE == RN_LOSS_BCE_DICE) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = min(4 * (j + 4 * k) + e, C - 1);
+        Ic[k][e] = a.stats[RN_LOSS_STATS_HEADER + 3 * c];
+        Uc[k][e] = a.stats[RN_LOSS_STATS_HEADER + 3 * c + 1] + a.stats[RN_LOSS_STATS_HEADER + 3 * c + 2];
+      }
+  }
+  const int64_t ngroups = (a.total_rows + RPW - 1) / RPW;
+  const int64_t wave_id = (int64_t)blockIdx.x * WAVES + wave, nwaves = (int64_t)gridDim.x * WAVES;
+  for (int64_t g0 = wave_id * 2; g0 < ngroups; g0 += nwaves * 2) {
+    float4 z[2][NK], l[2][NK];
+    float rl[2], rp[2], tmv[2];
+    float* dzp[2]; float* drp[2]; bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = min((g0 + u) * RPW + r16, a.total_rows - 1);
+      live[u] = (g0 + u) * RPW + r16 < a.total_rows;
+      const LossSeg& sg = a.seg[seg_of_row(a, r)];
+      const int64_t lr = r - sg.row_start;
+      tmv[u] = (live[u] && sg.tm[lr]) ? 1.f : 0.f;
+      rl[u] = sg.rl[lr * 4 + j]; rp[u] = sg.rp[lr * 4 + j];
+      dzp[u] = sg.dz + lr * C; drp[u] = sg.dr + lr * 4 + j;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int q = min(j + 4 * k, CQ - 1);
+        z[u][k] = *reinterpret_cast<const float4*>(sg.zl + lr * C + q * 4);
+        l[u][k] = *reinterpret_cast<const float4*>(sg.ll + lr * C + q * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float lmax = -1e30f;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const float zz[4] = {z[u][k].x, z[u][k].y, z[u][k].z, z[u][k].w}, ll[4] = {l[u][k].x, l[u][k].y, l[u][k].z, l[u][k].w};
+        float g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float zv = zz[e], lv = ll[e];
+          const float p = sigmoidf(zv);
+          if (j + 4 * k < CQ) lmax = fmaxf(lmax, lv);
+          if (MODE == RN_LOSS_BCE_DICE) {
+            const float U = Uc[k][e];
+            g[e] = k_bce * (p - lv) - k_dice * p * (1.f - p) * (lv * U - Ic[k][e]) / (U * U);
+          } else {
+            const bool pos = (lv == 1.f);
+            const float pt = pos ? p : 1.f - p;
+            const float al = pos ? 0.25f : 0.75f;
+            const float om = 1.f - pt;
+            const float dfdpt = -al * (-2.f * om * logf(pt + 1e-7f) + om * om / (pt + 1e-7f));
+            g[e] = k_focal * dfdpt * (pos ? 1.f : -1.f) * p * (1.f - p);
+          }
+          g[e] = tmv[u] != 0.f ? g[e] : 0.f;
+        }
+        if (live[u] && j + 4 * k < CQ) *reinterpret_cast<float4*>(dzp[u] + (j + 4 * k) * 4) = make_float4(g[0], g[1], g[2], g[3]);
+      }
+      lmax = fmaxf(lmax, __shfl_xor(lmax, 1, 64));
+      lmax = fmaxf(lmax, __shfl_xor(lmax, 2, 64));
+      if (live[u]) {
+        float g = 0.f;
+        if (tmv[u] != 0.f && lmax > 0.5f) g = k_reg * fminf(fmaxf(rp[u] - rl[u], -1.f), 1.f);   // d huber(l - p)/dp = clip(p - l)
+        *drp[u] = g;
+      }
+    }
+  }
+}
+
 // stage 1: sums[i] = sum over blocks of partial[b][i]; 16 values x 16 row lanes per block, fixed order
 __global__ __launch_bounds__(256) void loss_sum_kernel(const LossArgs a, int nblocks, double* __restrict__ sums) {
   __shared__ double sh[16][16];
@@ -254,6 +434,44 @@ int build(const rn_loss_seg* segs, int nseg, int C, int mode, LossArgs* a, bool 
   return RN_OK;
 }
 
+// the four-lanes-per-row kernels: C a multiple of 4, at most 128 (RN_LOSS_WAVE_PER_ROW=1: the wave-per-row kernels, measurements)
+bool use4(int C) {
+  static const bool off = getenv("RN_LOSS_WAVE_PER_ROW") && atoi(getenv("RN_LOSS_WAVE_PER_ROW"));
+  return !off && C % 4 == 0 && C >= 4 && C <= 128;
+}
+int nblocks4(int64_t rows) {      // one pass of two row groups per wave
+  int64_t b = (rows + RPW * 2 * WAVES - 1) / (RPW * 2 * WAVES);
+  if (b > BLOCKS) b = BLOCKS;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+template <bool REDUCE, int NK>
+void launch4_nk(const LossArgs& a, int mode, hipStream_t st) {
+  const dim3 grid(nblocks4(a.total_rows)), block(T);
+  if (REDUCE) {
+    if (mode == RN_LOSS_BCE_DICE) hipLaunchKernelGGL((loss_reduce4_kernel<NK, RN_LOSS_BCE_DICE>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((loss_reduce4_kernel<NK, RN_LOSS_FOCAL>), grid, block, 0, st, a);
+  } else {
+    if (mode == RN_LOSS_BCE_DICE) hipLaunchKernelGGL((loss_grad4_kernel<NK, RN_LOSS_BCE_DICE>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((loss_grad4_kernel<NK, RN_LOSS_FOCAL>), grid, block, 0, st, a);
+  }
+}
+template <bool REDUCE>
+bool launch4(const LossArgs& a, int C, int mode, hipStream_t st) {
+  if (!use4(C)) return false;
+  switch ((C / 4 + 3) / 4) {
+    case 1: launch4_nk<REDUCE, 1>(a, mode, st); break;
+    case 2: launch4_nk<REDUCE, 2>(a, mode, st); break;
+    case 3: launch4_nk<REDUCE, 3>(a, mode, st); break;
+    case 4: launch4_nk<REDUCE, 4>(a, mode, st); break;
+    case 5: launch4_nk<REDUCE, 5>(a, mode, st); break;
+    case 6: launch4_nk<REDUCE, 6>(a, mode, st); break;
+    case 7: launch4_nk<REDUCE, 7>(a, mode, st); break;
+    default: launch4_nk<REDUCE, 8>(a, mode, st); break;
+  }
+  return true;
+}
+
 int nblocks_for(int64_t rows) {
   int64_t b = (rows + WAVES * 4 - 1) / (WAVES * 4);
   if (b > BLOCKS) b = BLOCKS;
@@ -277,9 +495,9 @@ extern "C" int rn_loss_fwd(const rn_loss_seg* segs, int nseg, int num_classes, i
     return RN_EWORKSPACE;
   }
   a.partial = (float*)workspace; a.stats = stats; a.cls_out = class_loss_out; a.reg_out = regr_loss_out;
-  const int nb = nblocks_for(a.total_rows);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(nb), dim3(T), 0, st, a);
+  const int nb = use4(num_classes) ? nblocks4(a.total_rows) : nblocks_for(a.total_rows);
+  if (!launch4<true>(a, num_classes, mode, st)) hipLaunchKernelGGL(loss_reduce_kernel, dim3(nb), dim3(T), 0, st, a);
   double* sums = (double*)((char*)workspace + rn::align_up((size_t)BLOCKS * (NSCAL + 3 * (size_t)num_classes) * sizeof(float), 256));
   hipLaunchKernelGGL(loss_sum_kernel, dim3(rn::ceil_div(NSCAL + 3 * num_classes, 16)), dim3(256), 0, st, a, nb, sums);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, a, (const double*)sums);
@@ -293,7 +511,8 @@ extern "C" int rn_loss_bwd(const rn_loss_seg* segs, int nseg, int num_classes, i
   if (int e = build(segs, nseg, num_classes, mode, &a, true)) return e;
   RN_CHECK_ARG(stats && g_cls && g_reg, "loss bwd: null stats/upstream gradient");
   a.stats = const_cast<float*>(stats); a.g_cls = g_cls; a.g_reg = g_reg;
-  hipLaunchKernelGGL(loss_grad_kernel, dim3(nblocks_for(a.total_rows)), dim3(T), 0, (hipStream_t)stream, a);
+  if (!launch4<false>(a, num_classes, mode, (hipStream_t)stream))
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(nblocks_for(a.total_rows)), dim3(T), 0, (hipStream_t)stream, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }

@@ -1155,6 +1155,11 @@ __device__ __forceinline__ void chunk_output_body(const CArgs& a, const Fold& f,
 // kind of block (kernel transform, G^T dU G) uses the first NT threads of as many blocks as it needs
 template <int W>
 constexpr int chunk_threads() { return CK_T; }
+// Occupancy target of the backward transforms (waves per SIMD).  A head-tower layer is 736 / 624 blocks of 4 waves: at the
+// 172 / 182 registers the compiler picks on its own, two blocks fit a CU and the launch needs two rounds of 512 (the second
+// one 44 % / 22 % full); at <= 168 registers three fit and every block is resident at once.
+template <int W>
+constexpr int chunk_waves() { return W <= 2 ? 3 : 1; }
 
 template <int M, int W, template <int> class LT>
 __global__ __launch_bounds__(chunk_threads<W>()) void wino_gn_fwd_pre_kernel(const CArgs in, const Fold f, const WeightArgs wa,
@@ -1172,14 +1177,14 @@ __global__ __launch_bounds__(chunk_threads<W>()) void wino_gn_output_kernel(cons
   chunk_output_body<M, W, 0>(out, f, blockIdx.x / slabs, blockIdx.x % slabs);
 }
 template <int M, int W, template <int> class LT>
-__global__ __launch_bounds__(chunk_threads<W>()) void wino_gn_bwd_pre_kernel(const CArgs dgrad_in, const CArgs wgrad_dy, const Fold f,
+__global__ __launch_bounds__(chunk_threads<W>(), chunk_waves<W>()) void wino_gn_bwd_pre_kernel(const CArgs dgrad_in, const CArgs wgrad_dy, const Fold f,
                                                                                int nb_first, int slabs) {
   const int b = blockIdx.x;
   if (b < nb_first) chunk_input_body<M, W, LT>(dgrad_in, f, b / slabs, b % slabs);
   else chunk_dy_body<M, W, LT>(wgrad_dy, f, (b - nb_first) / slabs, (b - nb_first) % slabs);
 }
 template <int M, int W, int MODE>
-__global__ __launch_bounds__(chunk_threads<W>()) void wino_gn_bwd_post_kernel(const CArgs out, const Fold f, const DwArgs2 d, int nb_out,
+__global__ __launch_bounds__(chunk_threads<W>(), chunk_waves<W>()) void wino_gn_bwd_post_kernel(const CArgs out, const Fold f, const DwArgs2 d, int nb_out,
                                                                                 int slabs) {
   const int b = blockIdx.x;
   if (b < nb_out) chunk_output_body<M, W, MODE>(out, f, b / slabs, b % slabs);
