@@ -59,6 +59,17 @@ __device__ __forceinline__ void locate_wave(const DetArgs& a, int64_t wid, int* 
   *row0 = (int64_t)(w - a.lv[l].wave_off) * 64;
 }
 
+__device__ __forceinline__ void locate_wave32(const DetArgs& a, uint32_t wid, int* img, int* lvl, int64_t* row0) {
+  const uint32_t wpi = (uint32_t)a.waves_per_image;
+  const uint32_t im = wid / wpi;
+  const int w = (int)(wid - im * wpi);
+  *img = (int)im;
+  int l = 0;
+  while (l + 1 < a.nlv && w >= a.lv[l + 1].wave_off) ++l;
+  *lvl = l;
+  *row0 = (int64_t)(w - a.lv[l].wave_off) * 64;
+}
+
 // ---- 1. scan: lane i of a wave ends up holding (max prob, arg-max) of row row0+i.
 // Four lanes share a row (float4 loads, 64-B contiguous per row and instruction), 16 rows per
 // pass, 2 shuffle steps to combine; first index wins ties (tf.argmax).  C % 4 == 0 fast path.
@@ -388,63 +399,42 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* total) {
   return ex;
 }
 
-// ---- 2. exclusive scan of the wave counts (a few 10^4 entries), coalesced, in two small launches:
-//   a) one block per 1024 entries: exclusive scan inside the chunk -> wave_off; the chunk's total is parked in the
-//      chunk's first wave_count slot (the counts are not read again: the emit pass re-derives its flags)
-//   b) one block: exclusive scan of the (<= 1024) chunk totals, added to every entry of wave_off; counts[0] = total.
-// (A single block walking a contiguous run per thread took 77 us at the 1024^2 x 16 shape -- 64 uncoalesced lines per
-// load instruction through one CU's address path; with the run held in registers still 57.)
-__global__ __launch_bounds__(1024) void det_offsets_chunk_kernel(const DetArgs a) {
+// ---- 2. exclusive scan of the wave counts (a few 10^4 entries) in ONE launch of independent blocks: block b scans its 1024
+// entries and adds the sum of every entry in front of its chunk, which it forms itself (b x 1024 coalesced 4-byte loads
+// from L2, eight in flight per thread: ~50 k loads for the last block of the 1024^2 x 16 shape, 2-3 us) -- no second
+// launch for the chunk totals, no block waits for another.  Block 0 also clears what the next stages count into.
+// (A single block walking a contiguous run per thread took 77 us at that shape -- 64 uncoalesced lines per load
+// instruction through one CU's address path; the two-launch chunk scan this replaces: 4.8 + 10.8 us.)
+__global__ __launch_bounds__(1024) void det_offsets_kernel(const DetArgs a) {
+  __shared__ int part[16];
   const int64_t nw = (int64_t)a.n * a.waves_per_image;
-  const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x == 0) {
+    for (int k = tid; k < a.n * a.C; k += 1024) { a.seg_count[k] = 0; a.seg_fill[k] = 0; }   // emit counts, scatter fills
+    for (int k = tid; k < 1 + a.n; k += 1024) a.counts[1 + k] = 0;
+  }
+  const int64_t begin = (int64_t)blockIdx.x * 1024;
+  int before = 0;
+  for (int64_t k0 = tid; k0 < begin; k0 += 8 * 1024) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = a.wave_count[min(k0 + u * 1024, begin - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) before += (k0 + u * 1024 < begin) ? v[u] : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (lane == 0) part[wave] = before;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) base += part[w];
+  const int64_t i = begin + tid;
   const int v = i < nw ? a.wave_count[i] : 0;
   int total;
   const int ex = block_exclusive_scan_1024(v, &total);
-  if (i < nw) a.wave_off[i] = ex;
-  if (threadIdx.x == 0) a.wave_count[(int64_t)blockIdx.x * 1024] = total;
-}
-
-__global__ __launch_bounds__(1024) void det_offsets_kernel(const DetArgs a) {
-  __shared__ int base[1024];
-  for (int k = threadIdx.x; k < a.n * a.C; k += 1024) a.seg_count[k] = 0;   // the emit pass counts candidates per segment
-  const int64_t nw = (int64_t)a.n * a.waves_per_image;
-  const int nchunk = (int)((nw + 1023) / 1024);
-  if (nchunk <= 1024) {
-    const int t = (int)threadIdx.x < nchunk ? a.wave_count[(int64_t)threadIdx.x * 1024] : 0;
-    int total;
-    base[threadIdx.x] = block_exclusive_scan_1024(t, &total);
-    __syncthreads();
-    for (int c0 = 1; c0 < nchunk; c0 += 8) {  // chunk 0 is already final; eight loads in flight, then eight stores
-      int v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int64_t i = (int64_t)(c0 + j) * 1024 + threadIdx.x;
-        v[j] = a.wave_off[i < nw ? i : nw - 1];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int64_t i = (int64_t)(c0 + j) * 1024 + threadIdx.x;
-        if (c0 + j < nchunk && i < nw) a.wave_off[i] = v[j] + base[c0 + j];
-      }
-    }
-    if (threadIdx.x == 0) a.counts[0] = total;
-    return;
-  }
-  // more than 2^20 waves: chunk totals walked by thread 0 (never reached by the shapes of this network)
-  if (threadIdx.x == 0) {
-    long long run = 0;
-    for (int c = 0; c < nchunk; ++c) {
-      const int t = a.wave_count[(int64_t)c * 1024];
-      a.wave_count[(int64_t)c * 1024] = (int)run;
-      run += t;
-    }
-    a.counts[0] = run;
-  }
-  __syncthreads();
-  for (int c = 1; c < nchunk; ++c) {
-    const int64_t i = (int64_t)c * 1024 + threadIdx.x;
-    if (i < nw) a.wave_off[i] += a.wave_count[(int64_t)c * 1024];
-  }
+  if (i < nw) a.wave_off[i] = base + ex;
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) a.counts[0] = (int64_t)base + total;
 }
 
 // ---- anchor decode (utils.py:108-117)
@@ -479,7 +469,7 @@ __global__ __launch_bounds__(T) void det_emit_kernel(const DetArgs a) {
     const unsigned long long m = a.wave_mask[wid];       // (wave-uniform)
     if (m == 0ull || !((m >> lane) & 1ull)) continue;
     int img, l; int64_t row0;
-    locate_wave(a, wid, &img, &l, &row0);
+    locate_wave32(a, (uint32_t)wid, &img, &l, &row0);     // (32-bit divisions: a 64-bit one is ~100 instructions)
     const DetLevel& lv = a.lv[l];
     const int64_t in_img = lv.row_off + row0 + lane;
     const int64_t g = (int64_t)img * a.rows_per_image + in_img;
@@ -491,10 +481,10 @@ __global__ __launch_bounds__(T) void det_emit_kernel(const DetArgs a) {
     if (lv.boxes) {
       b = *reinterpret_cast<const float4*>(lv.boxes + ((size_t)img * lv.rows + row0 + lane) * 4);
     } else {  // decode this candidate only
-      int64_t q = row0 + lane;
-      const int an = (int)(q % lv.A); q /= lv.A;
-      const int x_ = (int)(q % lv.w);
-      const int y_ = (int)(q / lv.w);
+      uint32_t q = (uint32_t)(row0 + lane);             // (rows per level < 2^31: host-checked)
+      const int an = (int)(q % (uint32_t)lv.A); q /= (uint32_t)lv.A;
+      const int x_ = (int)(q % (uint32_t)lv.w);
+      const int y_ = (int)(q / (uint32_t)lv.w);
       const size_t ri = ((size_t)img * lv.rows + row0 + lane) * 4;
       float4 r;
       if (lv.half_reg) {
@@ -517,7 +507,50 @@ __device__ __forceinline__ uint32_t float_order(float s) {
   return (sb & 0x80000000u) ? ~sb : (sb | 0x80000000u);
 }
 
-// ---- 4a. exclusive scan of the per-segment counts -> seg_start[0..nseg] (one 1024-thread block; nseg = n * C)
+// ---- 4a + 4b. every candidate takes a slot of its segment's range (the order inside the range is irrelevant: 4c sorts it).
+// Every block forms the exclusive scan of the per-segment counts itself (nseg = n * C ints through LDS: 1280 at the
+// 1024^2 x 16 shape) instead of waiting for a one-block scan launch; block 0 publishes seg_start[0..nseg] for the stages
+// behind it.  seg_fill was cleared by det_offsets_kernel / det_zero_seg_kernel.
+constexpr int SCAT_T = 256, SCAT_MAXSEG = 8192;
+__global__ __launch_bounds__(SCAT_T) void det_seg_scatter_kernel(const DetArgs a) {
+  __shared__ int start[SCAT_MAXSEG + 1];
+  __shared__ int tsum[SCAT_T];
+  const int nseg = a.n * a.C, tid = threadIdx.x;
+  const int per = (nseg + SCAT_T - 1) / SCAT_T;
+  const int b = tid * per, e = min(b + per, nseg);
+  int local = 0;
+  for (int k = b; k < e; ++k) { const int c = a.seg_count[k]; start[k] = c; local += c; }
+  tsum[tid] = local;
+  __syncthreads();
+  if (tid < 64) {                                  // exclusive scan of the 256 thread totals by one wave (4 per lane)
+    int v[4], run = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v[u] = tsum[tid * 4 + u]; run += v[u]; }
+    int inc = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (tid >= o) inc += t;
+    }
+    int ex = inc - run;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { tsum[tid * 4 + u] = ex; ex += v[u]; }
+    if (tid == 63) start[nseg] = inc;
+  }
+  __syncthreads();
+  int run = tsum[tid];
+  for (int k = b; k < e; ++k) { const int c = start[k]; start[k] = run; run += c; }
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int k = tid; k <= nseg; k += SCAT_T) a.seg_start[k] = start[k];
+  const int64_t ncand = a.counts[0] < a.cap ? a.counts[0] : a.cap;
+  for (int64_t i = (int64_t)blockIdx.x * SCAT_T + tid; i < ncand; i += (int64_t)gridDim.x * SCAT_T) {
+    const int seg = a.cand_image[i] * a.C + a.cand_class[i];
+    const int slot = start[seg] + atomicAdd(&a.seg_fill[seg], 1);
+    a.keys[slot] = ((uint64_t)(0xFFFFFFFFu - float_order(a.cand_score[i])) << 32) | (uint64_t)(uint32_t)i;
+  }
+}
+// (more than SCAT_MAXSEG segments: the scan as its own launch, the scatter reading it from global memory)
 __global__ __launch_bounds__(1024) void det_seg_scan_kernel(const DetArgs a) {
   const int nseg = a.n * a.C;
   const int per = (nseg + 1023) / 1024;
@@ -529,13 +562,10 @@ __global__ __launch_bounds__(1024) void det_seg_scan_kernel(const DetArgs a) {
   for (int k = b; k < e; ++k) {
     a.seg_start[k] = run;
     run += a.seg_count[k];
-    a.seg_fill[k] = 0;
   }
   if (threadIdx.x == 0) a.seg_start[nseg] = total;
 }
-
-// ---- 4b. every candidate takes a slot of its segment's range (the order inside the range is irrelevant: 4c sorts it)
-__global__ void det_seg_scatter_kernel(const DetArgs a) {
+__global__ void det_seg_scatter_global_kernel(const DetArgs a) {
   const int64_t ncand = a.counts[0] < a.cap ? a.counts[0] : a.cap;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncand; i += (int64_t)gridDim.x * blockDim.x) {
     const int seg = a.cand_image[i] * a.C + a.cand_class[i];
@@ -647,33 +677,40 @@ __global__ __launch_bounds__(64) void det_nms_kernel(const DetArgs a) {
   if (lane == 0) a.seg_keep[k] = nk;
 }
 
-// ---- exclusive scan of kept counts per segment + per-image totals (single 1024-thread block)
-__global__ __launch_bounds__(1024) void det_keep_offsets_kernel(const DetArgs a) {
+// ---- 6. gather the survivors.  A segment's output offset = the kept counts of the segments in front of it, summed by the
+// block itself (n * C ints: 20 loads per lane at the 1024^2 x 16 shape) -- no one-block offsets launch in between; the
+// first segment of every image also writes the image's total, block 0 the grand total.
+__global__ __launch_bounds__(64) void det_gather_kernel(const DetArgs a) {
+  const int k = blockIdx.x, lane = threadIdx.x;
   const int nseg = a.n * a.C;
-  const int per = (nseg + 1023) / 1024;
-  const int b = threadIdx.x * per, e = min(b + per, nseg);
-  int local = 0;
-  for (int k = b; k < e; ++k) local += a.seg_keep[k];
-  int total;
-  int run = block_exclusive_scan_1024(local, &total);
-  for (int k = b; k < e; ++k) {
-    a.seg_off[k] = run;
-    run += a.seg_keep[k];
+  int before = 0;
+  for (int j0 = lane; j0 < k; j0 += 64 * 8) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = a.seg_keep[min(j0 + u * 64, nseg - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) before += (j0 + u * 64 < k) ? v[u] : 0;
   }
-  __syncthreads();  // seg_off complete (same block: global writes are visible after the barrier)
-  for (int img = threadIdx.x; img < a.n; img += 1024) {
-    const int first = a.seg_off[img * a.C];
-    const int next = img + 1 < a.n ? a.seg_off[(img + 1) * a.C] : total;
-    a.counts[2 + img] = next - first;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (k % a.C == 0) {                              // image total (and, for the first image's block, the grand total)
+    const int img = k / a.C;
+    int t = 0;
+    for (int j = lane; j < a.C; j += 64) t += a.seg_keep[k + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (lane == 0) a.counts[2 + img] = t;
+    if (k == 0) {
+      int all = 0;
+      for (int j = lane; j < nseg; j += 64) all += a.seg_keep[j];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) all += __shfl_xor(all, o, 64);
+      if (lane == 0) a.counts[1] = all;
+    }
   }
-  if (threadIdx.x == 0) a.counts[1] = total;
-}
-
-__global__ void det_gather_kernel(const DetArgs a) {
-  const int k = blockIdx.x;
-  const int nk = a.seg_keep[k], off = a.seg_off[k];
+  const int nk = a.seg_keep[k], off = before;
   const int* keep = a.keep_idx + (size_t)k * a.max_keep;
-  for (int i = threadIdx.x; i < nk; i += blockDim.x) {
+  for (int i = lane; i < nk; i += 64) {
     const int c = keep[i];
     const int64_t o = (int64_t)off + i;
     *reinterpret_cast<float4*>(a.out_boxes + o * 4) = *reinterpret_cast<const float4*>(a.cand_box + (size_t)c * 4);
@@ -723,6 +760,7 @@ int plan(const rn_det_level* levels, int nlevels, const rn_det_params* p, DetArg
   }
   a->rows_per_image = rows; a->waves_per_image = waves;
   const int64_t nrows = rows * p->n, nw = (int64_t)waves * p->n, cap = p->max_candidates;
+  RN_UNSUPPORTED(rows >= (1ll << 31) || nw >= (1ll << 31), "detect: %lld rows per image / %lld waves: the emit pass indexes them in 32 bits", (long long)rows, (long long)nw);
   const int64_t nseg = (int64_t)p->n * p->num_classes;
   const size_t sizes[18] = {
       (size_t)nrows * 4, (size_t)nrows * 4, (size_t)nw * 4, (size_t)nw * 4,            // row_score,row_class,wave_count,wave_off
@@ -784,7 +822,8 @@ __global__ void det_copy_candidates_kernel(const DetArgs a) {
 
 // candidates handed in as arrays (rn_nms_classwise): count them per segment
 __global__ void det_zero_seg_kernel(const DetArgs a) {
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < a.n * a.C; k += gridDim.x * blockDim.x) a.seg_count[k] = 0;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < a.n * a.C; k += gridDim.x * blockDim.x) { a.seg_count[k] = 0; a.seg_fill[k] = 0; }
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < 1 + a.n; k += gridDim.x * blockDim.x) a.counts[1 + k] = 0;
 }
 __global__ void det_count_arrays_kernel(const DetArgs a, const int64_t* count_dev) {
   const int64_t ncand = count_dev[0] < a.cap ? count_dev[0] : a.cap;
@@ -797,11 +836,14 @@ __global__ void det_count_arrays_kernel(const DetArgs a, const int64_t* count_de
 
 int sort_and_suppress(DetArgs& a, const WsLayout& L, void* workspace, hipStream_t st) {
   const int nseg = a.n * a.C;
-  hipLaunchKernelGGL(det_seg_scan_kernel, dim3(1), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(det_seg_scatter_kernel, dim3(256), dim3(256), 0, st, a);
+  if (nseg <= SCAT_MAXSEG) {
+    hipLaunchKernelGGL(det_seg_scatter_kernel, dim3(256), dim3(SCAT_T), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(det_seg_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(det_seg_scatter_global_kernel, dim3(256), dim3(256), 0, st, a);
+  }
   hipLaunchKernelGGL(det_seg_sort_kernel, dim3(nseg), dim3(SORT_T), 0, st, a);
   hipLaunchKernelGGL(det_nms_kernel, dim3(nseg), dim3(64), 0, st, a);
-  hipLaunchKernelGGL(det_keep_offsets_kernel, dim3(1), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(det_gather_kernel, dim3(nseg), dim3(64), 0, st, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
@@ -869,8 +911,7 @@ int run_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, 
       hipLaunchKernelGGL(det_scan_kernel, dim3(wblocks), dim3(T), 0, st, a);
     }
   }
-  hipLaunchKernelGGL(det_offsets_chunk_kernel, dim3((unsigned)((nw + 1023) / 1024)), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(det_offsets_kernel, dim3(1), dim3(1024), 0, st, a);
+  hipLaunchKernelGGL(det_offsets_kernel, dim3((unsigned)((nw + 1023) / 1024)), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(det_emit_kernel, dim3(wblocks < 2048u ? wblocks : 2048u), dim3(T), 0, st, a);
   if (decode_only) {
     hipLaunchKernelGGL(det_copy_candidates_kernel, dim3(256), dim3(256), 0, st, a);

@@ -130,8 +130,7 @@ def _det_call(fn_name, probs, boxes, num_classes, n, score_threshold, iou_thresh
     out_class = torch.empty((cap,), dtype=torch.int32, device=dev)
     out_image = torch.empty((cap,), dtype=torch.int32, device=dev)
     out_anchor = torch.empty((cap,), dtype=torch.int64, device=dev)
-    counts = torch.empty((2 + n,), dtype=torch.int64, device=dev)
-    _rn.check(L.rn_zero(_rn.ptr(counts), 2 * (2 + n), _rn.stream()), "rn_zero")     # (our kernel: no PyTorch fill on the detection path)
+    counts = torch.empty((2 + n,), dtype=torch.int64, device=dev)     # (every entry is written by the pipeline itself)
     _rn.check(getattr(L, fn_name)(levels, len(probs), C.byref(params), _rn.f32(out_boxes), _rn.f32(out_scores),
                                   _rn.ptr(out_class), _rn.ptr(out_image), _rn.ptr(out_anchor), _rn.ptr(counts),
                                   ws.data_ptr(), ws.numel(), _rn.stream()), fn_name)
@@ -174,7 +173,7 @@ def _nms_arrays(boxes, scores, class_ids, num_classes, max_output_size):
     oc = torch.empty((cap,), dtype=torch.int32, device=dev)
     oi = torch.empty((cap,), dtype=torch.int32, device=dev)
     oidx = torch.empty((cap,), dtype=torch.int64, device=dev)
-    counts = torch.zeros((3,), dtype=torch.int64, device=dev)
+    counts = torch.empty((3,), dtype=torch.int64, device=dev)
     if k == 0:
         return ob[:0], os_[:0], oc[:0].long(), oidx[:0]
     _rn.check(L.rn_nms_classwise(_rn.f32(boxes), _rn.f32(scores), _rn.ptr(cls32), _rn.ptr(img32), _rn.ptr(count),
