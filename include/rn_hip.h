@@ -219,6 +219,30 @@ int rn_cast_f32_to_f16(const float* x, void* y, int64_t count, rn_stream_t strea
 /* image [pixels,3] fp32 -> [pixels,4] fp16 with a zero 4th channel (the stem then gathers 8 bytes per tap) */
 int rn_pad_cast_rgb_f16(const float* x, void* y, int64_t pixels, rn_stream_t stream);
 int rn_conv2d_fwd_f16(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int out_f32, rn_stream_t stream);
+/* The same convolution with the GroupNorms around it folded in (Sequential([Conv2D, Normalization, activation]) of the
+ * backbones, e.g. resnet.py:53-64,88-101, normalization.py:20-35), fp16 output, one segment:
+ *   input side (in_mean != NULL): x is the RAW output of the previous conv; the kernel loads act(GN(x)) -- scale / shift per
+ *     (sample, channel) from in_mean / in_rstd [n][in_groups] and in_gamma / in_beta [cin] -- and pads with zeros AFTER
+ *     the activation, exactly what a stand-alone GroupNorm + activation pass would have stored;
+ *   output side (partial != NULL): per (m-tile, channel) sums of y and y^2, of the values as stored in fp16, in the
+ *     layout [2][n * rows][cout] with rows = rn_conv2d_f16_fold_rows(...) m-tiles per sample; rn_group_norm_finalize turns
+ *     them into mean / rstd [n][groups]; the conv must have no bias.
+ * rn_conv2d_f16_fold_rows returns 0 when the shape cannot fold (several segments, fp32 output, oh*ow not a whole number of
+ * m-tiles, cout/groups not a multiple of 8): the caller then uses rn_conv2d_fwd_f16 + rn_group_norm_fwd. */
+typedef struct rn_f16_fold {
+  const float* in_mean; const float* in_rstd; const float* in_gamma; const float* in_beta;
+  int in_groups; int in_act;
+  float* partial;
+} rn_f16_fold;
+int rn_conv2d_f16_fold_rows(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g);
+int rn_conv2d_fwd_f16_fold(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const rn_f16_fold* fold, rn_stream_t stream);
+/* mean / rstd [n][groups] from the partial sums above (fp64, fixed order); hw = oh * ow */
+int rn_group_norm_finalize(const float* partial, int n, int rows_per_sample, int hw, int c, int groups, float eps, float* mean,
+                           float* rstd, rn_stream_t stream);
+/* y = act(GN(x)) + residual, or act(GN(x) + residual) (act_after_residual), fp16 x / residual / y, from given statistics */
+int rn_group_norm_apply_f16(const void* x, const void* residual, void* y, int n, int hw, int c, int groups, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta, int act, int act_after_residual,
+                            rn_stream_t stream);
 
 /* ------------------------------------------------------------------ depthwise 3x3
  * Replaces tf.nn.depthwise_conv2d (DepthwiseConv2dNative + its two backprops),

@@ -30,9 +30,18 @@ struct SegH {
   const _Float16* x; const _Float16* wt; const float* bias; void* y;
   int n, h, w, oh, ow, cout, pad_t, pad_l, m, tiles_n, start, x_ld, x_coff;
 };
+// rn_f16_fold on the device: the GroupNorm in FRONT of the conv applied to the A operand between the global load and the LDS
+// store (x holds the raw output of the previous conv), and / or the statistics of the GroupNorm BEHIND the conv from the
+// epilogue ([2][prows][cout] per (m-tile, channel) sums of y and y^2 of the values as stored, gn_partial_kernel's layout)
+struct FoldH {
+  const float* in_mean; const float* in_rstd; const float* in_gamma; const float* in_beta;
+  int in_groups, in_cpg, in_act, in_c;
+  float* partial; int prows;
+};
 struct ArgsH {
   SegH seg[RN_MAX_SEG];
   int nseg, kh, kw, stride, cin, groups, cin_g, tpg, out_f32;
+  FoldH fold;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -64,9 +73,14 @@ __device__ __forceinline__ int find_seg(const ArgsH& a, int id) {
   return s;
 }
 
-template <int BM, int BN, int WM, int WN, int VEC, bool TAPU>
+// FOLD bit 0: GroupNorm + activation of the input applied on load; bit 1: statistics of the output from the epilogue.
+// Both need a tile's rows inside one sample (oh * ow a multiple of BM: host-checked) and a single segment.
+template <int BM, int BN, int WM, int WN, int VEC, bool TAPU, int FOLD>
 __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args) {
   constexpr int T = WM * WN * 64;
+  constexpr bool FIN = (FOLD & 1) != 0, FOUT = (FOLD & 2) != 0;
+  __shared__ float2 ntab[FIN ? 2048 : 1];            // (scale, shift) of every input channel of the tile's sample
+  __shared__ float sred[FOUT ? WM * BN * 2 : 1];
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int KQ = BK / VEC, RPP = T / KQ, A_PASS = BM / RPP, B_PASS = BN / RPP;
   static_assert(A_PASS >= 1 && B_PASS >= 1 && BM % RPP == 0 && BN % RPP == 0, "tile/threads mismatch");
@@ -93,6 +107,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
   const __amdgpu_buffer_rsrc_t xa = make_rsrc(sg.x, (unsigned)sg.n * H * W * ldx * 2u);
   const __amdgpu_buffer_rsrc_t wb = make_rsrc(sg.wt, (unsigned)cout * ktotal * 2u);
 
+  if (FIN) {
+    const FoldH& f = args.fold;
+    const int smp = m0 / OHW;
+    for (int c = tid; c < f.in_c; c += T) {
+      const int g_ = c / f.in_cpg;
+      const float mean = f.in_mean[smp * f.in_groups + g_], rstd = f.in_rstd[smp * f.in_groups + g_];
+      const float sc = rstd * f.in_gamma[c];
+      ntab[c] = make_float2(sc, f.in_beta[c] - mean * sc);
+    }
+    __syncthreads();
+  }
   const int kq = tid % KQ, r0 = tid / KQ;
   int ih0[A_PASS], iw0[A_PASS], rowoff[A_PASS];
 #pragma unroll
@@ -117,6 +142,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
 
   int t_kh = 0, t_kw = 0, t_ci = 0;
   vec_t ra[A_PASS], rb[B_PASS];
+  unsigned okbits = 0;      // FIN: which of the A vectors in flight lie inside the image
+  int ld_c = 0;             // FIN: input channel (of the whole tensor) of this thread's A vectors in flight
   auto load_tiles = [&](int kt) {
     int khh, kww, tapoff;
     const int k = kt * BK + kq * VEC;
@@ -124,24 +151,46 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
     if (TAPU) {
       khh = t_kh; kww = t_kw;
       tapoff = (khh * W + kww) * ldx + t_ci + kq * VEC;
+      ld_c = grp * cin + t_ci + kq * VEC;
       t_ci += BK;
       if (t_ci == cin) { t_ci = 0; if (++t_kw == kw) { t_kw = 0; ++t_kh; } }
     } else {
       const int tap = k / cin, ci = k - tap * cin;
       khh = tap / kw; kww = tap - khh * kw;
       tapoff = (khh * W + kww) * ldx + ci;
+      ld_c = grp * cin + ci;
     }
+    okbits = 0;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       const int ih = ih0[i] + khh, iw = iw0[i] + kww;
       const bool ok = kok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
       ra[i] = VecH<VEC>::load(xa, ok ? (unsigned)(rowoff[i] + tapoff) * 2u : OOB);
+      okbits |= ok ? (1u << i) : 0u;
     }
 #pragma unroll
     for (int j = 0; j < B_PASS; ++j)
       rb[j] = VecH<VEC>::load(wb, (kok && browoff[j] != OOB) ? browoff[j] + (unsigned)k * 2u : OOB);
   };
   auto store_tiles = [&]() {
+    if (FIN) {            // act(GN(x)) of the vectors in flight; zero where the tap lies in the padding (SAME pads the ACTIVATED tensor)
+      float2 t[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) t[j] = ntab[min(ld_c + j, 2047)];
+      const bool relu = args.fold.in_act == RN_ACT_RELU;
+#pragma unroll
+      for (int i = 0; i < A_PASS; ++i) {
+        vec_t v = ra[i];
+        const bool ok = (okbits >> i) & 1u;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float z = fmaf((float)v[j], t[j].x, t[j].y);
+          z = relu ? fmaxf(z, 0.f) : rn::act_fwd(z, args.fold.in_act);
+          v[j] = ok ? (_Float16)z : (_Float16)0.f;
+        }
+        ra[i] = v;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<vec_t*>(&As[(r0 + i * RPP) * LDH + kq * VEC]) = ra[i];
 #pragma unroll
@@ -193,6 +242,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
     _Float16* Cs = smem;
     constexpr int VPR = BN / 8;  // 16-byte vectors per tile row
     const __amdgpu_buffer_rsrc_t ys = make_rsrc(sg.y, (unsigned)M * (unsigned)cout * 2u);
+    float st1[TN], st2[TN];    // FOUT: this lane's column sums of y and y^2 (of the values as stored)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) st1[tn] = st2[tn] = 0.f;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       if (PASSES == 1 || wm == ps) {
@@ -205,7 +257,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
           for (int tm = 0; tm < TM; ++tm) {
             const int rb = (PASSES == 1 ? wm * (BM / WM) : 0) + tm * 32 + 4 * half;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Cs[(rb + (r & 3) + 8 * (r >> 2)) * LDS_ROW + lc] = (_Float16)(acc[tm][tn][r] + bv);
+            for (int r = 0; r < 16; ++r) {
+              const _Float16 hv = (_Float16)(acc[tm][tn][r] + bv);
+              Cs[(rb + (r & 3) + 8 * (r >> 2)) * LDS_ROW + lc] = hv;
+              if (FOUT) { const float fv = (float)hv; st1[tn] += fv; st2[tn] = fmaf(fv, fv, st2[tn]); }
+            }
           }
         }
       }
@@ -220,6 +276,27 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
                                                0, 0);
       }
       if (ps + 1 < PASSES) __syncthreads();
+    }
+    if (FOUT) {            // the two lane halves, then the WM wave rows -> one (sum, sum of squares) per column of the tile
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        st1[tn] += __shfl_xor(st1[tn], 32, 64);
+        st2[tn] += __shfl_xor(st2[tn], 32, 64);
+        if (lane < 32) {
+          const int lc = wn * (BN / WN) + tn * 32 + l31;
+          sred[(wm * BN + lc) * 2 + 0] = st1[tn];
+          sred[(wm * BN + lc) * 2 + 1] = st2[tn];
+        }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < nmax) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WM; ++w_) { t1 += sred[(w_ * BN + tid) * 2 + 0]; t2 += sred[(w_ * BN + tid) * 2 + 1]; }
+        float* p1 = args.fold.partial + (size_t)tile_m * cout + n0 + tid;
+        p1[0] = t1;
+        p1[(size_t)args.fold.prows * cout] = t2;
+      }
     }
     return;
   }
@@ -308,8 +385,11 @@ extern "C" int rn_pad_cast_rgb_f16(const float* x, void* y, int64_t pixels, rn_s
   return RN_OK;
 }
 
-extern "C" int rn_conv2d_fwd_f16(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int out_f32,
-                                 rn_stream_t stream) {
+namespace {
+// fold == nullptr: the plain convolution.  rows_out != nullptr: dry run -- *rows_out = m-tile rows per sample the statistics
+// would take (0: this shape cannot fold), nothing is launched.
+int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int out_f32, const rn_f16_fold* fold, int* rows_out,
+                  rn_stream_t stream) {
   RN_CHECK_ARG(segs && g && nseg >= 1 && nseg <= RN_MAX_SEG, "conv f16: bad segments");
   RN_CHECK_ARG(g->kh >= 1 && g->kw >= 1 && g->stride >= 1 && g->cin >= 1, "conv f16: bad geometry");
   const int G = g->groups > 1 ? g->groups : 1;
@@ -366,12 +446,41 @@ extern "C" int rn_conv2d_fwd_f16(const rn_conv_seg* segs, int nseg, const rn_con
   }
   const bool vec8 = a.cin_g % 8 == 0;
   const bool tapu = vec8 && a.cin_g % BK == 0;
+  int fbits = 0;
+  if (fold || rows_out) {
+    // a tile's rows must lie inside one sample, the fp16 staged epilogue must be the one that runs, one segment
+    const SegH& d = a.seg[0];
+    const int ohw = d.oh * d.ow;
+    const bool ok = nseg == 1 && vec8 && !out_f32 && (cout_g & 7) == 0 && ohw % kCfgs[c].bm == 0;
+    if (rows_out) { *rows_out = ok ? ohw / kCfgs[c].bm : 0; return RN_OK; }
+    RN_UNSUPPORTED(!ok, "conv f16 fold: this shape cannot fold its GroupNorms (see rn_conv2d_f16_fold_rows)");
+    if (fold->in_mean) {
+      RN_CHECK_ARG(fold->in_rstd && fold->in_gamma && fold->in_beta && fold->in_groups >= 1 && g->cin % fold->in_groups == 0,
+                   "conv f16 fold: incomplete input GroupNorm");
+      RN_UNSUPPORTED(g->cin > 2048 || d.x_ld != g->cin, "conv f16 fold: input GroupNorm over %d channels (<= 2048, dense)", g->cin);
+      a.fold.in_mean = fold->in_mean; a.fold.in_rstd = fold->in_rstd; a.fold.in_gamma = fold->in_gamma; a.fold.in_beta = fold->in_beta;
+      a.fold.in_groups = fold->in_groups; a.fold.in_cpg = g->cin / fold->in_groups; a.fold.in_act = fold->in_act; a.fold.in_c = g->cin;
+      fbits |= 1;
+    }
+    if (fold->partial) {
+      RN_CHECK_ARG(d.bias == nullptr, "conv f16 fold: the statistics are those of a bias-free conv (the GroupNorm behind it absorbs a bias)");
+      a.fold.partial = fold->partial; a.fold.prows = d.n * (ohw / kCfgs[c].bm);
+      fbits |= 2;
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
+#define RN_F16K(BM_, BN_, WM_, WN_, F_)                                                                             \
+  do {                                                                                                              \
+    if (tapu) hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 8, true, F_>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+    else hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 8, false, F_>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+  } while (0)
 #define RN_F16(BM_, BN_, WM_, WN_)                                                                                  \
   do {                                                                                                              \
-    if (tapu) hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 8, true>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
-    else if (vec8) hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 8, false>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
-    else hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 4, false>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+    if (fbits == 1) RN_F16K(BM_, BN_, WM_, WN_, 1);                                                                 \
+    else if (fbits == 2) RN_F16K(BM_, BN_, WM_, WN_, 2);                                                            \
+    else if (fbits == 3) RN_F16K(BM_, BN_, WM_, WN_, 3);                                                            \
+    else if (vec8) RN_F16K(BM_, BN_, WM_, WN_, 0);                                                                  \
+    else hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 4, false, 0>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
   } while (0)
   switch (c) {
     case 0: RN_F16(128, 128, 2, 2); break;
@@ -382,6 +491,23 @@ extern "C" int rn_conv2d_fwd_f16(const rn_conv_seg* segs, int nseg, const rn_con
     default: RN_F16(128, 32, 4, 1); break;
   }
 #undef RN_F16
+#undef RN_F16K
   RN_LAUNCH_CHECK();
   return RN_OK;
+}
+}  // namespace
+
+extern "C" int rn_conv2d_fwd_f16(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int out_f32, rn_stream_t stream) {
+  return conv_f16_impl(segs, nseg, g, out_f32, nullptr, nullptr, stream);
+}
+
+extern "C" int rn_conv2d_f16_fold_rows(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g) {
+  int rows = 0;
+  if (conv_f16_impl(segs, nseg, g, 0, nullptr, &rows, nullptr) != RN_OK) return 0;
+  return rows;
+}
+
+extern "C" int rn_conv2d_fwd_f16_fold(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const rn_f16_fold* fold, rn_stream_t stream) {
+  RN_CHECK_ARG(fold && (fold->in_mean || fold->partial), "conv f16 fold: nothing to fold");
+  return conv_f16_impl(segs, nseg, g, 0, fold, nullptr, stream);
 }

@@ -1665,3 +1665,49 @@ extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   }
   return RN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The fp16 inference path with the statistics taken from the producing conv (rn_conv2d_fwd_f16_fold): the conv's epilogue
+// writes per (m-tile, channel) sums in the layout of gn_partial_kernel, so the same fp64 finalize and the same fp16 apply
+// kernel run behind it -- without the statistics pass, and without the apply pass where the consumer is another folded conv.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int rn_group_norm_finalize(const float* partial, int n, int rows_per_sample, int hw, int c, int groups, float eps, float* mean,
+                                      float* rstd, rn_stream_t stream) {
+  RN_CHECK_ARG(partial && mean && rstd && n >= 1 && rows_per_sample >= 1 && hw >= 1 && c >= 1 && groups >= 1 && c % groups == 0,
+               "group_norm finalize: bad argument");
+  GnArgs a = {};
+  a.nseg = 1; a.c = c; a.groups = groups; a.cpg = c / groups; a.eps = eps;
+  a.partial = const_cast<float*>(partial);
+  GnSeg& d = a.seg[0];
+  d.mean = mean; d.rstd = rstd; d.n = n; d.hw = hw; d.sample_start = 0; d.chunk_start = 0; d.chunks = rows_per_sample;
+  a.total_samples = n; a.total_chunks = n * rows_per_sample;
+  hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(n * groups), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_group_norm_apply_f16(const void* x, const void* residual, void* y, int n, int hw, int c, int groups, const float* mean,
+                                       const float* rstd, const float* gamma, const float* beta, int act, int act_after_residual,
+                                       rn_stream_t stream) {
+  RN_CHECK_ARG(x && y && mean && rstd && gamma && beta && n >= 1 && hw >= 1 && groups >= 1 && c % groups == 0, "group_norm apply f16: bad argument");
+  RN_UNSUPPORTED(c % 8 != 0 || c > 2048, "group_norm apply f16: c=%d must be a multiple of 8 and <= 2048", c);
+  GnArgs a = {};
+  a.nseg = 1; a.c = c; a.groups = groups; a.cpg = c / groups; a.act = act; a.act_after_res = act_after_residual ? 1 : 0;
+  a.in_half = a.out_half = 1;
+  a.gamma = gamma; a.beta = beta;
+  GnSeg& d = a.seg[0];
+  d.x = (const float*)x; d.y = (float*)y; d.res = (const float*)residual;
+  d.mean = const_cast<float*>(mean); d.rstd = const_cast<float*>(rstd); d.n = n; d.hw = hw; d.sample_start = 0;
+  a.total_samples = n;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(apply_blocks(a, 8), n);
+  switch (act) {
+    case RN_ACT_RELU: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_RELU>, grid, dim3(T), 0, st, a); break;
+    case RN_ACT_ELU: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_ELU>, grid, dim3(T), 0, st, a); break;
+    case RN_ACT_RELU6: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_RELU6>, grid, dim3(T), 0, st, a); break;
+    case RN_ACT_SIGMOID: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_SIGMOID>, grid, dim3(T), 0, st, a); break;
+    default: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_NONE>, grid, dim3(T), 0, st, a); break;
+  }
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}

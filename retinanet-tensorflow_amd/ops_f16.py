@@ -105,6 +105,73 @@ def conv2d(x, w, bias=None, stride=1, groups=1, out_f32=False):
     return ys if multi else ys[0]
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# GroupNorms folded into the convs around them (rn_conv2d_fwd_f16_fold): a conv's epilogue emits the statistics of its
+# output, the NEXT conv applies GroupNorm + activation to its operand on load.  A `Pending` is a conv output whose
+# GroupNorm has not been applied yet: another folded conv consumes it as is, everything else calls materialise().
+# ---------------------------------------------------------------------------------------------------------------------
+import os
+FOLD_INTO_3X3 = os.environ.get("RN_F16_FOLD_3X3", "0") == "1"     # also apply a pending GroupNorm on the operand load of 3 x 3 convs
+FOLD = os.environ.get("RN_F16_FOLD", "1") == "1"     # (0: conv, then the three-kernel GroupNorm, as before -- A/B measurements, tests)
+
+
+class Pending(object):
+    """y = raw fp16 conv output [N,H,W,C]; (mean, rstd) [N,G]; the GroupNorm's gamma / beta / groups and the activation behind it."""
+
+    def __init__(self, y, mean, rstd, gamma, beta, groups, act):
+        self.y, self.mean, self.rstd, self.gamma, self.beta, self.groups, self.act = y, mean, rstd, gamma, beta, groups, act
+
+    def materialise(self, residual=None, act_after_residual=False):
+        y = self.y
+        n, h, w, c = y.shape
+        out = torch.empty_like(y)
+        _rn.check(_rn.lib().rn_group_norm_apply_f16(_rn.f16(y), _rn.f16(residual.contiguous()) if residual is not None else None, _rn.f16(out),
+                                                    n, h * w, c, self.groups, _rn.f32(self.mean), _rn.f32(self.rstd), _rn.f32(self.gamma),
+                                                    _rn.f32(self.beta), _rn.ACT[self.act], 1 if act_after_residual else 0, _rn.stream()),
+                  "rn_group_norm_apply_f16")
+        return out
+
+
+def conv2d_norm(x, w, norm, act=None, stride=1, groups=1):
+    """conv (no bias) -> GroupNorm `norm` (a layers.GroupNormalization) -> act, the GroupNorm NOT applied: returns a Pending, or
+    None when the shape cannot fold (the caller then takes conv2d + group_norm_act).  `x`: an fp16 tensor or a Pending (its
+    GroupNorm + activation are applied by this conv's operand load)."""
+    src = x.y if isinstance(x, Pending) else x.contiguous()
+    kh, kw, cin_g, cout = w.shape
+    wt, g2, cin = packed_weight(w, groups, None)
+    if src.shape[3] != cin:
+        return None
+    L = _rn.lib()
+    geom = _rn.ConvGeom(kh, kw, stride, cin, g2)
+    oh, _ = _rn.same_pad(src.shape[1], kh, stride)
+    ow, _ = _rn.same_pad(src.shape[2], kw, stride)
+    n = src.shape[0]
+    y = torch.empty((n, oh, ow, cout), dtype=torch.float16, device=src.device)
+    seg = (_rn.ConvSeg * 1)()
+    s = seg[0]
+    s.x, s.wgt, s.y, s.bias = _rn.f16(src), _rn.f16(wt), _rn.f16(y), None
+    s.n, s.h, s.w, s.cout = n, src.shape[1], src.shape[2], cout
+    rows = L.rn_conv2d_f16_fold_rows(seg, 1, C.byref(geom))
+    if rows <= 0:
+        return None
+    if norm.gamma is None:
+        norm.build(cout, src.device)
+    gout = gn_groups(cout, norm.groups)
+    partial = torch.empty((2, n * rows, cout), dtype=torch.float32, device=src.device)
+    fold = _rn.F16Fold()
+    fold.partial = partial.data_ptr()
+    if isinstance(x, Pending):
+        fold.in_mean, fold.in_rstd = x.mean.data_ptr(), x.rstd.data_ptr()
+        fold.in_gamma, fold.in_beta = x.gamma.data_ptr(), x.beta.data_ptr()
+        fold.in_groups, fold.in_act = x.groups, _rn.ACT[x.act]
+    _rn.check(L.rn_conv2d_fwd_f16_fold(seg, 1, C.byref(geom), C.byref(fold), _rn.stream()), "rn_conv2d_fwd_f16_fold")
+    mean = torch.empty((n, gout), dtype=torch.float32, device=src.device)
+    rstd = torch.empty((n, gout), dtype=torch.float32, device=src.device)
+    _rn.check(L.rn_group_norm_finalize(_rn.f32(partial), n, rows, oh * ow, cout, gout, float(norm.eps), _rn.f32(mean), _rn.f32(rstd),
+                                       _rn.stream()), "rn_group_norm_finalize")
+    return Pending(y, mean, rstd, norm.gamma.detach(), norm.beta.detach(), gout, act)
+
+
 def group_norm_act(x, gamma, beta, groups=32, eps=1e-5, act=None, residual=None, act_after_residual=False):
     """GroupNorm -> act (-> + residual) with fp32 or fp16 input and fp16 output/residual.  Lists allowed."""
     multi = isinstance(x, (list, tuple))

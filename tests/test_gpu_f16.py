@@ -137,3 +137,42 @@ def test_resnext_fpn_fp16_inference_matches_fp32(dev):
     # per-channel norms: this net amplifies a single rounding ~60x (its fp32 forward differs from the fp32 oracle by
     # ~1e-5..1e-4 for 6e-8 roundings, test_gpu_backbones), so 2^-11 * 60 ~ 3e-2 is what fp16 storage costs here
     assert worst <= 6e-2
+
+
+@pytest.mark.parametrize("project,size,cin,f", [(True, 32, 64, 64), ("down", 32, 256, 128), (False, 16, 512, 128), (False, 32, 1024, 256)])
+def test_resnext_bottleneck_fp16_folded_equals_layer_by_layer(dev, project, size, cin, f):
+    """The ResNeXt bottleneck with its GroupNorms folded into the convs (rn_conv2d_fwd_f16_fold: statistics from the conv
+    epilogue, GroupNorm + ReLU applied to the next conv's operand on load) vs conv -> three-kernel GroupNorm -> conv: the same
+    fp32 arithmetic on the same fp16 values, so they agree to an fp16 rounding or two (2e-3 of the range); and the folded
+    block vs the fp32 oracle block at the network-level fp16 tolerance."""
+    import layers, ops_f16, resnet
+    torch.manual_seed(11)
+    blk = resnet.ResNeXt_Bottleneck(f, project=project, kernel_initializer=layers.VarianceScaling(factor=2.0),
+                                    kernel_regularizer=None, in_channels=cin)
+    blk.build(cin)
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for name, p in blk.named_parameters():
+            if name.endswith("gamma"):
+                p.copy_(1 + 0.2 * torch.randn(p.shape, generator=g))
+            elif name.endswith("beta"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    blk.to(dev)
+    x = torch.randn(2, size, size, cin, generator=g).to(dev)
+    xh = ops_f16.to_half(x)
+    with torch.no_grad():
+        ref32 = blk(x, training=False)
+        layers.set_inference_dtype('f16')
+        try:
+            assert ops_f16.FOLD
+            folded = blk._call_f16_folded(xh)
+            assert folded is not None, "this shape must fold"
+            ops_f16.FOLD = False
+            plain = blk(xh, training=False)
+        finally:
+            ops_f16.FOLD = True
+            layers.set_inference_dtype('f32')
+    assert folded.dtype == torch.float16 and folded.shape == plain.shape
+    assert_close(folded.float().cpu().numpy(), plain.float().cpu().numpy(), 2e-3, "folded vs layer-by-layer fp16 bottleneck")
+    err = float((folded.float() - ref32).norm() / ref32.norm())
+    assert err < 1e-2, "folded fp16 bottleneck vs fp32: rel L2 %.3e" % err
