@@ -1,7 +1,7 @@
 """rocprofv3 --pmc target: the roofline kernels of bench.py in isolation (GPU box only), 30 launches each:
   fwd  batched forward products of the Winograd F(4x4,3x3) head-tower layer: 36 x [682 x 256] x [256 x 256]
   bwd  the merged backward products of the same layer (the largest in-step kernel)
-  gn   the largest stand-alone GroupNorm (+ELU+dropout) forward: 2 x 256 x 256 x 96
+  gn   the largest stand-alone GroupNorm (+ELU+dropout) forward: 2 x 256 x 256 x 32 (the stem's)
 usage (separate passes: FETCH_SIZE and WRITE_SIZE do not fit one):
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python tools/gemm_pmc.py
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python tools/gemm_pmc.py
@@ -28,8 +28,8 @@ L = _rn.lib()
 need = L.rn_winograd_bwd_products_workspace(tiles, 256, 256, 36)
 ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=dev)
 nsplit = C.c_int(0)
-x = torch.randn(2, 256, 256, 96, device=dev)
-gamma, beta = torch.ones(96, device=dev), torch.zeros(96, device=dev)
+x = torch.randn(2, 256, 256, 32, device=dev)
+gamma, beta = torch.ones(32, device=dev), torch.zeros(32, device=dev)
 for _ in range(30):
     _rn.check(L.rn_gemm_batched(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, 36, 0, _rn.stream()), "rn_gemm_batched")
     _rn.check(L.rn_winograd_bwd_products(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, _rn.f32(A), _rn.f32(dM), 256, 256, 36,
