@@ -251,8 +251,9 @@ def _loss_inputs(rng, c, levels=((2, 8, 8, 9), (2, 4, 4, 9), (2, 2, 2, 9)), fg_r
 
 
 @pytest.mark.parametrize("mode", ["bce_dice", "focal"])
-@pytest.mark.parametrize("c", [3, 80, 130])
+@pytest.mark.parametrize("c", [3, 4, 12, 80, 128, 130])
 def test_detection_loss_fwd_bwd(dev, mode, c):
+    """(c % 4 == 0 and <= 128: the four-lanes-per-row kernels, 1 / 1 / 5 / 8 quads per lane; 3 and 130: the wave-per-row kernels)"""
     import ops
     rng = np.random.default_rng(c)
     data = _loss_inputs(rng, c)
@@ -438,9 +439,10 @@ def _detection_inputs(rng, n, c, sizes, hot=0.02):
     return probs, boxes
 
 
-@pytest.mark.parametrize("n,c,hot", [(2, 5, 0.05), (3, 80, 0.02), (1, 3, 0.6)])
+@pytest.mark.parametrize("n,c,hot", [(2, 5, 0.05), (3, 80, 0.02), (1, 3, 0.6), (3, 2800, 0.3)])
 def test_detect_bit_exact_indices(dev, n, c, hot):
-    """boxes_decode + merge + nms_classwise for a batch == the oracle, index for index."""
+    """boxes_decode + merge + nms_classwise for a batch == the oracle, index for index.  (3 x 2800 = 8400 (image, class)
+    segments: more than the scatter kernel scans in LDS -- the stand-alone segment scan + global scatter path.)"""
     import utils
     rng = np.random.default_rng(n * 100 + c)
     sizes = [(8, 8), (4, 4), (2, 2), (1, 1), (1, 1)]
