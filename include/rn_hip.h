@@ -48,7 +48,7 @@ typedef struct rn_reduce_list rn_reduce_list;
 
 /* Version of this header's ABI: bumped whenever an entry point's arguments or a struct layout change.  rn_version() returns
  * the value the library was built with; a caller built against another value must not call anything else. */
-#define RN_API_VERSION 300
+#define RN_API_VERSION 310
 int rn_version(void);
 const char* rn_last_error(void);
 

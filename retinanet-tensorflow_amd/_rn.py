@@ -19,7 +19,7 @@ LOSS_MODE = {"bce_dice": 0, "focal": 1}
 OPT = {"momentum": 0, "rmsprop": 1, "adam": 2}
 OPT_BLOCK = 1024
 LOSS_STATS_HEADER = 8
-API_VERSION = 300        # RN_API_VERSION of include/rn_hip.h these bindings were written against
+API_VERSION = 310        # RN_API_VERSION of include/rn_hip.h these bindings were written against
 
 
 class RnError(RuntimeError):
