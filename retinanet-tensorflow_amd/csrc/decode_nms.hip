@@ -465,8 +465,18 @@ __global__ __launch_bounds__(T) void det_emit_kernel(const DetArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t nw = (int64_t)a.n * a.waves_per_image;
   const int64_t stride = ((int64_t)gridDim.x * T) >> 6;
-  for (int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6; wid < nw; wid += stride) {
-    const unsigned long long m = a.wave_mask[wid];       // (wave-uniform)
+  // the masks and offsets of the next EMIT_AHEAD waves this wave will visit are fetched together (a lane each), so the
+  // chain per visited wave is one round trip to memory (score / class / raw box), not two
+  constexpr int EMIT_AHEAD = 8;
+  for (int64_t wid0 = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6; wid0 < nw; wid0 += stride * EMIT_AHEAD) {
+    const int64_t wl = wid0 + (int64_t)min(lane, EMIT_AHEAD - 1) * stride;
+    const unsigned long long mine = (lane < EMIT_AHEAD && wl < nw) ? a.wave_mask[wl] : 0ull;
+    const int offmine = (lane < EMIT_AHEAD && wl < nw) ? a.wave_off[wl] : 0;
+#pragma unroll
+    for (int u = 0; u < EMIT_AHEAD; ++u) {
+    const int64_t wid = wid0 + (int64_t)u * stride;
+    const unsigned long long m = __shfl(mine, u, 64);    // (wave-uniform)
+    const int woff = __shfl(offmine, u, 64);
     if (m == 0ull || !((m >> lane) & 1ull)) continue;
     int img, l; int64_t row0;
     locate_wave32(a, (uint32_t)wid, &img, &l, &row0);     // (32-bit divisions: a 64-bit one is ~100 instructions)
@@ -475,7 +485,7 @@ __global__ __launch_bounds__(T) void det_emit_kernel(const DetArgs a) {
     const int64_t g = (int64_t)img * a.rows_per_image + in_img;
     const float s = a.row_score[g];
     const int c = a.row_class[g];
-    const int64_t pos = (int64_t)a.wave_off[wid] + __popcll(m & ((1ull << lane) - 1ull));
+    const int64_t pos = (int64_t)woff + __popcll(m & ((1ull << lane) - 1ull));
     if (pos >= a.cap) continue;  // overflow is reported through counts[0] > capacity
     float4 b;
     if (lv.boxes) {
@@ -498,6 +508,7 @@ __global__ __launch_bounds__(T) void det_emit_kernel(const DetArgs a) {
     *reinterpret_cast<float4*>(a.cand_box + pos * 4) = b;
     a.cand_score[pos] = s; a.cand_class[pos] = c; a.cand_image[pos] = img; a.cand_anchor[pos] = in_img;
     atomicAdd(&a.seg_count[img * a.C + c], 1);   // integer count: the same whatever the order of arrival
+    }
   }
 }
 
