@@ -226,7 +226,8 @@ int rn_conv2d_fwd_f16(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, 
  *     the activation, exactly what a stand-alone GroupNorm + activation pass would have stored;
  *   output side (partial != NULL): per (m-tile, channel) sums of y and y^2, of the values as stored in fp16, in the
  *     layout [2][n * rows][cout] with rows = rn_conv2d_f16_fold_rows(...) m-tiles per sample; rn_group_norm_finalize turns
- *     them into mean / rstd [n][groups]; the conv must have no bias.
+ *     them into mean / rstd [n][groups]; the conv must have no bias.  (The input side alone is not built: a conv whose
+ *     input is a pending GroupNorm is followed by one itself in every network here.)
  * rn_conv2d_f16_fold_rows returns 0 when the shape cannot fold (several segments, fp32 output, oh*ow not a whole number of
  * m-tiles, cout/groups not a multiple of 8): the caller then uses rn_conv2d_fwd_f16 + rn_group_norm_fwd. */
 typedef struct rn_f16_fold {

@@ -462,6 +462,7 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
       a.fold.in_groups = fold->in_groups; a.fold.in_cpg = g->cin / fold->in_groups; a.fold.in_act = fold->in_act; a.fold.in_c = g->cin;
       fbits |= 1;
     }
+    RN_UNSUPPORTED(!fold->partial, "conv f16 fold: the input-side fold is built together with the output statistics only (pass `partial`)");
     if (fold->partial) {
       RN_CHECK_ARG(d.bias == nullptr, "conv f16 fold: the statistics are those of a bias-free conv (the GroupNorm behind it absorbs a bias)");
       a.fold.partial = fold->partial; a.fold.prows = d.n * (ohw / kCfgs[c].bm);
@@ -476,8 +477,7 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
   } while (0)
 #define RN_F16(BM_, BN_, WM_, WN_)                                                                                  \
   do {                                                                                                              \
-    if (fbits == 1) RN_F16K(BM_, BN_, WM_, WN_, 1);                                                                 \
-    else if (fbits == 2) RN_F16K(BM_, BN_, WM_, WN_, 2);                                                            \
+    if (fbits == 2) RN_F16K(BM_, BN_, WM_, WN_, 2);                                                            \
     else if (fbits == 3) RN_F16K(BM_, BN_, WM_, WN_, 3);                                                            \
     else if (vec8) RN_F16K(BM_, BN_, WM_, WN_, 0);                                                                  \
     else hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 4, false, 0>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
