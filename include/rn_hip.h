@@ -48,7 +48,7 @@ typedef struct rn_reduce_list rn_reduce_list;
 
 /* Version of this header's ABI: bumped whenever an entry point's arguments or a struct layout change.  rn_version() returns
  * the value the library was built with; a caller built against another value must not call anything else. */
-#define RN_API_VERSION 310
+#define RN_API_VERSION 400
 int rn_version(void);
 const char* rn_last_error(void);
 
@@ -706,6 +706,13 @@ int rn_zero(float* p, int64_t count, rn_stream_t stream);
  * (class + box subnet, retinanet.py:283-291), C5 (P5 + P6, retinanet.py:214-216). */
 typedef struct rn_add_seg { const float* a; const float* b; float* out; int64_t count; } rn_add_seg;
 int rn_add_segs(const rn_add_seg* segs, int nseg, rn_stream_t stream);
+
+/* Measurement aid (bench.py `config.collective_standin`; not on the product path): what a ring all-reduce under the
+ * backbone's backward pass would take from the compute stream on ONE GPU -- `blocks` workgroups of 256 threads (RCCL runs
+ * one workgroup per channel) stream `bytes` from src to dst (16-byte aligned), paced by the constant 100 MHz clock so the
+ * copy lasts ~target_us (2 (R-1)/R x slice bytes at the ~150 GB/s a ring gets from one xGMI link).  Launch it on a side
+ * stream.  The reference's MirroredStrategy (train.py:261-267) has no counterpart: this replaces nothing. */
+int rn_debug_collective_standin(const void* src, void* dst, int64_t bytes, int blocks, float target_us, rn_stream_t stream);
 
 #ifdef __cplusplus
 }

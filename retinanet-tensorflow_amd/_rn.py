@@ -19,7 +19,7 @@ LOSS_MODE = {"bce_dice": 0, "focal": 1}
 OPT = {"momentum": 0, "rmsprop": 1, "adam": 2}
 OPT_BLOCK = 1024
 LOSS_STATS_HEADER = 8
-API_VERSION = 310        # RN_API_VERSION of include/rn_hip.h these bindings were written against
+API_VERSION = 400        # RN_API_VERSION of include/rn_hip.h these bindings were written against
 
 
 class RnError(RuntimeError):
@@ -170,6 +170,7 @@ SYMBOLS = [
     "rn_mb_rows_max", "rn_mb_compact_rows_layout", "rn_mb_compact_rows", "rn_mb_pointwise_rows", "rn_mb_pointwise_fwd", "rn_mb_depthwise_rows", "rn_mb_depthwise_fwd", "rn_mb_apply",
     "rn_mb_pointwise_bwd_rows", "rn_mb_pointwise_bwd_workspace", "rn_mb_pointwise_bwd",
     "rn_mb_depthwise_bwd_rows", "rn_mb_depthwise_bwd_workspace", "rn_mb_depthwise_bwd",
+    "rn_debug_collective_standin",
 ]
 
 
@@ -205,6 +206,7 @@ def lib():
         L.rn_conv2d_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_conv2d_dgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_zero.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.rn_debug_collective_standin.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]
         L.rn_conv2d_stats_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.rn_conv2d_fwd_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_depthwise_stats_rows.argtypes = [C.c_int] * 7 + [C.c_void_p]
@@ -378,16 +380,19 @@ def sync_counters(device):
     # tags / exchange rows).  Nothing may be allocated (and zero-filled) inside a graph capture: a capturing stream without
     # a region of its own takes the region of key 0 -- the one the warm-up pass before the capture sized -- which it shares
     # with nobody while the capture (and later the replay, on the stream that replays it) is the only user.
+    # Keys: a registered side stream has its own region (it runs concurrently with the main one); EVERY other stream -- the
+    # default stream, a warm-up stream, the capture stream: whichever is "the main stream" at the moment, never two at once --
+    # shares the region of key 0.  (A side stream never donates its region to key 0, and warm-up streams made for a
+    # re-capture do not leak a region each.)
     h = stream().value or 0
     capturing = torch.cuda.is_current_stream_capturing() if device.type == 'cuda' else False
-    key = (device.type, device.index, 0 if (capturing and (device.type, device.index, h) not in _sync_words) else h)
+    key = (device.type, device.index, h if h in SIDE_STREAMS else 0)
     t = _sync_words.get(key)
     if t is None:
         if capturing:
             raise RnError("the grid-resident GroupNorm's exchange region must exist before graph capture (run the step once eagerly)")
         t = torch.zeros(lib().rn_group_norm_sync_bytes() // 4, dtype=torch.int32, device=device)
         _sync_words[key] = t
-        _sync_words.setdefault((device.type, device.index, 0), t)
     return t
 
 

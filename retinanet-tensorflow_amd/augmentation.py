@@ -12,7 +12,7 @@ import _rn
 import utils
 
 
-def _flip(t, w_axis, neg_mod=0, neg_idx=0):
+def _flip(t, w_axis, neg_mod=0, neg_idx=0, out=None):
     t = t.contiguous()
     outer = 1
     for d in t.shape[:w_axis]:
@@ -22,7 +22,8 @@ def _flip(t, w_axis, neg_mod=0, neg_idx=0):
         inner *= d
     esz = t.element_size()
     assert esz in (1, 4), "flip: fp32 maps or 1-byte masks"
-    y = torch.empty_like(t)
+    y = torch.empty_like(t) if out is None else out
+    assert y.is_contiguous() and y.shape == t.shape and y.dtype == t.dtype
     _rn.check(_rn.lib().rn_flip_width(_rn.ptr(t), _rn.ptr(y), outer, t.shape[w_axis], inner, esz, neg_mod, neg_idx,
                                       _rn.stream()), "rn_flip_width")
     return y

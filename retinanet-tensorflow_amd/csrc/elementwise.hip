@@ -442,6 +442,35 @@ extern "C" int rn_flip_width(const void* x, void* y, int64_t outer, int w, int64
   return RN_OK;
 }
 
+// Stand-in for a ring all-reduce sharing the GPU with the backward pass (measurement aid, rn_hip.h): `blocks` workgroups of
+// 256 threads stream `bytes` from src to dst, paced by the constant 100 MHz clock so that the whole copy takes ~target_us.
+namespace {
+__global__ __launch_bounds__(256) void standin_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n16,
+                                                      int64_t ticks_total) {
+  constexpr int64_t CHUNK = 4096;                       // float4 per block and round: 64 KB
+  const int64_t per = (n16 + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = per * blockIdx.x, hi = min(lo + per, n16);
+  const int64_t rounds = (per + CHUNK - 1) / CHUNK;
+  const uint64_t t0 = wall_clock64();
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t b = lo + r * CHUNK, e = min(b + CHUNK, hi);
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) dst[i] = src[i];
+    // pace: round r may end no earlier than its share of the target duration
+    const uint64_t due = t0 + (uint64_t)(ticks_total * (r + 1) / rounds);
+    while (wall_clock64() < due) __builtin_amdgcn_s_sleep(32);
+  }
+}
+}  // namespace
+
+extern "C" int rn_debug_collective_standin(const void* src, void* dst, int64_t bytes, int blocks, float target_us, rn_stream_t stream) {
+  RN_CHECK_ARG(src && dst && bytes >= 16 && bytes % 16 == 0 && blocks >= 1 && blocks <= 1024 && target_us >= 0.f && target_us < 1e6f,
+               "collective_standin: bad argument");
+  hipLaunchKernelGGL(standin_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst,
+                     bytes / 16, (int64_t)(target_us * 100.0f));
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
 // out_s = a_s + b_s for up to RN_MAX_SEG tensors in one launch: the sum of the two gradients of a tensor that two
 // branches consume (a bottleneck's input: expand conv + residual; a pyramid level: class + box subnet).
 namespace {

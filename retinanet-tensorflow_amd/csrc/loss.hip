@@ -42,6 +42,12 @@ __device__ __forceinline__ int seg_of_row(const LossArgs& a, int64_t r) {
   return s;
 }
 __device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
+// d huber_1(l - p) / dp = clip(p - l, -1, 1); written with compares so that a NaN target stays NaN (fminf / fmaxf drop it)
+__device__ __forceinline__ float clip1(float e) { return e < -1.f ? -1.f : (e > 1.f ? 1.f : e); }
+// Masking rule of BOTH kernel families, forward and backward = the reference's: rows outside the trainable mask are REMOVED
+// (boolean_mask, utils.py:270-278: a select -- whatever they hold never reaches a sum); the foreground weight of the Huber term
+// is a MULTIPLY (tf.losses.huber_loss(weights=...), losses.py:146-152: a NaN target on a trainable background row gives
+// NaN * 0 = NaN in the loss and in the gradient, as in the reference graph).
 __device__ __forceinline__ float huber1(float e) {
   const float a = fabsf(e), q = fminf(a, 1.f);
   return 0.5f * q * q + (a - q);
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(T) void loss_reduce_kernel(const LossArgs a) {
     lmax = rn::wave_max(lmax);
     const bool fg = lmax > 0.5f;
     if (lane == 0) { s_m += 1.f; s_fg += fg ? 1.f : 0.f; }
-    if (fg && lane < 4) s_hub += huber1(sg.rl[lr * 4 + lane] - sg.rp[lr * 4 + lane]);
+    if (lane < 4) s_hub = fmaf(fg ? 1.f : 0.f, huber1(sg.rl[lr * 4 + lane] - sg.rp[lr * 4 + lane]), s_hub);
   }
   // wave-level sums of the scalars
   s_m = rn::wave_sum(s_m); s_fg = rn::wave_sum(s_fg); s_bce = rn::wave_sum(s_bce);
@@ -174,10 +180,12 @@ __global__ __launch_bounds__(T) void loss_reduce4_kernel(const LossArgs a) {
       }
       lmax = fmaxf(lmax, __shfl_xor(lmax, 1, 64));
       lmax = fmaxf(lmax, __shfl_xor(lmax, 2, 64));
-      const float fg = (lmax > 0.5f) ? tmv[u] : 0.f;
+      const float fgw = (lmax > 0.5f) ? 1.f : 0.f;
+      const float fg = fgw * tmv[u];
       s_cls += cls;
       if (j == 0) { s_m += tmv[u]; s_fg += fg; }
-      s_hub = fmaf(fg, huber1(rl[u] - rp[u]), s_hub);
+      const float hub = fgw * huber1(rl[u] - rp[u]);             // multiply: the foreground weight
+      s_hub += (tmv[u] != 0.f) ? hub : 0.f;                      // select: the trainable mask
     }
   }
   s_m = rn::wave_sum(s_m); s_fg = rn::wave_sum(s_fg); s_cls = rn::wave_sum(s_cls); s_hub = rn::wave_sum(s_hub);
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(T) void loss_grad4_kernel(const LossArgs a) {
       lmax = fmaxf(lmax, __shfl_xor(lmax, 2, 64));
       if (live[u]) {
         float g = 0.f;
-        if (tmv[u] != 0.f && lmax > 0.5f) g = k_reg * fminf(fmaxf(rp[u] - rl[u], -1.f), 1.f);   // d huber(l - p)/dp = clip(p - l)
+        if (tmv[u] != 0.f) g = ((lmax > 0.5f) ? 1.f : 0.f) * (k_reg * clip1(rp[u] - rl[u]));
         *drp[u] = g;
       }
     }
@@ -404,12 +412,8 @@ __global__ __launch_bounds__(T) void loss_grad_kernel(const LossArgs a) {
     }
     lmax = rn::wave_max(lmax);
     if (lane < 4) {
-      float g = 0.f;
-      if (lmax > 0.5f) {
-        const float e = sg.rp[lr * 4 + lane] - sg.rl[lr * 4 + lane];  // d huber(l - p)/dp = clip(p - l)
-        g = k_reg * fminf(fmaxf(e, -1.f), 1.f);
-      }
-      sg.dr[lr * 4 + lane] = g;
+      const float e = sg.rp[lr * 4 + lane] - sg.rl[lr * 4 + lane];    // d huber(l - p)/dp = clip(p - l)
+      sg.dr[lr * 4 + lane] = ((lmax > 0.5f) ? 1.f : 0.f) * (k_reg * clip1(e));
     }
   }
 }

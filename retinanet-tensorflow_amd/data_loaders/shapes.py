@@ -14,6 +14,7 @@ class Shapes(Base):
         self._image_size = tuple(image_size)
         self._class_names = ['square', 'triangle', 'circle']
         self._rng = np.random.default_rng(seed)
+        self._drawn = 0                        # samples drawn so far (by __iter__ or skip)
 
     @property
     def class_names(self):
@@ -24,23 +25,35 @@ class Shapes(Base):
         return len(self._class_names)
 
     def skip(self, n):
-        """Advance the sample stream by n samples (resuming a run: the checkpoint stores how many were drawn)."""
-        it = iter(self)
-        for _ in range(int(n)):
-            next(it)
+        """Advance the sample stream by n samples (resuming a run: the checkpoint stores how many were drawn).  Draws only --
+        the same random numbers `__iter__` consumes, nothing is rendered -- so resuming a long run costs microseconds per
+        skipped sample; skipping past `num_samples` just exhausts the stream."""
+        h, w = self._image_size
+        for _ in range(min(int(n), self._num_samples - self._drawn)):
+            self._draw(h, w)
+
+    def _draw(self, h, w):
+        """The random numbers of one sample, in the order __iter__ has always drawn them."""
+        rng = self._rng
+        self._drawn += 1
+        background = rng.integers(0, 255, (1, 1, 3)).astype(np.uint8)
+        items = []
+        for _ in range(int(rng.integers(1, 5))):
+            shape = int(rng.integers(0, 3))
+            color = rng.integers(0, 255, 3).astype(np.uint8)
+            s = int(rng.integers(12, max(13, min(h, w) // 5)))
+            y, x = int(rng.integers(s, h - s)), int(rng.integers(s, w - s))
+            items.append((shape, color, s, y, x))
+        return background, items
 
     def __iter__(self):
         h, w = self._image_size
         yy, xx = np.mgrid[0:h, 0:w]
-        for _ in range(self._num_samples):
-            rng = self._rng
-            image = np.ones((h, w, 3), np.uint8) * rng.integers(0, 255, (1, 1, 3)).astype(np.uint8)
+        while self._drawn < self._num_samples:
+            background, items = self._draw(h, w)
+            image = np.ones((h, w, 3), np.uint8) * background
             boxes, class_ids = [], []
-            for _ in range(int(rng.integers(1, 5))):
-                shape = int(rng.integers(0, 3))
-                color = rng.integers(0, 255, 3).astype(np.uint8)
-                s = int(rng.integers(12, max(13, min(h, w) // 5)))
-                y, x = int(rng.integers(s, h - s)), int(rng.integers(s, w - s))
+            for shape, color, s, y, x in items:
                 if shape == 0:
                     mask = (np.abs(yy - y) <= s) & (np.abs(xx - x) <= s)
                 elif shape == 1:                                   # upward triangle inscribed in the box

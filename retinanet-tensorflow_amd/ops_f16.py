@@ -125,7 +125,8 @@ class Pending(object):
         y = self.y
         n, h, w, c = y.shape
         out = torch.empty_like(y)
-        _rn.check(_rn.lib().rn_group_norm_apply_f16(_rn.f16(y), _rn.f16(residual.contiguous()) if residual is not None else None, _rn.f16(out),
+        residual = residual.contiguous() if residual is not None else None   # (a copy must outlive the launch: keep the name)
+        _rn.check(_rn.lib().rn_group_norm_apply_f16(_rn.f16(y), _rn.f16(residual) if residual is not None else None, _rn.f16(out),
                                                     n, h * w, c, self.groups, _rn.f32(self.mean), _rn.f32(self.rstd), _rn.f32(self.gamma),
                                                     _rn.f32(self.beta), _rn.ACT[self.act], 1 if act_after_residual else 0, _rn.stream()),
                   "rn_group_norm_apply_f16")

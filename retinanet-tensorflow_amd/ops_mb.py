@@ -241,7 +241,8 @@ class _MbChain(torch.autograd.Function):
         D = torch.empty((n, hl, wl, cl), dtype=torch.float32, device=dev)
         nm3 = _mb_norm(s3_last, training, seed_dev, False)
         tg = tap_grad.get(nb - 1)
-        gout = _rn.MbGout(D.data_ptr(), None, _rn.f32(tg.contiguous()) if tg is not None else None, C.pointer(nm3), 1,
+        tg = tg.contiguous() if tg is not None else None      # (kept alive in `keep` until the chain's last launch is queued)
+        gout = _rn.MbGout(D.data_ptr(), None, _rn.f32(tg) if tg is not None else None, C.pointer(nm3), 1,
                           _rn.MbRows(rows3.data_ptr(), lay3.rows_per_sample, lay3.width, lay3.bn), planes3.data_ptr())
         dyd = _rn.MbDy(dy_t.data_ptr(), None, None, 0, _rn.MbRows())
         pgrads[9 * nb] = pw_bwd(x_last, None, dyd, tail_w, gout, hl * wl, cl, ct)

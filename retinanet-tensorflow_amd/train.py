@@ -224,6 +224,7 @@ class Trainer(object):
         self._param_offset = {id(p): off for p, (off, _) in zip(self.arena.params, self.arena.offsets)}
         self._parts = []               # per step: (roots, grads-of-leaves getter, arena range) of segment B's parts
         self._graphs = None
+        self._graph_cache = {}         # input shape key (dataset.DeviceFeed.shape_key; None without a feed) -> captured segments
         self._static = None
         # the device word every fused dropout hashes (bumped by the optimizer kernel); replicas start it at different values
         # so that they draw different masks (each tower of the reference's MirroredStrategy has its own dropout stream)
@@ -323,8 +324,10 @@ class Trainer(object):
             if features is None:
                 # input_fn builds the step's labels on the device (anchor assignment); only the loss reads them: their
                 # kernels run on a side stream underneath the backbone's forward pass (the image itself -- written before
-                # the step, not by input_fn -- is read at once).  input_fn.concurrent = False keeps it on the main stream.
-                if self.device.type == 'cuda' and getattr(self.input_fn, 'concurrent', True):
+                # the step, not by input_fn -- is read at once).  OPT-IN (input_fn.concurrent = True): an input_fn that also
+                # creates / uploads / preprocesses the IMAGE must stay on the main stream, or the backbone would read the image
+                # with no ordering against the side stream that writes it.
+                if self.device.type == 'cuda' and getattr(self.input_fn, 'concurrent', False):
                     label_stream = _rn.side_stream(self.device, 2)
                     label_stream.wait_stream(torch.cuda.current_stream())
                     main_stream = torch.cuda.current_stream()
@@ -404,18 +407,32 @@ class Trainer(object):
                 ranges.append(self.segment_b(j))
             gbs.append(gb)
         self._parts = []
-        self._graphs = (ga, gbs, ranges)
+        self._graphs = (ga, gbs, ranges, self._graph_out, self._static)
 
     def step(self, features=None):
+        # a feed (dataset.DeviceFeed: input_fn with stage / consumed) puts a NEW sample into its static device buffers before
+        # every step -- the captured segment reads them, so the graph path trains on fresh data like the reference's
+        # train_input_fn (train.py:190-202); one set of captured segments per input shape
+        feed = self.input_fn if (features is None and hasattr(self.input_fn, 'stage')) else None
+        key = feed.stage() if feed is not None else None
         if self.use_graph:
             if self._graphs is None:
+                self._graph_cache = {}
+            cached = self._graph_cache.get(key)
+            if cached is None:
                 self._capture(features)
-            elif features is not None:
-                _copy_tree(self._static, features)
+                self._graph_cache[key] = self._graphs
+            else:
+                self._graphs = cached
+                self._graph_out, self._static = cached[3], cached[4]
+                if features is not None:
+                    _copy_tree(self._static, features)
             self._graphs[0].replay()
             class_loss, regr_loss = self._graph_out
         else:
             class_loss, regr_loss = self.segment_a(features)
+        if feed is not None:
+            feed.consumed()
         self.allreduce.launch(self.cut_offset, self.arena.count)      # heads + FPN: under the backbone's backward pass
         if self.use_graph:
             for gb, (lo, hi) in zip(self._graphs[1], self._graphs[2]):
@@ -548,6 +565,7 @@ def build_parser():
     parser.add_argument('--loss', type=str, choices=['bce_dice', 'focal'], default='bce_dice')
     parser.add_argument('--steps-per-epoch', type=int, default=100)
     parser.add_argument('--eval-images', type=int, default=0, help='after training: mAP / IoU metrics over this many samples')
+    parser.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly instead of replaying the captured step')
     return parser
 
 
@@ -599,31 +617,42 @@ def main(argv=None):
     torch.manual_seed(0)                                                           # same initial weights on every rank
     net = retinanet.RetinaNet(backbone=args.backbone, levels=levels, num_classes=loader.num_classes, activation=L.elu,
                               dropout_rate=args.dropout).to(dev)
+    # train_input_fn (train.py:190-202) = dataset.DeviceFeed: loader thread -> pinned host memory -> asynchronous upload ->
+    # static device buffers; rescale, normalisation, the h-flip and the anchor assignment of every NEW sample run inside the
+    # captured step (one hipGraph per backward segment, replayed per step; --no-graph launches the same kernels eagerly)
+    feed = dataset.DeviceFeed(loader, levels, scale=args.scale, device=dev)
     trainer = Trainer(net, levels, optimizer=args.optimizer, learning_rate=args.learning_rate,
-                      grad_clip_norm=args.grad_clip_norm, loss_mode=args.loss, device=dev)
+                      grad_clip_norm=args.grad_clip_norm, loss_mode=args.loss, device=dev, use_graph=not args.no_graph,
+                      input_fn=feed)
     step = 0
+    drawn0 = 0
     path = None if args.experiment is None else os.path.join(args.experiment, 'model.safetensors')
     if path is not None and os.path.exists(path):
         step = checkpoint.load(path, net, trainer)                                 # every rank reads the same file
         # like the reference (train.py:271-273: `for epoch in range(args.epochs): estimator.train(...)` on a restored global
         # step) a rerun trains args.epochs MORE epochs; what is carried over besides the weights: the step count, the
-        # optimizer slots, the dropout counter and the position in the sample stream
-        loader.skip(int(checkpoint.load_extra(path).get('samples_drawn', 0)))
+        # optimizer slots, the dropout counter and the position in the sample stream (counted in samples, not steps)
+        drawn0 = int(checkpoint.load_extra(path).get('samples_drawn', 0))
         if rank == 0:
             print('restored step', step)
+    loader.skip(drawn0)                                                            # (before the feed's thread draws: it starts lazily)
     broadcast_initial_state(trainer)
-    it = dataset.build_dataset(loader, levels, scale=args.scale, device=dev)       # train.py:192-203 train_input_fn
-    for epoch in range(args.epochs):
-        for _ in range(args.steps_per_epoch):
-            out = trainer.step(next(it))                                           # batch = [image, hflip]
-            step += 1
-            if step % 20 == 0 and rank == 0:
-                print('epoch %d step %d class_loss %.4f regr_loss %.4f reg %.4f' % (
-                    epoch, step, out['class_loss'].item(), out['regr_loss'].item(), out['regularization_loss'].item()),
-                    flush=True)
-        trainer.check_device_errors()
-        if path is not None and rank == 0:                                         # replicas are identical: rank 0 writes
-            checkpoint.save(path, net, trainer, step=step, extra={'epochs_done': epoch + 1, 'samples_drawn': step})
+    feed.start()
+    try:
+        for epoch in range(args.epochs):
+            for _ in range(args.steps_per_epoch):
+                out = trainer.step()                                               # batch = [image, hflip] of a new sample
+                step += 1
+                if step % 20 == 0 and rank == 0:
+                    print('epoch %d step %d class_loss %.4f regr_loss %.4f reg %.4f' % (
+                        epoch, step, out['class_loss'].item(), out['regr_loss'].item(), out['regularization_loss'].item()),
+                        flush=True)
+            trainer.check_device_errors()
+            if path is not None and rank == 0:                                     # replicas are identical: rank 0 writes
+                checkpoint.save(path, net, trainer, step=step,
+                                extra={'epochs_done': epoch + 1, 'samples_drawn': drawn0 + feed.samples_staged})
+    finally:
+        feed.close()
     if args.eval_images and rank == 0:
         res = evaluate(net, Shapes(None, image_size=(args.scale + args.scale // 4, args.scale), seed=12345), levels,
                        args.eval_images, scale=args.scale, device=dev)

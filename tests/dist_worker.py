@@ -12,6 +12,9 @@ RCCL are initialised once per process).  Not a test module.
       `world` processes share cuda:0 and average gradients through a gloo group (RCCL refuses two ranks on one
       device); each rank trains on its own batch -> SURVEY a29: the replicas' weights stay identical and equal
       one process that accumulates both batches' gradients.
+  rccl <out_dir>       (started by `python -m torch.distributed.run --nproc-per-node R`, R = min(#GPUs, 8) >= 2)
+      the production path on a multi-GPU node: one rank per GPU, backend 'nccl' (= RCCL over xGMI), hipGraph replay,
+      overlap on, three steps, each rank its own batch; rank 0 also runs the one-process accumulation of all R batches.
 """
 import json
 import os
@@ -117,8 +120,49 @@ def pair(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def rccl(out_dir):
+    """R ranks, one per GPU, in-place RCCL all-reduces of the arena slices under the backbone's backward pass."""
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import train
+    _, tr = build(dev, 100 + rank, use_graph=True, overlap=True, dropout=0.0)
+    assert tr.allreduce.active and tr.allreduce.world == world and not tr.allreduce.host_staged
+    train.broadcast_initial_state(tr)
+    tr.timing = {}
+    steps = 3
+    for _ in range(steps):
+        out = tr.step()
+    torch.cuda.synchronize()
+    launched = list(tr.allreduce.launched)
+    np.save(os.path.join(out_dir, "w_%d.npy" % rank), tr.arena.weights.cpu().numpy())
+    json.dump({"rank": rank, "world": world, "launched": launched, "cut_offset": tr.cut_offset, "count": tr.arena.count,
+               "exposed_ms": tr.allreduce_exposed_ms(), "losses": [float(out['class_loss']), float(out['regr_loss'])],
+               "graph": bool(tr._graphs is not None)}, open(os.path.join(out_dir, "r_%d.json" % rank), "w"))
+    tr.check_device_errors()
+    dist.barrier()
+    if rank == 0:
+        reps = [build(dev, 100 + r, use_graph=False, overlap=False, dropout=0.0)[1] for r in range(world)]
+        main = reps[0]
+        for _ in range(steps):
+            acc = torch.zeros_like(main.arena.grads)
+            for t in reps:
+                t.arena.weights.copy_(main.arena.weights)
+                t.forward_backward()
+                acc += t.arena.grads
+            main.arena.grads.copy_(acc)
+            main.opt.step(1.0 / world)
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "w_single.npy"), main.arena.weights.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "nccl1":
+    if sys.argv[1] == "rccl":
+        rccl(sys.argv[2])
+    elif sys.argv[1] == "nccl1":
         nccl1(sys.argv[2])
     elif sys.argv[1] == "pair":
         pair(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])

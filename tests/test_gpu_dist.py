@@ -41,7 +41,7 @@ def test_rccl_world1_forced_collectives_bit_equal_to_plain_step(tmp_path):
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus N` without a launcher starts the ranks itself (here N = 1 through the same path)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--force-collective",
-                        "--steps", "4", "--warmup", "3", "--no-cpu-baseline", "--no-nms", "--no-roofline"],
+                        "--steps", "4", "--warmup", "3", "--no-cpu-baseline", "--no-nms", "--no-roofline", "--no-extras"],
                        env={k: v for k, v in _env().items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")},
                        timeout=900, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -74,3 +74,45 @@ def test_two_replicas_equal_one_process_accumulating(tmp_path):
     assert np.array_equal(w0, w1)
     scale = float(np.abs(ws).max())
     assert float(np.abs(w0 - ws).max()) <= 1e-6 * scale, float(np.abs(w0 - ws).max())
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()          # (does not initialise the GPU in this process)
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs >= 2 GPUs: the in-place RCCL path with more than one rank")
+def test_rccl_world_n_replicas_identical_and_equal_to_accumulation(tmp_path):
+    """Self-enabling on a multi-GPU node (RCCL had never run with more than one rank on this code).
+    R = min(#GPUs, 8) ranks, one per GPU, backend 'nccl' (RCCL over xGMI, in place in HBM), hipGraph replay, overlap on,
+    three steps, each rank its own batch (train.py:261-267 MirroredStrategy semantics):
+      * every replica ends with bit-identical weights;
+      * they equal ONE process that accumulates the R batches' gradients and applies their mean, to 1e-6 of the range;
+      * every step issued its buckets in the planned order: the heads + FPN slice [cut, count) first (under the backbone's
+        backward pass), the backbone slice [0, cut) after it."""
+    world = min(_gpu_count(), 8)
+    env = {k: v for k, v in _env().items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), WORKER, "rccl", str(tmp_path)]
+    r = subprocess.run(cmd, env=env, timeout=1200, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    ws = [np.load(tmp_path / ("w_%d.npy" % i)) for i in range(world)]
+    for w in ws[1:]:
+        assert np.array_equal(ws[0], w)
+    single = np.load(tmp_path / "w_single.npy")
+    scale = float(np.abs(single).max())
+    assert float(np.abs(ws[0] - single).max()) <= 1e-6 * scale, float(np.abs(ws[0] - single).max())
+    for i in range(world):
+        res = json.load(open(tmp_path / ("r_%d.json" % i)))
+        assert res["world"] == world and res["graph"]
+        cut, count, launched = res["cut_offset"], res["count"], [tuple(x) for x in res["launched"]]
+        per = len(launched) // 3
+        assert per >= 2 and len(launched) == 3 * per
+        for s in range(3):
+            step = launched[s * per:(s + 1) * per]
+            heads = [b for b in step if b[0] >= cut]
+            backbone = [b for b in step if b[1] <= cut]
+            assert len(heads) + len(backbone) == per                       # no bucket straddles the cut
+            assert step[:len(heads)] == heads                               # heads + FPN region first
+            assert sorted(heads) [0][0] == cut and max(e for _, e in heads) == count
+            assert min(b for b, _ in backbone) == 0 and max(e for _, e in backbone) == cut

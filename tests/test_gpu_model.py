@@ -271,3 +271,45 @@ def test_stage_cut_backward_parts_bit_equal_to_single_segment(dev, backbone, use
         assert seen[0] == (ta.cut_offset, ta.arena.count) and len(seen) >= 4, seen
         assert all(a[0] == b[1] for a, b in zip(seen, seen[1:])) and seen[-1][0] == 0, seen
     assert torch.equal(ta.arena.weights, tb.arena.weights)
+
+
+def test_twenty_step_loss_curve_matches_oracle(dev):
+    """Loss-CURVE parity: twenty momentum steps at 64x64 on a stream of different batches, the product
+    through its replayed hipGraph segments, the oracle through train_ref.train_step -- every step's class loss, regression
+    loss and regulariser within 1e-3 relative (the bar loosens from the one-step 1e-4 because twenty updates compound
+    rounding differences through the weights), the weights after twenty steps within 2e-3 of their range."""
+    import levels as levels_mod, train
+    net, params, image0, labels0 = _tiny_problem(dev, seed=5)
+    rng = np.random.default_rng(55)
+    box_sets = [np.array([[0.1, 0.15, 0.6, 0.7], [0.5, 0.4, 0.95, 0.9], [0.05, 0.5, 0.4, 0.98]], np.float32),
+                np.array([[0.2, 0.2, 0.8, 0.8]], np.float32),
+                np.array([[0.0, 0.0, 0.5, 0.45], [0.45, 0.5, 1.0, 1.0]], np.float32),
+                np.array([[0.3, 0.1, 0.7, 0.5], [0.1, 0.55, 0.35, 0.95], [0.6, 0.6, 0.9, 0.85], [0.05, 0.05, 0.3, 0.3]], np.float32)]
+    batches = []
+    for b in box_sets:
+        cids = rng.integers(0, 3, len(b))
+        cls, reg, msk = dataset_ref.build_labels((64, 64), cids, b, 3)
+        fc, fr, fm, _ = dataset_ref.flip(cls, reg, msk)
+        img = rng.standard_normal((1, 64, 64, 3)).astype(np.float32)
+        image = torch.from_numpy(np.concatenate([img, img[:, :, ::-1]], 0).copy())
+        labels = {"classifications": {k: torch.from_numpy(np.stack([cls[k], fc[k]])) for k in cls},
+                  "regressions": {k: torch.from_numpy(np.stack([reg[k], fr[k]])) for k in cls},
+                  "trainable_masks": {k: torch.from_numpy(np.stack([msk[k], fm[k]])) for k in cls}}
+        batches.append((image, labels, _features(image, labels, dev)))
+    trainer = train.Trainer(net, levels_mod.build_levels(), optimizer="momentum", learning_rate=1e-2, loss_mode="bce_dice",
+                            device=dev, use_graph=True)
+    state, worst, curve = {}, 0.0, []
+    for step in range(1, 21):
+        image, labels, feats = batches[(step - 1) % len(batches)]
+        out = trainer.step(feats)
+        first, _ = train_ref.train_step(params, image, labels, 3, state, lr=1e-2, optimizer="momentum", step=step,
+                                        loss_mode="bce_dice")
+        torch.cuda.synchronize()
+        got = (out["class_loss"].item(), out["regr_loss"].item(), out["regularization_loss"].item())
+        curve.append(got[:2])
+        for g, w, what in zip(got, first[1:4], ("class", "regr", "regulariser")):
+            worst = max(worst, assert_close(g, w, 1e-3, "%s loss at step %d" % (what, step)))
+    assert curve[-4][0] < curve[0][0] and curve[-4][1] < curve[0][1], curve       # same batch, 16 steps later: it learns
+    for name, p in net.named_parameters():
+        assert_close(p.detach().cpu().numpy(), params[to_oracle_name(name)].numpy(), 2e-3, name + " after 20 steps")
+    print("worst loss error over 20 steps %.2e" % worst)

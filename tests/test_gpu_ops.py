@@ -719,6 +719,52 @@ def test_loss_without_foreground(dev):
         assert float(rg.grad.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("c", [80, 3])
+def test_loss_nan_targets_follow_the_references_masking(dev, c):
+    """A degenerate ground-truth box leaves NaN log-size targets on every anchor (dataset.py:118-121, see
+    test_assignment_degenerate_box_is_the_references_nan).  The reference REMOVES the rows outside the trainable mask
+    (boolean_mask, utils.py:270-278) and MULTIPLIES the Huber term by the foreground weight (losses.py:146-152): NaN targets
+    only on non-trainable rows -> finite loss and gradients; a NaN target on a trainable row (also a background one) -> NaN
+    loss, NaN gradient on that row, as the oracle.  Both kernel families (four lanes per row: C = 80; wave per row: C = 3)."""
+    import ops
+    rng = np.random.default_rng(40 + c)
+    z, lab, rp, rl, m = _loss_inputs(rng, c, levels=((2, 8, 8, 9),), fg_rate=0.1)[0]
+    m = m.copy()
+    m.reshape(-1)[:40] = False
+    m.reshape(-1)[40:80] = True
+
+    def run(rl_):
+        zc, rc = torch.from_numpy(z).requires_grad_(True), torch.from_numpy(rp).requires_grad_(True)
+        mt = torch.from_numpy(m)
+        cl, rlc = losses_ref.loss(torch.from_numpy(lab)[mt], torch.from_numpy(rl_)[mt], zc[mt], rc[mt], "focal")
+        (cl + rlc).backward()
+        zg, rg = _t(z, dev, True), _t(rp, dev, True)
+        clg, rlg, _ = ops.detection_loss([zg], [rg], [_t(lab, dev)], [_t(rl_, dev)], [_t(m.astype(np.uint8), dev)], c, "focal")
+        (clg + rlg).backward()
+        return rlc.item(), rc.grad.numpy(), rlg.item(), rg.grad.cpu().numpy(), clg.item(), cl.item()
+
+    # (1) NaN only where the mask removes the row: everything finite and equal to the oracle
+    a = rl.copy()
+    a.reshape(-1, 4)[:40, 2] = np.nan
+    ro, go, rk, gk, ck, co = run(a)
+    assert np.isfinite(rk) and np.isfinite(gk).all()
+    assert_close(rk, ro, TOL, "regr loss, NaN targets outside the mask")
+    assert_close(gk, go, TOL, "d reg, NaN targets outside the mask")
+    assert_close(ck, co, TOL, "class loss")
+    # (2) NaN on trainable rows (foreground or not): NaN * weight = NaN in the loss and in those rows' gradients
+    b = rl.copy()
+    b.reshape(-1, 4)[40:80, 2] = np.nan
+    ro, go, rk, gk, ck, co = run(b)
+    assert np.isnan(ro) and np.isnan(rk)
+    # (the loss is NaN either way; at the NaN elements themselves the kernel keeps NaN * weight = NaN, the torch oracle's
+    # abs / clamp backward happens to give 0 there -- every other element must agree)
+    ok = np.ones_like(gk, bool)
+    ok.reshape(-1, 4)[40:80, 2] = False
+    assert np.isnan(gk[~ok]).all() and np.isfinite(gk[ok]).all()
+    assert_close(gk[ok], go[ok], TOL, "d reg away from the NaN targets")
+    assert_close(ck, co, TOL, "class loss")
+
+
 def test_assignment_single_object_and_padding(dev):
     """One valid object per image; the padded slots of the [N, max_obj] arrays must be ignored."""
     import dataset, levels

@@ -1,8 +1,8 @@
 #!/bin/bash
 # PMC evidence of the training step (GPU box): kernel trace + three counter passes over the same bench command.
 export TMPDIR=/tmp; mkdir -p gpurun_out
-R=${ROUND:-r03}
-CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-nms --no-roofline --no-graph"
+R=${ROUND:-r04}
+CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-nms --no-roofline --no-extras --no-graph"
 rocprofv3 -L > gpurun_out/${R}_counters_list.txt 2>&1
 for P in trace fetch write sq; do rm -rf gpurun_out/${R}_pmc_$P; done
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_pmc_trace -- $CMD > gpurun_out/${R}_pmc_trace.log 2>&1

@@ -4,12 +4,12 @@
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 [ -z "$QUICK" ] && timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > gpurun_out/${R}_tests.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/${R}_smoke.log 2>&1
 timeout 600 python bench.py > gpurun_out/${R}_bench.log 2>&1
 rm -rf gpurun_out/${R}_prof gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_prof -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${R}_prof.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_prof -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/${R}_prof.log 2>&1
 TRACE=$(find gpurun_out/${R}_prof -name "bench_kernel_trace.csv" | head -1)
 python tools/timeline.py $TRACE > gpurun_out/${R}_bench_step_timeline.txt
 python tools/by_grid.py $TRACE > gpurun_out/${R}_bench_kernel_trace_by_grid.txt
