@@ -413,7 +413,7 @@ def cfg1_gpu(device, steps=100):
                       "every step is a new sample" % steps}
 
 
-def other_config(backbone, size, batch, steps=8, warmup=3, use_graph=True):
+def other_config(device, backbone, size, batch, steps=8, warmup=3, use_graph=True):
     """Per-GPU workload of BASELINE configs[2] / configs[3] (ResNeXt-50-FPN 800^2 bs 2, DenseNet-121-FPN 640^2 bs 4) on ONE GPU:
     the same step as the headline (assignment + forward + focal / smooth-L1 + backward in stage parts + momentum)."""
     import dataset, layers, levels, retinanet, train
@@ -760,7 +760,7 @@ def main():
             result["config"]["cfg1_gpu"] = cfg1_gpu(device)
             torch.cuda.empty_cache()
             result["other_configs"] = {"note": "per-GPU workloads of BASELINE configs[2] and configs[3] on ONE GPU (their multi-GPU runs are the driver's)",
-                                       "cfg3": other_config("resnet_50", 800, 2), "cfg4": other_config("densenet_121", 640, 4)}
+                                       "cfg3": other_config(device, "resnet_50", 800, 2), "cfg4": other_config(device, "densenet_121", 640, 4)}
             torch.cuda.empty_cache()
             result["inference"] = inference_benchmark(device)
             torch.cuda.empty_cache()

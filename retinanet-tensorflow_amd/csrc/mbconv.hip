@@ -699,6 +699,7 @@ struct PwBwdArgs {
   int d_tiles_n, dblocks;                     // data gradient: N-tiles over cin; blocks
   int w_tiles_m, w_tiles_n, chunk, sps;       // weight gradient: tiles over (cin, cout), pixels per split, splits per sample
   float* slab;                                // [n * sps][cin][cout]
+  int wfirst;                                 // the weight-gradient blocks take the LOWEST block indices (dispatched first)
 };
 // both halves use PB x PB tiles: 64 (2 x 2 waves per group) or, on the smallest maps, 32 (one wave per group; more blocks)
 constexpr int pw_lds(int pb) { return 2 * pb * LDK; }   // operand floats per group (dgrad: two k-contiguous tiles; wgrad needs 2 * BK * pb, less)
@@ -998,8 +999,13 @@ __global__ __launch_bounds__((DPB / 32) * (DPB / 32) * 64 * DKS) void mb_pw_bwd_
   __shared__ float gstat[GMAX][2];
   __shared__ float gc[GMAX][2];
   constexpr int NST = 1;      // operand tiles in flight per thread (measured: 4 stages cost occupancy on the big maps and buy nothing on the small)
-  if ((int)blockIdx.x < a.dblocks) mb_pw_dgrad_body<ACT_OUT, DPB, DKS, NST>(a, smem, tabD, gstat, gc, blockIdx.x);
-  else mb_pw_wgrad_body<(ACT_IN == -2 ? 0 : ACT_IN), WPB, WKS, NST>(a, smem, tabA, tabD, gstat, gc, (int)blockIdx.x - a.dblocks, (int)gridDim.x - a.dblocks);
+  // big maps: a weight-gradient block walks 8 - 32 K-tiles of pixels, a data-gradient block 1 - 5 of channels -- with more
+  // blocks than the chip holds at once the long ones go first (block indices are dispatched in order), or they form the tail
+  const int nw = (int)gridDim.x - a.dblocks;
+  const int b = (int)blockIdx.x;
+  const bool is_w = a.wfirst ? b < nw : b >= a.dblocks;
+  if (!is_w) mb_pw_dgrad_body<ACT_OUT, DPB, DKS, NST>(a, smem, tabD, gstat, gc, a.wfirst ? b - nw : b);
+  else mb_pw_wgrad_body<(ACT_IN == -2 ? 0 : ACT_IN), WPB, WKS, NST>(a, smem, tabA, tabD, gstat, gc, a.wfirst ? b : b - a.dblocks, nw);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1018,7 +1024,9 @@ struct DwBwdArgs {
 
 __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
-template <int ACT, bool MULTI>
+// S: the stride as a compile-time constant (1 | 2) -- the tap -> output index arithmetic of the data gradient divides by it
+// nine times per pixel and thread; with a runtime divisor that arithmetic, not memory, bounded the 256^2 / 128^2 maps
+template <int ACT, bool MULTI, int S>
 __global__ __launch_bounds__(T, 2) void mb_dw_bwd_kernel(const DwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];   // a1 patch [(th+2)(tw+2)][sw] | dy patch [oph*opw][sw]
   __shared__ __attribute__((aligned(16))) float tabA[4 * 128];   // scale | shift | mean | rstd of the slab's channels (GN1)
@@ -1035,7 +1043,9 @@ __global__ __launch_bounds__(T, 2) void mb_dw_bwd_kernel(const DwBwdArgs a) {
   // then live across the loop, so the stencil weights move from registers to LDS)
   const int blk = tt % a.nblk, sample = tt / a.nblk;
   const int tile_lo = MULTI ? blk * a.tpb : blk, tile_hi = MULTI ? min(tile_lo + a.tpb, ntile) : tile_lo + 1;
-  const int C = a.c, SW = a.sw, SQ = SW >> 2, c0 = slab * SW, s = a.stride;
+  const int C = a.c, SW = a.sw, SQ = SW >> 2, c0 = slab * SW;
+  constexpr int s = S;
+  const int tw_shift = 31 - __builtin_clz(a.tw);          // (the planner's tiles are powers of two)
   const int aph = a.th + 2, apw = a.tw + 2;
   float* a1p = dsm;
   float* dyp = dsm + (size_t)aph * apw * SW;
@@ -1132,7 +1142,7 @@ __global__ __launch_bounds__(T, 2) void mb_dw_bwd_kernel(const DwBwdArgs a) {
       const float4 sc = *reinterpret_cast<const float4*>(&tabA[q4 * 4]), sh = *reinterpret_cast<const float4*>(&tabA[128 + q4 * 4]);
       const float4 mn = *reinterpret_cast<const float4*>(&tabA[256 + q4 * 4]), rs = *reinterpret_cast<const float4*>(&tabA[384 + q4 * 4]);
       for (int p = pl; p < a.th * a.tw; p += lanes) {
-        const int ty = p / a.tw, tx = p - ty * a.tw;
+        const int ty = p >> tw_shift, tx = p - (ty << tw_shift);
         const int ih = ih0 + ty, iw = iw0 + tx;
         if (ih < a.h && iw < a.wd) {
           const float4 yv = *reinterpret_cast<const float4*>(y1 + (size_t)(ih * a.wd + iw) * C);
@@ -1140,13 +1150,13 @@ __global__ __launch_bounds__(T, 2) void mb_dw_bwd_kernel(const DwBwdArgs a) {
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh) {
             const int ohs = ih + a.pad_t - kh;
-            const int oh_ = ohs / s;                         // (ohs < 0 only with a 0 weight: see m below)
+            const int oh_ = S == 1 ? ohs : (ohs >> 1);       // (ohs < 0 only with a 0 weight: see m below)
             const bool rok = ohs >= 0 && oh_ * s == ohs && oh_ < a.oh;
             const int py = min(max(oh_ - oy0, 0), a.oph - 1);
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
               const int ows = iw + a.pad_l - kw;
-              const int ow_ = ows / s;
+              const int ow_ = S == 1 ? ows : (ows >> 1);
               const float m = (rok && ows >= 0 && ow_ * s == ows && ow_ < a.ow) ? 1.f : 0.f;
               const int px = min(max(ow_ - ox0, 0), a.opw - 1);
               const float4 dv = *reinterpret_cast<const float4*>(&dyp[((size_t)py * a.opw + px) * SW + q4 * 4]);
@@ -1529,6 +1539,8 @@ PwBwdCfg pw_bwd_cfg(int n, int hw, int cin, int cout) {
 void pw_wgrad_plan(int n, int hw, int cin, int cout, int pb, int ks, int* chunk, int* sps) {
   const int tiles = rn::ceil_div(cin, pb) * rn::ceil_div(cout, pb);
   int want = rn::ceil_div(384, tiles * n);             // splits per sample for ~384 blocks
+  static const int big_blocks = getenv("RN_MB_WGRAD_BIG_BLOCKS") ? atoi(getenv("RN_MB_WGRAD_BIG_BLOCKS")) : 384;
+  if (hw >= 16384 && big_blocks > 0) want = rn::ceil_div(big_blocks, tiles * n);   // (the 128^2 / 256^2 maps: tuning aid)
   if (const char* f = getenv("RN_MB_WGRAD_SPS")) { if (atoi(f) > 0) want = atoi(f); }   // tuning aid
   const int unit = 128 * ks;
   const int units = hw % unit == 0 ? hw / unit : 1;    // (hw is a multiple of 64; odd multiples: one split per sample)
@@ -1611,6 +1623,8 @@ extern "C" int rn_mb_pointwise_bwd(const float* x, const rn_mb_norm* in, const r
   const size_t need = (size_t)nsplit * cin * cout * sizeof(float);
   if (workspace_bytes < need) { rn::set_error("mb pointwise bwd: workspace %zu < %zu bytes", workspace_bytes, need); return RN_EWORKSPACE; }
   a.slab = nsplit == 1 ? dw : (float*)workspace;
+  static const int wfirst_env = getenv("RN_MB_WGRAD_FIRST") ? atoi(getenv("RN_MB_WGRAD_FIRST")) : 1;
+  a.wfirst = (wfirst_env && a.dblocks > 1024) ? 1 : 0;      // (only where the grid does not fit the chip in one go)
   const dim3 grid((unsigned)(a.dblocks + nsplit * a.w_tiles_m * a.w_tiles_n));
   hipStream_t st = (hipStream_t)stream;
   const int act_in = in ? in->act : -2, act_out = gout->norm ? gout->norm->act : RN_ACT_NONE;
@@ -1679,10 +1693,17 @@ extern "C" int rn_mb_depthwise_bwd(const rn_mb_norm* in, const rn_mb_dy* dy, con
   RN_UNSUPPORTED(lds > 64 * 1024, "mb depthwise bwd: patches of %zu bytes", lds);
   const dim3 grid((unsigned)((long)nrows * p.nslab));
   hipStream_t st = (hipStream_t)stream;
-  if (in->act == RN_ACT_ELU && p.tpb == 1) hipLaunchKernelGGL((mb_dw_bwd_kernel<RN_ACT_ELU, false>), grid, dim3(T), lds, st, a);
-  else if (in->act == RN_ACT_ELU) hipLaunchKernelGGL((mb_dw_bwd_kernel<RN_ACT_ELU, true>), grid, dim3(T), lds, st, a);
-  else if (in->act == RN_ACT_RELU6) hipLaunchKernelGGL((mb_dw_bwd_kernel<RN_ACT_RELU6, true>), grid, dim3(T), lds, st, a);
-  else hipLaunchKernelGGL((mb_dw_bwd_kernel<-1, true>), grid, dim3(T), lds, st, a);
+  RN_CHECK_ARG((p.tw & (p.tw - 1)) == 0, "mb depthwise bwd: tile width %d is not a power of two", p.tw);
+#define RN_DWB(ACT_, MULTI_)                                                                                           \
+  do {                                                                                                                 \
+    if (stride == 1) hipLaunchKernelGGL((mb_dw_bwd_kernel<ACT_, MULTI_, 1>), grid, dim3(T), lds, st, a);               \
+    else hipLaunchKernelGGL((mb_dw_bwd_kernel<ACT_, MULTI_, 2>), grid, dim3(T), lds, st, a);                           \
+  } while (0)
+  if (in->act == RN_ACT_ELU && p.tpb == 1) RN_DWB(RN_ACT_ELU, false);
+  else if (in->act == RN_ACT_ELU) RN_DWB(RN_ACT_ELU, true);
+  else if (in->act == RN_ACT_RELU6) RN_DWB(RN_ACT_RELU6, true);
+  else RN_DWB(-1, true);
+#undef RN_DWB
   RN_LAUNCH_CHECK();
   return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)9 * c, nrows, 0, st);
 }

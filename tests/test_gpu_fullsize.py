@@ -348,8 +348,8 @@ def test_cfg5_fp16_detections_match_the_fp32_oracle(dev):
     (`detect_raw(logits=True)`: sigmoid inside the scan, train.py:68-85) against the fp32 CPU oracle's
     `detect_image` (sigmoid -> boxes_decode -> merge -> nms_classwise).  The class-output bias is raised so that ~1 % of
     the anchors of the ORACLE clear 0.5 (what a trained detector produces).  Bars: >= 99 % of the oracle's survivors
-    (anchor row, class) are survivors of the fp16 path and vice versa; their boxes agree to 1e-2 of the image; scores to
-    2e-2 absolute."""
+    (anchor row, class) are survivors of the fp16 path and vice versa; their boxes agree to F16_BOX_TOL of the box's own extent;
+    scores to the margin."""
     import layers, levels, retinanet, utils
     classes, size, batch = 80, 1024, 2
     torch.manual_seed(21)
@@ -394,7 +394,10 @@ def test_cfg5_fp16_detections_match_the_fp32_oracle(dev):
         firm_ref += len(firm_w); firm_ref_found += sum(k in got for k in firm_w)
         firm_got += len(firm_g); firm_got_found += sum(k in want for k in firm_g)
         for key in common:
-            worst_box = max(worst_box, float(np.abs(ob[got[key]] - rb[want[key]]).max()))
+            # relative to the box's own extent (boxes are not clipped: a P7 anchor decodes to more than the image)
+            b = rb[want[key]]
+            ext = max(float(b[2] - b[0]), float(b[3] - b[1]), 1e-6)
+            worst_box = max(worst_box, float(np.abs(ob[got[key]] - b).max()) / ext)
             worst_score = max(worst_score, abs(float(os_[got[key]]) - float(rs[want[key]])))
         hot = ncand / float(sum(p.shape[0] * p.shape[1] * p.shape[2] for p in probs.values()))
         assert 0.003 < hot < 0.03, "oracle candidates should be ~1 %% of the anchors, got %.4f" % hot
@@ -405,10 +408,11 @@ def test_cfg5_fp16_detections_match_the_fp32_oracle(dev):
     assert total_ref > 1000
     assert firm_ref_found >= F16_FIRM_AGREEMENT * firm_ref and firm_got_found >= F16_FIRM_AGREEMENT * firm_got
     assert agree >= F16_ALL_AGREEMENT * total_ref and agree >= F16_ALL_AGREEMENT * total_got
-    assert worst_box <= 1e-2 and worst_score <= margin
+    assert worst_box <= F16_BOX_TOL and worst_score <= margin
 
 
 # bars of the fp16 detection test (set from the MI355X measurement of round 4)
 F16_SCORE_MARGIN = 2e-2          # a score may move by this much under fp16 storage
 F16_FIRM_AGREEMENT = 0.99        # survivors further than the margin above the threshold: >= 99 % identical (anchor, class)
+F16_BOX_TOL = 1e-2               # box corners, relative to the box's extent
 F16_ALL_AGREEMENT = 0.90         # all survivors, including the ones within the margin of the threshold

@@ -34,6 +34,7 @@ def _shapes_trainer(dev, use_graph, feed, dropout=0.2, seed=11, scale=128, loss=
     lv = levels_mod.build_levels()
     loader = Shapes(None, image_size=(scale + scale // 4, scale), seed=seed)
     torch.manual_seed(0)
+    layers.Dropout._next_seed[0] = 0x5EED             # the same dropout streams for every net built in this process
     net = retinanet.RetinaNet('mobilenet_v2', lv, loader.num_classes, layers.elu, dropout).to(dev)
     if feed:
         src = dataset.DeviceFeed(loader, lv, scale=scale, device=dev)
@@ -127,6 +128,9 @@ def test_shapes_training_reaches_a_pinned_map():
 
 
 # measured on MI355X (gpurun, round 4) with the committed seeds; see DESIGN.md section 4 "Training quality"
-TRAIN_STEPS = 1500
-MAP_PINNED, AP50_PINNED, MAP_TOL = 0.0, 0.0, 1.0          # placeholder until measured
-MAP_FLOOR, AP50_FLOOR = 0.0, 0.0
+# 2500 steps (9.5 s): mAP 0.6269, AP50 0.9106, AP75 0.7882 (tools/map_probe.py: 0.14 / 0.29 / 0.39 / 0.48 / 0.63 / 0.66 mAP after
+# 300 / 600 / 1000 / 1500 / 2500 / 4000 steps).  The tolerance allows for other rounding orders in later builds (2500 SGD steps
+# amplify them); the floors are what "it learned to detect shapes" means here.
+TRAIN_STEPS = 2500
+MAP_PINNED, AP50_PINNED, MAP_TOL = 0.6269, 0.9106, 0.08
+MAP_FLOOR, AP50_FLOOR = 0.45, 0.75

@@ -11,7 +11,7 @@ import bench
 
 def run(backbone, size, batch, steps=8, warmup=3, use_graph=True):
     torch.cuda.set_device(0)
-    return bench.other_config(backbone, size, batch, steps, warmup, use_graph)
+    return bench.other_config(torch.device('cuda:0'), backbone, size, batch, steps, warmup, use_graph)
 
 
 if __name__ == "__main__":

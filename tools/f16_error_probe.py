@@ -1,0 +1,55 @@
+"""Where does the fp16 inference path lose accuracy?  ResNeXt-50-FPN against the fp32 CPU oracle: relative L2 error per backbone tap, per
+pyramid level and at the outputs, for fp16 outputs vs fp32 outputs and with / without the GroupNorm fold (RN_F16_FOLD)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "retinanet-tensorflow_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+
+
+def main(size=384):
+    import layers, levels, retinanet
+    from test_gpu_fullsize import _whole_net_oracle, _randomize_norms, LEVELS
+    from helpers import to_oracle_name
+    from oracle import model_ref
+    dev = torch.device("cuda:0")
+    classes = 80
+    torch.manual_seed(5)
+    net = retinanet.RetinaNet('resnet_50', levels.build_levels(), classes, layers.elu, 0.0)
+    _randomize_norms(net, 6)
+    x = torch.randn(1, size, size, 3)
+    with torch.no_grad():
+        feats, ref = _whole_net_oracle('resnet_50', net, x, classes)
+        params = {to_oracle_name(k): v.detach().cpu().clone() for k, v in net.named_parameters()}
+        pyr = model_ref.fpn_forward(params, feats, "elu")
+        net.to(dev)
+
+        def rel(a, b):
+            a, b = a.double().cpu(), b.double().cpu()
+            return float((a - b).norm() / b.norm())
+
+        for outputs in ("f16", "f32"):
+            layers.set_inference_dtype('f16', outputs=outputs)
+            try:
+                out = net(x.to(dev), training=False)
+                f16 = net.base.backbone(x.to(dev), training=False)
+                p16 = net.base.fpn({k: f16[k] for k in ("C3", "C4", "C5")}, training=False)
+            finally:
+                layers.set_inference_dtype('f32')
+            row = ["outputs=" + outputs]
+            row += ["%s %.2e" % (k, rel(f16[k].float(), feats[k])) for k in ("C1", "C2", "C3", "C4", "C5") if k in f16 and k in feats]
+            row += ["%s %.2e" % (k, rel(p16[k].float(), pyr[k])) for k in LEVELS]
+            for k in LEVELS:
+                a, b = out["classifications"][k].float(), ref["classifications"][k]
+                row.append("cls%s %.2e (sig std %.3f, raw rel %.2e)" % (k, rel(a - a.mean(), b - b.mean()), float(b.std()), rel(a, b)))
+                row.append("reg%s %.2e" % (k, rel(out["regressions"][k].float(), ref["regressions"][k])))
+            print("; ".join(row), flush=True)
+        # a second fp32 evaluation of the product itself (different summation order): the noise floor of the comparison
+        out32 = net(x.to(dev), training=False)
+        print("fp32 product vs oracle: " + "; ".join("cls%s %.2e" % (k, rel(out32["classifications"][k] - out32["classifications"][k].mean(),
+                                                                             ref["classifications"][k] - ref["classifications"][k].mean())) for k in LEVELS))
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 384)

@@ -29,4 +29,5 @@ def main(loss="bce_dice", marks=(300, 600, 1000, 1500, 2500, 4000), lr=1e-2):
 
 
 if __name__ == "__main__":
-    main(*(sys.argv[1:2] or ["bce_dice"]))
+    main(sys.argv[1] if len(sys.argv) > 1 else "bce_dice", lr=float(sys.argv[2]) if len(sys.argv) > 2 else 1e-2,
+         marks=(300, 600, 1000, 1500, 2500) if len(sys.argv) > 2 else (300, 600, 1000, 1500, 2500, 4000))
