@@ -1319,7 +1319,8 @@ struct DwPlan { int th, tw, tiles_h, tiles_w, sw, nslab, ph, pw, tpb, nblk; };
 // tiles per block of the depthwise kernels: about two blocks per CU (RN_MB_DW_TPB overrides: measurements)
 int dw_tiles_per_block(long blocks, int ntile) {
   static const int forced = getenv("RN_MB_DW_TPB") ? atoi(getenv("RN_MB_DW_TPB")) : 0;
-  int tpb = forced > 0 ? forced : (int)(blocks / 512);
+  static const int target = getenv("RN_MB_DW_BLOCKS") ? atoi(getenv("RN_MB_DW_BLOCKS")) : 512;    // blocks per launch (tuning aid)
+  int tpb = forced > 0 ? forced : (int)(blocks / (target > 0 ? target : 512));
   if (tpb < 1) tpb = 1;
   if (tpb > ntile) tpb = ntile;
   return tpb;

@@ -8,6 +8,7 @@ reference mobilenet_v2.py:41-94 is applied by the kernel that consumes it, a bot
 -- it consumes the last bottleneck's GroupNorm while loading, the node returns its RAW output and the statistic rows of it.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -38,11 +39,14 @@ def _rows(query, *args):
     return lay, int(nbytes)
 
 
+COMPACT_ABOVE = int(os.environ.get('RN_MB_COMPACT_ABOVE', '256'))     # tuning aid: compact the rows of a sample when there are more
+
+
 def _compact(rows, lay, n, dev):
     """(rows, layout) a consumer can merge: the producer's, or -- more rows per sample than rn_mb_rows_max() (the largest maps) --
     their sums over runs of consecutive rows (rn_mb_compact_rows, one small launch)."""
     L = _rn.lib()
-    if lay.rows_per_sample <= L.rn_mb_rows_max():
+    if lay.rows_per_sample <= min(L.rn_mb_rows_max(), COMPACT_ABOVE):
         return rows, lay
     src = _rn.MbRows(rows.data_ptr(), lay.rows_per_sample, lay.width, lay.bn)
     out = _rn.MbRows()

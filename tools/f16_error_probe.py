@@ -45,6 +45,18 @@ def main(size=384):
                 row.append("cls%s %.2e (sig std %.3f, raw rel %.2e)" % (k, rel(a - a.mean(), b - b.mean()), float(b.std()), rel(a, b)))
                 row.append("reg%s %.2e" % (k, rel(out["regressions"][k].float(), ref["regressions"][k])))
             print("; ".join(row), flush=True)
+        # conditioning of the (random-init) network itself: ONE relative perturbation of rms 2^-11 / sqrt(3) (what one fp16 rounding is) of
+        # the input image, everything in fp32 -- how much of it arrives at the outputs
+        g = torch.Generator().manual_seed(1)
+        eps = 2.0 ** -11 / 3 ** 0.5
+        xp = x * (1 + eps * torch.randn(x.shape, generator=g))
+        base = net(x.to(dev), training=False)
+        pert = net(xp.to(dev), training=False)
+        print("fp32 product, input perturbed by one fp16 rounding (rms %.1e): " % eps + "; ".join(
+            "cls%s %.2e reg%s %.2e" % (k, rel(pert["classifications"][k] - pert["classifications"][k].mean(), base["classifications"][k] - base["classifications"][k].mean()),
+                                       k, rel(pert["regressions"][k], base["regressions"][k])) for k in LEVELS), flush=True)
+        fb, fp_ = net.base.backbone(x.to(dev), training=False), net.base.backbone(xp.to(dev), training=False)
+        print("   backbone taps: " + "; ".join("%s %.2e" % (k, rel(fp_[k], fb[k])) for k in ("C3", "C4", "C5")), flush=True)
         # a second fp32 evaluation of the product itself (different summation order): the noise floor of the comparison
         out32 = net(x.to(dev), training=False)
         print("fp32 product vs oracle: " + "; ".join("cls%s %.2e" % (k, rel(out32["classifications"][k] - out32["classifications"][k].mean(),
