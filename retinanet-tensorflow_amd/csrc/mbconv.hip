@@ -1009,6 +1009,364 @@ __global__ __launch_bounds__((DPB / 32) * (DPB / 32) * 64 * DKS) void mb_pw_bwd_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Pointwise backward of the LARGE maps (256^2 / 128^2: narrow convs, 16 .. 144 channels), both gradients from ONE pass over
+// the pixels.  The tile kernels above read g and y twice (data-gradient blocks + weight-gradient blocks) and pay a prologue per
+// 64-row tile; here a block owns a run of pixels of one sample and each of its four WAVES walks 16-row chunks on its own:
+//   chunk rows are contiguous in memory -> every operand arrives as coalesced float4 rows (g, y -> dy formed on the way into
+//   the wave's LDS tile; the conv's input likewise), the next chunk's loads are in flight while this one is multiplied;
+//   d[16, cin]  = dy[16, cout] W^T              v_mfma_f32_16x16x4_f32, K = cout, W resident in LDS for the whole block
+//   dW[cin,cout] += A^T[cin, 16] dy[16, cout]   same tiles, K = the chunk's 16 pixels, accumulators live across the chunks
+//   epilogue as the tile kernel's (g = d act'(z) mask, per-channel sums), rows / planes ONCE per block, dW partial per block.
+// Y_IS_A (the linear conv: the GroupNorm block the data gradient enters IS the conv's input block): the wave's input tile holds
+// the RAW tensor -- the weight gradient's operand is normalised as it is read, the epilogue reads the raw value and leaves its
+// result in place.  Otherwise (the expand conv) the tile holds the operand, and the narrow tensors of the epilogue (the output
+// block's raw y, the addends) come as scalar loads in the accumulator layout, in flight with the chunk.
+// No barrier inside the loop (a wave reads only the LDS tiles it wrote).  HBM-bound by construction: 2 cout + cin (.. 4 cin)
+// floats read and cin written per pixel; the MFMA work is ~1/10 of that time.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct PwBigArgs {
+  int dbg;                                    // tuning aid (RN_MB_DBG=pwB:<phase>): stop after a phase
+  const float* x; NormDev in; int has_in;
+  DyDev dy; const float* w; GoutDev go;
+  int n, hw, cin, cout;
+  int ppb, bps;                               // pixels per block (multiple of 16), blocks per sample
+  float* slab;                                // [n * bps][cin][cout]
+};
+constexpr int pw_big_lds_floats(int nti, int nto) {      // W [CI][CO + 4] | per wave: Dt [16][CO + 4], At [16][CI + 4]
+  return nti * 16 * (nto * 16 + 4) + 4 * 16 * ((nto * 16 + 4) + (nti * 16 + 4));
+}
+
+template <int NTI, int NTO, bool Y_IS_A>
+__global__ __launch_bounds__(T, 2) void mb_pw_bwd_big_kernel(const PwBigArgs a) {
+  constexpr int CI = NTI * 16, CO = NTO * 16, SA = CI + 4, SD = CO + 4;
+  constexpr int NG = (CO * 4 + 63) / 64, NA = (CI * 4 + 63) / 64;     // float4 loads per lane and chunk: dy side, input side
+  constexpr int NE = Y_IS_A ? 1 : 4 * NTI;                            // scalar epilogue loads per lane and tensor
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ __attribute__((aligned(16))) float tabD[3 * CO];
+  __shared__ __attribute__((aligned(16))) float tabA[2 * CI];
+  __shared__ __attribute__((aligned(16))) float tabO[4 * CI];         // mean | rstd | gamma | beta per output channel
+  __shared__ float gstat[GMAX][2];
+  __shared__ float gc[GMAX][2];
+  __shared__ __attribute__((aligned(16))) double mscratch[(T + GMAX) * 2];   // the row merges' own scratch: W goes to its tile at once
+  static_assert(pw_big_lds_floats(NTI, NTO) >= 2 * NTI * NTO * 256 && pw_big_lds_floats(NTI, NTO) >= 10 * CI, "the operand tiles double as the final exchange");
+  constexpr bool PF = NTI * NTO < 18;            // the next chunk's rows in flight under the products (the widest tiles: registers)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = blockIdx.x, sample = blk / a.bps, bis = blk - sample * a.bps;
+  const int KI = a.cin, NO = a.cout, M = a.n * a.hw;
+  const int p_begin = sample * a.hw + bis * a.ppb;
+  const bool plain = a.dy.dy != nullptr;
+  const GoutDev& go = a.go;
+  float* Wl = lds;
+  float* Dt = lds + CI * SD + wave * 16 * (SD + SA);
+  float* At = Dt + 16 * SD;
+  // ---- the chunk loads: float4 slot lane + 64 j of a chunk's 16 * C contiguous floats is (row, col) = divmod(4 (lane + 64 j), C);
+  // slot 0's pair is kept, the others follow by adding divmod(256, C) (no per-slot registers, no division in the loop)
+  const int g_r0 = (lane * 4) / NO, g_c0 = lane * 4 - g_r0 * NO, g_dr = 256 / NO, g_dc = 256 - g_dr * NO;
+  const int a_r0 = (lane * 4) / KI, a_c0 = lane * 4 - a_r0 * KI, a_dr = 256 / KI, a_dc = 256 - a_dr * KI;
+  auto g_slot = [&](int j, int& row, int& col) {      // (j is a compile-time constant at every call: the loop below folds)
+    row = g_r0; col = g_c0;
+    for (int t = 0; t < j; ++t) { row += g_dr; col += g_dc; if (col >= NO) { col -= NO; ++row; } }
+    return (lane + 64 * j) * 4 < 16 * NO;
+  };
+  auto a_slot = [&](int j, int& row, int& col) {
+    row = a_r0; col = a_c0;
+    for (int t = 0; t < j; ++t) { row += a_dr; col += a_dc; if (col >= KI) { col -= KI; ++row; } }
+    return (lane + 64 * j) * 4 < 16 * KI;
+  };
+  const float* gsrc = plain ? a.dy.dy : a.dy.g;
+  const float* ysrc = plain ? a.dy.dy : a.dy.nd.y;
+  const float* asrc = a.has_in ? a.in.y : a.x;
+  const bool y_sep = !Y_IS_A && go.has_norm;
+  const __amdgpu_buffer_rsrc_t rg = make_rsrc(gsrc, (unsigned)M * NO * 4u);
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(ysrc, (unsigned)M * NO * 4u);
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(asrc, (unsigned)M * KI * 4u);
+  const __amdgpu_buffer_rsrc_t ryo = make_rsrc(y_sep ? go.nd.y : asrc, (unsigned)M * KI * 4u);
+  const __amdgpu_buffer_rsrc_t r1 = make_rsrc(go.add1 ? go.add1 : asrc, (unsigned)M * KI * 4u);
+  const __amdgpu_buffer_rsrc_t r2 = make_rsrc(go.add2 ? go.add2 : asrc, (unsigned)M * KI * 4u);
+  const int l15 = lane & 15, lq = lane >> 4;
+  float4 vg[NG], vy[NG], va[NA];
+  float eyo[NE], e1[NE], e2[NE];                  // accumulator layout: [i * 4 + r] = (row 4 lq + r, col 16 i + l15)
+#pragma unroll
+  for (int t = 0; t < NE; ++t) { eyo[t] = 0.f; e1[t] = 0.f; e2[t] = 0.f; }
+  auto load_chunk = [&](int p) {                  // p: first pixel of the chunk
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const unsigned off = (lane + 64 * j) * 4 < 16 * NO ? ((unsigned)p * NO + (unsigned)(lane + 64 * j) * 4u) * 4u : OOB;
+      vg[j] = Vec<4>::load(rg, off);
+      vy[j] = Vec<4>::load(ry, plain ? OOB : off);
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      va[j] = Vec<4>::load(ra, (lane + 64 * j) * 4 < 16 * KI ? ((unsigned)p * KI + (unsigned)(lane + 64 * j) * 4u) * 4u : OOB);
+    if (!Y_IS_A) {
+#pragma unroll
+      for (int i = 0; i < NTI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = i * 16 + l15;
+          const unsigned off = col < KI ? ((unsigned)(p + 4 * lq + r) * KI + col) * 4u : OOB;
+          eyo[(i * 4 + r) % NE] = Vec<1>::load(ryo, y_sep ? off : OOB);
+          e1[(i * 4 + r) % NE] = Vec<1>::load(r1, go.add1 ? off : OOB);
+          e2[(i * 4 + r) % NE] = Vec<1>::load(r2, go.add2 ? off : OOB);
+        }
+    }
+  };
+  const int nchunk = a.ppb >> 4;
+  // ---- prologue (all 256 threads).  Everything from memory first: W (-> its LDS tile, zero padding included), the tables' inputs
+  constexpr int WQ = (CI * (CO >> 2) + T - 1) / T;
+  {
+    float4 wv[WQ];
+#pragma unroll
+    for (int j = 0; j < WQ; ++j) {
+      const int e = tid + j * T, ci = e / (CO >> 2), q = e - ci * (CO >> 2);
+      const bool ok = ci < KI && q * 4 < NO;
+      wv[j] = ok ? *reinterpret_cast<const float4*>(a.w + (size_t)ci * NO + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < WQ; ++j) {
+      const int e = tid + j * T, ci = e / (CO >> 2), q = e - ci * (CO >> 2);
+      if (ci < CI) *reinterpret_cast<float4*>(&Wl[ci * SD + q * 4]) = wv[j];
+    }
+    // zero padding of this thread's share of the waves' tiles: dy columns [NO, CO), input columns [KI, CI)
+    for (int e = tid; e < 4 * 16 * (CO - NO + CI - KI); e += T) {
+      const int per = CO - NO + CI - KI, wv_ = e / (16 * per), r_ = (e / per) % 16, c_ = e % per;
+      float* dt = lds + CI * SD + wv_ * 16 * (SD + SA);
+      if (c_ < CO - NO) dt[r_ * SD + NO + c_] = 0.f;
+      else dt[16 * SD + r_ * SA + KI + (c_ - (CO - NO))] = 0.f;
+    }
+  }
+  ChanPre<1> pre_d, pre_a;
+  GroupPre gp_d = {0.f, 1.f}, gp_a = {0.f, 1.f};
+  if (!plain) {
+    prefetch_chan<1>(a.dy.nd.gamma, nullptr, 0, NO, tid, pre_d);
+    gp_d = prefetch_groups(a.dy.nd, sample, 0, a.dy.nd.groups, tid);
+  }
+  if (a.has_in) {
+    prefetch_chan<1>(a.in.gamma, a.in.beta, 0, KI, tid, pre_a);
+    gp_a = prefetch_groups(a.in, sample, 0, a.in.groups, tid);
+  }
+  if (go.has_norm) {
+    for (int c = tid; c < CI; c += T) {
+      const int cc = min(c, KI - 1), og = cc / go.nd.cpg;
+      tabO[c] = go.nd.mean[sample * go.nd.groups + og];
+      tabO[CI + c] = go.nd.rstd[sample * go.nd.groups + og];
+      tabO[2 * CI + c] = go.nd.gamma[cc];
+      tabO[3 * CI + c] = go.nd.beta[cc];
+    }
+  }
+  bool mask = false, drop_in = false;
+  uint64_t seed = 0, seed_in = 0;
+  if (!plain) {
+    dy_table(a.dy, sample, a.hw, 0, NO, mscratch, gstat, gc, tabD, CO, gp_d, pre_d, tid);
+    mask = a.dy.g_plain && a.dy.nd.drop_rate > 0.f;
+    seed = a.dy.nd.seed + (a.dy.nd.seed_dev ? *a.dy.nd.seed_dev : 0ull);
+  }
+  if (a.has_in) {
+    group_stats(a.in, sample, a.hw, 0, a.in.groups, false, mscratch, gstat, gp_a, tid);
+    scale_shift_table(a.in, 0, KI, 0, gstat, tabA, tabA + CI, pre_a, tid);
+    drop_in = a.in.drop_rate > 0.f;
+    seed_in = a.in.seed + (a.in.seed_dev ? *a.in.seed_dev : 0ull);
+  }
+  __syncthreads();
+  f32x4 accw[NTI][NTO];
+#pragma unroll
+  for (int i = 0; i < NTI; ++i)
+#pragma unroll
+    for (int o = 0; o < NTO; ++o) accw[i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float s1[NTI], s2[NTI];
+#pragma unroll
+  for (int i = 0; i < NTI; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  const NormDev& ond = go.nd;
+  const bool odrop = go.has_norm && ond.drop_rate > 0.f;
+  const uint64_t oseed = go.has_norm ? ond.seed + (ond.seed_dev ? *ond.seed_dev : 0ull) : 0ull;
+  if (a.dbg == 1) return;
+  if (PF && wave < nchunk) load_chunk(p_begin + wave * 16);
+  for (int ch = wave; ch < nchunk; ch += 4) {
+    const int p = p_begin + ch * 16;
+    if (!PF) load_chunk(p);
+    // ---- operands -> this wave's LDS tiles
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      int row, col;
+      if (g_slot(j, row, col)) {
+        float4 v = vg[j];
+        if (!plain) v = dy_of(v, vy[j], tabD, CO, col, mask, a.dy.nd.drop_rate, a.dy.nd.keep_scale, seed, (uint64_t)(p + row) * NO + col);
+        *reinterpret_cast<float4*>(&Dt[row * SD + col]) = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      int row, col;
+      if (a_slot(j, row, col)) {
+        float4 v = va[j];
+        if (!Y_IS_A && a.has_in)
+          v = norm_act_drop<-1>(v, *reinterpret_cast<const float4*>(&tabA[col]), *reinterpret_cast<const float4*>(&tabA[CI + col]),
+                                a.in.act, drop_in, a.in.drop_rate, a.in.keep_scale, seed_in, (uint64_t)(p + row) * KI + col);
+        *reinterpret_cast<float4*>(&At[row * SA + col]) = v;
+      }
+    }
+    float yo[NE], ad[NE];
+#pragma unroll
+    for (int t = 0; t < NE; ++t) { yo[t] = eyo[t]; ad[t] = e1[t] + e2[t]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (PF && ch + 4 < nchunk) load_chunk(p + 64); // the next chunk's rows are in flight under the products
+    if (a.dbg == 2) continue;
+    // ---- d = dy W^T  (A: dy[row = l15][k], B: W[ci = l15][k], four k per step: k = 4 ks + lq)
+    f32x4 accd[NTI];
+#pragma unroll
+    for (int i = 0; i < NTI; ++i) accd[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (k is summed in the order that lets a lane fetch FOUR of its k values with one b128 read: in step 4 s + t lane group lq
+    // supplies k = 16 s + 4 lq + t, of dy and of W alike; the padding columns up to CO are zeros)
+#pragma unroll 2
+    for (int ks = 0; ks < NTO; ++ks) {
+      const float4 a4 = *reinterpret_cast<const float4*>(&Dt[l15 * SD + 16 * ks + 4 * lq]);
+      const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int i = 0; i < NTI; ++i) {
+        const float4 b4 = *reinterpret_cast<const float4*>(&Wl[(i * 16 + l15) * SD + 16 * ks + 4 * lq]);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accd[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[t], bb[t], accd[i], 0, 0, 0);
+      }
+    }
+    // ---- dW += A^T dy over the chunk's 16 pixels.  k (the pixel) is summed in the order px = 4 lq + t: in step t lane group lq
+    // supplies pixel 4 lq + t of A and of dy -- the (row, col) set a lane feeds is then exactly the set it OWNS in the
+    // accumulator layout of d, so with Y_IS_A one pass over the element does both jobs: z, exp and the dropout mask once ->
+    // the operand drop(act(z)) for the MFMA, g = d act'(z) mask for the epilogue, left in place of the raw value.
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = 4 * lq + t;
+      float bv[NTO];
+#pragma unroll
+      for (int o = 0; o < NTO; ++o) bv[o] = Dt[row * SD + o * 16 + l15];
+#pragma unroll
+      for (int i = 0; i < NTI; ++i) {
+        const int col = i * 16 + l15;
+        const bool cok = col < KI;
+        float av = At[row * SA + col];
+        if (Y_IS_A) {
+          const float raw = av;
+          const float z = fmaf(raw, tabA[col], tabA[CI + col]);
+          const float m = drop_in ? keep1(seed_in, (uint64_t)(p + row) * KI + col, a.in.drop_rate, a.in.keep_scale) : 1.f;
+          float fa, fg;                              // act(z), act'(z)
+          if (a.in.act == RN_ACT_ELU) { const float ez = __expf(fminf(z, 0.f)); fa = z > 0.f ? z : ez - 1.f; fg = z > 0.f ? 1.f : ez; }
+          else { fa = act_of<-1>(z, a.in.act); fg = actgrad_of<-1>(z, a.in.act); }
+          av = cok ? fa * m : 0.f;
+          const float xh = (raw - tabO[col]) * tabO[CI + col];
+          const float d = accd[i][t];
+          float g = cok ? d * fg * m : 0.f;
+          s1[i] += g; s2[i] = fmaf(g, xh, s2[i]);
+          At[row * SA + col] = cok ? (go.store_plain ? d : g) : 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < NTO; ++o) accw[i][o] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[o], accw[i][o], 0, 0, 0);
+      }
+    }
+    // ---- epilogue in the accumulator layout: lane holds d[row = 4 lq + r][col = 16 i + l15]; result -> At -> coalesced rows
+    if (!Y_IS_A) {
+#pragma unroll
+      for (int i = 0; i < NTI; ++i) {
+        const int col = i * 16 + l15;
+        const bool cok = col < KI;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * lq + r;
+          const float d = accd[i][r] + ad[(i * 4 + r) % NE];
+          float outv = d;
+          if (go.has_norm) {
+            const float xh = (yo[(i * 4 + r) % NE] - tabO[col]) * tabO[CI + col];
+            const float z = fmaf(xh, tabO[2 * CI + col], tabO[3 * CI + col]);
+            float g = d * actgrad_of<-1>(z, ond.act);
+            if (odrop) g *= keep1(oseed, (uint64_t)(p + row) * KI + col, ond.drop_rate, ond.keep_scale);
+            if (!cok) g = 0.f;
+            s1[i] += g; s2[i] = fmaf(g, xh, s2[i]);
+            outv = go.store_plain ? d : g;
+          }
+          if (!cok) outv = 0.f;
+          At[row * SA + col] = outv;                 // (this lane alone reads / writes the element in this phase)
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      int row, col;
+      if (a_slot(j, row, col))
+        *reinterpret_cast<float4*>(go.out + (size_t)p * KI + (size_t)(lane + 64 * j) * 4) = *reinterpret_cast<const float4*>(&At[row * SA + col]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (a.dbg == 3) { if (accw[0][0][0] == 123.456f) a.slab[0] = s1[0]; return; }
+  // ---- block totals: the four waves' dW accumulators, (w0 + w2) + (w1 + w3), through LDS; then the rows / planes
+  __syncthreads();
+  float* ex = lds;                                // [2][tile][r][lane]
+  auto put = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < NTI; ++i)
+#pragma unroll
+      for (int o = 0; o < NTO; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ex[((slot * NTI * NTO + i * NTO + o) * 4 + r) * 64 + lane] = accw[i][o][r];
+  };
+  auto add = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < NTI; ++i)
+#pragma unroll
+      for (int o = 0; o < NTO; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accw[i][o][r] += ex[((slot * NTI * NTO + i * NTO + o) * 4 + r) * 64 + lane];
+  };
+  if (wave >= 2) put(wave - 2);
+  __syncthreads();
+  if (wave < 2) add(wave);
+  __syncthreads();
+  if (wave < 2) put(wave);
+  __syncthreads();
+  {
+    float* slab = a.slab + (size_t)blk * KI * NO;
+    for (int e = tid; e < NTI * NTO * 256; e += T) {     // e = (tile, r, lane): (w0 + w2) + (w1 + w3)
+      const int ln = e & 63, r = (e >> 6) & 3, tl = e >> 8;
+      const int i = tl / NTO, o = tl - i * NTO;
+      const int ci = i * 16 + 4 * (ln >> 4) + r, co = o * 16 + (ln & 15);
+      if (ci < KI && co < NO) slab[(size_t)ci * NO + co] = ex[((0 * NTI * NTO + tl) * 4 + r) * 64 + ln] + ex[((1 * NTI * NTO + tl) * 4 + r) * 64 + ln];
+    }
+  }
+  if (!go.has_norm) return;
+  __syncthreads();
+  float* red = lds;                               // [wave][2][CI]
+#pragma unroll
+  for (int i = 0; i < NTI; ++i) {
+    float t1 = s1[i], t2 = s2[i];
+    t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+    t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
+    if (lane < 16) { red[(wave * 2 + 0) * CI + i * 16 + lane] = t1; red[(wave * 2 + 1) * CI + i * 16 + lane] = t2; }
+  }
+  __syncthreads();
+  float* chan = lds + 8 * CI;                     // [CI][2]
+  const int prow = sample * a.bps + bis;
+  for (int c = tid; c < KI; c += T) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { t1 += red[(w * 2 + 0) * CI + c]; t2 += red[(w * 2 + 1) * CI + c]; }
+    chan[c * 2 + 0] = t1; chan[c * 2 + 1] = t2;
+    go.planes[(size_t)prow * KI + c] = t1;
+    go.planes[go.plane_stride + (size_t)prow * KI + c] = t2;
+  }
+  __syncthreads();
+  if (tid < ond.groups) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int c = tid * ond.cpg; c < (tid + 1) * ond.cpg; ++c) {
+      const float w = ond.gamma[c];
+      t1 += w * chan[c * 2 + 0]; t2 += w * chan[c * 2 + 1];
+    }
+    go.grows.rows[(size_t)prow * go.grows.W + tid] = make_float2(t1, t2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // depthwise 3x3 backward: block = (sample, TH x TW INPUT tile, channel slab).  LDS: the dy patch (dy = rstd (gamma g - c1
 // - xhat c2) formed once per element) and the a1 patch (drop(act(GN(y1))), formed once per element).  Data gradient of the
 // tile's pixels -> g1 = d act'(z1) mask with its rows / planes; weight-gradient partial sums over the outputs whose window
@@ -1550,6 +1908,27 @@ void pw_wgrad_plan(int n, int hw, int cin, int cout, int pb, int ks, int* chunk,
     if (units % d == 0) best = d;
   *sps = best; *chunk = hw / best;
 }
+// the one-pass kernel of the large maps (mb_pw_bwd_big_kernel): which (cin, cout) it is built for, pixels per block
+struct PwBigCfg { int nti, nto, ppb, bps; };
+bool pw_big_cfg(int n, int hw, int cin, int cout, PwBigCfg* c) {
+  static const bool on = !(getenv("RN_MB_PW_BIG") && atoi(getenv("RN_MB_PW_BIG")) == 0);
+  static const int min_hw = getenv("RN_MB_PW_BIG_MIN_HW") ? atoi(getenv("RN_MB_PW_BIG_MIN_HW")) : 16384;
+  if (!on || hw < min_hw || hw % 64 || cin % 4 || cout % 4) return false;
+  const int nti = rn::ceil_div(cin, 16), nto = rn::ceil_div(cout, 16);
+  const bool built = (nti == 2 && nto == 2) || (nti == 1 && nto == 6) || (nti == 2 && nto == 9) || (nti == 2 && nto == 1) ||
+                     (nti == 6 && nto == 2) || (nti == 9 && nto == 2);
+  if (!built) return false;
+  if (nti == 9 && hw < 65536 && !getenv("RN_MB_PW_BIG_MIN_HW")) return false;   // (144 -> 24 at 128^2: measured slower than the tile kernel: its 36 + 72 accumulator
+                                                                                 // registers leave the fused operand / epilogue pass spilling)
+  // ~512 blocks (two per CU), a block's pixels a multiple of 64 that divides the sample; at most rn_mb_rows_max() rows per sample
+  static const int target = getenv("RN_MB_PW_BIG_BLOCKS") ? atoi(getenv("RN_MB_PW_BIG_BLOCKS")) : 512;
+  int ppb = 64;
+  while ((long)n * hw / ppb > target && hw % (ppb * 2) == 0) ppb *= 2;
+  while (hw / ppb > RMAX && hw % (ppb * 2) == 0) ppb *= 2;
+  if (hw / ppb > RMAX) return false;
+  c->nti = nti; c->nto = nto; c->ppb = ppb; c->bps = hw / ppb;
+  return true;
+}
 struct DwBwdPlan { int th, tw, tiles_h, tiles_w, sw, nslab, oph, opw, tpb, nblk; };
 bool dw_bwd_plan(int n, int h, int w, int c, int stride, int cpg, DwBwdPlan* p) {
   p->sw = dw_slab(c, cpg);
@@ -1579,6 +1958,11 @@ size_t dw_bwd_lds_bytes(const DwBwdPlan& p) {
 
 extern "C" size_t rn_mb_pointwise_bwd_rows(int n, int hw, int cin, int cout, int groups, rn_mb_rows* layout) {
   if (n < 1 || hw < 1 || cin < 4 || cout < 4 || groups < 1 || cin % groups || hw % 64) return 0;
+  PwBigCfg big;
+  if (pw_big_cfg(n, hw, cin, cout, &big)) {      // one row per block, one N-tile that spans cin
+    if (layout) { layout->rows_per_sample = big.bps; layout->width = groups + 1; layout->bn = big.nti * 16; }
+    return (size_t)n * big.bps * (groups + 1) * 8;
+  }
   const int pb = pw_bwd_cfg(n, hw, cin, cout).dpb;
   const int R = hw / pb, W = groups + rn::ceil_div(cin, pb);
   if (cin / groups > pb) return 0;
@@ -1587,6 +1971,8 @@ extern "C" size_t rn_mb_pointwise_bwd_rows(int n, int hw, int cin, int cout, int
 }
 extern "C" size_t rn_mb_pointwise_bwd_workspace(int n, int hw, int cin, int cout) {
   if (n < 1 || hw < 64 || hw % 64 || cin < 4 || cout < 4) return 0;
+  PwBigCfg big;
+  if (pw_big_cfg(n, hw, cin, cout, &big)) return (size_t)n * big.bps * cin * cout * sizeof(float);
   int chunk, sps;
   const PwBwdCfg c = pw_bwd_cfg(n, hw, cin, cout);
   pw_wgrad_plan(n, hw, cin, cout, c.wpb, c.wks, &chunk, &sps);
@@ -1615,6 +2001,39 @@ extern "C" int rn_mb_pointwise_bwd(const float* x, const rn_mb_norm* in, const r
   rn_mb_rows want = {};
   if (gout->norm) RN_UNSUPPORTED(!rn_mb_pointwise_bwd_rows(n, hw, cin, cout, gout->norm->groups, &want), "mb pointwise bwd: this shape cannot emit gradient rows");
   if (int e = fill_gout(gout, &a.go, n, cin, want, "mb pointwise bwd")) return e;
+  PwBigCfg big;
+  if (pw_big_cfg(n, hw, cin, cout, &big)) {
+    PwBigArgs b = {};
+    b.dbg = dbg_word("pwB");
+    b.x = a.x; b.in = a.in; b.has_in = a.has_in; b.dy = a.dy; b.w = w; b.go = a.go;
+    b.n = n; b.hw = hw; b.cin = cin; b.cout = cout; b.ppb = big.ppb; b.bps = big.bps;
+    const int nsplit = n * big.bps;
+    const size_t need = (size_t)nsplit * cin * cout * sizeof(float);
+    if (workspace_bytes < need) { rn::set_error("mb pointwise bwd: workspace %zu < %zu bytes", workspace_bytes, need); return RN_EWORKSPACE; }
+    b.slab = (float*)workspace;
+    // the linear conv: the block the data gradient enters is the conv's own input block (no addends there)
+    const bool y_is_a = a.has_in && a.go.has_norm && a.go.nd.y == a.in.y && !a.go.add1 && !a.go.add2;
+    const dim3 grid((unsigned)nsplit);
+    hipStream_t st = (hipStream_t)stream;
+#define RN_PWBIG(NTI_, NTO_)                                                                                                    \
+  do {                                                                                                                          \
+    constexpr size_t lds = (size_t)pw_big_lds_floats(NTI_, NTO_) * 4;                                                           \
+    static const bool attr_ = (hipFuncSetAttribute((const void*)mb_pw_bwd_big_kernel<NTI_, NTO_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) & \
+                              (hipFuncSetAttribute((const void*)mb_pw_bwd_big_kernel<NTI_, NTO_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess); \
+    RN_UNSUPPORTED(!attr_, "mb pointwise bwd: %zu bytes of LDS per block refused", lds);                                                                                                                \
+    if (y_is_a) hipLaunchKernelGGL((mb_pw_bwd_big_kernel<NTI_, NTO_, true>), grid, dim3(T), lds, st, b);                        \
+    else hipLaunchKernelGGL((mb_pw_bwd_big_kernel<NTI_, NTO_, false>), grid, dim3(T), lds, st, b);                              \
+  } while (0)
+    if (big.nti == 2 && big.nto == 2) RN_PWBIG(2, 2);
+    else if (big.nti == 1 && big.nto == 6) RN_PWBIG(1, 6);
+    else if (big.nti == 2 && big.nto == 9) RN_PWBIG(2, 9);
+    else if (big.nti == 2 && big.nto == 1) RN_PWBIG(2, 1);
+    else if (big.nti == 6 && big.nto == 2) RN_PWBIG(6, 2);
+    else RN_PWBIG(9, 2);
+#undef RN_PWBIG
+    RN_LAUNCH_CHECK();
+    return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)cin * cout, nsplit, 0, st);
+  }
   const PwBwdCfg cfg = pw_bwd_cfg(n, hw, cin, cout);
   a.d_tiles_n = rn::ceil_div(cin, cfg.dpb);
   a.dblocks = n * hw / cfg.dpb * a.d_tiles_n;
