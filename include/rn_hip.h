@@ -695,6 +695,15 @@ int rn_grad_norm_l2reg(const float* w, const float* grad, const float* wd_per_bl
 int rn_optimizer_step(int kind, float* w, const float* grad, float* state1, float* state2,
                       const float* wd_per_block, int64_t count, float lr, float grad_scale, float clip_norm,
                       const float* norm_sq, int64_t step, uint64_t* advance_counter, uint64_t advance_by, rn_stream_t stream);
+/* The same update WITHOUT clipping, for a slice [w, w + count) of the arena, that also forms the slice's share of
+ * (sum g'^2, L2 regulariser value) in the same pass (one read of w and grad instead of two): rn_optimizer_norm_pairs(count)
+ * (double, double) pairs into `partial`; rn_norm_reg_finalize sums the pairs of all slices (fixed order) into out2[2] =
+ * what rn_grad_norm_l2reg writes.  A trainer can so update the heads + FPN slice while the backbone's backward pass runs. */
+int64_t rn_optimizer_norm_pairs(int64_t count);
+int rn_optimizer_step_norm(int kind, float* w, const float* grad, float* state1, float* state2, const float* wd_per_block,
+                           int64_t count, float lr, float grad_scale, int64_t step, uint64_t* advance_counter,
+                           uint64_t advance_by, double* partial, rn_stream_t stream);
+int rn_norm_reg_finalize(const double* partial, int64_t npairs, float* out2, rn_stream_t stream);
 /* *counter += inc on the stream (the same counter, for callers that run backward passes without an optimizer step) */
 int rn_counter_add(uint64_t* counter, uint64_t inc, rn_stream_t stream);
 /* p[0..count) = 0 (16-byte aligned): the gradient arena before a backward pass (the reference's graph zero-initialises

@@ -170,7 +170,7 @@ SYMBOLS = [
     "rn_mb_rows_max", "rn_mb_compact_rows_layout", "rn_mb_compact_rows", "rn_mb_pointwise_rows", "rn_mb_pointwise_fwd", "rn_mb_depthwise_rows", "rn_mb_depthwise_fwd", "rn_mb_apply",
     "rn_mb_pointwise_bwd_rows", "rn_mb_pointwise_bwd_workspace", "rn_mb_pointwise_bwd",
     "rn_mb_depthwise_bwd_rows", "rn_mb_depthwise_bwd_workspace", "rn_mb_depthwise_bwd",
-    "rn_debug_collective_standin",
+    "rn_debug_collective_standin", "rn_optimizer_norm_pairs", "rn_optimizer_step_norm", "rn_norm_reg_finalize",
 ]
 
 
@@ -206,6 +206,11 @@ def lib():
         L.rn_conv2d_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_conv2d_dgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.rn_zero.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.rn_optimizer_norm_pairs.argtypes = [C.c_int64]
+        L.rn_optimizer_norm_pairs.restype = C.c_int64
+        L.rn_optimizer_step_norm.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int64, C.c_float, C.c_float, C.c_int64, C.c_void_p, C.c_uint64,
+                                             C.c_void_p, C.c_void_p]
+        L.rn_norm_reg_finalize.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.rn_debug_collective_standin.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]
         L.rn_conv2d_stats_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.rn_conv2d_fwd_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

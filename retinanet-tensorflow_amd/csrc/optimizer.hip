@@ -42,11 +42,16 @@ __global__ void norm_reg_finalize_kernel(const double* __restrict__ partial, int
   if (threadIdx.x == 0) { out2[0] = (float)a; out2[1] = (float)b; }
 }
 
-template <int KIND>
+// NORM: the pass that applies the update also forms this launch's share of (sum g'^2, L2 regulariser value) -- both at the
+// weights BEFORE the update, as rn_grad_norm_l2reg does -- into partial[block] (no clipping then: the norm is not an input)
+template <int KIND, bool NORM>
 __global__ __launch_bounds__(T) void opt_step_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                      float* __restrict__ s1, float* __restrict__ s2,
                                                      const float* __restrict__ wd, int64_t count, float lr, float gs,
-                                                     float clip, const float* __restrict__ norm_sq, unsigned long long* advance, unsigned long long advance_by) {
+                                                     float clip, const float* __restrict__ norm_sq, unsigned long long* advance, unsigned long long advance_by,
+                                                     double* __restrict__ partial) {
+  __shared__ double red[2][T / 64];
+  double n2 = 0.0, rg = 0.0;
   if (advance && blockIdx.x == 0 && threadIdx.x == 0) *advance += advance_by;  // the step counter the dropout masks hash (fresh masks next step)
   float cs = 1.f;
   if (clip > 0.f) {
@@ -62,6 +67,11 @@ __global__ __launch_bounds__(T) void opt_step_kernel(float* __restrict__ w, cons
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KIND != RN_OPT_MOMENTUM) bv = *reinterpret_cast<float4*>(s2 + i * 4);
     float* wp = &wv.x; const float* gp = &gv.x; float* ap = &av.x; float* bp = &bv.x;
+    if (NORM) {
+      const float t0 = gv.x * gs + d * wv.x, t1 = gv.y * gs + d * wv.y, t2 = gv.z * gs + d * wv.z, t3 = gv.w * gs + d * wv.w;
+      n2 += (double)(t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3);
+      rg += (double)(0.5f * d * (wv.x * wv.x + wv.y * wv.y + wv.z * wv.z + wv.w * wv.w));
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gg = (gp[j] * gs + d * wp[j]) * cs;
@@ -81,6 +91,17 @@ __global__ __launch_bounds__(T) void opt_step_kernel(float* __restrict__ w, cons
     *reinterpret_cast<float4*>(w + i * 4) = wv;
     *reinterpret_cast<float4*>(s1 + i * 4) = av;
     if (KIND != RN_OPT_MOMENTUM) *reinterpret_cast<float4*>(s2 + i * 4) = bv;
+  }
+  if (NORM) {
+    n2 = rn::wave_sum_d(n2); rg = rn::wave_sum_d(rg);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = n2; red[1][wave] = rg; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double a = 0.0, b = 0.0;
+      for (int i = 0; i < T / 64; ++i) { a += red[0][i]; b += red[1][i]; }
+      partial[blockIdx.x * 2] = a; partial[blockIdx.x * 2 + 1] = b;
+    }
   }
 }
 
@@ -110,31 +131,60 @@ extern "C" int rn_grad_norm_l2reg(const float* w, const float* grad, const float
   return RN_OK;
 }
 
-extern "C" int rn_optimizer_step(int kind, float* w, const float* grad, float* state1, float* state2,
-                                 const float* wd_per_block, int64_t count, float lr, float grad_scale, float clip_norm,
-                                 const float* norm_sq, int64_t step, uint64_t* advance_counter, uint64_t advance_by, rn_stream_t stream) {
+namespace {
+int launch_opt(int kind, float* w, const float* grad, float* state1, float* state2, const float* wd_per_block, int64_t count, float lr,
+               float grad_scale, float clip_norm, const float* norm_sq, int64_t step, uint64_t* advance_counter, uint64_t advance_by,
+               double* partial, hipStream_t st) {
   RN_CHECK_ARG(w && grad && state1 && wd_per_block, "optimizer: null pointer");
   RN_CHECK_ARG(count > 0 && count % RN_OPT_BLOCK == 0, "optimizer: count %lld not a multiple of %d", (long long)count,
                RN_OPT_BLOCK);
   RN_CHECK_ARG(clip_norm <= 0.f || norm_sq, "optimizer: clipping needs norm_sq");
   RN_CHECK_ARG(kind == RN_OPT_MOMENTUM || state2, "optimizer: state2 required for rmsprop/adam");
-  hipStream_t st = (hipStream_t)stream;
   const unsigned nb = grid_for(count / 4);
-  if (kind == RN_OPT_MOMENTUM) {
-    hipLaunchKernelGGL(opt_step_kernel<RN_OPT_MOMENTUM>, dim3(nb), dim3(T), 0, st, w, grad, state1, state2, wd_per_block,
-                       count, lr, grad_scale, clip_norm, norm_sq, (unsigned long long*)advance_counter, (unsigned long long)advance_by);
-  } else if (kind == RN_OPT_RMSPROP) {
-    hipLaunchKernelGGL(opt_step_kernel<RN_OPT_RMSPROP>, dim3(nb), dim3(T), 0, st, w, grad, state1, state2, wd_per_block,
-                       count, lr, grad_scale, clip_norm, norm_sq, (unsigned long long*)advance_counter, (unsigned long long)advance_by);
-  } else if (kind == RN_OPT_ADAM) {
+  float lr_eff = lr;
+  if (kind == RN_OPT_ADAM) {
     RN_CHECK_ARG(step >= 1, "optimizer: adam step must be >= 1");
-    const double lr_t = (double)lr * sqrt(1.0 - pow(0.999, (double)step)) / (1.0 - pow(0.9, (double)step));
-    hipLaunchKernelGGL(opt_step_kernel<RN_OPT_ADAM>, dim3(nb), dim3(T), 0, st, w, grad, state1, state2, wd_per_block,
-                       count, (float)lr_t, grad_scale, clip_norm, norm_sq, (unsigned long long*)advance_counter, (unsigned long long)advance_by);
-  } else {
+    lr_eff = (float)((double)lr * sqrt(1.0 - pow(0.999, (double)step)) / (1.0 - pow(0.9, (double)step)));
+  } else if (kind != RN_OPT_MOMENTUM && kind != RN_OPT_RMSPROP) {
     rn::set_error("optimizer: unknown kind %d", kind);
     return RN_EINVAL;
   }
+#define RN_OPT_LAUNCH(KIND_)                                                                                                  \
+  do {                                                                                                                        \
+    if (partial) hipLaunchKernelGGL((opt_step_kernel<KIND_, true>), dim3(nb), dim3(T), 0, st, w, grad, state1, state2, wd_per_block, count, lr_eff, \
+                                    grad_scale, clip_norm, norm_sq, (unsigned long long*)advance_counter, (unsigned long long)advance_by, partial); \
+    else hipLaunchKernelGGL((opt_step_kernel<KIND_, false>), dim3(nb), dim3(T), 0, st, w, grad, state1, state2, wd_per_block, count, lr_eff, \
+                            grad_scale, clip_norm, norm_sq, (unsigned long long*)advance_counter, (unsigned long long)advance_by, partial); \
+  } while (0)
+  if (kind == RN_OPT_MOMENTUM) RN_OPT_LAUNCH(RN_OPT_MOMENTUM);
+  else if (kind == RN_OPT_RMSPROP) RN_OPT_LAUNCH(RN_OPT_RMSPROP);
+  else RN_OPT_LAUNCH(RN_OPT_ADAM);
+#undef RN_OPT_LAUNCH
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+}  // namespace
+
+extern "C" int rn_optimizer_step(int kind, float* w, const float* grad, float* state1, float* state2,
+                                 const float* wd_per_block, int64_t count, float lr, float grad_scale, float clip_norm,
+                                 const float* norm_sq, int64_t step, uint64_t* advance_counter, uint64_t advance_by, rn_stream_t stream) {
+  return launch_opt(kind, w, grad, state1, state2, wd_per_block, count, lr, grad_scale, clip_norm, norm_sq, step, advance_counter, advance_by,
+                    nullptr, (hipStream_t)stream);
+}
+
+extern "C" int64_t rn_optimizer_norm_pairs(int64_t count) { return count > 0 ? (int64_t)grid_for(count / 4) : 0; }
+
+extern "C" int rn_optimizer_step_norm(int kind, float* w, const float* grad, float* state1, float* state2, const float* wd_per_block,
+                                      int64_t count, float lr, float grad_scale, int64_t step, uint64_t* advance_counter,
+                                      uint64_t advance_by, double* partial, rn_stream_t stream) {
+  RN_CHECK_ARG(partial, "optimizer step + norm: null partial buffer");
+  return launch_opt(kind, w, grad, state1, state2, wd_per_block, count, lr, grad_scale, 0.f, nullptr, step, advance_counter, advance_by,
+                    partial, (hipStream_t)stream);
+}
+
+extern "C" int rn_norm_reg_finalize(const double* partial, int64_t npairs, float* out2, rn_stream_t stream) {
+  RN_CHECK_ARG(partial && out2 && npairs >= 1 && npairs < (1 << 30), "norm_reg_finalize: bad argument");
+  hipLaunchKernelGGL(norm_reg_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, (int)npairs, out2);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }

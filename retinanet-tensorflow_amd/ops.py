@@ -209,6 +209,9 @@ def end_deferred_reductions():
         cur = torch.cuda.current_stream()
         try:
             _rn.check(L.rn_flush_reductions(C.byref(_defer_lists[cur.cuda_stream]), _rn.stream()), "rn_flush_reductions")
+            for st in _midway_streams:             # the flushes started midway (their inputs stay alive in _deferred_keep until here)
+                cur.wait_stream(st)
+            del _midway_streams[:]
             for st in _deferred_streams:
                 # fork again from the current stream first: after autograd's end-of-backward join a side stream is no
                 # longer part of an ongoing hipGraph capture, and its flush would run eagerly instead of being captured
@@ -219,6 +222,29 @@ def end_deferred_reductions():
         finally:
             del _deferred_keep[:]
             del _deferred_streams[:]
+
+
+FLUSH_MIDWAY = os.environ.get("RN_FLUSH_MIDWAY", "0") == "1"     # measured: 446 vs 450 images/s -- off (a fork / join edge costs more than the tail it shortens)
+
+
+def flush_deferred_midway(device):
+    """Run the row reductions recorded so far on the current stream NOW, on a side stream (index 4), and go on recording: a
+    long backward node (the MobileNetV2 chain: ~50 reductions, most of them recorded while the small maps are processed) then
+    leaves only its last few for the flush that sits on the critical path after the last backward kernel.  The side stream is
+    joined by end_deferred_reductions (and by _rn.join_side_streams)."""
+    if not (_deferring and FLUSH_MIDWAY):
+        return
+    cur = torch.cuda.current_stream()
+    lst = _defer_lists.get(cur.cuda_stream)
+    if lst is None or lst.count == 0:
+        return
+    side = _rn.side_stream(device, 4)
+    side.wait_stream(cur)
+    _rn.check(_rn.lib().rn_flush_reductions(C.byref(lst), C.c_void_p(side.cuda_stream)), "rn_flush_reductions")
+    _midway_streams.append(side)
+
+
+_midway_streams = []
 
 
 def _grad_workspace(need, device):

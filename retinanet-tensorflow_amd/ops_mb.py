@@ -254,9 +254,14 @@ class _MbChain(torch.autograd.Function):
         keep = [tg]
 
         dx0 = None
+        flushed = False
         for i in range(nb - 1, -1, -1):
             stride, residual, n1, n2, n3 = blocks_cfg[i]
             x_in, s1, s2, s3 = saved[i]
+            if not flushed and saved[i][0].shape[1] * saved[i][0].shape[2] >= 16384:
+                # the large maps begin: everything recorded so far is reduced beside them (ops.flush_deferred_midway)
+                ops.flush_deferred_midway(dev)
+                flushed = True
             w1, g1_, b1_, wd, g2_, b2_, w3, g3_, b3_ = params[9 * i:9 * i + 9]
             _, h, w, c = x_in.shape
             wide, cout = w1.shape[3], w3.shape[3]

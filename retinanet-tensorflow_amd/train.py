@@ -15,6 +15,7 @@ xGMI bandwidth, and the whole step (forward, loss, backward, optimizer) can be c
 hipGraph -- the launch-bound small kernels of the pyramid's coarse levels then cost no host time.
 """
 import contextlib
+import ctypes
 import os
 
 import numpy as np
@@ -28,6 +29,8 @@ import utils
 from levels import build_levels
 
 OPT_BLOCK = _rn.OPT_BLOCK
+FUSED_OPT_NORM = os.environ.get("RN_FUSED_OPT_NORM", "1") == "1"     # (tuning aids; both parity-neutral)
+EARLY_HEAD_UPDATE = os.environ.get("RN_EARLY_HEAD_UPDATE", "0") == "1"     # measured: 444 vs 448 images/s (one more stream in the step costs more than the overlap buys)
 
 
 class ParamArena(object):
@@ -79,11 +82,18 @@ class Optimizer(object):
         self.state1 = torch.ones_like(arena.weights) if kind == 'rmsprop' else torch.zeros_like(arena.weights)
         self.state2 = torch.zeros_like(arena.weights) if kind != 'momentum' else None
         self.norm_reg = torch.zeros(2, dtype=torch.float32, device=dev)   # [sum g'^2, L2 reg loss]
+        self._partial, self._pairs = None, 0
         self.step_count = 0
 
     def step(self, grad_scale=1.0, advance_counter=None):
         """`advance_counter`: the device word the dropout masks hash; bumped by the optimizer kernel itself."""
         a = self.arena
+        if self.clip <= 0.0 and a.weights.is_cuda and FUSED_OPT_NORM:
+            # no clipping: the norm is not an input of the update -- one pass over the arena forms it beside the update
+            self.begin_step()
+            self.step_slice(0, a.count, grad_scale, advance_counter)
+            self.finish_step()
+            return
         L_ = _rn.lib()
         ws = _rn.workspace(L_.rn_optimizer_workspace(a.count), a.weights.device)
         _rn.check(L_.rn_grad_norm_l2reg(_rn.f32(a.weights), _rn.f32(a.grads), _rn.f32(a.wd_per_block), a.count,
@@ -98,6 +108,34 @@ class Optimizer(object):
                                        ops.DROPOUT_COUNTER_STEP, _rn.stream()), 'rn_optimizer_step')
         import ops_f16
         ops_f16.weights_changed()      # fp16-packed copies of the kernels (inference path) are stale now
+
+    # -- the update in slices of the arena (no clipping): Trainer.step updates the heads + FPN slice on a side stream while the
+    # backbone's backward pass still runs, the rest after it; every slice's launch leaves its share of (sum g'^2, regulariser)
+    def begin_step(self):
+        self.step_count += 1
+        self._pairs = 0
+        if self._partial is None:
+            n = 4 * int(_rn.lib().rn_optimizer_norm_pairs(self.arena.count)) + 16
+            self._partial = torch.zeros(2 * n, dtype=torch.float64, device=self.arena.weights.device)
+
+    def step_slice(self, lo, hi, grad_scale, advance_counter=None, stream=None):
+        a, L_ = self.arena, _rn.lib()
+        assert 0 <= lo < hi <= a.count and lo % OPT_BLOCK == 0 and hi % OPT_BLOCK == 0
+        npairs = int(L_.rn_optimizer_norm_pairs(hi - lo))
+        assert 2 * (self._pairs + npairs) <= self._partial.numel()
+        part = self._partial[2 * self._pairs:]
+        self._pairs += npairs
+        _rn.check(L_.rn_optimizer_step_norm(_rn.OPT[self.kind], a.weights[lo:].data_ptr(), a.grads[lo:].data_ptr(), self.state1[lo:].data_ptr(),
+                                            self.state2[lo:].data_ptr() if self.state2 is not None else None,
+                                            a.wd_per_block[lo // OPT_BLOCK:].data_ptr(), hi - lo, self.lr, grad_scale, self.step_count,
+                                            advance_counter.data_ptr() if advance_counter is not None else None, ops.DROPOUT_COUNTER_STEP,
+                                            part.data_ptr(), stream if stream is not None else _rn.stream()), 'rn_optimizer_step_norm')
+
+    def finish_step(self):
+        _rn.check(_rn.lib().rn_norm_reg_finalize(self._partial.data_ptr(), self._pairs, _rn.f32(self.norm_reg), _rn.stream()),
+                  'rn_norm_reg_finalize')
+        import ops_f16
+        ops_f16.weights_changed()
 
     @property
     def regularization_loss(self):
@@ -386,7 +424,9 @@ class Trainer(object):
         return out
 
     def _capture(self, features):
-        self._static = features
+        # the captured segments read PRIVATE copies of the features: a caller may hand in other tensors (or reuse these) on
+        # later steps -- step() copies them into the static buffers -- and must never find its own tensors overwritten
+        self._static = _clone_tree(features)
         # warm-up on a side stream (allocator + workspace sizing), then capture
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -434,6 +474,19 @@ class Trainer(object):
         if feed is not None:
             feed.consumed()
         self.allreduce.launch(self.cut_offset, self.arena.count)      # heads + FPN: under the backbone's backward pass
+        # ... and, without clipping (the global norm would need every gradient first), their UPDATE too: on a side stream, behind
+        # segment A and the slice's collectives, while the backbone's backward pass (which reads neither these weights nor these
+        # gradients) runs on the main stream
+        early = (EARLY_HEAD_UPDATE and FUSED_OPT_NORM and self.opt.clip <= 0.0 and 0 < self.cut_offset < self.arena.count
+                 and self.device.type == 'cuda' and not self.allreduce.host_staged)
+        if early:
+            side = _rn.side_stream(self.device, 5)
+            side.wait_stream(torch.cuda.current_stream())
+            self.opt.begin_step()
+            with torch.cuda.stream(side):
+                for w in self.allreduce._works:
+                    w.wait()                                          # (makes `side` wait for the collective, not the host)
+                self.opt.step_slice(self.cut_offset, self.arena.count, 1.0 / self.allreduce.world, None, ctypes.c_void_p(side.cuda_stream))
         if self.use_graph:
             for gb, (lo, hi) in zip(self._graphs[1], self._graphs[2]):
                 gb.replay()
@@ -452,7 +505,12 @@ class Trainer(object):
             self.timing.setdefault('exposed_events', []).append((e0, e1))
         else:
             grad_scale = self.allreduce.wait()
-        self.opt.step(grad_scale, self.drop_counter)          # also bumps the dropout counter: fresh masks next step
+        if early:
+            torch.cuda.current_stream().wait_stream(side)
+            self.opt.step_slice(0, self.cut_offset, grad_scale, self.drop_counter)   # also bumps the dropout counter
+            self.opt.finish_step()
+        else:
+            self.opt.step(grad_scale, self.drop_counter)      # also bumps the dropout counter: fresh masks next step
         self.steps_done += 1
         # (only the opt-in grid-resident GroupNorm can flag anything; checked after the first steps too, not only every
         # check_interval: a poisoned update must not be trained on for long)
@@ -495,6 +553,16 @@ def _for_each_tensor(tree, fn):
     elif isinstance(tree, (list, tuple)):
         for v in tree:
             _for_each_tensor(v, fn)
+
+
+def _clone_tree(tree):
+    if torch.is_tensor(tree):
+        return tree.clone()
+    if isinstance(tree, dict):
+        return {k: _clone_tree(v) for k, v in tree.items()}
+    if isinstance(tree, (list, tuple)):
+        return type(tree)(_clone_tree(v) for v in tree)
+    return tree
 
 
 def _copy_tree(dst, src):
