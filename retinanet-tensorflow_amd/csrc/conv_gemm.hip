@@ -959,9 +959,11 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
     RN_CHECK_ARG(sr.rows->rows, "conv fwd stats: null rows");
     a.st.rows = (float2*)sr.rows->rows; a.st.groups = groups; a.st.cpg = d.cout / groups;
   }
+  static const int fpad_env = getenv("RN_PROD_LDS_PAD_FWD") ? atoi(getenv("RN_PROD_LDS_PAD_FWD")) : 0;
+  const int fpad = bt.n > 1 ? fpad_env : 0;      // (batched = the Winograd products; see RN_PROD_LDS_PAD_BWD)
 #define RN_FWD(BM_, BN_, WM_, WN_)                                                                   \
   do {                                                                                               \
-    if (tapu) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 4, true>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
+    if (tapu) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 4, true>), dim3(tiles), dim3(WM_* WN_ * 64), fpad, st, a); \
     else if (vec) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 4, false>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
     else hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 1, false>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a);     \
   } while (0)
@@ -1330,10 +1332,13 @@ int rn::launch_winograd_bwd_products(const float* Ad, const float* Bd, float* Cd
   *nsplit_out = pw.nsplit;
   const ConvArgs4 d4 = compact(pd.a), w4 = compact(pw.a);
   const dim3 grid((unsigned)(pd.blocks + pw.blocks));
+  // tuning aid: unused dynamic LDS caps the products' blocks per CU, leaving registers / wave slots for the OTHER subnet's
+  // transform kernel that runs beside them (RN_PROD_LDS_PAD_BWD bytes)
+  static const int pad = getenv("RN_PROD_LDS_PAD_BWD") ? atoi(getenv("RN_PROD_LDS_PAD_BWD")) : 0;
 #define RN_BWD(WBM_, WBN_, WWM_, WWN_)                                                                                          \
   do {                                                                                                                          \
-    if (pd.tapu) hipLaunchKernelGGL((conv_bwd_kernel<64, 64, 2, 2, true, WBM_, WBN_, WWM_, WWN_>), grid, dim3(256), 0, st, d4, w4, pd.blocks); \
-    else hipLaunchKernelGGL((conv_bwd_kernel<64, 64, 2, 2, false, WBM_, WBN_, WWM_, WWN_>), grid, dim3(256), 0, st, d4, w4, pd.blocks);        \
+    if (pd.tapu) hipLaunchKernelGGL((conv_bwd_kernel<64, 64, 2, 2, true, WBM_, WBN_, WWM_, WWN_>), grid, dim3(256), pad, st, d4, w4, pd.blocks); \
+    else hipLaunchKernelGGL((conv_bwd_kernel<64, 64, 2, 2, false, WBM_, WBN_, WWM_, WWN_>), grid, dim3(256), pad, st, d4, w4, pd.blocks);        \
   } while (0)
   switch (pw.cfg) {
     case 0: RN_BWD(128, 128, 2, 2); break;
