@@ -5,9 +5,9 @@ cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${ROUND:-r04}
-[ -z "$QUICK" ] && timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > gpurun_out/${R}_tests.log
+[ -z "$QUICK" ] && timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -12 > gpurun_out/${R}_tests.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/${R}_smoke.log 2>&1
-timeout 600 python bench.py > gpurun_out/${R}_bench.log 2>&1
+timeout 900 python bench.py > gpurun_out/${R}_bench.log 2>&1
 rm -rf gpurun_out/${R}_prof gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_prof -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/${R}_prof.log 2>&1
 TRACE=$(find gpurun_out/${R}_prof -name "bench_kernel_trace.csv" | head -1)
@@ -18,10 +18,15 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpu
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${R}_pmc_write -- python tools/gemm_pmc.py > gpurun_out/${R}_pmc_w.log 2>&1
 python tools/pmc_traffic.py gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write > gpurun_out/${R}_pmc_traffic.json
 ROUND=$R bash tools/pmc_step.sh > gpurun_out/${R}_pmc_step.log 2>&1
-[ -z "$QUICK" ] && timeout 600 python tools/bench_configs.py > gpurun_out/${R}_cfgs.log 2>&1
-[ -z "$QUICK" ] && timeout 400 python tools/bench_inference.py > gpurun_out/${R}_inf.log 2>&1
+[ -z "$QUICK" ] && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_inf_prof -o inf -- python tools/inf_prof.py > gpurun_out/${R}_inf_prof.log 2>&1
+[ -z "$QUICK" ] && cp $(find gpurun_out/${R}_inf_prof -name "inf_kernel_stats.csv" | head -1) gpurun_out/${R}_inference_f16_kernel_stats.csv
+rm -rf gpurun_out/${R}_inf_prof
 [ -z "$QUICK" ] && timeout 200 python tools/tower_bench.py 720 > gpurun_out/${R}_tower.log 2>&1
 rm -rf gpurun_out/${R}_nms_prof
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_nms_prof -o nms -- python tools/nms_prof.py > gpurun_out/${R}_nms.log 2>&1
 python tools/by_grid.py $(find gpurun_out/${R}_nms_prof -name "nms_kernel_trace.csv" | head -1) > gpurun_out/${R}_nms_kernels_by_grid.txt
+rm -rf gpurun_out/${R}_nms_prof
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_nms_prof -o nms -- python tools/nms_prof.py stress > gpurun_out/${R}_nms_stress.log 2>&1
+python tools/by_grid.py $(find gpurun_out/${R}_nms_prof -name "nms_kernel_trace.csv" | head -1) > gpurun_out/${R}_nms_stress_kernels_by_grid.txt
+rm -rf gpurun_out/${R}_nms_prof gpurun_out/${R}_prof gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write
 tail -3 gpurun_out/${R}_tests.log; tail -1 gpurun_out/${R}_smoke.log; tail -1 gpurun_out/${R}_bench.log | cut -c1-400
