@@ -1687,7 +1687,11 @@ bool dw_plan(int n, int oh, int ow, int c, int stride, int cpg, DwPlan* p) {
   p->sw = dw_slab(c, cpg);
   if (!p->sw) return false;
   p->nslab = c / p->sw;
-  int th = stride == 1 ? 8 : 4, tw = 8;
+  // (tuning aids: the tile the planner starts from on the large maps -- a taller tile halves the halo and the round trips per pixel)
+  static const int th_big = getenv("RN_MB_DWF_TH") ? atoi(getenv("RN_MB_DWF_TH")) : 8;
+  static const int tw_big = getenv("RN_MB_DWF_TW") ? atoi(getenv("RN_MB_DWF_TW")) : 8;
+  const bool big = (long)oh * ow >= 16384;
+  int th = stride == 1 ? (big ? th_big : 8) : (big ? th_big / 2 : 4), tw = big ? tw_big : 8;
   if (th > oh) th = oh;
   if (tw > ow) tw = ow;
   auto blocks = [&]() { return (long)n * rn::ceil_div(oh, th) * rn::ceil_div(ow, tw) * p->nslab; };
@@ -1934,9 +1938,13 @@ bool dw_bwd_plan(int n, int h, int w, int c, int stride, int cpg, DwBwdPlan* p) 
   p->sw = dw_slab(c, cpg);
   if (!p->sw) return false;
   p->nslab = c / p->sw;
-  int th = 8, tw = 8;
+  static const int th_big = getenv("RN_MB_DWB_TH") ? atoi(getenv("RN_MB_DWB_TH")) : 8;
+  static const int tw_big = getenv("RN_MB_DWB_TW") ? atoi(getenv("RN_MB_DWB_TW")) : 8;
+  const bool big = (long)h * w >= 16384;
+  int th = big ? th_big : 8, tw = big ? tw_big : 8;
   auto blocks = [&]() { return (long)n * rn::ceil_div(h, th) * rn::ceil_div(w, tw) * p->nslab; };
-  while (blocks() < 384 && th * tw > 16) {
+  auto too_big = [&]() { return (long)(th + 2) * (tw + 2) * (p->sw / 4) > NP * T || (long)(th / stride + 2) * (tw / stride + 2) * (p->sw / 4) > NP * T; };
+  while ((blocks() < 384 && th * tw > 16) || (too_big() && th * tw > 16)) {
     if (th >= tw) th /= 2; else tw /= 2;
   }
   p->th = th; p->tw = tw;                              // powers of two >= 2: aligned to stride 1 / 2
