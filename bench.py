@@ -706,7 +706,7 @@ def main():
         per_rank = [float(t.item()) for t in per_rank]
         dist_info = {"rccl_ranks": world, "allreduce_exposed_ms_per_rank": [round(x, 4) for x in per_rank],
                      "allreduce_exposed_ms_max": round(max(per_rank), 4), "allreduce_exposed_ms_mean": round(sum(per_rank) / world, 4),
-                     "slices": allreduce_slices(step.trainer) if world > 1 else []}
+                     "slices": allreduce_slices(step.trainer)}
 
     result = None
     if rank == 0:

@@ -52,6 +52,12 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert ar["backend"] == "rccl" and ar["ranks"] == 1 and ar["collectives_issued"]
     assert res["config"]["backward_segments"] == 2 and ar["bytes_overlapped_with_backbone_backward"] > ar["bytes_after_backward"] > 0
     assert res["config"]["gn_barrier_timeouts"] == 0
+    # the multi-GPU evidence fields (every rank takes part in them: exercised here with one rank so that an 8-GPU run cannot
+    # be the first time this code executes)
+    assert ar["rccl_ranks"] == 1 and len(ar["allreduce_exposed_ms_per_rank"]) == 1
+    assert ar["allreduce_exposed_ms_max"] >= ar["allreduce_exposed_ms_mean"] >= 0.0
+    assert len(ar["slices"]) == 2 and all(sl["bytes"] > 0 and sl["ms_alone"] > 0 for sl in ar["slices"])
+    assert sum(sl["bytes"] for sl in ar["slices"]) == ar["bytes_overlapped_with_backbone_backward"] + ar["bytes_after_backward"]
 
 
 def test_two_replicas_equal_one_process_accumulating(tmp_path):
