@@ -1384,7 +1384,10 @@ __device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b :
 
 // S: the stride as a compile-time constant (1 | 2) -- the tap -> output index arithmetic of the data gradient divides by it
 // nine times per pixel and thread; with a runtime divisor that arithmetic, not memory, bounded the 256^2 / 128^2 maps
-template <int ACT, bool MULTI, int S>
+// NPA / NPD: patch loads in flight per thread (input patch / dy patch), sized for the launch's tile and slab by the host (NP is the
+// upper bound any plan may need): the registers they free let PF = the next tile's three raw patches be fetched while this tile's
+// stencils run -- the large maps walk 4 - 8 tiles per block and ran their loop at 2 TB/s with every tile's loads exposed
+template <int ACT, bool MULTI, int S, int NPA = NP, int NPD = NP, bool PF = false>
 __global__ __launch_bounds__(T, 2) void mb_dw_bwd_kernel(const DwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];   // a1 patch [(th+2)(tw+2)][sw] | dy patch [oph*opw][sw]
   __shared__ __attribute__((aligned(16))) float tabA[4 * 128];   // scale | shift | mean | rstd of the slab's channels (GN1)
@@ -1419,22 +1422,24 @@ __global__ __launch_bounds__(T, 2) void mb_dw_bwd_kernel(const DwBwdArgs a) {
   const __amdgpu_buffer_rsrc_t xs = make_rsrc(a.in.y + (size_t)sample * a.h * a.wd * C + c0, (unsigned)(a.h * a.wd * C - c0) * 4u);
   const __amdgpu_buffer_rsrc_t gs = make_rsrc(a.dy.g + (size_t)sample * a.oh * a.ow * C + c0, (unsigned)(a.oh * a.ow * C - c0) * 4u);
   const __amdgpu_buffer_rsrc_t ys = make_rsrc(a.dy.nd.y + (size_t)sample * a.oh * a.ow * C + c0, (unsigned)(a.oh * a.ow * C - c0) * 4u);
-  float4 av[NP], gv[NP], yv2[NP];
-  int pka[NP], pkd[NP];
+  float4 av[NPA], gv[NPD], yv2[NPD];
+  int pka[NPA], pkd[NPD];
 #pragma unroll
-  for (int j = 0; j < NP; ++j) { pka[j] = patch_pack(tid + j * T, atotal, SQ, apw); pkd[j] = patch_pack(tid + j * T, dtotal, SQ, a.opw); }
+  for (int j = 0; j < NPA; ++j) pka[j] = patch_pack(tid + j * T, atotal, SQ, apw);
+#pragma unroll
+  for (int j = 0; j < NPD; ++j) pkd[j] = patch_pack(tid + j * T, dtotal, SQ, a.opw);
   auto load_patches = [&](int tile) {
     const int ih0 = (tile / a.tiles_w) * a.th, iw0 = (tile % a.tiles_w) * a.tw;
     const int ay0 = ih0 - a.pad_t, ax0 = iw0 - a.pad_l;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
+    for (int j = 0; j < NPA; ++j) {
       const PatchElem e = patch_at(pka[j], ay0, ax0, a.h, a.wd);
       av[j] = Vec<4>::load(xs, (e.live && e.inside) ? ((unsigned)e.pix * C + e.q * 4) * 4u : OOB);
     }
     // dy patch: output rows [oy0, +oph), cols [ox0, +opw): every output that touches the tile
     const int oy0 = floor_div(ih0 + a.pad_t - 2 + (s - 1), s), ox0 = floor_div(iw0 + a.pad_l - 2 + (s - 1), s);
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
+    for (int j = 0; j < NPD; ++j) {
       const PatchElem e = patch_at(pkd[j], oy0, ox0, a.oh, a.ow);
       const unsigned off = (e.live && e.inside) ? ((unsigned)e.pix * C + e.q * 4) * 4u : OOB;
       gv[j] = Vec<4>::load(gs, off);
@@ -1476,7 +1481,7 @@ __global__ __launch_bounds__(T, 2) void mb_dw_bwd_kernel(const DwBwdArgs a) {
     const int ay0 = ih0 - a.pad_t, ax0 = iw0 - a.pad_l;
     const int oy0 = floor_div(ih0 + a.pad_t - 2 + (s - 1), s), ox0 = floor_div(iw0 + a.pad_l - 2 + (s - 1), s);
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
+    for (int j = 0; j < NPA; ++j) {
       const PatchElem e = patch_at(pka[j], ay0, ax0, a.h, a.wd);
       if (e.live) {
         float4 o = norm_act_drop<ACT>(av[j], *reinterpret_cast<const float4*>(&tabA[e.q * 4]), *reinterpret_cast<const float4*>(&tabA[128 + e.q * 4]),
@@ -1486,7 +1491,7 @@ __global__ __launch_bounds__(T, 2) void mb_dw_bwd_kernel(const DwBwdArgs a) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
+    for (int j = 0; j < NPD; ++j) {
       const PatchElem e = patch_at(pkd[j], oy0, ox0, a.oh, a.ow);
       if (e.live) {
         float4 o = dy_of(gv[j], yv2[j], tabD, 128, e.q * 4, false, 0.f, 1.f, 0ull, 0ull);
@@ -1495,6 +1500,7 @@ __global__ __launch_bounds__(T, 2) void mb_dw_bwd_kernel(const DwBwdArgs a) {
       }
     }
     __syncthreads();
+    if (PF && tile + 1 < tile_hi) load_patches(tile + 1);     // (the raw patches of the next tile, under this tile's stencils)
     // ---- data gradient of the tile's pixels, then g1 and its sums
     if (active) {
       const float4 sc = *reinterpret_cast<const float4*>(&tabA[q4 * 4]), sh = *reinterpret_cast<const float4*>(&tabA[128 + q4 * 4]);
@@ -1568,7 +1574,7 @@ __global__ __launch_bounds__(T, 2) void mb_dw_bwd_kernel(const DwBwdArgs a) {
   if (MULTI) {
 #pragma nounroll
     for (int tile = tile_lo + 1; tile < tile_hi; ++tile) {
-      load_patches(tile);
+      if (!PF) load_patches(tile);
       process_tile(tile);
     }
   }
@@ -2127,7 +2133,18 @@ extern "C" int rn_mb_depthwise_bwd(const rn_mb_norm* in, const rn_mb_dy* dy, con
     if (stride == 1) hipLaunchKernelGGL((mb_dw_bwd_kernel<ACT_, MULTI_, 1>), grid, dim3(T), lds, st, a);               \
     else hipLaunchKernelGGL((mb_dw_bwd_kernel<ACT_, MULTI_, 2>), grid, dim3(T), lds, st, a);                           \
   } while (0)
-  if (in->act == RN_ACT_ELU && p.tpb == 1) RN_DWB(RN_ACT_ELU, false);
+  // (the large maps' launches: loads sized for the plan, next tile prefetched; RN_MB_DWB_PF=0: the plain variant)
+  static const bool pf_on = !(getenv("RN_MB_DWB_PF") && atoi(getenv("RN_MB_DWB_PF")) == 0);
+  const int npa = rn::ceil_div((p.th + 2) * (p.tw + 2) * (p.sw / 4), T), npd = rn::ceil_div(p.oph * p.opw * (p.sw / 4), T);
+  if (in->act == RN_ACT_ELU && p.tpb > 1 && pf_on && stride == 1 && npa <= 4 && npd <= 4)
+    hipLaunchKernelGGL((mb_dw_bwd_kernel<RN_ACT_ELU, true, 1, 4, 4, true>), grid, dim3(T), lds, st, a);
+  else if (in->act == RN_ACT_ELU && p.tpb > 1 && pf_on && stride == 1 && npa <= 5 && npd <= 5)
+    hipLaunchKernelGGL((mb_dw_bwd_kernel<RN_ACT_ELU, true, 1, 5, 5, true>), grid, dim3(T), lds, st, a);
+  else if (in->act == RN_ACT_ELU && p.tpb > 1 && pf_on && stride == 2 && npa <= 4 && npd <= 2)
+    hipLaunchKernelGGL((mb_dw_bwd_kernel<RN_ACT_ELU, true, 2, 4, 2, true>), grid, dim3(T), lds, st, a);
+  else if (in->act == RN_ACT_ELU && p.tpb > 1 && pf_on && stride == 2 && npa <= 5 && npd <= 2)
+    hipLaunchKernelGGL((mb_dw_bwd_kernel<RN_ACT_ELU, true, 2, 5, 2, true>), grid, dim3(T), lds, st, a);
+  else if (in->act == RN_ACT_ELU && p.tpb == 1) RN_DWB(RN_ACT_ELU, false);
   else if (in->act == RN_ACT_ELU) RN_DWB(RN_ACT_ELU, true);
   else if (in->act == RN_ACT_RELU6) RN_DWB(RN_ACT_RELU6, true);
   else RN_DWB(-1, true);
