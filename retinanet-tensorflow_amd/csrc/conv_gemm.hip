@@ -554,7 +554,11 @@ __global__ __launch_bounds__(256) void conv_bwd_kernel(const ConvArgs4 d, const 
 // reductions, RL = 64 for tall ones (>= REDUCE_TALL rows: the depthwise weight-gradient partials have up to 4096), where
 // the length of a lane's dependent chain matters more than the segment width.
 constexpr int REDUCE_TALL = 512;
-__host__ __device__ inline int64_t reduce_cols_per_block(int nrows) { return nrows >= REDUCE_TALL ? 16 : 64; }
+// ... and RL = 4 for the shortest (< REDUCE_SHORT rows: the 2 - 10 split-K slabs of a weight gradient -- most of a step's ~130
+// reductions): 1 KB row segments, a quarter of the blocks (the batched launch was bound by the block dispatch rate: 28 721
+// blocks of 1 - 4 KB of work each took 45 us)
+constexpr int REDUCE_SHORT = 32;
+__host__ __device__ inline int64_t reduce_cols_per_block(int nrows) { return nrows >= REDUCE_TALL ? 16 : (nrows < REDUCE_SHORT ? 256 : 64); }
 
 template <int RL>
 __device__ __forceinline__ void reduce_rows_lanes(const float* __restrict__ in, float* __restrict__ out, int64_t count, int nrows,
@@ -619,7 +623,7 @@ __device__ __forceinline__ void reduce_rows_lanes(const float* __restrict__ in, 
       if (i + 3 < count) t.w = out[i + 3];
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { const float4 u = sh[r * CL + cl]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    for (int r = 0; r < (RL < 16 ? RL : 16); ++r) { const float4 u = sh[r * CL + cl]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
     out[i] = t.x;
     if (i + 1 < count) out[i + 1] = t.y;
     if (i + 2 < count) out[i + 2] = t.z;
@@ -631,6 +635,7 @@ __device__ __forceinline__ void reduce_rows_block(const float* __restrict__ in, 
                                                   int accumulate, int block) {
   __shared__ float4 sh[256];
   if (nrows >= REDUCE_TALL) reduce_rows_lanes<64>(in, out, count, nrows, accumulate, block, sh);  // block-uniform
+  else if (nrows < REDUCE_SHORT) reduce_rows_lanes<4>(in, out, count, nrows, accumulate, block, sh);
   else reduce_rows_lanes<16>(in, out, count, nrows, accumulate, block, sh);
 }
 
