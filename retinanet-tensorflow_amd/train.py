@@ -359,6 +359,7 @@ class Trainer(object):
         """forward + loss + backward of the heads and the FPN (the whole backward pass when there is no cut)."""
         with self._scoped():
             label_stream = None
+            zeroed = False
             if features is None:
                 # input_fn builds the step's labels on the device (anchor assignment); only the loss reads them: their
                 # kernels run on a side stream underneath the backbone's forward pass (the image itself -- written before
@@ -371,6 +372,10 @@ class Trainer(object):
                     main_stream = torch.cuda.current_stream()
                     with torch.cuda.stream(label_stream):
                         features = self.input_fn()
+                        # (the gradient arena is cleared here too, underneath the backbone's forward pass, instead of between the
+                        # loss and its gradient: nothing reads or writes it before the join in front of the loss)
+                        self.arena.zero_grad()
+                        zeroed = True
                     _for_each_tensor(features, lambda t: t.record_stream(main_stream) if t.is_cuda else None)   # (allocated on the side stream, read on this one)
                 else:
                     features = self.input_fn()
@@ -386,7 +391,8 @@ class Trainer(object):
                                                 mode=self.loss_mode)
             # kernels that write a parameter's gradient directly overwrite it; gradients that reach a parameter
             # through autograd (e.g. the concatenated head kernels) are accumulated -> the arena starts at zero
-            self.arena.zero_grad()
+            if not zeroed:
+                self.arena.zero_grad()
             # d(class_loss + regr_loss): both roots seeded with the same pre-allocated 1 (no add / fill kernels in the step)
             self._backward([class_loss, regr_loss], [self._one, self._one])
             if self._cut_src is not None:
