@@ -51,6 +51,23 @@ def side_stream(device):
     return _rn.side_stream(device, 1)
 
 
+HEADS_OFFSET_US = float(os.environ.get("RN_HEADS_OFFSET_US", "0"))
+# fp16 inference: GroupNorm statistics of the head towers from the conv epilogues on levels with at least this many rows (n h w)
+F16_HEAD_STATS = os.environ.get("RN_F16_HEAD_STATS", "0") == "1"      # measured: 678 vs 680 images/s at cfg 5 -- off (the two subnets' streams already hide the pass)
+F16_HEAD_STATS_MIN_ROWS = int(os.environ.get("RN_F16_HEAD_STATS_MIN_ROWS", "32768"))
+_delay_buf = {}
+
+
+def _delay(device, stream, us):
+    """One workgroup that sleeps ~`us` microseconds on `stream` (rn_debug_collective_standin with a 4 KB copy)."""
+    b = _delay_buf.get(device)
+    if b is None:
+        b = _delay_buf[device] = torch.zeros(2048, dtype=torch.float32, device=device)
+    import ctypes
+    _rn.check(_rn.lib().rn_debug_collective_standin(b[:1024].data_ptr(), b[1024:].data_ptr(), 4096, 1, float(us),
+                                                    ctypes.c_void_p(stream.cuda_stream)), "rn_debug_collective_standin")
+
+
 def build_backbone(backbone, activation, dropout_rate):
     assert backbone in BACKBONES
     if backbone == 'mobilenet_v2':
@@ -115,10 +132,42 @@ class _Subnet(Model):
             return self.out_conv(blocks[-1][1].fused(raw, training, act=act))
         return None
 
+    def _f16_tower(self, maps):
+        """fp16 inference: the four [conv, GroupNorm, act] blocks with the GroupNorm STATISTICS taken from the conv's epilogue
+        (ops_f16.conv2d_norm: no statistics pass over the conv output) on the levels where that pass costs -- the large maps,
+        one launch per level -- while the small levels keep the one-launch-for-all-levels path.  Returns the tower's outputs
+        (normalised, activated) per level, or None when nothing folds."""
+        import ops_f16
+        if not (ops_f16.FOLD and F16_HEAD_STATS):
+            return None
+        blocks = [blk.layers for blk in self.pre_conv.layers]          # [conv, norm, act] each
+        big = [i for i, m in enumerate(maps) if m.dtype == torch.float16 and m.shape[0] * m.shape[1] * m.shape[2] >= F16_HEAD_STATS_MIN_ROWS]
+        if not big:
+            return None
+        small = [i for i in range(len(maps)) if i not in big]
+        cur = list(maps)
+        for conv, norm, act in blocks:
+            nxt = [None] * len(cur)
+            for i in big:
+                p = ops_f16.conv2d_norm(cur[i], conv.weight, norm, L.activation_name(act), 1, 1)
+                if p is None:
+                    return None
+                nxt[i] = p.materialise()
+            if small:
+                ys = norm.fused(conv([cur[i] for i in small]), False, act=L.activation_name(act))
+                for i, y in zip(small, ys):
+                    nxt[i] = y
+            cur = nxt
+        return cur
+
     def call(self, input, training):
         """`input`: one feature map, or a list of maps (all pyramid levels, one launch per layer)."""
         multi = isinstance(input, (list, tuple))
         out = self._folded(list(input) if multi else [input], training)
+        if out is None and L.INFERENCE_F16 and not training and multi and all(torch.is_tensor(m) and m.is_cuda for m in input):
+            tower = self._f16_tower(list(input))
+            if tower is not None:
+                out = list(self.out_conv(tower))
         if out is None:
             out = self.out_conv(self.pre_conv(input, training))
             out = list(out) if multi else [out]
@@ -226,6 +275,8 @@ class RetinaNetBase(Model):
                 side.wait_stream(main)
                 cls_out = self.classification_subnet(maps_c, training)
                 with torch.cuda.stream(side):
+                    if HEADS_OFFSET_US > 0:            # tuning aid: start the box subnet a fraction of a layer later
+                        _delay(maps[0].device, side, HEADS_OFFSET_US)
                     reg_out = self.regression_subnet(maps_r, training)
                 main.wait_stream(side)
             else:
