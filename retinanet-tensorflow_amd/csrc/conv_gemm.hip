@@ -110,7 +110,16 @@ __device__ __forceinline__ void conv_stats_epilogue(const f32x16 (&acc)[BM / WM 
 // block-uniform scalars advanced incrementally -- no per-thread division in the K loop.
 // =============================================================================================
 template <int BM, int BN, int WM, int WN, int VEC, bool TAPU>
-__global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(const ConvArgs args) {
+// waves per SIMD the 64 x 64 batched-product instantiations are compiled for (the register cap that goes with it: 72 / 80): one
+// more resident block per CU than the default allocation gave -- 1 584 forward blocks then fit the chip in one round (1 792
+// slots instead of 1 536).  Stand-alone time unchanged, +0.3 % in the step (interleaved A/B of two builds, RN_LIB_PATH).
+#ifndef RN_OCC_FWD
+#define RN_OCC_FWD 7
+#endif
+#ifndef RN_OCC_BWD
+#define RN_OCC_BWD 6
+#endif
+__global__ __launch_bounds__(WM* WN * 64, (BM == 64 && BN == 64 && VEC == 4 && TAPU) ? RN_OCC_FWD : 1) void conv_fwd_kernel(const ConvArgs args) {
   constexpr int T = WM * WN * 64;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int KQ = BK / VEC, A_RPP = T / KQ, A_PASS = BM / A_RPP;
@@ -539,7 +548,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
 // weight-gradient splits (independent work on the same dy).  The small backbone convs are launch-latency-bound, and two
 // half-empty grids fill the chip better together.  Two compact argument blocks (<= 4 segments each) fit the kernarg.
 template <int DBM, int DBN, int DWM, int DWN, bool DTAPU, int WBM, int WBN, int WWM, int WWN>
-__global__ __launch_bounds__(256) void conv_bwd_kernel(const ConvArgs4 d, const ConvArgs4 w, int dblocks) {
+__global__ __launch_bounds__(256, (DTAPU && WBM == 64 && WBN == 64) ? RN_OCC_BWD : 1) void conv_bwd_kernel(const ConvArgs4 d, const ConvArgs4 w, int dblocks) {
   constexpr int LDSF = dgrad_lds_floats<DBM, DBN>() > wgrad_lds_floats<WBM, WBN>() ? dgrad_lds_floats<DBM, DBN>()
                                                                                    : wgrad_lds_floats<WBM, WBN>();
   static_assert(DWM * DWN == 4 && WWM * WWN == 4, "both halves use 256-thread blocks");
