@@ -466,22 +466,28 @@ __global__ __launch_bounds__(T) void det_emit_kernel(const DetArgs a) {
   // A block's waves are a CONTIGUOUS run (its four waves interleaved inside it): with many candidates the per-segment counts
   // are then formed in LDS and reach seg_count as one atomic per (block, segment it met) -- a run lies in one or two images --
   // instead of one per candidate (3.14 M atomics on n * C counters: 0.47 ms on the all-candidates input).
-  __shared__ int hist[EMIT_MAXSEG];
+  extern __shared__ int hist[];                    // n * C counters in the many-candidates mode, nothing otherwise (the host sizes it)
   const int lane = threadIdx.x & 63;
   const int64_t nw = (int64_t)a.n * a.waves_per_image;
   const int nseg = a.n * a.C;
-  const int64_t total = a.counts[0];               // (consumed at the first count: the load rides along with the mask loads)
-  if (nseg <= EMIT_MAXSEG) {
+  // which of the two: decided from the caller's capacity (a kernel argument: no load in front of the walk) -- a capacity of an
+  // eighth of the rows or more announces the many-candidates case; the ~1 % case keeps the strided walk and one atomic per candidate
+  const bool use_hist = nseg <= EMIT_MAXSEG && a.cap * 8 >= (int64_t)a.n * a.rows_per_image;
+  int64_t w_begin, w_end, stride;
+  if (use_hist) {
     for (int k = threadIdx.x; k < nseg; k += T) hist[k] = 0;
     __syncthreads();
+    const int64_t per_blk = (nw + gridDim.x - 1) / gridDim.x;
+    w_begin = (int64_t)blockIdx.x * per_blk + (threadIdx.x >> 6);
+    w_end = (int64_t)blockIdx.x * per_blk + per_blk < nw ? (int64_t)blockIdx.x * per_blk + per_blk : nw;
+    stride = T >> 6;
+  } else {
+    w_begin = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6; w_end = nw; stride = ((int64_t)gridDim.x * T) >> 6;
   }
-  const int64_t per_blk = (nw + gridDim.x - 1) / gridDim.x;
-  const int64_t w_begin = (int64_t)blockIdx.x * per_blk, w_end = w_begin + per_blk < nw ? w_begin + per_blk : nw;
-  const int64_t stride = T >> 6;
   // the masks and offsets of the next EMIT_AHEAD waves this wave will visit are fetched together (a lane each), so the
   // chain per visited wave is one round trip to memory (score / class / raw box), not two
   constexpr int EMIT_AHEAD = 8;
-  for (int64_t wid0 = w_begin + (threadIdx.x >> 6); wid0 < w_end; wid0 += stride * EMIT_AHEAD) {
+  for (int64_t wid0 = w_begin; wid0 < w_end; wid0 += stride * EMIT_AHEAD) {
     const int64_t wl = wid0 + (int64_t)min(lane, EMIT_AHEAD - 1) * stride;
     const unsigned long long mine = (lane < EMIT_AHEAD && wl < w_end) ? a.wave_mask[wl] : 0ull;
     const int offmine = (lane < EMIT_AHEAD && wl < w_end) ? a.wave_off[wl] : 0;
@@ -520,11 +526,11 @@ __global__ __launch_bounds__(T) void det_emit_kernel(const DetArgs a) {
     }
     *reinterpret_cast<float4*>(a.cand_box + pos * 4) = b;
     a.cand_score[pos] = s; a.cand_class[pos] = c; a.cand_image[pos] = img; a.cand_anchor[pos] = in_img;
-    if (nseg <= EMIT_MAXSEG && total > (int64_t)gridDim.x * 64) atomicAdd(&hist[img * a.C + c], 1);
+    if (use_hist) atomicAdd(&hist[img * a.C + c], 1);
     else atomicAdd(&a.seg_count[img * a.C + c], 1);   // integer count: the same whatever the order of arrival
     }
   }
-  if (nseg <= EMIT_MAXSEG && total > (int64_t)gridDim.x * 64) {
+  if (use_hist) {
     __syncthreads();
     for (int k = threadIdx.x; k < nseg; k += T) {
       const int c = hist[k];
@@ -990,7 +996,11 @@ int run_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, 
     }
   }
   hipLaunchKernelGGL(det_offsets_kernel, dim3((unsigned)((nw + 1023) / 1024)), dim3(1024), 0, st, a);
-  hipLaunchKernelGGL(det_emit_kernel, dim3(wblocks < 2048u ? wblocks : 2048u), dim3(T), 0, st, a);
+  {
+    const int nseg_ = a.n * a.C;
+    const bool hist = nseg_ <= EMIT_MAXSEG && a.cap * 8 >= (int64_t)a.n * a.rows_per_image;     // (the kernel's own rule)
+    hipLaunchKernelGGL(det_emit_kernel, dim3(wblocks < 2048u ? wblocks : 2048u), dim3(T), hist ? (size_t)nseg_ * sizeof(int) : 0, st, a);
+  }
   if (decode_only) {
     hipLaunchKernelGGL(det_copy_candidates_kernel, dim3(256), dim3(256), 0, st, a);
     RN_LAUNCH_CHECK();
