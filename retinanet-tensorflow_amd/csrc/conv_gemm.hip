@@ -544,6 +544,99 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(const ConvArgs 
   conv_wgrad_body<BM, BN, WM, WN, VEC>(args, smem, blockIdx.x, gridDim.x);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The stem: 3 x 3 / stride 2, 3 -> 32 channels, no bias (mobilenet_v2.py:112-114).  27 multiply-adds per output: nothing for
+// the matrix cores (the scalar-gather implicit GEMM spent 24 us on 23 MB) -- a direct kernel.  Block = 256 consecutive output
+// pixels of one sample (8 runs of 32 along a row), thread = (pixel of the run, channel quad): the run's three input rows
+// (65 pixels x 3 channels each) are staged in LDS (coalesced loads, the next run's in flight under this run's arithmetic),
+// weights in LDS, 128-byte rows out.  The GroupNorm statistics of the 256 pixels leave as one row (the conv kernels' layout),
+// so the GroupNorm behind it is one apply kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int STEM_PPB = 256, STEM_RUN = 32, STEM_PATCH = 3 * (2 * STEM_RUN + 1) * 3;   // 585 floats
+struct StemArgs { const float* x; const float* w; float* y; float2* rows; int n, h, wd, oh, ow, pad_t, pad_l; };
+__global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const StemArgs a) {
+  __shared__ float patch[2][STEM_PATCH + 3];
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, q = tid & 7, px = tid >> 3;
+  const int ohw = a.oh * a.ow;
+  const int blocks_per_sample = ohw / STEM_PPB;
+  const int sample = blockIdx.x / blocks_per_sample, p_base = (blockIdx.x - sample * blocks_per_sample) * STEM_PPB;
+  const float* __restrict__ xs = a.x + (size_t)sample * a.h * a.wd * 3;
+  float4 wq[27];                                     // this thread's quad of every tap's weights (registers: LDS reads would bound the kernel)
+#pragma unroll
+  for (int t = 0; t < 27; ++t) wq[t] = *reinterpret_cast<const float4*>(a.w + t * 32 + q * 4);
+  constexpr int NL = (STEM_PATCH + 255) / 256;       // 3 loads per thread and run
+  float pre[NL];
+  auto load_run = [&](int run) {
+    const int p0 = p_base + run * STEM_RUN;
+    const int oy = p0 / a.ow, ox0 = p0 - oy * a.ow;
+    const int iy0 = oy * 2 - a.pad_t, ix0 = ox0 * 2 - a.pad_l;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int idx = tid + k * 256;
+      const int r = idx / 195, off = idx - r * 195;            // row of the patch, float inside it (65 pixels x 3)
+      const int iy = iy0 + r, ix = ix0 + off / 3;
+      const bool ok = idx < STEM_PATCH && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.wd;
+      // (clamped address x 0/1 mask: a load under a condition is compiled to branch + load + wait, one round trip per element)
+      const int iyc = min(max(iy, 0), a.h - 1), ixc = min(max(ix, 0), a.wd - 1);
+      pre[k] = xs[((size_t)iyc * a.wd + ixc) * 3 + (off - (off / 3) * 3)] * (ok ? 1.f : 0.f);
+    }
+  };
+  auto store_run = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int idx = tid + k * 256;
+      if (idx < STEM_PATCH) patch[buf][idx] = pre[k];
+    }
+  };
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  load_run(0);
+  store_run(0);
+  __syncthreads();
+  constexpr int NRUN = STEM_PPB / STEM_RUN;
+  for (int run = 0; run < NRUN; ++run) {
+    if (run + 1 < NRUN) load_run(run + 1);
+    const float* __restrict__ pt = patch[run & 1];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+          const float xv = pt[kh * 195 + (2 * px + kw) * 3 + ci];
+          const float4 w4 = wq[(kh * 3 + kw) * 3 + ci];
+          acc[0] = fmaf(xv, w4.x, acc[0]); acc[1] = fmaf(xv, w4.y, acc[1]);
+          acc[2] = fmaf(xv, w4.z, acc[2]); acc[3] = fmaf(xv, w4.w, acc[3]);
+        }
+    const size_t o = ((size_t)sample * ohw + p_base + run * STEM_RUN + px) * 32 + q * 4;
+    *reinterpret_cast<float4*>(a.y + o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[j] += acc[j]; s2[j] = fmaf(acc[j], acc[j], s2[j]); }
+    if (run + 1 < NRUN) store_run((run + 1) & 1);
+    __syncthreads();
+  }
+  if (!a.rows) return;
+  // per-channel sums over the block's pixels: the 8 pixel lanes of a wave by shuffles (lane = q + 8 px), the 4 waves through LDS
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < 8) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[wave][(lane * 4 + j) * 2] = s1[j]; red[wave][(lane * 4 + j) * 2 + 1] = s2[j]; }
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { t1 += red[w][tid * 2]; t2 += red[w][tid * 2 + 1]; }
+    a.rows[(size_t)blockIdx.x * 32 + tid] = make_float2(t1, t2);
+  }
+}
+
 // Both gradients of one convolution in ONE launch: blocks [0, dblocks) run the data-gradient tiles, the rest the
 // weight-gradient splits (independent work on the same dy).  The small backbone convs are launch-latency-bound, and two
 // half-empty grids fill the chip better together.  Two compact argument blocks (<= 4 segments each) fit the kernarg.
@@ -922,6 +1015,34 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
     d.m = d.n * d.oh * d.ow;
     set_x_view(d, segs[s], g->cin);
     vec = vec && ((d.cout / G) % 4 == 0);
+  }
+  {
+    // the stem (see stem_conv_fwd_kernel): its own direct kernel, rows of 256 pixels
+    static const bool stem_on = !(getenv("RN_STEM_DIRECT") && atoi(getenv("RN_STEM_DIRECT")) == 0);
+    const SegDev& d = a.seg[0];
+    if (stem_on && nseg == 1 && bt.n == 1 && G == 1 && g->kh == 3 && g->kw == 3 && g->cin == 3 && g->stride == 2 && d.cout == 32 &&
+        !d.bias && d.x_ld == 3 && d.x_coff == 0 && d.ow % STEM_RUN == 0 && (d.oh * d.ow) % STEM_PPB == 0 && (long)d.m * 32 < (1l << 31)) {
+      const int ohw = d.oh * d.ow;
+      if (sc.need_out) { *sc.need_out = 0; return RN_OK; }
+      float2* rows = nullptr;
+      if (sr.rows || sr.bytes_out) {
+        const int groups = sr.rows ? sr.rows->groups : sr.groups;
+        const bool ok = groups >= 1 && 32 % groups == 0 && rn_group_norm_rows_ok(32, groups, ohw / STEM_PPB, 0);
+        if (sr.bytes_out) {
+          *sr.bytes_out = ok ? (size_t)(d.m / STEM_PPB) * 32 * 8 : 0;
+          if (ok && sr.layout_out) { sr.layout_out->rows_per_sample = ohw / STEM_PPB; sr.layout_out->per_group = 0; sr.layout_out->groups = groups; }
+          return RN_OK;
+        }
+        RN_UNSUPPORTED(!ok || sr.rows->rows_per_sample != ohw / STEM_PPB || sr.rows->per_group != 0,
+                       "conv fwd stats: this shape / layout cannot produce GroupNorm rows (rn_conv2d_stats_rows)");
+        RN_CHECK_ARG(sr.rows->rows, "conv fwd stats: null rows");
+        rows = (float2*)sr.rows->rows;
+      }
+      StemArgs st_a = {d.a, d.b, d.out, rows, d.n, d.h, d.w, d.oh, d.ow, d.pad_t, d.pad_l};
+      hipLaunchKernelGGL(stem_conv_fwd_kernel, dim3((unsigned)(d.m / STEM_PPB)), dim3(256), 0, (hipStream_t)stream, st_a);
+      RN_LAUNCH_CHECK();
+      return RN_OK;
+    }
   }
   const int c = (G > 1 && a.seg[0].cout / G <= 64)
                     ? cfg_for_group_width(a.seg[0].cout / G)
