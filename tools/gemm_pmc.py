@@ -1,7 +1,7 @@
 """rocprofv3 --pmc target: the roofline kernels of bench.py in isolation (GPU box only), 30 launches each:
   fwd  batched forward products of the Winograd F(4x4,3x3) head-tower layer: 36 x [682 x 256] x [256 x 256]
   bwd  the merged backward products of the same layer (the largest in-step kernel)
-  gn   the largest stand-alone GroupNorm (+ELU+dropout) forward: 2 x 256 x 256 x 32 (the stem's)
+  gn   the stem: direct conv 3 -> 32 (statistics in the epilogue) + its GroupNorm (+ELU+dropout) apply pass
 usage (separate passes: FETCH_SIZE and WRITE_SIZE do not fit one):
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python tools/gemm_pmc.py
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python tools/gemm_pmc.py
@@ -28,13 +28,15 @@ L = _rn.lib()
 need = L.rn_winograd_bwd_products_workspace(tiles, 256, 256, 36)
 ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=dev)
 nsplit = C.c_int(0)
-x = torch.randn(2, 256, 256, 32, device=dev)
+img = torch.randn(2, 512, 512, 3, device=dev)
+w_stem = torch.randn(3, 3, 3, 32, device=dev) * 0.1
 gamma, beta = torch.ones(32, device=dev), torch.zeros(32, device=dev)
 for _ in range(30):
     _rn.check(L.rn_gemm_batched(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, 36, 0, _rn.stream()), "rn_gemm_batched")
     _rn.check(L.rn_winograd_bwd_products(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, _rn.f32(A), _rn.f32(dM), 256, 256, 36,
                                          ws.data_ptr(), ws.numel(), C.byref(nsplit), _rn.stream()), "rn_winograd_bwd_products")
     with torch.no_grad():
-        ops.group_norm_act(x, gamma, beta, groups=32, act="elu", drop_rate=0.2, seed=1)
+        y = ops.conv2d(img, w_stem, None, 2, gn=(32, 1e-5))
+        ops.group_norm_act(y, gamma, beta, groups=32, act="elu", drop_rate=0.2, seed=1)
 torch.cuda.synchronize()
 print("tiles", tiles, "nsplit", nsplit.value)

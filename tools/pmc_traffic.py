@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 KERNELS = {"fwd_products": ("conv_fwd_kernel",), "bwd_products": ("conv_bwd_kernel",),
-           "group_norm": ("gn_rows_partial_kernel", "gn_apply_rows_kernel")}
+           "group_norm": ("stem_conv_fwd_kernel", "gn_apply_rows_kernel")}
 
 
 def per_kernel(directory, counter):
