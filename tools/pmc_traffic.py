@@ -5,6 +5,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -27,8 +28,10 @@ def main(fetch_dir, write_dir):
     for key, names in KERNELS.items():
         total = 0.0
         for n in names:
-            f = [v for k, vals in fetch.items() if n in k for v in vals]
-            w = [v for k, vals in write.items() if n in k for v in vals]
+            # the demangled name STARTS with the kernel's name ("conv_fwd_kernel" is also a substring of "stem_conv_fwd_kernel")
+            mine = lambda k: re.match(r"(void\s+)?%s\b" % re.escape(n), k) is not None
+            f = [v for k, vals in fetch.items() if mine(k) for v in vals]
+            w = [v for k, vals in write.items() if mine(k) for v in vals]
             if not f or not w:
                 continue
             fk, wk = sum(f) / len(f), sum(w) / len(w)
