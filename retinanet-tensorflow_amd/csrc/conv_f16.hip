@@ -75,7 +75,11 @@ __device__ __forceinline__ int find_seg(const ArgsH& a, int id) {
 
 // FOLD bit 0: GroupNorm + activation of the input applied on load; bit 1: statistics of the output from the epilogue.
 // Both need a tile's rows inside one sample (oh * ow a multiple of BM: host-checked) and a single segment.
-template <int BM, int BN, int WM, int WN, int VEC, bool TAPU, int FOLD>
+// PIPE (the 256 x 256 tile: ONE block of 8 waves per CU, so nothing else covers a block's own stalls): the operand tiles are
+// double-buffered in (dynamic) LDS -- tile t+1 goes from the staging registers into the other buffer between the MFMAs of tile
+// t and the loads of tile t+2 are issued behind it: one barrier per K-tile instead of two, and no wave waits on LDS stores or
+// on the first fragment reads with the matrix pipe idle.
+template <int BM, int BN, int WM, int WN, int VEC, bool TAPU, int FOLD, bool PIPE = false, int DBG = 0>
 __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args) {
   constexpr int T = WM * WN * 64;
   constexpr bool FIN = (FOLD & 1) != 0, FOUT = (FOLD & 2) != 0;
@@ -85,9 +89,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
   constexpr int KQ = BK / VEC, RPP = T / KQ, A_PASS = BM / RPP, B_PASS = BN / RPP;
   static_assert(A_PASS >= 1 && B_PASS >= 1 && BM % RPP == 0 && BN % RPP == 0, "tile/threads mismatch");
   typedef typename VecH<VEC>::type vec_t;
-  __shared__ __attribute__((aligned(16))) _Float16 smem[(BM + BN) * LDH];
-  _Float16* As = smem;
-  _Float16* Bs = smem + BM * LDH;
+  constexpr int BUF = (BM + BN) * LDH;
+  extern __shared__ __attribute__((aligned(16))) _Float16 dyn_smem[];
+  __shared__ __attribute__((aligned(16))) _Float16 st_smem[PIPE ? 8 : BUF];
+  _Float16* smem = PIPE ? dyn_smem : st_smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -172,7 +177,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
     for (int j = 0; j < B_PASS; ++j)
       rb[j] = VecH<VEC>::load(wb, (kok && browoff[j] != OOB) ? browoff[j] + (unsigned)k * 2u : OOB);
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int buf) {
+    _Float16* As = smem + buf * BUF;
+    _Float16* Bs = As + BM * LDH;
     if (FIN) {            // act(GN(x)) of the vectors in flight; zero where the tap lies in the padding (SAME pads the ACTIVATED tensor)
       float2 t[VEC];
 #pragma unroll
@@ -207,27 +214,134 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
 
   const int l31 = lane & 31, half = lane >> 5;
   const int nk = (ktotal + BK - 1) / BK;
-  load_tiles(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    store_tiles();
-    __syncthreads();
-    if (kt + 1 < nk) load_tiles(kt + 1);
+  auto mma_step = [&](const _Float16* As, const _Float16* Bs, int ks) {
+    half8 a[TM], b[TN];
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      half8 a[TM], b[TN];
+    for (int tm = 0; tm < TM; ++tm)
+      a[tm] = *reinterpret_cast<const half8*>(&As[(wm * (BM / WM) + tm * 32 + l31) * LDH + ks * 16 + half * 8]);
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-        a[tm] = *reinterpret_cast<const half8*>(&As[(wm * (BM / WM) + tm * 32 + l31) * LDH + ks * 16 + half * 8]);
+    for (int tn = 0; tn < TN; ++tn)
+      b[tn] = *reinterpret_cast<const half8*>(&Bs[(wn * (BN / WN) + tn * 32 + l31) * LDH + ks * 16 + half * 8]);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
-        b[tn] = *reinterpret_cast<const half8*>(&Bs[(wn * (BN / WN) + tn * 32 + l31) * LDH + ks * 16 + half * 8]);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+  };
+  if constexpr (PIPE) {
+    // ONE block of 8 waves per CU: nothing but the block's own instruction order hides its memory operations.  A wave issues in
+    // order, so a burst of LDS stores / global loads / fragment reads keeps it away from the matrix pipe until the queues have
+    // taken the whole burst (measured on the cfg-5 head conv: the 8 stores of a K-tile cost 18 % of the kernel's time, its 8
+    // loads 19 %, the fragment reads 12 %).  Here every K-step issues ONE memory operation behind each MFMA: the fragment reads
+    // of the next K-step (two register slots), the LDS stores of tile t+1 (other buffer) and, right behind each store, the
+    // global load of the same vector for tile t+2 (a full tile ahead of its store).  One barrier per K-tile; the first
+    // fragments of the next tile are read behind it, under the last MFMAs of this one.  The order is pinned with scheduling
+    // barriers (the compiler sinks reads to their uses and hoists stores otherwise); the loop body is branch-free: loads past
+    // the last tile go out of range (zeros, no traffic), their stores land in the buffer nobody reads any more.
+    static_assert(!FIN && TAPU && VEC == 8 && TM == 4 && TN == 2 && A_PASS == 4 && B_PASS == 4 && BK == 64, "PIPE: the 256 x 256 / 8-wave shape");
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    half8 fa[2][TM], fb[2][TN];
+    const int arow = (wm * (BM / WM) + l31) * LDH + half * 8, brow = BM * LDH + (wn * (BN / WN) + l31) * LDH + half * 8;
+    auto rdA = [&](const _Float16* buf, int ks, int slot, int tm) {
+      fa[slot][tm] = *reinterpret_cast<const half8*>(&buf[arow + tm * 32 * LDH + ks * 16]);
+    };
+    auto rdB = [&](const _Float16* buf, int ks, int slot, int tn) {
+      fb[slot][tn] = *reinterpret_cast<const half8*>(&buf[brow + tn * 32 * LDH + ks * 16]);
+    };
+    auto mf = [&](int slot, int tm, int tn) {
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[slot][tm], fb[slot][tn], acc[tm][tn], 0, 0, 0);
+    };
+    // tile being loaded: block-uniform tap state -> (khh, kww, element offset of the tap, byte offset into a weight row)
+    int l_kh = 0, l_kw = 0, l_tap = 0;
+    unsigned l_kb = 0;
+    bool l_in = true;
+    auto prep = [&](int kt) {
+      l_kh = t_kh; l_kw = t_kw;
+      l_tap = (t_kh * W + t_kw) * ldx + t_ci + kq * VEC;
+      l_kb = (unsigned)(kt * BK + kq * VEC) * 2u;
+      l_in = kt < nk;
+      t_ci += BK;
+      if (t_ci == cin) { t_ci = 0; if (++t_kw == kw) { t_kw = 0; ++t_kh; } }
+    };
+    auto ldA = [&](int i) {
+      const int ok = (int)((unsigned)(ih0[i] + l_kh) < (unsigned)H) & (int)((unsigned)(iw0[i] + l_kw) < (unsigned)W) & (int)l_in;
+      ra[i] = VecH<VEC>::load(xa, ok ? (unsigned)(rowoff[i] + l_tap) * 2u : OOB);
+    };
+    auto ldB = [&](int j) {
+      const int ok = (int)(browoff[j] != OOB) & (int)l_in;
+      rb[j] = VecH<VEC>::load(wb, ok ? browoff[j] + l_kb : OOB);
+    };
+    const int st_off = r0 * LDH + kq * VEC;
+    auto stA = [&](_Float16* buf, int i) { *reinterpret_cast<vec_t*>(&buf[st_off + i * RPP * LDH]) = ra[i]; };
+    auto stB = [&](_Float16* buf, int j) { *reinterpret_cast<vec_t*>(&buf[BM * LDH + st_off + j * RPP * LDH]) = rb[j]; };
+
+    prep(0);
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+    for (int i = 0; i < 4; ++i) { ldA(i); ldB(i); }
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i) { stA(smem, i); stB(smem, i); }
+    prep(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ldA(i); ldB(i); }
     __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) rdA(smem, 0, 0, t);
+    rdB(smem, 0, 0, 0); rdB(smem, 0, 0, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+      const _Float16* Ac = smem + (kt & 1) * BUF;
+      _Float16* An = smem + ((kt + 1) & 1) * BUF;
+      prep(kt + 2);
+      SB();
+      // K-step 0 (slot 0) | fragments of K-step 1 -> slot 1 | vectors A0 A1 A2: tile t+1 -> LDS, tile t+2 <- memory
+      mf(0, 0, 0); SB(); if constexpr (!(DBG & 4)) rdA(Ac, 1, 1, 0); if constexpr (!(DBG & 2)) stA(An, 0); SB();
+      mf(0, 0, 1); SB(); if constexpr (!(DBG & 4)) rdB(Ac, 1, 1, 0); if constexpr (!(DBG & 1)) ldA(0); SB();
+      mf(0, 1, 0); SB(); if constexpr (!(DBG & 4)) rdB(Ac, 1, 1, 1); if constexpr (!(DBG & 2)) stA(An, 1); SB();
+      mf(0, 1, 1); SB(); if constexpr (!(DBG & 4)) rdA(Ac, 1, 1, 1); if constexpr (!(DBG & 1)) ldA(1); SB();
+      mf(0, 2, 0); SB(); if constexpr (!(DBG & 4)) rdA(Ac, 1, 1, 2); if constexpr (!(DBG & 2)) stA(An, 2); SB();
+      mf(0, 2, 1); SB(); if constexpr (!(DBG & 4)) rdA(Ac, 1, 1, 3); if constexpr (!(DBG & 1)) ldA(2); SB();
+      mf(0, 3, 0); SB();
+      mf(0, 3, 1); SB();
+      // K-step 1 (slot 1) | K-step 2 -> slot 0 | A3 B0 B1
+      mf(1, 0, 0); SB(); if constexpr (!(DBG & 4)) rdA(Ac, 2, 0, 0); if constexpr (!(DBG & 2)) stA(An, 3); SB();
+      mf(1, 0, 1); SB(); if constexpr (!(DBG & 4)) rdB(Ac, 2, 0, 0); if constexpr (!(DBG & 1)) ldA(3); SB();
+      mf(1, 1, 0); SB(); if constexpr (!(DBG & 4)) rdB(Ac, 2, 0, 1); if constexpr (!(DBG & 2)) stB(An, 0); SB();
+      mf(1, 1, 1); SB(); if constexpr (!(DBG & 4)) rdA(Ac, 2, 0, 1); if constexpr (!(DBG & 1)) ldB(0); SB();
+      mf(1, 2, 0); SB(); if constexpr (!(DBG & 4)) rdA(Ac, 2, 0, 2); if constexpr (!(DBG & 2)) stB(An, 1); SB();
+      mf(1, 2, 1); SB(); if constexpr (!(DBG & 4)) rdA(Ac, 2, 0, 3); if constexpr (!(DBG & 1)) ldB(1); SB();
+      mf(1, 3, 0); SB();
+      mf(1, 3, 1); SB();
+      // K-step 2 (slot 0) | K-step 3 -> slot 1 | B2 B3
+      mf(0, 0, 0); SB(); if constexpr (!(DBG & 4)) rdA(Ac, 3, 1, 0); if constexpr (!(DBG & 2)) stB(An, 2); SB();
+      mf(0, 0, 1); SB(); if constexpr (!(DBG & 4)) rdB(Ac, 3, 1, 0); if constexpr (!(DBG & 1)) ldB(2); SB();
+      mf(0, 1, 0); SB(); if constexpr (!(DBG & 4)) rdB(Ac, 3, 1, 1); if constexpr (!(DBG & 2)) stB(An, 3); SB();
+      mf(0, 1, 1); SB(); if constexpr (!(DBG & 4)) rdA(Ac, 3, 1, 1); if constexpr (!(DBG & 1)) ldB(3); SB();
+      mf(0, 2, 0); SB(); if constexpr (!(DBG & 4)) rdA(Ac, 3, 1, 2); SB();
+      mf(0, 2, 1); SB(); if constexpr (!(DBG & 4)) rdA(Ac, 3, 1, 3); SB();
+      mf(0, 3, 0); SB();
+      mf(0, 3, 1); SB();
+      // K-step 3 (slot 1) | barrier: this buffer's fragments are all in registers, the other buffer is complete | K-step 0 of
+      // the next tile -> slot 0
+      mf(1, 0, 0); SB();
+      mf(1, 0, 1); SB();
+      if constexpr (!(DBG & 8)) __syncthreads(); SB();
+      mf(1, 1, 0); SB(); if constexpr (!(DBG & 4)) rdA(An, 0, 0, 0); SB();
+      mf(1, 1, 1); SB(); if constexpr (!(DBG & 4)) rdB(An, 0, 0, 0); SB();
+      mf(1, 2, 0); SB(); if constexpr (!(DBG & 4)) rdB(An, 0, 0, 1); SB();
+      mf(1, 2, 1); SB(); if constexpr (!(DBG & 4)) rdA(An, 0, 0, 1); SB();
+      mf(1, 3, 0); SB(); if constexpr (!(DBG & 4)) rdA(An, 0, 0, 2); SB();
+      mf(1, 3, 1); SB(); if constexpr (!(DBG & 4)) rdA(An, 0, 0, 3); SB();
+    }
+#undef SB
+  } else {
+    load_tiles(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      store_tiles(0);
+      __syncthreads();
+      if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) mma_step(smem, smem + BM * LDH, ks);
+      __syncthreads();
+    }
   }
 
   // epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -236,9 +350,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
     // 8 global stores per thread instead of 64 two-byte ones, every row of the tile a contiguous 2*BN-byte run.
     constexpr int LDS_ROW = BN + 8;  // halfs; +8 keeps the two half-waves (rows r, r+4) on different banks
     // tiles taller than the operand LDS can stage go in WM passes of BM / WM rows (the rows of one wave row)
-    constexpr int PASSES = (BM * LDS_ROW <= (BM + BN) * LDH) ? 1 : WM;
+    constexpr int CAP = (PIPE ? 2 : 1) * BUF;   // halfs of LDS the staged tile may use
+    constexpr int PASSES = (BM * LDS_ROW <= CAP) ? 1 : WM;
     constexpr int ROWS = BM / PASSES;
-    static_assert(ROWS * LDS_ROW <= (BM + BN) * LDH, "staging tile must fit the operand tiles' LDS");
+    static_assert(ROWS * LDS_ROW <= CAP, "staging tile must fit the operand tiles' LDS");
     _Float16* Cs = smem;
     constexpr int VPR = BN / 8;  // 16-byte vectors per tile row
     const __amdgpu_buffer_rsrc_t ys = make_rsrc(sg.y, (unsigned)M * (unsigned)cout * 2u);
@@ -482,6 +597,24 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
     else if (vec8) RN_F16K(BM_, BN_, WM_, WN_, 0);                                                                  \
     else hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 4, false, 0>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
   } while (0)
+  // the 256 x 256 tile, dense taps, no input-side fold: the double-buffered variant (147 KB of dynamic LDS)
+  static const bool pipe_on = !(getenv("RN_F16_PIPE") && atoi(getenv("RN_F16_PIPE")) == 0);
+  if (c == 5 && tapu && pipe_on && (fbits == 0 || fbits == 2)) {
+    constexpr size_t lds = 2 * (256 + 256) * LDH * sizeof(_Float16);
+    static const bool attr_ = (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
+                              (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
+    RN_UNSUPPORTED(!attr_, "conv f16: %zu bytes of LDS per block refused", lds);
+    if (const char* d = getenv("RN_F16_DBG")) {
+      const int v = atoi(d);
+#define RN_DBGK(V_) if (v == V_) { (void)hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 0, true, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, true, V_>), dim3(tiles), dim3(512), lds, st, a); return RN_OK; }
+      RN_DBGK(1) RN_DBGK(2) RN_DBGK(3) RN_DBGK(4) RN_DBGK(7) RN_DBGK(8) RN_DBGK(15)
+#undef RN_DBGK
+    }
+    if (fbits == 2) hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 2, true>), dim3(tiles), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, true>), dim3(tiles), dim3(512), lds, st, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+  }
   switch (c) {
     case 0: RN_F16(128, 128, 2, 2); break;
     case 1: RN_F16(128, 64, 2, 2); break;

@@ -53,10 +53,13 @@ def test_conv_f16(dev, case):
 
 @pytest.mark.parametrize("cfg", ["4", "5"])
 @pytest.mark.parametrize("case", [(2, 40, 38, 256, 384, 3, 1, 1, True, False), (1, 67, 33, 128, 264, 1, 1, 1, False, False),
-                                  (2, 30, 30, 64, 256, 3, 2, 1, False, True)], ids=lambda c: "x".join(map(str, c)))
+                                  (2, 30, 30, 64, 256, 3, 2, 1, False, True),
+                                  (1, 20, 20, 64, 256, 1, 1, 1, False, False)],       # ONE K-tile: the pipelined loop's prologue only
+                         ids=lambda c: "x".join(map(str, c)))
 def test_conv_f16_large_tiles(dev, monkeypatch, case, cfg):
     """The 256x128 / 256x256 tile shapes (chosen automatically only for the 3x3 head convs of large batches): forced
-    here on moderate shapes with ragged M / N edges; same checks as test_conv_f16."""
+    here on moderate shapes with ragged M / N edges; same checks as test_conv_f16.  cfg 5 with dense taps is the
+    software-pipelined kernel (double-buffered LDS, one memory operation behind each MFMA): 1, 2, 9 and 36 K-tiles."""
     monkeypatch.setenv("RN_CONV_CFG", cfg)
     test_conv_f16(dev, case)
 

@@ -34,3 +34,20 @@ t = timeit(lambda: ops_f16.conv2d(xs[0], w))
 print("P3 alone: %.1f us  %.0f TFLOP/s" % (t, 2 * 16 * 128 * 128 * 2304 * 256 / t / 1e6))
 t = timeit(lambda: ops_f16.conv2d(xs, w), iters=200)
 print("multi-level launch, 200 back to back: %.1f us  %.0f TFLOP/s" % (t, flops / t / 1e6))
+if len(sys.argv) > 1 and sys.argv[1] == "power":
+    # is the rate set by the power / clock management rather than by the kernel?  Same launch on all-zero operands (no toggling in
+    # the multipliers) and on tiny values, and the tile shapes on P3 alone
+    z = [torch.zeros_like(x) for x in xs]
+    t = timeit(lambda: ops_f16.conv2d(z, w), iters=200)
+    print("zero activations, 200 back to back: %.1f us  %.0f TFLOP/s" % (t, flops / t / 1e6))
+    wz = torch.zeros_like(w)
+    t = timeit(lambda: ops_f16.conv2d(z, wz), iters=200)
+    print("zero activations and weights, 200 back to back: %.1f us  %.0f TFLOP/s" % (t, flops / t / 1e6))
+    t = timeit(lambda: ops_f16.conv2d(xs, w), iters=200)
+    print("random again, 200 back to back: %.1f us  %.0f TFLOP/s" % (t, flops / t / 1e6))
+    for cfg in ("0", "4", "5"):
+        os.environ["RN_CONV_CFG"] = cfg
+        t = timeit(lambda: ops_f16.conv2d(xs[0], w), iters=100)
+        print("P3 alone, cfg %s: %.1f us  %.0f TFLOP/s" % (cfg, t, 2 * 16 * 128 * 128 * 2304 * 256 / t / 1e6))
+        t = timeit(lambda: ops_f16.conv2d(z[0], wz), iters=100)
+        print("P3 alone, cfg %s, zeros: %.1f us  %.0f TFLOP/s" % (cfg, t, 2 * 16 * 128 * 128 * 2304 * 256 / t / 1e6))
