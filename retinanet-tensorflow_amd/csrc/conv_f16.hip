@@ -229,15 +229,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
   };
   if constexpr (PIPE) {
-    // ONE block of 8 waves per CU: nothing but the block's own instruction order hides its memory operations.  A wave issues in
-    // order, so a burst of LDS stores / global loads / fragment reads keeps it away from the matrix pipe until the queues have
-    // taken the whole burst (measured on the cfg-5 head conv: the 8 stores of a K-tile cost 18 % of the kernel's time, its 8
-    // loads 19 %, the fragment reads 12 %).  Here every K-step issues ONE memory operation behind each MFMA: the fragment reads
-    // of the next K-step (two register slots), the LDS stores of tile t+1 (other buffer) and, right behind each store, the
-    // global load of the same vector for tile t+2 (a full tile ahead of its store).  One barrier per K-tile; the first
-    // fragments of the next tile are read behind it, under the last MFMAs of this one.  The order is pinned with scheduling
-    // barriers (the compiler sinks reads to their uses and hoists stores otherwise); the loop body is branch-free: loads past
-    // the last tile go out of range (zeros, no traffic), their stores land in the buffer nobody reads any more.
+    // ONE block of 8 waves per CU (128 accumulator registers per lane): nothing but the block's own instruction order hides its
+    // memory operations, and a wave issues in order.  Here every K-step issues ONE memory operation behind each MFMA: the
+    // fragment reads of the next K-step (two register slots), the LDS stores of tile t+1 (other buffer) and, right behind each
+    // store, the global load of the same vector for tile t+2 (a full tile ahead of its store).  One barrier per K-tile; the
+    // first fragments of the next tile are read behind it, under the last MFMAs of this one.  The order is pinned with
+    // scheduling barriers (the compiler sinks reads to their uses and hoists stores otherwise); the loop body is branch-free:
+    // loads past the last tile go out of range (zeros, no traffic), their stores land in the buffer nobody reads any more.
+    // Measured on the cfg-5 head conv by leaving one kind of operation out (RN_F16_DBG_BUILD): no operand traffic at all
+    // 1.6 - 1.7 PFLOP/s (the clock the chip holds under this load; bare 32x32x16 loops on random data: 1.66), no fragment reads
+    // 1.33, no global loads 1.17, no LDS stores 1.56 -- the eight `ds_write_b128` of a K-tile are what is left to remove
+    // (13 cycles of VGPR -> LDS transfer each, MI355X_MICROARCH.md LDS table; they cost the same 25 - 35 % in every order
+    // tried).  Also built and measured, not kept: LDS-DMA (`buffer_load_dwordx4 ... lds` into XOR-swizzled unpadded rows, no
+    // staging registers, no store instructions; correct, lanes out of range deposit zeros) -- the same time as this kernel,
+    // the DMAs' issue cost replaces the stores'; and the two waves of a SIMD in opposite phases (memory phase / 16 MFMAs back
+    // to back, four barriers per K-tile, wave row 1 one barrier behind): 10 % slower.
     static_assert(!FIN && TAPU && VEC == 8 && TM == 4 && TN == 2 && A_PASS == 4 && B_PASS == 4 && BK == 64, "PIPE: the 256 x 256 / 8-wave shape");
 #define SB() __builtin_amdgcn_sched_barrier(0)
     half8 fa[2][TM], fb[2][TN];
@@ -604,12 +610,14 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
     static const bool attr_ = (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
                               (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
     RN_UNSUPPORTED(!attr_, "conv f16: %zu bytes of LDS per block refused", lds);
+#ifdef RN_F16_DBG_BUILD   // tuning aid (make CXXFLAGS+=-DRN_F16_DBG_BUILD): the loop with one kind of operation left out (bit 0 loads, 1 LDS stores, 2 fragment reads, 3 barrier)
     if (const char* d = getenv("RN_F16_DBG")) {
       const int v = atoi(d);
 #define RN_DBGK(V_) if (v == V_) { (void)hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 0, true, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, true, V_>), dim3(tiles), dim3(512), lds, st, a); return RN_OK; }
       RN_DBGK(1) RN_DBGK(2) RN_DBGK(3) RN_DBGK(4) RN_DBGK(7) RN_DBGK(8) RN_DBGK(15)
 #undef RN_DBGK
     }
+#endif
     if (fbits == 2) hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 2, true>), dim3(tiles), dim3(512), lds, st, a);
     else hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, true>), dim3(tiles), dim3(512), lds, st, a);
     RN_LAUNCH_CHECK();
