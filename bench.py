@@ -198,10 +198,27 @@ def roofline_kernels(device):
     if os.path.exists(PMC_TRAFFIC_FILE):
         traffic = json.load(open(PMC_TRAFFIC_FILE))
 
-    def entry(name, kernel, bound, work, ms, peak, unit, bytes_, tkey):
+    def rocprof_avg_us(kernel_prefix, blocks):
+        """Average duration of (kernel, grid) in the newest committed kernel trace (profiles/r*_bench_kernel_trace_by_grid.txt): the
+        dispatch's own begin -> end.  `kernel_ms` below is what HIP events see around a replayed one-kernel graph: the same
+        launch PLUS the ~3 - 4 us between two dependent dispatches; the two are printed side by side."""
+        files = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_trace_by_grid.txt")))
+        if not files:
+            return None, None
+        for line in open(files[-1]):
+            name = line[:65].strip()
+            cols = line[65:].split()
+            if name.replace("void ", "").startswith(kernel_prefix) and len(cols) >= 3 and cols[0] == str(blocks):
+                return float(cols[2]) / 1e3, os.path.basename(files[-1])
+        return None, None
+
+    def entry(name, kernel, bound, work, ms, peak, unit, bytes_, tkey, prof=None):
         ach = work / (ms * 1e-3) / (1e12 if bound == "mfma" else 1e9)
+        prof_ms, prof_file = rocprof_avg_us(*prof) if prof else (None, None)
         return {"name": name, "kernel": kernel, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                 "frac": round(ach / peak, 4), "kernel_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_,
+                "rocprof_kernel_ms": None if prof_ms is None else round(prof_ms, 4),
+                "rocprof_source": None if prof_ms is None else "stored: " + prof_file,
                 "traffic": traffic.get(tkey),
                 # `traffic` is NOT counted in this run: it is the PMC measurement of the same kernel and shape kept in
                 # profiles/ (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE)
@@ -209,10 +226,12 @@ def roofline_kernels(device):
 
     bwd = entry("head-tower layer, merged backward products (largest in-step kernel, 8 launches per step)",
                 "conv_bwd_kernel<64,64,2,2,true,64,64,2,2>: 36 x ([682x256]x[256x256]^T dgrad + [256x682]x[682x256] wgrad partials)",
-                "mfma", 2 * flops, bwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", bwd_bytes, "bwd_products")
+                "mfma", 2 * flops, bwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", bwd_bytes, "bwd_products",
+                prof=("conv_bwd_kernel<64, 64, 2, 2, true, 64, 64, 2, 2>", 36 * (44 + 32)))
     bwd["flops_per_launch"] = 2 * flops
     fwd = entry("head-tower layer, forward products", "conv_fwd_kernel<64,64,2,2,4,true>, batched: 36 x [682x256]x[256x256]",
-                "mfma", flops, fwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", fwd_bytes, "fwd_products")
+                "mfma", flops, fwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", fwd_bytes, "fwd_products",
+                prof=("conv_fwd_kernel<64, 64, 2, 2, 4, true>", 36 * 44))
     fwd["flops_per_launch"] = flops
     fwd["layer_ms"] = round(layer_ms, 4)
     fwd["layer_direct_conv_equivalent_tflops"] = round(2.0 * pixels * 2304 * 256 / (layer_ms * 1e-3) / 1e12, 1)

@@ -48,7 +48,7 @@ typedef struct rn_reduce_list rn_reduce_list;
 
 /* Version of this header's ABI: bumped whenever an entry point's arguments or a struct layout change.  rn_version() returns
  * the value the library was built with; a caller built against another value must not call anything else. */
-#define RN_API_VERSION 400
+#define RN_API_VERSION 401
 int rn_version(void);
 const char* rn_last_error(void);
 
@@ -212,8 +212,12 @@ int rn_conv3x3_winograd_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout
 /* ------------------------------------------------------------------ fp16 inference convolution
  * BASELINE configs[4] ("Inference-only ResNeXt-50-FPN 1024x1024 bs=16, fp16"): forward conv on the f16
  * matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate).  Segment fields as rn_conv2d_fwd but x is
- * fp16 NHWC, wgt is the PACKED kernel Wt[cout][kh*kw*cin/G] (fp16, from rn_pack_weights_f16), bias fp32,
- * y fp16 (out_f32 = 0) or fp32 (out_f32 = 1).  cin/G must be a multiple of 4. */
+ * fp16 NHWC, wgt is the PACKED kernel (fp16, written by rn_pack_weights_f16 into a buffer of rn_pack_weights_f16_bytes
+ * bytes), bias fp32, y fp16 (out_f32 = 0) or fp32 (out_f32 = 1).  cin/G must be a multiple of 4.
+ * The packed kernel is Wt[cout][kh*kw*cin/G] and, when kh*kw*cin/G is a multiple of 16, 256-byte aligned behind it, the
+ * same values once more in matrix-core fragment order Wf[ceil(cout/32)][K/16][64 lanes][8] (channels padded with zeros):
+ * the large-tile kernel reads its weight operand from that copy straight into registers. */
+size_t rn_pack_weights_f16_bytes(int kh, int kw, int cin_g, int cout);
 int rn_pack_weights_f16(const float* w, void* wt, int kh, int kw, int cin_g, int cout, rn_stream_t stream);
 int rn_cast_f32_to_f16(const float* x, void* y, int64_t count, rn_stream_t stream);
 /* image [pixels,3] fp32 -> [pixels,4] fp16 with a zero 4th channel (the stem then gathers 8 bytes per tap) */

@@ -28,6 +28,7 @@ constexpr unsigned OOB = 0x80000000u;
 
 struct SegH {
   const _Float16* x; const _Float16* wt; const float* bias; void* y;
+  const _Float16* wf;   // the kernel once more in MFMA-fragment order (frag_offset_halfs behind wt), nullptr when K % 16 != 0
   int n, h, w, oh, ow, cout, pad_t, pad_l, m, tiles_n, start, x_ld, x_coff;
 };
 // rn_f16_fold on the device: the GroupNorm in FRONT of the conv applied to the A operand between the global load and the LDS
@@ -79,7 +80,7 @@ __device__ __forceinline__ int find_seg(const ArgsH& a, int id) {
 // double-buffered in (dynamic) LDS -- tile t+1 goes from the staging registers into the other buffer between the MFMAs of tile
 // t and the loads of tile t+2 are issued behind it: one barrier per K-tile instead of two, and no wave waits on LDS stores or
 // on the first fragment reads with the matrix pipe idle.
-template <int BM, int BN, int WM, int WN, int VEC, bool TAPU, int FOLD, bool PIPE = false, int DBG = 0>
+template <int BM, int BN, int WM, int WN, int VEC, bool TAPU, int FOLD, int PIPE = 0, int DBG = 0>
 __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args) {
   constexpr int T = WM * WN * 64;
   constexpr bool FIN = (FOLD & 1) != 0, FOUT = (FOLD & 2) != 0;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
       for (int tn = 0; tn < TN; ++tn)
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
   };
-  if constexpr (PIPE) {
+  if constexpr (PIPE == 1) {
     // ONE block of 8 waves per CU (128 accumulator registers per lane): nothing but the block's own instruction order hides its
     // memory operations, and a wave issues in order.  Here every K-step issues ONE memory operation behind each MFMA: the
     // fragment reads of the next K-step (two register slots), the LDS stores of tile t+1 (other buffer) and, right behind each
@@ -338,6 +339,115 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
       mf(1, 3, 1); SB(); if constexpr (!(DBG & 4)) rdA(An, 0, 0, 3); SB();
     }
 #undef SB
+  } else if constexpr (PIPE == 2) {
+    // The pipelined loop above with the WEIGHT operand kept out of LDS: rn_pack_weights_f16 leaves a second copy of the kernel
+    // in MFMA-fragment order -- Wf[cout / 32][K / 16][lane][8 halfs]: what lane l of a wave feeds `v_mfma_f32_32x32x16_f16`
+    // for 32 output channels x 16 k is 16 contiguous bytes, a wave's fragment 1 KB contiguous -- so a B fragment is ONE global
+    // load straight into the registers the MFMA reads (L2-resident data; the two wave rows of a tile fetch the same lines).
+    // Per K-tile and wave that removes 4 of the 8 `ds_write_b128` (what the leave-one-out builds name as the loop's cost), 8 of
+    // the 24 fragment reads and the B tiles' LDS; the 8 fragments of tile t+1 are requested as the MFMAs of tile t release
+    // their registers, a full tile ahead of their use.
+    static_assert(!FIN && TAPU && VEC == 8 && TM == 4 && TN == 2 && A_PASS == 4 && BK == 64, "PIPE: the 256 x 256 / 8-wave shape");
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    half8 fa[2][TM], fbg[4][TN];
+    const int arow = (wm * (BM / WM) + l31) * LDH + half * 8;
+    auto rdA = [&](const _Float16* buf, int ks, int slot, int tm) {
+      fa[slot][tm] = *reinterpret_cast<const half8*>(&buf[arow + tm * 32 * LDH + ks * 16]);
+    };
+    auto mf = [&](int slot, int ks, int tm, int tn) {
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[slot][tm], fbg[ks][tn], acc[tm][tn], 0, 0, 0);
+    };
+    int l_kh = 0, l_kw = 0, l_tap = 0;
+    bool l_in = true;
+    auto prep = [&](int kt) {
+      l_kh = t_kh; l_kw = t_kw;
+      l_tap = (t_kh * W + t_kw) * ldx + t_ci + kq * VEC;
+      l_in = kt < nk;
+      t_ci += BK;
+      if (t_ci == cin) { t_ci = 0; if (++t_kw == kw) { t_kw = 0; ++t_kh; } }
+    };
+    auto ldA = [&](int i) {
+      const int ok = (int)((unsigned)(ih0[i] + l_kh) < (unsigned)H) & (int)((unsigned)(iw0[i] + l_kw) < (unsigned)W) & (int)l_in;
+      ra[i] = VecH<VEC>::load(xa, ok ? (unsigned)(rowoff[i] + l_tap) * 2u : OOB);
+    };
+    const int st_off = r0 * LDH + kq * VEC;
+    auto stA = [&](_Float16* buf, int i) { *reinterpret_cast<vec_t*>(&buf[st_off + i * RPP * LDH]) = ra[i]; };
+    // fragment (32-channel block nt, 16-k step kidx) starts at ((nt * K/16 + kidx) * 64 lanes) * 16 bytes; channel blocks past
+    // the (padded) kernel are out of the descriptor's range: zeros
+    const int ks16 = ktotal >> 4;
+    const int nblk = (cout + 31) >> 5;
+    const __amdgpu_buffer_rsrc_t wfr = make_rsrc(sg.wf, (unsigned)nblk * 32u * (unsigned)ktotal * 2u);
+    unsigned bbase[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int nt = (n0 >> 5) + wn * (BN / WN / 32) + tn;
+      bbase[tn] = nt < nblk ? ((unsigned)nt * (unsigned)ks16 * 64u + (unsigned)lane) * 16u : OOB;
+    }
+    auto ldBf = [&](int kt, int ks, int tn) {   // fragments of tile kt (past the last tile: not requested)
+      const unsigned vo = kt < nk ? bbase[tn] : OOB;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wfr, vo, (kt * 4 + ks) * 1024, 0);
+      fbg[ks][tn] = __builtin_bit_cast(half8, v);
+    };
+
+    prep(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ldA(i);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { ldBf(0, ks, 0); ldBf(0, ks, 1); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stA(smem, i);
+    prep(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ldA(i);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) rdA(smem, 0, 0, t);
+    constexpr int ABUF = BM * LDH;                  // halfs per A buffer
+    for (int kt = 0; kt < nk; ++kt) {
+      const _Float16* Ac = smem + (kt & 1) * ABUF;
+      _Float16* An = smem + ((kt + 1) & 1) * ABUF;
+      prep(kt + 2);
+      SB();
+      // K-step 0 (slot 0) | A fragments of K-step 1 -> slot 1 | A0 A1: tile t+1 -> LDS, tile t+2 <- memory | B fragments (t+1, 0)
+      mf(0, 0, 0, 0); SB(); rdA(Ac, 1, 1, 0); stA(An, 0); SB();
+      mf(0, 0, 0, 1); SB(); rdA(Ac, 1, 1, 1); ldA(0); SB();
+      mf(0, 0, 1, 0); SB(); rdA(Ac, 1, 1, 2); stA(An, 1); SB();
+      mf(0, 0, 1, 1); SB(); rdA(Ac, 1, 1, 3); ldA(1); SB();
+      mf(0, 0, 2, 0); SB();
+      mf(0, 0, 2, 1); SB();
+      mf(0, 0, 3, 0); SB(); ldBf(kt + 1, 0, 0); SB();
+      mf(0, 0, 3, 1); SB(); ldBf(kt + 1, 0, 1); SB();
+      // K-step 1 (slot 1) | K-step 2 -> slot 0 | A2 A3 | B fragments (t+1, 1)
+      mf(1, 1, 0, 0); SB(); rdA(Ac, 2, 0, 0); stA(An, 2); SB();
+      mf(1, 1, 0, 1); SB(); rdA(Ac, 2, 0, 1); ldA(2); SB();
+      mf(1, 1, 1, 0); SB(); rdA(Ac, 2, 0, 2); stA(An, 3); SB();
+      mf(1, 1, 1, 1); SB(); rdA(Ac, 2, 0, 3); ldA(3); SB();
+      mf(1, 1, 2, 0); SB();
+      mf(1, 1, 2, 1); SB();
+      mf(1, 1, 3, 0); SB(); ldBf(kt + 1, 1, 0); SB();
+      mf(1, 1, 3, 1); SB(); ldBf(kt + 1, 1, 1); SB();
+      // K-step 2 (slot 0) | K-step 3 -> slot 1 | B fragments (t+1, 2)
+      mf(0, 2, 0, 0); SB(); rdA(Ac, 3, 1, 0); SB();
+      mf(0, 2, 0, 1); SB(); rdA(Ac, 3, 1, 1); SB();
+      mf(0, 2, 1, 0); SB(); rdA(Ac, 3, 1, 2); SB();
+      mf(0, 2, 1, 1); SB(); rdA(Ac, 3, 1, 3); SB();
+      mf(0, 2, 2, 0); SB();
+      mf(0, 2, 2, 1); SB();
+      mf(0, 2, 3, 0); SB(); ldBf(kt + 1, 2, 0); SB();
+      mf(0, 2, 3, 1); SB(); ldBf(kt + 1, 2, 1); SB();
+      // K-step 3 (slot 1) | barrier: this buffer's fragments are all in registers, the other buffer is complete | K-step 0 of
+      // the next tile -> slot 0 | B fragments (t+1, 3)
+      mf(1, 3, 0, 0); SB();
+      mf(1, 3, 0, 1); SB();
+      __syncthreads(); SB();
+      mf(1, 3, 1, 0); SB(); rdA(An, 0, 0, 0); SB();
+      mf(1, 3, 1, 1); SB(); rdA(An, 0, 0, 1); SB();
+      mf(1, 3, 2, 0); SB(); rdA(An, 0, 0, 2); SB();
+      mf(1, 3, 2, 1); SB(); rdA(An, 0, 0, 3); SB();
+      mf(1, 3, 3, 0); SB(); ldBf(kt + 1, 3, 0); SB();
+      mf(1, 3, 3, 1); SB(); ldBf(kt + 1, 3, 1); SB();
+    }
+#undef SB
   } else {
     load_tiles(0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -356,7 +466,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
     // 8 global stores per thread instead of 64 two-byte ones, every row of the tile a contiguous 2*BN-byte run.
     constexpr int LDS_ROW = BN + 8;  // halfs; +8 keeps the two half-waves (rows r, r+4) on different banks
     // tiles taller than the operand LDS can stage go in WM passes of BM / WM rows (the rows of one wave row)
-    constexpr int CAP = (PIPE ? 2 : 1) * BUF;   // halfs of LDS the staged tile may use
+    constexpr int CAP = (PIPE ? 2 : 1) * BUF;   // (the host passes 2 * BUF halfs of dynamic LDS to both pipelined variants)   // halfs of LDS the staged tile may use
     constexpr int PASSES = (BM * LDS_ROW <= CAP) ? 1 : WM;
     constexpr int ROWS = BM / PASSES;
     static_assert(ROWS * LDS_ROW <= CAP, "staging tile must fit the operand tiles' LDS");
@@ -455,6 +565,18 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, _Float16* __res
   wt[i] = (_Float16)w[(size_t)k * cout + co];
 }
 
+// Wf[cout/32 (padded)][K/16][lane][8] <- w: lane l of a fragment holds channel (l & 31) of the block and k = 16 step + 8 (l >> 5) .. + 7
+__global__ void pack_weights_frag_kernel(const float* __restrict__ w, _Float16* __restrict__ wf, int ktotal, int cout, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i & 7), l = (int)((i >> 3) & 63);
+  const int64_t f = i >> 9;                      // fragment index = nt * (K/16) + kstep
+  const int ks16 = ktotal >> 4;
+  const int nt = (int)(f / ks16), kstep = (int)(f - (int64_t)nt * ks16);
+  const int n = nt * 32 + (l & 31), k = kstep * 16 + (l >> 5) * 8 + e;
+  wf[i] = n < cout ? (_Float16)w[(size_t)k * cout + n] : (_Float16)0.f;
+}
+
 __global__ void cast_f32_to_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int64_t count) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = (_Float16)x[i];
@@ -477,12 +599,32 @@ const double kT0[4] = {700, 550, 430, 430}, kT1[4] = {1780, 1000, 515, 560};
 
 }  // namespace
 
+namespace {
+// the fragment-ordered copy starts this many halfs behind Wt (256-byte aligned); 0: there is none (K % 16 != 0)
+inline int64_t frag_offset_halfs(int64_t ktotal, int64_t cout) { return (ktotal & 15) ? 0 : (int64_t)(rn::align_up((size_t)(ktotal * cout * 2), 256) / 2); }
+inline int64_t frag_halfs(int64_t ktotal, int64_t cout) { return (ktotal & 15) ? 0 : ((cout + 31) / 32) * 32 * ktotal; }
+}  // namespace
+
+extern "C" size_t rn_pack_weights_f16_bytes(int kh, int kw, int cin_g, int cout) {
+  if (kh < 1 || kw < 1 || cin_g < 1 || cout < 1) return 0;
+  const int64_t k = (int64_t)kh * kw * cin_g;
+  const int64_t off = frag_offset_halfs(k, cout);
+  return (size_t)(off ? (off + frag_halfs(k, cout)) * 2 : k * cout * 2);
+}
+
 extern "C" int rn_pack_weights_f16(const float* w, void* wt, int kh, int kw, int cin_g, int cout, rn_stream_t stream) {
   RN_CHECK_ARG(w && wt && kh >= 1 && kw >= 1 && cin_g >= 1 && cout >= 1, "pack_weights_f16: bad argument");
   const int64_t total = (int64_t)kh * kw * cin_g * cout;
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)rn::ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
                      (_Float16*)wt, kh * kw * cin_g, cout);
   RN_LAUNCH_CHECK();
+  const int64_t k = (int64_t)kh * kw * cin_g, off = frag_offset_halfs(k, cout);
+  if (off) {
+    const int64_t ftotal = frag_halfs(k, cout);
+    hipLaunchKernelGGL(pack_weights_frag_kernel, dim3((unsigned)rn::ceil_div64(ftotal, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (_Float16*)wt + off, (int)k, cout, ftotal);
+    RN_LAUNCH_CHECK();
+  }
   return RN_OK;
 }
 
@@ -525,6 +667,10 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
     RN_UNSUPPORTED(G > 1 && segs[s].cout != segs[0].cout, "conv f16: grouped segments must share cout");
     SegH& d = a.seg[s];
     d.x = (const _Float16*)segs[s].x; d.wt = (const _Float16*)segs[s].wgt; d.bias = segs[s].bias; d.y = segs[s].y;
+    {
+      const int64_t kk = (int64_t)g->kh * g->kw * (g->cin / G), off = frag_offset_halfs(kk, segs[s].cout);
+      d.wf = off ? d.wt + off : nullptr;
+    }
     d.n = segs[s].n; d.h = segs[s].h; d.w = segs[s].w; d.cout = segs[s].cout;
     rn::same_pad(d.h, g->kh, g->stride, &d.oh, &d.pad_t);
     rn::same_pad(d.w, g->kw, g->stride, &d.ow, &d.pad_l);
@@ -603,23 +749,25 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
     else if (vec8) RN_F16K(BM_, BN_, WM_, WN_, 0);                                                                  \
     else hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 4, false, 0>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
   } while (0)
-  // the 256 x 256 tile, dense taps, no input-side fold: the double-buffered variant (147 KB of dynamic LDS)
-  static const bool pipe_on = !(getenv("RN_F16_PIPE") && atoi(getenv("RN_F16_PIPE")) == 0);
-  if (c == 5 && tapu && pipe_on && (fbits == 0 || fbits == 2)) {
+  // the 256 x 256 tile, dense taps, no input-side fold: the software-pipelined variants (147 KB of dynamic LDS); RN_F16_PIPE: 0 the
+  // plain loop, 1 both operands through LDS, 2 (default) the weight fragments straight from the fragment-ordered copy
+  static const int pipe_mode = getenv("RN_F16_PIPE") ? atoi(getenv("RN_F16_PIPE")) : 2;
+  if (c == 5 && tapu && pipe_mode && G == 1 && (fbits == 0 || fbits == 2)) {
     constexpr size_t lds = 2 * (256 + 256) * LDH * sizeof(_Float16);
-    static const bool attr_ = (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
-                              (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
+    static const bool attr_ = (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
+                              (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
+                              (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
+                              (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
     RN_UNSUPPORTED(!attr_, "conv f16: %zu bytes of LDS per block refused", lds);
-#ifdef RN_F16_DBG_BUILD   // tuning aid (make CXXFLAGS+=-DRN_F16_DBG_BUILD): the loop with one kind of operation left out (bit 0 loads, 1 LDS stores, 2 fragment reads, 3 barrier)
-    if (const char* d = getenv("RN_F16_DBG")) {
-      const int v = atoi(d);
-#define RN_DBGK(V_) if (v == V_) { (void)hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 0, true, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, true, V_>), dim3(tiles), dim3(512), lds, st, a); return RN_OK; }
-      RN_DBGK(1) RN_DBGK(2) RN_DBGK(3) RN_DBGK(4) RN_DBGK(7) RN_DBGK(8) RN_DBGK(15)
-#undef RN_DBGK
+    bool frag = pipe_mode == 2;
+    for (int s = 0; s < nseg; ++s) frag = frag && a.seg[s].wf != nullptr;
+    if (frag) {
+      if (fbits == 2) hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 2>), dim3(tiles), dim3(512), lds, st, a);
+      else hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, 2>), dim3(tiles), dim3(512), lds, st, a);
+    } else {
+      if (fbits == 2) hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 1>), dim3(tiles), dim3(512), lds, st, a);
+      else hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, 1>), dim3(tiles), dim3(512), lds, st, a);
     }
-#endif
-    if (fbits == 2) hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 2, true>), dim3(tiles), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, true>), dim3(tiles), dim3(512), lds, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
   }

@@ -24,7 +24,8 @@ SUPER_GROUP = 32    # narrow groups are merged into block-diagonal groups of thi
 
 def _pack(w):
     kh, kw, cin_g, cout = w.shape
-    wt = torch.empty((cout, kh * kw * cin_g), dtype=torch.float16, device=w.device)
+    # Wt[cout, K] and, behind it, the fragment-ordered copy the large-tile kernel reads (rn_hip.h: rn_pack_weights_f16_bytes)
+    wt = torch.empty((int(_rn.lib().rn_pack_weights_f16_bytes(kh, kw, cin_g, cout)) // 2,), dtype=torch.float16, device=w.device)
     _rn.check(_rn.lib().rn_pack_weights_f16(_rn.f32(w.contiguous()), _rn.f16(wt), kh, kw, cin_g, cout, _rn.stream()),
               "rn_pack_weights_f16")
     return wt
