@@ -52,6 +52,7 @@ def side_stream(device):
 
 
 HEADS_OFFSET_US = float(os.environ.get("RN_HEADS_OFFSET_US", "0"))
+HEADS_BOX_FIRST = os.environ.get("RN_HEADS_BOX_FIRST", "0") == "1"
 # fp16 inference: GroupNorm statistics of the head towers from the conv epilogues on levels with at least this many rows (n h w)
 F16_HEAD_STATS = os.environ.get("RN_F16_HEAD_STATS", "0") == "1"      # measured: 678 vs 680 images/s at cfg 5 -- off (the two subnets' streams already hide the pass)
 F16_HEAD_STATS_MIN_ROWS = int(os.environ.get("RN_F16_HEAD_STATS_MIN_ROWS", "32768"))
@@ -273,11 +274,16 @@ class RetinaNetBase(Model):
             if HEADS_TWO_STREAMS and maps[0].is_cuda:
                 main, side = torch.cuda.current_stream(), side_stream(maps[0].device)
                 side.wait_stream(main)
-                cls_out = self.classification_subnet(maps_c, training)
-                with torch.cuda.stream(side):
-                    if HEADS_OFFSET_US > 0:            # tuning aid: start the box subnet a fraction of a layer later
-                        _delay(maps[0].device, side, HEADS_OFFSET_US)
-                    reg_out = self.regression_subnet(maps_r, training)
+                if HEADS_BOX_FIRST:                    # tuning aid: the box subnet's launches recorded before the class subnet's
+                    with torch.cuda.stream(side):
+                        reg_out = self.regression_subnet(maps_r, training)
+                    cls_out = self.classification_subnet(maps_c, training)
+                else:
+                    cls_out = self.classification_subnet(maps_c, training)
+                    with torch.cuda.stream(side):
+                        if HEADS_OFFSET_US > 0:        # tuning aid: start the box subnet a fraction of a layer later
+                            _delay(maps[0].device, side, HEADS_OFFSET_US)
+                        reg_out = self.regression_subnet(maps_r, training)
                 main.wait_stream(side)
             else:
                 cls_out = self.classification_subnet(maps_c, training)

@@ -442,10 +442,17 @@ class Trainer(object):
                 self.forward_backward(self._static, advance_dropout=False)
             self.drop_counter.copy_(counter)       # the warm-up passes do not count: replay i draws the masks eager step i draws
         torch.cuda.current_stream().wait_stream(s)
-        ga = torch.cuda.CUDAGraph()
+        dot = os.environ.get("RN_GRAPH_DOT")       # tuning aid: the captured segment A as a DOT file (nodes = kernels, edges = dependencies)
+        ga = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread may poll events while the capture is open
         with torch.cuda.graph(ga, capture_error_mode="thread_local"):
             self._graph_out = self.segment_a(self._static)
+        if dot:
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipGraphDebugDotPrint.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint]
+            err = hip.hipGraphDebugDotPrint(ctypes.c_void_p(ga.raw_cuda_graph()), dot.encode(), 0)
+            print("hipGraphDebugDotPrint ->", err, dot, flush=True)
+            ga.instantiate()
         gbs, ranges = [], []
         for j in range(self.num_parts()):          # one graph per part of segment B: the collectives go between the replays
             gb = torch.cuda.CUDAGraph()
