@@ -433,8 +433,11 @@ class Trainer(object):
         # the captured segments read PRIVATE copies of the features: a caller may hand in other tensors (or reuse these) on
         # later steps -- step() copies them into the static buffers -- and must never find its own tensors overwritten
         self._static = _clone_tree(features)
-        # warm-up on a side stream (allocator + workspace sizing), then capture
-        s = torch.cuda.Stream()
+        # warm-up on a side stream (allocator + workspace sizing), then capture; ONE warm-up stream per trainer: every shape
+        # key re-captures, and per-stream state elsewhere (_rn.sync_counters) is keyed by the stream handle
+        s = getattr(self, "_warm_stream", None)
+        if s is None:
+            s = self._warm_stream = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             counter = self.drop_counter.clone()
