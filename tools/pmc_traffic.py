@@ -29,7 +29,7 @@ def main(fetch_dir, write_dir):
         total = 0.0
         for n in names:
             # the demangled name STARTS with the kernel's name ("conv_fwd_kernel" is also a substring of "stem_conv_fwd_kernel")
-            mine = lambda k: re.match(r"(void\s+)?%s\b" % re.escape(n), k) is not None
+            mine = lambda k: re.match(r"(void\s+)?(\(anonymous namespace\)::)?%s\b" % re.escape(n), k) is not None
             f = [v for k, vals in fetch.items() if mine(k) for v in vals]
             w = [v for k, vals in write.items() if mine(k) for v in vals]
             if not f or not w:
