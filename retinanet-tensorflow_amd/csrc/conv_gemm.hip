@@ -1466,7 +1466,10 @@ int rn::launch_winograd_bwd_products(const float* Ad, const float* Bd, float* Cd
   }
   *nsplit_out = pw.nsplit;
   const ConvArgs4 d4 = compact(pd.a), w4 = compact(pw.a);
-  const dim3 grid((unsigned)(pd.blocks + pw.blocks));
+  // RN_DEBUG_SKIP_WGRAD_BLOCKS=1 (TIMING ONLY, wrong weight gradients): the weight-gradient blocks are not launched -- what the
+  // heads' backward pass would take with its weight gradients computed elsewhere
+  static const bool skip_w = getenv("RN_DEBUG_SKIP_WGRAD_BLOCKS") && atoi(getenv("RN_DEBUG_SKIP_WGRAD_BLOCKS")) == 1;
+  const dim3 grid((unsigned)(pd.blocks + (skip_w ? 0 : pw.blocks)));
   // tuning aid: unused dynamic LDS caps the products' blocks per CU, leaving registers / wave slots for the OTHER subnet's
   // transform kernel that runs beside them (RN_PROD_LDS_PAD_BWD bytes)
   static const int pad = getenv("RN_PROD_LDS_PAD_BWD") ? atoi(getenv("RN_PROD_LDS_PAD_BWD")) : 0;
