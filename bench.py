@@ -197,6 +197,9 @@ def roofline_kernels(device):
     traffic = {}
     if os.path.exists(PMC_TRAFFIC_FILE):
         traffic = json.load(open(PMC_TRAFFIC_FILE))
+        # a stored measurement of ANOTHER workload (a stale file) must not be printed beside this one
+        if traffic.get("_shape") != {"points": 36, "tiles": tiles, "cin": 256, "cout": 256, "batch": BATCH, "image": IMAGE_SIZE}:
+            traffic = {}
 
     def rocprof_avg_us(kernel_prefix, blocks):
         """Average duration of (kernel, grid) in the newest committed kernel trace (profiles/r*_bench_kernel_trace_by_grid.txt): the

@@ -39,6 +39,8 @@ def main(fetch_dir, write_dir):
             total += (2.0 * fk + wk) * 1024.0       # gfx950: FETCH_SIZE reports half of the bytes of wide streaming reads
         out[key] = int(total) if total else None
     out["_detail"] = detail
+    # what tools/gemm_pmc.py launched: bench.py compares this with its own workload and drops `traffic` when they differ
+    out["_shape"] = {"points": 36, "tiles": 2 * sum(((s + 3) // 4) ** 2 for s in (64, 32, 16, 8, 4)), "cin": 256, "cout": 256, "batch": 2, "image": 512}
     out["_note"] = "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), averaged over the dispatches of tools/gemm_pmc.py"
     print(json.dumps(out, indent=1))
 
