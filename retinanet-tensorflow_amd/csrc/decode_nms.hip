@@ -341,6 +341,75 @@ __global__ __launch_bounds__(T) void det_scan_q_kernel(const DetArgs a) {
   if (lane == 0) { a.wave_count[wid] = __popcll(m); a.wave_mask[wid] = m; }
 }
 
+// fp16 maps with C = 8 CVT classes: the wave's 64 rows are ONE contiguous range of memory, read as whole 1 KB instructions
+// (lane l takes chunks l, l + 64, ...: 128-byte requests only -- the four-lanes-per-row kernels above issue 64-byte pieces of
+// 16 rows per instruction and stream at 4.4 TB/s, this pattern at 5.4), every load of the wave in flight at once; the chunks
+// are transposed through the wave's own LDS region (row stride an odd number of 16-byte units: conflict-free both ways) so
+// that lane l then holds row l whole and reduces it alone -- ascending class order, strict >: the first maximum wins, no
+// shuffles -- with the exact logit -> probability rule of scan_rows_reduce from the same registers.  No block barrier: a
+// wave touches only its own region.
+template <int CVT, bool LOGIT>
+__global__ __launch_bounds__(T) void det_scan_t_kernel(const DetArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char scan_t_lds[];
+  constexpr int RS = (CVT | 1) * 16;                   // LDS row stride
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
+  const int64_t nw = (int64_t)a.n * a.waves_per_image;
+  if (wid >= nw) return;
+  int img, l; int64_t row0;
+  locate_wave(a, wid, &img, &l, &row0);
+  const DetLevel& lv = a.lv[l];
+  const int nrow = (int)((lv.rows - row0) < 64 ? (lv.rows - row0) : 64);
+  const char* base = reinterpret_cast<const char*>(lv.prob) + ((size_t)img * lv.rows + row0) * (CVT * 16);
+  char* lds = scan_t_lds + wave * (64 * RS);
+  const int total = nrow * CVT;
+  half8 v[CVT];
+#pragma unroll
+  for (int j = 0; j < CVT; ++j) v[j] = reinterpret_cast<const half8*>(base)[min(lane + 64 * j, total - 1)];
+#pragma unroll
+  for (int j = 0; j < CVT; ++j) {
+    const int c = lane + 64 * j;                       // (chunks past the last row: clamped duplicates, parked in rows nobody reads)
+    const int r = c / CVT, ps = c - r * CVT;
+    *reinterpret_cast<half8*>(lds + r * RS + ps * 16) = v[j];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the wave's own stores have landed
+  __builtin_amdgcn_wave_barrier();
+  const char* row = lds + min(lane, nrow - 1) * RS;
+#pragma unroll
+  for (int j = 0; j < CVT; ++j) v[j] = *reinterpret_cast<const half8*>(row + j * 16);
+  float best = -1e30f; int bi = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < CVT; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float pv = (float)v[j][i];
+      if (pv > best) { best = pv; bi = j * 8 + i; }
+    }
+  if (LOGIT) {   // see scan_rows_reduce: sigmoid of the max logit, exact handling of possible ties in probability space
+    const float m = best;
+    float pb = to_prob(m, true);
+    int pi = bi;
+    float zlo = m - (5e-7f * (1.f + __expf(m)) + 1e-6f * fabsf(m));
+    zlo = fminf(zlo, 16.f);
+#pragma unroll
+    for (int j = 0; j < CVT; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float z = (float)v[j][i];
+        if (z >= zlo && j * 8 + i != bi) {             // rare: a possible tie / inversion in probability space
+          const float pz = to_prob(z, true);
+          if (pz > pb || (pz == pb && j * 8 + i < pi)) { pb = pz; pi = j * 8 + i; }
+        }
+      }
+    best = pb; bi = pi;
+  }
+  const bool flag = lane < nrow && best > a.score_thr;
+  const int64_t g = (int64_t)img * a.rows_per_image + lv.row_off + row0 + lane;
+  if (flag) { a.row_score[g] = best; a.row_class[g] = bi; }
+  const unsigned long long m = __ballot(flag);
+  if (lane == 0) { a.wave_count[wid] = __popcll(m); a.wave_mask[wid] = m; }
+}
+
 __global__ __launch_bounds__(T) void det_scan_kernel(const DetArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
@@ -965,7 +1034,13 @@ int run_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, 
     const int v0 = a.lv[0].half_prob ? 8 : 4;
     const int qpl = a.C % v0 == 0 ? (a.C / v0 + 3) / 4 : 0;
     lds_ok = lds_ok && getenv("RN_SCAN_LDS") != nullptr;   // measured slower than the specialised kernels: opt-in only
-    if (uniform && qpl >= 1 && qpl <= 8 && !lds_ok) {
+    // fp16 maps of 80 classes (cfg 5): the transposing scan; RN_SCAN_T=0: the four-lanes-per-row kernels
+    static const bool scan_t = !(getenv("RN_SCAN_T") && atoi(getenv("RN_SCAN_T")) == 0);
+    if (scan_t && uniform && a.lv[0].half_prob && a.C == 80 && !lds_ok) {
+      constexpr size_t tl = (size_t)(T / 64) * 64 * ((10 | 1) * 16);
+      if (a.lv[0].logit) hipLaunchKernelGGL((det_scan_t_kernel<10, true>), dim3(wblocks), dim3(T), tl, st, a);
+      else hipLaunchKernelGGL((det_scan_t_kernel<10, false>), dim3(wblocks), dim3(T), tl, st, a);
+    } else if (uniform && qpl >= 1 && qpl <= 8 && !lds_ok) {
 #define RN_SCAN_Q(H_, L_)                                                                                         \
       switch (qpl) {                                                                                              \
         case 1: hipLaunchKernelGGL((det_scan_q_kernel<H_, L_, 1>), dim3(wblocks), dim3(T), 0, st, a); break;      \
