@@ -341,17 +341,19 @@ __global__ __launch_bounds__(T) void det_scan_q_kernel(const DetArgs a) {
   if (lane == 0) { a.wave_count[wid] = __popcll(m); a.wave_mask[wid] = m; }
 }
 
-// fp16 maps with C = 8 CVT classes: the wave's 64 rows are ONE contiguous range of memory, read as whole 1 KB instructions
-// (lane l takes chunks l, l + 64, ...: 128-byte requests only -- the four-lanes-per-row kernels above issue 64-byte pieces of
-// 16 rows per instruction and stream at 4.4 TB/s, this pattern at 5.4), every load of the wave in flight at once; the chunks
-// are transposed through the wave's own LDS region (row stride an odd number of 16-byte units: conflict-free both ways) so
-// that lane l then holds row l whole and reduces it alone -- ascending class order, strict >: the first maximum wins, no
-// shuffles -- with the exact logit -> probability rule of scan_rows_reduce from the same registers.  No block barrier: a
-// wave touches only its own region.
+// fp16 maps with C = 8 CVT classes (CVT even): the wave's 64 rows are ONE contiguous range of memory, read as whole 1 KB
+// instructions (lane l takes chunks l, l + 64, ...: 128-byte requests only -- the four-lanes-per-row kernels above issue
+// 64-byte pieces of 16 rows per instruction and stream at 4.4 TB/s, this pattern at 5.4), every load of the wave in flight at
+// once.  The chunks are then transposed through the wave's own LDS region, 32 rows at a time (5.6 KB per wave: 28 waves per CU;
+// row stride an odd number of 16-byte units: conflict-free both ways): lanes l and l + 32 hold the two halves of row l's
+// classes, reduce them in ascending class order (strict >: the first maximum wins) and exchange once; the exact logit ->
+// probability rule of scan_rows_reduce follows from the same registers.  No block barrier: a wave touches only its own region.
 template <int CVT, bool LOGIT>
 __global__ __launch_bounds__(T) void det_scan_t_kernel(const DetArgs a) {
+  static_assert(CVT % 2 == 0, "the two lanes of a row take CVT / 2 chunks each");
   extern __shared__ __attribute__((aligned(16))) char scan_t_lds[];
   constexpr int RS = (CVT | 1) * 16;                   // LDS row stride
+  constexpr int HC = CVT / 2;                          // chunks per lane and half
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t wid = ((int64_t)blockIdx.x * T + threadIdx.x) >> 6;
   const int64_t nw = (int64_t)a.n * a.waves_per_image;
@@ -361,51 +363,69 @@ __global__ __launch_bounds__(T) void det_scan_t_kernel(const DetArgs a) {
   const DetLevel& lv = a.lv[l];
   const int nrow = (int)((lv.rows - row0) < 64 ? (lv.rows - row0) : 64);
   const char* base = reinterpret_cast<const char*>(lv.prob) + ((size_t)img * lv.rows + row0) * (CVT * 16);
-  char* lds = scan_t_lds + wave * (64 * RS);
+  char* lds = scan_t_lds + wave * (32 * RS);
   const int total = nrow * CVT;
   half8 v[CVT];
 #pragma unroll
   for (int j = 0; j < CVT; ++j) v[j] = reinterpret_cast<const half8*>(base)[min(lane + 64 * j, total - 1)];
+  const int part = lane >> 5;                          // 0: classes [0, 4 CVT), 1: the rest
+  const char* rd = lds + (lane & 31) * RS + part * HC * 16;
+  float my_s = 0.f; int my_c = 0;
 #pragma unroll
-  for (int j = 0; j < CVT; ++j) {
-    const int c = lane + 64 * j;                       // (chunks past the last row: clamped duplicates, parked in rows nobody reads)
-    const int r = c / CVT, ps = c - r * CVT;
-    *reinterpret_cast<half8*>(lds + r * RS + ps * 16) = v[j];
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the wave's own stores have landed
-  __builtin_amdgcn_wave_barrier();
-  const char* row = lds + min(lane, nrow - 1) * RS;
+  for (int h = 0; h < 2; ++h) {                        // rows [32 h, 32 h + 32) = chunks [32 CVT h, + 32 CVT) = loads HC h .. HC h + HC - 1
 #pragma unroll
-  for (int j = 0; j < CVT; ++j) v[j] = *reinterpret_cast<const half8*>(row + j * 16);
-  float best = -1e30f; int bi = 0x7fffffff;
-#pragma unroll
-  for (int j = 0; j < CVT; ++j)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float pv = (float)v[j][i];
-      if (pv > best) { best = pv; bi = j * 8 + i; }
+    for (int j = 0; j < HC; ++j) {
+      const int c = lane + 64 * j;
+      const int r = c / CVT, ps = c - r * CVT;
+      *reinterpret_cast<half8*>(lds + r * RS + ps * 16) = v[HC * h + j];
     }
-  if (LOGIT) {   // see scan_rows_reduce: sigmoid of the max logit, exact handling of possible ties in probability space
-    const float m = best;
-    float pb = to_prob(m, true);
-    int pi = bi;
-    float zlo = m - (5e-7f * (1.f + __expf(m)) + 1e-6f * fabsf(m));
-    zlo = fminf(zlo, 16.f);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the wave's own stores have landed
+    __builtin_amdgcn_wave_barrier();
+    half8 u[HC];
 #pragma unroll
-    for (int j = 0; j < CVT; ++j)
+    for (int j = 0; j < HC; ++j) u[j] = *reinterpret_cast<const half8*>(rd + j * 16);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                // (the next half overwrites the region)
+    __builtin_amdgcn_wave_barrier();
+    float best = -1e30f; int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < HC; ++j)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float z = (float)v[j][i];
-        if (z >= zlo && j * 8 + i != bi) {             // rare: a possible tie / inversion in probability space
-          const float pz = to_prob(z, true);
-          if (pz > pb || (pz == pb && j * 8 + i < pi)) { pb = pz; pi = j * 8 + i; }
-        }
+        const float pv = (float)u[j][i];
+        if (pv > best) { best = pv; bi = (part * HC + j) * 8 + i; }
       }
-    best = pb; bi = pi;
+    {
+      const float ob = __shfl_xor(best, 32, 64);
+      const int oi = __shfl_xor(bi, 32, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (LOGIT) {   // see scan_rows_reduce: sigmoid of the max logit, exact handling of possible ties in probability space
+      const float m = best;
+      float pb = to_prob(m, true);
+      int pi = bi;
+      float zlo = m - (5e-7f * (1.f + __expf(m)) + 1e-6f * fabsf(m));
+      zlo = fminf(zlo, 16.f);
+#pragma unroll
+      for (int j = 0; j < HC; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float z = (float)u[j][i];
+          const int ci = (part * HC + j) * 8 + i;
+          if (z >= zlo && ci != bi) {                  // rare: a possible tie / inversion in probability space
+            const float pz = to_prob(z, true);
+            if (pz > pb || (pz == pb && ci < pi)) { pb = pz; pi = ci; }
+          }
+        }
+      const float ob = __shfl_xor(pb, 32, 64);
+      const int oi = __shfl_xor(pi, 32, 64);
+      if (ob > pb || (ob == pb && oi < pi)) { pb = ob; pi = oi; }
+      best = pb; bi = pi;
+    }
+    if (part == h) { my_s = best; my_c = bi; }         // lanes l and l + 32 both hold row 32 h + (l & 31): lane 32 h + (l & 31) keeps it
   }
-  const bool flag = lane < nrow && best > a.score_thr;
+  const bool flag = lane < nrow && my_s > a.score_thr;
   const int64_t g = (int64_t)img * a.rows_per_image + lv.row_off + row0 + lane;
-  if (flag) { a.row_score[g] = best; a.row_class[g] = bi; }
+  if (flag) { a.row_score[g] = my_s; a.row_class[g] = my_c; }
   const unsigned long long m = __ballot(flag);
   if (lane == 0) { a.wave_count[wid] = __popcll(m); a.wave_mask[wid] = m; }
 }
@@ -1037,7 +1057,7 @@ int run_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, 
     // fp16 maps of 80 classes (cfg 5): the transposing scan; RN_SCAN_T=0: the four-lanes-per-row kernels
     static const bool scan_t = !(getenv("RN_SCAN_T") && atoi(getenv("RN_SCAN_T")) == 0);
     if (scan_t && uniform && a.lv[0].half_prob && a.C == 80 && !lds_ok) {
-      constexpr size_t tl = (size_t)(T / 64) * 64 * ((10 | 1) * 16);
+      constexpr size_t tl = (size_t)(T / 64) * 32 * ((10 | 1) * 16);
       if (a.lv[0].logit) hipLaunchKernelGGL((det_scan_t_kernel<10, true>), dim3(wblocks), dim3(T), tl, st, a);
       else hipLaunchKernelGGL((det_scan_t_kernel<10, false>), dim3(wblocks), dim3(T), tl, st, a);
     } else if (uniform && qpl >= 1 && qpl <= 8 && !lds_ok) {
