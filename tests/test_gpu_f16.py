@@ -64,6 +64,37 @@ def test_conv_f16_large_tiles(dev, monkeypatch, case, cfg):
     test_conv_f16(dev, case)
 
 
+def test_packed_kernel_layout(dev):
+    """rn_pack_weights_f16 (rn_hip.h): Wt[cout][K] and, 256-byte aligned behind it when K % 16 == 0, the same values in
+    matrix-core fragment order Wf[ceil(cout/32)][K/16][64 lanes][8] -- lane l of a fragment holds output channel (l & 31) of
+    the 32-channel block and k = 16 step + 8 (l >> 5) .. + 7; channels past cout are zeros."""
+    import ctypes as C
+    import _rn
+    L = _rn.lib()
+    rng = np.random.default_rng(11)
+    for kh, kw, cin_g, cout in ((3, 3, 32, 40), (1, 1, 64, 256), (3, 3, 4, 24)):        # the last one: K = 36, no fragment copy
+        w = rng.standard_normal((kh, kw, cin_g, cout)).astype(np.float32)
+        K = kh * kw * cin_g
+        nbytes = int(L.rn_pack_weights_f16_bytes(kh, kw, cin_g, cout))
+        frag = K % 16 == 0
+        off = (cout * K * 2 + 255) // 256 * 256 // 2
+        rows = (cout + 31) // 32 * 32
+        assert nbytes == ((off + rows * K) * 2 if frag else cout * K * 2)
+        buf = torch.zeros(nbytes // 2, dtype=torch.float16, device=dev)
+        _rn.check(L.rn_pack_weights_f16(_rn.f32(torch.from_numpy(w).to(dev)), _rn.f16(buf), kh, kw, cin_g, cout, _rn.stream()),
+                  "rn_pack_weights_f16")
+        got = buf.cpu().numpy()
+        wk = w.reshape(K, cout).astype(np.float16)                                       # [k][co]
+        np.testing.assert_array_equal(got[:cout * K].reshape(cout, K), wk.T)
+        if frag:
+            wf = got[off:off + rows * K].reshape(rows // 32, K // 16, 64, 8)
+            lane = np.arange(64)
+            n = np.arange(rows // 32)[:, None, None, None] * 32 + (lane & 31)[None, None, :, None]
+            k = np.arange(K // 16)[None, :, None, None] * 16 + ((lane >> 5) * 8)[None, None, :, None] + np.arange(8)[None, None, None, :]
+            want = np.where(n < cout, wk[k, np.minimum(n, cout - 1)], np.float16(0))
+            np.testing.assert_array_equal(wf, want)
+
+
 def test_group_norm_pool_upsample_f16(dev):
     import ops_f16
     rng = np.random.default_rng(3)
