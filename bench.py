@@ -751,8 +751,9 @@ def main():
                                    (args.loss, args.dropout),
                        "global_batch": world * BATCH, "image_size": IMAGE_SIZE, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "backward_segments": 2 if step.trainer.cut_offset else 1,
-                       "parity_note": "every oracle parity test of this step runs at dropout 0 (SURVEY K9: masks are not reproducible "
-                                      "across implementations); the dropout path timed here has self-consistency tests only",
+                       "parity": "this step at this dropout rate is oracle-checked with the kernels' counter-based masks injected at the "
+                                 "reference's dropout sites (tests/test_gpu_fullsize.py::test_cfg2_full_size_train_step_matches_oracle[0.2], "
+                                 "tests/test_gpu_dropout.py)",
                        "allreduce": {"backend": "rccl" if dist is not None else None, "ranks": world,
                                      "collectives_issued": bool(step.trainer.allreduce.active),
                                      "bytes_overlapped_with_backbone_backward": 4 * (step.trainer.arena.count - step.trainer.cut_offset),

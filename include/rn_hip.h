@@ -366,7 +366,15 @@ int rn_upsample_add_bwd_top(const float* dy, float* dtop, int n, int h, int w, i
                             rn_stream_t stream);
 
 /* stand-alone inverted dropout (DenseNet puts tf.layers.Dropout after a conv: densenet.py:44,67,77,143);
- * the same counter-based mask in forward and backward: dx = rn_dropout(dy) with the same seed. */
+ * the same counter-based mask in forward and backward: dx = rn_dropout(dy) with the same seed.
+ *
+ * THE MASK FUNCTION (every dropout of this library: rn_dropout*, rn_gn_params, rn_dwgn_params, rn_mb_norm).  Element e (flat
+ * index into the dense NHWC tensor the dropout acts on) with s = seed + (seed_dev ? *seed_dev : 0), all arithmetic mod 2^32:
+ *     h  = lo32(e) * 0x9E3779B1 + lo32(s);   h ^= hi32(e) * 0x85EBCA77 + hi32(s);
+ *     h ^= h >> 16;  h *= 0x85EBCA6B;  h ^= h >> 13;  h *= 0xC2B2AE35;  h ^= h >> 16;
+ *     u  = (float)(h >> 8) * 2^-24;          y = u >= rate ? x * (1.f / (1.f - rate)) : 0
+ * Nothing else enters it (not the launch shape, not the kernel that applies it), so a checker can be handed the very masks
+ * a step draws: oracle/dropout_ref.py restates it, tests/test_gpu_dropout.py compares the two bit for bit. */
 int rn_dropout(const float* x, float* y, int64_t count, float rate, uint64_t seed, const uint64_t* seed_dev,
                rn_stream_t stream);
 /* The same between channel slices: y[p, y_coff + ch] = dropout(x[p, x_coff + ch]), ch < c, rows x_ld / y_ld floats apart; the

@@ -58,8 +58,12 @@ def resnext50_forward(p, x, prefix="backbone"):
     return out
 
 
-def densenet_forward(p, x, blocks, act="elu", prefix="backbone"):
-    """densenet.py:246-262 (dropout = identity)."""
+def densenet_forward(p, x, blocks, act="elu", prefix="backbone", dropout=None):
+    """densenet.py:246-262.  Dropout sites (densenet.py:23 ``Dropout = tf.layers.Dropout``): after the 1x1 and after the
+    3x3 conv of a BottleneckCompositeFunction (:67, :77) and after a TransitionLayer's conv (:143); site names are the
+    product's module paths (``..._mods.2`` / ``..._mods.5``).  `dropout`: hook(site, x) -> x (oracle/dropout_ref.Sites),
+    None = identity."""
+    drop = dropout if dropout is not None else (lambda _site, t: t)
     out = {}
     x = T.conv2d_same(x, p[prefix + ".conv1._mods.0.weight"], 2)
     x = T.activation(_gn(p, prefix + ".conv1._mods.1", x), act)
@@ -70,15 +74,15 @@ def densenet_forward(p, x, blocks, act="elu", prefix="backbone"):
             f = "%s.dense_block_%d._fns.%d._mods" % (prefix, i, d)
             # BottleneckCompositeFunction: [GN, act, conv1x1, drop, GN, act, conv3x3, drop] -> mods 0,1,2(drop),3,4,5(drop)
             y = T.activation(_gn(p, f + ".0", x), act)
-            y = T.conv2d_same(y, p[f + ".1.weight"], 1)
+            y = drop(f + ".2", T.conv2d_same(y, p[f + ".1.weight"], 1))
             y = T.activation(_gn(p, f + ".3", y), act)
-            y = T.conv2d_same(y, p[f + ".4.weight"], 1)
+            y = drop(f + ".5", T.conv2d_same(y, p[f + ".4.weight"], 1))
             x = torch.cat([x, y], -1)
         out["C%d" % (i + 1)] = x
         if i < 4:
             t = "%s.transition_layer_%d._mods" % (prefix, i)
             x = _gn(p, t + ".0", x)
-            x = T.conv2d_same(x, p[t + ".1.weight"], 1)
+            x = drop(t + ".2", T.conv2d_same(x, p[t + ".1.weight"], 1))
             x = T.avg_pool_same(x, 2, 2)
     return out
 
@@ -86,7 +90,7 @@ def densenet_forward(p, x, blocks, act="elu", prefix="backbone"):
 DENSENET_BLOCKS = {"densenet_121": [None, 6, 12, 24, 16], "densenet_169": [None, 6, 12, 32, 32]}
 
 
-def backbone_forward(name, p, x, act="elu"):
+def backbone_forward(name, p, x, act="elu", dropout=None):
     if name == "resnet_50":
-        return resnext50_forward(p, x)
-    return densenet_forward(p, x, DENSENET_BLOCKS[name], act)
+        return resnext50_forward(p, x)           # no dropout in ResNeXt
+    return densenet_forward(p, x, DENSENET_BLOCKS[name], act, dropout=dropout)

@@ -12,8 +12,9 @@ Follows the reference:
   * FeaturePyramidNetwork  retinanet.py:118-221     -> fpn_forward()
   * Classification/RegressionSubnet retinanet.py:24-115 -> subnet_forward()
   * RetinaNetBase.call     retinanet.py:272-296     -> retinanet_forward()
-Dropout is the identity here (parity is defined at dropout_rate 0 / training=False; the
-reference's Dropout draws from TF's RNG, which cannot be reproduced).
+Dropout: the reference's sites (mobilenet_v2.py:62,71,79,117,184) call the ``dropout`` hook when one is given
+(``dropout(site, x) -> x``, see oracle/dropout_ref.py: the product's counter-based masks injected, SURVEY K9);
+with ``dropout=None`` they are the identity (dropout_rate 0 / training=False).  TF's own RNG stream cannot be reproduced.
 """
 import math
 
@@ -37,29 +38,33 @@ MOBILENET_V2_TAPS = {"bottleneck_1_1": "C1", "bottleneck_2_2": "C2", "bottleneck
                      "bottleneck_5_3": "C4"}
 
 
-def _cna(p, prefix, x, act, stride=1, depthwise=False):
-    """conv -> GroupNorm -> activation (one reference Sequential([...]) block)."""
+def _cna(p, prefix, x, act, stride=1, depthwise=False, dropout=None):
+    """conv -> GroupNorm -> activation [-> Dropout] (one reference Sequential([...]) block); the Dropout of the
+    MobileNetV2 blocks is the hook's site ``prefix + ".dropout"``."""
     w = p[prefix + ".conv.weight"]
     x = T.depthwise_conv2d_same(x, w, stride) if depthwise else T.conv2d_same(x, w, stride)
     x = T.group_norm(x, p[prefix + ".norm.gamma"], p[prefix + ".norm.beta"])
-    return T.activation(x, act)
+    x = T.activation(x, act)
+    return dropout(prefix + ".dropout", x) if dropout is not None else x
 
 
 # --------------------------------------------------------------------------- MobileNetV2
-def mobilenet_v2_forward(p, x, act="elu", prefix="backbone"):
+def mobilenet_v2_forward(p, x, act="elu", prefix="backbone", dropout=None):
+    """mobilenet_v2.py:187-223; every block ends with tf.layers.Dropout (:62 expand, :71 depthwise, :79 linear, :117
+    input conv, :184 output conv)."""
     out = {}
-    x = _cna(p, prefix + ".input_conv", x, act, stride=2)
+    x = _cna(p, prefix + ".input_conv", x, act, stride=2, dropout=dropout)
     for name, _filters, _t, stride in MOBILENET_V2_BLOCKS:
         b = "%s.%s" % (prefix, name)
         identity = x
-        x = _cna(p, b + ".expand_conv", x, act)
-        x = _cna(p, b + ".depthwise_conv", x, act, stride=stride, depthwise=True)
-        x = _cna(p, b + ".linear_conv", x, None)
+        x = _cna(p, b + ".expand_conv", x, act, dropout=dropout)
+        x = _cna(p, b + ".depthwise_conv", x, act, stride=stride, depthwise=True, dropout=dropout)
+        x = _cna(p, b + ".linear_conv", x, None, dropout=dropout)
         if x.shape == identity.shape:            # mobilenet_v2.py:91-92
             x = x + identity
         if name in MOBILENET_V2_TAPS:
             out[MOBILENET_V2_TAPS[name]] = x
-    x = _cna(p, prefix + ".output_conv", x, act)
+    x = _cna(p, prefix + ".output_conv", x, act, dropout=dropout)
     out["C5"] = x
     return out
 
@@ -168,11 +173,12 @@ def init_params(backbone="mobilenet_v2", num_classes=80, num_anchors=9, seed=0):
     return params
 
 
-def retinanet_forward(p, image, num_classes, num_anchors=9, act="elu", backbone="mobilenet_v2"):
-    """RetinaNetBase.call retinanet.py:272-296: same subnet weights for all 5 levels."""
+def retinanet_forward(p, image, num_classes, num_anchors=9, act="elu", backbone="mobilenet_v2", dropout=None):
+    """RetinaNetBase.call retinanet.py:272-296: same subnet weights for all 5 levels.  `dropout`: the backbone's dropout
+    hook (retinanet.py:12-21 hands dropout_rate to the backbone only: FPN and subnets have no dropout)."""
     if backbone != "mobilenet_v2":
         raise NotImplementedError(backbone)
-    feats = mobilenet_v2_forward(p, image, act)
+    feats = mobilenet_v2_forward(p, image, act, dropout=dropout)
     pyr = fpn_forward(p, feats, act)
     cls = {k: subnet_forward(p, v, "classification_subnet", num_anchors, num_classes, act)
            for k, v in pyr.items()}

@@ -22,10 +22,11 @@ def compact(per_level, masks):
 
 
 def total_loss(params, image, labels, num_classes, loss_mode="bce_dice", act="elu",
-               backbone="mobilenet_v2"):
+               backbone="mobilenet_v2", dropout=None):
     """labels: dict(classifications, regressions, trainable_masks) of dicts P3..P7 with a
-    leading batch axis.  Returns (total, class_loss, regr_loss, reg_loss)."""
-    out = model_ref.retinanet_forward(params, image, num_classes, act=act, backbone=backbone)
+    leading batch axis.  Returns (total, class_loss, regr_loss, reg_loss).  `dropout`: optional hook with the masks of
+    this step (oracle/dropout_ref.Sites); None = dropout_rate 0."""
+    out = model_ref.retinanet_forward(params, image, num_classes, act=act, backbone=backbone, dropout=dropout)
     masks = {k: labels["trainable_masks"][k].bool() for k in LEVELS}
     cls_loss, regr_loss = losses_ref.loss(
         compact(labels["classifications"], masks), compact(labels["regressions"], masks),
@@ -74,7 +75,7 @@ def apply_optimizer(kind, params, grads, state, lr, step):
 
 
 def train_step(params, image, labels, num_classes, state, lr=1e-2, optimizer="momentum",
-               step=1, loss_mode="bce_dice", grad_clip_norm=None, replicas=None):
+               step=1, loss_mode="bce_dice", grad_clip_norm=None, replicas=None, dropout=None):
     """One optimizer step.  `replicas`: optional list of (image, labels) per replica; the
     gradient is then the mean over replicas (MirroredStrategy).  Returns the
     loss tuple of the first replica and the dict of applied gradients."""
@@ -82,7 +83,7 @@ def train_step(params, image, labels, num_classes, state, lr=1e-2, optimizer="mo
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
     sums, first = None, None
     for img, lab in batches:
-        losses = total_loss(leaves, img, lab, num_classes, loss_mode)
+        losses = total_loss(leaves, img, lab, num_classes, loss_mode, dropout=dropout)
         gs = torch.autograd.grad(losses[0], list(leaves.values()))
         sums = list(gs) if sums is None else [a + b for a, b in zip(sums, gs)]
         if first is None:

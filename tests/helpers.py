@@ -79,3 +79,22 @@ def coco_like_objects(rng, image_size, max_obj=32):
     boxes = np.stack([y1, x1, np.minimum(y2, 1.0), np.minimum(x2, 1.0)], 1).astype(np.float32)
     cls = rng.integers(0, 80, o).astype(np.int32)
     return boxes, cls
+
+
+def dropout_sites(net, rate, counter=0):
+    """The oracle's dropout hook (oracle/dropout_ref.Sites) carrying the seeds of the PRODUCT's Dropout layers: site name =
+    the layer's module path without the leading ``base.``; for the [conv, Normalization, act, Dropout] blocks of MobileNetV2
+    the trailing ``._mods.<i>`` becomes ``.dropout`` (oracle/model_ref._cna), DenseNet's composite functions / transition
+    layers keep their ``._mods.<i>`` (oracle/backbones_ref.densenet_forward)."""
+    import layers
+    from oracle import dropout_ref
+    seeds = {}
+    for name, m in net.named_modules():
+        if isinstance(m, layers.Dropout):
+            name = re.sub(r"^base\.", "", name)
+            if "._fns." not in name and "transition_layer" not in name:
+                name = re.sub(r"\._mods\.\d+$", ".dropout", name)
+            if not name.startswith("backbone"):
+                name = "backbone." + name if name else name
+            seeds[name] = m.seed
+    return dropout_ref.Sites(seeds, rate, counter)

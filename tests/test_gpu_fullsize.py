@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close, coco_like_objects, load_oracle_params, to_oracle_name
+from helpers import assert_close, coco_like_objects, dropout_sites, load_oracle_params, to_oracle_name
 from oracle import backbones_ref, dataset_ref, model_ref, train_ref, utils_ref
 
 pytestmark = pytest.mark.gpu
@@ -22,10 +22,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-def test_cfg2_full_size_train_step_matches_oracle(dev):
-    """BASELINE configs[1] as stated: 512x512, batch [image, hflip], 80 classes, focal + smooth-L1, dropout 0 (the
-    oracle has no RNG stream to share), momentum step.  Assignment maps bit-exact; both losses <= 1e-4 relative;
-    gradients / updated weights of every parameter tensor <= 5e-4 of max(|tensor|, 1e-3 x the largest gradient)."""
+@pytest.mark.parametrize("rate", [0.0, 0.2])
+def test_cfg2_full_size_train_step_matches_oracle(dev, rate):
+    """BASELINE configs[1] as stated: 512x512, batch [image, hflip], 80 classes, focal + smooth-L1, momentum step, at
+    dropout 0 and at the dropout 0.2 the benchmark trains with (reference train.py:91): the oracle is handed the masks the
+    product's kernels draw (oracle/dropout_ref.py, SURVEY K9 "injected masks"; bit-for-bit mask checks:
+    tests/test_gpu_dropout.py) at the reference's 53 dropout sites (mobilenet_v2.py:62,71,79,117,184).  Assignment maps
+    bit-exact; both losses <= 1e-4 relative; gradients of every parameter tensor <= 5e-4 of max(|tensor|, 1e-3 x the largest
+    gradient); updated weights <= 1e-5."""
     import dataset, layers, levels as levels_mod, retinanet, train
     size, classes = 512, 80
     rng = np.random.default_rng(42)
@@ -37,8 +41,9 @@ def test_cfg2_full_size_train_step_matches_oracle(dev):
         elif k.endswith(".beta"):
             params[k] = 0.1 * torch.randn(params[k].shape, generator=g)
     lv = levels_mod.build_levels()
-    net = retinanet.RetinaNet('mobilenet_v2', lv, classes, layers.elu, 0.0).to(dev)
+    net = retinanet.RetinaNet('mobilenet_v2', lv, classes, layers.elu, rate).to(dev)
     load_oracle_params(net, params)
+    hook = dropout_sites(net, rate) if rate else None           # (step counter 0: the trainer's first step)
     img = rng.standard_normal((1, size, size, 3)).astype(np.float32)
     image = torch.from_numpy(np.concatenate([img, img[:, :, ::-1]], 0).copy())
     boxes, cls = coco_like_objects(rng, size)
@@ -64,7 +69,8 @@ def test_cfg2_full_size_train_step_matches_oracle(dev):
     cl, rl = trainer.forward_backward(feats)
     grads_hip = {to_oracle_name(n): p.grad.detach().cpu().numpy().copy() for n, p in net.named_parameters()}
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-    tot, ocl, orl, oreg = train_ref.total_loss(leaves, image, labels, classes, "focal")
+    tot, ocl, orl, oreg = train_ref.total_loss(leaves, image, labels, classes, "focal", dropout=hook)
+    assert hook is None or (sorted(hook.seen) == sorted(hook.seeds) and len(hook.seeds) == 53)
     grads = dict(zip(leaves.keys(), torch.autograd.grad(ocl + orl, list(leaves.values()))))
     assert_close(cl.item(), ocl.item(), 1e-4, "class loss (focal)")
     assert_close(rl.item(), orl.item(), 1e-4, "regression loss (smooth-L1)")
@@ -76,12 +82,12 @@ def test_cfg2_full_size_train_step_matches_oracle(dev):
         if err > worst[1]:
             worst = (name, err)
         assert err <= 5e-4, "grad %s: relative error %.3e" % (name, err)
-    print("cfg2 full size: class loss %.6f (oracle %.6f), regr loss %.6f (oracle %.6f), worst gradient error %.2e (%s)"
-          % (cl.item(), ocl.item(), rl.item(), orl.item(), worst[1], worst[0]))
+    print("cfg2 full size, dropout %.1f: class loss %.6f (oracle %.6f), regr loss %.6f (oracle %.6f), worst gradient error %.2e (%s)"
+          % (rate, cl.item(), ocl.item(), rl.item(), orl.item(), worst[1], worst[0]))
     # the optimizer step on top (L2 regulariser folded into the update)
     trainer.opt.step(1.0)
     state = {}
-    train_ref.train_step(params, image, labels, classes, state, lr=1e-2, optimizer="momentum", step=1, loss_mode="focal")
+    train_ref.train_step(params, image, labels, classes, state, lr=1e-2, optimizer="momentum", step=1, loss_mode="focal", dropout=hook)
     for name, p in net.named_parameters():
         assert_close(p.detach().cpu().numpy(), params[to_oracle_name(name)].numpy(), 1e-5, "weights after the step: " + name)
 

@@ -162,3 +162,30 @@ def test_oracle_e2e_fixture_is_stable(golden_dir):
     for k, s in zip(("P3", "P4", "P5", "P6", "P7"), sizes):
         assert out["classifications"][k].shape == (2, s, s, 9, 3)
         assert out["regressions"][k].shape == (2, s, s, 9, 4)
+
+
+def test_dropout_mask_restatement_vector_equals_scalar_and_sites_cover_the_reference():
+    """oracle/dropout_ref.py: the vectorised numpy form of the mask function == the plain-integer form element by element
+    (small / 64-bit seeds, indices beyond 2^32); keep fraction and tf.nn.dropout scaling; and the hook visits exactly the
+    reference's dropout sites (mobilenet_v2.py:62,71,79,117,184: stem + 17 x 3 + output conv = 53)."""
+    import torch
+    from oracle import dropout_ref, model_ref
+    idx = np.array([0, 1, 2, 3, 1000, 2 ** 31 + 5, 2 ** 32 - 1, 2 ** 32 + 7, 2 ** 40 + 3], dtype=np.uint64)
+    for seed in (0, 0x5EED + 0x9E3779B1, (1 << 40) + 12345, 0x632BE59BD9B4E019, 2 ** 64 - 1):
+        v = dropout_ref.uniform01(seed, idx)
+        w = np.array([dropout_ref.uniform01_scalar(seed, int(i)) for i in idx], dtype=np.float32)
+        assert np.array_equal(v, w) and (v >= 0).all() and (v < 1).all()
+    keep = dropout_ref.keep_mask(123, (4, 32, 32, 24), 0.2)
+    assert abs(keep.mean() - 0.8) < 0.01
+    assert not np.array_equal(keep, dropout_ref.keep_mask(124, (4, 32, 32, 24), 0.2))
+    x = torch.full((4, 32, 32, 24), 2.0)
+    y = dropout_ref.apply(x, keep, 0.2)
+    assert set(np.unique(y.numpy()).tolist()) == {0.0, float(np.float32(2.0) / (np.float32(1) - np.float32(0.2)))}
+    seen = []
+
+    def hook(site, t):
+        seen.append(site)
+        return t
+    p = model_ref.init_params("mobilenet_v2", num_classes=3)
+    model_ref.retinanet_forward(p, torch.zeros(1, 64, 64, 3), 3, dropout=hook)
+    assert len(seen) == 53 and len(set(seen)) == 53 and all(s.startswith("backbone.") and s.endswith(".dropout") for s in seen)
