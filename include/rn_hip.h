@@ -48,7 +48,7 @@ typedef struct rn_reduce_list rn_reduce_list;
 
 /* Version of this header's ABI: bumped whenever an entry point's arguments or a struct layout change.  rn_version() returns
  * the value the library was built with; a caller built against another value must not call anything else. */
-#define RN_API_VERSION 401
+#define RN_API_VERSION 402
 int rn_version(void);
 const char* rn_last_error(void);
 
@@ -552,6 +552,36 @@ int rn_mb_depthwise_fwd(const rn_mb_norm* in, const float* w, float* y, int n, i
                         int stat_groups, rn_stream_t stream);
 /* out = dropout(act(GN(in->y))) [+ residual]: writes a normalised tensor out (the end of a chain; tests) */
 int rn_mb_apply(const rn_mb_norm* in, const float* residual, float* out, int n, int hw, rn_stream_t stream);
+
+/* ---- XCD-resident small-map section (csrc/mb_resident.hip): the same forward kernels as PHASES of one launch.
+ * For the part of the chain whose per-sample working set fits one XCD's 4 MB L2 (maps of <= 32 x 32 pixels at the BASELINE sizes:
+ * bottleneck_4_1's depthwise conv ... bottleneck_7_1 and the output conv of mobilenet_v2.py:120-223, ~33 dependent launches).
+ * Grid = 8 x B blocks; the blocks with equal blockIdx.x % 8 sit on one XCD (checked at run time) and work on sample
+ * blockIdx.x % 8 (+ 8 ...); between phases they meet at a same-XCD counter barrier (no cache write-back, no cross-XCD fence).
+ * A phase = one rn_mb_pointwise_fwd (with `in`; ELU or no activation) or one rn_mb_depthwise_fwd (ELU) call, same meaning of
+ * every field.  Statistic rows of resident phases have their OWN layouts (rn_mb_resident_rows): the tiling follows the cluster.
+ * Caller's obligations: every buffer written by a phase is written by that phase only and read only by LATER phases of the
+ * call; `sync` = rn_mb_resident_sync_bytes() zero-initialised device bytes, private to the stream, written by these launches
+ * only.  Word 512 of `sync` is the error word: bit 0 = a barrier wait timed out (a block of the cluster never arrived; the
+ * outputs of that call are invalid and the caller must zero `sync` before the next use), bit 1 = a cluster's blocks were seen
+ * on two XCDs (placement is not as assumed: results may be stale; stop using the resident path on this device).
+ * RN_EUNSUPPORTED: a phase cannot run resident (shape, activation) or the cluster does not fit an XCD -- nothing was launched,
+ * use the launch-ordered entry points. */
+enum { RN_MB_PHASE_POINTWISE = 0, RN_MB_PHASE_DEPTHWISE = 1 };
+typedef struct rn_mb_phase {
+  int32_t kind;
+  const rn_mb_norm* in;        /* the GroupNorm block this phase consumes while loading (rows from the previous phase / kernel) */
+  const float* residual;       /* pointwise after a linear block: + residual (or NULL) */
+  float* materialise;          /* pointwise: the formed operand written out once (or NULL) */
+  const float* w; float* y;    /* pointwise: w [cin, cout], y [n, h wd, cout]; depthwise: w [3, 3, c], y [n, oh, ow, c] */
+  int32_t h, wd, cin, cout, stride;   /* the INPUT map; depthwise: cin == cout, stride 1 / 2; pointwise: stride ignored */
+  rn_mb_rows stat_out;         /* y's rows (layout: rn_mb_resident_rows); stat_out.rows == NULL: none */
+  int32_t stat_groups;
+} rn_mb_phase;
+size_t rn_mb_resident_sync_bytes(void);
+/* layout + bytes of the rows a resident phase of this shape emits for a GroupNorm of `groups` groups; 0: cannot run resident */
+size_t rn_mb_resident_rows(int kind, int n, int h, int wd, int cin, int cout, int stride, int groups, rn_mb_rows* layout);
+int rn_mb_resident_fwd(const rn_mb_phase* phases, int nphase, int n, void* sync, rn_stream_t stream);
 
 /* the gradient of a conv output y, as a backward kernel loads it */
 typedef struct rn_mb_dy {

@@ -19,7 +19,7 @@ LOSS_MODE = {"bce_dice": 0, "focal": 1}
 OPT = {"momentum": 0, "rmsprop": 1, "adam": 2}
 OPT_BLOCK = 1024
 LOSS_STATS_HEADER = 8
-API_VERSION = 401        # RN_API_VERSION of include/rn_hip.h these bindings were written against
+API_VERSION = 402        # RN_API_VERSION of include/rn_hip.h these bindings were written against
 
 
 class RnError(RuntimeError):
@@ -117,6 +117,16 @@ class MbNorm(C.Structure):
                 ("drop_rate", C.c_float), ("drop_seed", C.c_uint64), ("drop_seed_dev", C.c_void_p)]
 
 
+class MbPhase(C.Structure):
+    """rn_mb_phase: one phase of the XCD-resident section (rn_mb_resident_fwd)"""
+    _fields_ = [("kind", C.c_int32), ("in_", C.POINTER(MbNorm)), ("residual", C.c_void_p), ("materialise", C.c_void_p),
+                ("w", C.c_void_p), ("y", C.c_void_p), ("h", C.c_int32), ("wd", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("stride", C.c_int32), ("stat_out", MbRows), ("stat_groups", C.c_int32)]
+
+
+MB_PHASE_POINTWISE, MB_PHASE_DEPTHWISE = 0, 1
+
+
 class MbDy(C.Structure):
     """rn_mb_dy"""
     _fields_ = [("dy", C.c_void_p), ("norm", C.POINTER(MbNorm)), ("g", C.c_void_p), ("g_plain", C.c_int32), ("grows", MbRows)]
@@ -168,6 +178,7 @@ SYMBOLS = [
     "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
     "rn_optimizer_workspace", "rn_grad_norm_l2reg", "rn_optimizer_step", "rn_counter_add", "rn_add_segs",
     "rn_mb_rows_max", "rn_mb_compact_rows_layout", "rn_mb_compact_rows", "rn_mb_pointwise_rows", "rn_mb_pointwise_fwd", "rn_mb_depthwise_rows", "rn_mb_depthwise_fwd", "rn_mb_apply",
+    "rn_mb_resident_sync_bytes", "rn_mb_resident_rows", "rn_mb_resident_fwd",
     "rn_mb_pointwise_bwd_rows", "rn_mb_pointwise_bwd_workspace", "rn_mb_pointwise_bwd",
     "rn_mb_depthwise_bwd_rows", "rn_mb_depthwise_bwd_workspace", "rn_mb_depthwise_bwd",
     "rn_debug_collective_standin", "rn_optimizer_norm_pairs", "rn_optimizer_step_norm", "rn_norm_reg_finalize",
@@ -309,6 +320,10 @@ def lib():
         for name in ("rn_mb_pointwise_rows", "rn_mb_depthwise_rows", "rn_mb_pointwise_bwd_rows", "rn_mb_pointwise_bwd_workspace",
                      "rn_mb_depthwise_bwd_rows", "rn_mb_depthwise_bwd_workspace"):
             getattr(L, name).restype = C.c_size_t
+        L.rn_mb_resident_sync_bytes.restype = C.c_size_t
+        L.rn_mb_resident_rows.restype = C.c_size_t
+        L.rn_mb_resident_rows.argtypes = [C.c_int] * 8 + [C.c_void_p]
+        L.rn_mb_resident_fwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.rn_mb_compact_rows_layout.restype = C.c_size_t
         L.rn_mb_compact_rows_layout.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.rn_mb_compact_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -403,15 +418,46 @@ def sync_counters(device):
     return t
 
 
+_resident_words = {}
+
+
+def resident_sync(device):
+    """The zeroed region (rn_mb_resident_sync_bytes()) per (device, main / side stream) for rn_mb_resident_fwd: the clusters'
+    barrier counters; word 512 is the error word (bit 0: a wait timed out, bit 1: a cluster was not on one XCD).  Same keying
+    as sync_counters: every stream that is not a registered side stream is 'the main stream'."""
+    h = stream().value or 0
+    key = (device.type, device.index, h if h in SIDE_STREAMS else 0)
+    t = _resident_words.get(key)
+    if t is None:
+        if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            raise RnError("the resident section's counters must exist before graph capture (run the step once eagerly)")
+        t = torch.zeros(lib().rn_mb_resident_sync_bytes() // 4, dtype=torch.int32, device=device)
+        _resident_words[key] = t
+    return t
+
+
+def resident_errors():
+    """OR of the resident sections' error words over all regions (0: fine; synchronises)."""
+    e = 0
+    for t in _resident_words.values():
+        e |= int(t[512].item())
+    return e
+
+
 def barrier_timeouts():
-    """Number of (device, stream) counter sets whose error word is set (should always be 0)."""
-    return sum(int(t[2].item()) for t in {id(t): t for t in _sync_words.values()}.values())
+    """Number of (device, stream) counter sets whose error word is set (should always be 0): the grid-resident GroupNorm's
+    exchange regions and the MobileNetV2 resident section's clusters."""
+    return (sum(int(t[2].item()) for t in {id(t): t for t in _sync_words.values()}.values()) +
+            sum(1 for t in _resident_words.values() if int(t[512].item()) != 0))
 
 
 def reset_barrier_timeouts():
-    """Clear the error words (after the caller has dealt with a reported timeout, e.g. by switching the path off)."""
+    """Clear the error words (after the caller has dealt with a reported timeout, e.g. by switching the path off); the
+    resident section's counters are zeroed entirely (a timed-out launch leaves them dirty)."""
     for t in {id(t): t for t in _sync_words.values()}.values():
         t[2] = 0
+    for t in _resident_words.values():
+        t.zero_()
 
 
 def side_stream(device, index=0):

@@ -1095,7 +1095,8 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
     a.st.rows = (float2*)sr.rows->rows; a.st.groups = groups; a.st.cpg = d.cout / groups;
   }
   static const int fpad_env = getenv("RN_PROD_LDS_PAD_FWD") ? atoi(getenv("RN_PROD_LDS_PAD_FWD")) : 0;
-  const int fpad = bt.n > 1 ? fpad_env : 0;      // (batched = the Winograd products; see RN_PROD_LDS_PAD_BWD)
+  static const int fpad_only_m = getenv("RN_PROD_LDS_PAD_FWD_ONLY_M") ? atoi(getenv("RN_PROD_LDS_PAD_FWD_ONLY_M")) : 0;   // (probe: only products of this many rows)
+  const int fpad = (bt.n > 1 && (!fpad_only_m || a.seg[0].m == fpad_only_m)) ? fpad_env : 0;      // (batched = the Winograd products; see RN_PROD_LDS_PAD_BWD)
 #define RN_FWD(BM_, BN_, WM_, WN_)                                                                   \
   do {                                                                                               \
     if (tapu) hipLaunchKernelGGL((conv_fwd_kernel<BM_, BN_, WM_, WN_, 4, true>), dim3(tiles), dim3(WM_* WN_ * 64), fpad, st, a); \

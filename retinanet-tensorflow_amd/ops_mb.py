@@ -40,6 +40,15 @@ def _rows(query, *args):
 
 
 COMPACT_ABOVE = int(os.environ.get('RN_MB_COMPACT_ABOVE', '256'))     # tuning aid: compact the rows of a sample when there are more
+# The small-map part of the chain as phases of ONE launch per <= 14 kernels (csrc/mb_resident.hip: per-sample clusters on one XCD,
+# same-XCD phase barriers).  It starts at the first kernel from which on every kernel's output map has <= RESIDENT_MAX_HW pixels
+# and reads <= RESIDENT_MAX_IN_BYTES per sample (the XCD's L2 is 4 MB).  OFF by default (RN_MB_RESIDENT=1 opts in): correct
+# and tested, but measured SLOWER at the headline shape -- 712 us for the 33 phases against ~420 us for the 33 launches it
+# replaces (428 vs 458 images/s): a batch of two samples keeps only 2 of the 8 XCDs busy, and a phase costs what a kernel cost
+# (tools/mb_resident_phases.py: ~5 us of prologue, 2 us per K-tile, 1.5 us of epilogue per tile), not the launch boundary.
+RESIDENT = os.environ.get('RN_MB_RESIDENT', '0') == '1'
+RESIDENT_MAX_HW = int(os.environ.get('RN_MB_RESIDENT_MAX_HW', '1024'))
+RESIDENT_MAX_IN_BYTES = int(os.environ.get('RN_MB_RESIDENT_MAX_IN_BYTES', str(3328 * 1024)))
 
 
 def _compact(rows, lay, n, dev):
@@ -78,6 +87,37 @@ def _mb_norm(st, training, seed_dev, with_rows):
     return m
 
 
+def _count_resident(nphases):
+    """(test hook: called with the number of phases whenever a forward pass takes the resident section)"""
+
+
+def _resident_start(n, h, w, c, blocks_cfg, shapes, tail_cout):
+    """Index of the first kernel (3 i + j for kernel j of bottleneck i, 3 nb for the tail conv) of the resident section, or
+    None.  `shapes`: per bottleneck (wide, cout).  Every kernel from the index on must qualify (maps only shrink along the chain)."""
+    if not RESIDENT:
+        return None
+    L = _rn.lib()
+    ok = []
+    for (stride, _res, n1, n2, n3), (wide, cout) in zip(blocks_cfg, shapes):
+        oh, _ = _rn.same_pad(h, 3, stride)
+        ow, _ = _rn.same_pad(w, 3, stride)
+        g1, g3 = ops.gn_groups(wide, n1.groups_arg), ops.gn_groups(cout, n3.groups_arg)
+        acts = (n1.act in ('elu',), n2.act in ('elu',), n3.act is None)
+        ok.append(h * w <= RESIDENT_MAX_HW and h * w * c * 4 <= RESIDENT_MAX_IN_BYTES and acts[2] and
+                  bool(L.rn_mb_resident_rows(_rn.MB_PHASE_POINTWISE, n, h, w, c, wide, 1, g1, None)))
+        ok.append(oh * ow <= RESIDENT_MAX_HW and h * w * wide * 4 <= RESIDENT_MAX_IN_BYTES and acts[0] and
+                  bool(L.rn_mb_resident_rows(_rn.MB_PHASE_DEPTHWISE, n, h, w, wide, wide, stride, g1, None)))
+        ok.append(oh * ow <= RESIDENT_MAX_HW and oh * ow * wide * 4 <= RESIDENT_MAX_IN_BYTES and acts[1] and
+                  bool(L.rn_mb_resident_rows(_rn.MB_PHASE_POINTWISE, n, oh, ow, wide, cout, 1, g3, None)))
+        h, w, c = oh, ow, cout
+    ok.append(h * w <= RESIDENT_MAX_HW and h * w * c * 4 <= RESIDENT_MAX_IN_BYTES and h * w % 32 == 0 and c % 4 == 0 and tail_cout % 4 == 0)
+    ok[0] = False                   # the chain's first kernel reads a plain tensor: launch-ordered
+    start = len(ok)
+    while start > 0 and ok[start - 1]:
+        start -= 1
+    return start if start < len(ok) else None
+
+
 def chain_supported(shape, blocks):
     """Can the rn_mb_* kernels run `blocks` on an fp32 device tensor of `shape` [n,h,w,c]?  (Every row layout must exist.)"""
     L = _rn.lib()
@@ -112,10 +152,33 @@ class _MbChain(torch.autograd.Function):
         nb = len(blocks_cfg)
         st_ = _rn.stream()
 
-        def new_stage(y, query_args, query, groups, norm):
+        shapes = [(params[9 * i].shape[3], params[9 * i + 6].shape[3]) for i in range(nb)]
+        res_from = _resident_start(n, h, w, c, blocks_cfg, shapes, params[9 * nb].shape[3]) if x.is_cuda else None
+        phases, keep = [], []       # the resident section's phases (rn_mb_phase) and what they point to
+
+        def resident(k):
+            return res_from is not None and k >= res_from
+
+        def phase(kind, nm, res_t, mat_t, w_t, y_t, hh, ww, cin, cout, stride, s_out, groups):
+            ph = _rn.MbPhase()
+            ph.kind, ph.in_ = kind, C.pointer(nm)
+            ph.residual = _rn.f32(res_t) if res_t is not None else None
+            ph.materialise = _rn.f32(mat_t) if mat_t is not None else None
+            ph.w, ph.y = _rn.f32(w_t), _rn.f32(y_t)
+            ph.h, ph.wd, ph.cin, ph.cout, ph.stride = hh, ww, cin, cout, stride
+            if s_out is not None:
+                ph.stat_out = _rn.MbRows(s_out.rows.data_ptr(), s_out.lay.rows_per_sample, s_out.lay.width, s_out.lay.bn)
+                ph.stat_groups = groups
+            keep.append(nm)
+            phases.append(ph)
+
+        def new_stage(y, query_args, query, groups, norm, res_kind=None, res_args=None):
             s = _Stage()
             s.y, s.c, s.groups, s.norm, s.hw = y, y.shape[3], groups, norm, y.shape[1] * y.shape[2]
-            s.lay, nbytes = _rows(query, *query_args)
+            if res_kind is not None:        # a resident phase writes its rows in the cluster's tiling
+                s.lay, nbytes = _rows(L.rn_mb_resident_rows, res_kind, *res_args)
+            else:
+                s.lay, nbytes = _rows(query, *query_args)
             assert nbytes, "mb_chain: unsupported shape (chain_supported() says so)"
             s.rows = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
             s.mean = torch.empty((y.shape[0], groups), dtype=torch.float32, device=dev)
@@ -141,8 +204,15 @@ class _MbChain(torch.autograd.Function):
             ow, _ = _rn.same_pad(w, 3, stride)
             # expand 1x1: A = the chain input, or the previous bottleneck's output formed while loading (and written out once)
             y1 = torch.empty((n, h, w, wide), dtype=torch.float32, device=dev)
-            s1 = new_stage(y1, (n, h * w, c, wide, gr1), L.rn_mb_pointwise_rows, gr1, n1)
-            if pend is None:
+            r0, r1, r2 = resident(3 * i), resident(3 * i + 1), resident(3 * i + 2)
+            s1 = new_stage(y1, (n, h * w, c, wide, gr1), L.rn_mb_pointwise_rows, gr1, n1,
+                           _rn.MB_PHASE_POINTWISE if r0 else None, (n, h, w, c, wide, 1, gr1))
+            if r0:
+                x_in = torch.empty((n, h, w, c), dtype=torch.float32, device=dev)
+                phase(_rn.MB_PHASE_POINTWISE, _mb_norm(pend, training, seed_dev, True), pend_res, x_in, w1, y1, h, w, c, wide, 1, s1, gr1)
+                if (i - 1) in tap_after:
+                    taps.append(x_in)
+            elif pend is None:
                 _rn.check(L.rn_mb_pointwise_fwd(_rn.f32(x_in), None, None, None, _rn.f32(w1), _rn.f32(y1), n, h * w, c, wide, rows_arg(s1), gr1, st_),
                           "rn_mb_pointwise_fwd")
             else:
@@ -152,20 +222,29 @@ class _MbChain(torch.autograd.Function):
                                                 _rn.f32(w1), _rn.f32(y1), n, h * w, c, wide, rows_arg(s1), gr1, st_), "rn_mb_pointwise_fwd")
                 if (i - 1) in tap_after:
                     taps.append(x_in)
-            s1.rows, s1.lay = _compact(s1.rows, s1.lay, n, dev)
+            if not r0:
+                s1.rows, s1.lay = _compact(s1.rows, s1.lay, n, dev)
             # depthwise 3x3 on drop(act(GN1(y1)))
             y2 = torch.empty((n, oh, ow, wide), dtype=torch.float32, device=dev)
-            s2 = new_stage(y2, (n, h, w, wide, stride, gr1), L.rn_mb_depthwise_rows, gr1, n2)
+            s2 = new_stage(y2, (n, h, w, wide, stride, gr1), L.rn_mb_depthwise_rows, gr1, n2,
+                           _rn.MB_PHASE_DEPTHWISE if r1 else None, (n, h, w, wide, wide, stride, gr1))
             nm = _mb_norm(s1, training, seed_dev, True)
-            _rn.check(L.rn_mb_depthwise_fwd(C.byref(nm), _rn.f32(wd), _rn.f32(y2), n, h, w, stride, rows_arg(s2), gr1, st_), "rn_mb_depthwise_fwd")
-            s2.rows, s2.lay = _compact(s2.rows, s2.lay, n, dev)
+            if r1:
+                phase(_rn.MB_PHASE_DEPTHWISE, nm, None, None, wd, y2, h, w, wide, wide, stride, s2, gr1)
+            else:
+                _rn.check(L.rn_mb_depthwise_fwd(C.byref(nm), _rn.f32(wd), _rn.f32(y2), n, h, w, stride, rows_arg(s2), gr1, st_), "rn_mb_depthwise_fwd")
+                s2.rows, s2.lay = _compact(s2.rows, s2.lay, n, dev)
             # linear 1x1 on drop(act(GN2(y2)))
             y3 = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=dev)
-            s3 = new_stage(y3, (n, oh * ow, wide, cout, gr3), L.rn_mb_pointwise_rows, gr3, n3)
+            s3 = new_stage(y3, (n, oh * ow, wide, cout, gr3), L.rn_mb_pointwise_rows, gr3, n3,
+                           _rn.MB_PHASE_POINTWISE if r2 else None, (n, oh, ow, wide, cout, 1, gr3))
             nm = _mb_norm(s2, training, seed_dev, True)
-            _rn.check(L.rn_mb_pointwise_fwd(None, C.byref(nm), None, None, _rn.f32(w3), _rn.f32(y3), n, oh * ow, wide, cout, rows_arg(s3), gr3, st_),
-                      "rn_mb_pointwise_fwd")
-            s3.rows, s3.lay = _compact(s3.rows, s3.lay, n, dev)
+            if r2:
+                phase(_rn.MB_PHASE_POINTWISE, nm, None, None, w3, y3, oh, ow, wide, cout, 1, s3, gr3)
+            else:
+                _rn.check(L.rn_mb_pointwise_fwd(None, C.byref(nm), None, None, _rn.f32(w3), _rn.f32(y3), n, oh * ow, wide, cout, rows_arg(s3), gr3, st_),
+                          "rn_mb_pointwise_fwd")
+                s3.rows, s3.lay = _compact(s3.rows, s3.lay, n, dev)
             saved.append((x_in, s1, s2, s3))
             pend, pend_res = s3, (x_in if residual else None)
             h, w, c = oh, ow, cout
@@ -177,8 +256,16 @@ class _MbChain(torch.autograd.Function):
         y_t = torch.empty((n, h, w, ct), dtype=torch.float32, device=dev)
         nm = _mb_norm(pend, training, seed_dev, True)
         # the tail's rows go out in the layer-by-layer GroupNorm's layout: a stand-alone apply follows (ops.group_norm_act)
-        _rn.check(L.rn_mb_pointwise_fwd(None, C.byref(nm), _rn.f32(pend_res) if pend_res is not None else None, _rn.f32(x_last), _rn.f32(tail_w),
-                                        _rn.f32(y_t), n, h * w, c, ct, None, 0, st_), "rn_mb_pointwise_fwd")
+        if resident(3 * nb):
+            phase(_rn.MB_PHASE_POINTWISE, nm, pend_res, x_last, tail_w, y_t, h, w, c, ct, 1, None, 0)
+        else:
+            assert not phases, "the resident section runs to the end of the chain"
+            _rn.check(L.rn_mb_pointwise_fwd(None, C.byref(nm), _rn.f32(pend_res) if pend_res is not None else None, _rn.f32(x_last), _rn.f32(tail_w),
+                                            _rn.f32(y_t), n, h * w, c, ct, None, 0, st_), "rn_mb_pointwise_fwd")
+        if phases:
+            _count_resident(len(phases))
+            arr = (_rn.MbPhase * len(phases))(*phases)
+            _rn.check(L.rn_mb_resident_fwd(arr, len(phases), n, _rn.resident_sync(dev).data_ptr(), st_), "rn_mb_resident_fwd")
         if (nb - 1) in tap_after:
             taps.append(x_last)
         ctx.cfg = cfg

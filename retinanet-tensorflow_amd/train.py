@@ -414,15 +414,16 @@ class Trainer(object):
         probe = int(os.environ.get("RN_PROBE_SIDE_PRODUCTS", "0"))   # tuning aid: N head-tower-sized batched products on a side
         side = None                                                   # stream beside the backbone's backward pass
         if probe and self.device.type == 'cuda':
+            pm = int(os.environ.get("RN_PROBE_M", "682"))
             if not hasattr(self, "_probe_buf"):
-                self._probe_buf = (torch.randn(36, 682, 256, device=self.device), torch.randn(36, 256, 256, device=self.device) * 0.01,
-                                   torch.empty(36, 682, 256, device=self.device))
+                self._probe_buf = (torch.randn(36, pm, 256, device=self.device), torch.randn(36, 256, 256, device=self.device) * 0.01,
+                                   torch.empty(36, pm, 256, device=self.device))
             A_, B_, C_ = self._probe_buf
             main, side = torch.cuda.current_stream(), _rn.side_stream(self.device, 6)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 for _ in range(probe):
-                    _rn.check(_rn.lib().rn_gemm_batched(_rn.f32(A_), _rn.f32(B_), _rn.f32(C_), 682, 256, 256, 36, 0, _rn.stream()), "rn_gemm_batched")
+                    _rn.check(_rn.lib().rn_gemm_batched(_rn.f32(A_), _rn.f32(B_), _rn.f32(C_), A_.shape[1], 256, 256, 36, 0, _rn.stream()), "rn_gemm_batched")
         for j in (range(len(self._parts)) if part is None else [part]):
             roots, seeds, rng = self._parts[j]
             with self._scoped():

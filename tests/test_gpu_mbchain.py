@@ -167,3 +167,37 @@ def test_chain_inference_mode(dev):
             bb.__dict__.pop('_chain_cache', None)
     for k in ("C3", "C4", "C5"):
         assert_close(a[k].cpu().numpy(), b[k].cpu().numpy(), 2e-5, "inference " + k)
+
+
+@pytest.mark.parametrize("size,batch,rate", [(512, 2, 0.2), (256, 2, 0.0), (512, 1, 0.2), (256, 3, 0.2)])
+def test_resident_section_equals_launch_ordered_kernels(dev, size, batch, rate, monkeypatch):
+    """The small-map part of the chain as phases of one launch per <= 14 kernels (csrc/mb_resident.hip: per-sample clusters on
+    one XCD, same-XCD phase barriers) == the launch-ordered kernels: C3 / C4 / C5 to 2e-5 (same arithmetic per element; the
+    statistic rows are summed in the cluster's tiling), every gradient to 2e-4 (the backward kernels are the same on both
+    sides and read the mean / rstd the forward pass published), run-to-run bit-identical, error word clean."""
+    import _rn, ops_mb
+    bb, _ = _backbone(dev, rate, seed=11)
+    rng = np.random.default_rng(size + batch)
+    x = torch.from_numpy(rng.standard_normal((batch, size, size, 3)).astype(np.float32)).to(dev)
+    shapes = {"C3": (batch, size // 8, size // 8, 32), "C4": (batch, size // 16, size // 16, 96), "C5": (batch, size // 32, size // 32, 32)}
+    cot = {k: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev) for k, s in shapes.items()}
+    calls = []
+    monkeypatch.setattr(ops_mb, "RESIDENT", True)          # (opt-in: measured slower than the launch-ordered kernels, DESIGN section 9)
+    monkeypatch.setattr(ops_mb, "_count_resident", calls.append, raising=False)
+    out_r, g_r, dx_r = _run(bb, x, cot)
+    assert calls and calls[0] >= 20, "the resident section must run here (phases: %s)" % calls
+    out_r2, _, _ = _run(bb, x, cot)
+    torch.cuda.synchronize()
+    assert _rn.resident_errors() == 0
+    for k in shapes:
+        assert torch.equal(out_r[k], out_r2[k]), "run-to-run " + k
+    monkeypatch.setattr(ops_mb, "RESIDENT", False)
+    out_l, g_l, dx_l = _run(bb, x, cot)
+    for k in shapes:
+        assert_close(out_r[k].cpu().numpy(), out_l[k].cpu().numpy(), 2e-5, "resident vs launch-ordered " + k)
+    scale = max(float(v.abs().max()) for v in g_l.values())
+    for name in g_l:
+        r = g_l[name].cpu().numpy()
+        err = float(np.abs(g_r[name].cpu().numpy() - r).max()) / max(float(np.abs(r).max()), 1e-3 * scale)
+        assert err <= 2e-4, "gradient %s: %.2e" % (name, err)
+    assert_close(dx_r.cpu().numpy(), dx_l.cpu().numpy(), 2e-4, "image gradient")
