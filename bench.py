@@ -739,6 +739,14 @@ def main():
                      "slices": allreduce_slices(step.trainer)}
 
     result = None
+    # the gradient slices in the order the trainer reduces them: heads + FPN after segment A, then one per part of the backbone's
+    # backward pass (MobileNetV2 has two parts while a collective is active: cut behind the C3 tap)
+    tr_ = step.trainer
+    if tr_.cut_offset:
+        parts = [tuple(r) for r in tr_._graphs[2]] if tr_._graphs else [(0, tr_.cut_offset)]
+        sched = [(tr_.cut_offset, tr_.arena.count)] + parts
+    else:
+        sched = [(0, tr_.arena.count)]
     if rank == 0:
         ips = world * BATCH * args.steps / elapsed
         result = {
@@ -750,14 +758,16 @@ def main():
                                    "%s + smooth-L1, dropout %.2f, momentum SGD, anchor assignment in the step" %
                                    (args.loss, args.dropout),
                        "global_batch": world * BATCH, "image_size": IMAGE_SIZE, "parallelism": "dp%d" % world,
-                       "hip_graph": not args.no_graph, "backward_segments": 2 if step.trainer.cut_offset else 1,
+                       "hip_graph": not args.no_graph, "backward_segments": len(sched),
                        "parity": "this step at this dropout rate is oracle-checked with the kernels' counter-based masks injected at the "
                                  "reference's dropout sites (tests/test_gpu_fullsize.py::test_cfg2_full_size_train_step_matches_oracle[0.2], "
                                  "tests/test_gpu_dropout.py)",
                        "allreduce": {"backend": "rccl" if dist is not None else None, "ranks": world,
                                      "collectives_issued": bool(step.trainer.allreduce.active),
-                                     "bytes_overlapped_with_backbone_backward": 4 * (step.trainer.arena.count - step.trainer.cut_offset),
-                                     "bytes_after_backward": 4 * step.trainer.cut_offset,
+                                     # the slices in the order they are reduced; only the LAST one is reduced after the last backward kernel
+                                     "slice_schedule_bytes": [4 * (hi - lo) for lo, hi in sched],
+                                     "bytes_overlapped_with_backbone_backward": sum(4 * (hi - lo) for lo, hi in sched[:-1]),
+                                     "bytes_after_backward": 4 * (sched[-1][1] - sched[-1][0]),
                                      "allreduce_exposed_ms": round(exposed, 4)},
                        "final_class_loss": round(losses[0], 6),
                        "final_regr_loss": round(losses[1], 6),

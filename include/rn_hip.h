@@ -75,6 +75,9 @@ typedef struct rn_conv_seg {
                         [x_coff, x_coff+cin) of a buffer with x_ld channels per pixel (x, dx point at the
                         buffer's first element): lets two convs consume / fill halves of one tensor      */
   int32_t x_coff;
+  int64_t wgt_bytes; /* fp16 convs (rn_conv2d_fwd_f16*): bytes of the packed-kernel buffer `wgt` points at.  The fragment-ordered
+                        copy behind Wt is read only when this proves it is there (>= rn_pack_weights_f16_bytes); 0 = unknown:
+                        a Wt-only buffer is assumed.  Ignored by the fp32 entry points. */
 } rn_conv_seg;
 
 typedef struct rn_conv_geom {
@@ -208,6 +211,15 @@ int rn_conv3x3_winograd_wgrad(const rn_conv_seg* segs, int nseg, int cin, int co
 size_t rn_conv3x3_winograd_bwd_workspace(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile, int have_v, int have_urot);
 int rn_conv3x3_winograd_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, float* dw, int accumulate, int tile,
                             void* workspace, size_t workspace_bytes, const float* v_buf, const float* urot_buf, rn_stream_t stream);
+
+/* How the batched fp32 products of the Winograd convolutions are evaluated (process-wide; default 0, or the environment's
+ * RN_PROD_X3 at first use):
+ *   0  the exact fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32): a k-ordered fmaf chain
+ *   1  every fp32 operand split exactly into three bf16 values, six bf16 matrix-core products with fp32 accumulation
+ *      (csrc/gemm_x3.hip): relative error <= ~2^-23 per elementary product, 2.7 x less matrix-core time.  Storage stays fp32.
+ * Shapes the split kernels do not take (K or N not a multiple of 4, matrices >= 2 GiB) use mode 0 regardless. */
+int rn_set_product_mode(int mode);
+int rn_get_product_mode(void);
 
 /* ------------------------------------------------------------------ fp16 inference convolution
  * BASELINE configs[4] ("Inference-only ResNeXt-50-FPN 1024x1024 bs=16, fp16"): forward conv on the f16

@@ -30,7 +30,7 @@ class ConvSeg(C.Structure):
     _fields_ = [("x", C.c_void_p), ("wgt", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p),
                 ("dy", C.c_void_p), ("dx", C.c_void_p),
                 ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cout", C.c_int32),
-                ("x_ld", C.c_int32), ("x_coff", C.c_int32)]
+                ("x_ld", C.c_int32), ("x_coff", C.c_int32), ("wgt_bytes", C.c_int64)]
 
 
 class AssignLevel(C.Structure):
@@ -178,7 +178,7 @@ SYMBOLS = [
     "rn_boxes_decode", "rn_nms_classwise_workspace", "rn_nms_classwise",
     "rn_optimizer_workspace", "rn_grad_norm_l2reg", "rn_optimizer_step", "rn_counter_add", "rn_add_segs",
     "rn_mb_rows_max", "rn_mb_compact_rows_layout", "rn_mb_compact_rows", "rn_mb_pointwise_rows", "rn_mb_pointwise_fwd", "rn_mb_depthwise_rows", "rn_mb_depthwise_fwd", "rn_mb_apply",
-    "rn_mb_resident_sync_bytes", "rn_mb_resident_rows", "rn_mb_resident_fwd",
+    "rn_mb_resident_sync_bytes", "rn_mb_resident_rows", "rn_mb_resident_fwd", "rn_set_product_mode", "rn_get_product_mode",
     "rn_mb_pointwise_bwd_rows", "rn_mb_pointwise_bwd_workspace", "rn_mb_pointwise_bwd",
     "rn_mb_depthwise_bwd_rows", "rn_mb_depthwise_bwd_workspace", "rn_mb_depthwise_bwd",
     "rn_debug_collective_standin", "rn_optimizer_norm_pairs", "rn_optimizer_step_norm", "rn_norm_reg_finalize",
@@ -409,6 +409,8 @@ def sync_counters(device):
     h = stream().value or 0
     capturing = torch.cuda.is_current_stream_capturing() if device.type == 'cuda' else False
     key = (device.type, device.index, h if h in SIDE_STREAMS else 0)
+    if key[2] == 0:
+        _hand_over(('gn',) + key, h, device)
     t = _sync_words.get(key)
     if t is None:
         if capturing:
@@ -419,6 +421,25 @@ def sync_counters(device):
 
 
 _resident_words = {}
+_region_owner = {}      # region key -> raw handle of the stream that used the shared "main stream" region last
+
+
+def _hand_over(key, h, device):
+    """The regions of key 0 are shared by every stream that is not a registered side stream, on the understanding that only one
+    of them runs these kernels at a time.  Enforced here instead of assumed: when a DIFFERENT stream asks for the region, it is
+    made to wait for everything the previous user has queued (an event recorded on that stream now), so two such streams --
+    say an evaluation stream beside the training stream -- serialise on the region instead of sharing barrier words.  Inside a
+    graph capture nothing can be recorded on an outside stream: the capture's owner (train.Trainer) orders it behind the warm-up
+    stream itself."""
+    last = _region_owner.get(key)
+    if last is not None and last != h and device.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
+        try:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.ExternalStream(last, device=device) if last else torch.cuda.default_stream(device))
+            torch.cuda.current_stream(device).wait_event(ev)
+        except RuntimeError:
+            pass                # (the previous stream no longer exists: nothing left to wait for)
+    _region_owner[key] = h
 
 
 def resident_sync(device):
@@ -427,6 +448,8 @@ def resident_sync(device):
     as sync_counters: every stream that is not a registered side stream is 'the main stream'."""
     h = stream().value or 0
     key = (device.type, device.index, h if h in SIDE_STREAMS else 0)
+    if key[2] == 0:
+        _hand_over(('mb',) + key, h, device)
     t = _resident_words.get(key)
     if t is None:
         if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():

@@ -668,8 +668,11 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
     SegH& d = a.seg[s];
     d.x = (const _Float16*)segs[s].x; d.wt = (const _Float16*)segs[s].wgt; d.bias = segs[s].bias; d.y = segs[s].y;
     {
+      // the fragment-ordered copy is used only when the caller's buffer size proves it exists (a Wt-only buffer of an older
+      // packing must not be read past its end)
       const int64_t kk = (int64_t)g->kh * g->kw * (g->cin / G), off = frag_offset_halfs(kk, segs[s].cout);
-      d.wf = off ? d.wt + off : nullptr;
+      const bool there = off && segs[s].wgt_bytes >= (int64_t)rn_pack_weights_f16_bytes(g->kh, g->kw, g->cin / G, segs[s].cout);
+      d.wf = there ? d.wt + off : nullptr;
     }
     d.n = segs[s].n; d.h = segs[s].h; d.w = segs[s].w; d.cout = segs[s].cout;
     rn::same_pad(d.h, g->kh, g->stride, &d.oh, &d.pad_t);
@@ -758,18 +761,19 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
                               (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
                               (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
                               (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
-    RN_UNSUPPORTED(!attr_, "conv f16: %zu bytes of LDS per block refused", lds);
-    bool frag = pipe_mode == 2;
-    for (int s = 0; s < nseg; ++s) frag = frag && a.seg[s].wf != nullptr;
-    if (frag) {
-      if (fbits == 2) hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 2>), dim3(tiles), dim3(512), lds, st, a);
-      else hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, 2>), dim3(tiles), dim3(512), lds, st, a);
-    } else {
-      if (fbits == 2) hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 1>), dim3(tiles), dim3(512), lds, st, a);
-      else hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, 1>), dim3(tiles), dim3(512), lds, st, a);
+    if (attr_) {           // (refused: the plain loop below computes the same bits from 36 KB of static LDS)
+      bool frag = pipe_mode == 2;
+      for (int s = 0; s < nseg; ++s) frag = frag && a.seg[s].wf != nullptr;
+      if (frag) {
+        if (fbits == 2) hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 2>), dim3(tiles), dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, 2>), dim3(tiles), dim3(512), lds, st, a);
+      } else {
+        if (fbits == 2) hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 1>), dim3(tiles), dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, 1>), dim3(tiles), dim3(512), lds, st, a);
+      }
+      RN_LAUNCH_CHECK();
+      return RN_OK;
     }
-    RN_LAUNCH_CHECK();
-    return RN_OK;
   }
   switch (c) {
     case 0: RN_F16(128, 128, 2, 2); break;

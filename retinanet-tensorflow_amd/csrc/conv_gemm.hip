@@ -982,6 +982,7 @@ extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_
 // b_nk == 0: B_b is [K x N] (forward kernel);  b_nk != 0: B_b is [N x K] (the data-gradient kernel's layout).
 int rn::launch_batched_gemm(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, int b_nk,
                             hipStream_t st) {
+  if (rn::product_mode() == 1 && rn::gemm_x3_ok(M, K, N)) return rn::launch_batched_gemm_x3(A, B, C, M, K, N, nbatch, b_nk, st);
   rn_conv_seg sg = {};
   sg.n = 1; sg.h = 1; sg.w = M; sg.wgt = B;
   rn_conv_geom g1 = {1, 1, 1, b_nk ? N : K, 1};
@@ -1320,10 +1321,14 @@ size_t rn::batched_gemm_tn_workspace(int M, int K, int N, int nbatch) {
   rn_conv_geom g1 = {1, 1, 1, K, 1};
   WgradPlan p;
   if (plan_wgrad(&sg, 1, &g1, &p, nbatch)) return 0;
-  return (size_t)p.nsplit * nbatch * K * N * sizeof(float);
+  const size_t f32 = (size_t)p.nsplit * nbatch * K * N * sizeof(float);
+  const size_t x3 = rn::gemm_x3_ok(M, K, N) ? rn::batched_gemm_tn_workspace_x3(M, K, N, nbatch) : 0;    // (either mode may run)
+  return f32 > x3 ? f32 : x3;
 }
 int rn::launch_batched_gemm_tn(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, void* workspace,
                                size_t workspace_bytes, hipStream_t st, int* nsplit_out) {
+  if (nsplit_out && !C && rn::product_mode() == 1 && rn::gemm_x3_ok(M, K, N))
+    return rn::launch_batched_gemm_tn_x3(A, B, M, K, N, nbatch, workspace, workspace_bytes, st, nsplit_out);
   rn_conv_seg sg = {};
   sg.n = 1; sg.h = 1; sg.w = M; sg.cout = N; sg.x = A; sg.dy = B;
   rn_conv_geom g1 = {1, 1, 1, K, 1};
@@ -1446,6 +1451,10 @@ extern "C" int rn_conv2d_bwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
 int rn::launch_winograd_bwd_products(const float* Ad, const float* Bd, float* Cd, int M, int Kd, int Nd, const float* Aw,
                                      const float* Bw, int Kw, int Nw, int nbatch, void* workspace, size_t workspace_bytes,
                                      hipStream_t st, int* nsplit_out) {
+  if (rn::product_mode() == 1 && rn::gemm_x3_ok(M, Kd, Nd) && rn::gemm_x3_ok(M, Kw, Nw)) {
+    if (int e = rn::launch_batched_gemm_x3(Ad, Bd, Cd, M, Kd, Nd, nbatch, 1, st)) return e;
+    return rn::launch_batched_gemm_tn_x3(Aw, Bw, M, Kw, Nw, nbatch, workspace, workspace_bytes, st, nsplit_out);
+  }
   rn_conv_seg sd = {}, sw = {};
   sd.n = 1; sd.h = 1; sd.w = M; sd.wgt = Bd; sd.dy = Ad; sd.dx = Cd; sd.cout = Kd;
   rn_conv_geom gd = {1, 1, 1, Nd, 1};

@@ -49,6 +49,15 @@ int launch_batched_gemm_tn(const float* A, const float* B, float* C, int M, int 
 int launch_winograd_bwd_products(const float* Ad, const float* Bd, float* Cd, int M, int Kd, int Nd, const float* Aw,
                                  const float* Bw, int Kw, int Nw, int nbatch, void* workspace, size_t workspace_bytes,
                                  hipStream_t st, int* nsplit_out);
+// The same three products on the bf16 matrix cores from exact three-way splits of the fp32 operands (gemm_x3.hip); used by
+// the functions above when product_mode() == 1 and gemm_x3_ok().
+int product_mode();
+void set_product_mode(int m);
+bool gemm_x3_ok(int M, int K, int N);
+int launch_batched_gemm_x3(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, int b_nk, hipStream_t st);
+size_t batched_gemm_tn_workspace_x3(int M, int K, int N, int nbatch);
+int launch_batched_gemm_tn_x3(const float* A, const float* B, int M, int K, int N, int nbatch, void* workspace, size_t workspace_bytes,
+                              hipStream_t st, int* nsplit_out);
 // Entry points that end with a row reduction open one of these with their `defer` argument: while it is alive (this
 // call, this thread) launch_reduce_rows records into the caller's list instead of launching.
 struct DeferScope {

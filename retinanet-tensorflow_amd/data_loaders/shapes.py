@@ -14,7 +14,7 @@ class Shapes(Base):
         self._image_size = tuple(image_size)
         self._class_names = ['square', 'triangle', 'circle']
         self._rng = np.random.default_rng(seed)
-        self._drawn = 0                        # samples drawn so far (by __iter__ or skip)
+        self._drawn = 0                        # position in the sample stream (advanced by every iterator and by skip)
 
     @property
     def class_names(self):
@@ -27,9 +27,10 @@ class Shapes(Base):
     def skip(self, n):
         """Advance the sample stream by n samples (resuming a run: the checkpoint stores how many were drawn).  Draws only --
         the same random numbers `__iter__` consumes, nothing is rendered -- so resuming a long run costs microseconds per
-        skipped sample; skipping past `num_samples` just exhausts the stream."""
+        skipped sample.  The stream itself is endless; `num_samples` bounds ONE pass (one iterator), as the reference's loader
+        yields num_samples items per `__iter__` (data_loaders/shapes.py:46-55)."""
         h, w = self._image_size
-        for _ in range(min(int(n), self._num_samples - self._drawn)):
+        for _ in range(int(n)):
             self._draw(h, w)
 
     def _draw(self, h, w):
@@ -49,7 +50,7 @@ class Shapes(Base):
     def __iter__(self):
         h, w = self._image_size
         yy, xx = np.mgrid[0:h, 0:w]
-        while self._drawn < self._num_samples:
+        for _ in range(self._num_samples):             # per ITERATOR: a second iter() yields the next num_samples of the stream
             background, items = self._draw(h, w)
             image = np.ones((h, w, 3), np.uint8) * background
             boxes, class_ids = [], []

@@ -42,6 +42,7 @@ MB_CHAIN = os.environ.get("RN_MB_CHAIN", "1") == "1"
 # statistic rows go through rn_mb_compact_rows first).  RN_MB_CHAIN_MAX_HW=16384: the round-3 first version (chain from
 # bottleneck_2_2 on).
 MB_CHAIN_MAX_HW = int(os.environ.get("RN_MB_CHAIN_MAX_HW", 0))
+STAGE_CUT_AFTER = 'bottleneck_3_3'      # (the C3 tap: everything above it is 95 % of the backbone's gradient bytes and runs on maps <= 32 x 32)
 
 
 class DepthwiseConv2D(L.DepthwiseConv2D):
@@ -133,6 +134,13 @@ class MobileNetV2(Model):
                 channels = filters
         self.output_conv = conv_block(32, 1, 1, channels)
         self.out_channels = {'C3': 32, 'C4': 96, 'C5': 32}
+        # train.Trainer installs a callable here while a collective is active (see resnet.ResNeXt.stage_cut): the backward pass
+        # of the chain then runs in two parts, cut behind STAGE_CUT_AFTER, and the upper part's 7.3 MB of gradients (95 % of the
+        # backbone's) are all-reduced underneath the lower part's backward pass on the large maps.  The cut costs one identity
+        # 1x1 conv forward and backward on the C3 map (the chain kernels apply a GroupNorm in their CONSUMER: the first half
+        # needs one) -- about 25 us per step, so it is taken only where there is a collective to hide.
+        self.stage_cut = None
+        self.stage_cut_needs_collective = True
 
     def _chain_blocks(self, first):
         blocks = []
@@ -147,6 +155,14 @@ class MobileNetV2(Model):
                 conv3.weight, ops_mb.Norm(norm3.gamma, norm3.beta, norm3.groups, norm3.eps, None, drop3.rate, drop3.seed),
                 dw.strides, b._same_shape))
         return blocks
+
+    def _identity(self, c, device):
+        """[1, 1, c, c] identity kernel (a constant, not a parameter) for the stage cut's pass-through conv."""
+        cache = self.__dict__.setdefault('_eye_cache', {})
+        key = (c, str(device))
+        if key not in cache:
+            cache[key] = torch.eye(c, dtype=torch.float32, device=device).reshape(1, 1, c, c).contiguous()
+        return cache[key]
 
     def _chain_start(self, x, training):
         """Index of the first bottleneck the fused chain runs (None: no chain) for the stem output x."""
@@ -176,7 +192,10 @@ class MobileNetV2(Model):
         out = {}
         input = self.input_conv(input, training)
         start = self._chain_start(input, training)
+        cut_at = self.block_names[self.block_names.index(STAGE_CUT_AFTER) + 1]
         for name in (self.block_names if start is None else self.block_names[:start]):
+            if name == cut_at and self.stage_cut is not None and training and torch.is_grad_enabled():
+                input = self.stage_cut(getattr(self, name), input, tuple(out.keys()))      # (layer by layer: the cut costs nothing)
             input = getattr(self, name)(input, training)
             if name in _TAP_AFTER:      # a tap feeds the next block and (C3, C4) the pyramid
                 out[_TAP_AFTER[name]], input = ops.fanout(input, 2)
@@ -185,9 +204,20 @@ class MobileNetV2(Model):
             out['C5'] = self.output_conv(input, training)
             return out
         names = self.block_names[start:]
+        blocks = self._chain_blocks(start)
+        seed_dev = L.Dropout.seed_device_counter
+        if (self.stage_cut is not None and training and torch.is_grad_enabled() and STAGE_CUT_AFTER in names[:-1]):
+            k = names.index(STAGE_CUT_AFTER) + 1          # first half: names[:k], ends with the identity conv; second half: names[k:]
+            c_mid = blocks[k - 1].w3.shape[3]
+            eye = self._identity(c_mid, input.device)
+            tap_a = [i for i, name in enumerate(names[:k]) if name in _TAP_AFTER]
+            taps, y_mid = ops_mb.mb_chain(input, blocks[:k], eye, tap_a, training=training, seed_dev=seed_dev, tail_const=True)
+            for i, t in zip(tap_a, taps):
+                out[_TAP_AFTER[names[i]]] = t
+            x_mid = self.stage_cut(getattr(self, names[k]), y_mid, tuple(out.keys()))
+            input, blocks, names = x_mid, blocks[k:], names[k:]
         tap_after = [i for i, name in enumerate(names) if name in _TAP_AFTER]
-        taps, y_tail = ops_mb.mb_chain(input, self._chain_blocks(start), conv_o.weight, tap_after, training=training,
-                                       seed_dev=L.Dropout.seed_device_counter)
+        taps, y_tail = ops_mb.mb_chain(input, blocks, conv_o.weight, tap_after, training=training, seed_dev=seed_dev)
         for i, t in zip(tap_after, taps):
             out[_TAP_AFTER[names[i]]] = t
         # the output block's own GroupNorm + activation + dropout (its 1x1 conv ran as the chain's tail)

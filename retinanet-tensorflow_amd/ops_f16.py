@@ -100,6 +100,7 @@ def conv2d(x, w, bias=None, stride=1, groups=1, out_f32=False):
         ys.append(y)
         s = segs[i]
         s.x, s.wgt, s.y = _rn.f16(t), _rn.f16(wt), _rn.ptr(y)
+        s.wgt_bytes = wt.numel() * 2          # proves that the fragment-ordered copy sits behind Wt (rn_conv_seg.wgt_bytes)
         s.bias = _rn.f32(bias) if bias is not None else None
         s.n, s.h, s.w, s.cout = t.shape[0], t.shape[1], t.shape[2], cout
     _rn.check(L.rn_conv2d_fwd_f16(segs, len(xs), C.byref(geom), 1 if out_f32 else 0, _rn.stream()), "rn_conv2d_fwd_f16")
@@ -152,6 +153,7 @@ def conv2d_norm(x, w, norm, act=None, stride=1, groups=1):
     seg = (_rn.ConvSeg * 1)()
     s = seg[0]
     s.x, s.wgt, s.y, s.bias = _rn.f16(src), _rn.f16(wt), _rn.f16(y), None
+    s.wgt_bytes = wt.numel() * 2
     s.n, s.h, s.w, s.cout = n, src.shape[1], src.shape[2], cout
     rows = L.rn_conv2d_f16_fold_rows(seg, 1, C.byref(geom))
     if rows <= 0:

@@ -309,8 +309,13 @@ class _MbChain(torch.autograd.Function):
             _rn.check(L.rn_reduce_rows(_rn.f32(planes[1]), _rn.f32(dg_buf), c, nrows, 0, st_, ops._defer_arg()), "rn_reduce_rows")
             pgrads[slot_g], pgrads[slot_b] = dg, db
 
-        def pw_bwd(x_plain, in_stage, dy, w, gout, hw, cin, cout):
-            dw_buf, dw = ops._grad_slot(w)
+        def pw_bwd(x_plain, in_stage, dy, w, gout, hw, cin, cout, const_w=False):
+            if const_w:             # a fixed kernel (the identity of a stage cut): its weight gradient goes nowhere
+                dw_buf, dw = torch.empty_like(w), None
+                if ops._deferring:
+                    ops._deferred_keep.append(dw_buf)
+            else:
+                dw_buf, dw = ops._grad_slot(w)
             need = L.rn_mb_pointwise_bwd_workspace(n, hw, cin, cout)
             ws = ops._grad_workspace(need, dev)
             nm_in = _mb_norm(in_stage, training, seed_dev, False) if in_stage is not None else None
@@ -336,7 +341,7 @@ class _MbChain(torch.autograd.Function):
         gout = _rn.MbGout(D.data_ptr(), None, _rn.f32(tg) if tg is not None else None, C.pointer(nm3), 1,
                           _rn.MbRows(rows3.data_ptr(), lay3.rows_per_sample, lay3.width, lay3.bn), planes3.data_ptr())
         dyd = _rn.MbDy(dy_t.data_ptr(), None, None, 0, _rn.MbRows())
-        pgrads[9 * nb] = pw_bwd(x_last, None, dyd, tail_w, gout, hl * wl, cl, ct)
+        pgrads[9 * nb] = pw_bwd(x_last, None, dyd, tail_w, gout, hl * wl, cl, ct, const_w=bool(tail_cfg))
         rows3, lay3 = _compact(rows3, lay3, n, dev)
         keep = [tg]
 
@@ -408,14 +413,16 @@ class _MbChain(torch.autograd.Function):
         return (None, dx0) + tuple(pgrads)
 
 
-def mb_chain(x, blocks, tail_w, tap_after=(), training=True, seed_dev=None):
+def mb_chain(x, blocks, tail_w, tap_after=(), training=True, seed_dev=None, tail_const=False):
     """x [n,h,w,c] -> (list of tap tensors (outputs of the bottlenecks whose index is in `tap_after`, ascending), raw output of
-    the tail 1x1 conv applied to the last bottleneck's output).  See the module docstring."""
+    the tail 1x1 conv applied to the last bottleneck's output).  See the module docstring.  tail_const: `tail_w` is a fixed
+    kernel, not a parameter (the identity with which a stage cut ends the first half of a chain, mobilenet_v2.py): no weight
+    gradient is returned for it."""
     cfg_blocks = tuple((b.stride, b.residual, b.n1, b.n2, b.n3) for b in blocks)
     flat = []
     for b in blocks:
         flat += [b.w1, b.n1.gamma, b.n1.beta, b.wd, b.n2.gamma, b.n2.beta, b.w3, b.n3.gamma, b.n3.beta]
     flat.append(tail_w)
-    cfg = (cfg_blocks, None, frozenset(tap_after), bool(training), seed_dev)
+    cfg = (cfg_blocks, bool(tail_const), frozenset(tap_after), bool(training), seed_dev)
     out = _MbChain.apply(cfg, x, *flat)
     return list(out[:-1]), out[-1]

@@ -14,9 +14,11 @@ single kernel, the gradient all-reduce is a few large contiguous messages sized 
 xGMI bandwidth, and the whole step (forward, loss, backward, optimizer) can be captured into one
 hipGraph -- the launch-bound small kernels of the pyramid's coarse levels then cost no host time.
 """
+import collections
 import contextlib
 import ctypes
 import os
+import sys
 
 import numpy as np
 import torch
@@ -82,7 +84,13 @@ class Optimizer(object):
         self.state1 = torch.ones_like(arena.weights) if kind == 'rmsprop' else torch.zeros_like(arena.weights)
         self.state2 = torch.zeros_like(arena.weights) if kind != 'momentum' else None
         self.norm_reg = torch.zeros(2, dtype=torch.float32, device=dev)   # [sum g'^2, L2 reg loss]
-        self._partial, self._pairs = None, 0
+        # (sum g'^2, regulariser) pairs of the slices of a step: allocated HERE, not lazily in begin_step -- a first-step zero-fill
+        # on the main stream would not be ordered against a side stream's slice update that writes its pairs (EARLY_HEAD_UPDATE)
+        self._pairs = 0
+        self._partial = None
+        if dev.type == 'cuda':
+            n = 4 * int(_rn.lib().rn_optimizer_norm_pairs(arena.count)) + 16
+            self._partial = torch.zeros(2 * n, dtype=torch.float64, device=dev)
         self.step_count = 0
 
     def step(self, grad_scale=1.0, advance_counter=None):
@@ -114,9 +122,7 @@ class Optimizer(object):
     def begin_step(self):
         self.step_count += 1
         self._pairs = 0
-        if self._partial is None:
-            n = 4 * int(_rn.lib().rn_optimizer_norm_pairs(self.arena.count)) + 16
-            self._partial = torch.zeros(2 * n, dtype=torch.float64, device=self.arena.weights.device)
+        assert self._partial is not None, "the fused norm path needs a device arena"
 
     def step_slice(self, lo, hi, grad_scale, advance_counter=None, stream=None):
         a, L_ = self.arena, _rn.lib()
@@ -194,6 +200,12 @@ class GradientAllReduce(object):
         del self._works[:]
         return 1.0 / self.world
 
+    def wait_on_current_stream(self):
+        """Make the CURRENT stream wait for every collective issued so far (Work.wait() orders the stream, not the host) without
+        forgetting them: wait() on the main stream later still covers them."""
+        for w in self._works:
+            w.wait()
+
     def __call__(self):
         self.launch(0, self.arena.count)
         return self.wait()
@@ -258,11 +270,20 @@ class Trainer(object):
         # part j's slice of the gradient arena is reduced underneath the parts that follow it
         bb = getattr(base, 'backbone', None) if self._cut_base is not None else None
         self._stage_bb = bb if (bb is not None and hasattr(bb, 'stage_cut') and os.environ.get("RN_STAGE_CUTS", "1") == "1") else None
+        # (a backbone whose cut costs kernels -- MobileNetV2's chain -- takes it only where a collective is there to hide)
+        if self._stage_bb is not None and getattr(bb, 'stage_cut_needs_collective', False) and not self.allreduce.active:
+            self._stage_bb = None
         self._stage_cuts = []          # per step: (arena offset, source tensor, detached leaf, names of the taps made before it)
         self._param_offset = {id(p): off for p, (off, _) in zip(self.arena.params, self.arena.offsets)}
         self._parts = []               # per step: (roots, grads-of-leaves getter, arena range) of segment B's parts
         self._graphs = None
-        self._graph_cache = {}         # input shape key (dataset.DeviceFeed.shape_key; None without a feed) -> captured segments
+        # input shape key (dataset.DeviceFeed.shape_key; None without a feed) -> captured segments, least recently used first.
+        # Every entry owns its graphs' private activation pool and static buffers, so the cache is BOUNDED (RN_GRAPH_CACHE, default 4
+        # shapes): a loader with many raw sizes should bucket / pad them; a key beyond the bound evicts the least recently used set
+        # (its next appearance re-captures: two warm-up passes + capture, logged).
+        self._graph_cache = collections.OrderedDict()
+        self.graph_cache_max = max(1, int(os.environ.get("RN_GRAPH_CACHE", "4")))
+        self.recaptures = 0
         self._static = None
         # the device word every fused dropout hashes (bumped by the optimizer kernel); replicas start it at different values
         # so that they draw different masks (each tower of the reference's MirroredStrategy has its own dropout stream)
@@ -488,12 +509,19 @@ class Trainer(object):
         key = feed.stage() if feed is not None else None
         if self.use_graph:
             if self._graphs is None:
-                self._graph_cache = {}
+                self._graph_cache.clear()
             cached = self._graph_cache.get(key)
             if cached is None:
+                if self._graph_cache:
+                    self.recaptures += 1
+                    print("[trainer] new input shape %s: capturing another graph set (%d cached, bound %d)" %
+                          (key, len(self._graph_cache), self.graph_cache_max), file=sys.stderr, flush=True)
+                while len(self._graph_cache) >= self.graph_cache_max:
+                    self._graph_cache.popitem(last=False)             # least recently used: its pool is freed with it
                 self._capture(features)
                 self._graph_cache[key] = self._graphs
             else:
+                self._graph_cache.move_to_end(key)
                 self._graphs = cached
                 self._graph_out, self._static = cached[3], cached[4]
                 if features is not None:
@@ -515,8 +543,7 @@ class Trainer(object):
             side.wait_stream(torch.cuda.current_stream())
             self.opt.begin_step()
             with torch.cuda.stream(side):
-                for w in self.allreduce._works:
-                    w.wait()                                          # (makes `side` wait for the collective, not the host)
+                self.allreduce.wait_on_current_stream()               # (makes `side` wait for the collectives, not the host)
                 self.opt.step_slice(self.cut_offset, self.arena.count, 1.0 / self.allreduce.world, None, ctypes.c_void_p(side.cuda_stream))
         if self.use_graph:
             for gb, (lo, hi) in zip(self._graphs[1], self._graphs[2]):

@@ -32,7 +32,8 @@ import torch.distributed as dist
 SIZE, CLASSES = 128, 5
 
 
-def build(dev, seed_batch, use_graph, overlap, force_collective=False, dropout=0.1):
+def build(dev, seed_batch, use_graph, overlap, force_collective=False, dropout=0.1, size=None):
+    SIZE = size or globals()["SIZE"]
     import dataset, layers, levels as levels_mod, retinanet, train
     layers.Dropout._next_seed[0] = 0x5EED             # same dropout streams for every net built in this process
     torch.manual_seed(0)
@@ -68,8 +69,10 @@ def nccl1(out_path):
     wa = plain.arena.weights.clone()
     la = [float(a['class_loss']), float(a['regr_loss'])]
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    os.environ["RN_STAGE_CUTS"] = "0"          # (a): the bit-for-bit comparison -- MobileNetV2's stage cut re-groups one sum, see (c)
     _, tr = build(dev, 11, use_graph=True, overlap=True, force_collective=True)
-    assert tr.cut_offset > 0 and tr.allreduce.active and tr.allreduce.world == 1
+    os.environ["RN_STAGE_CUTS"] = "1"
+    assert tr.cut_offset > 0 and tr.allreduce.active and tr.allreduce.world == 1 and tr._stage_bb is None
     tr.timing = {}
     for _ in range(3):
         b = tr.step()
@@ -81,6 +84,29 @@ def nccl1(out_path):
            "buckets_per_step": len(launched) // 3, "exposed_ms": tr.allreduce_exposed_ms(),
            "max_abs_diff": float((wa - tr.arena.weights).abs().max())}
     tr.check_device_errors()
+    # (c) the same with MobileNetV2's stage cut: the chain's backward pass in two parts, three gradient slices per step
+    # (256 px: the fused chain runs, so the cut goes through its identity pass-through; at 128 px the backbone runs layer by layer)
+    _, p2 = build(dev, 11, use_graph=False, overlap=False, size=256)
+    for _ in range(3):
+        first_plain = p2.step()
+        if _ == 0:
+            fp = [float(first_plain['class_loss']), float(first_plain['regr_loss'])]
+    first_plain, wa = fp, p2.arena.weights.clone()
+    _, tc = build(dev, 11, use_graph=True, overlap=True, force_collective=True, size=256)
+    assert tc._stage_bb is not None
+    seen = []
+    orig = tc.allreduce.launch
+    tc.allreduce.launch = lambda start=0, end=None: (seen.append([start, tc.arena.count if end is None else end]), orig(start, end))[1]
+    firsts = None
+    for i in range(3):
+        del seen[:]
+        c = tc.step()
+        if i == 0:
+            firsts = [float(c['class_loss']), float(c['regr_loss'])]
+    torch.cuda.synchronize()
+    res["stage_cut"] = {"slices": [list(x) for x in seen], "first_step_losses": firsts, "first_step_losses_plain": first_plain,
+                        "max_abs_diff": float((wa - tc.arena.weights).abs().max()), "scale": float(wa.abs().max())}
+    tc.check_device_errors()
     dist.barrier()
     dist.destroy_process_group()
     json.dump(res, open(out_path, "w"))

@@ -77,20 +77,32 @@ def _trainer_worker(rank, world, port, out_dir):
             self.arena.grads.zero_()
             self.arena.grads[self.cut_offset:].copy_(torch.randn(self.arena.count - self.cut_offset, generator=g))
             events.append("A")
+            # what the real segment A plans when MobileNetV2's stage cut is installed (a collective is active): the chain's
+            # backward pass in two parts, cut in front of bottleneck_4_1 (mobilenet_v2.STAGE_CUT_AFTER = bottleneck_3_3)
+            self._parts = [(None, None, (stage_off[0], self.cut_offset)), (None, None, (0, stage_off[0]))]
             return torch.zeros(()), torch.zeros(())
 
-        def segment_b(self):
-            # region A's collective was launched before this runs; it may already have summed that slice
-            g = torch.Generator().manual_seed(5000 + 1000 * self.steps_done + rank)
-            self.arena.grads[:self.cut_offset].copy_(torch.randn(self.cut_offset, generator=g))
-            events.append("B")
+        def segment_b(self, part=None):
+            # the slices above this part's were launched before this runs; they may already have been summed
+            lo, hi = self._parts[part][2]
+            g = torch.Generator().manual_seed(5000 + 1000 * self.steps_done + 100 * part + rank)
+            self.arena.grads[lo:hi].copy_(torch.randn(hi - lo, generator=g))
+            events.append("B%d" % part)
+            return (lo, hi)
 
+    stage_off = [0]
     tr = FakeKernels(net, lv, device='cpu', learning_rate=0.1)
     tr.allreduce.per = 1 << 18                                  # 1 MB buckets: several per region
     first_fpn = next(iter(net.base.fpn.parameters()))
     offs = {id(p): o for p, (o, _) in zip(tr.arena.params, tr.arena.offsets)}
     assert tr.cut_offset == offs[id(first_fpn)] > 0
     assert all(offs[id(p)] < tr.cut_offset for p in net.base.backbone.parameters())
+    # the stage cut the real forward pass would make: the trainer holds the backbone's hook, the slice above it starts at
+    # bottleneck_4_1's first parameter and is 95 % of the backbone's gradients
+    import mobilenet_v2
+    assert tr._stage_bb is net.base.backbone and mobilenet_v2.STAGE_CUT_AFTER == 'bottleneck_3_3'
+    stage_off[0] = offs[id(next(iter(net.base.backbone.bottleneck_4_1.parameters())))]
+    assert 0 < stage_off[0] < tr.cut_offset and 4 * stage_off[0] <= 1 << 20 and stage_off[0] < 0.06 * tr.cut_offset
     assert all(offs[id(p)] >= tr.cut_offset for m in (net.base.fpn, net.base.classification_subnet, net.base.regression_subnet)
                for p in m.parameters())
     # the cut hook is installed only while one of the trainer's segments runs (plain autograd users of the net never see it)
@@ -113,8 +125,9 @@ def _trainer_worker(rank, world, port, out_dir):
         del tr.allreduce.launched[:]
         del events[:]
         tr.step({})
-        # schedule: A, all-reduce(heads + FPN), B, all-reduce(backbone), optimizer
-        assert events == ["A", ("launch", tr.cut_offset, tr.arena.count), "B", ("launch", 0, tr.cut_offset), "opt"], events
+        # schedule: A, all-reduce(heads + FPN), B part 0 (the chain above the C3 tap), all-reduce(its slice), B part 1, all-reduce, optimizer
+        assert events == ["A", ("launch", tr.cut_offset, tr.arena.count), "B0", ("launch", stage_off[0], tr.cut_offset),
+                          "B1", ("launch", 0, stage_off[0]), "opt"], events
         # buckets tile the arena exactly once, on OPT_BLOCK boundaries
         cover = sorted(tr.allreduce.launched)
         assert cover[0][0] == 0 and cover[-1][1] == tr.arena.count and len(cover) > 4
@@ -125,7 +138,9 @@ def _trainer_worker(rank, world, port, out_dir):
             g = torch.Generator().manual_seed(1000 * step + r)
             want[tr.cut_offset:] += torch.randn(tr.arena.count - tr.cut_offset, generator=g)
             g = torch.Generator().manual_seed(5000 + 1000 * step + r)
-            want[:tr.cut_offset] += torch.randn(tr.cut_offset, generator=g)
+            want[stage_off[0]:tr.cut_offset] += torch.randn(tr.cut_offset - stage_off[0], generator=g)
+            g = torch.Generator().manual_seed(5000 + 1000 * step + 100 + r)
+            want[:stage_off[0]] += torch.randn(stage_off[0], generator=g)
         assert torch.allclose(tr.arena.grads, want, atol=1e-6)
     w = [torch.zeros_like(tr.arena.weights) for _ in range(world)]
     dist.all_gather(w, tr.arena.weights)

@@ -36,6 +36,15 @@ def test_rccl_world1_forced_collectives_bit_equal_to_plain_step(tmp_path):
     assert 0 < res["cut_offset"] < res["count"]
     # heads + FPN region first (issued under the backbone's backward pass), the backbone region after it
     assert res["launched"][0][0] >= res["cut_offset"] and res["launched"][res["buckets_per_step"] - 1][1] <= res["cut_offset"]
+    # ... and with MobileNetV2's stage cut (the chain's backward pass in two parts, train.py:261-267): three slices per step,
+    # tiling the arena from the top down; the identity pass-through at the cut is exact in the forward pass (same first-step
+    # losses, bit for bit) and re-groups one GroupNorm's gradient sums in the backward pass (weights within 1e-6 of the range)
+    sc = res["stage_cut"]
+    assert sc["first_step_losses"] == sc["first_step_losses_plain"], sc
+    assert sc["max_abs_diff"] <= 1e-6 * sc["scale"], sc
+    lo = sc["slices"]
+    assert len(lo) == 3 and lo[0] == [res["cut_offset"], res["count"]] and lo[1][1] == res["cut_offset"] and lo[2] == [0, lo[1][0]], lo
+    assert 4 * lo[2][1] <= 1 << 20, lo
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
@@ -50,13 +59,16 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert res["n_gpus"] == 1 and res["steps"] == 4
     ar = res["config"]["allreduce"]
     assert ar["backend"] == "rccl" and ar["ranks"] == 1 and ar["collectives_issued"]
-    assert res["config"]["backward_segments"] == 2 and ar["bytes_overlapped_with_backbone_backward"] > ar["bytes_after_backward"] > 0
+    # heads + FPN, then the chain above the C3 tap, then the rest of the backbone (MobileNetV2's stage cut is on: a collective is active)
+    assert res["config"]["backward_segments"] == 3 and len(ar["slice_schedule_bytes"]) == 3
+    assert ar["bytes_overlapped_with_backbone_backward"] > ar["bytes_after_backward"] > 0
+    assert ar["bytes_after_backward"] <= 1 << 20, ar            # <= 1 MB left after the last backward kernel
     assert res["config"]["gn_barrier_timeouts"] == 0
     # the multi-GPU evidence fields (every rank takes part in them: exercised here with one rank so that an 8-GPU run cannot
     # be the first time this code executes)
     assert ar["rccl_ranks"] == 1 and len(ar["allreduce_exposed_ms_per_rank"]) == 1
     assert ar["allreduce_exposed_ms_max"] >= ar["allreduce_exposed_ms_mean"] >= 0.0
-    assert len(ar["slices"]) == 2 and all(sl["bytes"] > 0 and sl["ms_alone"] > 0 for sl in ar["slices"])
+    assert len(ar["slices"]) == 3 and all(sl["bytes"] > 0 and sl["ms_alone"] > 0 for sl in ar["slices"])
     assert sum(sl["bytes"] for sl in ar["slices"]) == ar["bytes_overlapped_with_backbone_backward"] + ar["bytes_after_backward"]
 
 

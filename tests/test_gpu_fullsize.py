@@ -147,6 +147,60 @@ def test_cfg5_full_image_decode_nms_bit_exact(dev, kind):
         assert per_class.max() == utils_ref.NMS_MAX_OUTPUT_SIZE      # the 1000-per-class cap is exercised
 
 
+@pytest.mark.parametrize("kind", ["hot1pct", "stress"])
+def test_cfg5_batch16_decode_nms_matches_per_image_oracle(dev, kind):
+    """The launch bench.py times for "NMS boxes/ms": BASELINE configs[4]'s batch -- 16 images of 1024 x 1024, 1 280
+    (image, class) segments, 3.14 M anchors, fp16 class LOGITS and fp16 box deltas as the fp16 net writes them, the sigmoid
+    inside the scan (train.py:68-85; the transposing scan det_scan_t_kernel for fp16 maps of 80 classes), bench.py's
+    capacities -- against the oracle run image by image (utils_ref.boxes_decode + nms_classwise on numpy's fp32 sigmoid of the
+    same fp16 logits), 16 different seeds.  Survivors, classes, order and boxes are the oracle's exactly; scores to 1e-6 (the
+    kernel's sigmoid uses the hardware exponential: ~2 ulp).  hot1pct: ~1 % of the anchors above 0.5 (what the headline
+    boxes/ms is quoted on); stress: logits ~ N(-2, 2^2), nearly every anchor a candidate, the 1000-per-class cap reached."""
+    import levels as levels_mod, utils
+    size, classes, batch = 1024, 80, 16
+    lv = levels_mod.build_levels()
+    anchors = {k: lv[k].normalized_anchor_sizes((size, size)) for k in lv}
+    logits, regs = {k: [] for k in lv}, {k: [] for k in lv}
+    for i in range(batch):
+        rng = np.random.default_rng(1000 + i)
+        for j, k in enumerate(lv):
+            s = -(-size // 2 ** (3 + j))
+            if kind == "stress":
+                z = (rng.standard_normal((s, s, 9, classes), dtype=np.float32) * 2 - 2)
+            else:
+                z = -1.0 - 3.0 * rng.random((s, s, 9, classes), dtype=np.float32)
+                sel = rng.random((s, s, 9)) < 0.01
+                z[sel, rng.integers(0, classes, int(sel.sum()))] = (4.0 * rng.random(int(sel.sum())) + 0.01).astype(np.float32)
+            logits[k].append(z.astype(np.float16))
+            regs[k].append((rng.standard_normal((s, s, 9, 4), dtype=np.float32) * 0.3).astype(np.float16))
+    tl = {k: torch.from_numpy(np.stack(v)).to(dev) for k, v in logits.items()}
+    tr = {k: torch.from_numpy(np.stack(v)).to(dev) for k, v in regs.items()}
+    rows = sum(int(v.numel() // classes) for v in tl.values())
+    assert rows == batch * 196416
+    cap = int(rows * (0.05 if kind == "hot1pct" else 1.0))                     # bench.py's capacities
+    got = utils.detect_raw(tl, tr, anchors, classes, capacity=cap, logits=True)
+    assert len(got) == batch
+    dec = {k: utils.regression_postprocess(tr[k].float(), anchors[k]).cpu().numpy() for k in lv}
+    n_cand = n_kept = 0
+    for i in range(batch):
+        parts = []
+        for k in lv:
+            z = logits[k][i].astype(np.float32)
+            p = (np.float32(1.0) / (np.float32(1.0) + np.exp(-z))).astype(np.float32)
+            parts.append(utils_ref.boxes_decode(p, dec[k][i]))
+        merged = utils_ref.merge_boxes_decoded(parts)
+        exp = utils_ref.nms_classwise(merged, classes)
+        n_cand += len(merged.scores)
+        n_kept += len(exp.scores)
+        assert np.array_equal(got[i].class_ids.cpu().numpy(), exp.class_ids), "image %d: classes / count" % i
+        assert np.array_equal(got[i].boxes.cpu().numpy(), exp.boxes), "image %d: boxes" % i
+        assert_close(got[i].scores.cpu().numpy(), exp.scores, 1e-6, "image %d: scores" % i)
+        if kind == "stress":
+            assert np.bincount(exp.class_ids, minlength=classes).max() == utils_ref.NMS_MAX_OUTPUT_SIZE
+    assert n_cand > (20000 if kind == "hot1pct" else 2000000) and n_kept > 10000
+    print("cfg5 batch 16, %s: %d candidates -> %d kept over 16 images, every image index for index" % (kind, n_cand, n_kept))
+
+
 def _whole_net_oracle(backbone, net, x, classes):
     """backbone oracle (literal reference form) + FPN + shared subnets (oracle/model_ref.py) on the product's parameters."""
     params = {to_oracle_name(k): v.detach().cpu().clone() for k, v in net.named_parameters()}
@@ -209,6 +263,15 @@ def _oracle_losses_and_grads(backbone, weights, image, lab_c, lab_r, masks, clas
     return float(ocl.detach()), float(orl.detach()), {n: g.double().numpy() for n, g in grads.items()}
 
 
+# How many parameter tensors may be judged against the fp64 oracle instead of the fp32 one.  Measured (round 5): at 800 x 800
+# ResNeXt-50 (ReLU after every conv, a max pool, random init) sends 159 of the net's 208 tensors there (the product is then on
+# geometric average 0.42 x as far from the fp64 gradient as the fp32 oracle: CLOSER; worst tensor 1.53 x) -- the fp32 and fp64 ORACLES
+# themselves differ by up to 1.6e-1 -- so for this net the full-size gradient bar IS the accuracy comparison below (the 5e-4
+# bar against the fp32 oracle is held by the same kernels at 96 - 256 px: tests/test_gpu_backbones.py); DenseNet-121 (ELU,
+# one max pool): 1 of 409.
+FP64_CLAUSE_CAP = {"resnet_50": 175, "densenet_121": 8}
+
+
 @pytest.mark.parametrize("backbone,size,batch", [("resnet_50", 800, 2), ("densenet_121", 640, 4)])
 def test_cfg3_cfg4_full_size_train_step_matches_oracle(dev, backbone, size, batch):
     """BASELINE configs[2] / configs[3] as stated -- ResNeXt-50-FPN 800x800 batch 2 (pyramid 100/50/25/13/7: odd maps,
@@ -222,7 +285,9 @@ def test_cfg3_cfg4_full_size_train_step_matches_oracle(dev, backbone, size, batc
     rounding of the switch and fall differently under any two fp32 summation orders -- a handful of flipped gates each time,
     so the two fp32 evaluations scatter around the fp64 one by comparable (not equal) amounts: the fp32 and fp64 ORACLES
     differ by up to 1.6e-1 on some ResNeXt-50 tensors at 800 x 800, 1e-3 on DenseNet's (ELU: only its max-pool switches).
-    Everything that is not affected agrees to ~4e-5."""
+    Everything that is not affected agrees to ~4e-5.  The number of tensors that take the second clause is printed and capped
+    (FP64_CLAUSE_CAP), and over those tensors the product must on geometric average be within 1.5 x the fp32 oracle's own distance
+    to the fp64 gradient."""
     import dataset, layers, levels as levels_mod, retinanet, train
     classes = 80
     rng = np.random.default_rng(100 + size)
@@ -271,6 +336,17 @@ def test_cfg3_cfg4_full_size_train_step_matches_oracle(dev, backbone, size, batc
             if e_prod > max(5e-4, 3.0 * e_orc):
                 bad.append("%s: product vs fp32 oracle %.2e, vs fp64 oracle %.2e (fp32 oracle vs fp64 oracle %.2e)" % (n, e, e_prod, e_orc))
         assert not bad, "%s: %d of %d parameter gradients off: %s" % (backbone, len(bad), len(errs), "; ".join(bad[:8]))
+        # How much of the net leans on the clause is printed and capped, and the clause itself is made a comparison of
+        # ACCURACY: over the tensors that took it, the product's distance to the fp64 gradient must on (geometric) average be
+        # no larger than 1.5 x the fp32 oracle's own distance to it -- a kernel that is merely "not 3 x worse" everywhere fails.
+        cap = FP64_CLAUSE_CAP[backbone]
+        ratios = np.array([err(grads_hip[n], g64[n]) / max(err(g32[n], g64[n]), 1e-9) for _, n in loose])
+        geo = float(np.exp(np.log(np.maximum(ratios, 1e-9)).mean()))
+        print("%s: %d of %d tensors took the fp64 clause (cap %d); product / fp32-oracle distance to the fp64 gradient: geometric mean %.2f, "
+              "max %.2f; largest fp32-oracle distances: %s" % (backbone, len(loose), len(errs), cap, geo, float(ratios.max()),
+                                                               ", ".join("%s %.1e" % (n, e) for e, n in loose[:4])))
+        assert len(loose) <= cap, "%s: %d tensors needed the fp64 arbitration (cap %d)" % (backbone, len(loose), cap)
+        assert geo <= 1.5, "%s: the product is on average %.2f x further from the fp64 gradient than the fp32 oracle is" % (backbone, geo)
         worst64 = max(err(g32[n], g64[n]) for n in g32)
         note = "; %d tensor(s) judged against the fp64 oracle (%s); fp32 vs fp64 oracle differ by up to %.1e" % (
             len(loose), ", ".join("%s %.1e" % (n, e) for e, n in loose[:3]), worst64)

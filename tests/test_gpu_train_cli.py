@@ -28,14 +28,14 @@ def test_cli_trains_and_resumes(tmp_path, capsys):
     assert 0.0 <= float(vals["class_iou"]) <= 1.0
 
 
-def _shapes_trainer(dev, use_graph, feed, dropout=0.2, seed=11, scale=128, loss="bce_dice"):
+def _shapes_trainer(dev, use_graph, feed, dropout=0.2, seed=11, scale=128, loss="bce_dice", backbone='mobilenet_v2'):
     import dataset, layers, levels as levels_mod, retinanet, train
     from data_loaders.shapes import Shapes
     lv = levels_mod.build_levels()
     loader = Shapes(None, image_size=(scale + scale // 4, scale), seed=seed)
     torch.manual_seed(0)
     layers.Dropout._next_seed[0] = 0x5EED             # the same dropout streams for every net built in this process
-    net = retinanet.RetinaNet('mobilenet_v2', lv, loader.num_classes, layers.elu, dropout).to(dev)
+    net = retinanet.RetinaNet(backbone, lv, loader.num_classes, layers.elu, dropout).to(dev)
     if feed:
         src = dataset.DeviceFeed(loader, lv, scale=scale, device=dev)
         tr = train.Trainer(net, lv, learning_rate=1e-2, loss_mode=loss, device=dev, use_graph=use_graph, input_fn=src)

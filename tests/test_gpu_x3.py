@@ -1,0 +1,124 @@
+"""The batched products of the Winograd convolutions evaluated on the bf16 matrix cores from EXACT three-way bf16 splits of the
+fp32 operands (csrc/gemm_x3.hip, rn_set_product_mode(1)) against an fp64 reference, beside the exact fp32 matrix-core kernels
+(mode 0): the split products must be as accurate as the fp32 instruction -- error relative to sum |a||b| within 2 x the fp32
+kernel's own, and below 3e-7 -- on every operand layout the network uses (retinanet.py:37-62,85-106: forward [K][N] weights,
+data gradient [N][K], weight gradient = A^T B with the sum over tiles split across blocks), ragged M / N, short and long K, and
+operands spanning 12 orders of magnitude.  Then a whole Winograd conv layer forward + backward in both modes vs the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+from oracle import tf_ops_ref as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def product_mode():
+    import _rn
+    L = _rn.lib()
+    before = L.rn_get_product_mode()
+    yield L.rn_set_product_mode
+    L.rn_set_product_mode(before)
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _operands(rng, shape, wide):
+    x = rng.standard_normal(shape)
+    if wide:            # magnitudes over 12 decades, mixed signs: the splits' exponents differ wildly inside one dot product
+        x = x * 10.0 ** rng.uniform(-6, 6, shape)
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("M,K,N,nb,b_nk,wide", [(682, 256, 256, 4, 0, False), (682, 256, 256, 3, 1, False), (682, 256, 720, 2, 0, False),
+                                                (100, 32, 64, 5, 0, False), (64, 1024, 128, 2, 1, False), (37, 36, 20, 3, 0, False),
+                                                (300, 256, 256, 2, 0, True), (300, 256, 256, 2, 1, True)])
+def test_batched_products_split_bf16_as_accurate_as_fp32(dev, product_mode, M, K, N, nb, b_nk, wide):
+    import _rn
+    rng = np.random.default_rng(M + K + N)
+    A = _operands(rng, (nb, M, K), wide)
+    B = _operands(rng, (nb, N, K) if b_nk else (nb, K, N), wide)
+    Bm = np.swapaxes(B, 1, 2) if b_nk else B
+    ref = np.einsum("bmk,bkn->bmn", A.astype(np.float64), Bm.astype(np.float64))
+    mag = np.einsum("bmk,bkn->bmn", np.abs(A).astype(np.float64), np.abs(Bm).astype(np.float64))
+    Ad, Bd = _t(A, dev), _t(B, dev)
+    errs = []
+    for mode in (0, 1):
+        product_mode(mode)
+        Cd = torch.full((nb, M, N), float("nan"), device=dev)
+        _rn.check(_rn.lib().rn_gemm_batched(_rn.f32(Ad), _rn.f32(Bd), _rn.f32(Cd), M, K, N, nb, b_nk, _rn.stream()), "rn_gemm_batched")
+        got = Cd.cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all()
+        errs.append(float((np.abs(got - ref) / mag).max()))
+    print("products %dx%dx%d x%d b_nk=%d%s: error / sum|a||b|: fp32 MFMA %.2e, split bf16 %.2e" % (M, K, N, nb, b_nk, " wide" if wide else "", errs[0], errs[1]))
+    assert errs[1] <= max(2.0 * errs[0], 3e-7), errs
+
+
+@pytest.mark.parametrize("M,Kd,Nd,nb", [(682, 256, 256, 4), (682, 720, 256, 2), (150, 64, 32, 3)])
+def test_backward_products_split_bf16(dev, product_mode, M, Kd, Nd, nb):
+    """The two products of a Winograd backward pass (rn_winograd_bwd_products): dV = dM Urot^T and the split partial sums of
+    dU = V^T dM (contraction over the M tiles, ragged last range); slabs summed in fp64 vs the fp64 reference, both modes."""
+    import _rn
+    L = _rn.lib()
+    rng = np.random.default_rng(M + Kd)
+    dM = _operands(rng, (nb, M, Kd), False)            # [T x Cout]
+    Urot = _operands(rng, (nb, Nd, Kd), False)         # [Cin x Cout] in the data gradient's [N][K] layout
+    V = _operands(rng, (nb, M, Nd), False)             # [T x Cin]
+    ref_d = np.einsum("bmk,bnk->bmn", dM.astype(np.float64), Urot.astype(np.float64))
+    mag_d = np.einsum("bmk,bnk->bmn", np.abs(dM).astype(np.float64), np.abs(Urot).astype(np.float64))
+    ref_w = np.einsum("bmk,bmn->bkn", V.astype(np.float64), dM.astype(np.float64))       # [Cin x Cout]
+    mag_w = np.einsum("bmk,bmn->bkn", np.abs(V).astype(np.float64), np.abs(dM).astype(np.float64))
+    dMd, Ud, Vd = _t(dM, dev), _t(Urot, dev), _t(V, dev)
+    out = []
+    for mode in (0, 1):
+        product_mode(mode)
+        need = L.rn_winograd_bwd_products_workspace(M, Nd, Kd, nb)
+        ws = torch.full((need // 4,), float("nan"), device=dev)
+        Cd = torch.full((nb, M, Nd), float("nan"), device=dev)
+        ns = C.c_int(0)
+        _rn.check(L.rn_winograd_bwd_products(_rn.f32(dMd), _rn.f32(Ud), _rn.f32(Cd), M, Kd, Nd, _rn.f32(Vd), _rn.f32(dMd), Nd, Kd, nb,
+                                             ws.data_ptr(), need, C.byref(ns), _rn.stream()), "rn_winograd_bwd_products")
+        slabs = ws[:ns.value * nb * Nd * Kd].reshape(ns.value, nb, Nd, Kd).cpu().numpy().astype(np.float64)
+        assert np.isfinite(slabs).all() and ns.value >= 1
+        ed = float((np.abs(Cd.cpu().numpy().astype(np.float64) - ref_d) / mag_d).max())
+        ew = float((np.abs(slabs.sum(0) - ref_w) / mag_w).max())
+        out.append((ed, ew, ns.value))
+    print("backward products M=%d: dgrad error fp32 %.2e / split %.2e; wgrad fp32 %.2e (%d slabs) / split %.2e (%d slabs)" %
+          (M, out[0][0], out[1][0], out[0][1], out[0][2], out[1][1], out[1][2]))
+    assert out[1][0] <= max(2.0 * out[0][0], 3e-7) and out[1][1] <= max(2.0 * out[0][1], 3e-7), out
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_winograd_layer_both_product_modes_vs_oracle(dev, product_mode, mode):
+    """A 3x3 / 256 -> 256 conv over three pyramid levels through the Winograd path (forward, data gradient, weight gradient)
+    in both product modes against the oracle's direct convolution: 1e-4 (the bar of tests/test_gpu_ops.py's conv tests)."""
+    import ops
+    product_mode(mode)
+    rng = np.random.default_rng(3)
+    xs = [rng.standard_normal((2, s, s, 256)).astype(np.float32) for s in (16, 8, 5)]
+    w = (rng.standard_normal((3, 3, 256, 256)) / np.sqrt(9 * 256)).astype(np.float32)
+    xc = [torch.from_numpy(x).requires_grad_(True) for x in xs]
+    wc = torch.from_numpy(w).requires_grad_(True)
+    yc = [T.conv2d_same(x, wc, 1) for x in xc]
+    dys = [rng.standard_normal(tuple(y.shape)).astype(np.float32) for y in yc]
+    torch.autograd.backward(yc, [torch.from_numpy(d) for d in dys])
+    xg = [_t(x, dev).requires_grad_(True) for x in xs]
+    wg = _t(w, dev).requires_grad_(True)
+    yg = ops.conv2d(xg, wg, None, 1)
+    torch.autograd.backward(yg, [_t(d, dev) for d in dys])
+    for i in range(3):
+        assert_close(yg[i].detach().cpu().numpy(), yc[i].detach().numpy(), 1e-4, "winograd fwd level %d (mode %d)" % (i, mode))
+        assert_close(xg[i].grad.cpu().numpy(), xc[i].grad.numpy(), 1e-4, "winograd dx level %d (mode %d)" % (i, mode))
+    assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), 1e-4, "winograd dw (mode %d)" % mode)

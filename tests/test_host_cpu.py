@@ -227,6 +227,12 @@ def test_shapes_loader_skip_resumes_the_stream():
     b.skip(3)
     nxt = next(iter(b))
     assert np.array_equal(nxt['image'], first[3]['image']) and np.array_equal(nxt['boxes'], first[3]['boxes'])
+    # num_samples bounds ONE pass, as the reference's loader does (data_loaders/shapes.py:46-55): a second iter() is the next
+    # epoch of the same stream, not an empty one
+    c = Shapes(None, num_samples=3, image_size=(64, 64), seed=5)
+    e1, e2 = list(c), list(c)
+    assert len(e1) == 3 and len(e2) == 3
+    assert np.array_equal(e1[2]['image'], first[2]['image']) and np.array_equal(e2[0]['image'], first[3]['image'])
 
 
 def test_map_hand_computed_coco_known_answer():
