@@ -9,11 +9,13 @@ A "step" = anchor assignment for the batch + forward + focal/smooth-L1 loss + ba
 heads + FPN slice under the backbone's backward pass) + momentum optimizer, fp32, dropout 0.2 (reference default), on a
 synthetic COCO-shaped batch [image, hflip(image)] that is resident in HBM before the timed region.
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     : the largest kernel INSIDE the step -- the merged backward products of a Winograd F(4x4,3x3) head-tower
-                 layer (data-gradient products + weight-gradient partial products of 3x3 256->256 over P3..P7, one launch)
-                 -- timed from a replayed hipGraph with HIP events on the launch stream, against the 157.3 TFLOP/s dense
-                 fp32 MFMA peak of MI355X_MICROARCH.md; executed (not direct-conv equivalent) FLOPs.  `entries` holds the
-                 forward product and the largest GroupNorm beside it;
+  roofline     : the dominant kernel INSIDE the step -- the forward products of a Winograd F(4x4,3x3) head-tower layer
+                 (36 x [682x256] x [256x256], 17 launches per step; the two backward product launches of the same layer are
+                 `entries[0]`) -- timed from a replayed hipGraph with HIP events on the launch stream.  The products run on
+                 the bf16 matrix cores from exact three-way splits of the fp32 operands (csrc/gemm_x3.hip): `achieved` =
+                 EXECUTED bf16 FLOPs (6 x the fp32 product's) against the 2.5 PFLOP/s dense bf16 peak of MI355X_MICROARCH.md,
+                 `fp32_equivalent` = the product's own FLOPs against the 157.3 TFLOP/s fp32 matrix-core peak (the yardstick of
+                 rounds 1-4).  `entries` also holds the stem (the largest stand-alone GroupNorm);
   nms          : decode + candidate scan + hand-written segment sort + class-wise NMS at BASELINE configs[4]'s shape, fp16
                  logits / box deltas as the fp16 net writes them (sigmoid inside the scan), ~1 % hot and the stress input;
   cpu_baseline : the CPU oracle (restatement of the reference's TF semantics, TF itself is not installable) timed on
@@ -227,20 +229,42 @@ def roofline_kernels(device):
                 # profiles/ (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE)
                 "traffic_source": ("stored: " + os.path.basename(PMC_TRAFFIC_FILE)) if traffic.get(tkey) is not None else None}
 
-    bwd = entry("head-tower layer, merged backward products (largest in-step kernel, 8 launches per step)",
-                "conv_bwd_kernel<64,64,2,2,true,64,64,2,2>: 36 x ([682x256]x[256x256]^T dgrad + [256x682]x[682x256] wgrad partials)",
-                "mfma", 2 * flops, bwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", bwd_bytes, "bwd_products",
-                prof=("conv_bwd_kernel<64, 64, 2, 2, true, 64, 64, 2, 2>", 36 * (44 + 32)))
-    bwd["flops_per_launch"] = 2 * flops
-    fwd = entry("head-tower layer, forward products", "conv_fwd_kernel<64,64,2,2,4,true>, batched: 36 x [682x256]x[256x256]",
-                "mfma", flops, fwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", fwd_bytes, "fwd_products",
-                prof=("conv_fwd_kernel<64, 64, 2, 2, 4, true>", 36 * 44))
-    fwd["flops_per_launch"] = flops
+    x3 = bool(L.rn_get_product_mode())
+    if x3:
+        # the products run on the bf16 matrix cores from exact three-way splits (csrc/gemm_x3.hip): SIX bf16 products per fp32
+        # product.  `achieved` counts the EXECUTED bf16 FLOPs against the dense bf16 peak; `fp32_equivalent` is the algorithmic
+        # (fp32) FLOPs of the same launch against the fp32 matrix-core peak the previous rounds' kernels were priced on.
+        tm, tn = -(-tiles // 128), 2
+        fwd = entry("head-tower layer, forward products (largest in-step kernel: 17 launches per step)",
+                    "gemm_x3_kernel<false,true,2,2>: 36 x [682x256]x[256x256], fp32 operands split into 3 bf16, 6 bf16 MFMA products, fp32 accumulate",
+                    "mfma", 6 * flops, fwd_ms, FP16_MFMA_PEAK_TFLOPS, "TFLOP/s", fwd_bytes, "fwd_products",
+                    prof=("gemm_x3_kernel<false, true, 2, 2>", 36 * tm * tn))
+        fwd["flops_per_launch"] = flops
+        fwd["executed_bf16_flops_per_launch"] = 6 * flops
+        fwd["fp32_equivalent"] = {"achieved": round(flops / (fwd_ms * 1e-3) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(flops / (fwd_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+        bwd = entry("head-tower layer, backward products: data-gradient launch + weight-gradient launch (8 pairs per step)",
+                    "gemm_x3_kernel<false,false,2,2> + gemm_x3_kernel<true,true,2,2>: 36 x ([682x256]x[256x256]^T + [256x682]x[682x256] in %d ranges)" % max(nsplit.value, 1),
+                    "mfma", 12 * flops, bwd_ms, FP16_MFMA_PEAK_TFLOPS, "TFLOP/s", bwd_bytes, "bwd_products")
+        bwd["flops_per_launch"] = 2 * flops
+        bwd["executed_bf16_flops_per_launch"] = 12 * flops
+        bwd["fp32_equivalent"] = {"achieved": round(2 * flops / (bwd_ms * 1e-3) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(2 * flops / (bwd_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+    else:
+        bwd = entry("head-tower layer, merged backward products (largest in-step kernel, 8 launches per step)",
+                    "conv_bwd_kernel<64,64,2,2,true,64,64,2,2>: 36 x ([682x256]x[256x256]^T dgrad + [256x682]x[682x256] wgrad partials)",
+                    "mfma", 2 * flops, bwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", bwd_bytes, "bwd_products",
+                    prof=("conv_bwd_kernel<64, 64, 2, 2, true, 64, 64, 2, 2>", 36 * (44 + 32)))
+        bwd["flops_per_launch"] = 2 * flops
+        fwd = entry("head-tower layer, forward products", "conv_fwd_kernel<64,64,2,2,4,true>, batched: 36 x [682x256]x[256x256]",
+                    "mfma", flops, fwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", fwd_bytes, "fwd_products",
+                    prof=("conv_fwd_kernel<64, 64, 2, 2, 4, true>", 36 * 44))
+        fwd["flops_per_launch"] = flops
     fwd["layer_ms"] = round(layer_ms, 4)
     fwd["layer_direct_conv_equivalent_tflops"] = round(2.0 * pixels * 2304 * 256 / (layer_ms * 1e-3) / 1e12, 1)
     gn = entry("the stem: direct 3x3/2 conv 3->32 of the 512^2 batch (statistics in its epilogue) + its GroupNorm + ELU + dropout as one apply pass",
                "stem_conv_fwd_kernel + gn_apply_rows_kernel", "hbm", gn_bytes, gn_ms, HBM_PEAK_GBPS, "GB/s", gn_bytes, "group_norm")
-    return bwd, fwd, gn
+    return (fwd, bwd, gn) if x3 else (bwd, fwd, gn)      # (first = the `roofline` object: the step's dominant kernel)
 
 
 def _cfg5_inputs(device, batch, image_size, kind, seed=7):
@@ -759,6 +783,11 @@ def main():
                                    (args.loss, args.dropout),
                        "global_batch": world * BATCH, "image_size": IMAGE_SIZE, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "backward_segments": len(sched),
+                       "arithmetic": ("fp32 storage, accumulation and results everywhere; the Winograd products (88 % of the multiply-adds) are evaluated "
+                                      "on the bf16 matrix cores from EXACT three-way bf16 splits of the fp32 operands, six partial products per "
+                                      "product: error <= ~2^-23 per elementary product, measured equal to the fp32 MFMA kernels' against fp64 "
+                                      "(tests/test_gpu_x3.py); RN_PROD_X3=0 selects the fp32 matrix-core kernels") if _rn.lib().rn_get_product_mode()
+                                     else "fp32 everywhere (exact fp32 matrix-core instruction)",
                        "parity": "this step at this dropout rate is oracle-checked with the kernels' counter-based masks injected at the "
                                  "reference's dropout sites (tests/test_gpu_fullsize.py::test_cfg2_full_size_train_step_matches_oracle[0.2], "
                                  "tests/test_gpu_dropout.py)",
@@ -786,8 +815,8 @@ def main():
         if dist_info is not None:
             result["config"]["allreduce"].update(dist_info)
         if not args.no_roofline:
-            bwd, fwd, gn = roofline_kernels(device)
-            result["roofline"] = dict(bwd, entries=[fwd, gn])
+            main, second, gn = roofline_kernels(device)
+            result["roofline"] = dict(main, entries=[second, gn])
         if not args.no_nms:
             result["nms"] = nms_benchmark(device)
         if not args.no_extras and world == 1:

@@ -212,7 +212,7 @@ size_t rn_conv3x3_winograd_bwd_workspace(const rn_conv_seg* segs, int nseg, int 
 int rn_conv3x3_winograd_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, float* dw, int accumulate, int tile,
                             void* workspace, size_t workspace_bytes, const float* v_buf, const float* urot_buf, rn_stream_t stream);
 
-/* How the batched fp32 products of the Winograd convolutions are evaluated (process-wide; default 0, or the environment's
+/* How the batched fp32 products of the Winograd convolutions are evaluated (process-wide; default 1, or the environment's
  * RN_PROD_X3 at first use):
  *   0  the exact fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32): a k-ordered fmaf chain
  *   1  every fp32 operand split exactly into three bf16 values, six bf16 matrix-core products with fp32 accumulation

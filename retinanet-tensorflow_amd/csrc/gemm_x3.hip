@@ -19,9 +19,10 @@
 //   forward products       M_xi = V_xi U_xi         Op1 = V [T x Cin] KC,  Op2 = U [Cin x Cout]     KS
 //   data-gradient products dV_xi = dM_xi Urot_xi^T  Op1 = dM          KC,  Op2 = Urot [Cin x Cout..] KC ([N][K] layout)
 //   weight-gradient        dU_xi = V_xi^T dM_xi     Op1 = V  KS (k = tile index), Op2 = dM KS; k split over blocks, partial slabs
-// Tile 64 x 64 x 32, 4 waves (32 x 32 each), LDS [row][k] bf16 per plane with 80-byte rows (conflict-free b128 fragment reads);
-// the KS loader reads 8 consecutive k of one row as 8 coalesced dword loads and writes them as ONE b128 per plane -- the
-// transpose happens in registers.
+// Tile 128 x 128 x 32 (64 x 64 x 32 for small launches), 4 waves, LDS [row][k] bf16 per plane with 80-byte rows (conflict-free b128
+// fragment reads);
+// a KS tile is kept [k pair][row] in LDS (see TileLoad): float4 loads along the rows, one b128 store per plane, fragments as
+// four b32 reads -- the transpose costs nothing.
 #include "conv_tiles.h"
 #include "rn_common.h"
 
@@ -31,15 +32,15 @@ using namespace rn_tiles;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
 
-constexpr int XM = 64, XN = 64, XK = 32, XT = 256;
-constexpr int LDR = 40;               // halfs per LDS row: 32 k + 8 pad = 80 bytes
-constexpr int PLANE = 64 * LDR;       // halfs per (operand, plane)
+constexpr int XK = 32, XT = 256;
+constexpr int LDR = 40;               // halfs per LDS row of a KC tile: 32 k + 8 pad = 80 bytes
 
 struct X3Op { const float* p; long bstride; int ld, rows; };
 struct X3Args {
   X3Op a, b;
   float* c; long c_bstride, c_sstride; int ldc;
   int K, chunk, nsplit, nbatch, tiles_m, tiles_n;
+  int dbg;      // RN_X3_DBG (timing aid, wrong results): bit 0 no MFMAs, bit 1 no split / LDS stores, bit 2 no global loads after the first, bit 3 no fragment reads
 };
 
 // x = h1 + h2 + h3 exactly, each with <= 8 significant bits (fp32 bit patterns whose low 16 bits are zero)
@@ -52,62 +53,102 @@ __device__ __forceinline__ void split3(float x, unsigned& h1, unsigned& h2, unsi
 // two bf16 (the high halves of lo and hi) in one dword, lo in the low half (the lower k)
 __device__ __forceinline__ unsigned pack_hi(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
-// One operand tile [64 rows][32 k]: 8 fp32 values per thread.
-//   KC: two float4 (4 consecutive k of rows t/8 and t/8 + 32);  KS: 8 dwords (8 consecutive k of row t % 64)
-template <bool KS>
+// One operand tile [ROWS rows][32 k] (ROWS = 64 or 128): ROWS / 32 float4 loads per thread either way.
+//   KC (k contiguous in memory): 4 consecutive k of rows t/8 + 32 i  -> LDS [row][k] bf16, 80-byte rows: a lane's MFMA fragment
+//      (8 consecutive k of one row) is ONE ds_read_b128
+//   KS (rows contiguous in memory): rows 4 (t%16) + 64 i2 .. +3 at k = 2 (t/16) and 2 (t/16) + 1 -> LDS [k pair][row] dwords (a
+//      dword = the bf16 pair (k, k + 1) of one row; rows of ROWS + 4 dwords): the thread's four rows of a plane are ONE
+//      ds_write_b128, a fragment is four ds_read_b32 a k-pair apart (lanes = consecutive rows: conflict-free) -- the transpose
+//      costs nothing
+template <int ROWS>
+struct TileGeom {
+  static constexpr int PLANE = ROWS * LDR;        // halfs per plane (the KS image, 16 x (ROWS + 4) dwords, is smaller)
+  static constexpr int KS_LD = ROWS + 4;          // dwords per k-pair row of a KS tile
+  static constexpr int NQ = ROWS / 32;            // float4 per thread
+};
+template <bool KS, int ROWS>
 struct TileLoad {
-  float v[8];
+  typedef TileGeom<ROWS> G;
+  float4 q[G::NQ];
   __device__ __forceinline__ void load(const __amdgpu_buffer_rsrc_t rs, const X3Op& op, int row0, int k0, int k1, int t) {
     if (KS) {
-      const int row = row0 + (t & 63), k = k0 + (t >> 6) * 8;
-      const bool rok = row < op.rows;
+      const int k = k0 + (t >> 4) * 2;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        v[j] = Vec<1>::load(rs, (rok && k + j < k1) ? ((unsigned)(k + j) * (unsigned)op.ld + (unsigned)row) * 4u : OOB);
+      for (int i2 = 0; i2 < G::NQ / 2; ++i2) {
+        const int row = row0 + (t & 15) * 4 + 64 * i2;
+        const bool rok = row < op.rows;               // (rows % 4 == 0: a quad is inside or outside)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          q[2 * i2 + i] = Vec<4>::load(rs, (rok && k + i < k1) ? ((unsigned)(k + i) * (unsigned)op.ld + (unsigned)row) * 4u : OOB);
+      }
     } else {
       const int k = k0 + (t & 7) * 4;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < G::NQ; ++i) {
         const int row = row0 + (t >> 3) + 32 * i;
-        const float4 q = Vec<4>::load(rs, (row < op.rows && k < k1) ? ((unsigned)row * (unsigned)op.ld + (unsigned)k) * 4u : OOB);
-        v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+        q[i] = Vec<4>::load(rs, (row < op.rows && k < k1) ? ((unsigned)row * (unsigned)op.ld + (unsigned)k) * 4u : OOB);
       }
     }
   }
   // the three planes of this thread's values -> LDS (`tile`: the operand's plane 0; planes PLANE halfs apart)
   __device__ __forceinline__ void store(unsigned short* tile, int t) const {
-    unsigned h[3][8];
+    if (KS) {       // q[2 i2] = rows r..r+3 at k, q[2 i2 + 1] = the same rows at k + 1
 #pragma unroll
-    for (int j = 0; j < 8; ++j) split3(v[j], h[0][j], h[1][j], h[2][j]);
-    if (KS) {
-      unsigned short* dst = tile + (t & 63) * LDR + (t >> 6) * 8;
+      for (int i2 = 0; i2 < G::NQ / 2; ++i2) {
+        const float v[8] = {q[2 * i2].x, q[2 * i2].y, q[2 * i2].z, q[2 * i2].w, q[2 * i2 + 1].x, q[2 * i2 + 1].y, q[2 * i2 + 1].z, q[2 * i2 + 1].w};
+        unsigned h[3][8];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        u32x4 w;
-        w.x = pack_hi(h[p][0], h[p][1]); w.y = pack_hi(h[p][2], h[p][3]);
-        w.z = pack_hi(h[p][4], h[p][5]); w.w = pack_hi(h[p][6], h[p][7]);
-        *reinterpret_cast<u32x4*>(dst + p * PLANE) = w;
+        for (int j = 0; j < 8; ++j) split3(v[j], h[0][j], h[1][j], h[2][j]);
+        unsigned* dst = reinterpret_cast<unsigned*>(tile) + (t >> 4) * G::KS_LD + (t & 15) * 4 + 64 * i2;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          u32x4 w;
+          w.x = pack_hi(h[p][0], h[p][4]); w.y = pack_hi(h[p][1], h[p][5]);
+          w.z = pack_hi(h[p][2], h[p][6]); w.w = pack_hi(h[p][3], h[p][7]);
+          *reinterpret_cast<u32x4*>(dst + p * (G::PLANE / 2)) = w;
+        }
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < G::NQ; ++i) {
+        unsigned h[3][4];
+        split3(q[i].x, h[0][0], h[1][0], h[2][0]); split3(q[i].y, h[0][1], h[1][1], h[2][1]);
+        split3(q[i].z, h[0][2], h[1][2], h[2][2]); split3(q[i].w, h[0][3], h[1][3], h[2][3]);
         unsigned short* dst = tile + ((t >> 3) + 32 * i) * LDR + (t & 7) * 4;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           u32x2v w;
-          w.x = pack_hi(h[p][4 * i], h[p][4 * i + 1]); w.y = pack_hi(h[p][4 * i + 2], h[p][4 * i + 3]);
-          *reinterpret_cast<u32x2v*>(dst + p * PLANE) = w;
+          w.x = pack_hi(h[p][0], h[p][1]); w.y = pack_hi(h[p][2], h[p][3]);
+          *reinterpret_cast<u32x2v*>(dst + p * G::PLANE) = w;
         }
       }
     }
   }
 };
+// a lane's fragment of k-step s (k = 16 s + 8 h .. + 7) of row `row` of the tile's plane p
+template <bool KS, int ROWS>
+__device__ __forceinline__ bf16x8 fragment(const unsigned short* tile, int p, int row, int h, int s) {
+  typedef TileGeom<ROWS> G;
+  if (KS) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(tile) + p * (G::PLANE / 2) + (8 * s + 4 * h) * G::KS_LD + row;
+    u32x4 w;
+    w.x = src[0]; w.y = src[G::KS_LD]; w.z = src[2 * G::KS_LD]; w.w = src[3 * G::KS_LD];
+    return __builtin_bit_cast(bf16x8, w);
+  }
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tile + p * G::PLANE + row * LDR + s * 16 + h * 8));
+}
 
-template <bool A_KS, bool B_KS>
-__global__ __launch_bounds__(XT) void gemm_x3_kernel(const X3Args a) {
-  __shared__ __attribute__((aligned(16))) unsigned short lds[6 * PLANE];
+// Block tile (64 WT) x (64 WT) x 32, 4 waves as 2 x 2, each wave WT x WT MFMA tiles of 32 x 32.  WT = 2 (128 x 128) halves
+// the LDS traffic and the split's VALU work per matrix-core instruction (the 64 x 64 tile is bound by their SUM: 28 us for the
+// head-tower product against 8 us of matrix-core time); WT = 1 is for launches too small to fill the chip with 128 x 128 tiles.
+// NST register stages: the operand tiles of NST K-steps are in flight at once.
+template <bool A_KS, bool B_KS, int WT, int NST>
+__global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Args a) {
+  constexpr int ROWS = 64 * WT;
+  typedef TileGeom<ROWS> G;
+  __shared__ __attribute__((aligned(16))) unsigned short lds[6 * G::PLANE];
   unsigned short* At = lds;
-  unsigned short* Bt = lds + 3 * PLANE;
+  unsigned short* Bt = lds + 3 * G::PLANE;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
@@ -115,81 +156,137 @@ __global__ __launch_bounds__(XT) void gemm_x3_kernel(const X3Args a) {
   const int tile_m = (bid / a.tiles_n) % a.tiles_m;
   const int rest = bid / (a.tiles_n * a.tiles_m);
   const int batch = rest % a.nbatch, split = rest / a.nbatch;
-  const int m0 = tile_m * XM, n0 = tile_n * XN;
+  const int m0 = tile_m * ROWS, n0 = tile_n * ROWS;
   const int kbeg = split * a.chunk, kend = min(a.K, kbeg + a.chunk);
   const float* pa = a.a.p + (size_t)batch * a.a.bstride;
   const float* pb = a.b.p + (size_t)batch * a.b.bstride;
   // (the descriptor covers the whole batch matrix: rows x ld for KC, K x ld for KS)
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(pa, (unsigned)(A_KS ? a.K : a.a.rows) * (unsigned)a.a.ld * 4u);
   const __amdgpu_buffer_rsrc_t rb = make_rsrc(pb, (unsigned)(B_KS ? a.K : a.b.rows) * (unsigned)a.b.ld * 4u);
-  TileLoad<A_KS> la;
-  TileLoad<B_KS> lb;
-  f32x16 acc[1][1];
-  zero_acc<1, 1>(acc);
+  TileLoad<A_KS, ROWS> la[NST];
+  TileLoad<B_KS, ROWS> lb[NST];
+  f32x16 acc[WT][WT];
+  zero_acc<WT, WT>(acc);
   const int nk = (kend - kbeg + XK - 1) / XK;
-  if (nk > 0) {
-    la.load(ra, a.a, m0, kbeg, kend, t);
-    lb.load(rb, a.b, n0, kbeg, kend, t);
-  }
-  const unsigned short* afr = At + (wm * 32 + r) * LDR + h * 8;
-  const unsigned short* bfr = Bt + (wn * 32 + r) * LDR + h * 8;
-  for (int it = 0; it < nk; ++it) {
-    la.store(At, t);
-    lb.store(Bt, t);
-    __syncthreads();
-    if (it + 1 < nk) {
-      la.load(ra, a.a, m0, kbeg + (it + 1) * XK, kend, t);
-      lb.load(rb, a.b, n0, kbeg + (it + 1) * XK, kend, t);
+#pragma unroll
+  for (int st = 0; st < NST; ++st)
+    if (st < nk) {
+      la[st].load(ra, a.a, m0, kbeg + st * XK, kend, t);
+      lb[st].load(rb, a.b, n0, kbeg + st * XK, kend, t);
     }
+  for (int it0 = 0; it0 < nk; it0 += NST) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 fa[3], fb[3];
+    for (int st = 0; st < NST; ++st) {
+      const int it = it0 + st;
+      if (it < nk) {                         // (block-uniform)
+        if (!(a.dbg & 2)) {
+          la[st].store(At, t);
+          lb[st].store(Bt, t);
+        }
+        __syncthreads();
+        if (it + NST < nk && !(a.dbg & 4)) {
+          la[st].load(ra, a.a, m0, kbeg + (it + NST) * XK, kend, t);
+          lb[st].load(rb, a.b, n0, kbeg + (it + NST) * XK, kend, t);
+        }
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        fa[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(afr + p * PLANE + s * 16));
-        fb[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bfr + p * PLANE + s * 16));
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 fa[WT][3], fb[WT][3];
+          if (!(a.dbg & 8)) {
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+#pragma unroll
+              for (int p = 0; p < 3; ++p) {
+                fa[i][p] = fragment<A_KS, ROWS>(At, p, (wm * WT + i) * 32 + r, h, s);
+                fb[i][p] = fragment<B_KS, ROWS>(Bt, p, (wn * WT + i) * 32 + r, h, s);
+              }
+          } else {
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+#pragma unroll
+              for (int p = 0; p < 3; ++p) { fa[i][p] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)t, 1u, 2u, 3u}); fb[i][p] = fa[i][p]; }
+          }
+          if (!(a.dbg & 1))
+#pragma unroll
+          for (int i = 0; i < WT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j) {   // (the small terms first)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
       }
-      // (the small terms first)
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[0][0], 0, 0, 0);
     }
-    __syncthreads();
   }
   float* pc = a.c + (size_t)split * a.c_sstride + (size_t)batch * a.c_bstride;
-  store_tile<XM, XN, 2, 2>(acc, pc, nullptr, m0, n0, a.a.rows, a.b.rows, a.ldc, wm, wn, lane);
+  store_tile<ROWS, ROWS, 2, 2>(acc, pc, nullptr, m0, n0, a.a.rows, a.b.rows, a.ldc, wm, wn, lane);
 }
+
+// Measured and not kept (round 5): the same tiles as a "ping-pong" block of 512 threads -- two groups of 4 waves, each with its
+// own 128 x 128 tile and LDS image, held half a K-step apart by the block's barriers so that every SIMD always has one wave on the
+// matrix cores and one on the vector unit -- 27.1 us against 27.6 us for the head-tower product: the pieces of this kernel add up
+// (leave-one-out, RN_X3_DBG: 10.6 us launch + epilogue, + 8.3 matrix cores, + 4.5 split and LDS stores, + 3.1 fragment reads,
+// + 1.4 global loads) whatever the interleaving, as they would under a power-limited clock: what shortens it is less WORK
+// (operands split once by their producers instead of once per consuming block), not a different schedule.
 
 int g_mode = -1;
 int mode() {
   if (g_mode < 0) {
     const char* e = getenv("RN_PROD_X3");
-    g_mode = e ? (atoi(e) != 0) : 0;
+    g_mode = e ? (atoi(e) != 0) : 1;
   }
   return g_mode;
 }
 
 bool fits(long elems) { return elems > 0 && (double)elems * 4.0 < 2147483648.0; }
 
-int launch(const X3Args& a, bool a_ks, bool b_ks, hipStream_t st) {
+// tiles of 128 x 128 where they still give every CU work (>= 1.25 blocks per CU), 64 x 64 otherwise
+int tile_rows(long rows_a, long rows_b, long batches) {
+  static const int forced = getenv("RN_X3_TILE") ? atoi(getenv("RN_X3_TILE")) : 0;      // tuning aid: 64 / 128
+  if (forced == 64 || forced == 128) return forced;
+  const long big = batches * rn::ceil_div64(rows_a, 128) * rn::ceil_div64(rows_b, 128);
+  return big >= 320 ? 128 : 64;
+}
+
+int launch(X3Args a, bool a_ks, bool b_ks, int rows, hipStream_t st) {
+  static const int dbg = getenv("RN_X3_DBG") ? atoi(getenv("RN_X3_DBG")) : 0;
+  a.dbg = dbg;
+  a.tiles_m = rn::ceil_div(a.a.rows, rows); a.tiles_n = rn::ceil_div(a.b.rows, rows);
   const long blocks = (long)a.nsplit * a.nbatch * a.tiles_m * a.tiles_n;
   RN_UNSUPPORTED(blocks <= 0 || blocks > 0x7fffffffL, "gemm x3: %ld blocks", blocks);
   const dim3 grid((unsigned)blocks);
-  if (a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<true, true>), grid, dim3(XT), 0, st, a);
-  else if (!a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, true>), grid, dim3(XT), 0, st, a);
-  else if (!a_ks && !b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, false>), grid, dim3(XT), 0, st, a);
-  else hipLaunchKernelGGL((gemm_x3_kernel<true, false>), grid, dim3(XT), 0, st, a);
+  static const int nst_env = getenv("RN_X3_NST") ? atoi(getenv("RN_X3_NST")) : 0;      // register stages (tuning aid)
+#define RN_X3K(WT_, NST_)                                                                                                \
+  do {                                                                                                               \
+    if (a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<true, true, WT_, NST_>), grid, dim3(XT), 0, st, a);              \
+    else if (!a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, true, WT_, NST_>), grid, dim3(XT), 0, st, a);       \
+    else if (!a_ks && !b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, false, WT_, NST_>), grid, dim3(XT), 0, st, a);     \
+    else hipLaunchKernelGGL((gemm_x3_kernel<true, false, WT_, NST_>), grid, dim3(XT), 0, st, a);                          \
+  } while (0)
+  if (rows == 128) {
+    if (nst_env == 1) RN_X3K(2, 1);
+    else RN_X3K(2, 2);
+  } else {
+    if (nst_env == 1) RN_X3K(1, 1);
+    else if (nst_env == 2) RN_X3K(1, 2);
+    else RN_X3K(1, 3);
+  }
+#undef RN_X3K
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
 
 // k-ranges of the weight-gradient product: enough blocks to fill the chip, chunks of whole K-tiles
-void tn_split(int M, int K, int N, int nbatch, int* nsplit, int* chunk) {
-  const long tiles = (long)nbatch * rn::ceil_div(K, XM) * rn::ceil_div(N, XN);
-  int ns = (int)rn::ceil_div64(1024, tiles > 0 ? tiles : 1);
+void tn_split(int M, int K, int N, int nbatch, int* nsplit, int* chunk, int* rows) {
+  // (the tile follows the UNSPLIT problem: with 128 x 128 tiles a head-tower layer is 144 tiles x 3 ranges of the 682 tiles)
+  const int tr = tile_rows(K, N, (long)nbatch * 3);
+  *rows = tr;
+  const long tiles = (long)nbatch * rn::ceil_div(K, tr) * rn::ceil_div(N, tr);
+  int ns = (int)rn::ceil_div64(tr == 128 ? 400 : 1024, tiles > 0 ? tiles : 1);
   const int kt = rn::ceil_div(M, XK);
   if (ns > kt) ns = kt;
   if (ns > 16) ns = 16;
@@ -205,6 +302,7 @@ namespace rn {
 int product_mode() { return mode(); }
 void set_product_mode(int m) { g_mode = m ? 1 : 0; }
 
+// (K and N multiples of 4: float4 loads along k of the KC operands and along the rows of the KS operands)
 bool gemm_x3_ok(int M, int K, int N) {
   return M >= 1 && K >= 4 && N >= 4 && K % 4 == 0 && N % 4 == 0 && fits((long)M * K) && fits((long)K * N) && fits((long)M * N);
 }
@@ -215,21 +313,20 @@ int launch_batched_gemm_x3(const float* A, const float* B, float* C, int M, int 
   a.b = b_nk ? X3Op{B, (long)K * N, K, N} : X3Op{B, (long)K * N, N, N};
   a.c = C; a.c_bstride = (long)M * N; a.c_sstride = 0; a.ldc = N;
   a.K = K; a.chunk = rn::ceil_div(K, XK) * XK; a.nsplit = 1; a.nbatch = nbatch;
-  a.tiles_m = rn::ceil_div(M, XM); a.tiles_n = rn::ceil_div(N, XN);
-  return launch(a, false, b_nk == 0, st);
+  return launch(a, false, b_nk == 0, tile_rows(M, N, nbatch), st);
 }
 
 size_t batched_gemm_tn_workspace_x3(int M, int K, int N, int nbatch) {
-  int ns, ck;
-  tn_split(M, K, N, nbatch, &ns, &ck);
+  int ns, ck, tr;
+  tn_split(M, K, N, nbatch, &ns, &ck, &tr);
   return (size_t)ns * nbatch * K * N * sizeof(float);
 }
 
 // slabs [nsplit][nbatch][K][N] of A_b^T B_b (A_b [M x K], B_b [M x N]) in `workspace`
 int launch_batched_gemm_tn_x3(const float* A, const float* B, int M, int K, int N, int nbatch, void* workspace, size_t workspace_bytes,
                               hipStream_t st, int* nsplit_out) {
-  int ns, ck;
-  tn_split(M, K, N, nbatch, &ns, &ck);
+  int ns, ck, tr;
+  tn_split(M, K, N, nbatch, &ns, &ck, &tr);
   const size_t need = (size_t)ns * nbatch * K * N * sizeof(float);
   if (workspace_bytes < need) {
     rn::set_error("gemm x3 tn: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -240,9 +337,8 @@ int launch_batched_gemm_tn_x3(const float* A, const float* B, int M, int K, int 
   a.b = {B, (long)M * N, N, N};
   a.c = (float*)workspace; a.c_bstride = (long)K * N; a.c_sstride = (long)nbatch * K * N; a.ldc = N;
   a.K = M; a.chunk = ck; a.nsplit = ns; a.nbatch = nbatch;
-  a.tiles_m = rn::ceil_div(K, XM); a.tiles_n = rn::ceil_div(N, XN);
   *nsplit_out = ns;
-  return launch(a, true, true, st);
+  return launch(a, true, true, tr, st);
 }
 }  // namespace rn
 

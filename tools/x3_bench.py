@@ -43,5 +43,5 @@ for mode in (0, 1, 0, 1):
     b = timed(lambda: _rn.check(L.rn_winograd_bwd_products(_rn.f32(A), _rn.f32(B), _rn.f32(Cc), M, K, N, _rn.f32(A), _rn.f32(A), K, N, P,
                                                           ws.data_ptr(), need, C.byref(ns), _rn.stream()), "bwd"))
     gf = 2.0 * P * M * K * N / 1e9
-    print("mode %d: forward product %.1f us (%.1f TFLOP/s fp32-equivalent), dgrad %.1f us, merged backward products %.1f us (%d slabs; %.1f TFLOP/s)"
-          % (mode, f, gf / f * 1e3 / 1e3, d, b, ns.value, 2 * gf / b * 1e3 / 1e3))
+    print("mode %d: forward product %.1f us (%.1f TFLOP/s fp32-equivalent), dgrad %.1f us, backward products (dgrad + wgrad) %.1f us (%d slabs; %.1f TFLOP/s)"
+          % (mode, f, gf / f * 1e3, d, b, ns.value, 2 * gf / b * 1e3))
