@@ -502,11 +502,19 @@ typedef struct rn_wino_gn_bwd {
   const float* out_gamma;
   int32_t out_groups;
   float out_eps;
+  int32_t defer_wgrad;    /* != 0: this call leaves dw alone -- its weight-gradient half (the product V^T dM over the tiles and the
+                             G^T dU G back-transform, nothing of which anybody needs before the optimizer step) is run later by
+                             rn_conv3x3_winograd_gn_bwd_wgrad FROM THE SAME WORKSPACE, which the caller keeps untouched until then:
+                             e.g. on a side stream beside the backbone's latency-bound backward pass */
 } rn_wino_gn_bwd;
 /* dx (or g, see above) for every segment and dw (+)=; workspace rn_conv3x3_winograd_bwd_workspace bytes. */
 int rn_conv3x3_winograd_gn_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, float* dw, int accumulate,
                                int tile, const rn_wino_gn_bwd* gn, void* workspace, size_t workspace_bytes, const float* v_buf,
                                const float* urot_buf, rn_stream_t stream);
+/* The deferred half of a rn_conv3x3_winograd_gn_bwd call made with gn->defer_wgrad: same segments, cin, cout, tile, workspace
+ * (untouched since), v_buf and the same urot_buf-was-given flag; dw (+)= as `accumulate` says. */
+int rn_conv3x3_winograd_gn_bwd_wgrad(const rn_conv_seg* segs, int nseg, int cin, int cout, float* dw, int accumulate, int tile,
+                                     void* workspace, size_t workspace_bytes, const float* v_buf, int urot_was_given, rn_stream_t stream);
 /* out[i] = (accumulate ? out[i] : 0) + sum_r in[r * count + i], r < nrows, fixed order (bit-reproducible); joins the
  * caller's deferred batch when `defer` is given.  Finishes dgamma / dbeta from in_g_rows_chan. */
 int rn_reduce_rows(const float* in, float* out, int64_t count, int nrows, int accumulate, rn_stream_t stream, rn_reduce_list* defer);

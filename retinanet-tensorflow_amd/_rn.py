@@ -52,7 +52,7 @@ class WinoGnBwd(C.Structure):
     _fields_ = [("in_rows", C.c_void_p), ("in_gamma", C.c_void_p), ("in_beta", C.c_void_p), ("in_groups", C.c_int32),
                 ("in_act", C.c_int32), ("in_eps", C.c_float), ("in_g_rows_group", C.c_void_p), ("in_g_rows_chan", C.c_void_p),
                 ("out_rows", C.c_void_p), ("out_g_rows_group", C.c_void_p), ("out_gamma", C.c_void_p),
-                ("out_groups", C.c_int32), ("out_eps", C.c_float)]
+                ("out_groups", C.c_int32), ("out_eps", C.c_float), ("defer_wgrad", C.c_int32)]
 
 
 class ReduceDesc(C.Structure):
@@ -167,7 +167,7 @@ SYMBOLS = [
     "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes",
     "rn_conv3x3_winograd_bwd_workspace", "rn_conv3x3_winograd_bwd", "rn_flush_reductions", "rn_gemm_batched",
-    "rn_winograd_bwd_products_workspace", "rn_winograd_bwd_products", "rn_wino_gn_rows", "rn_conv3x3_winograd_gn", "rn_conv3x3_winograd_gn_bwd", "rn_reduce_rows", "rn_resize_bilinear_normalize",
+    "rn_winograd_bwd_products_workspace", "rn_winograd_bwd_products", "rn_wino_gn_rows", "rn_conv3x3_winograd_gn", "rn_conv3x3_winograd_gn_bwd", "rn_conv3x3_winograd_gn_bwd_wgrad", "rn_reduce_rows", "rn_resize_bilinear_normalize",
     "rn_dwgn_supported", "rn_dwgn_fwd", "rn_dwgn_bwd", "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad", "rn_depthwise_bwd",
     "rn_group_norm_sync_bytes", "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
@@ -255,6 +255,8 @@ def lib():
                                               [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_conv3x3_winograd_gn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rn_conv3x3_winograd_gn_bwd_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                                       C.c_void_p, C.c_int, C.c_void_p]
         L.rn_conv3x3_winograd_gn_bwd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rn_reduce_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

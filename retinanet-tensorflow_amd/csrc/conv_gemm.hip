@@ -1326,9 +1326,9 @@ size_t rn::batched_gemm_tn_workspace(int M, int K, int N, int nbatch) {
   return f32 > x3 ? f32 : x3;
 }
 int rn::launch_batched_gemm_tn(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, void* workspace,
-                               size_t workspace_bytes, hipStream_t st, int* nsplit_out) {
+                               size_t workspace_bytes, hipStream_t st, int* nsplit_out, int background) {
   if (nsplit_out && !C && rn::product_mode() == 1 && rn::gemm_x3_ok(M, K, N))
-    return rn::launch_batched_gemm_tn_x3(A, B, M, K, N, nbatch, workspace, workspace_bytes, st, nsplit_out);
+    return rn::launch_batched_gemm_tn_x3(A, B, M, K, N, nbatch, workspace, workspace_bytes, st, nsplit_out, background);
   rn_conv_seg sg = {};
   sg.n = 1; sg.h = 1; sg.w = M; sg.cout = N; sg.x = A; sg.dy = B;
   rn_conv_geom g1 = {1, 1, 1, K, 1};

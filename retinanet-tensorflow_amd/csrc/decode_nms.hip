@@ -806,11 +806,17 @@ __device__ __forceinline__ bool suppresses_fast(const NBox& i, const NBox& j, fl
   return valid && r;
 }
 
-// ---- 5. one wave per (image, class) segment
+// ---- 5. one block of four waves per (image, class) segment.  Greedy NMS is sequential in the candidates, but the test of a batch
+// of 64 candidates against everything kept so far is not: the four waves each take a quarter of the kept boxes (interleaved in
+// groups of four), their survivor masks are ANDed through LDS, and wave 0 resolves the batch in order.  The predicate is the same
+// whatever the order it is evaluated in: index-for-index the results of the one-wave kernel (stress input: 1.24 -> see DESIGN).
 constexpr int KEEP_LDS = 1024;
-__global__ __launch_bounds__(64) void det_nms_kernel(const DetArgs a) {
+constexpr int NMS_WAVES = 4;
+__global__ __launch_bounds__(64 * NMS_WAVES) void det_nms_kernel(const DetArgs a) {
   __shared__ NBox kept[KEEP_LDS];
-  const int k = blockIdx.x, lane = threadIdx.x;
+  __shared__ unsigned long long masks[NMS_WAVES];
+  __shared__ int s_nk;
+  const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s0 = a.seg_start[k], s1 = a.seg_start[k + 1];
   int nk = 0;
   int* keep_out = a.keep_idx + (size_t)k * a.max_keep;
@@ -824,30 +830,37 @@ __global__ __launch_bounds__(64) void det_nms_kernel(const DetArgs a) {
       me = norm_box(*reinterpret_cast<const float4*>(a.cand_box + (size_t)cand * 4));
     }
     bool alive = have;
-    // against everything kept so far: four boxes per step, all loads of a step independent (the one-box loop with a per-lane
-    // early exit was a chain of dependent LDS reads: ~200 cycles per kept box, 1.95 ms on the all-candidates input)
-    for (int j = 0; j < nk; j += 4) {
+    // against this wave's share of everything kept so far: four boxes per step, all loads of a step independent
+    for (int j = 4 * wave; j < nk; j += 4 * NMS_WAVES) {
       const NBox k0 = kept[j], k1 = kept[min(j + 1, nk - 1)], k2 = kept[min(j + 2, nk - 1)], k3 = kept[min(j + 3, nk - 1)];
       const bool s0_ = suppresses_fast(k0, me, a.iou_thr), s1_ = suppresses_fast(k1, me, a.iou_thr);   // (a repeated last box changes nothing)
       const bool s2_ = suppresses_fast(k2, me, a.iou_thr), s3_ = suppresses_fast(k3, me, a.iou_thr);
       alive = alive && !(s0_ || s1_ || s2_ || s3_);
       if (__ballot(alive) == 0ull) break;
     }
-    // resolve the 64 candidates in order
-    unsigned long long live = __ballot(alive);
-    while (live != 0ull && nk < a.max_keep) {
-      const int i = __ffsll((long long)live) - 1;
-      NBox bi;
-      bi.ymin = __shfl(me.ymin, i, 64); bi.xmin = __shfl(me.xmin, i, 64);
-      bi.ymax = __shfl(me.ymax, i, 64); bi.xmax = __shfl(me.xmax, i, 64); bi.area = __shfl(me.area, i, 64);
-      if (lane == i) { kept[nk] = me; keep_out[nk] = (int)cand; alive = false; }
-      if (alive && lane > i && suppresses_fast(bi, me, a.iou_thr)) alive = false;
-      ++nk;
-      live = __ballot(alive);
+    const unsigned long long mine = __ballot(alive);
+    if (lane == 0) masks[wave] = mine;
+    __syncthreads();
+    if (wave == 0) {
+      // resolve the 64 candidates in order
+      unsigned long long live = masks[0] & masks[1] & masks[2] & masks[3];
+      alive = ((live >> lane) & 1ull) != 0ull;
+      while (live != 0ull && nk < a.max_keep) {
+        const int i = __ffsll((long long)live) - 1;
+        NBox bi;
+        bi.ymin = __shfl(me.ymin, i, 64); bi.xmin = __shfl(me.xmin, i, 64);
+        bi.ymax = __shfl(me.ymax, i, 64); bi.xmax = __shfl(me.xmax, i, 64); bi.area = __shfl(me.area, i, 64);
+        if (lane == i) { kept[nk] = me; keep_out[nk] = (int)cand; alive = false; }
+        if (alive && lane > i && suppresses_fast(bi, me, a.iou_thr)) alive = false;
+        ++nk;
+        live = __ballot(alive);
+      }
+      if (lane == 0) s_nk = nk;
     }
-    __syncthreads();                               // kept[] of this batch is visible to the next batch's checks
+    __syncthreads();                               // kept[] and the count of this batch are visible to every wave's next checks
+    nk = s_nk;
   }
-  if (lane == 0) a.seg_keep[k] = nk;
+  if (threadIdx.x == 0) a.seg_keep[k] = nk;
 }
 
 // ---- 6. gather the survivors.  A segment's output offset = the kept counts of the segments in front of it, summed by the
@@ -1016,7 +1029,7 @@ int sort_and_suppress(DetArgs& a, const WsLayout& L, void* workspace, hipStream_
     hipLaunchKernelGGL(det_seg_scatter_global_kernel, dim3(256), dim3(256), 0, st, a);
   }
   hipLaunchKernelGGL(det_seg_sort_kernel, dim3(nseg), dim3(SORT_T), 0, st, a);
-  hipLaunchKernelGGL(det_nms_kernel, dim3(nseg), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(det_nms_kernel, dim3(nseg), dim3(64 * NMS_WAVES), 0, st, a);
   hipLaunchKernelGGL(det_gather_kernel, dim3(nseg), dim3(64), 0, st, a);
   RN_LAUNCH_CHECK();
   return RN_OK;

@@ -252,7 +252,7 @@ int tile_rows(long rows_a, long rows_b, long batches) {
   return big >= 320 ? 128 : 64;
 }
 
-int launch(X3Args a, bool a_ks, bool b_ks, int rows, hipStream_t st) {
+int launch(X3Args a, bool a_ks, bool b_ks, int rows, hipStream_t st, unsigned lds_pad = 0) {
   static const int dbg = getenv("RN_X3_DBG") ? atoi(getenv("RN_X3_DBG")) : 0;
   a.dbg = dbg;
   a.tiles_m = rn::ceil_div(a.a.rows, rows); a.tiles_n = rn::ceil_div(a.b.rows, rows);
@@ -262,7 +262,7 @@ int launch(X3Args a, bool a_ks, bool b_ks, int rows, hipStream_t st) {
   static const int nst_env = getenv("RN_X3_NST") ? atoi(getenv("RN_X3_NST")) : 0;      // register stages (tuning aid)
 #define RN_X3K(WT_, NST_)                                                                                                \
   do {                                                                                                               \
-    if (a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<true, true, WT_, NST_>), grid, dim3(XT), 0, st, a);              \
+    if (a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<true, true, WT_, NST_>), grid, dim3(XT), lds_pad, st, a);        \
     else if (!a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, true, WT_, NST_>), grid, dim3(XT), 0, st, a);       \
     else if (!a_ks && !b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, false, WT_, NST_>), grid, dim3(XT), 0, st, a);     \
     else hipLaunchKernelGGL((gemm_x3_kernel<true, false, WT_, NST_>), grid, dim3(XT), 0, st, a);                          \
@@ -323,8 +323,13 @@ size_t batched_gemm_tn_workspace_x3(int M, int K, int N, int nbatch) {
 }
 
 // slabs [nsplit][nbatch][K][N] of A_b^T B_b (A_b [M x K], B_b [M x N]) in `workspace`
+// background != 0 (and RN_X3_BG_PAD > 0; measured, no gain: 482 vs 483 images/s, so off): the launch runs BESIDE latency-bound
+// kernels of another stream (the deferred weight gradients of
+// the head towers beside the backbone's backward pass): unused dynamic LDS keeps it at one block per CU, so that half of every
+// SIMD's registers stay free for the other stream's blocks (at two blocks per CU -- 2 x 220 of 512 registers -- they would wait
+// for a 25 us block to retire before every launch)
 int launch_batched_gemm_tn_x3(const float* A, const float* B, int M, int K, int N, int nbatch, void* workspace, size_t workspace_bytes,
-                              hipStream_t st, int* nsplit_out) {
+                              hipStream_t st, int* nsplit_out, int background) {
   int ns, ck, tr;
   tn_split(M, K, N, nbatch, &ns, &ck, &tr);
   const size_t need = (size_t)ns * nbatch * K * N * sizeof(float);
@@ -338,7 +343,16 @@ int launch_batched_gemm_tn_x3(const float* A, const float* B, int M, int K, int 
   a.c = (float*)workspace; a.c_bstride = (long)K * N; a.c_sstride = (long)nbatch * K * N; a.ldc = N;
   a.K = M; a.chunk = ck; a.nsplit = ns; a.nbatch = nbatch;
   *nsplit_out = ns;
-  return launch(a, true, true, tr, st);
+  static const int bg_pad = getenv("RN_X3_BG_PAD") ? atoi(getenv("RN_X3_BG_PAD")) : 0;
+  unsigned pad = 0;
+  if (background && tr == 128 && bg_pad > 0) {
+    static const bool ok =
+        hipFuncSetAttribute((const void*)gemm_x3_kernel<true, true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bg_pad) == hipSuccess &&
+        hipFuncSetAttribute((const void*)gemm_x3_kernel<true, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, bg_pad) == hipSuccess;
+    if (ok) pad = (unsigned)bg_pad;
+    else (void)hipGetLastError();
+  }
+  return launch(a, true, true, tr, st, pad);
 }
 }  // namespace rn
 

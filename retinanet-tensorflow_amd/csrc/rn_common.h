@@ -44,7 +44,7 @@ int launch_batched_gemm(const float* A, const float* B, float* C, int M, int K, 
 size_t batched_gemm_tn_workspace(int M, int K, int N, int nbatch);
 // nsplit_out != nullptr: no final reduction; the partial products stay in workspace as [nsplit][nbatch][K][N].
 int launch_batched_gemm_tn(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, void* workspace,
-                           size_t workspace_bytes, hipStream_t st, int* nsplit_out = nullptr);
+                           size_t workspace_bytes, hipStream_t st, int* nsplit_out = nullptr, int background = 0);
 // data-gradient product + weight-gradient partial products of a Winograd backward pass in one launch
 int launch_winograd_bwd_products(const float* Ad, const float* Bd, float* Cd, int M, int Kd, int Nd, const float* Aw,
                                  const float* Bw, int Kw, int Nw, int nbatch, void* workspace, size_t workspace_bytes,
@@ -57,7 +57,7 @@ bool gemm_x3_ok(int M, int K, int N);
 int launch_batched_gemm_x3(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, int b_nk, hipStream_t st);
 size_t batched_gemm_tn_workspace_x3(int M, int K, int N, int nbatch);
 int launch_batched_gemm_tn_x3(const float* A, const float* B, int M, int K, int N, int nbatch, void* workspace, size_t workspace_bytes,
-                              hipStream_t st, int* nsplit_out);
+                              hipStream_t st, int* nsplit_out, int background = 0);
 // Entry points that end with a row reduction open one of these with their `defer` argument: while it is alive (this
 // call, this thread) launch_reduce_rows records into the caller's list instead of launching.
 struct DeferScope {

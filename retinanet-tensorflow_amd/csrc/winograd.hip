@@ -1346,13 +1346,17 @@ int run_gn_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float
   }
   RN_LAUNCH_CHECK();
   int nsplit = 1;
-  if (int e = rn::launch_winograd_bwd_products(Vdy, Urot, Mdx, T_, cout, cin, V, dM, cin, cout, P2, ws + L.slab, ws_bytes - L.slab, st,
-                                               &nsplit))
+  const bool defer = gn->defer_wgrad != 0;      // (the weight-gradient half runs later from this workspace: run_gn_bwd_wgrad)
+  if (defer) {
+    if (int e = rn::launch_batched_gemm(Vdy, Urot, Mdx, T_, cout, cin, P2, 1, st)) return e;
+  } else if (int e = rn::launch_winograd_bwd_products(Vdy, Urot, Mdx, T_, cout, cin, V, dM, cin, cout, P2, ws + L.slab, ws_bytes - L.slab, st,
+                                                      &nsplit)) {
     return e;
+  }
   oa.buf = Mdx; oa.bias = nullptr;
   {
     const DwArgs2 d = {(const float*)(ws + L.slab), dw, kn, nsplit, accumulate};
-    const int slabs = cin / (CK_LANES * wi), nb_out = oa.total_chunks * slabs, nb_dw = (int)rn::ceil_div64(kn, NT);
+    const int slabs = cin / (CK_LANES * wi), nb_out = oa.total_chunks * slabs, nb_dw = defer ? 0 : (int)rn::ceil_div64(kn, NT);
     if (!fold_in) { fi.groups = 1; fi.cpg = CK_LANES * wi; }
     if (fold_in) RN_WGN(wi, hipLaunchKernelGGL((wino_gn_bwd_post_kernel<M, W, 1>), dim3(nb_out + nb_dw), dim3(chunk_threads<W>()), 0, st, oa, fi, d, nb_out, slabs));
     else RN_WGN(wi, hipLaunchKernelGGL((wino_gn_bwd_post_kernel<M, W, 0>), dim3(nb_out + nb_dw), dim3(chunk_threads<W>()), 0, st, oa, fi, d, nb_out, slabs));
@@ -1361,6 +1365,23 @@ int run_gn_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float
   return RN_OK;
 }
 #undef RN_WGN
+
+// the deferred half of run_gn_bwd: dU = V^T dM over the tiles (partial slabs), dw (+)= G^T dU G
+template <int M>
+int run_gn_bwd_wgrad(const rn_conv_seg* segs, int nseg, int cin, int cout, float* dw, int accumulate, char* ws, const BwdLayout& L,
+                     size_t ws_bytes, const float* v_buf, hipStream_t st) {
+  constexpr int P2 = (M + 2) * (M + 2);
+  const int T_ = (int)tiles_of(segs, nseg, M);
+  const int64_t kn = (int64_t)cin * cout;
+  const float* V = v_buf ? v_buf : (const float*)(ws + L.v);
+  const float* dM = (const float*)(ws + L.dm);
+  int nsplit = 1;
+  if (int e = rn::launch_batched_gemm_tn(V, dM, nullptr, T_, cin, cout, P2, ws + L.slab, ws_bytes - L.slab, st, &nsplit, 1)) return e;
+  hipLaunchKernelGGL(wino_dw_kernel<M>, dim3((unsigned)rn::ceil_div64(kn, NT)), dim3(NT), 0, st, (const float*)(ws + L.slab), dw, kn, nsplit,
+                     accumulate);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
 
 int check_fold(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile) {
   RN_CHECK_ARG(segs && nseg >= 1 && nseg <= RN_MAX_SEG && (tile == 2 || tile == 4), "winograd gn: bad segments / tile");
@@ -1373,6 +1394,21 @@ int check_fold(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile) {
   return RN_OK;
 }
 }  // namespace
+
+extern "C" int rn_conv3x3_winograd_gn_bwd_wgrad(const rn_conv_seg* segs, int nseg, int cin, int cout, float* dw, int accumulate, int tile,
+                                                void* workspace, size_t workspace_bytes, const float* v_buf, int urot_was_given,
+                                                rn_stream_t stream) {
+  if (int e = check_fold(segs, nseg, cin, cout, tile)) return e;
+  RN_CHECK_ARG(dw && workspace, "winograd gn bwd wgrad: null pointer");
+  const BwdLayout L = bwd_layout(segs, nseg, cin, cout, tile, v_buf == nullptr, urot_was_given == 0);
+  if (workspace_bytes < L.total) {
+    rn::set_error("winograd gn bwd wgrad: workspace %zu < %zu bytes", workspace_bytes, L.total);
+    return RN_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return tile == 2 ? run_gn_bwd_wgrad<2>(segs, nseg, cin, cout, dw, accumulate, (char*)workspace, L, workspace_bytes, v_buf, st)
+                   : run_gn_bwd_wgrad<4>(segs, nseg, cin, cout, dw, accumulate, (char*)workspace, L, workspace_bytes, v_buf, st);
+}
 
 extern "C" int rn_conv3x3_winograd_gn(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, const float* bias, int tile,
                                       const rn_wino_gn* gn, void* workspace, size_t workspace_bytes, float* v_buf, float* urot_buf,

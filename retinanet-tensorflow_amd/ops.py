@@ -625,12 +625,19 @@ class _WinoTower(torch.autograd.Function):
             dw_buf, dw = _grad_slot(w)
             need = L.rn_conv3x3_winograd_bwd_workspace(segs, n, cin, cout, tile, 1 if v_buf is not None else 0,
                                                        1 if u_buf is not None else 0)
-            ws = _rn.workspace(need, dev)
+            # the weight-gradient half of the layer (product over the tiles + back-transform: nobody needs dw before the
+            # optimizer) can be left for later -- train.Trainer runs it on a side stream beside the backbone's backward pass,
+            # whose latency-bound kernels leave most of the chip idle.  It then works from THIS call's workspace: a private one.
+            defer = WGRAD_DEFER is not None and dw is None
+            ws = torch.empty(int(need), dtype=torch.uint8, device=dev) if defer else _rn.workspace(need, dev)
+            gnb.defer_wgrad = 1 if defer else 0
             _rn.check(L.rn_conv3x3_winograd_gn_bwd(segs, n, cin, cout, _rn.f32(w), _rn.f32(dw_buf), 0, tile, C.byref(gnb),
                                                    ws.data_ptr(), ws.numel(),
                                                    _rn.f32(v_buf) if v_buf is not None else None,
                                                    _rn.f32(u_buf) if u_buf is not None else None, _rn.stream()),
                       "rn_conv3x3_winograd_gn_bwd")
+            if defer:
+                WGRAD_DEFER.append((segs, n, cin, cout, dw_buf, tile, ws, v_buf, 1 if u_buf is not None else 0, x_in))
             grads[3 * i if i < k else 3 * k] = dw
             if i == nconv - 1 and out_b is not None and ctx.needs_input_grad[2 + n + 3 * k + 1]:
                 db_buf, db = _grad_slot(out_b)
@@ -652,6 +659,20 @@ class _WinoTower(torch.autograd.Function):
             cur_dy = dxs
             g_rows_group_next = grg
         return (None, None) + tuple(cur_dy) + tuple(grads)
+
+
+# None: every Winograd-tower layer finishes its weight gradient inside its backward call.  A list: the calls record their
+# weight-gradient halves here instead (see _WinoTower.backward) and run_deferred_wgrads launches them.
+WGRAD_DEFER = None
+
+
+def run_deferred_wgrads(records):
+    """Launch the recorded weight-gradient halves (rn_conv3x3_winograd_gn_bwd_wgrad) on the CURRENT stream, in order."""
+    L = _rn.lib()
+    for segs, n, cin, cout, dw_buf, tile, ws, v_buf, urot_given, _keep in records:
+        _rn.check(L.rn_conv3x3_winograd_gn_bwd_wgrad(segs, n, cin, cout, _rn.f32(dw_buf), 0, tile, ws.data_ptr(), ws.numel(),
+                                                     _rn.f32(v_buf) if v_buf is not None else None, urot_given, _rn.stream()),
+                  "rn_conv3x3_winograd_gn_bwd_wgrad")
 
 
 def wino_tower(xs, tower, out_w=None, out_b=None, groups=32, eps=1e-5, act=None):

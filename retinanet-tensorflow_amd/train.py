@@ -276,6 +276,14 @@ class Trainer(object):
         self._stage_cuts = []          # per step: (arena offset, source tensor, detached leaf, names of the taps made before it)
         self._param_offset = {id(p): off for p, (off, _) in zip(self.arena.params, self.arena.offsets)}
         self._parts = []               # per step: (roots, grads-of-leaves getter, arena range) of segment B's parts
+        # The head towers' WEIGHT gradients (half of their backward products) beside the backbone's backward pass instead of inside
+        # the heads' (ops.WGRAD_DEFER): segment A records them, segment B launches them on a side stream before its own kernels.
+        # Only where no collective is waiting for the heads' gradient slice (one rank): with several ranks that slice is
+        # all-reduced underneath the backbone's backward pass and must be complete when segment A ends.  RN_DEFER_WGRAD=0: off.
+        self.defer_wgrad = (os.environ.get("RN_DEFER_WGRAD", "1") == "1" and self.device.type == 'cuda' and not self.allreduce.active
+                            and self.direct_param_grads)
+        self._deferred_wgrads = []
+        self._deferred_running = []
         self._graphs = None
         # input shape key (dataset.DeviceFeed.shape_key; None without a feed) -> captured segments, least recently used first.
         # Every entry owns its graphs' private activation pool and static buffers, so the cache is BOUNDED (RN_GRAPH_CACHE, default 4
@@ -415,11 +423,18 @@ class Trainer(object):
             if not zeroed:
                 self.arena.zero_grad()
             # d(class_loss + regr_loss): both roots seeded with the same pre-allocated 1 (no add / fill kernels in the step)
-            self._backward([class_loss, regr_loss], [self._one, self._one])
+            ops.WGRAD_DEFER = [] if self.defer_wgrad else None
+            try:
+                self._backward([class_loss, regr_loss], [self._one, self._one])
+            finally:
+                self._deferred_wgrads, ops.WGRAD_DEFER = (ops.WGRAD_DEFER or []), None
             if self._cut_src is not None:
                 self._parts = self._plan_parts()
                 self._cut_src = self._cut_leaves = None
                 self._stage_cuts = []
+            if self._deferred_wgrads and not self._parts:       # no segment B to hide them under: finish them here
+                ops.run_deferred_wgrads(self._deferred_wgrads)
+                self._deferred_wgrads = []
             return class_loss.detach(), regr_loss.detach()
 
     def num_parts(self):
@@ -445,6 +460,13 @@ class Trainer(object):
             with torch.cuda.stream(side):
                 for _ in range(probe):
                     _rn.check(_rn.lib().rn_gemm_batched(_rn.f32(A_), _rn.f32(B_), _rn.f32(C_), A_.shape[1], 256, 256, 36, 0, _rn.stream()), "rn_gemm_batched")
+        if self._deferred_wgrads:             # the towers' weight-gradient halves: forked off here, joined by _backward's join of the side streams
+            wside = _rn.side_stream(self.device, 7)
+            wside.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(wside):
+                ops.run_deferred_wgrads(self._deferred_wgrads)
+            self._deferred_running = self._deferred_wgrads      # (their workspaces stay allocated until the next step replaces this)
+            self._deferred_wgrads = []
         for j in (range(len(self._parts)) if part is None else [part]):
             roots, seeds, rng = self._parts[j]
             with self._scoped():

@@ -531,3 +531,88 @@ F16_FIRM_AGREEMENT = 0.99        # survivors further than the margin above the t
 F16_ALL_AGREEMENT = 0.90         # all survivors, including the ones within the margin of the threshold
 F16_BOX_RMS_TOL = 3e-2           # box corners relative to the box's own extent, rms over the shared survivors
 F16_BOX_WORST_TOL = 0.2          # ... and the worst one (a 6-sigma tail of ~15 000 coordinates)
+
+
+def test_fp16_on_a_trained_net_matches_the_fp32_oracle(dev):
+    """fp16 inference judged on a TRAINED detector instead of a random-init one, whose conditioning dominates
+    the random-init comparison above: ResNeXt-50-FPN (the cfg-5 model; the fp16 path covers it) trained by the product's own
+    loop -- DeviceFeed + hipGraph step, BCE + dice + Huber, momentum 0.9, lr 1e-2 -- on the seeded shapes stream at 256 x 256 for
+    2 000 steps (~16 s), then 16 held-out images through
+      * the fp16 product (fp16 storage end to end, logits + box deltas read as stored, sigmoid inside the scan),
+      * the fp32 product,
+      * the fp32 CPU ORACLE (literal 32-split ResNeXt bottlenecks + FPN + shared subnets, sigmoid, boxes_decode, nms_classwise).
+    Bars (measured in round 5: 103 / 103 survivors shared, scores within 3.7e-3, corners within 3.1e-4 of the box extent, mAP equal):
+    survivors of the oracle scoring above 0.52 are survivors of the fp16 path with the same class, and vice versa, for
+    >= 98 % of them; shared survivors' corners within 1e-2 of the box extent and scores within 1e-2; mAP of the fp16 detections
+    within 0.01 of the fp32 product's; and the fp32 product agrees with the oracle to 1e-3 on scores (training left the weights at
+    scales where the fp32 paths agree closely)."""
+    import dataset, layers, metrics, train, utils
+    from data_loaders.shapes import Shapes
+    from test_gpu_train_cli import _shapes_trainer
+    from tools_f16_probe import agreement                       # tools/f16_trained_probe.py (matching by class and IoU)
+    steps, images, classes = 2000, 16, 3
+    net, tr, feed, lv = _shapes_trainer(dev, True, True, dropout=0.0, seed=0, scale=256, backbone='resnet_50')
+    try:
+        first = [tr.step()["class_loss"].item() for _ in range(20)]
+        for _ in range(steps - 20):
+            out = tr.step()
+    finally:
+        feed.close()
+    tr.check_device_errors()
+    assert out["class_loss"].item() < 0.7 * float(np.mean(first))
+    loader = Shapes(None, image_size=(320, 256), seed=12345)
+    it = dataset.build_dataset(loader, lv, scale=256, device=dev)
+    cpu_net_params = {k: v.detach().cpu().clone() for k, v in net.named_parameters()}
+    d32, d16, gts, shared, total_o, shared_h, total_h, worst_box, worst_score, worst_32 = [], [], [], 0, 0, 0, 0, 0.0, 0.0, 0.0
+    margin = 0.52               # "confident": further above the 0.5 threshold than the score bar below
+
+    def run(image, f16):
+        size = (int(image.shape[1]), int(image.shape[2]))
+        anchors = {k: lv[k].normalized_anchor_sizes(size) for k in lv}
+        layers.set_inference_dtype('f16' if f16 else 'f32')
+        try:
+            with torch.no_grad():
+                o = net(image, training=False)
+                return utils.detect_raw(o["classifications"], o["regressions"], anchors, classes, logits=True)[0]
+        finally:
+            layers.set_inference_dtype('f32')
+
+    class _Net(object):                                         # (what _whole_net_oracle reads: named_parameters)
+        def named_parameters(self):
+            return cpu_net_params.items()
+
+    for _ in range(images):
+        b = next(it)
+        image = b['image'][:1]
+        a32, a16 = run(image, False), run(image, True)
+        with torch.no_grad():
+            _, ref = _whole_net_oracle('resnet_50', _Net(), image.cpu(), classes)
+        probs = {k: torch.sigmoid(ref["classifications"][k][0]).numpy() for k in LEVELS}
+        regs = {k: ref["regressions"][k][0].numpy() for k in LEVELS}
+        orc = utils_ref.detect_image(probs, regs, (int(image.shape[1]), int(image.shape[2])), classes)
+        orc_t = utils.BoxesDecoded(torch.from_numpy(orc.boxes), torch.from_numpy(orc.scores), torch.from_numpy(orc.class_ids))
+        strong = orc.scores > margin
+        strong_t = utils.BoxesDecoded(orc_t.boxes[strong], orc_t.scores[strong], orc_t.class_ids[strong])
+        so, sh, ds, db = agreement(strong_t, a16)              # oracle's confident survivors found by the fp16 path
+        conf = a16.scores.float() > margin
+        sh2, _, _, _ = agreement(utils.BoxesDecoded(a16.boxes[conf], a16.scores[conf].float(), a16.class_ids[conf]), orc_t)
+        shared += round(so * int(strong.sum()))
+        total_o += int(strong.sum())
+        shared_h += round(sh2 * int(conf.sum()))
+        total_h += int(conf.sum())
+        worst_box, worst_score = max(worst_box, db), max(worst_score, ds)
+        _, _, ds32, _ = agreement(orc_t, a32)
+        worst_32 = max(worst_32, ds32)
+        d32.append((a32.boxes.cpu().numpy(), a32.scores.cpu().numpy(), a32.class_ids.cpu().numpy()))
+        d16.append((a16.boxes.cpu().numpy(), a16.scores.float().cpu().numpy(), a16.class_ids.cpu().numpy()))
+        gts.append((np.asarray(b['boxes'], np.float32), np.asarray(b['class_ids'])))
+    m32 = metrics.mean_average_precision(d32, gts, classes)
+    m16 = metrics.mean_average_precision(d16, gts, classes)
+    print("trained ResNeXt-50-FPN (%d steps): mAP fp32 %.4f / fp16 %.4f; oracle's confident survivors found by fp16: %d of %d, fp16's found by "
+          "the oracle: %d of %d; worst corner difference %.1e of the extent, worst score difference %.1e (fp32 product vs oracle: %.1e)" %
+          (steps, m32["mAP"], m16["mAP"], shared, total_o, shared_h, total_h, worst_box, worst_score, worst_32))
+    assert m32["mAP"] > 0.3, "the net must have learned something for this test to mean anything"
+    assert total_o >= 20 and shared >= 0.98 * total_o
+    assert total_h >= 20 and shared_h >= 0.98 * total_h
+    assert worst_box <= 1e-2 and worst_score <= 1e-2 and worst_32 <= 1e-3
+    assert abs(m16["mAP"] - m32["mAP"]) <= 0.01

@@ -313,3 +313,34 @@ def test_twenty_step_loss_curve_matches_oracle(dev):
     for name, p in net.named_parameters():
         assert_close(p.detach().cpu().numpy(), params[to_oracle_name(name)].numpy(), 2e-3, name + " after 20 steps")
     print("worst loss error over 20 steps %.2e" % worst)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_deferred_tower_weight_gradients_change_no_bit(dev, use_graph, monkeypatch):
+    """The head towers' weight-gradient halves run on a side stream beside the backbone's backward pass (Trainer.defer_wgrad,
+    rn_conv3x3_winograd_gn_bwd_wgrad) instead of inside the heads' backward pass: the same kernels on the same operands, so
+    losses and weights after three steps are bit-identical to the undeferred schedule, eager and under graph replay."""
+    import dataset, layers, levels as levels_mod, retinanet, train
+    lv = levels_mod.build_levels()
+
+    def build(defer):
+        monkeypatch.setenv("RN_DEFER_WGRAD", "1" if defer else "0")
+        layers.Dropout._next_seed[0] = 0x5EED
+        torch.manual_seed(4)
+        net = retinanet.RetinaNet('mobilenet_v2', lv, 4, layers.elu, 0.2).to(dev)
+        return train.Trainer(net, lv, loss_mode="focal", device=dev, use_graph=use_graph)
+
+    ta, tb = build(True), build(False)
+    assert ta.defer_wgrad and not tb.defer_wgrad and ta.cut_offset > 0
+    rng = np.random.default_rng(2)
+    size = 256
+    image = torch.from_numpy(rng.standard_normal((2, size, size, 3)).astype(np.float32)).to(dev)
+    boxes = torch.tensor([[[0.1, 0.2, 0.7, 0.8], [0.4, 0.1, 0.9, 0.5]]], device=dev)
+    cids = torch.tensor([[1, 3]], dtype=torch.int32, device=dev)
+    c, r, m = dataset.build_labels((size, size), cids, boxes, lv, 4, flip_pair=True)
+    feats = {"image": image, "detection": {"classifications": c, "regressions": r}, "trainable_masks": m}
+    for _ in range(3):
+        oa, ob = ta.step(feats), tb.step(feats)
+        assert oa["class_loss"].item() == ob["class_loss"].item() and oa["regr_loss"].item() == ob["regr_loss"].item()
+    torch.cuda.synchronize()
+    assert torch.equal(ta.arena.weights, tb.arena.weights)
