@@ -40,7 +40,7 @@ struct X3Args {
   X3Op a, b;
   float* c; long c_bstride, c_sstride; int ldc;
   int K, chunk, nsplit, nbatch, tiles_m, tiles_n;
-  int dbg;      // RN_X3_DBG (timing aid, wrong results): bit 0 no MFMAs, bit 1 no split / LDS stores, bit 2 no global loads after the first, bit 3 no fragment reads
+  int dbg;      // RN_X3_DBG (timing aid, wrong results): bit 0 no MFMAs, bit 1 no split / LDS stores, bit 2 no global loads after the first, bit 3 no fragment reads, bit 4 the dword epilogue
 };
 
 // x = h1 + h2 + h3 exactly, each with <= 8 significant bits (fp32 bit patterns whose low 16 bits are zero)
@@ -223,7 +223,33 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
     }
   }
   float* pc = a.c + (size_t)split * a.c_sstride + (size_t)batch * a.c_bstride;
-  store_tile<ROWS, ROWS, 2, 2>(acc, pc, nullptr, m0, n0, a.a.rows, a.b.rows, a.ldc, wm, wn, lane);
+  if (WT == 2 && !(a.dbg & 16)) {
+    // 16-byte stores through LDS: the accumulator layout (lane = column, registers = rows) would go out as 64 dword stores per
+    // lane in 128-byte pieces; staged per wave as [32 rows][64 columns] it leaves as 8 x 16-byte stores per lane and 32-row half,
+    // every instruction writing four whole 256-byte row segments.  (The operand tiles are dead: the K loop ended with a barrier.)
+    float* stage = reinterpret_cast<float*>(lds) + wave * (32 * 68);           // 68-float rows: 16-byte aligned, rows 4 banks apart
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(pc, (unsigned)a.a.rows * (unsigned)a.ldc * 4u);
+    const int col0 = n0 + wn * 64;
+#pragma unroll
+    for (int i = 0; i < WT; ++i) {
+#pragma unroll
+      for (int j = 0; j < WT; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) stage[((q & 3) + 8 * (q >> 2) + 4 * h) * 68 + j * 32 + r] = acc[i][j][q];
+      // (one wave writes and reads its own region: no block barrier, the wave's LDS operations complete in order)
+      const int row_base = m0 + (wm * WT + i) * 32;
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const int rr = v * 4 + (lane >> 4), cc = (lane & 15) * 4;
+        const float4 o = *reinterpret_cast<const float4*>(&stage[rr * 68 + cc]);
+        const int row = row_base + rr, col = col0 + cc;
+        const unsigned voff = (row < a.a.rows && col < a.b.rows) ? ((unsigned)row * (unsigned)a.ldc + (unsigned)col) * 4u : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, voff, 0, 0);
+      }
+    }
+  } else {
+    store_tile<ROWS, ROWS, 2, 2>(acc, pc, nullptr, m0, n0, a.a.rows, a.b.rows, a.ldc, wm, wn, lane);
+  }
 }
 
 // Measured and not kept (round 5): the same tiles as a "ping-pong" block of 512 threads -- two groups of 4 waves, each with its

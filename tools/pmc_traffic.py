@@ -9,8 +9,12 @@ import re
 import sys
 from collections import defaultdict
 
-KERNELS = {"fwd_products": ("conv_fwd_kernel",), "bwd_products": ("conv_bwd_kernel",),
-           "group_norm": ("stem_conv_fwd_kernel", "gn_apply_rows_kernel")}
+# product mode 1 (split bf16, csrc/gemm_x3.hip): forward = <false, true, ...>, backward = data gradient <false, false, ...> +
+# weight gradient <true, true, ...> (two launches); product mode 0: the fp32 matrix-core kernels
+KERNELS_X3 = {"fwd_products": ("gemm_x3_kernel<false, true",), "bwd_products": ("gemm_x3_kernel<false, false", "gemm_x3_kernel<true, true"),
+              "group_norm": ("stem_conv_fwd_kernel", "gn_apply_rows_kernel")}
+KERNELS_F32 = {"fwd_products": ("conv_fwd_kernel",), "bwd_products": ("conv_bwd_kernel",),
+               "group_norm": ("stem_conv_fwd_kernel", "gn_apply_rows_kernel")}
 
 
 def per_kernel(directory, counter):
@@ -25,11 +29,12 @@ def per_kernel(directory, counter):
 def main(fetch_dir, write_dir):
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     out, detail = {}, {}
-    for key, names in KERNELS.items():
+    x3 = any("gemm_x3_kernel" in k for k in fetch)
+    for key, names in (KERNELS_X3 if x3 else KERNELS_F32).items():
         total = 0.0
         for n in names:
             # the demangled name STARTS with the kernel's name ("conv_fwd_kernel" is also a substring of "stem_conv_fwd_kernel")
-            mine = lambda k: re.match(r"(void\s+)?(\(anonymous namespace\)::)?%s\b" % re.escape(n), k) is not None
+            mine = lambda k: re.match(r"(void\s+)?(\(anonymous namespace\)::)?%s(\b|,)" % re.escape(n), k) is not None
             f = [v for k, vals in fetch.items() if mine(k) for v in vals]
             w = [v for k, vals in write.items() if mine(k) for v in vals]
             if not f or not w:
@@ -41,6 +46,7 @@ def main(fetch_dir, write_dir):
     out["_detail"] = detail
     # what tools/gemm_pmc.py launched: bench.py compares this with its own workload and drops `traffic` when they differ
     out["_shape"] = {"points": 36, "tiles": 2 * sum(((s + 3) // 4) ** 2 for s in (64, 32, 16, 8, 4)), "cin": 256, "cout": 256, "batch": 2, "image": 512}
+    out["_product_mode"] = 1 if x3 else 0
     out["_note"] = "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), averaged over the dispatches of tools/gemm_pmc.py"
     print(json.dumps(out, indent=1))
 

@@ -4,8 +4,8 @@
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=${ROUND:-r04}
-[ -z "$QUICK" ] && timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -12 > gpurun_out/${R}_tests.log
+R=${ROUND:-r05}
+[ -z "$QUICK" ] && timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -12 > gpurun_out/${R}_tests.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/${R}_smoke.log 2>&1
 timeout 900 python bench.py > gpurun_out/${R}_bench.log 2>&1
 rm -rf gpurun_out/${R}_prof gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write
@@ -29,4 +29,9 @@ rm -rf gpurun_out/${R}_nms_prof
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_nms_prof -o nms -- python tools/nms_prof.py stress > gpurun_out/${R}_nms_stress.log 2>&1
 python tools/by_grid.py $(find gpurun_out/${R}_nms_prof -name "nms_kernel_trace.csv" | head -1) > gpurun_out/${R}_nms_stress_kernels_by_grid.txt
 rm -rf gpurun_out/${R}_nms_prof gpurun_out/${R}_prof gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write
+[ -z "$QUICK" ] && (hipcc --offload-arch=gfx950 -O3 tools/micro/boundary.hip -o /tmp/boundary && /tmp/boundary > gpurun_out/${R}_micro_boundary.txt 2>&1)
+[ -z "$QUICK" ] && (hipcc --offload-arch=gfx950 -O3 tools/micro/xcd_cluster.hip -o /tmp/xcd_cluster && timeout 300 /tmp/xcd_cluster > gpurun_out/${R}_micro_xcd_cluster.txt 2>&1)
+[ -z "$QUICK" ] && (RN_MB_RESIDENT=1 timeout 300 python tools/mb_resident_phases.py 512 2 > gpurun_out/${R}_mb_resident_phases.txt 2>&1)
+[ -z "$QUICK" ] && (timeout 300 python tools/x3_bench.py > gpurun_out/${R}_x3_products.txt 2>&1; for v in 0 1 2 4 8 15; do echo "RN_X3_DBG=$v $(env RN_X3_DBG=$v timeout 300 python tools/x3_bench.py 2>&1 | grep 'mode 1' | tail -1)"; done > gpurun_out/${R}_x3_leave_one_out.txt 2>&1)
+[ -z "$QUICK" ] && (timeout 600 python tools/f16_trained_probe.py 2500 1e-2 2>&1 | tail -8 > gpurun_out/${R}_f16_trained_probe.txt)
 tail -3 gpurun_out/${R}_tests.log; tail -1 gpurun_out/${R}_smoke.log; tail -1 gpurun_out/${R}_bench.log | cut -c1-400
