@@ -50,6 +50,7 @@ TRAIN_GFLOP_PER_IMAGE = 239.2       # BASELINE.md section 3 (3 x forward conv FL
 # Winograd F(4x4,3x3): 36 instead of 144 multiplies per 4x4 output tile = exactly 1/4 (every pyramid map of a 512^2 image is a
 # whole number of tiles).  EXECUTED = (39.87 - 38.268) + 38.268 / 4 = 11.169 GMAC forward -> x 2 FLOP x 3 passes:
 EXECUTED_TRAIN_GFLOP_PER_IMAGE = 67.0
+PRODUCT_REPS = 8                    # back-to-back launches per graph when the product kernels are timed alone (_graph_time)
 FP16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
 INFERENCE_GFLOP_PER_IMAGE = 596.0   # cfg 5 forward, 297.98 GMAC per 1024^2 image
 
@@ -124,14 +125,18 @@ class Step(object):
         return out['class_loss'], out['regr_loss']
 
 
-def _graph_time(fn, iters=100):
+def _graph_time(fn, iters=100, reps=1):
     """Average device time of `fn` (launches on the current stream) from a replayed hipGraph, HIP events on the replay
-    stream, clocks warmed up first (an idle MI355X needs >= 10 ms of continuous work: 100 ms of replays)."""
+    stream, clocks warmed up first (an idle MI355X needs >= 10 ms of continuous work: 100 ms of replays).  `reps` > 1 records
+    that many back-to-back calls per graph: one stream, each launch waits for the one before it, so the time per launch is the
+    kernel's duration + the 1.4 - 1.7 us between two nodes of one graph (profiles/r05_micro_boundary.txt) instead of + the
+    ~4 us between two graph launches."""
     fn()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, capture_error_mode="thread_local"):
-        fn()
+        for _ in range(reps):
+            fn()
     t_end = time.perf_counter() + 0.1
     while time.perf_counter() < t_end:
         for _ in range(20):
@@ -143,7 +148,7 @@ def _graph_time(fn, iters=100):
         g.replay()
     e1.record()
     e1.synchronize()
-    return e0.elapsed_time(e1) / iters
+    return e0.elapsed_time(e1) / (iters * reps)
 
 
 def roofline_kernels(device):
@@ -165,7 +170,7 @@ def roofline_kernels(device):
     B = torch.randn(36, 256, 256, device=device) * 0.01
     Cm = torch.empty(36, tiles, 256, device=device)
     fwd_ms = _graph_time(lambda: _rn.check(L.rn_gemm_batched(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, 36, 0,
-                                                             _rn.stream()), "rn_gemm_batched"))
+                                                             _rn.stream()), "rn_gemm_batched"), reps=PRODUCT_REPS)
     dM = torch.randn(36, tiles, 256, device=device)
     need = L.rn_winograd_bwd_products_workspace(tiles, 256, 256, 36)
     ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=device)
@@ -173,7 +178,7 @@ def roofline_kernels(device):
     bwd_ms = _graph_time(lambda: _rn.check(L.rn_winograd_bwd_products(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256,
                                                                       _rn.f32(A), _rn.f32(dM), 256, 256, 36, ws.data_ptr(),
                                                                       ws.numel(), C.byref(nsplit), _rn.stream()),
-                                           "rn_winograd_bwd_products"))
+                                           "rn_winograd_bwd_products"), reps=PRODUCT_REPS)
     flops = 2.0 * 36 * tiles * 256 * 256
     plane = 4.0 * 36 * tiles * 256
     # algorithmic bytes: fwd reads V + U, writes M; bwd reads Vdy + Urot + V + dM, writes Mdx + the nsplit dU slabs
@@ -200,13 +205,14 @@ def roofline_kernels(device):
     if os.path.exists(PMC_TRAFFIC_FILE):
         traffic = json.load(open(PMC_TRAFFIC_FILE))
         # a stored measurement of ANOTHER workload (a stale file) must not be printed beside this one
-        if traffic.get("_shape") != {"points": 36, "tiles": tiles, "cin": 256, "cout": 256, "batch": BATCH, "image": IMAGE_SIZE}:
+        if traffic.get("_shape") != {"points": 36, "tiles": tiles, "cin": 256, "cout": 256, "batch": BATCH, "image": IMAGE_SIZE} \
+                or int(traffic.get("_product_mode", 0)) != int(L.rn_get_product_mode()):
             traffic = {}
 
     def rocprof_avg_us(kernel_prefix, blocks):
         """Average duration of (kernel, grid) in the newest committed kernel trace (profiles/r*_bench_kernel_trace_by_grid.txt): the
-        dispatch's own begin -> end.  `kernel_ms` below is what HIP events see around a replayed one-kernel graph: the same
-        launch PLUS the ~3 - 4 us between two dependent dispatches; the two are printed side by side."""
+        dispatch's own begin -> end.  `kernel_ms` below is what HIP events see around replayed graphs of PRODUCT_REPS back-to-back
+        launches: the same launch PLUS the 1.4 - 1.7 us between two dependent nodes of a graph; the two are printed side by side."""
         files = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_trace_by_grid.txt")))
         if not files:
             return None, None
@@ -771,6 +777,15 @@ def main():
         sched = [(tr_.cut_offset, tr_.arena.count)] + parts
     else:
         sched = [(0, tr_.arena.count)]
+    # one rank issues no collective and therefore takes no cut inside MobileNetV2's chain (it costs two kernels and hides
+    # nothing): the schedule several ranks follow is printed beside this run's own
+    multi = [4 * (hi - lo) for lo, hi in sched]
+    bb_ = getattr(getattr(tr_, '_cut_base', None), 'backbone', None)
+    if tr_.cut_offset and not tr_.allreduce.active and getattr(bb_, 'stage_cut_needs_collective', False):
+        import mobilenet_v2
+        first = next(iter(getattr(bb_, bb_.block_names[bb_.block_names.index(mobilenet_v2.STAGE_CUT_AFTER) + 1]).parameters()))
+        off = tr_._param_offset[id(first)]
+        multi = [4 * (tr_.arena.count - tr_.cut_offset), 4 * (tr_.cut_offset - off), 4 * off]
     if rank == 0:
         ips = world * BATCH * args.steps / elapsed
         result = {
@@ -797,6 +812,9 @@ def main():
                                      "slice_schedule_bytes": [4 * (hi - lo) for lo, hi in sched],
                                      "bytes_overlapped_with_backbone_backward": sum(4 * (hi - lo) for lo, hi in sched[:-1]),
                                      "bytes_after_backward": 4 * (sched[-1][1] - sched[-1][0]),
+                                     # (with >= 2 ranks: tests/dist_worker.py part (c) runs exactly this schedule over RCCL)
+                                     "slice_schedule_bytes_with_2_or_more_ranks": multi,
+                                     "bytes_after_backward_with_2_or_more_ranks": multi[-1],
                                      "allreduce_exposed_ms": round(exposed, 4)},
                        "final_class_loss": round(losses[0], 6),
                        "final_regr_loss": round(losses[1], 6),
