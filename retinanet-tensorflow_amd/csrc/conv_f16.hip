@@ -68,13 +68,24 @@ struct VecH<4> {
   }
 };
 
+// (fp16) fma(fp32(x), sc, sh) of the two halfs of `p`, each with its own fp32 (sc, sh): v_fma_mixlo_f16 / v_fma_mixhi_f16 read the
+// fp16 operand from the chosen half, compute in fp32 and write the chosen half of the destination (the compiler selects
+// v_fma_mix_f32 + a separate convert for the same expression)
+__device__ __forceinline__ uint32_t fma_mix_pair(uint32_t p, float sc0, float sh0, float sc1, float sh1) {
+  uint32_t d;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=&v"(d) : "v"(p), "v"(sc0), "v"(sh0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(p), "v"(sc1), "v"(sh1));
+  return d;
+}
+
 __device__ __forceinline__ int find_seg(const ArgsH& a, int id) {
   int s = 0;
   while (s + 1 < a.nseg && id >= a.seg[s + 1].start) ++s;
   return s;
 }
 
-// FOLD bit 0: GroupNorm + activation of the input applied on load; bit 1: statistics of the output from the epilogue.
+// FOLD bit 0: GroupNorm + activation of the input applied on load; bit 1: statistics of the output from the epilogue; bit 2
+// (with bit 0): the input's activation is ReLU, known at compile time.
 // Both need a tile's rows inside one sample (oh * ow a multiple of BM: host-checked) and a single segment.
 // PIPE (the 256 x 256 tile: ONE block of 8 waves per CU, so nothing else covers a block's own stalls): the operand tiles are
 // double-buffered in (dynamic) LDS -- tile t+1 goes from the staging registers into the other buffer between the MFMAs of tile
@@ -83,7 +94,7 @@ __device__ __forceinline__ int find_seg(const ArgsH& a, int id) {
 template <int BM, int BN, int WM, int WN, int VEC, bool TAPU, int FOLD, int PIPE = 0, int DBG = 0>
 __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args) {
   constexpr int T = WM * WN * 64;
-  constexpr bool FIN = (FOLD & 1) != 0, FOUT = (FOLD & 2) != 0;
+  constexpr bool FIN = (FOLD & 1) != 0, FOUT = (FOLD & 2) != 0, FIN_RELU = (FOLD & 4) != 0;
   __shared__ float2 ntab[FIN ? 2048 : 1];            // (scale, shift) of every input channel of the tile's sample
   __shared__ float sred[FOUT ? WM * BN * 2 : 1];
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -185,16 +196,27 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
       float2 t[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) t[j] = ntab[min(ld_c + j, 2047)];
-      const bool relu = args.fold.in_act == RN_ACT_RELU;
 #pragma unroll
       for (int i = 0; i < A_PASS; ++i) {
         vec_t v = ra[i];
         const bool ok = (okbits >> i) & 1u;
+        if constexpr (FIN_RELU) {
+          // ReLU commutes with the rounding to fp16 (monotone, 0 exact): fp16 in -> fp32 fma -> fp16 out is ONE mixed-precision
+          // instruction per element (v_fma_mixlo / mixhi_f16), the ReLU one packed max per pair -- 1.5 operations per element
+          // where convert, fma, max, convert are 4; that pass is as long as the tile's MFMAs otherwise
+          static_assert(VEC % 2 == 0, "pairs of halfs");
+          typedef uint32_t pairs_t __attribute__((ext_vector_type(VEC / 2)));
+          pairs_t pv = __builtin_bit_cast(pairs_t, v);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          float z = fmaf((float)v[j], t[j].x, t[j].y);
-          z = relu ? fmaxf(z, 0.f) : rn::act_fwd(z, args.fold.in_act);
-          v[j] = ok ? (_Float16)z : (_Float16)0.f;
+          for (int j = 0; j < VEC / 2; ++j) pv[j] = fma_mix_pair(pv[j], t[2 * j].x, t[2 * j].y, t[2 * j + 1].x, t[2 * j + 1].y);
+          const vec_t zero = {};
+          v = ok ? __builtin_elementwise_max(__builtin_bit_cast(vec_t, pv), zero) : zero;
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const float z = rn::act_fwd(fmaf((float)v[j], t[j].x, t[j].y), args.fold.in_act);
+            v[j] = ok ? (_Float16)z : (_Float16)0.f;
+          }
         }
         ra[i] = v;
       }
@@ -748,6 +770,7 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
 #define RN_F16(BM_, BN_, WM_, WN_)                                                                                  \
   do {                                                                                                              \
     if (fbits == 2) RN_F16K(BM_, BN_, WM_, WN_, 2);                                                            \
+    else if (fbits == 3 && a.fold.in_act == RN_ACT_RELU) RN_F16K(BM_, BN_, WM_, WN_, 7);                            \
     else if (fbits == 3) RN_F16K(BM_, BN_, WM_, WN_, 3);                                                            \
     else if (vec8) RN_F16K(BM_, BN_, WM_, WN_, 0);                                                                  \
     else hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 4, false, 0>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \

@@ -1671,10 +1671,66 @@ extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
 // writes per (m-tile, channel) sums in the layout of gn_partial_kernel, so the same fp64 finalize and the same fp16 apply
 // kernel run behind it -- without the statistics pass, and without the apply pass where the consumer is another folded conv.
 // ---------------------------------------------------------------------------------------------------------------------
+namespace {
+// rn_group_norm_finalize for rows whose channels split into 64-channel slabs of whole groups: block = (sample, slab), thread =
+// (channel of the slab, one of four row lanes) -- every load instruction of a wave reads 256 contiguous bytes of a row (the
+// per-group kernel above reads one float per lane from `cpg`-wide pieces of `rows` different rows: 12.7 us per launch at cfg 5,
+// 68 launches per forward pass).  fp64, fixed order: rows of a lane in order, lanes in order, channels of a group in order.
+struct FinColsArgs { const float* partial; float* mean; float* rstd; int rows, c, groups, cpg, hw; size_t plane; float eps; };
+__global__ __launch_bounds__(T) void gn_finalize_cols_kernel(const FinColsArgs a) {
+  __shared__ double red[4][64][2];
+  __shared__ double chan[64][2];
+  const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+  const int slabs = a.c >> 6;
+  const int sample = blockIdx.x / slabs, slab = blockIdx.x - sample * slabs;
+  const float* __restrict__ p1 = a.partial + (size_t)sample * a.rows * a.c + slab * 64 + cl;
+  const float* __restrict__ p2 = p1 + a.plane;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r0 = rl; r0 < a.rows; r0 += 32) {
+    float u[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const size_t rr = (size_t)min(r0 + 4 * j, a.rows - 1) * a.c;
+      u[j] = p1[rr]; v[j] = p2[rr];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (r0 + 4 * j < a.rows) { s1 += (double)u[j]; s2 += (double)v[j]; }
+  }
+  red[rl][cl][0] = s1; red[rl][cl][1] = s2;
+  __syncthreads();
+  if (tid < 64) {
+    chan[tid][0] = ((red[0][tid][0] + red[1][tid][0]) + red[2][tid][0]) + red[3][tid][0];
+    chan[tid][1] = ((red[0][tid][1] + red[1][tid][1]) + red[2][tid][1]) + red[3][tid][1];
+  }
+  __syncthreads();
+  const int gps = 64 / a.cpg;            // groups per slab
+  if (tid < gps) {
+    double v1 = 0.0, v2 = 0.0;
+    for (int j = 0; j < a.cpg; ++j) { v1 += chan[tid * a.cpg + j][0]; v2 += chan[tid * a.cpg + j][1]; }
+    const double m = (double)a.hw * (double)a.cpg;
+    const double mean = v1 / m;
+    double var = v2 / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const int g = slab * gps + tid;
+    a.mean[sample * a.groups + g] = (float)mean;
+    a.rstd[sample * a.groups + g] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+}
+}  // namespace
+
 extern "C" int rn_group_norm_finalize(const float* partial, int n, int rows_per_sample, int hw, int c, int groups, float eps, float* mean,
                                       float* rstd, rn_stream_t stream) {
   RN_CHECK_ARG(partial && mean && rstd && n >= 1 && rows_per_sample >= 1 && hw >= 1 && c >= 1 && groups >= 1 && c % groups == 0,
                "group_norm finalize: bad argument");
+  const int cpg = c / groups;
+  static const bool no_cols = getenv("RN_GN_FINALIZE_COLS") && atoi(getenv("RN_GN_FINALIZE_COLS")) == 0;    // (A/B measurements)
+  if (!no_cols && c % 64 == 0 && cpg <= 64 && 64 % cpg == 0) {
+    FinColsArgs f = {partial, mean, rstd, rows_per_sample, c, groups, cpg, hw, (size_t)n * rows_per_sample * c, eps};
+    hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(n * (c / 64)), dim3(T), 0, (hipStream_t)stream, f);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+  }
   GnArgs a = {};
   a.nseg = 1; a.c = c; a.groups = groups; a.cpg = c / groups; a.eps = eps;
   a.partial = const_cast<float*>(partial);

@@ -210,3 +210,26 @@ def test_resnext_bottleneck_fp16_folded_equals_layer_by_layer(dev, project, size
     assert_close(folded.float().cpu().numpy(), plain.float().cpu().numpy(), 2e-3, "folded vs layer-by-layer fp16 bottleneck")
     err = float((folded.float() - ref32).norm() / ref32.norm())
     assert err < 1e-2, "folded fp16 bottleneck vs fp32: rel L2 %.3e" % err
+
+
+@pytest.mark.parametrize("n,rows,c,groups", [(3, 37, 256, 32), (2, 256, 128, 32), (2, 5, 2048, 32), (2, 9, 64, 32),
+                                              (2, 33, 96, 32), (1, 4, 320, 32)])
+def test_group_norm_finalize_matches_fp64(dev, n, rows, c, groups):
+    """rn_group_norm_finalize (the merge of a folded conv's per-tile statistic rows into mean / rstd) against fp64 numpy: the
+    64-channel-slab kernel (c % 64 == 0, whole groups per slab) and the per-group kernel (every other shape)."""
+    import _rn
+    rng = np.random.default_rng(5)
+    hw = rows * 64
+    part = rng.normal(0.3, 1.0, size=(2, n * rows, c)).astype(np.float32)
+    part[1] = np.abs(part[1]) * 40 + 20            # sums of squares: large enough for a positive variance
+    p = torch.from_numpy(part).to(dev)
+    mean = torch.empty((n, groups), dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    _rn.check(_rn.lib().rn_group_norm_finalize(_rn.f32(p), n, rows, hw, c, groups, 1e-5, _rn.f32(mean), _rn.f32(rstd), _rn.stream()),
+              "rn_group_norm_finalize")
+    cpg = c // groups
+    s = part.astype(np.float64).reshape(2, n, rows, groups, cpg).sum(axis=(2, 4))
+    m = s[0] / (hw * cpg)
+    var = np.maximum(s[1] / (hw * cpg) - m * m, 0.0)
+    assert_close(mean.cpu().numpy(), m.astype(np.float32), 1e-6, "mean")
+    assert_close(rstd.cpu().numpy(), (1.0 / np.sqrt(var + 1e-5)).astype(np.float32), 1e-6, "rstd")
