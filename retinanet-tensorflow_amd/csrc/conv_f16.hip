@@ -42,6 +42,7 @@ struct FoldH {
 struct ArgsH {
   SegH seg[RN_MAX_SEG];
   int nseg, kh, kw, stride, cin, groups, cin_g, tpg, out_f32;
+  int a_nt;      // the activation operand is read exactly once by the whole launch (1 x 1 conv, one N-tile): non-temporal loads
   FoldH fold;
 };
 
@@ -58,12 +59,20 @@ struct VecH<8> {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
     return __builtin_bit_cast(half8, v);
   }
+  static __device__ __forceinline__ half8 load_nt(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 2);      // aux bit 1: nt
+    return __builtin_bit_cast(half8, v);
+  }
 };
 template <>
 struct VecH<4> {
   typedef half4 type;
   static __device__ __forceinline__ half4 load(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+    return __builtin_bit_cast(half4, v);
+  }
+  static __device__ __forceinline__ half4 load_nt(__amdgpu_buffer_rsrc_t rs, unsigned voff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 2);
     return __builtin_bit_cast(half4, v);
   }
 };
@@ -178,12 +187,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
       ld_c = grp * cin + ci;
     }
     okbits = 0;
+    unsigned aoff[A_PASS];
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
       const int ih = ih0[i] + khh, iw = iw0[i] + kww;
       const bool ok = kok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-      ra[i] = VecH<VEC>::load(xa, ok ? (unsigned)(rowoff[i] + tapoff) * 2u : OOB);
+      aoff[i] = ok ? (unsigned)(rowoff[i] + tapoff) * 2u : OOB;
       okbits |= ok ? (1u << i) : 0u;
+    }
+    if (args.a_nt) {
+#pragma unroll
+      for (int i = 0; i < A_PASS; ++i) ra[i] = VecH<VEC>::load_nt(xa, aoff[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PASS; ++i) ra[i] = VecH<VEC>::load(xa, aoff[i]);
     }
 #pragma unroll
     for (int j = 0; j < B_PASS; ++j)
@@ -738,6 +755,14 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
   }
   const bool vec8 = a.cin_g % 8 == 0;
   const bool tapu = vec8 && a.cin_g % BK == 0;
+  {
+    // (RN_F16_NT: 0 never, 1 whenever the operand is read once; default: only where it cannot stay cached anyway, >= 32 MB)
+    static const int nt_mode = getenv("RN_F16_NT") ? atoi(getenv("RN_F16_NT")) : -1;
+    const SegH& d0 = a.seg[0];
+    const bool once = nseg == 1 && G == 1 && g->kh == 1 && g->kw == 1 && g->stride == 1 && d0.tiles_n == 1;
+    const double bytes = (double)d0.n * d0.h * d0.w * d0.x_ld * 2.0;
+    a.a_nt = once && (nt_mode >= 0 ? nt_mode != 0 : bytes >= 33554432.0);
+  }
   int fbits = 0;
   if (fold || rows_out) {
     // a tile's rows must lie inside one sample, the fp16 staged epilogue must be the one that runs, one segment

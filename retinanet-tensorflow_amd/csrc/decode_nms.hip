@@ -348,7 +348,7 @@ __global__ __launch_bounds__(T) void det_scan_q_kernel(const DetArgs a) {
 // row stride an odd number of 16-byte units: conflict-free both ways): lanes l and l + 32 hold the two halves of row l's
 // classes, reduce them in ascending class order (strict >: the first maximum wins) and exchange once; the exact logit ->
 // probability rule of scan_rows_reduce follows from the same registers.  No block barrier: a wave touches only its own region.
-template <int CVT, bool LOGIT>
+template <int CVT, bool LOGIT, bool NT_LOADS = true>
 __global__ __launch_bounds__(T) void det_scan_t_kernel(const DetArgs a) {
   static_assert(CVT % 2 == 0, "the two lanes of a row take CVT / 2 chunks each");
   extern __shared__ __attribute__((aligned(16))) char scan_t_lds[];
@@ -367,7 +367,12 @@ __global__ __launch_bounds__(T) void det_scan_t_kernel(const DetArgs a) {
   const int total = nrow * CVT;
   half8 v[CVT];
 #pragma unroll
-  for (int j = 0; j < CVT; ++j) v[j] = reinterpret_cast<const half8*>(base)[min(lane + 64 * j, total - 1)];
+  for (int j = 0; j < CVT; ++j) {
+    const half8* src = reinterpret_cast<const half8*>(base) + min(lane + 64 * j, total - 1);
+    // the 528 MB of a cfg-5 batch are read once: non-temporal loads keep them from displacing each other (and the candidate
+    // lists) in L2 / the memory-side cache: 5.2 -> 5.8 TB/s (0.174 -> 0.160 ms per batch; RN_SCAN_NT=0: plain loads)
+    v[j] = NT_LOADS ? __builtin_nontemporal_load(src) : *src;
+  }
   const int part = lane >> 5;                          // 0: classes [0, 4 CVT), 1: the rest
   const char* rd = lds + (lane & 31) * RS + part * HC * 16;
   float my_s = 0.f; int my_c = 0;
@@ -1071,7 +1076,11 @@ int run_detect(const rn_det_level* levels, int nlevels, const rn_det_params* p, 
     static const bool scan_t = !(getenv("RN_SCAN_T") && atoi(getenv("RN_SCAN_T")) == 0);
     if (scan_t && uniform && a.lv[0].half_prob && a.C == 80 && !lds_ok) {
       constexpr size_t tl = (size_t)(T / 64) * 32 * ((10 | 1) * 16);
-      if (a.lv[0].logit) hipLaunchKernelGGL((det_scan_t_kernel<10, true>), dim3(wblocks), dim3(T), tl, st, a);
+      static const bool nt = !(getenv("RN_SCAN_NT") && atoi(getenv("RN_SCAN_NT")) == 0);   // (0: A/B measurements)
+      if (!nt) {
+        if (a.lv[0].logit) hipLaunchKernelGGL((det_scan_t_kernel<10, true, false>), dim3(wblocks), dim3(T), tl, st, a);
+        else hipLaunchKernelGGL((det_scan_t_kernel<10, false, false>), dim3(wblocks), dim3(T), tl, st, a);
+      } else if (a.lv[0].logit) hipLaunchKernelGGL((det_scan_t_kernel<10, true>), dim3(wblocks), dim3(T), tl, st, a);
       else hipLaunchKernelGGL((det_scan_t_kernel<10, false>), dim3(wblocks), dim3(T), tl, st, a);
     } else if (uniform && qpl >= 1 && qpl <= 8 && !lds_ok) {
 #define RN_SCAN_Q(H_, L_)                                                                                         \

@@ -47,6 +47,7 @@ struct GnArgs {
   // rows path: [chunk][per_group ? groups : c] pairs (the producer's, rn_gn_params.stat_rows, or rows_out below); slab width
   const float2* rows; int rows_per_group, rows_sw;   // (rows of a sample: seg.chunks, first row: seg.chunk_start)
   float2* rows_out;                                  // gn_rows_partial_kernel: [total_chunks][groups]
+  int nt_loads;    // fp16 apply: x and the residual are read for the last time here -- non-temporal loads (large inference batches)
 };
 
 __device__ __forceinline__ int seg_of_sample(const GnArgs& a, int q) {
@@ -632,9 +633,13 @@ __global__ __launch_bounds__(T) void gn_apply_f16x8_kernel(const GnArgs a) {
 #pragma unroll 2
   for (int64_t i = (int64_t)blockIdx.x * T + tid; i < total; i += (int64_t)gridDim.x * T) {
     const int c0 = (int)(i % C8) * 8;
-    const gn_half8 xv = *reinterpret_cast<const gn_half8*>(x + i * 8);
+    const gn_half8* xp = reinterpret_cast<const gn_half8*>(x + i * 8);
+    const gn_half8 xv = a.nt_loads ? __builtin_nontemporal_load(xp) : *xp;
     gn_half8 rv;
-    if (r) rv = *reinterpret_cast<const gn_half8*>(r + i * 8);
+    if (r) {
+      const gn_half8* rp = reinterpret_cast<const gn_half8*>(r + i * 8);
+      rv = a.nt_loads ? __builtin_nontemporal_load(rp) : *rp;
+    }
     gn_half8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1672,6 +1677,12 @@ extern "C" int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
 // kernel run behind it -- without the statistics pass, and without the apply pass where the consumer is another folded conv.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
+// fp16 apply passes: tensors that cannot stay in the caches until their next use anyway (>= 32 MB: the cfg-5 batch) are read
+// with non-temporal loads (RN_F16_NT=0: never; =1: always)
+int f16_nt_loads(double bytes) {
+  static const int mode = getenv("RN_F16_NT") ? atoi(getenv("RN_F16_NT")) : -1;
+  return mode >= 0 ? (mode != 0) : (bytes >= 33554432.0);
+}
 // rn_group_norm_finalize for rows whose channels split into 64-channel slabs of whole groups: block = (sample, slab), thread =
 // (channel of the slab, one of four row lanes) -- every load instruction of a wave reads 256 contiguous bytes of a row (the
 // per-group kernel above reads one float per lane from `cpg`-wide pieces of `rows` different rows: 12.7 us per launch at cfg 5,
@@ -1750,6 +1761,7 @@ extern "C" int rn_group_norm_apply_f16(const void* x, const void* residual, void
   GnArgs a = {};
   a.nseg = 1; a.c = c; a.groups = groups; a.cpg = c / groups; a.act = act; a.act_after_res = act_after_residual ? 1 : 0;
   a.in_half = a.out_half = 1;
+  a.nt_loads = f16_nt_loads((double)n * hw * c * 2.0);
   a.gamma = gamma; a.beta = beta;
   GnSeg& d = a.seg[0];
   d.x = (const float*)x; d.y = (float*)y; d.res = (const float*)residual;
