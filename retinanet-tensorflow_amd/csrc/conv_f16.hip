@@ -104,7 +104,9 @@ template <int BM, int BN, int WM, int WN, int VEC, bool TAPU, int FOLD, int PIPE
 __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args) {
   constexpr int T = WM * WN * 64;
   constexpr bool FIN = (FOLD & 1) != 0, FOUT = (FOLD & 2) != 0, FIN_RELU = (FOLD & 4) != 0;
-  __shared__ float2 ntab[FIN ? 2048 : 1];            // (scale, shift) of every input channel of the tile's sample
+  // (scale, shift) of every input channel of the tile's sample; the pipelined variant keeps the table in the half of its dynamic
+  // LDS that the weight tiles do not use (PIPE == 2 reads its weights from the fragment-ordered copy) -- 160 KB are all there is
+  __shared__ float2 ntab_st[(FIN && !PIPE) ? 2048 : 1];
   __shared__ float sred[FOUT ? WM * BN * 2 : 1];
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int KQ = BK / VEC, RPP = T / KQ, A_PASS = BM / RPP, B_PASS = BN / RPP;
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
   extern __shared__ __attribute__((aligned(16))) _Float16 dyn_smem[];
   __shared__ __attribute__((aligned(16))) _Float16 st_smem[PIPE ? 8 : BUF];
   _Float16* smem = PIPE ? dyn_smem : st_smem;
+  float2* ntab = (FIN && PIPE) ? reinterpret_cast<float2*>(dyn_smem + 2 * BM * LDH) : ntab_st;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
     // Per K-tile and wave that removes 4 of the 8 `ds_write_b128` (what the leave-one-out builds name as the loop's cost), 8 of
     // the 24 fragment reads and the B tiles' LDS; the 8 fragments of tile t+1 are requested as the MFMAs of tile t release
     // their registers, a full tile ahead of their use.
-    static_assert(!FIN && TAPU && VEC == 8 && TM == 4 && TN == 2 && A_PASS == 4 && BK == 64, "PIPE: the 256 x 256 / 8-wave shape");
+    static_assert((!FIN || FIN_RELU) && TAPU && VEC == 8 && TM == 4 && TN == 2 && A_PASS == 4 && BK == 64, "PIPE: the 256 x 256 / 8-wave shape");
 #define SB() __builtin_amdgcn_sched_barrier(0)
     half8 fa[2][TM], fbg[4][TN];
     const int arow = (wm * (BM / WM) + l31) * LDH + half * 8;
@@ -410,7 +413,28 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
       ra[i] = VecH<VEC>::load(xa, ok ? (unsigned)(rowoff[i] + l_tap) * 2u : OOB);
     };
     const int st_off = r0 * LDH + kq * VEC;
-    auto stA = [&](_Float16* buf, int i) { *reinterpret_cast<vec_t*>(&buf[st_off + i * RPP * LDH]) = ra[i]; };
+    // FIN (1 x 1 convs only: the host checks; a tile is then the channels [64 kt, 64 kt + 64) of 256 pixels, no padding taps):
+    // ReLU(GN(x)) of a vector between its staging registers and LDS -- the table entries of the tile on its way to LDS (two float4
+    // pairs per lane, read once per K-tile), one mixed-precision fma per element, one packed max per pair
+    float4 tq[FIN ? 4 : 1];
+    auto ldT = [&](int kt) {
+      if constexpr (FIN) {
+        const float4* tp = reinterpret_cast<const float4*>(ntab + min(kt * BK + kq * VEC, 2040));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tq[j] = tp[j];
+      }
+    };
+    auto stA = [&](_Float16* buf, int i) {
+      if constexpr (FIN) {
+        typedef uint32_t pairs_t __attribute__((ext_vector_type(4)));
+        pairs_t pv = __builtin_bit_cast(pairs_t, ra[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = fma_mix_pair(pv[j], tq[j].x, tq[j].y, tq[j].z, tq[j].w);
+        const vec_t zero = {};
+        ra[i] = __builtin_elementwise_max(__builtin_bit_cast(vec_t, pv), zero);
+      }
+      *reinterpret_cast<vec_t*>(&buf[st_off + i * RPP * LDH]) = ra[i];
+    };
     // fragment (32-channel block nt, 16-k step kidx) starts at ((nt * K/16 + kidx) * 64 lanes) * 16 bytes; channel blocks past
     // the (padded) kernel are out of the descriptor's range: zeros
     const int ks16 = ktotal >> 4;
@@ -433,6 +457,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
     for (int i = 0; i < 4; ++i) ldA(i);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { ldBf(0, ks, 0); ldBf(0, ks, 1); }
+    ldT(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) stA(smem, i);
     prep(1);
@@ -446,6 +471,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
       const _Float16* Ac = smem + (kt & 1) * ABUF;
       _Float16* An = smem + ((kt + 1) & 1) * ABUF;
       prep(kt + 2);
+      ldT(kt + 1);
       SB();
       // K-step 0 (slot 0) | A fragments of K-step 1 -> slot 1 | A0 A1: tile t+1 -> LDS, tile t+2 <- memory | B fragments (t+1, 0)
       mf(0, 0, 0, 0); SB(); rdA(Ac, 1, 1, 0); stA(An, 0); SB();
@@ -743,7 +769,12 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
     // 861-904 vs 760 TFLOP/s on the 3x3 head convs of a 1024^2 batch of 16, 619 vs 544 on a 1x1 512->256
     long big = 0;
     for (int s = 0; s < nseg; ++s) big += (long)rn::ceil_div(a.seg[s].m, 256) * rn::ceil_div(a.seg[s].cout, 256);
-    if (G == 1 && (long)g->kh * g->kw * g->cin >= 512 && big >= 512 && a.cin_g % 8 == 0) c = 5;
+    // (1 x 1 convs whose output channels fill whole 256-wide tiles take it from K = 128: cfg 5's conv 3 / projection convs
+    // 237 vs 290 us at 128 -> 256, 155 vs 196 us at 256 -> 512; a 128-wide output would waste half of every tile: 262 vs 189 us)
+    static const long min_k_env = getenv("RN_F16_PIPE_MIN_K") ? atol(getenv("RN_F16_PIPE_MIN_K")) : 0;     // (tuning aid)
+    const bool whole_n = g->kh == 1 && g->kw == 1 && nseg == 1 && a.seg[0].cout % 256 == 0;
+    const long min_k = min_k_env > 0 ? min_k_env : (whole_n ? 128 : 512);
+    if (G == 1 && (long)g->kh * g->kw * g->cin >= min_k && big >= 512 && a.cin_g % 8 == 0) c = 5;
   }
   a.tpg = G > 1 ? rn::ceil_div(cout_g, kCfgs[c].bn) : (1 << 20);
   int tiles = 0;
@@ -803,16 +834,22 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
   // the 256 x 256 tile, dense taps, no input-side fold: the software-pipelined variants (147 KB of dynamic LDS); RN_F16_PIPE: 0 the
   // plain loop, 1 both operands through LDS, 2 (default) the weight fragments straight from the fragment-ordered copy
   static const int pipe_mode = getenv("RN_F16_PIPE") ? atoi(getenv("RN_F16_PIPE")) : 2;
-  if (c == 5 && tapu && pipe_mode && G == 1 && (fbits == 0 || fbits == 2)) {
+  // (an input-side fold rides along where it is a ReLU GroupNorm in front of a 1 x 1 conv: ResNeXt's conv 3)
+  const bool fin_pipe = fbits == 3 && pipe_mode == 2 && g->kh == 1 && g->kw == 1 && g->stride == 1 && a.fold.in_act == RN_ACT_RELU &&
+                        nseg == 1 && a.seg[0].wf != nullptr;
+  if (c == 5 && tapu && pipe_mode && G == 1 && (fbits == 0 || fbits == 2 || fin_pipe)) {
     constexpr size_t lds = 2 * (256 + 256) * LDH * sizeof(_Float16);
     static const bool attr_ = (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
                               (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
                               (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
-                              (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
+                              (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) &&
+                              (hipFuncSetAttribute((const void*)conv_f16_kernel<256, 256, 2, 4, 8, true, 7, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
     if (attr_) {           // (refused: the plain loop below computes the same bits from 36 KB of static LDS)
       bool frag = pipe_mode == 2;
       for (int s = 0; s < nseg; ++s) frag = frag && a.seg[s].wf != nullptr;
-      if (frag) {
+      if (fin_pipe) {
+        hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 7, 2>), dim3(tiles), dim3(512), lds, st, a);
+      } else if (frag) {
         if (fbits == 2) hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 2, 2>), dim3(tiles), dim3(512), lds, st, a);
         else hipLaunchKernelGGL((conv_f16_kernel<256, 256, 2, 4, 8, true, 0, 2>), dim3(tiles), dim3(512), lds, st, a);
       } else {

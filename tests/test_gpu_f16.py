@@ -233,3 +233,37 @@ def test_group_norm_finalize_matches_fp64(dev, n, rows, c, groups):
     var = np.maximum(s[1] / (hw * cpg) - m * m, 0.0)
     assert_close(mean.cpu().numpy(), m.astype(np.float32), 1e-6, "mean")
     assert_close(rstd.cpu().numpy(), (1.0 / np.sqrt(var + 1e-5)).astype(np.float32), 1e-6, "rstd")
+
+
+@pytest.mark.parametrize("size,cmid,cout", [(32, 128, 256), (16, 64, 512), (32, 320, 256)])
+def test_pipelined_conv_with_groupnorm_on_load(dev, monkeypatch, size, cmid, cout):
+    """ResNeXt's conv 3 on the software-pipelined 256 x 256 kernel (forced onto a small shape): ReLU(GN(y2)) applied between the
+    staging registers and LDS (one mixed-precision fma per element) against the same conv on the MATERIALISED ReLU(GN(y2)) -- the
+    same fp32 arithmetic on the same fp16 values: equal to an fp16 rounding (1e-3 of the range); its output statistics against
+    fp64 sums of its own output.  2, 1 and 5 K-tiles."""
+    import layers, ops_f16
+    monkeypatch.setenv("RN_CONV_CFG", "5")
+    g = torch.Generator().manual_seed(cmid + cout)
+    x = (torch.randn(2, size, size, cmid, generator=g) * 1.5 + 0.3).to(dev).half()
+    w2 = (torch.randn(1, 1, cmid, cmid, generator=g) / cmid ** 0.5).to(dev)
+    w3 = (torch.randn(1, 1, cmid, cout, generator=g) / cmid ** 0.5).to(dev)
+
+    class Norm(object):
+        def __init__(self, c):
+            self.groups, self.eps = 32, 1e-5
+            self.gamma = (1 + 0.2 * torch.randn(c, generator=g)).to(dev)
+            self.beta = (0.1 * torch.randn(c, generator=g)).to(dev)
+        def build(self, c, d):
+            pass
+    n2, n3 = Norm(cmid), Norm(cout)
+    p2 = ops_f16.conv2d_norm(x, w2, n2, act='relu')
+    assert p2 is not None
+    folded = ops_f16.conv2d_norm(p2, w3, n3, act='relu')            # GroupNorm + ReLU on load
+    plain = ops_f16.conv2d_norm(p2.materialise(), w3, n3, act='relu')
+    assert folded is not None and plain is not None
+    assert_close(folded.y.float().cpu().numpy(), plain.y.float().cpu().numpy(), 1e-3, "conv 3: GroupNorm on load vs materialised input")
+    y = folded.y.float().cpu().numpy().astype(np.float64).reshape(2, size * size, 32, cout // 32)
+    mean = y.mean(axis=(1, 3))
+    rstd = 1.0 / np.sqrt(y.var(axis=(1, 3)) + 1e-5)
+    assert_close(folded.mean.cpu().numpy(), mean.astype(np.float32), 1e-5, "statistics of the folded conv: mean")
+    assert_close(folded.rstd.cpu().numpy(), rstd.astype(np.float32), 1e-4, "statistics of the folded conv: rstd")

@@ -34,8 +34,26 @@ def main(backbone="resnet_50", size=1024, batch=16, iters=5):
             run()
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / iters
+        # the same pass replayed from ONE hipGraph (static input buffer, static outputs: what a serving loop at a fixed shape does)
+        graph_ips = None
+        if os.environ.get("RN_INF_GRAPH", "1") == "1":
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    og = run()
+                g.replay(); torch.cuda.synchronize()
+                assert og[5].cpu().tolist()[:2] == counts[:2], "graph replay: candidate / survivor counts differ from the eager pass"
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    g.replay()
+                torch.cuda.synchronize()
+                graph_ips = round(batch * iters / (time.perf_counter() - t0), 2)
+                del g, og
+            except Exception as e:       # (reported, not fatal: the eager figure stands)
+                graph_ips = "failed: %s" % (str(e)[:120],)
         print(json.dumps({"backbone": backbone, "image_size": size, "batch": batch, "dtype": dtype,
                           "images_per_sec": round(batch / el, 2), "ms_per_batch": round(el * 1e3, 2),
+                          "images_per_sec_graph": graph_ips,
                           "candidates": counts[0], "kept": counts[1], "conv_TFLOPs": round(596.0 * batch / el / 1e3, 1),
                           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
     layers.set_inference_dtype("f32")
