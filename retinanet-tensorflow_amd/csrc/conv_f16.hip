@@ -642,6 +642,134 @@ __global__ void pack_weights_frag_kernel(const float* __restrict__ w, _Float16* 
   wf[i] = n < cout ? (_Float16)w[(size_t)k * cout + n] : (_Float16)0.f;
 }
 
+// =====================================================================================================================
+// Grouped 3 x 3 / stride 1 conv with as many input as output channels per group (ResNeXt's conv 2: 32 groups of 4 / 8 / 16 / 32):
+// the implicit-GEMM kernel above runs one group per N-tile -- a [128 x 9 cin_g] x [9 cin_g x cout_g] product whose operand
+// gather reads 8 - 64 bytes per (pixel, tap) and whose 32-wide N-tile holds 4 - 32 useful columns: 2.0 - 2.5 x the time its
+// bytes take.  Here a block owns a 16 x 16 tile of output pixels of one sample and one SUPER-GROUP of 32 consecutive channels
+// (= 8 / 4 / 2 / 1 groups): the 18 x 18 x 32 input patch goes to LDS ONCE (64 contiguous bytes per pixel; 1.27 x the tile, not
+// 9 x), the super-group's kernel is block-diagonal over its groups (zeros elsewhere: the matrix cores are not the bound) and
+// sits in registers in MFMA-fragment order (18 fragments per lane from rn_pack_weights_f16's third copy), and the nine taps are
+// nine shifted fragment reads of the same patch: 36 MFMAs and 36 `ds_read_b128` per wave, no barrier inside.
+//   wave w: output rows [4 w, 4 w + 4) of the tile = two 32-pixel M-tiles (2 rows x 16 columns each)
+//   patch pixel stride 80 bytes: the 16 pixels of a row a half-wave reads land on 16 different 16-byte bank groups
+// The epilogue is the one of the kernel above (tile staged through LDS, 16-byte stores, statistics of the values as stored).
+// =====================================================================================================================
+struct G3Args {
+  const _Float16* x; const _Float16* ws; _Float16* y; float* partial;
+  int n, h, w, c, tiles_w, tiles_per_sample, nsg, prows;
+};
+constexpr int G3_PW = 18, G3_PST = 40;      // patch width (pixels), pixel stride (halfs)
+
+template <bool FOUT>
+__global__ __launch_bounds__(256) void conv3x3_sg32_f16_kernel(const G3Args a) {
+  __shared__ __attribute__((aligned(16))) _Float16 patch[G3_PW * G3_PW * G3_PST];     // 25 920 bytes; later: the staged output tile
+  __shared__ float sred[FOUT ? 4 * 32 * 2 : 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
+  const int sg = bid % a.nsg;                        // super-groups of one tile are neighbours: they share the pixels' cache lines
+  const int t = bid / a.nsg;
+  const int tile = t % a.tiles_per_sample, smp = t / a.tiles_per_sample;
+  const int ty0 = (tile / a.tiles_w) * 16, tx0 = (tile % a.tiles_w) * 16;
+  const int H = a.h, W = a.w, C = a.c;
+  const __amdgpu_buffer_rsrc_t xs = make_rsrc(a.x + (size_t)smp * H * W * C, (unsigned)H * W * C * 2u);
+  // ---- everything from memory first: the patch (<= 6 chunks of 16 bytes per thread), the 18 weight fragments
+  constexpr int NCH = G3_PW * G3_PW * 4, PER = (NCH + 255) / 256;
+  half8 pv[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int e = tid + j * 256;
+    const int pix = min(e, NCH - 1) >> 2, q = e & 3;
+    const int py = pix / G3_PW, px = pix - py * G3_PW;
+    const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+    const bool ok = e < NCH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    pv[j] = VecH<8>::load(xs, ok ? (unsigned)((gy * W + gx) * C + sg * 32 + q * 8) * 2u : OOB);     // (SAME padding: zeros)
+  }
+  half8 bw[9][2];
+  const half8* wsp = reinterpret_cast<const half8*>(a.ws) + (size_t)sg * 18 * 64 + lane;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) bw[tap][ks] = wsp[(tap * 2 + ks) * 64];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int e = tid + j * 256;
+    if (e < NCH) *reinterpret_cast<half8*>(&patch[(e >> 2) * G3_PST + (e & 3) * 8]) = pv[j];
+  }
+  __syncthreads();
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int ry = l31 >> 4, rx = l31 & 15;
+  const _Float16* ap = patch + ((4 * wave + ry) * G3_PW + rx) * G3_PST + khalf * 8;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const half8 a0 = *reinterpret_cast<const half8*>(ap + (kh * G3_PW + kw) * G3_PST + ks * 16);
+        const half8 a1 = *reinterpret_cast<const half8*>(ap + ((kh + 2) * G3_PW + kw) * G3_PST + ks * 16);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bw[kh * 3 + kw][ks], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bw[kh * 3 + kw][ks], acc[1], 0, 0, 0);
+      }
+  __syncthreads();                                 // the patch is dead: the staged output tile takes its place
+  // C/D map: col (channel) = lane & 31, pixel of the M-tile = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  _Float16* cs = patch + wave * (64 * G3_PST);     // [64 pixels of the wave][32 channels], pixel stride 80 bytes
+  float st1 = 0.f, st2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const _Float16 hv = (_Float16)acc[i][r];
+      cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * G3_PST + l31] = hv;
+      if (FOUT) { const float fv = (float)hv; st1 += fv; st2 = fmaf(fv, fv, st2); }
+    }
+  __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the wave's own stores have landed (a wave reads only its own region)
+  __builtin_amdgcn_wave_barrier();
+  const __amdgpu_buffer_rsrc_t ys = make_rsrc(a.y + (size_t)smp * H * W * C, (unsigned)H * W * C * 2u);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = lane + j * 64;                   // chunk of the wave's 64 pixels x 4 x 16 bytes
+    const int p = e >> 2, q = e & 3;
+    const int gy = ty0 + 4 * wave + (p >> 4), gx = tx0 + (p & 15);
+    const u32x4 d = *reinterpret_cast<const u32x4*>(&cs[p * G3_PST + q * 8]);
+    __builtin_amdgcn_raw_buffer_store_b128(d, ys, (unsigned)((gy * W + gx) * C + sg * 32 + q * 8) * 2u, 0, 0);
+  }
+  if (FOUT) {
+    st1 += __shfl_xor(st1, 32, 64);
+    st2 += __shfl_xor(st2, 32, 64);
+    if (lane < 32) { sred[(wave * 32 + lane) * 2 + 0] = st1; sred[(wave * 32 + lane) * 2 + 1] = st2; }
+    __syncthreads();
+    if (tid < 32) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < 4; ++w_) { t1 += sred[(w_ * 32 + tid) * 2 + 0]; t2 += sred[(w_ * 32 + tid) * 2 + 1]; }
+      float* p1 = a.partial + (size_t)(smp * a.tiles_per_sample + tile) * C + sg * 32 + tid;
+      p1[0] = t1;
+      p1[(size_t)a.prows * C] = t2;
+    }
+  }
+}
+
+// Ws[cout / 32][9 taps][2 k-steps][lane][8]: the block-diagonal 32 x 32 kernel of a super-group in MFMA-fragment order -- lane l
+// holds output channel (l & 31) and input channels 16 step + 8 (l >> 5) .. + 7 of the super-group; zero where the two channels
+// belong to different groups (groups of cin_g input AND cin_g output channels)
+__global__ void pack_weights_sg_kernel(const float* __restrict__ w, _Float16* __restrict__ ws, int cin_g, int cout, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i & 7), l = (int)((i >> 3) & 63);
+  const int64_t f = i >> 9;
+  const int ks = (int)(f & 1), tap = (int)((f >> 1) % 9), sg = (int)(f / 18);
+  const int k = ks * 16 + (l >> 5) * 8 + e, n = l & 31;
+  const int ci = sg * 32 + k, co = sg * 32 + n;
+  const bool same = ci / cin_g == co / cin_g;
+  ws[i] = same ? (_Float16)w[(size_t)(tap * cin_g + ci % cin_g) * cout + co] : (_Float16)0.f;
+}
+
 __global__ void cast_f32_to_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int64_t count) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = (_Float16)x[i];
@@ -668,12 +796,25 @@ namespace {
 // the fragment-ordered copy starts this many halfs behind Wt (256-byte aligned); 0: there is none (K % 16 != 0)
 inline int64_t frag_offset_halfs(int64_t ktotal, int64_t cout) { return (ktotal & 15) ? 0 : (int64_t)(rn::align_up((size_t)(ktotal * cout * 2), 256) / 2); }
 inline int64_t frag_halfs(int64_t ktotal, int64_t cout) { return (ktotal & 15) ? 0 : ((cout + 31) / 32) * 32 * ktotal; }
+// the super-group copy of a 3 x 3 kernel with 4 / 8 / 16 / 32 input channels per group (pack_weights_sg_kernel; read as a grouped
+// kernel with as many output channels per group) starts 256-byte aligned behind whatever precedes it; 0: there is none
+inline bool sg_shape(int kh, int kw, int cin_g, int cout) {
+  return kh == 3 && kw == 3 && (cin_g == 4 || cin_g == 8 || cin_g == 16 || cin_g == 32) && cout % 32 == 0;
+}
+inline int64_t sg_offset_halfs(int kh, int kw, int cin_g, int cout) {
+  if (!sg_shape(kh, kw, cin_g, cout)) return 0;
+  const int64_t k = (int64_t)kh * kw * cin_g, off = frag_offset_halfs(k, cout);
+  const int64_t end = off ? off + frag_halfs(k, cout) : k * cout;
+  return (int64_t)(rn::align_up((size_t)(end * 2), 256) / 2);
+}
+inline int64_t sg_halfs(int cout) { return (int64_t)(cout / 32) * 18 * 64 * 8; }
 }  // namespace
 
 extern "C" size_t rn_pack_weights_f16_bytes(int kh, int kw, int cin_g, int cout) {
   if (kh < 1 || kw < 1 || cin_g < 1 || cout < 1) return 0;
   const int64_t k = (int64_t)kh * kw * cin_g;
   const int64_t off = frag_offset_halfs(k, cout);
+  if (const int64_t so = sg_offset_halfs(kh, kw, cin_g, cout)) return (size_t)(so + sg_halfs(cout)) * 2;
   return (size_t)(off ? (off + frag_halfs(k, cout)) * 2 : k * cout * 2);
 }
 
@@ -688,6 +829,12 @@ extern "C" int rn_pack_weights_f16(const float* w, void* wt, int kh, int kw, int
     const int64_t ftotal = frag_halfs(k, cout);
     hipLaunchKernelGGL(pack_weights_frag_kernel, dim3((unsigned)rn::ceil_div64(ftotal, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        (_Float16*)wt + off, (int)k, cout, ftotal);
+    RN_LAUNCH_CHECK();
+  }
+  if (const int64_t so = sg_offset_halfs(kh, kw, cin_g, cout)) {
+    const int64_t stotal = sg_halfs(cout);
+    hipLaunchKernelGGL(pack_weights_sg_kernel, dim3((unsigned)rn::ceil_div64(stotal, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (_Float16*)wt + so, cin_g, cout, stotal);
     RN_LAUNCH_CHECK();
   }
   return RN_OK;
@@ -714,6 +861,11 @@ extern "C" int rn_pad_cast_rgb_f16(const float* x, void* y, int64_t pixels, rn_s
 }
 
 namespace {
+bool shape_ok_but_fin(bool sg_on, const rn_f16_fold* fold, int nseg, int G, const rn_conv_geom* g, int64_t so, int cout_g, int cin_g, const SegH& d,
+                      int out_f32) {
+  return sg_on && fold && fold->in_mean && nseg == 1 && G > 1 && g->stride == 1 && so != 0 && cout_g == cin_g && d.cout == g->cin &&
+         d.h % 16 == 0 && d.w % 16 == 0 && !out_f32;
+}
 // fold == nullptr: the plain convolution.  rows_out != nullptr: dry run -- *rows_out = m-tile rows per sample the statistics
 // would take (0: this shape cannot fold), nothing is launched.
 int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int out_f32, const rn_f16_fold* fold, int* rows_out,
@@ -750,6 +902,32 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
                    "conv f16: a tensor of segment %d is >= 2 GiB", s);
   }
   const int cout_g = a.seg[0].cout / G;
+  {
+    // ResNeXt's conv 2 on 16 x 16 pixel tiles of 32-channel super-groups (conv3x3_sg32_f16_kernel); RN_F16_SG=0: the implicit GEMM
+    static const bool sg_on = !(getenv("RN_F16_SG") && atoi(getenv("RN_F16_SG")) == 0);
+    const SegH& d = a.seg[0];
+    const int64_t so = sg_offset_halfs(g->kh, g->kw, a.cin_g, d.cout);
+    const bool shape_ok = sg_on && nseg == 1 && G > 1 && g->stride == 1 && so != 0 && cout_g == a.cin_g && d.x_ld == g->cin && d.x_coff == 0 &&
+                          d.cout == g->cin && d.h % 16 == 0 && d.w % 16 == 0 && !out_f32 && d.bias == nullptr &&
+                          segs[0].wgt_bytes >= (int64_t)rn_pack_weights_f16_bytes(g->kh, g->kw, a.cin_g, d.cout) &&
+                          !(fold && fold->in_mean);
+    // (the dry run cannot know about an input-side fold: the row count it reports is this kernel's)
+    RN_UNSUPPORTED(shape_ok_but_fin(sg_on, fold, nseg, G, g, so, cout_g, a.cin_g, d, out_f32),
+                   "conv f16 fold: a GroupNorm on the operand load of a grouped 3 x 3 conv needs RN_F16_SG=0 (the super-group kernel reads materialised inputs)");
+    if (shape_ok) {
+      const int rows = (d.h / 16) * (d.w / 16);
+      if (rows_out) { *rows_out = rows; return RN_OK; }
+      G3Args ga = {};
+      ga.x = d.x; ga.ws = d.wt + so; ga.y = (_Float16*)d.y; ga.partial = fold ? fold->partial : nullptr;
+      ga.n = d.n; ga.h = d.h; ga.w = d.w; ga.c = d.cout; ga.tiles_w = d.w / 16; ga.tiles_per_sample = rows; ga.nsg = d.cout / 32;
+      ga.prows = d.n * rows;
+      const unsigned blocks = (unsigned)((long)d.n * rows * ga.nsg);
+      if (ga.partial) hipLaunchKernelGGL(conv3x3_sg32_f16_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ga);
+      else hipLaunchKernelGGL(conv3x3_sg32_f16_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ga);
+      RN_LAUNCH_CHECK();
+      return RN_OK;
+    }
+  }
   int c;
   if (const char* force = getenv("RN_CONV_CFG")) {
     c = atoi(force) % 6;

@@ -114,6 +114,8 @@ def conv2d(x, w, bias=None, stride=1, groups=1, out_f32=False):
 # ---------------------------------------------------------------------------------------------------------------------
 import os
 FOLD_INTO_3X3 = os.environ.get("RN_F16_FOLD_3X3", "0") == "1"     # also apply a pending GroupNorm on the operand load of 3 x 3 convs
+if FOLD_INTO_3X3:
+    os.environ.setdefault("RN_F16_SG", "0")         # (the super-group kernel of the grouped 3 x 3 convs reads materialised inputs)
 FOLD = os.environ.get("RN_F16_FOLD", "1") == "1"     # (0: conv, then the three-kernel GroupNorm, as before -- A/B measurements, tests)
 
 

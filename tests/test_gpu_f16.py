@@ -27,6 +27,10 @@ CASES = [
     (2, 12, 12, 128, 128, 3, 1, 32, False, False),     # ResNeXt stage 2: 4 channels per group (8-byte gathers)
     (2, 10, 10, 256, 256, 3, 2, 32, False, False),     # 8 per group, stride 2
     (1, 6, 6, 1024, 1024, 3, 1, 32, False, False),     # 32 per group
+    (2, 16, 32, 128, 128, 3, 1, 32, False, False),     # maps of whole 16 x 16 tiles: the super-group kernel (conv3x3_sg32_f16_kernel), 4 per group
+    (1, 32, 16, 256, 256, 3, 1, 32, False, False),     # 8 per group
+    (1, 16, 16, 512, 512, 3, 1, 32, False, False),     # 16 per group
+    (2, 16, 16, 1024, 1024, 3, 1, 32, False, False),   # 32 per group: one group per super-group
     (1, 5, 5, 2048, 256, 1, 1, 1, False, False),
 ]
 
@@ -72,14 +76,19 @@ def test_packed_kernel_layout(dev):
     import _rn
     L = _rn.lib()
     rng = np.random.default_rng(11)
-    for kh, kw, cin_g, cout in ((3, 3, 32, 40), (1, 1, 64, 256), (3, 3, 4, 24)):        # the last one: K = 36, no fragment copy
+    # (3, 3, 4, 24): K = 36, no fragment copy; the last two: 3 x 3 kernels of 8 / 32 channels per group with cout % 32 == 0 carry a
+    # third copy, Ws[cout / 32][9 taps][2][64 lanes][8]: the block-diagonal 32 x 32 kernel of every 32-channel super-group
+    for kh, kw, cin_g, cout in ((3, 3, 32, 40), (1, 1, 64, 256), (3, 3, 4, 24), (3, 3, 8, 64), (3, 3, 32, 64)):
         w = rng.standard_normal((kh, kw, cin_g, cout)).astype(np.float32)
         K = kh * kw * cin_g
         nbytes = int(L.rn_pack_weights_f16_bytes(kh, kw, cin_g, cout))
         frag = K % 16 == 0
         off = (cout * K * 2 + 255) // 256 * 256 // 2
         rows = (cout + 31) // 32 * 32
-        assert nbytes == ((off + rows * K) * 2 if frag else cout * K * 2)
+        end = (off + rows * K) if frag else cout * K
+        sg = kh == 3 and kw == 3 and cin_g in (4, 8, 16, 32) and cout % 32 == 0
+        sg_off = (end * 2 + 255) // 256 * 256 // 2
+        assert nbytes == ((sg_off + cout // 32 * 18 * 64 * 8) * 2 if sg else end * 2)
         buf = torch.zeros(nbytes // 2, dtype=torch.float16, device=dev)
         _rn.check(L.rn_pack_weights_f16(_rn.f32(torch.from_numpy(w).to(dev)), _rn.f16(buf), kh, kw, cin_g, cout, _rn.stream()),
                   "rn_pack_weights_f16")
@@ -93,6 +102,16 @@ def test_packed_kernel_layout(dev):
             k = np.arange(K // 16)[None, :, None, None] * 16 + ((lane >> 5) * 8)[None, None, :, None] + np.arange(8)[None, None, None, :]
             want = np.where(n < cout, wk[k, np.minimum(n, cout - 1)], np.float16(0))
             np.testing.assert_array_equal(wf, want)
+        if sg:
+            ws = got[sg_off:sg_off + cout // 32 * 18 * 64 * 8].reshape(cout // 32, 9, 2, 64, 8)
+            lane = np.arange(64)
+            sgi = np.arange(cout // 32)[:, None, None, None, None]
+            tap = np.arange(9)[None, :, None, None, None]
+            kk = np.arange(2)[None, None, :, None, None] * 16 + ((lane >> 5) * 8)[None, None, None, :, None] + np.arange(8)[None, None, None, None, :]
+            ci, co = sgi * 32 + kk, sgi * 32 + (lane & 31)[None, None, None, :, None]
+            w16 = w.reshape(9, cin_g, cout).astype(np.float16)
+            want = np.where(ci // cin_g == co // cin_g, w16[tap, ci % cin_g, co], np.float16(0))
+            np.testing.assert_array_equal(ws, want)
 
 
 def test_group_norm_pool_upsample_f16(dev):
