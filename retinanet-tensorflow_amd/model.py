@@ -64,6 +64,25 @@ class Sequential(Model):
                 input = layer(input, norm=self.layers[i + 1])    # the conv also emits the GroupNorm's statistics where it can
                 i += 1
                 continue
+            if (L.INFERENCE_F16 and not training and isinstance(layer, L.Conv2D) and i + 1 < n
+                    and isinstance(self.layers[i + 1], L.GroupNormalization) and torch.is_tensor(input) and input.is_cuda
+                    and input.dtype == torch.float16 and layer.weight is not None and layer.bias is None):
+                # fp16 inference: the GroupNorm's statistics from the conv's epilogue (ops_f16.conv2d_norm) -- no statistics pass
+                # over the conv output; the GroupNorm [+ activation] is then ONE apply pass.  Dropout is the identity here.
+                import ops_f16
+                j, act = i + 2, None
+                if j < n and L.activation_name(self.layers[j]) is not None:
+                    act, j = L.activation_name(self.layers[j]), j + 1
+                if j < n and isinstance(self.layers[j], L.Dropout):
+                    j += 1
+                p = ops_f16.conv2d_norm(input, layer.weight, self.layers[i + 1], act, layer.strides, layer.groups) if ops_f16.FOLD else None
+                if p is not None:
+                    res = residual if j == n else None
+                    input = p.materialise(residual=res)
+                    if res is not None:
+                        residual = None
+                    i = j
+                    continue
             target = layer.call if isinstance(layer, Model) else layer
             if isinstance(layer, torch.nn.Module) and not isinstance(layer, Model):
                 target = layer.forward
