@@ -48,7 +48,7 @@ typedef struct rn_reduce_list rn_reduce_list;
 
 /* Version of this header's ABI: bumped whenever an entry point's arguments or a struct layout change.  rn_version() returns
  * the value the library was built with; a caller built against another value must not call anything else. */
-#define RN_API_VERSION 402
+#define RN_API_VERSION 403
 int rn_version(void);
 const char* rn_last_error(void);
 
@@ -404,6 +404,11 @@ int rn_maxpool_fwd(const float* x, float* y, uint8_t* argmax, int n, int h, int 
 /* fp16-storage forward variants for the inference path (same semantics) */
 int rn_act_fwd_f16(const void* x, void* y, int64_t count, int act, rn_stream_t stream);
 int rn_maxpool_fwd_f16(const void* x, void* y, int n, int h, int w, int c, int k, int stride, rn_stream_t stream);
+/* fp16 inference: y = maxpool_kxk/stride(act(GroupNorm(x))) from the RAW conv output x [n,h,w,c] (fp16) and the GroupNorm's
+ * per-(sample, group) mean / rstd (rn_group_norm_finalize): ResNeXt's stem (resnet.py:192-201: conv, normalization, relu,
+ * max_pooling2d) without writing the normalised tensor.  Bit-equal to rn_group_norm_apply_f16 followed by rn_maxpool_fwd_f16. */
+int rn_maxpool_gn_fwd_f16(const void* x, void* y, int n, int h, int w, int c, int k, int stride, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, int groups, int act, rn_stream_t stream);
 int rn_upsample_add_fwd_f16(const void* lateral, const void* top, void* y, int n, int h, int w, int th, int tw, int c,
                             rn_stream_t stream);
 /* two forms of the same gradient: from x (re-scans every window) or from the forward pass's argmax bytes (5 bytes

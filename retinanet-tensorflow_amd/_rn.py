@@ -19,7 +19,7 @@ LOSS_MODE = {"bce_dice": 0, "focal": 1}
 OPT = {"momentum": 0, "rmsprop": 1, "adam": 2}
 OPT_BLOCK = 1024
 LOSS_STATS_HEADER = 8
-API_VERSION = 402        # RN_API_VERSION of include/rn_hip.h these bindings were written against
+API_VERSION = 403        # RN_API_VERSION of include/rn_hip.h these bindings were written against
 
 
 class RnError(RuntimeError):
@@ -171,7 +171,7 @@ SYMBOLS = [
     "rn_dwgn_supported", "rn_dwgn_fwd", "rn_dwgn_bwd", "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad", "rn_depthwise_bwd",
     "rn_group_norm_sync_bytes", "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
-    "rn_pack_weights_f16", "rn_pack_weights_f16_bytes", "rn_cast_f32_to_f16", "rn_pad_cast_rgb_f16", "rn_conv2d_fwd_f16", "rn_conv2d_f16_fold_rows", "rn_conv2d_fwd_f16_fold", "rn_group_norm_finalize", "rn_group_norm_apply_f16", "rn_maxpool_fwd_f16", "rn_upsample_add_fwd_f16",
+    "rn_pack_weights_f16", "rn_pack_weights_f16_bytes", "rn_cast_f32_to_f16", "rn_pad_cast_rgb_f16", "rn_conv2d_fwd_f16", "rn_conv2d_f16_fold_rows", "rn_conv2d_fwd_f16_fold", "rn_group_norm_finalize", "rn_group_norm_apply_f16", "rn_maxpool_fwd_f16", "rn_maxpool_gn_fwd_f16", "rn_upsample_add_fwd_f16",
     "rn_act_fwd_f16", "rn_flip_width", "rn_dropout", "rn_dropout_strided", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_maxpool_bwd_arg", "rn_avgpool_fwd", "rn_avgpool_bwd",
     "rn_loss_workspace", "rn_loss_fwd", "rn_loss_bwd",
     "rn_iou", "rn_anchor_assign", "rn_anchor_assign_levels", "rn_anchor_assign_levels_pair", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
@@ -283,6 +283,7 @@ def lib():
         L.rn_group_norm_apply_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.rn_maxpool_fwd_f16.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
+        L.rn_maxpool_gn_fwd_f16.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p]
         L.rn_upsample_add_fwd_f16.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_act_fwd_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.rn_flip_width.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]

@@ -977,9 +977,12 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
     // a tile's rows must lie inside one sample, the fp16 staged epilogue must be the one that runs, one segment
     const SegH& d = a.seg[0];
     const int ohw = d.oh * d.ow;
-    const bool ok = nseg == 1 && vec8 && !out_f32 && (cout_g & 7) == 0 && ohw % kCfgs[c].bm == 0;
+    // (the output statistics do not care how the operands are gathered: the RGB stem's 4-channel vectors qualify; the input-side
+    // fold transforms whole 8-channel vectors)
+    const bool ok = nseg == 1 && !out_f32 && (cout_g & 7) == 0 && ohw % kCfgs[c].bm == 0;
     if (rows_out) { *rows_out = ok ? ohw / kCfgs[c].bm : 0; return RN_OK; }
     RN_UNSUPPORTED(!ok, "conv f16 fold: this shape cannot fold its GroupNorms (see rn_conv2d_f16_fold_rows)");
+    RN_UNSUPPORTED(fold->in_mean && !vec8, "conv f16 fold: a GroupNorm on the operand load needs input channels in multiples of 8");
     if (fold->in_mean) {
       RN_CHECK_ARG(fold->in_rstd && fold->in_gamma && fold->in_beta && fold->in_groups >= 1 && g->cin % fold->in_groups == 0,
                    "conv f16 fold: incomplete input GroupNorm");
@@ -1003,10 +1006,11 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
   } while (0)
 #define RN_F16(BM_, BN_, WM_, WN_)                                                                                  \
   do {                                                                                                              \
-    if (fbits == 2) RN_F16K(BM_, BN_, WM_, WN_, 2);                                                            \
+    if (fbits == 2 && vec8) RN_F16K(BM_, BN_, WM_, WN_, 2);                                                    \
     else if (fbits == 3 && a.fold.in_act == RN_ACT_RELU) RN_F16K(BM_, BN_, WM_, WN_, 7);                            \
     else if (fbits == 3) RN_F16K(BM_, BN_, WM_, WN_, 3);                                                            \
     else if (vec8) RN_F16K(BM_, BN_, WM_, WN_, 0);                                                                  \
+    else if (fbits == 2) hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 4, false, 2>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
     else hipLaunchKernelGGL((conv_f16_kernel<BM_, BN_, WM_, WN_, 4, false, 0>), dim3(tiles), dim3(WM_* WN_ * 64), 0, st, a); \
   } while (0)
   // the 256 x 256 tile, dense taps, no input-side fold: the software-pipelined variants (147 KB of dynamic LDS); RN_F16_PIPE: 0 the

@@ -123,6 +123,54 @@ __global__ void maxpool_fwd_kernel(const PoolArgs a) {
   }
 }
 
+// fp16 inference: max pool of act(GN(y)) straight from the RAW conv output y (ResNeXt's stem: conv -> GroupNorm -> ReLU -> 3x3/2
+// max pool at 512^2 x 64 x 16 images) -- the normalised 537 MB tensor is neither written nor read back.  Thread = (output pixel,
+// 8 channels); (scale, shift) of the sample's channels in LDS; fp32 arithmetic, one rounding to fp16 at the end: rounding is
+// monotone, so the result equals the max pool of the fp16-rounded normalised tensor bit for bit.
+struct PoolGnArgs {
+  const _Float16* x; _Float16* out; const float* mean; const float* rstd; const float* gamma; const float* beta;
+  int n, h, w, c, k, s, oh, ow, pt, pl, groups, act;
+};
+typedef _Float16 pool_half8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(T) void maxpool_gn_f16_kernel(const PoolGnArgs a) {
+  __shared__ float2 tab[2048];
+  const int smp = blockIdx.y, tid = threadIdx.x;
+  const int cpg = a.c / a.groups;
+  for (int c = tid; c < a.c; c += T) {
+    const int g = c / cpg;
+    const float sc = a.rstd[smp * a.groups + g] * a.gamma[c];
+    tab[c] = make_float2(sc, a.beta[c] - a.mean[smp * a.groups + g] * sc);
+  }
+  __syncthreads();
+  const int C8 = a.c >> 3;
+  const int64_t total = (int64_t)a.oh * a.ow * C8;
+  const _Float16* __restrict__ x = a.x + (size_t)smp * a.h * a.w * a.c;
+  _Float16* __restrict__ out = a.out + (size_t)smp * a.oh * a.ow * a.c;
+  for (int64_t i = (int64_t)blockIdx.x * T + tid; i < total; i += (int64_t)gridDim.x * T) {
+    const int q = (int)(i % C8);
+    const int p = (int)(i / C8);
+    const int ow_ = p % a.ow, oh_ = p / a.ow;
+    float sc[8], sh[8], m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float2 t = tab[q * 8 + j]; sc[j] = t.x; sh[j] = t.y; m[j] = -INFINITY; }
+    for (int kh = 0; kh < a.k; ++kh) {
+      const int ih = oh_ * a.s - a.pt + kh;
+      if ((unsigned)ih >= (unsigned)a.h) continue;
+      for (int kw = 0; kw < a.k; ++kw) {
+        const int iw = ow_ * a.s - a.pl + kw;
+        if ((unsigned)iw >= (unsigned)a.w) continue;           // (padded cells never win)
+        const pool_half8 v = *reinterpret_cast<const pool_half8*>(x + ((size_t)ih * a.w + iw) * a.c + q * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], rn::act_fwd(fmaf((float)v[j], sc[j], sh[j]), a.act));
+      }
+    }
+    pool_half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)m[j];
+    *reinterpret_cast<pool_half8*>(out + (size_t)i * 8) = o;
+  }
+}
+
 // gradient goes to the FIRST maximum of each window (row-major window order); gather form: every
 // input cell sums dy of the windows in which it is that first maximum => deterministic, no atomics
 __global__ void maxpool_bwd_kernel(const PoolArgs a) {
@@ -351,6 +399,24 @@ extern "C" int rn_maxpool_fwd_f16(const void* x, void* y, int n, int h, int w, i
   RN_CHECK_ARG(x && y, "maxpool fwd f16: null pointer");
   a.x = (const float*)x; a.out = (float*)y; a.is_half = 1;
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)n * a.oh * a.ow * (c / 4))), dim3(T), 0, (hipStream_t)stream, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+extern "C" int rn_maxpool_gn_fwd_f16(const void* x, void* y, int n, int h, int w, int c, int k, int stride, const float* mean,
+                                    const float* rstd, const float* gamma, const float* beta, int groups, int act, rn_stream_t stream) {
+  PoolArgs pa = {};
+  if (int e = fill_pool(&pa, n, h, w, c, k, stride)) return e;
+  RN_CHECK_ARG(x && y && mean && rstd && gamma && beta && groups >= 1 && c % groups == 0, "maxpool gn fwd f16: bad argument");
+  RN_UNSUPPORTED(c % 8 != 0 || c > 2048, "maxpool gn fwd f16: c=%d must be a multiple of 8 and <= 2048", c);
+  PoolGnArgs a = {};
+  a.x = (const _Float16*)x; a.out = (_Float16*)y; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta;
+  a.n = n; a.h = h; a.w = w; a.c = c; a.k = k; a.s = stride; a.oh = pa.oh; a.ow = pa.ow; a.pt = pa.pt; a.pl = pa.pl;
+  a.groups = groups; a.act = act;
+  const int64_t per = (int64_t)a.oh * a.ow * (c / 8);
+  int64_t bx = (per + T - 1) / T;
+  if (bx > 4096) bx = 4096;
+  hipLaunchKernelGGL(maxpool_gn_f16_kernel, dim3((unsigned)bx, (unsigned)n), dim3(T), 0, (hipStream_t)stream, a);
   RN_LAUNCH_CHECK();
   return RN_OK;
 }

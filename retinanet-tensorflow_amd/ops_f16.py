@@ -137,13 +137,28 @@ class Pending(object):
         return out
 
 
+def max_pool_norm(p, k=3, stride=2):
+    """max_pool(act(GroupNorm(y))) of a Pending conv output in one pass over y (rn_maxpool_gn_fwd_f16): the normalised tensor is
+    never written.  Bit-equal to max_pool(p.materialise())."""
+    y = p.y
+    n, h, w, c = y.shape
+    oh, _ = _rn.same_pad(h, k, stride)
+    ow, _ = _rn.same_pad(w, k, stride)
+    out = torch.empty((n, oh, ow, c), dtype=torch.float16, device=y.device)
+    _rn.check(_rn.lib().rn_maxpool_gn_fwd_f16(_rn.f16(y), _rn.f16(out), n, h, w, c, k, stride, _rn.f32(p.mean), _rn.f32(p.rstd),
+                                              _rn.f32(p.gamma), _rn.f32(p.beta), p.groups, _rn.ACT[p.act], _rn.stream()),
+              "rn_maxpool_gn_fwd_f16")
+    return out
+
+
 def conv2d_norm(x, w, norm, act=None, stride=1, groups=1):
     """conv (no bias) -> GroupNorm `norm` (a layers.GroupNormalization) -> act, the GroupNorm NOT applied: returns a Pending, or
     None when the shape cannot fold (the caller then takes conv2d + group_norm_act).  `x`: an fp16 tensor or a Pending (its
     GroupNorm + activation are applied by this conv's operand load)."""
     src = x.y if isinstance(x, Pending) else x.contiguous()
     kh, kw, cin_g, cout = w.shape
-    wt, g2, cin = packed_weight(w, groups, None)
+    pad = src.shape[3] if (groups == 1 and src.shape[3] > cin_g and not isinstance(x, Pending)) else None     # RGB image padded to 4 channels
+    wt, g2, cin = packed_weight(w, groups, pad)
     if src.shape[3] != cin:
         return None
     L = _rn.lib()

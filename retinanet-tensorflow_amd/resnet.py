@@ -127,11 +127,18 @@ class ResNeXt_ConvInput(Model):
                               kernel_regularizer=kernel_regularizer, in_channels=3)
         self._bn = Normalization(channels=64)
 
-    def call(self, input, training):
+    def call(self, input, training, pool=None):
+        """`pool` (fp16 inference): the MaxPooling2D behind the stem -- conv with the GroupNorm statistics from its epilogue, then
+        GroupNorm + ReLU + max pool in ONE pass over the conv output (ops_f16.max_pool_norm); returns the pooled tensor."""
         if L.INFERENCE_F16 and not training and input.dtype != L.torch.float16:
             import ops_f16
             input = ops_f16.image_to_half4(input)        # fp16 inference: the stem runs on the f16 matrix cores too
-        return self._bn.fused(self._conv(input), training, act='relu')
+            if pool is not None and ops_f16.FOLD and self._conv.weight is not None:
+                p = ops_f16.conv2d_norm(input, self._conv.weight, self._bn, 'relu', self._conv.strides, 1)
+                if p is not None:
+                    return ops_f16.max_pool_norm(p, pool.pool_size, pool.strides)
+        out = self._bn.fused(self._conv(input), training, act='relu')
+        return pool(out) if pool is not None else out
 
 
 class ResNeXt(Model):
@@ -146,9 +153,14 @@ class ResNeXt(Model):
 
     def call(self, input, training):
         out = {}
-        input = self._conv_1(input, training=training)
-        out['C1'] = input
-        input = self._conv_1_max_pool(input)
+        if L.INFERENCE_F16 and not training:
+            # (fp16 inference: stem and pool as one normalise-and-pool pass; C1 itself -- which no caller of an inference pass
+            # reads -- is not materialised)
+            input = self._conv_1(input, training=training, pool=self._conv_1_max_pool)
+        else:
+            input = self._conv_1(input, training=training)
+            out['C1'] = input
+            input = self._conv_1_max_pool(input)
         import ops
         for i, stage in enumerate((self._conv_2, self._conv_3, self._conv_4, self._conv_5)):
             if i > 0 and self.stage_cut is not None and training and L.torch.is_grad_enabled():

@@ -286,3 +286,34 @@ def test_pipelined_conv_with_groupnorm_on_load(dev, monkeypatch, size, cmid, cou
     rstd = 1.0 / np.sqrt(y.var(axis=(1, 3)) + 1e-5)
     assert_close(folded.mean.cpu().numpy(), mean.astype(np.float32), 1e-5, "statistics of the folded conv: mean")
     assert_close(folded.rstd.cpu().numpy(), rstd.astype(np.float32), 1e-4, "statistics of the folded conv: rstd")
+
+
+def test_stem_conv_statistics_and_fused_norm_pool(dev):
+    """ResNeXt's stem in fp16 inference: the 7x7/2 conv of the 4-channel-padded image with the GroupNorm statistics from its
+    epilogue (4-wide operand vectors), then GroupNorm + ReLU + 3x3/2 max pool in one pass (rn_maxpool_gn_fwd_f16) -- bit-equal to
+    the apply pass followed by the plain max pool; statistics against fp64 sums of the conv's own output."""
+    import layers, ops_f16
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(2, 64, 96, 3, generator=g).to(dev)
+    w = (torch.randn(7, 7, 3, 64, generator=g) / (147 ** 0.5)).to(dev)
+
+    class Norm(object):
+        def __init__(self, c):
+            self.groups, self.eps = 32, 1e-5
+            self.gamma = (1 + 0.2 * torch.randn(c, generator=g)).to(dev)
+            self.beta = (0.1 * torch.randn(c, generator=g)).to(dev)
+        def build(self, c, d):
+            pass
+    n = Norm(64)
+    x4 = ops_f16.image_to_half4(img)
+    p = ops_f16.conv2d_norm(x4, w, n, 'relu', 2, 1)
+    assert p is not None, "the stem conv must emit its statistics"
+    plain = ops_f16.conv2d(x4, w, None, 2, 1)
+    assert torch.equal(p.y, plain)
+    y = p.y.float().cpu().numpy().astype(np.float64).reshape(2, 32 * 48, 32, 2)
+    assert_close(p.mean.cpu().numpy(), y.mean(axis=(1, 3)).astype(np.float32), 1e-5, "stem statistics: mean")
+    assert_close(p.rstd.cpu().numpy(), (1.0 / np.sqrt(y.var(axis=(1, 3)) + 1e-5)).astype(np.float32), 1e-4, "stem statistics: rstd")
+    fused = ops_f16.max_pool_norm(p, 3, 2)
+    two = ops_f16.max_pool(p.materialise(), 3, 2)
+    assert fused.shape == two.shape == (2, 16, 24, 64)
+    assert torch.equal(fused, two)
