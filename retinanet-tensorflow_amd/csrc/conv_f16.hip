@@ -658,13 +658,18 @@ __global__ void pack_weights_frag_kernel(const float* __restrict__ w, _Float16* 
 struct G3Args {
   const _Float16* x; const _Float16* ws; _Float16* y; float* partial;
   int n, h, w, c, tiles_w, tiles_per_sample, nsg, prows;
+  // FIN: x is the RAW output of the conv in front; act(GN(x)) is formed between the patch's staging registers and LDS -- once per
+  // patch element (1.27 x the tile; the implicit GEMM would do it once per tap) -- and the GroupNorm's apply pass disappears
+  const float* in_mean; const float* in_rstd; const float* in_gamma; const float* in_beta;
+  int in_groups, in_cpg, in_act;
 };
 constexpr int G3_PW = 18, G3_PST = 40;      // patch width (pixels), pixel stride (halfs)
 
-template <bool FOUT>
+template <bool FOUT, int FIN>       // FIN: 0 none, 1 any activation, 2 ReLU (one mixed-precision fma per element + a packed max per pair)
 __global__ __launch_bounds__(256) void conv3x3_sg32_f16_kernel(const G3Args a) {
   __shared__ __attribute__((aligned(16))) _Float16 patch[G3_PW * G3_PW * G3_PST];     // 25 920 bytes; later: the staged output tile
   __shared__ float sred[FOUT ? 4 * 32 * 2 : 1];
+  __shared__ __attribute__((aligned(16))) float2 ntab[FIN ? 32 : 1];                  // (scale, shift) of the super-group's channels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
   const int sg = bid % a.nsg;                        // super-groups of one tile are neighbours: they share the pixels' cache lines
@@ -676,6 +681,7 @@ __global__ __launch_bounds__(256) void conv3x3_sg32_f16_kernel(const G3Args a) {
   // ---- everything from memory first: the patch (<= 6 chunks of 16 bytes per thread), the 18 weight fragments
   constexpr int NCH = G3_PW * G3_PW * 4, PER = (NCH + 255) / 256;
   half8 pv[PER];
+  unsigned okbits = 0;
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int e = tid + j * 256;
@@ -684,6 +690,12 @@ __global__ __launch_bounds__(256) void conv3x3_sg32_f16_kernel(const G3Args a) {
     const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
     const bool ok = e < NCH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
     pv[j] = VecH<8>::load(xs, ok ? (unsigned)((gy * W + gx) * C + sg * 32 + q * 8) * 2u : OOB);     // (SAME padding: zeros)
+    okbits |= ok ? (1u << j) : 0u;
+  }
+  if (FIN && tid < 32) {
+    const int c = sg * 32 + tid, g_ = c / a.in_cpg;
+    const float sc = a.in_rstd[smp * a.in_groups + g_] * a.in_gamma[c];
+    ntab[tid] = make_float2(sc, a.in_beta[c] - a.in_mean[smp * a.in_groups + g_] * sc);
   }
   half8 bw[9][2];
   const half8* wsp = reinterpret_cast<const half8*>(a.ws) + (size_t)sg * 18 * 64 + lane;
@@ -691,6 +703,31 @@ __global__ __launch_bounds__(256) void conv3x3_sg32_f16_kernel(const G3Args a) {
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) bw[tap][ks] = wsp[(tap * 2 + ks) * 64];
+  if (FIN) {
+    __syncthreads();
+    // a thread's chunks all sit at the same channel offset (256 % 4 == 0): its eight (scale, shift) pairs once.  Padding taps stay
+    // zero: SAME pads the ACTIVATED tensor
+    const float4* tp = reinterpret_cast<const float4*>(ntab + (tid & 3) * 8);
+    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+    const half8 zero = {};
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const bool ok = (okbits >> j) & 1u;
+      if (FIN == 2) {
+        typedef uint32_t pairs_t __attribute__((ext_vector_type(4)));
+        pairs_t p4 = __builtin_bit_cast(pairs_t, pv[j]);
+        p4[0] = fma_mix_pair(p4[0], t0.x, t0.y, t0.z, t0.w); p4[1] = fma_mix_pair(p4[1], t1.x, t1.y, t1.z, t1.w);
+        p4[2] = fma_mix_pair(p4[2], t2.x, t2.y, t2.z, t2.w); p4[3] = fma_mix_pair(p4[3], t3.x, t3.y, t3.z, t3.w);
+        pv[j] = ok ? __builtin_elementwise_max(__builtin_bit_cast(half8, p4), zero) : zero;
+      } else {
+        const float scv[8] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z}, shv[8] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w};
+        half8 v = pv[j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ok ? (_Float16)rn::act_fwd(fmaf((float)v[i], scv[i], shv[i]), a.in_act) : (_Float16)0.f;
+        pv[j] = v;
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int e = tid + j * 256;
@@ -861,11 +898,6 @@ extern "C" int rn_pad_cast_rgb_f16(const float* x, void* y, int64_t pixels, rn_s
 }
 
 namespace {
-bool shape_ok_but_fin(bool sg_on, const rn_f16_fold* fold, int nseg, int G, const rn_conv_geom* g, int64_t so, int cout_g, int cin_g, const SegH& d,
-                      int out_f32) {
-  return sg_on && fold && fold->in_mean && nseg == 1 && G > 1 && g->stride == 1 && so != 0 && cout_g == cin_g && d.cout == g->cin &&
-         d.h % 16 == 0 && d.w % 16 == 0 && !out_f32;
-}
 // fold == nullptr: the plain convolution.  rows_out != nullptr: dry run -- *rows_out = m-tile rows per sample the statistics
 // would take (0: this shape cannot fold), nothing is launched.
 int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int out_f32, const rn_f16_fold* fold, int* rows_out,
@@ -909,11 +941,7 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
     const int64_t so = sg_offset_halfs(g->kh, g->kw, a.cin_g, d.cout);
     const bool shape_ok = sg_on && nseg == 1 && G > 1 && g->stride == 1 && so != 0 && cout_g == a.cin_g && d.x_ld == g->cin && d.x_coff == 0 &&
                           d.cout == g->cin && d.h % 16 == 0 && d.w % 16 == 0 && !out_f32 && d.bias == nullptr &&
-                          segs[0].wgt_bytes >= (int64_t)rn_pack_weights_f16_bytes(g->kh, g->kw, a.cin_g, d.cout) &&
-                          !(fold && fold->in_mean);
-    // (the dry run cannot know about an input-side fold: the row count it reports is this kernel's)
-    RN_UNSUPPORTED(shape_ok_but_fin(sg_on, fold, nseg, G, g, so, cout_g, a.cin_g, d, out_f32),
-                   "conv f16 fold: a GroupNorm on the operand load of a grouped 3 x 3 conv needs RN_F16_SG=0 (the super-group kernel reads materialised inputs)");
+                          segs[0].wgt_bytes >= (int64_t)rn_pack_weights_f16_bytes(g->kh, g->kw, a.cin_g, d.cout);
     if (shape_ok) {
       const int rows = (d.h / 16) * (d.w / 16);
       if (rows_out) { *rows_out = rows; return RN_OK; }
@@ -921,9 +949,20 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
       ga.x = d.x; ga.ws = d.wt + so; ga.y = (_Float16*)d.y; ga.partial = fold ? fold->partial : nullptr;
       ga.n = d.n; ga.h = d.h; ga.w = d.w; ga.c = d.cout; ga.tiles_w = d.w / 16; ga.tiles_per_sample = rows; ga.nsg = d.cout / 32;
       ga.prows = d.n * rows;
+      int fin = 0;
+      if (fold && fold->in_mean) {
+        RN_CHECK_ARG(fold->in_rstd && fold->in_gamma && fold->in_beta && fold->in_groups >= 1 && g->cin % fold->in_groups == 0 && fold->partial,
+                     "conv f16 fold: incomplete input GroupNorm");
+        ga.in_mean = fold->in_mean; ga.in_rstd = fold->in_rstd; ga.in_gamma = fold->in_gamma; ga.in_beta = fold->in_beta;
+        ga.in_groups = fold->in_groups; ga.in_cpg = g->cin / fold->in_groups; ga.in_act = fold->in_act;
+        fin = fold->in_act == RN_ACT_RELU ? 2 : 1;
+      }
       const unsigned blocks = (unsigned)((long)d.n * rows * ga.nsg);
-      if (ga.partial) hipLaunchKernelGGL(conv3x3_sg32_f16_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ga);
-      else hipLaunchKernelGGL(conv3x3_sg32_f16_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ga);
+      hipStream_t st_ = (hipStream_t)stream;
+      if (fin == 2) hipLaunchKernelGGL((conv3x3_sg32_f16_kernel<true, 2>), dim3(blocks), dim3(256), 0, st_, ga);
+      else if (fin == 1) hipLaunchKernelGGL((conv3x3_sg32_f16_kernel<true, 1>), dim3(blocks), dim3(256), 0, st_, ga);
+      else if (ga.partial) hipLaunchKernelGGL((conv3x3_sg32_f16_kernel<true, 0>), dim3(blocks), dim3(256), 0, st_, ga);
+      else hipLaunchKernelGGL((conv3x3_sg32_f16_kernel<false, 0>), dim3(blocks), dim3(256), 0, st_, ga);
       RN_LAUNCH_CHECK();
       return RN_OK;
     }

@@ -114,8 +114,18 @@ def conv2d(x, w, bias=None, stride=1, groups=1, out_f32=False):
 # ---------------------------------------------------------------------------------------------------------------------
 import os
 FOLD_INTO_3X3 = os.environ.get("RN_F16_FOLD_3X3", "0") == "1"     # also apply a pending GroupNorm on the operand load of 3 x 3 convs
-if FOLD_INTO_3X3:
-    os.environ.setdefault("RN_F16_SG", "0")         # (the super-group kernel of the grouped 3 x 3 convs reads materialised inputs)
+SG_KERNEL = os.environ.get("RN_F16_SG", "1") != "0"
+
+
+def sg_kernel_takes(shape, w, stride, groups):
+    """True where rn_conv2d_fwd_f16(_fold) runs a grouped 3 x 3 conv on 16 x 16-pixel tiles of 32-channel super-groups
+    (csrc/conv_f16.hip, conv3x3_sg32_f16_kernel): it applies a pending GroupNorm + activation ONCE per input element (while the
+    patch goes to LDS), so the conv in front need not materialise its GroupNorm (resnet.ResNeXt_Bottleneck)."""
+    kh, kw, cin_g, cout = w.shape
+    return (SG_KERNEL and groups > 1 and stride == 1 and kh == 3 and kw == 3 and cout == cin_g * groups and cin_g in (4, 8, 16, 32)
+            and shape[3] == cout and shape[1] % 16 == 0 and shape[2] % 16 == 0)
+
+
 FOLD = os.environ.get("RN_F16_FOLD", "1") == "1"     # (0: conv, then the three-kernel GroupNorm, as before -- A/B measurements, tests)
 
 

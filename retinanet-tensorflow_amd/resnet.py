@@ -85,7 +85,10 @@ class ResNeXt_Bottleneck(Model):
             return None
         # (the 3 x 3 conv reads every input element through nine taps: applying the GroupNorm on load would repeat its
         # arithmetic nine times -- measured 232 vs ~125 + 60 us per block at cfg 5 -- so its input is materialised once)
-        a1 = p1 if ops_f16.FOLD_INTO_3X3 else p1.materialise()
+        # (... except where the grouped conv runs on LDS-resident input patches: there the GroupNorm is applied once per patch
+        # element on the way into LDS and conv 1's apply pass disappears too)
+        fold_in = ops_f16.FOLD_INTO_3X3 or ops_f16.sg_kernel_takes(p1.y.shape, self._conv_2.weight, stride, self._conv_2.groups)
+        a1 = p1 if fold_in else p1.materialise()
         p2 = ops_f16.conv2d_norm(a1, self._conv_2.weight, self._bn_2, act='relu', stride=stride, groups=self._conv_2.groups)
         if p2 is None:
             return None
