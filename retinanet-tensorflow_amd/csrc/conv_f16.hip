@@ -663,11 +663,26 @@ struct G3Args {
   const float* in_mean; const float* in_rstd; const float* in_gamma; const float* in_beta;
   int in_groups, in_cpg, in_act;
 };
-constexpr int G3_PW = 18, G3_PST = 40;      // patch width (pixels), pixel stride (halfs)
+constexpr int G3_PST = 40;      // pixel stride of the LDS patch and of the staged output tile (halfs): 80 bytes
 
-template <bool FOUT, int FIN>       // FIN: 0 none, 1 any activation, 2 ReLU (one mixed-precision fma per element + a packed max per pair)
+// S = 1: 16 x 16 output pixels per block, wave w the rows [4 w, 4 w + 4) = two 32-pixel M-tiles; 18 x 18 input patch.
+// S = 2 (the first bottleneck of a stage; even maps: SAME pads bottom / right only): 8 x 16 output pixels, wave w the rows
+// [2 w, 2 w + 2) = one M-tile; 17 x 33 patch with the even and the odd columns of a row in two runs, so that the 16 pixels a
+// half-wave reads for one tap (input columns 2 x + kw) are neighbours in LDS as they are for S = 1.
+template <int S>
+struct G3Geom {
+  static constexpr int TH = S == 1 ? 16 : 8, TW = 16;
+  static constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;          // 18 x 18 | 17 x 33
+  static constexpr int ROW = S == 1 ? PW : 34;                                 // LDS entries per patch row
+  static constexpr int NT = S == 1 ? 2 : 1;                                    // M-tiles per wave
+  static constexpr int NCH = PH * PW * 4, PER = (NCH + 255) / 256;             // 16-byte chunks of the patch, per thread
+  static __device__ __forceinline__ int lds_pix(int py, int px) { return S == 1 ? py * ROW + px : py * ROW + (px & 1) * 17 + (px >> 1); }
+};
+
+template <bool FOUT, int FIN, int S>       // FIN: 0 none, 1 any activation, 2 ReLU (one mixed-precision fma per element + a packed max per pair)
 __global__ __launch_bounds__(256) void conv3x3_sg32_f16_kernel(const G3Args a) {
-  __shared__ __attribute__((aligned(16))) _Float16 patch[G3_PW * G3_PW * G3_PST];     // 25 920 bytes; later: the staged output tile
+  typedef G3Geom<S> G;
+  __shared__ __attribute__((aligned(16))) _Float16 patch[G::PH * G::ROW * G3_PST];     // 25.9 | 46.2 KB; later: the staged output tile
   __shared__ float sred[FOUT ? 4 * 32 * 2 : 1];
   __shared__ __attribute__((aligned(16))) float2 ntab[FIN ? 32 : 1];                  // (scale, shift) of the super-group's channels
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -675,20 +690,20 @@ __global__ __launch_bounds__(256) void conv3x3_sg32_f16_kernel(const G3Args a) {
   const int sg = bid % a.nsg;                        // super-groups of one tile are neighbours: they share the pixels' cache lines
   const int t = bid / a.nsg;
   const int tile = t % a.tiles_per_sample, smp = t / a.tiles_per_sample;
-  const int ty0 = (tile / a.tiles_w) * 16, tx0 = (tile % a.tiles_w) * 16;
-  const int H = a.h, W = a.w, C = a.c;
+  const int ty0 = (tile / a.tiles_w) * G::TH, tx0 = (tile % a.tiles_w) * G::TW;      // output pixels
+  const int H = a.h, W = a.w, C = a.c, OH = H / S, OW = W / S;
+  const int pad = S == 1 ? 1 : 0;                    // SAME, top / left (even maps)
   const __amdgpu_buffer_rsrc_t xs = make_rsrc(a.x + (size_t)smp * H * W * C, (unsigned)H * W * C * 2u);
-  // ---- everything from memory first: the patch (<= 6 chunks of 16 bytes per thread), the 18 weight fragments
-  constexpr int NCH = G3_PW * G3_PW * 4, PER = (NCH + 255) / 256;
-  half8 pv[PER];
+  // ---- everything from memory first: the patch (6 | 9 chunks of 16 bytes per thread), the 18 weight fragments
+  half8 pv[G::PER];
   unsigned okbits = 0;
 #pragma unroll
-  for (int j = 0; j < PER; ++j) {
+  for (int j = 0; j < G::PER; ++j) {
     const int e = tid + j * 256;
-    const int pix = min(e, NCH - 1) >> 2, q = e & 3;
-    const int py = pix / G3_PW, px = pix - py * G3_PW;
-    const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
-    const bool ok = e < NCH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const int pix = min(e, G::NCH - 1) >> 2, q = e & 3;
+    const int py = pix / G::PW, px = pix - py * G::PW;
+    const int gy = ty0 * S - pad + py, gx = tx0 * S - pad + px;
+    const bool ok = e < G::NCH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
     pv[j] = VecH<8>::load(xs, ok ? (unsigned)((gy * W + gx) * C + sg * 32 + q * 8) * 2u : OOB);     // (SAME padding: zeros)
     okbits |= ok ? (1u << j) : 0u;
   }
@@ -711,7 +726,7 @@ __global__ __launch_bounds__(256) void conv3x3_sg32_f16_kernel(const G3Args a) {
     const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
     const half8 zero = {};
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
+    for (int j = 0; j < G::PER; ++j) {
       const bool ok = (okbits >> j) & 1u;
       if (FIN == 2) {
         typedef uint32_t pairs_t __attribute__((ext_vector_type(4)));
@@ -729,36 +744,43 @@ __global__ __launch_bounds__(256) void conv3x3_sg32_f16_kernel(const G3Args a) {
     }
   }
 #pragma unroll
-  for (int j = 0; j < PER; ++j) {
+  for (int j = 0; j < G::PER; ++j) {
     const int e = tid + j * 256;
-    if (e < NCH) *reinterpret_cast<half8*>(&patch[(e >> 2) * G3_PST + (e & 3) * 8]) = pv[j];
+    if (e < G::NCH) {
+      const int pix = e >> 2;
+      const int py = pix / G::PW, px = pix - py * G::PW;
+      *reinterpret_cast<half8*>(&patch[G::lds_pix(py, px) * G3_PST + (e & 3) * 8]) = pv[j];
+    }
   }
   __syncthreads();
-  f32x16 acc[2];
+  f32x16 acc[G::NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < G::NT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   const int l31 = lane & 31, khalf = lane >> 5;
   const int ry = l31 >> 4, rx = l31 & 15;
-  const _Float16* ap = patch + ((4 * wave + ry) * G3_PW + rx) * G3_PST + khalf * 8;
+  const int oy = (G::TH / 4) * wave + ry;             // first M-tile's output row of this lane (the second one: + 2)
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const half8 a0 = *reinterpret_cast<const half8*>(ap + (kh * G3_PW + kw) * G3_PST + ks * 16);
-        const half8 a1 = *reinterpret_cast<const half8*>(ap + ((kh + 2) * G3_PW + kw) * G3_PST + ks * 16);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bw[kh * 3 + kw][ks], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bw[kh * 3 + kw][ks], acc[1], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < G::NT; ++i) {
+          const int lp = G::lds_pix((oy + 2 * i) * S + kh, rx * S + kw);
+          const half8 av = *reinterpret_cast<const half8*>(&patch[lp * G3_PST + ks * 16 + khalf * 8]);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bw[kh * 3 + kw][ks], acc[i], 0, 0, 0);
+        }
       }
   __syncthreads();                                 // the patch is dead: the staged output tile takes its place
   // C/D map: col (channel) = lane & 31, pixel of the M-tile = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  _Float16* cs = patch + wave * (64 * G3_PST);     // [64 pixels of the wave][32 channels], pixel stride 80 bytes
+  constexpr int WPX = 32 * G::NT;                  // output pixels per wave
+  _Float16* cs = patch + wave * (WPX * G3_PST);    // [pixels of the wave][32 channels], pixel stride 80 bytes
   float st1 = 0.f, st2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < G::NT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const _Float16 hv = (_Float16)acc[i][r];
@@ -767,14 +789,14 @@ __global__ __launch_bounds__(256) void conv3x3_sg32_f16_kernel(const G3Args a) {
     }
   __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the wave's own stores have landed (a wave reads only its own region)
   __builtin_amdgcn_wave_barrier();
-  const __amdgpu_buffer_rsrc_t ys = make_rsrc(a.y + (size_t)smp * H * W * C, (unsigned)H * W * C * 2u);
+  const __amdgpu_buffer_rsrc_t ys = make_rsrc(a.y + (size_t)smp * OH * OW * C, (unsigned)OH * OW * C * 2u);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e = lane + j * 64;                   // chunk of the wave's 64 pixels x 4 x 16 bytes
+  for (int j = 0; j < WPX / 16; ++j) {
+    const int e = lane + j * 64;                   // chunk of the wave's pixels x 4 x 16 bytes
     const int p = e >> 2, q = e & 3;
-    const int gy = ty0 + 4 * wave + (p >> 4), gx = tx0 + (p & 15);
+    const int gy = ty0 + (G::TH / 4) * wave + (p >> 4), gx = tx0 + (p & 15);
     const u32x4 d = *reinterpret_cast<const u32x4*>(&cs[p * G3_PST + q * 8]);
-    __builtin_amdgcn_raw_buffer_store_b128(d, ys, (unsigned)((gy * W + gx) * C + sg * 32 + q * 8) * 2u, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(d, ys, (unsigned)((gy * OW + gx) * C + sg * 32 + q * 8) * 2u, 0, 0);
   }
   if (FOUT) {
     st1 += __shfl_xor(st1, 32, 64);
@@ -939,15 +961,17 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
     static const bool sg_on = !(getenv("RN_F16_SG") && atoi(getenv("RN_F16_SG")) == 0);
     const SegH& d = a.seg[0];
     const int64_t so = sg_offset_halfs(g->kh, g->kw, a.cin_g, d.cout);
-    const bool shape_ok = sg_on && nseg == 1 && G > 1 && g->stride == 1 && so != 0 && cout_g == a.cin_g && d.x_ld == g->cin && d.x_coff == 0 &&
-                          d.cout == g->cin && d.h % 16 == 0 && d.w % 16 == 0 && !out_f32 && d.bias == nullptr &&
+    const int S_ = g->stride;
+    const bool shape_ok = sg_on && nseg == 1 && G > 1 && (S_ == 1 || S_ == 2) && so != 0 && cout_g == a.cin_g && d.x_ld == g->cin && d.x_coff == 0 &&
+                          d.cout == g->cin && d.h % (16 * S_) == 0 && d.w % (16 * S_) == 0 && !out_f32 && d.bias == nullptr &&
                           segs[0].wgt_bytes >= (int64_t)rn_pack_weights_f16_bytes(g->kh, g->kw, a.cin_g, d.cout);
     if (shape_ok) {
-      const int rows = (d.h / 16) * (d.w / 16);
+      const int th = S_ == 1 ? 16 : 8;
+      const int rows = (d.h / S_ / th) * (d.w / S_ / 16);
       if (rows_out) { *rows_out = rows; return RN_OK; }
       G3Args ga = {};
       ga.x = d.x; ga.ws = d.wt + so; ga.y = (_Float16*)d.y; ga.partial = fold ? fold->partial : nullptr;
-      ga.n = d.n; ga.h = d.h; ga.w = d.w; ga.c = d.cout; ga.tiles_w = d.w / 16; ga.tiles_per_sample = rows; ga.nsg = d.cout / 32;
+      ga.n = d.n; ga.h = d.h; ga.w = d.w; ga.c = d.cout; ga.tiles_w = d.w / S_ / 16; ga.tiles_per_sample = rows; ga.nsg = d.cout / 32;
       ga.prows = d.n * rows;
       int fin = 0;
       if (fold && fold->in_mean) {
@@ -959,10 +983,15 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
       }
       const unsigned blocks = (unsigned)((long)d.n * rows * ga.nsg);
       hipStream_t st_ = (hipStream_t)stream;
-      if (fin == 2) hipLaunchKernelGGL((conv3x3_sg32_f16_kernel<true, 2>), dim3(blocks), dim3(256), 0, st_, ga);
-      else if (fin == 1) hipLaunchKernelGGL((conv3x3_sg32_f16_kernel<true, 1>), dim3(blocks), dim3(256), 0, st_, ga);
-      else if (ga.partial) hipLaunchKernelGGL((conv3x3_sg32_f16_kernel<true, 0>), dim3(blocks), dim3(256), 0, st_, ga);
-      else hipLaunchKernelGGL((conv3x3_sg32_f16_kernel<false, 0>), dim3(blocks), dim3(256), 0, st_, ga);
+#define RN_G3(S__)                                                                                                          \
+      do {                                                                                                                      \
+        if (fin == 2) hipLaunchKernelGGL((conv3x3_sg32_f16_kernel<true, 2, S__>), dim3(blocks), dim3(256), 0, st_, ga);           \
+        else if (fin == 1) hipLaunchKernelGGL((conv3x3_sg32_f16_kernel<true, 1, S__>), dim3(blocks), dim3(256), 0, st_, ga);      \
+        else if (ga.partial) hipLaunchKernelGGL((conv3x3_sg32_f16_kernel<true, 0, S__>), dim3(blocks), dim3(256), 0, st_, ga);    \
+        else hipLaunchKernelGGL((conv3x3_sg32_f16_kernel<false, 0, S__>), dim3(blocks), dim3(256), 0, st_, ga);                   \
+      } while (0)
+      if (S_ == 1) RN_G3(1); else RN_G3(2);
+#undef RN_G3
       RN_LAUNCH_CHECK();
       return RN_OK;
     }

@@ -122,8 +122,8 @@ def sg_kernel_takes(shape, w, stride, groups):
     (csrc/conv_f16.hip, conv3x3_sg32_f16_kernel): it applies a pending GroupNorm + activation ONCE per input element (while the
     patch goes to LDS), so the conv in front need not materialise its GroupNorm (resnet.ResNeXt_Bottleneck)."""
     kh, kw, cin_g, cout = w.shape
-    return (SG_KERNEL and groups > 1 and stride == 1 and kh == 3 and kw == 3 and cout == cin_g * groups and cin_g in (4, 8, 16, 32)
-            and shape[3] == cout and shape[1] % 16 == 0 and shape[2] % 16 == 0)
+    return (SG_KERNEL and groups > 1 and stride in (1, 2) and kh == 3 and kw == 3 and cout == cin_g * groups and cin_g in (4, 8, 16, 32)
+            and shape[3] == cout and shape[1] % (16 * stride) == 0 and shape[2] % (16 * stride) == 0)
 
 
 FOLD = os.environ.get("RN_F16_FOLD", "1") == "1"     # (0: conv, then the three-kernel GroupNorm, as before -- A/B measurements, tests)

@@ -31,6 +31,8 @@ CASES = [
     (1, 32, 16, 256, 256, 3, 1, 32, False, False),     # 8 per group
     (1, 16, 16, 512, 512, 3, 1, 32, False, False),     # 16 per group
     (2, 16, 16, 1024, 1024, 3, 1, 32, False, False),   # 32 per group: one group per super-group
+    (2, 32, 64, 256, 256, 3, 2, 32, False, False),     # stride 2 on maps of whole 32 x 32 input tiles: the same kernel, 8 x 16 output tiles
+    (1, 64, 32, 512, 512, 3, 2, 32, False, False),
     (1, 5, 5, 2048, 256, 1, 1, 1, False, False),
 ]
 
