@@ -48,7 +48,7 @@ typedef struct rn_reduce_list rn_reduce_list;
 
 /* Version of this header's ABI: bumped whenever an entry point's arguments or a struct layout change.  rn_version() returns
  * the value the library was built with; a caller built against another value must not call anything else. */
-#define RN_API_VERSION 403
+#define RN_API_VERSION 404
 int rn_version(void);
 const char* rn_last_error(void);
 
@@ -260,6 +260,17 @@ int rn_group_norm_finalize(const float* partial, int n, int rows_per_sample, int
 int rn_group_norm_apply_f16(const void* x, const void* residual, void* y, int n, int hw, int c, int groups, const float* mean,
                             const float* rstd, const float* gamma, const float* beta, int act, int act_after_residual,
                             rn_stream_t stream);
+/* The same with a residual that is itself the RAW fp16 output of a conv whose activation-free GroupNorm has not been applied yet
+ * (ResNeXt's projection branch, resnet.py:62-71: identity = normalization(conv(input))): residual' = GN_r(residual) is formed
+ * in fp32 inside this pass and never written -- y = act(GN(x) + GN_r(residual)) (act_after_residual) or act(GN(x)) + GN_r(..). */
+typedef struct rn_gn_residual_norm {
+  const float* mean; const float* rstd;       /* [n][groups] */
+  const float* gamma; const float* beta;      /* [c] */
+  int groups;
+} rn_gn_residual_norm;
+int rn_group_norm_apply_res_f16(const void* x, const void* residual, const rn_gn_residual_norm* residual_norm, void* y, int n, int hw, int c,
+                                int groups, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                                int act_after_residual, rn_stream_t stream);
 
 /* ------------------------------------------------------------------ depthwise 3x3
  * Replaces tf.nn.depthwise_conv2d (DepthwiseConv2dNative + its two backprops),

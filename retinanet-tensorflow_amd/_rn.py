@@ -19,7 +19,7 @@ LOSS_MODE = {"bce_dice": 0, "focal": 1}
 OPT = {"momentum": 0, "rmsprop": 1, "adam": 2}
 OPT_BLOCK = 1024
 LOSS_STATS_HEADER = 8
-API_VERSION = 403        # RN_API_VERSION of include/rn_hip.h these bindings were written against
+API_VERSION = 404        # RN_API_VERSION of include/rn_hip.h these bindings were written against
 
 
 class RnError(RuntimeError):
@@ -99,6 +99,10 @@ class GnRows(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("rows_per_sample", C.c_int32), ("per_group", C.c_int32), ("groups", C.c_int32)]
 
 
+class GnResidualNorm(C.Structure):
+    _fields_ = [("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("groups", C.c_int)]
+
+
 class F16Fold(C.Structure):
     """rn_f16_fold"""
     _fields_ = [("in_mean", C.c_void_p), ("in_rstd", C.c_void_p), ("in_gamma", C.c_void_p), ("in_beta", C.c_void_p),
@@ -171,7 +175,7 @@ SYMBOLS = [
     "rn_dwgn_supported", "rn_dwgn_fwd", "rn_dwgn_bwd", "rn_depthwise_fwd", "rn_depthwise_dgrad", "rn_depthwise_wgrad_workspace", "rn_depthwise_wgrad", "rn_depthwise_bwd",
     "rn_group_norm_sync_bytes", "rn_group_norm_workspace", "rn_group_norm_fwd", "rn_group_norm_bwd",
     "rn_act_fwd", "rn_act_bwd", "rn_upsample_add_fwd", "rn_upsample_add_bwd_top",
-    "rn_pack_weights_f16", "rn_pack_weights_f16_bytes", "rn_cast_f32_to_f16", "rn_pad_cast_rgb_f16", "rn_conv2d_fwd_f16", "rn_conv2d_f16_fold_rows", "rn_conv2d_fwd_f16_fold", "rn_group_norm_finalize", "rn_group_norm_apply_f16", "rn_maxpool_fwd_f16", "rn_maxpool_gn_fwd_f16", "rn_upsample_add_fwd_f16",
+    "rn_pack_weights_f16", "rn_pack_weights_f16_bytes", "rn_cast_f32_to_f16", "rn_pad_cast_rgb_f16", "rn_conv2d_fwd_f16", "rn_conv2d_f16_fold_rows", "rn_conv2d_fwd_f16_fold", "rn_group_norm_finalize", "rn_group_norm_apply_f16", "rn_group_norm_apply_res_f16", "rn_maxpool_fwd_f16", "rn_maxpool_gn_fwd_f16", "rn_upsample_add_fwd_f16",
     "rn_act_fwd_f16", "rn_flip_width", "rn_dropout", "rn_dropout_strided", "rn_maxpool_fwd", "rn_maxpool_bwd", "rn_maxpool_bwd_arg", "rn_avgpool_fwd", "rn_avgpool_bwd",
     "rn_loss_workspace", "rn_loss_fwd", "rn_loss_bwd",
     "rn_iou", "rn_anchor_assign", "rn_anchor_assign_levels", "rn_anchor_assign_levels_pair", "rn_decode_boxes", "rn_detect_workspace", "rn_detect",
@@ -282,6 +286,8 @@ def lib():
         L.rn_group_norm_finalize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rn_group_norm_apply_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.rn_group_norm_apply_res_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.rn_maxpool_fwd_f16.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p]
         L.rn_maxpool_gn_fwd_f16.argtypes = [C.c_void_p] * 2 + [C.c_int] * 6 + [C.c_void_p] * 4 + [C.c_int] * 2 + [C.c_void_p]
         L.rn_upsample_add_fwd_f16.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p]

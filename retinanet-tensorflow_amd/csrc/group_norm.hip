@@ -48,6 +48,8 @@ struct GnArgs {
   const float2* rows; int rows_per_group, rows_sw;   // (rows of a sample: seg.chunks, first row: seg.chunk_start)
   float2* rows_out;                                  // gn_rows_partial_kernel: [total_chunks][groups]
   int nt_loads;    // fp16 apply: x and the residual are read for the last time here -- non-temporal loads (large inference batches)
+  // fp16 apply: the residual is itself a RAW conv output whose (activation-free) GroupNorm is applied here (ResNeXt's projection branch)
+  const float* res_mean; const float* res_rstd; const float* res_gamma; const float* res_beta; int res_groups;
 };
 
 __device__ __forceinline__ int seg_of_sample(const GnArgs& a, int q) {
@@ -607,9 +609,10 @@ __global__ __launch_bounds__(RT) void gn_rows_partial_kernel(const GnArgs a) {
 
 // fp16-storage inference apply: 8 channels (16 B) per thread, no dropout.  y = act(z) + r  or  act(z + r).
 typedef _Float16 gn_half8 __attribute__((ext_vector_type(8)));
-template <int ACT>
+template <int ACT, bool RES_NORM = false>
 __global__ __launch_bounds__(T) void gn_apply_f16x8_kernel(const GnArgs a) {
   __shared__ float tab[2048][2];  // scale = rstd*gamma, shift = beta - mean*rstd*gamma  (z = x*scale + shift)
+  __shared__ float tabr[RES_NORM ? 2048 : 1][2];   // the same for the residual's own GroupNorm
   const int q = blockIdx.y, tid = threadIdx.x;
   const int s = seg_of_sample(a, q);
   const GnSeg& sg = a.seg[s];
@@ -622,6 +625,12 @@ __global__ __launch_bounds__(T) void gn_apply_f16x8_kernel(const GnArgs a) {
     const float sc = rstd * a.gamma[c];
     tab[c][0] = sc;
     tab[c][1] = a.beta[c] - mean * sc;
+    if (RES_NORM) {
+      const int gr = c / (C / a.res_groups);
+      const float scr = a.res_rstd[nl * a.res_groups + gr] * a.res_gamma[c];
+      tabr[c][0] = scr;
+      tabr[c][1] = a.res_beta[c] - a.res_mean[nl * a.res_groups + gr] * scr;
+    }
   }
   __syncthreads();
   const size_t base = (size_t)nl * sg.hw * C;
@@ -645,7 +654,8 @@ __global__ __launch_bounds__(T) void gn_apply_f16x8_kernel(const GnArgs a) {
     for (int j = 0; j < 8; ++j) {
       const float2 t = *reinterpret_cast<const float2*>(&tab[c0 + j][0]);
       const float z = (float)xv[j] * t.x + t.y;
-      const float rr = r ? (float)rv[j] : 0.f;
+      float rr = r ? (float)rv[j] : 0.f;
+      if (RES_NORM) { const float2 tr = *reinterpret_cast<const float2*>(&tabr[c0 + j][0]); rr = rr * tr.x + tr.y; }
       const float v = aar ? rn::act_fwd(z + rr, ACT) : rn::act_fwd(z, ACT) + rr;
       o[j] = (_Float16)v;
     }
@@ -1753,9 +1763,25 @@ extern "C" int rn_group_norm_finalize(const float* partial, int n, int rows_per_
   return RN_OK;
 }
 
+namespace {
+int apply_f16_impl(const void* x, const void* residual, void* y, int n, int hw, int c, int groups, const float* mean, const float* rstd,
+                   const float* gamma, const float* beta, int act, int act_after_residual, const rn_gn_residual_norm* rn_, rn_stream_t stream);
+}
 extern "C" int rn_group_norm_apply_f16(const void* x, const void* residual, void* y, int n, int hw, int c, int groups, const float* mean,
                                        const float* rstd, const float* gamma, const float* beta, int act, int act_after_residual,
                                        rn_stream_t stream) {
+  return apply_f16_impl(x, residual, y, n, hw, c, groups, mean, rstd, gamma, beta, act, act_after_residual, nullptr, stream);
+}
+extern "C" int rn_group_norm_apply_res_f16(const void* x, const void* residual, const rn_gn_residual_norm* residual_norm, void* y, int n, int hw,
+                                           int c, int groups, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                                           int act_after_residual, rn_stream_t stream) {
+  RN_CHECK_ARG(residual && residual_norm && residual_norm->mean && residual_norm->rstd && residual_norm->gamma && residual_norm->beta &&
+               residual_norm->groups >= 1 && c % residual_norm->groups == 0, "group_norm apply res f16: bad residual GroupNorm");
+  return apply_f16_impl(x, residual, y, n, hw, c, groups, mean, rstd, gamma, beta, act, act_after_residual, residual_norm, stream);
+}
+namespace {
+int apply_f16_impl(const void* x, const void* residual, void* y, int n, int hw, int c, int groups, const float* mean, const float* rstd,
+                   const float* gamma, const float* beta, int act, int act_after_residual, const rn_gn_residual_norm* rn_, rn_stream_t stream) {
   RN_CHECK_ARG(x && y && mean && rstd && gamma && beta && n >= 1 && hw >= 1 && groups >= 1 && c % groups == 0, "group_norm apply f16: bad argument");
   RN_UNSUPPORTED(c % 8 != 0 || c > 2048, "group_norm apply f16: c=%d must be a multiple of 8 and <= 2048", c);
   GnArgs a = {};
@@ -1769,6 +1795,17 @@ extern "C" int rn_group_norm_apply_f16(const void* x, const void* residual, void
   a.total_samples = n;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(apply_blocks(a, 8), n);
+  if (rn_) {
+    a.res_mean = rn_->mean; a.res_rstd = rn_->rstd; a.res_gamma = rn_->gamma; a.res_beta = rn_->beta; a.res_groups = rn_->groups;
+    switch (act) {
+      case RN_ACT_RELU: hipLaunchKernelGGL((gn_apply_f16x8_kernel<RN_ACT_RELU, true>), grid, dim3(T), 0, st, a); break;
+      case RN_ACT_ELU: hipLaunchKernelGGL((gn_apply_f16x8_kernel<RN_ACT_ELU, true>), grid, dim3(T), 0, st, a); break;
+      case RN_ACT_NONE: hipLaunchKernelGGL((gn_apply_f16x8_kernel<RN_ACT_NONE, true>), grid, dim3(T), 0, st, a); break;
+      default: RN_UNSUPPORTED(true, "group_norm apply res f16: activation %d (relu, elu, none)", act);
+    }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+  }
   switch (act) {
     case RN_ACT_RELU: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_RELU>, grid, dim3(T), 0, st, a); break;
     case RN_ACT_ELU: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_ELU>, grid, dim3(T), 0, st, a); break;
@@ -1779,3 +1816,4 @@ extern "C" int rn_group_norm_apply_f16(const void* x, const void* residual, void
   RN_LAUNCH_CHECK();
   return RN_OK;
 }
+}  // namespace

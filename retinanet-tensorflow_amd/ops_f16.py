@@ -139,6 +139,16 @@ class Pending(object):
         y = self.y
         n, h, w, c = y.shape
         out = torch.empty_like(y)
+        if isinstance(residual, Pending):
+            # the residual's own (activation-free) GroupNorm is applied inside this pass: no apply pass of its own
+            assert residual.act is None and residual.y.shape == y.shape
+            rn_ = _rn.GnResidualNorm(residual.mean.data_ptr(), residual.rstd.data_ptr(), residual.gamma.data_ptr(), residual.beta.data_ptr(),
+                                     residual.groups)
+            _rn.check(_rn.lib().rn_group_norm_apply_res_f16(_rn.f16(y), _rn.f16(residual.y), C.byref(rn_), _rn.f16(out), n, h * w, c, self.groups,
+                                                            _rn.f32(self.mean), _rn.f32(self.rstd), _rn.f32(self.gamma), _rn.f32(self.beta),
+                                                            _rn.ACT[self.act], 1 if act_after_residual else 0, _rn.stream()),
+                      "rn_group_norm_apply_res_f16")
+            return out
         residual = residual.contiguous() if residual is not None else None   # (a copy must outlive the launch: keep the name)
         _rn.check(_rn.lib().rn_group_norm_apply_f16(_rn.f16(y), _rn.f16(residual) if residual is not None else None, _rn.f16(out),
                                                     n, h * w, c, self.groups, _rn.f32(self.mean), _rn.f32(self.rstd), _rn.f32(self.gamma),

@@ -98,7 +98,8 @@ class ResNeXt_Bottleneck(Model):
         identity = input
         if self._identity_conv is not None:
             pi = ops_f16.conv2d_norm(input, self._identity_conv.weight, self._identity_bn, act=None, stride=self._identity_conv.strides)
-            identity = pi.materialise() if pi is not None else self._identity_bn.fused(self._identity_conv(input), False)
+            # (the projection's GroupNorm has no activation: it is applied inside the block's final apply pass, never written)
+            identity = pi if pi is not None else self._identity_bn.fused(self._identity_conv(input), False)
         return p3.materialise(residual=identity, act_after_residual=True)
 
 
