@@ -149,6 +149,93 @@ __global__ __launch_bounds__(T) void gn_partial_kernel(const GnArgs a) {
   }
 }
 
+// The forward statistics pass over fp16 storage (the inference path: the head towers' maps, 179 MB per GroupNorm at cfg 5): 16 bytes
+// (8 channels) per lane and load, four loads in flight -- the generic kernel above walks 8-byte quads through a converting load and
+// streams at 1.9 TB/s there.  Same chunks, same output layout; channel octets x pixel lanes, the lanes summed in order.
+typedef _Float16 part_half8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(T) void gn_partial_f16x8_kernel(const GnArgs a) {
+  __shared__ float red[T][16];
+  const int tid = threadIdx.x;
+  const int ch = blockIdx.x;
+  const int s = seg_of_chunk(a, ch);
+  const GnSeg& sg = a.seg[s];
+  const int local = ch - sg.chunk_start;
+  const int nl = local / sg.chunks, ck = local - nl * sg.chunks;
+  const int C = a.c, C8 = C >> 3;                  // (the host checks: C8 divides T)
+  const int lanes = T / C8;
+  const int p_begin = ck * sg.ppc, p_end = min(p_begin + sg.ppc, sg.hw);
+  const _Float16* __restrict__ x = reinterpret_cast<const _Float16*>(sg.x) + (size_t)nl * sg.hw * sg.x_ld;
+  const int q8 = tid % C8, pl = tid / C8;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  for (int p0 = p_begin + pl; p0 < p_end; p0 += 4 * lanes) {
+    part_half8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const part_half8*>(x + (size_t)min(p0 + u * lanes, p_end - 1) * sg.x_ld + q8 * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p0 + u * lanes < p_end) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s1[j] += f; s2[j] = fmaf(f, f, s2[j]); }
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[tid][j] = s1[j]; red[tid][8 + j] = s2[j]; }
+  __syncthreads();
+  for (int e = tid; e < C8 * 16; e += T) {
+    const int q = e >> 4, comp = e & 15;
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += red[l * C8 + q][comp];
+    a.partial[(size_t)(comp >> 3) * a.total_chunks * C + (size_t)ch * C + q * 8 + (comp & 7)] = t;
+  }
+}
+
+// the forward finalize by 64-channel slabs (see gn_finalize_cols_kernel below), any number of segments: block = (sample, slab)
+__global__ __launch_bounds__(T) void gn_finalize_cols_segs_kernel(const GnArgs a) {
+  __shared__ double red[4][64][2];
+  __shared__ double chan[64][2];
+  const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+  const int slabs = a.c >> 6;
+  const int q = blockIdx.x / slabs, slab = blockIdx.x - q * slabs;
+  const int s = seg_of_sample(a, q);
+  const GnSeg& sg = a.seg[s];
+  const int nl = q - sg.sample_start, rows = sg.chunks;
+  const float* __restrict__ p1 = a.partial + (size_t)(sg.chunk_start + nl * rows) * a.c + slab * 64 + cl;
+  const float* __restrict__ p2 = p1 + (size_t)a.total_chunks * a.c;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r0 = rl; r0 < rows; r0 += 32) {
+    float u[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const size_t rr = (size_t)min(r0 + 4 * j, rows - 1) * a.c;
+      u[j] = p1[rr]; v[j] = p2[rr];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (r0 + 4 * j < rows) { s1 += (double)u[j]; s2 += (double)v[j]; }
+  }
+  red[rl][cl][0] = s1; red[rl][cl][1] = s2;
+  __syncthreads();
+  if (tid < 64) {
+    chan[tid][0] = ((red[0][tid][0] + red[1][tid][0]) + red[2][tid][0]) + red[3][tid][0];
+    chan[tid][1] = ((red[0][tid][1] + red[1][tid][1]) + red[2][tid][1]) + red[3][tid][1];
+  }
+  __syncthreads();
+  const int gps = 64 / a.cpg;
+  if (tid < gps) {
+    double v1 = 0.0, v2 = 0.0;
+    for (int j = 0; j < a.cpg; ++j) { v1 += chan[tid * a.cpg + j][0]; v2 += chan[tid * a.cpg + j][1]; }
+    const double m = (double)sg.hw * (double)a.cpg;
+    const double mean = v1 / m;
+    double var = v2 / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const int g = slab * gps + tid;
+    sg.mean[nl * a.groups + g] = (float)mean;
+    sg.rstd[nl * a.groups + g] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+}
+
 // Finalize: fp64 reduction of the chunk partials, one 256-thread block per (sample, group):
 //   BWD=false -> mean / rstd;  BWD=true -> coef[g] = (sum_c gamma_c*S1_c, sum_c gamma_c*S2_c)/m.
 // In the backward launch the blocks after samples*groups compute the parameter gradients
@@ -1594,8 +1681,18 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
     RN_LAUNCH_CHECK();
     return RN_OK;
   }
-  hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(a.total_chunks), dim3(T), 0, st, a);
-  hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(a.total_samples * a.groups), dim3(T), 0, st, a);
+  {
+    static const bool f16_stats = !(getenv("RN_GN_F16_STATS") && atoi(getenv("RN_GN_F16_STATS")) == 0);     // (0: the generic kernels; A/B)
+    const int c8 = a.c >> 3;
+    if (f16_stats && a.in_half && !a.strided && a.c % 8 == 0 && c8 <= T && T % c8 == 0)
+      hipLaunchKernelGGL(gn_partial_f16x8_kernel, dim3(a.total_chunks), dim3(T), 0, st, a);
+    else
+      hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(a.total_chunks), dim3(T), 0, st, a);
+    if (f16_stats && a.c % 64 == 0 && a.cpg <= 64 && 64 % a.cpg == 0)
+      hipLaunchKernelGGL(gn_finalize_cols_segs_kernel, dim3(a.total_samples * (a.c / 64)), dim3(T), 0, st, a);
+    else
+      hipLaunchKernelGGL(gn_finalize_kernel<false>, dim3(a.total_samples * a.groups), dim3(T), 0, st, a);
+  }
   if (a.in_half && a.out_half && a.c % 8 == 0 && a.drop_rate == 0.f)
     switch (a.act) {  // activation as a template parameter: no per-element switch in a bandwidth-bound pass
       case RN_ACT_RELU: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_RELU>, dim3(apply_blocks(a, 8), a.total_samples), dim3(T), 0, st, a); break;
