@@ -228,7 +228,14 @@ int rn_get_product_mode(void);
  * bytes), bias fp32, y fp16 (out_f32 = 0) or fp32 (out_f32 = 1).  cin/G must be a multiple of 4.
  * The packed kernel is Wt[cout][kh*kw*cin/G] and, when kh*kw*cin/G is a multiple of 16, 256-byte aligned behind it, the
  * same values once more in matrix-core fragment order Wf[ceil(cout/32)][K/16][64 lanes][8] (channels padded with zeros):
- * the large-tile kernel reads its weight operand from that copy straight into registers. */
+ * the large-tile kernel reads its weight operand from that copy straight into registers.
+ * A 3 x 3 kernel with 4 / 8 / 16 / 32 input channels per group and cout % 32 == 0 carries a THIRD copy, 256-byte aligned behind
+ * the others: Ws[cout/32][9 taps][2][64 lanes][8], the block-diagonal 32 x 32 kernel of every super-group of 32 consecutive
+ * channels in fragment order (lane l: output channel l & 31, input channels 16 step + 8 (l >> 5) .. + 7 of the super-group; zero
+ * where the two belong to different groups of cin_g channels).  Grouped 3 x 3 convs with as many input as output channels per
+ * group on maps of whole 16 x 16 (stride 1) / 32 x 32 (stride 2) pixel tiles -- ResNeXt's conv 2, resnet.py:36-49 -- run from it:
+ * a block keeps the input patch of a 16 x 16 (8 x 16) output tile of one super-group in LDS and the kernel in registers; with
+ * rn_conv2d_fwd_f16_fold a GroupNorm + activation in front is applied once per patch element on its way into LDS. */
 size_t rn_pack_weights_f16_bytes(int kh, int kw, int cin_g, int cout);
 int rn_pack_weights_f16(const float* w, void* wt, int kh, int kw, int cin_g, int cout, rn_stream_t stream);
 int rn_cast_f32_to_f16(const float* x, void* y, int64_t count, rn_stream_t stream);

@@ -1,5 +1,5 @@
-"""cfg 5 (ResNeXt-50 32x4d, 1024^2, batch 16) fp16 inference, layer by layer: every distinct conv / GroupNorm-apply shape of the
-backbone timed ALONE from a replayed graph, with the bytes it must move and the FLOPs it executes -> GB/s, TFLOP/s and the time
+"""cfg 5 (ResNeXt-50 32x4d, 1024^2, batch 16) fp16 inference, layer by layer: every distinct conv / GroupNorm-apply launch of the
+backbone's bottlenecks as the product issues them (resnet.ResNeXt_Bottleneck._call_f16_folded), timed ALONE from a replayed graph, with the bytes it must move and the FLOPs it executes -> GB/s, TFLOP/s and the time
 the faster of the two rooflines would allow (HBM at 4.8 TB/s sustained, fp16 MFMA at 1.0 PFLOP/s sustained on random data).
 Usage: python tools/f16_layer_probe.py [batch]"""
 import os, sys, time
@@ -66,10 +66,13 @@ for si, (s, mid, out, nblk) in enumerate(stages):
         u, f = report(tag + " conv1 1x1 %d->%d @%d^2" % (cin, mid, hin), graph_time(lambda: ops_f16.conv2d_norm(x, w1, n1, act='relu')),
                       2.0 * M_in * (cin + mid), 2.0 * M_in * cin * mid)
         tot[0] += n_of * u; tot[1] += n_of * f
-        u, f = report(tag + " apply GN1 %d @%d^2" % (mid, hin), graph_time(lambda: p1.materialise()), 4.0 * M_in * mid, 0.0)
-        tot[0] += n_of * u; tot[1] += n_of * f
-        a1 = p1.materialise()
         stride = 2 if (first and si > 0) else 1
+        if ops_f16.sg_kernel_takes(p1.y.shape, w2, stride, 32):
+            a1 = p1                                   # the grouped conv applies GN1 + ReLU while its input patch goes to LDS
+        else:
+            u, f = report(tag + " apply GN1 %d @%d^2" % (mid, hin), graph_time(lambda: p1.materialise()), 4.0 * M_in * mid, 0.0)
+            tot[0] += n_of * u; tot[1] += n_of * f
+            a1 = p1.materialise()
         p2 = ops_f16.conv2d_norm(a1, w2, n2, act='relu', stride=stride, groups=32)
         u, f = report(tag + " conv2 3x3 g32 %d s%d" % (mid, stride), graph_time(lambda: ops_f16.conv2d_norm(a1, w2, n2, act='relu', stride=stride, groups=32)),
                       2.0 * (M_in + M) * mid, 2.0 * M * 9 * (mid // 32) * mid)
@@ -86,9 +89,7 @@ for si, (s, mid, out, nblk) in enumerate(stages):
             u, f = report(tag + " identity 1x1 %d->%d s%d" % (cin, out, stride), graph_time(lambda: ops_f16.conv2d_norm(x, wi, ni, act=None, stride=stride)),
                           2.0 * (M_in * cin / (stride * stride) + M * out), 2.0 * M * cin * out)
             tot[0] += u; tot[1] += f
-            u, f = report(tag + " apply identity GN %d" % out, graph_time(lambda: pi.materialise()), 4.0 * M * out, 0.0)
-            tot[0] += u; tot[1] += f
-            ident = pi.materialise()
+            ident = pi                                # (its GroupNorm is applied inside the block's final apply pass)
         u, f = report(tag + " apply GN3 + residual + relu %d @%d^2" % (out, s), graph_time(lambda: p3.materialise(residual=ident, act_after_residual=True)),
                       6.0 * M * out, 0.0)
         tot[0] += n_of * u; tot[1] += n_of * f

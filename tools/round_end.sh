@@ -34,4 +34,5 @@ rm -rf gpurun_out/${R}_nms_prof gpurun_out/${R}_prof gpurun_out/${R}_pmc_fetch g
 [ -z "$QUICK" ] && (RN_MB_RESIDENT=1 timeout 300 python tools/mb_resident_phases.py 512 2 > gpurun_out/${R}_mb_resident_phases.txt 2>&1)
 [ -z "$QUICK" ] && (timeout 300 python tools/x3_bench.py > gpurun_out/${R}_x3_products.txt 2>&1; for v in 0 1 2 4 8 15; do echo "RN_X3_DBG=$v $(env RN_X3_DBG=$v timeout 300 python tools/x3_bench.py 2>&1 | grep 'mode 1' | tail -1)"; done > gpurun_out/${R}_x3_leave_one_out.txt 2>&1)
 [ -z "$QUICK" ] && (timeout 600 python tools/f16_trained_probe.py 2500 1e-2 2>&1 | tail -8 > gpurun_out/${R}_f16_trained_probe.txt)
+[ -z "$QUICK" ] && (timeout 400 python tools/f16_layer_probe.py > gpurun_out/${R}_f16_layers.txt 2>&1; timeout 300 python tools/bench_inference.py > gpurun_out/${R}_inference_lines.txt 2>&1)
 tail -3 gpurun_out/${R}_tests.log; tail -1 gpurun_out/${R}_smoke.log; tail -1 gpurun_out/${R}_bench.log | cut -c1-400
