@@ -817,6 +817,8 @@ def main():
                                    (args.loss, args.dropout),
                        "global_batch": world * BATCH, "image_size": IMAGE_SIZE, "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "backward_segments": len(sched),
+                       # one rank: nothing goes between the segments, so they, and the update, are captured as ONE graph
+                       "whole_step_in_one_graph": bool(tr_._graphs and len(tr_._graphs) > 5 and tr_._graphs[5]),
                        "arithmetic": ("fp32 storage, accumulation and results everywhere; the Winograd products (88 % of the multiply-adds) are evaluated "
                                       "on the bf16 matrix cores from EXACT three-way bf16 splits of the fp32 operands, six partial products per "
                                       "product: error <= ~2^-23 per elementary product, measured equal to the fp32 MFMA kernels' against fp64 "

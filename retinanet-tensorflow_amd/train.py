@@ -291,6 +291,12 @@ class Trainer(object):
         # (its next appearance re-captures: two warm-up passes + capture, logged).
         self._graph_cache = collections.OrderedDict()
         self.graph_cache_max = max(1, int(os.environ.get("RN_GRAPH_CACHE", "4")))
+        # One rank: nothing happens between the segments (the collectives are what they are cut for) -- the whole step, update
+        # included, is then ONE captured graph: the ~80 us a step the GPU idles at the two graph boundaries and in front of the
+        # eagerly launched update (profiles/r05_bench_step_timeline.txt: "idle stretches") disappear.  The update's host-side
+        # scalars are constants of such a graph: momentum SGD without clipping only (no step-dependent scalar), and a changed
+        # learning rate captures again (the rate is part of the cache key).  RN_WHOLE_STEP_GRAPH=0: segments as with several ranks.
+        self.whole_step_graph = os.environ.get("RN_WHOLE_STEP_GRAPH", "1") == "1"
         self.recaptures = 0
         self._static = None
         # the device word every fused dropout hashes (bumped by the optimizer kernel); replicas start it at different values
@@ -521,7 +527,38 @@ class Trainer(object):
                 ranges.append(self.segment_b(j))
             gbs.append(gb)
         self._parts = []
-        self._graphs = (ga, gbs, ranges, self._graph_out, self._static)
+        self._graphs = (ga, gbs, ranges, self._graph_out, self._static, False)
+
+    def _whole_step_ok(self):
+        return (self.whole_step_graph and self.use_graph and not self.allreduce.active
+                and self.opt.kind == 'momentum' and self.opt.clip <= 0.0 and FUSED_OPT_NORM and self.device.type == 'cuda')
+
+    def _capture_whole(self, features):
+        """segment A, every part of segment B and the optimizer's update as ONE graph (see __init__: whole_step_graph)."""
+        self._static = _clone_tree(features)
+        s = getattr(self, "_warm_stream", None)
+        if s is None:
+            s = self._warm_stream = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            counter = self.drop_counter.clone()
+            for _ in range(2):
+                self.forward_backward(self._static, advance_dropout=False)
+            self.drop_counter.copy_(counter)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        count = self.opt.step_count
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            self._graph_out = self.segment_a(self._static)
+            n = self.num_parts()
+            ranges = []
+            for j in range(n if n else (1 if self.cut_offset else 0)):
+                ranges.append((self.segment_b(j) if n else self.segment_b()) or (0, self.cut_offset))
+            self.opt.step(1.0, self.drop_counter)
+        self.opt.step_count = count                 # (recorded, not run: replays count their own steps)
+        self._parts = []
+        # (the parts' arena ranges are kept for reporting: the schedule several ranks would follow; no graph per part)
+        self._graphs = (g, [], ranges, self._graph_out, self._static, True)
 
     def step(self, features=None):
         # a feed (dataset.DeviceFeed: input_fn with stage / consumed) puts a NEW sample into its static device buffers before
@@ -529,6 +566,9 @@ class Trainer(object):
         # train_input_fn (train.py:190-202); one set of captured segments per input shape
         feed = self.input_fn if (features is None and hasattr(self.input_fn, 'stage')) else None
         key = feed.stage() if feed is not None else None
+        whole = self._whole_step_ok()
+        if whole:
+            key = (key, 'whole', self.opt.lr)
         if self.use_graph:
             if self._graphs is None:
                 self._graph_cache.clear()
@@ -540,7 +580,10 @@ class Trainer(object):
                           (key, len(self._graph_cache), self.graph_cache_max), file=sys.stderr, flush=True)
                 while len(self._graph_cache) >= self.graph_cache_max:
                     self._graph_cache.popitem(last=False)             # least recently used: its pool is freed with it
-                self._capture(features)
+                if whole:
+                    self._capture_whole(features)
+                else:
+                    self._capture(features)
                 self._graph_cache[key] = self._graphs
             else:
                 self._graph_cache.move_to_end(key)
@@ -554,6 +597,14 @@ class Trainer(object):
             class_loss, regr_loss = self.segment_a(features)
         if feed is not None:
             feed.consumed()
+        if self.use_graph and self._graphs[5]:
+            # the whole step was that one replay: what is left is the update's host-side bookkeeping
+            self.opt.step_count += 1
+            import ops_f16
+            ops_f16.weights_changed()
+            self.steps_done += 1
+            self.last = {'class_loss': class_loss, 'regr_loss': regr_loss, 'regularization_loss': self.opt.regularization_loss}
+            return self.last
         self.allreduce.launch(self.cut_offset, self.arena.count)      # heads + FPN: under the backbone's backward pass
         # ... and, without clipping (the global norm would need every gradient first), their UPDATE too: on a side stream, behind
         # segment A and the slice's collectives, while the backbone's backward pass (which reads neither these weights nor these

@@ -260,6 +260,9 @@ def test_stage_cut_backward_parts_bit_equal_to_single_segment(dev, backbone, use
     ta = train.Trainer(net_a, lv, loss_mode="focal", device=dev, use_graph=use_graph)
     tb = train.Trainer(net_b, lv, loss_mode="focal", device=dev, use_graph=use_graph, overlap=False)
     assert ta._stage_bb is not None and tb.cut_offset == 0
+    # (`ta` keeps the segments several ranks replay -- their schedule is what is checked here; `tb`, one rank's default, captures
+    # the whole step, update included, as ONE graph: the bit-equal weights below cover that path too)
+    ta.whole_step_graph = False
     seen = []
     orig = ta.allreduce.launch
     ta.allreduce.launch = lambda start=0, end=None: (seen.append((start, ta.arena.count if end is None else end)), orig(start, end))[1]
@@ -344,3 +347,42 @@ def test_deferred_tower_weight_gradients_change_no_bit(dev, use_graph, monkeypat
         assert oa["class_loss"].item() == ob["class_loss"].item() and oa["regr_loss"].item() == ob["regr_loss"].item()
     torch.cuda.synchronize()
     assert torch.equal(ta.arena.weights, tb.arena.weights)
+
+
+def test_whole_step_graph_equals_segments_and_eager(dev):
+    """One rank: segment A, segment B and the optimizer's update captured as ONE graph (Trainer.whole_step_graph) against the
+    segments several ranks replay (two graphs + the eagerly launched update) and against eager launches: the same kernels on the
+    same operands -- losses, regulariser, weights, optimizer slots and the dropout counter bit-identical after four steps at
+    dropout 0.2; a changed learning rate captures again instead of replaying the old constant."""
+    import dataset, layers, levels as levels_mod, ops, retinanet, train
+    lv = levels_mod.build_levels()
+
+    def build(use_graph, whole):
+        layers.Dropout._next_seed[0] = 0x5EED
+        torch.manual_seed(4)
+        net = retinanet.RetinaNet('mobilenet_v2', lv, 4, layers.elu, 0.2).to(dev)
+        t = train.Trainer(net, lv, loss_mode="focal", device=dev, use_graph=use_graph)
+        t.whole_step_graph = whole
+        return t
+
+    tw, ts, te = build(True, True), build(True, False), build(False, False)
+    rng = np.random.default_rng(2)
+    size = 256
+    image = torch.from_numpy(rng.standard_normal((2, size, size, 3)).astype(np.float32)).to(dev)
+    boxes = torch.tensor([[[0.1, 0.2, 0.7, 0.8], [0.4, 0.1, 0.9, 0.5]]], device=dev)
+    cids = torch.tensor([[1, 3]], dtype=torch.int32, device=dev)
+    c, r, m = dataset.build_labels((size, size), cids, boxes, lv, 4, flip_pair=True)
+    feats = {"image": image, "detection": {"classifications": c, "regressions": r}, "trainable_masks": m}
+    for i in range(4):
+        if i == 2:
+            for t in (tw, ts, te):
+                t.opt.lr = 0.5 * t.opt.lr
+        ow, os_, oe = tw.step(feats), ts.step(feats), te.step(feats)
+        for k in ("class_loss", "regr_loss", "regularization_loss"):
+            assert ow[k].item() == os_[k].item() == oe[k].item(), (i, k, ow[k].item(), os_[k].item(), oe[k].item())
+    torch.cuda.synchronize()
+    assert tw._graphs[5] and not ts._graphs[5] and len(tw._graph_cache) == 2
+    assert torch.equal(tw.arena.weights, ts.arena.weights) and torch.equal(tw.arena.weights, te.arena.weights)
+    assert torch.equal(tw.opt.state1, ts.opt.state1) and torch.equal(tw.opt.state1, te.opt.state1)
+    assert tw.drop_counter.item() == ts.drop_counter.item() == te.drop_counter.item() == 4 * ops.DROPOUT_COUNTER_STEP
+    assert tw.opt.step_count == ts.opt.step_count == te.opt.step_count == 4 and tw.steps_done == 4

@@ -48,6 +48,18 @@ def main(path):
     print("step: %d kernels, wall %.0f us, >=1 kernel running %.0f us (%.0f%%), idle %.0f us (%.0f%%), two overlapping %.0f us"
           % (len(step), wall, busy / 1e3, 100 * busy / 1e3 / wall, wall - busy / 1e3, 100 * (wall - busy / 1e3) / wall, over / 1e3))
     print("queues:", sorted(set(r['Queue_Id'] for r in step)))
+    # where the GPU is idle: the longest stretches with no kernel running, with the kernels on either side
+    gaps, cur_end, prev = [], t0, None
+    for r in sorted(step + [rows[hi]], key=lambda r: int(r['Start_Timestamp'])):
+        st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        if st > cur_end and prev is not None:
+            gaps.append((st - cur_end, (cur_end - t0) / 1e3, short(prev['Kernel_Name']), short(r['Kernel_Name'])))
+        if en > cur_end:
+            cur_end, prev = en, r
+    gaps.sort(reverse=True)
+    print("idle stretches: %d, the longest:" % len(gaps))
+    for g, at, a_, b_ in gaps[:8]:
+        print("  %6.1f us at %7.1f us: after %s, before %s" % (g / 1e3, at, a_, b_))
     tot = sum(v[1] for v in fam.values())
     print("sum of kernel durations %.0f us" % tot)
     for k, (n, us) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
