@@ -319,3 +319,69 @@ def test_stem_conv_statistics_and_fused_norm_pool(dev):
     two = ops_f16.max_pool(p.materialise(), 3, 2)
     assert fused.shape == two.shape == (2, 16, 24, 64)
     assert torch.equal(fused, two)
+
+
+@pytest.mark.parametrize("act,stride", [("elu", 1), ("relu", 2), (None, 1), ("elu", 2)])
+def test_super_group_conv_with_pending_groupnorm_equals_materialised(dev, act, stride):
+    """The grouped 3 x 3 kernel on LDS-resident patches (conv3x3_sg32_f16_kernel) applying a PENDING GroupNorm + activation while
+    the patch goes to LDS (FIN = 2: ReLU through v_fma_mixlo/hi_f16 + packed max; FIN = 1: any activation in fp32) against the
+    same kernel on the materialised tensor: the same fp32 arithmetic on the same fp16 values -- equal bits for FIN = 1, an fp16 ulp
+    of the activation for FIN = 2; zero padding stays zero AFTER the activation (beta != 0 would show at the borders)."""
+    import ops_f16
+    g = torch.Generator().manual_seed(31 + stride)
+    c = 256
+    x = (torch.randn(2, 32, 64, c, generator=g) * 1.3 + 0.2).to(dev).half()
+    w1 = (torch.randn(1, 1, c, c, generator=g) / c ** 0.5).to(dev)
+    w2 = (torch.randn(3, 3, c // 32, c, generator=g) / (9 * c / 32) ** 0.5).to(dev)
+
+    class Norm(object):
+        def __init__(self):
+            self.groups, self.eps = 32, 1e-5
+            self.gamma = (1 + 0.2 * torch.randn(c, generator=g)).to(dev)
+            self.beta = (0.5 + 0.1 * torch.randn(c, generator=g)).to(dev)
+        def build(self, c_, d):
+            pass
+    n1, n2 = Norm(), Norm()
+    p1 = ops_f16.conv2d_norm(x, w1, n1, act=act)
+    assert ops_f16.sg_kernel_takes(p1.y.shape, w2, stride, 32)
+    folded = ops_f16.conv2d_norm(p1, w2, n2, act='relu', stride=stride, groups=32)
+    plain = ops_f16.conv2d_norm(p1.materialise(), w2, n2, act='relu', stride=stride, groups=32)
+    assert folded is not None and plain is not None and folded.y.shape == (2, 32 // stride, 64 // stride, c)
+    if act == "relu":
+        # v_fma_mixlo/hi_f16 rounds the exact fma ONCE, to fp16; the apply pass rounds it to fp32 first: the rare double-rounding
+        # cases differ by one fp16 ulp of the activation (the mixed-precision instruction is the more exact one)
+        assert_close(folded.y.float().cpu().numpy(), plain.y.float().cpu().numpy(), 1e-3, "GroupNorm + ReLU on the patch load vs materialised")
+        assert_close(folded.mean.cpu().numpy(), plain.mean.cpu().numpy(), 1e-4, "mean")
+        assert_close(folded.rstd.cpu().numpy(), plain.rstd.cpu().numpy(), 1e-4, "rstd")
+    else:
+        assert torch.equal(folded.y, plain.y), float((folded.y.float() - plain.y.float()).abs().max())
+        assert torch.equal(folded.mean, plain.mean) and torch.equal(folded.rstd, plain.rstd)
+
+
+@pytest.mark.parametrize("act,after", [("relu", True), (None, False), ("elu", True)])
+def test_apply_with_pending_residual_norm(dev, act, after):
+    """rn_group_norm_apply_res_f16 (the residual is a raw conv output with its own activation-free GroupNorm) against the apply pass
+    on the MATERIALISED residual: the fused pass skips one fp16 rounding of the residual, so the two agree to an fp16 rounding of it
+    (1e-3 of the range), and the fused one is the closer of the two to the fp32 result."""
+    import ops_f16
+    g = torch.Generator().manual_seed(5)
+    n, h, w, c = 2, 24, 20, 256
+    mk = lambda: (torch.randn(n, h, w, c, generator=g) * 1.5 + 0.3).to(dev).half()
+    y, r = mk(), mk()
+    stat = lambda t: (t.float().reshape(n, h * w, 32, c // 32).mean(dim=(1, 3)), 1.0 / torch.sqrt(t.float().reshape(n, h * w, 32, c // 32).var(dim=(1, 3), unbiased=False) + 1e-5))
+    gam = lambda: (1 + 0.2 * torch.randn(c, generator=g)).to(dev)
+    bet = lambda: (0.1 * torch.randn(c, generator=g)).to(dev)
+    my, ry = stat(y); mr, rr = stat(r)
+    py = ops_f16.Pending(y, my.contiguous(), ry.contiguous(), gam(), bet(), 32, act)
+    pr = ops_f16.Pending(r, mr.contiguous(), rr.contiguous(), gam(), bet(), 32, None)
+    fused = py.materialise(residual=pr, act_after_residual=after)
+    two = py.materialise(residual=pr.materialise(), act_after_residual=after)
+    assert_close(fused.float().cpu().numpy(), two.float().cpu().numpy(), 1e-3, "fused residual norm vs materialised residual")
+    # fp32 reference of the same expression
+    def gn(t, p):
+        xh = (t.float().reshape(n, h * w, 32, c // 32) - p.mean.reshape(n, 1, 32, 1)) * p.rstd.reshape(n, 1, 32, 1)
+        return xh.reshape(n, h, w, c) * p.gamma + p.beta
+    f = {"relu": torch.relu, "elu": torch.nn.functional.elu, None: (lambda t: t)}[act]
+    ref = f(gn(y, py) + gn(r, pr)) if after else f(gn(y, py)) + gn(r, pr)
+    e_f = float((fused.float() - ref).abs().max()); e_t = float((two.float() - ref).abs().max())
+    assert e_f <= e_t * 1.05 + 1e-6, (e_f, e_t)
