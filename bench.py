@@ -12,10 +12,12 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline     : the dominant kernel INSIDE the step -- the forward products of a Winograd F(4x4,3x3) head-tower layer
                  (36 x [682x256] x [256x256], 17 launches per step; the two backward product launches of the same layer are
                  `entries[0]`) -- timed from a replayed hipGraph with HIP events on the launch stream.  The products run on
-                 the bf16 matrix cores from exact three-way splits of the fp32 operands (csrc/gemm_x3.hip): `achieved` =
-                 EXECUTED bf16 FLOPs (6 x the fp32 product's) against the 2.5 PFLOP/s dense bf16 peak of MI355X_MICROARCH.md,
-                 `fp32_equivalent` = the product's own FLOPs against the 157.3 TFLOP/s fp32 matrix-core peak (the yardstick of
-                 rounds 1-4).  `entries` also holds the stem (the largest stand-alone GroupNorm);
+                 the bf16 matrix cores from exact three-way splits of the fp32 operands (csrc/gemm_x3.hip): `achieved` / `frac` =
+                 the launch's ALGORITHMIC fp32 FLOPs against the 157.3 TFLOP/s dense fp32 matrix-core peak of MI355X_MICROARCH.md
+                 (the yardstick of rounds 1-4; round 5 printed this as `fp32_equivalent`), `executed_bf16` = the six bf16
+                 partial products per fp32 product the kernel issues, against the 2.5 PFLOP/s dense bf16 peak (round 5's top-level
+                 figure).  `traffic` / `rocprof_kernel_ms` are replayed from profiles/ only while the kernel sources hash to what
+                 was measured (tools/src_hash.py).  `entries` also holds the stem (the largest stand-alone GroupNorm);
   nms          : decode + candidate scan + hand-written segment sort + class-wise NMS at BASELINE configs[4]'s shape, fp16
                  logits / box deltas as the fp16 net writes them (sigmoid inside the scan), ~1 % hot and the stress input;
   cpu_baseline : the CPU oracle (restatement of the reference's TF semantics, TF itself is not installable) timed on
@@ -50,6 +52,9 @@ TRAIN_GFLOP_PER_IMAGE = 239.2       # BASELINE.md section 3 (3 x forward conv FL
 # Winograd F(4x4,3x3): 36 instead of 144 multiplies per 4x4 output tile = exactly 1/4 (every pyramid map of a 512^2 image is a
 # whole number of tiles).  EXECUTED = (39.87 - 38.268) + 38.268 / 4 = 11.169 GMAC forward -> x 2 FLOP x 3 passes:
 EXECUTED_TRAIN_GFLOP_PER_IMAGE = 67.0
+# name prefix and grid of the forward product launch of a head-tower layer in a rocprofv3 trace (the `roofline` kernel)
+X3_FWD_KERNEL = "gemm_x3_kernel<false, true, 2, 2>"
+X3_FWD_GRID = lambda tiles: 36 * (-(-tiles // 128)) * 2       # noqa: E731
 PRODUCT_REPS = 8                    # back-to-back launches per graph when the product kernels are timed alone (_graph_time)
 FP16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
 INFERENCE_GFLOP_PER_IMAGE = 596.0   # cfg 5 forward, 297.98 GMAC per 1024^2 image
@@ -93,7 +98,7 @@ class Step(object):
     """assignment + train step; the replica-local work is train.Trainer's two backward segments (each one hipGraph), the
     gradient all-reduce of the heads + FPN region runs under the backbone's backward pass."""
 
-    def __init__(self, device, use_graph, loss_mode, dropout, rank, overlap=True, force_collective=False):
+    def __init__(self, device, use_graph, loss_mode, dropout, rank, overlap=True, force_collective=False, capture_collectives=None):
         import dataset, layers, levels, retinanet, train
         torch.manual_seed(0)                       # identical initial weights on every rank
         self.levels = levels.build_levels()
@@ -104,7 +109,7 @@ class Step(object):
         self.dataset = dataset
         self.trainer = train.Trainer(self.net, self.levels, optimizer='momentum', learning_rate=1e-2,
                                      loss_mode=loss_mode, device=device, use_graph=use_graph, overlap=overlap,
-                                     force_collective=force_collective, input_fn=self.features,
+                                     force_collective=force_collective, input_fn=self.features, capture_collectives=capture_collectives,
                                      wgrad_side_stream=os.environ.get("RN_WGRAD_SIDE_STREAM") == "1")
         train.broadcast_initial_state(self.trainer)
 
@@ -201,12 +206,16 @@ def roofline_kernels(device):
     with torch.no_grad():
         layer_ms = _graph_time(lambda: ops.conv2d(xs, w, None, 1))
     pixels = BATCH * sum(s * s for s in sizes)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from src_hash import kernel_source_hash
+    src_sha = kernel_source_hash()
     traffic = {}
     if os.path.exists(PMC_TRAFFIC_FILE):
         traffic = json.load(open(PMC_TRAFFIC_FILE))
         # a stored measurement of ANOTHER workload (a stale file) must not be printed beside this one
         if traffic.get("_shape") != {"points": 36, "tiles": tiles, "cin": 256, "cout": 256, "batch": BATCH, "image": IMAGE_SIZE} \
-                or int(traffic.get("_product_mode", 0)) != int(L.rn_get_product_mode()):
+                or int(traffic.get("_product_mode", 0)) != int(L.rn_get_product_mode()) \
+                or traffic.get("_kernel_source_sha") != src_sha:      # ... nor one of OTHER kernel code (edited since it was measured)
             traffic = {}
 
     def rocprof_avg_us(kernel_prefix, blocks):
@@ -216,6 +225,9 @@ def roofline_kernels(device):
         files = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_trace_by_grid.txt")))
         if not files:
             return None, None
+        head = open(files[-1]).readline()
+        if not head.startswith("# kernel_source_sha:") or head.split(":", 1)[1].strip() != src_sha:
+            return None, None          # the committed trace is of other kernel code: not this run's evidence
         for line in open(files[-1]):
             name = line[:65].strip()
             cols = line[65:].split()
@@ -237,25 +249,27 @@ def roofline_kernels(device):
 
     x3 = bool(L.rn_get_product_mode())
     if x3:
-        # the products run on the bf16 matrix cores from exact three-way splits (csrc/gemm_x3.hip): SIX bf16 products per fp32
-        # product.  `achieved` counts the EXECUTED bf16 FLOPs against the dense bf16 peak; `fp32_equivalent` is the algorithmic
-        # (fp32) FLOPs of the same launch against the fp32 matrix-core peak the previous rounds' kernels were priced on.
-        tm, tn = -(-tiles // 128), 2
-        fwd = entry("head-tower layer, forward products (largest in-step kernel: 17 launches per step)",
-                    "gemm_x3_kernel<false,true,2,2>: 36 x [682x256]x[256x256], fp32 operands split into 3 bf16, 6 bf16 MFMA products, fp32 accumulate",
-                    "mfma", 6 * flops, fwd_ms, FP16_MFMA_PEAK_TFLOPS, "TFLOP/s", fwd_bytes, "fwd_products",
-                    prof=("gemm_x3_kernel<false, true, 2, 2>", 36 * tm * tn))
-        fwd["flops_per_launch"] = flops
-        fwd["executed_bf16_flops_per_launch"] = 6 * flops
-        fwd["fp32_equivalent"] = {"achieved": round(flops / (fwd_ms * 1e-3) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(flops / (fwd_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
-        bwd = entry("head-tower layer, backward products: data-gradient launch + weight-gradient launch (8 pairs per step)",
-                    "gemm_x3_kernel<false,false,2,2> + gemm_x3_kernel<true,true,2,2>: 36 x ([682x256]x[256x256]^T + [256x682]x[682x256] in %d ranges)" % max(nsplit.value, 1),
-                    "mfma", 12 * flops, bwd_ms, FP16_MFMA_PEAK_TFLOPS, "TFLOP/s", bwd_bytes, "bwd_products")
-        bwd["flops_per_launch"] = 2 * flops
-        bwd["executed_bf16_flops_per_launch"] = 12 * flops
-        bwd["fp32_equivalent"] = {"achieved": round(2 * flops / (bwd_ms * 1e-3) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(2 * flops / (bwd_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+        # the products run on the bf16 matrix cores from exact three-way splits (csrc/gemm_x3.hip): SIX bf16 products per fp32 product.
+        # Top level (`achieved` / `peak` / `frac`): the ALGORITHMIC fp32 FLOPs of the launch against the dense fp32 matrix-core
+        # peak -- the scale rounds 1-4 were quoted on, comparable round over round, and not inflated by redundant work.
+        # `executed_bf16`: the six bf16 partial products the kernel actually issues, against the dense bf16 peak of that instruction.
+        def x3_entry(e, alg_flops, ms):
+            e["flops_per_launch"] = alg_flops
+            e["executed_bf16_flops_per_launch"] = 6 * alg_flops
+            ex = 6 * alg_flops / (ms * 1e-3) / 1e12
+            e["executed_bf16"] = {"achieved": round(ex, 2), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ex / FP16_MFMA_PEAK_TFLOPS, 4),
+                                  "what": "6 bf16 MFMA products per fp32 product (exact 3-way split), priced against the dense bf16 peak"}
+            # timing method (changed in round 5; kept since): HIP events around replayed graphs of `reps` back-to-back launches
+            e["reps"] = PRODUCT_REPS
+            return e
+
+        fwd = x3_entry(entry("head-tower layer, forward products (largest in-step kernel: 17 launches per step)",
+                             "gemm_x3_kernel: 36 x [682x256]x[256x256], fp32 operands split into 3 bf16, 6 bf16 MFMA products, fp32 accumulate",
+                             "mfma", flops, fwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", fwd_bytes, "fwd_products",
+                             prof=(X3_FWD_KERNEL, X3_FWD_GRID(tiles))), flops, fwd_ms)
+        bwd = x3_entry(entry("head-tower layer, backward products: data-gradient launch + weight-gradient launch (8 pairs per step)",
+                             "gemm_x3_kernel (dgrad) + gemm_x3_kernel (wgrad): 36 x ([682x256]x[256x256]^T + [256x682]x[682x256] in %d ranges)" % max(nsplit.value, 1),
+                             "mfma", 2 * flops, bwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", bwd_bytes, "bwd_products"), 2 * flops, bwd_ms)
     else:
         bwd = entry("head-tower layer, merged backward products (largest in-step kernel, 8 launches per step)",
                     "conv_bwd_kernel<64,64,2,2,true,64,64,2,2>: 36 x ([682x256]x[256x256]^T dgrad + [256x682]x[682x256] wgrad partials)",
@@ -583,6 +597,7 @@ class _StandinAllReduce(object):
         import _rn
         self._rn, self.arena, self.blocks, self.ranks, self.link = _rn, arena, blocks, ranks, link_GBps
         self.active, self.world, self.rank, self.launched = True, 1, 0, []
+        self.capturable, self.host_staged = True, False                  # (a kernel on a private stream: recorded into the step's graph)
         self.stream = torch.cuda.Stream(device=arena.grads.device)       # (private: not one of _rn's joined side streams)
         self.sink = torch.empty_like(arena.grads)
 
@@ -631,12 +646,46 @@ def collective_standin(step, steps=60, warmup=10):
     return out
 
 
+def collective_path_n1(args, device, plain_ips, steps=100, warmup=20):
+    """The step several ranks run, on ONE rank: an RCCL process group of world size 1 with the collectives issued (nodes of the
+    step's graph), the FPN / subnets split of the heads' slice behind the deferred weight-gradient products, MobileNetV2's
+    stage cut.  What a scaling efficiency should be read against: the N = 1 `value` carries no collective and no stage cut."""
+    import torch.distributed as dist
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        step = Step(device, use_graph=not args.no_graph, loss_mode=args.loss, dropout=args.dropout, rank=0, force_collective=True)
+        step.trainer.check_interval = 0
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        tr = step.trainer
+        ips = BATCH * steps / el
+        out = {"images_per_sec": round(ips, 2), "ms_per_step": round(1e3 * el / steps, 4), "of_plain": round(ips / plain_ips, 4),
+               "whole_step_in_one_graph": bool(tr._graphs and tr._graphs[5]), "collectives_captured_in_graph": bool(tr.allreduce.capturable),
+               "tower_weight_gradients_deferred": bool(tr.defer_wgrad), "slice_schedule_bytes": [4 * (hi - lo) for lo, hi in tr.schedule]}
+        del step, tr
+    finally:
+        if own:
+            dist.destroy_process_group()
+    torch.cuda.empty_cache()
+    return out
+
+
 def allreduce_slices(trainer, iters=20):
     """Per-slice RCCL all-reduce time alone (HIP events on the launch stream around `iters` back-to-back collectives) and
     its bus bandwidth 2 (R-1)/R x bytes / time: what one xGMI ring sustains for the messages this step sends."""
     import torch.distributed as dist
     ar = trainer.allreduce
-    ranges = [(trainer.cut_offset, trainer.arena.count)] + ([tuple(r) for r in trainer._graphs[2]] if trainer._graphs else [(0, trainer.cut_offset)])
+    ranges = [tuple(r) for r in trainer.schedule] or [(0, trainer.arena.count)]
     buf = torch.zeros_like(trainer.arena.grads)
     out = []
     for lo, hi in ranges:
@@ -733,12 +782,13 @@ def main():
 
     import ops
 
-    def run_once():
+    def run_once(capture_collectives=None, steps=None, warmup=None):
         """Build the step, warm up, time exactly args.steps steps; returns (step, elapsed, exposed, losses, gn_timeouts)."""
+        steps = args.steps if steps is None else steps
         step = Step(device, use_graph=not args.no_graph, loss_mode=args.loss, dropout=args.dropout, rank=rank,
-                    overlap=not args.no_overlap, force_collective=args.force_collective)
+                    overlap=not args.no_overlap, force_collective=args.force_collective, capture_collectives=capture_collectives)
         step.trainer.check_interval = 0            # checked explicitly below (a timeout switches the path, it does not abort)
-        for _ in range(args.warmup):
+        for _ in range(args.warmup if warmup is None else warmup):
             step()
 
         def barrier():
@@ -749,7 +799,7 @@ def main():
         step.trainer.timing = {}
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             out = step()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -779,23 +829,35 @@ def main():
 
     # multi-GPU evidence, collected on every rank (collectives) before rank 0 prints: per-rank exposed time, per-slice bus rate
     dist_info = None
+    segmented = None
+    if dist is not None and step.trainer.allreduce.active and step.trainer._graphs and step.trainer._graphs[5]:
+        # the collectives are nodes of the step's graph: no event can be put around the final wait.  The time the compute stream
+        # waits for collectives after the last backward kernel is measured on the OTHER path -- one graph per part, eager
+        # collectives between them (what runs where RCCL's all-reduce cannot be captured) -- in a short second run, every rank
+        # taking part; its rate is printed beside the headline as the A/B of the two paths on this node
+        st2, el2, ex2, _l2, _t2 = run_once(capture_collectives=False, steps=min(args.steps, 40), warmup=min(args.warmup, 10))
+        segmented = {"images_per_sec": round(world * BATCH * min(args.steps, 40) / el2, 2), "allreduce_exposed_ms": round(ex2, 4),
+                     "slice_schedule_bytes": [4 * (hi - lo) for lo, hi in st2.trainer.schedule]}
+        exposed_tr = st2.trainer
+    else:
+        exposed_tr = step.trainer
     if dist is not None:
         per_rank = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
-        dist.all_gather(per_rank, torch.tensor([step.trainer.allreduce_exposed_ms()], dtype=torch.float64, device=device))
+        dist.all_gather(per_rank, torch.tensor([exposed_tr.allreduce_exposed_ms()], dtype=torch.float64, device=device))
         per_rank = [float(t.item()) for t in per_rank]
         dist_info = {"rccl_ranks": world, "allreduce_exposed_ms_per_rank": [round(x, 4) for x in per_rank],
                      "allreduce_exposed_ms_max": round(max(per_rank), 4), "allreduce_exposed_ms_mean": round(sum(per_rank) / world, 4),
                      "slices": allreduce_slices(step.trainer)}
+        if segmented is not None:
+            dist_info["one_graph_per_part_eager_collectives"] = segmented
+            exposed = segmented["allreduce_exposed_ms"]
+        del exposed_tr
 
     result = None
     # the gradient slices in the order the trainer reduces them: heads + FPN after segment A, then one per part of the backbone's
     # backward pass (MobileNetV2 has two parts while a collective is active: cut behind the C3 tap)
     tr_ = step.trainer
-    if tr_.cut_offset:
-        parts = [tuple(r) for r in tr_._graphs[2]] if tr_._graphs else [(0, tr_.cut_offset)]
-        sched = [(tr_.cut_offset, tr_.arena.count)] + parts
-    else:
-        sched = [(0, tr_.arena.count)]
+    sched = [tuple(r) for r in tr_.schedule] or [(0, tr_.arena.count)]     # the slices in the order the last step issued them
     # one rank issues no collective and therefore takes no cut inside MobileNetV2's chain (it costs two kernels and hides
     # nothing): the schedule several ranks follow is printed beside this run's own
     multi = [4 * (hi - lo) for lo, hi in sched]
@@ -804,7 +866,8 @@ def main():
         import mobilenet_v2
         first = next(iter(getattr(bb_, bb_.block_names[bb_.block_names.index(mobilenet_v2.STAGE_CUT_AFTER) + 1]).parameters()))
         off = tr_._param_offset[id(first)]
-        multi = [4 * (tr_.arena.count - tr_.cut_offset), 4 * (tr_.cut_offset - off), 4 * off]
+        # (FPN slice when segment A ends, the subnets' slice behind their deferred weight-gradient products, then the chain's two parts)
+        multi = [4 * (tr_.heads_offset - tr_.cut_offset), 4 * (tr_.arena.count - tr_.heads_offset), 4 * (tr_.cut_offset - off), 4 * off]
     if rank == 0:
         ips = world * BATCH * args.steps / elapsed
         result = {
@@ -816,9 +879,13 @@ def main():
                                    "%s + smooth-L1, dropout %.2f, momentum SGD, anchor assignment in the step" %
                                    (args.loss, args.dropout),
                        "global_batch": world * BATCH, "image_size": IMAGE_SIZE, "parallelism": "dp%d" % world,
-                       "hip_graph": not args.no_graph, "backward_segments": len(sched),
-                       # one rank: nothing goes between the segments, so they, and the update, are captured as ONE graph
+                       "hip_graph": not args.no_graph,
+                       "backward_segments": 1 + sum(1 for lo, hi in sched if hi <= tr_.cut_offset) if tr_.cut_offset else 1,
+                       # segment A, the collectives (nodes of the graph when RCCL's all-reduce replays correctly from a captured
+                       # graph: probed at start-up on every rank), every part of segment B and the update: ONE graph per step
                        "whole_step_in_one_graph": bool(tr_._graphs and len(tr_._graphs) > 5 and tr_._graphs[5]),
+                       "collectives_captured_in_graph": bool(tr_.allreduce.active and tr_._graphs and tr_._graphs[5]),
+                       "tower_weight_gradients_deferred": bool(tr_.defer_wgrad),
                        "arithmetic": ("fp32 storage, accumulation and results everywhere; the Winograd products (88 % of the multiply-adds) are evaluated "
                                       "on the bf16 matrix cores from EXACT three-way bf16 splits of the fp32 operands, six partial products per "
                                       "product: error <= ~2^-23 per elementary product, measured equal to the fp32 MFMA kernels' against fp64 "
@@ -865,6 +932,10 @@ def main():
                 result["config"]["collective_standin"] = collective_standin(step)
             del step
             torch.cuda.empty_cache()
+            if not args.no_graph and not started:
+                cp = collective_path_n1(args, device, ips)
+                result["config"]["allreduce"]["n1_collective_path"] = cp
+                result["config"]["allreduce"]["n1_collective_path_images_per_sec"] = cp["images_per_sec"]
             result["config"]["fresh_data"] = fresh_data(device, ips)
             result["config"]["cfg1_gpu"] = cfg1_gpu(device)
             torch.cuda.empty_cache()

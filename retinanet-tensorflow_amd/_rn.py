@@ -448,7 +448,10 @@ def _hand_over(key, h, device):
             torch.cuda.current_stream(device).wait_event(ev)
         except RuntimeError:
             pass                # (the previous stream no longer exists: nothing left to wait for)
-    _region_owner[key] = h
+    if device.type != 'cuda' or not torch.cuda.is_current_stream_capturing():
+        # (a capture stream is not an owner anyone can wait for later: it may be gone by then, and nothing could be recorded on
+        # it from outside anyway -- the previous REAL owner stays on record)
+        _region_owner[key] = h
 
 
 def resident_sync(device):
@@ -474,6 +477,12 @@ def resident_errors():
     for t in _resident_words.values():
         e |= int(t[512].item())
     return e
+
+
+def barrier_timeout_sources():
+    """(GroupNorm exchange regions with their error word set, MobileNetV2 resident-section counter sets with theirs set)."""
+    return (sum(int(t[2].item()) for t in {id(t): t for t in _sync_words.values()}.values()),
+            sum(1 for t in _resident_words.values() if int(t[512].item()) != 0))
 
 
 def barrier_timeouts():
@@ -504,11 +513,11 @@ def side_stream(device, index=0):
     return st
 
 
-def join_side_streams(device):
-    """Make the current stream wait for everything queued on this device's side streams."""
+def join_side_streams(device, skip=()):
+    """Make the current stream wait for everything queued on this device's side streams (except the indices in `skip`)."""
     cur = torch.cuda.current_stream(device)
-    for (t, i, _), st in _side_streams.items():
-        if t == device.type and i == device.index:
+    for (t, i, idx), st in _side_streams.items():
+        if t == device.type and i == device.index and idx not in skip:
             cur.wait_stream(st)
 
 

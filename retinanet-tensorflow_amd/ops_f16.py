@@ -177,7 +177,9 @@ def conv2d_norm(x, w, norm, act=None, stride=1, groups=1):
     GroupNorm + activation are applied by this conv's operand load)."""
     src = x.y if isinstance(x, Pending) else x.contiguous()
     kh, kw, cin_g, cout = w.shape
-    pad = src.shape[3] if (groups == 1 and src.shape[3] > cin_g and not isinstance(x, Pending)) else None     # RGB image padded to 4 channels
+    # the RGB image padded to 4 fp16 channels against a 3-input kernel -- and nothing else: any other channel mismatch is a
+    # mis-wired layer and must not be papered over with zero weights (the check below then returns None and the caller raises)
+    pad = 4 if (groups == 1 and src.shape[3] == 4 and cin_g == 3 and not isinstance(x, Pending)) else None
     wt, g2, cin = packed_weight(w, groups, pad)
     if src.shape[3] != cin:
         return None

@@ -161,6 +161,7 @@ class ResNeXt(Model):
             # (fp16 inference: stem and pool as one normalise-and-pool pass; C1 itself -- which no caller of an inference pass
             # reads -- is not materialised)
             input = self._conv_1(input, training=training, pool=self._conv_1_max_pool)
+            out['C1'] = None            # (the key the other paths and the reference return, resnet.py:203: present, not materialised here)
         else:
             input = self._conv_1(input, training=training)
             out['C1'] = input

@@ -32,7 +32,6 @@ from levels import build_levels
 
 OPT_BLOCK = _rn.OPT_BLOCK
 FUSED_OPT_NORM = os.environ.get("RN_FUSED_OPT_NORM", "1") == "1"     # (tuning aids; both parity-neutral)
-EARLY_HEAD_UPDATE = os.environ.get("RN_EARLY_HEAD_UPDATE", "0") == "1"     # measured: 444 vs 448 images/s (one more stream in the step costs more than the overlap buys)
 
 
 class ParamArena(object):
@@ -85,7 +84,7 @@ class Optimizer(object):
         self.state2 = torch.zeros_like(arena.weights) if kind != 'momentum' else None
         self.norm_reg = torch.zeros(2, dtype=torch.float32, device=dev)   # [sum g'^2, L2 reg loss]
         # (sum g'^2, regulariser) pairs of the slices of a step: allocated HERE, not lazily in begin_step -- a first-step zero-fill
-        # on the main stream would not be ordered against a side stream's slice update that writes its pairs (EARLY_HEAD_UPDATE)
+        # on the main stream would not be ordered against a side stream's slice update that writes its pairs
         self._pairs = 0
         self._partial = None
         if dev.type == 'cuda':
@@ -174,9 +173,54 @@ class GradientAllReduce(object):
         self.buckets = self.buckets_of(0, arena.count)
         self._works = []
         self.launched = []          # (start, end) of every bucket issued since the last wait(): for tests
+        self._capturable = None     # decided once, by doing it: probe_capturable()
 
     def buckets_of(self, start, end):
         return [(s, min(s + self.per, end)) for s in range(start, end, self.per)]
+
+    @property
+    def capturable(self):
+        """May launch() / wait() be recorded into a hipGraph (the collectives as nodes of the step's graph)?"""
+        return bool(self._capturable)
+
+    def probe_capturable(self, device):
+        """Decide -- by doing it, on every rank, with a known answer -- whether this backend's all-reduce can be CAPTURED into a
+        hipGraph and replayed: rank r contributes r + 1, a replay must leave world (world + 1) / 2 everywhere, twice (a second
+        replay must not reduce the first one's result again).  An exception or a wrong sum on ANY rank (MIN over ranks, eager
+        collective) selects the eager collectives between captured segments on EVERY rank.  RN_DP_CAPTURE=0 skips the probe
+        (never capture), =1 / auto (default) runs it."""
+        if self._capturable is not None:
+            return self._capturable
+        self._capturable = False
+        if (not self.active or self.host_staged or device.type != 'cuda' or os.environ.get("RN_DP_CAPTURE", "auto") == "0"):
+            return False
+        ok, why = 1.0, ""
+        try:
+            cur = torch.cuda.current_stream(device)
+            buf = torch.full((OPT_BLOCK,), float(self.rank + 1), dtype=torch.float32, device=device)
+            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)     # eager first: the communicator connects outside any capture
+            torch.cuda.synchronize(device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                w = self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w.wait()
+            want = float(self.world * (self.world + 1) // 2)
+            for _ in range(2):
+                buf.fill_(float(self.rank + 1))
+                g.replay()
+                cur.synchronize()
+                if not bool((buf == want).all().item()):
+                    ok, why = 0.0, "replayed all-reduce gave %r, expected %r" % (float(buf[0].item()), want)
+            del g
+        except Exception as e:       # noqa: BLE001 -- any failure means "do not capture", never "abort the run"
+            ok, why = 0.0, "%s: %s" % (type(e).__name__, e)
+        t = torch.tensor([ok], dtype=torch.float32, device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        self._capturable = bool(t.item() == 1.0)
+        if not self._capturable and self.rank == 0:
+            print("[trainer] collectives are not captured into the step's graph (%s): eager collectives between captured segments"
+                  % (why or "another rank's probe failed"), file=sys.stderr, flush=True)
+        return self._capturable
 
     def launch(self, start=0, end=None):
         end = self.arena.count if end is None else end
@@ -226,7 +270,7 @@ class Trainer(object):
     def __init__(self, net, levels=None, optimizer='momentum', learning_rate=1e-2, grad_clip_norm=None,
                  loss_mode='bce_dice', device='cuda', use_graph=False, process_group=None,
                  direct_param_grads=True, wgrad_side_stream=False, defer_reductions=True, overlap=True,
-                 force_collective=False, input_fn=None, check_interval=50):
+                 force_collective=False, input_fn=None, check_interval=50, capture_collectives=None):
         self.net, self.levels = net, levels or build_levels()
         self.device = torch.device(device)
         if self.device.type == 'cuda':
@@ -278,10 +322,24 @@ class Trainer(object):
         self._parts = []               # per step: (roots, grads-of-leaves getter, arena range) of segment B's parts
         # The head towers' WEIGHT gradients (half of their backward products) beside the backbone's backward pass instead of inside
         # the heads' (ops.WGRAD_DEFER): segment A records them, segment B launches them on a side stream before its own kernels.
-        # Only where no collective is waiting for the heads' gradient slice (one rank): with several ranks that slice is
-        # all-reduced underneath the backbone's backward pass and must be complete when segment A ends.  RN_DEFER_WGRAD=0: off.
-        self.defer_wgrad = (os.environ.get("RN_DEFER_WGRAD", "1") == "1" and self.device.type == 'cuda' and not self.allreduce.active
-                            and self.direct_param_grads)
+        # With several ranks the step keeps them there (round 6): the slice that is complete when segment A ends -- the FPN's,
+        # [cut_offset, heads_offset) -- is all-reduced at once, the subnets' slice [heads_offset, count) BEHIND the deferred products
+        # on their stream (the collective waits for that stream, not for the backbone's backward pass).  A forked stream must be
+        # joined inside the graph that forked it, so with one graph PER PART and eager collectives between them (the fallback when
+        # the collectives cannot be captured) the deferral is off.  RN_DEFER_WGRAD=0: off everywhere.
+        self.heads_offset = self.arena.count
+        if base is not None and hasattr(base, 'classification_subnet'):
+            first = next(iter(base.classification_subnet.parameters()), None)
+            self.heads_offset = self._param_offset.get(id(first), self.arena.count)
+        # One captured graph per step needs nothing between its parts -- or collectives that can themselves be recorded into the
+        # graph (GradientAllReduce.probe_capturable decides that by doing it, identically on every rank).
+        self.whole_step_graph = os.environ.get("RN_WHOLE_STEP_GRAPH", "1") == "1"
+        if capture_collectives is False:          # (A/B aid and fallback: eager collectives between one graph per part)
+            self.allreduce._capturable = False
+        if self.allreduce.active and use_graph and self.whole_step_graph and self.device.type == 'cuda':
+            self.allreduce.probe_capturable(self.device)
+        self.defer_wgrad = (os.environ.get("RN_DEFER_WGRAD", "1") == "1" and self.device.type == 'cuda' and self.direct_param_grads
+                            and (not self.allreduce.active or not use_graph or self._whole_step_ok()))
         self._deferred_wgrads = []
         self._deferred_running = []
         self._graphs = None
@@ -291,12 +349,12 @@ class Trainer(object):
         # (its next appearance re-captures: two warm-up passes + capture, logged).
         self._graph_cache = collections.OrderedDict()
         self.graph_cache_max = max(1, int(os.environ.get("RN_GRAPH_CACHE", "4")))
-        # One rank: nothing happens between the segments (the collectives are what they are cut for) -- the whole step, update
-        # included, is then ONE captured graph: the ~80 us a step the GPU idles at the two graph boundaries and in front of the
-        # eagerly launched update (profiles/r05_bench_step_timeline.txt: "idle stretches") disappear.  The update's host-side
-        # scalars are constants of such a graph: momentum SGD without clipping only (no step-dependent scalar), and a changed
-        # learning rate captures again (the rate is part of the cache key).  RN_WHOLE_STEP_GRAPH=0: segments as with several ranks.
-        self.whole_step_graph = os.environ.get("RN_WHOLE_STEP_GRAPH", "1") == "1"
+        # The whole step -- segment A, the collectives, every part of segment B, the update -- is ONE captured graph wherever
+        # nothing has to happen on the host between its parts: the ~80 us a step the GPU idles at the graph boundaries and in
+        # front of an eagerly launched update (profiles/r05_bench_step_timeline.txt: "idle stretches") disappear.  The update's
+        # host-side scalars are constants of such a graph: momentum SGD without clipping only (no step-dependent scalar), and a
+        # changed learning rate captures again (the rate is part of the cache key).  RN_WHOLE_STEP_GRAPH=0: one graph per part.
+        self.schedule = []             # the gradient slices of the last recorded / eager step, in the order their all-reduce was issued
         self.recaptures = 0
         self._static = None
         # the device word every fused dropout hashes (bumped by the optimizer kernel); replicas start it at different values
@@ -370,7 +428,7 @@ class Trainer(object):
         parts.append((roots, seeds, (0, hi)))
         return parts
 
-    def _backward(self, roots, grads):
+    def _backward(self, roots, grads, skip_join=()):
         defer = self.defer_reductions and self.device.type == 'cuda' and ops.DIRECT_PARAM_GRADS
         if defer:                                  # ~130 gradient row reductions -> one launch per segment
             import retinanet
@@ -388,7 +446,7 @@ class Trainer(object):
         # weight-gradient kernels may run on side streams and write straight into the arena: join them before
         # anything (the collective, the optimizer) reads it
         if self.device.type == 'cuda':
-            _rn.join_side_streams(self.device)
+            _rn.join_side_streams(self.device, skip=skip_join)
 
     def segment_a(self, features=None):
         """forward + loss + backward of the heads and the FPN (the whole backward pass when there is no cut)."""
@@ -447,9 +505,15 @@ class Trainer(object):
         """Parts of segment B planned by the last segment_a (1 without stage cuts, 0 without any cut)."""
         return len(self._parts)
 
-    def segment_b(self, part=None):
+    WGRAD_STREAM = 7                   # _rn.side_stream index of the deferred weight-gradient products
+
+    def segment_b(self, part=None, join_wgrads=True, after_wgrads=None):
         """backward of the backbone from the gradients segment A left at the cut: every part (part=None), or part j of
-        num_parts() (last stage first).  Returns the (start, end) arena slice that is complete after it."""
+        num_parts() (last stage first).  Returns the (start, end) arena slice that is complete after it.
+
+        The first call of a step forks the deferred tower weight gradients (segment A's records) onto their side stream;
+        `after_wgrads()` runs on that stream behind them (the all-reduce of their slice); `join_wgrads=False` leaves the stream
+        un-joined when the call returns -- the caller joins it (_join_wgrads) before anything reads those gradients."""
         if not self._parts:
             return None
         rng = None
@@ -466,23 +530,38 @@ class Trainer(object):
             with torch.cuda.stream(side):
                 for _ in range(probe):
                     _rn.check(_rn.lib().rn_gemm_batched(_rn.f32(A_), _rn.f32(B_), _rn.f32(C_), A_.shape[1], 256, 256, 36, 0, _rn.stream()), "rn_gemm_batched")
-        if self._deferred_wgrads:             # the towers' weight-gradient halves: forked off here, joined by _backward's join of the side streams
-            wside = _rn.side_stream(self.device, 7)
-            wside.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(wside):
-                ops.run_deferred_wgrads(self._deferred_wgrads)
-            self._deferred_running = self._deferred_wgrads      # (their workspaces stay allocated until the next step replaces this)
-            self._deferred_wgrads = []
+        if self._deferred_wgrads:             # the towers' weight-gradient halves: forked off here
+            self._fork_wgrads(after_wgrads)
+        skip = () if join_wgrads else (self.WGRAD_STREAM,)
         for j in (range(len(self._parts)) if part is None else [part]):
             roots, seeds, rng = self._parts[j]
             with self._scoped():
-                self._backward(roots, [l.grad for l in seeds])
+                self._backward(roots, [l.grad for l in seeds], skip_join=skip)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         if part is None:
             self._parts = []
             return (0, self.cut_offset)
         return rng
+
+    def _fork_wgrads(self, after=None):
+        if self.device.type == 'cuda':
+            wside = _rn.side_stream(self.device, self.WGRAD_STREAM)
+            wside.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(wside):
+                ops.run_deferred_wgrads(self._deferred_wgrads)
+                if after is not None:
+                    after()
+        else:                                 # (no streams: tests of the schedule on CPU)
+            ops.run_deferred_wgrads(self._deferred_wgrads)
+            if after is not None:
+                after()
+        self._deferred_running = self._deferred_wgrads      # (their workspaces stay allocated until the next step replaces this)
+        self._deferred_wgrads = []
+
+    def _join_wgrads(self):
+        if self.device.type == 'cuda':
+            torch.cuda.current_stream().wait_stream(_rn.side_stream(self.device, self.WGRAD_STREAM))
 
     def forward_backward(self, features=None, advance_dropout=True):
         """Both segments, no collective, no update.  The dropout counter is bumped here (one tiny launch); step() leaves
@@ -493,10 +572,49 @@ class Trainer(object):
             ops.advance_dropout_counter(self.drop_counter)
         return out
 
-    def _capture(self, features):
-        # the captured segments read PRIVATE copies of the features: a caller may hand in other tensors (or reuse these) on
-        # later steps -- step() copies them into the static buffers -- and must never find its own tensors overwritten
-        self._static = _clone_tree(features)
+    def _run_step(self, features=None, timed=False):
+        """The device work of ONE step in issue order -- the same sequence whether it is launched eagerly or recorded into one
+        graph, with one rank or many (MirroredStrategy's per-tower step + cross-tower sum, train.py:111-134, 261-267):
+
+            segment A (assignment, forward, loss, backward of the heads and the FPN; tower weight gradients recorded, not run)
+            all-reduce  [cut_offset, heads_offset)      the FPN's slice             } under segment B
+            fork: deferred tower weight gradients  ->  all-reduce [heads_offset, count) behind them, on their stream
+            for every part j of the backbone's backward pass, last stage first:  part j  ->  all-reduce of its slice
+            join, wait for the collectives, optimizer update (1 / world folded in; bumps the dropout counter)
+
+        Without deferred products the first collective covers [cut_offset, count).  With one rank launch() / wait() do nothing."""
+        ar = self.allreduce
+        del self.schedule[:]
+
+        def reduce(lo, hi):
+            if hi > lo:
+                self.schedule.append((lo, hi))
+                ar.launch(lo, hi)
+
+        class_loss, regr_loss = self.segment_a(features)
+        deferred = bool(self._deferred_wgrads) and bool(self._parts)
+        top = self.heads_offset if (deferred and ar.active) else self.arena.count
+        reduce(self.cut_offset, top)                       # heads + FPN (or the FPN alone): under the backbone's backward pass
+        after = (lambda: reduce(top, self.arena.count)) if top < self.arena.count else None
+        n = self.num_parts()
+        for j in range(n if n else (1 if self.cut_offset else 0)):
+            rng = self.segment_b(j, join_wgrads=False, after_wgrads=after) if n else None
+            reduce(*(rng or (0, self.cut_offset)))         # this part's slice: under the parts that follow
+        self._parts = []
+        if deferred:
+            self._join_wgrads()
+        if timed and self.timing is not None and self.device.type == 'cuda':
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            grad_scale = ar.wait()
+            e1.record()
+            self.timing.setdefault('exposed_events', []).append((e0, e1))
+        else:
+            grad_scale = ar.wait()
+        self.opt.step(grad_scale, self.drop_counter)       # also bumps the dropout counter: fresh masks next step
+        return class_loss, regr_loss
+
+    def _warm_up(self):
         # warm-up on a side stream (allocator + workspace sizing), then capture; ONE warm-up stream per trainer: every shape
         # key re-captures, and per-stream state elsewhere (_rn.sync_counters) is keyed by the stream handle
         s = getattr(self, "_warm_stream", None)
@@ -509,6 +627,14 @@ class Trainer(object):
                 self.forward_backward(self._static, advance_dropout=False)
             self.drop_counter.copy_(counter)       # the warm-up passes do not count: replay i draws the masks eager step i draws
         torch.cuda.current_stream().wait_stream(s)
+
+    def _capture(self, features):
+        """One graph for segment A and one per part of segment B; collectives and the update are eager launches between / after
+        the replays (several ranks whose collectives cannot be captured; RN_WHOLE_STEP_GRAPH=0; Adam / RMSProp / clipping)."""
+        # the captured segments read PRIVATE copies of the features: a caller may hand in other tensors (or reuse these) on
+        # later steps -- step() copies them into the static buffers -- and must never find its own tensors overwritten
+        self._static = _clone_tree(features)
+        self._warm_up()
         dot = os.environ.get("RN_GRAPH_DOT")       # tuning aid: the captured segment A as a DOT file (nodes = kernels, edges = dependencies)
         ga = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread may poll events while the capture is open
@@ -524,41 +650,29 @@ class Trainer(object):
         for j in range(self.num_parts()):          # one graph per part of segment B: the collectives go between the replays
             gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
-                ranges.append(self.segment_b(j))
+                ranges.append(self.segment_b(j))   # (deferred weight gradients, if any, are forked AND joined inside the first part)
             gbs.append(gb)
         self._parts = []
         self._graphs = (ga, gbs, ranges, self._graph_out, self._static, False)
 
     def _whole_step_ok(self):
-        return (self.whole_step_graph and self.use_graph and not self.allreduce.active
-                and self.opt.kind == 'momentum' and self.opt.clip <= 0.0 and FUSED_OPT_NORM and self.device.type == 'cuda')
+        ar = self.allreduce
+        return (self.whole_step_graph and self.use_graph and self.device.type == 'cuda'
+                and (not ar.active or (getattr(ar, 'capturable', False) and not getattr(ar, 'host_staged', False)))
+                and self.opt.kind == 'momentum' and self.opt.clip <= 0.0 and FUSED_OPT_NORM)
 
     def _capture_whole(self, features):
-        """segment A, every part of segment B and the optimizer's update as ONE graph (see __init__: whole_step_graph)."""
+        """_run_step as ONE graph (see __init__: whole_step_graph): with several ranks the collectives are nodes of it."""
         self._static = _clone_tree(features)
-        s = getattr(self, "_warm_stream", None)
-        if s is None:
-            s = self._warm_stream = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            counter = self.drop_counter.clone()
-            for _ in range(2):
-                self.forward_backward(self._static, advance_dropout=False)
-            self.drop_counter.copy_(counter)
-        torch.cuda.current_stream().wait_stream(s)
+        self._warm_up()
         g = torch.cuda.CUDAGraph()
         count = self.opt.step_count
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            self._graph_out = self.segment_a(self._static)
-            n = self.num_parts()
-            ranges = []
-            for j in range(n if n else (1 if self.cut_offset else 0)):
-                ranges.append((self.segment_b(j) if n else self.segment_b()) or (0, self.cut_offset))
-            self.opt.step(1.0, self.drop_counter)
+            self._graph_out = self._run_step(self._static)
         self.opt.step_count = count                 # (recorded, not run: replays count their own steps)
-        self._parts = []
-        # (the parts' arena ranges are kept for reporting: the schedule several ranks would follow; no graph per part)
-        self._graphs = (g, [], ranges, self._graph_out, self._static, True)
+        ranges = [r for r in self.schedule if r[1] <= self.cut_offset]
+        # (the parts' arena ranges are kept for reporting; no graph per part)
+        self._graphs = (g, [], ranges, self._graph_out, self._static, True, list(self.schedule))
 
     def step(self, features=None):
         # a feed (dataset.DeviceFeed: input_fn with stage / consumed) puts a NEW sample into its static device buffers before
@@ -568,7 +682,7 @@ class Trainer(object):
         key = feed.stage() if feed is not None else None
         whole = self._whole_step_ok()
         if whole:
-            key = (key, 'whole', self.opt.lr)
+            key = (key, 'whole', self.opt.lr, id(self.allreduce))
         if self.use_graph:
             if self._graphs is None:
                 self._graph_cache.clear()
@@ -576,8 +690,8 @@ class Trainer(object):
             if cached is None:
                 if self._graph_cache:
                     self.recaptures += 1
-                    print("[trainer] new input shape %s: capturing another graph set (%d cached, bound %d)" %
-                          (key, len(self._graph_cache), self.graph_cache_max), file=sys.stderr, flush=True)
+                    print("[trainer] new graph key %s (input shape / learning rate / collective): capturing another graph set "
+                          "(%d cached, bound %d)" % (key, len(self._graph_cache), self.graph_cache_max), file=sys.stderr, flush=True)
                 while len(self._graph_cache) >= self.graph_cache_max:
                     self._graph_cache.popitem(last=False)             # least recently used: its pool is freed with it
                 if whole:
@@ -593,59 +707,44 @@ class Trainer(object):
                     _copy_tree(self._static, features)
             self._graphs[0].replay()
             class_loss, regr_loss = self._graph_out
+            if self._graphs[5]:
+                # the whole step was that one replay: what is left is the update's host-side bookkeeping
+                self.schedule[:] = self._graphs[6]
+                self.opt.step_count += 1
+                import ops_f16
+                ops_f16.weights_changed()
+            else:
+                del self.schedule[:]
+                ar = self.allreduce
+
+                def reduce(lo, hi):
+                    if hi > lo:
+                        self.schedule.append((lo, hi))
+                        ar.launch(lo, hi)
+                reduce(self.cut_offset, self.arena.count)             # heads + FPN: under the backbone's backward pass
+                for gb, (lo, hi) in zip(self._graphs[1], self._graphs[2]):
+                    gb.replay()
+                    reduce(lo, hi)                                    # this part's slice: under the parts that follow
+                if self.timing is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    grad_scale = ar.wait()
+                    e1.record()
+                    self.timing.setdefault('exposed_events', []).append((e0, e1))
+                else:
+                    grad_scale = ar.wait()
+                self.opt.step(grad_scale, self.drop_counter)
         else:
-            class_loss, regr_loss = self.segment_a(features)
+            class_loss, regr_loss = self._run_step(features, timed=True)
         if feed is not None:
             feed.consumed()
-        if self.use_graph and self._graphs[5]:
-            # the whole step was that one replay: what is left is the update's host-side bookkeeping
-            self.opt.step_count += 1
-            import ops_f16
-            ops_f16.weights_changed()
-            self.steps_done += 1
-            self.last = {'class_loss': class_loss, 'regr_loss': regr_loss, 'regularization_loss': self.opt.regularization_loss}
-            return self.last
-        self.allreduce.launch(self.cut_offset, self.arena.count)      # heads + FPN: under the backbone's backward pass
-        # ... and, without clipping (the global norm would need every gradient first), their UPDATE too: on a side stream, behind
-        # segment A and the slice's collectives, while the backbone's backward pass (which reads neither these weights nor these
-        # gradients) runs on the main stream
-        early = (EARLY_HEAD_UPDATE and FUSED_OPT_NORM and self.opt.clip <= 0.0 and 0 < self.cut_offset < self.arena.count
-                 and self.device.type == 'cuda' and not self.allreduce.host_staged)
-        if early:
-            side = _rn.side_stream(self.device, 5)
-            side.wait_stream(torch.cuda.current_stream())
-            self.opt.begin_step()
-            with torch.cuda.stream(side):
-                self.allreduce.wait_on_current_stream()               # (makes `side` wait for the collectives, not the host)
-                self.opt.step_slice(self.cut_offset, self.arena.count, 1.0 / self.allreduce.world, None, ctypes.c_void_p(side.cuda_stream))
-        if self.use_graph:
-            for gb, (lo, hi) in zip(self._graphs[1], self._graphs[2]):
-                gb.replay()
-                self.allreduce.launch(lo, hi)                         # this part's slice: under the parts that follow
-        else:
-            n = self.num_parts()
-            for j in range(n if n else (1 if self.cut_offset else 0)):
-                rng = self.segment_b(j) if n else self.segment_b()
-                self.allreduce.launch(*(rng or (0, self.cut_offset)))
-            self._parts = []
-        if self.timing is not None and self.device.type == 'cuda':
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            grad_scale = self.allreduce.wait()
-            e1.record()
-            self.timing.setdefault('exposed_events', []).append((e0, e1))
-        else:
-            grad_scale = self.allreduce.wait()
-        if early:
-            torch.cuda.current_stream().wait_stream(side)
-            self.opt.step_slice(0, self.cut_offset, grad_scale, self.drop_counter)   # also bumps the dropout counter
-            self.opt.finish_step()
-        else:
-            self.opt.step(grad_scale, self.drop_counter)      # also bumps the dropout counter: fresh masks next step
         self.steps_done += 1
-        # (only the opt-in grid-resident GroupNorm can flag anything; checked after the first steps too, not only every
-        # check_interval: a poisoned update must not be trained on for long)
-        if self.check_interval and ops.GN_GRID_RESIDENT and (self.steps_done in (1, 2, 4, 8) or self.steps_done % self.check_interval == 0):
+        # (only the opt-in waiting kernels -- the grid-resident GroupNorm, the XCD-resident MobileNetV2 section -- can flag
+        # anything; checked after the first steps too, not only every check_interval: a poisoned update must not be trained on
+        # for long.  The same check on every path, the one-graph step included.)
+        import ops_mb
+        if (self.check_interval and (ops.GN_GRID_RESIDENT or ops_mb.RESIDENT)
+                and (self.steps_done in (1, 2, 4, 8) or self.steps_done % self.check_interval == 0)):
             self.check_device_errors()
         self.last = {'class_loss': class_loss, 'regr_loss': regr_loss,
                      'regularization_loss': self.opt.regularization_loss}
@@ -660,19 +759,28 @@ class Trainer(object):
         return float(sum(a.elapsed_time(b) for a, b in ev) / len(ev))
 
     def check_device_errors(self):
-        """Raise if any kernel of this process has flagged an error on the device (synchronises)."""
-        n = _rn.barrier_timeouts()
+        """Raise if any kernel of this process has flagged an error on the device (synchronises).  Two opt-in kernel families
+        wait for co-resident blocks and can time out: the grid-resident GroupNorm (ops.GN_GRID_RESIDENT) and the XCD-resident
+        MobileNetV2 section (ops_mb.RESIDENT); the one that flagged is the one switched off."""
+        import ops_mb
+        n_gn, n_mb = _rn.barrier_timeout_sources()
         if self.allreduce.active:       # every rank must take the same decision, or the others hang in the next all-reduce
-            t = torch.tensor([float(n)], device=self.device)
+            t = torch.tensor([float(n_gn), float(n_mb)], device=self.device)
             self.allreduce.dist.all_reduce(t, op=self.allreduce.dist.ReduceOp.MAX, group=self.allreduce.group)
-            n = int(t.item())
-        if n:
-            ops.GN_GRID_RESIDENT = False        # the launch-ordered kernels from here on (on every rank: n is the max over ranks)
+            n_gn, n_mb = int(t[0].item()), int(t[1].item())
+        if n_gn or n_mb:
+            what = []
+            if n_gn:
+                ops.GN_GRID_RESIDENT = False        # the launch-ordered kernels from here on (on every rank: the counts are maxima over ranks)
+                what.append("%d GroupNorm exchange wait(s) (ops.GN_GRID_RESIDENT is now False)" % n_gn)
+            if n_mb:
+                ops_mb.RESIDENT = False
+                what.append("%d MobileNetV2 resident-section barrier(s) (ops_mb.RESIDENT is now False)" % n_mb)
             _rn.reset_barrier_timeouts()
-            self._graphs = None                 # the captured segments contain the grid-resident kernels: capture again
-            raise _rn.RnError("%d GroupNorm exchange wait(s) timed out on some rank: the updates since the last check are invalid; "
-                              "the grid-resident path is now off (ops.GN_GRID_RESIDENT = False) -- reload the last checkpoint "
-                              "and continue" % n)
+            self._graphs = None                 # the captured graphs contain the waiting kernels: capture again ...
+            self._graph_cache.clear()           # ... for every input shape
+            raise _rn.RnError("timed out on some rank: %s: the updates since the last check are invalid -- reload the last "
+                              "checkpoint and continue" % "; ".join(what))
 
 
 def _for_each_tensor(tree, fn):

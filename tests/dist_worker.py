@@ -32,7 +32,7 @@ import torch.distributed as dist
 SIZE, CLASSES = 128, 5
 
 
-def build(dev, seed_batch, use_graph, overlap, force_collective=False, dropout=0.1, size=None):
+def build(dev, seed_batch, use_graph, overlap, force_collective=False, dropout=0.1, size=None, capture_collectives=None):
     SIZE = size or globals()["SIZE"]
     import dataset, layers, levels as levels_mod, retinanet, train
     layers.Dropout._next_seed[0] = 0x5EED             # same dropout streams for every net built in this process
@@ -53,7 +53,8 @@ def build(dev, seed_batch, use_graph, overlap, force_collective=False, dropout=0
         return {'image': image, 'detection': {'classifications': c, 'regressions': r}, 'trainable_masks': m}
 
     tr = train.Trainer(net, lv, optimizer='momentum', learning_rate=1e-2, loss_mode='focal', device=dev,
-                       use_graph=use_graph, overlap=overlap, force_collective=force_collective, input_fn=features)
+                       use_graph=use_graph, overlap=overlap, force_collective=force_collective, input_fn=features,
+                       capture_collectives=capture_collectives)
     return net, tr
 
 
@@ -71,18 +72,32 @@ def nccl1(out_path):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     os.environ["RN_STAGE_CUTS"] = "0"          # (a): the bit-for-bit comparison -- MobileNetV2's stage cut re-groups one sum, see (c)
     _, tr = build(dev, 11, use_graph=True, overlap=True, force_collective=True)
+    _, ts = build(dev, 11, use_graph=True, overlap=True, force_collective=True, capture_collectives=False)
     os.environ["RN_STAGE_CUTS"] = "1"
     assert tr.cut_offset > 0 and tr.allreduce.active and tr.allreduce.world == 1 and tr._stage_bb is None
+    # round 6: RCCL's all-reduce replays correctly from a captured graph here (probed with a known answer), so the step several
+    # ranks run is ONE graph with the collectives as nodes and keeps the deferred tower weight gradients; `ts` is the fallback
+    # (one graph per part, eager collectives between them, no deferral)
+    res_modes = {"capturable": bool(tr.allreduce.capturable), "defer_wgrad": bool(tr.defer_wgrad),
+                 "fallback_capturable": bool(ts.allreduce.capturable), "fallback_defer_wgrad": bool(ts.defer_wgrad)}
     tr.timing = {}
+    ts.timing = {}
     for _ in range(3):
         b = tr.step()
+        b2 = ts.step()
     torch.cuda.synchronize()
-    launched = list(tr.allreduce.launched)
+    res_modes["whole_step_graph"] = bool(tr._graphs[5])
+    res_modes["fallback_whole_step_graph"] = bool(ts._graphs[5])
     res = {"bit_equal_weights": bool(torch.equal(wa, tr.arena.weights)),
+           "bit_equal_weights_fallback": bool(torch.equal(wa, ts.arena.weights)),
            "losses_plain": la, "losses_dist": [float(b['class_loss']), float(b['regr_loss'])],
-           "cut_offset": tr.cut_offset, "count": tr.arena.count, "launched": launched[:8],
-           "buckets_per_step": len(launched) // 3, "exposed_ms": tr.allreduce_exposed_ms(),
+           "losses_fallback": [float(b2['class_loss']), float(b2['regr_loss'])],
+           "cut_offset": tr.cut_offset, "heads_offset": tr.heads_offset, "count": tr.arena.count,
+           "schedule": [list(x) for x in tr.schedule], "schedule_fallback": [list(x) for x in ts.schedule],
+           "exposed_ms": ts.allreduce_exposed_ms(), "modes": res_modes,
            "max_abs_diff": float((wa - tr.arena.weights).abs().max())}
+    ts.check_device_errors()
+    del ts
     tr.check_device_errors()
     # (c) the same with MobileNetV2's stage cut: the chain's backward pass in two parts, three gradient slices per step
     # (256 px: the fused chain runs, so the cut goes through its identity pass-through; at 128 px the backbone runs layer by layer)
@@ -94,17 +109,13 @@ def nccl1(out_path):
     first_plain, wa = fp, p2.arena.weights.clone()
     _, tc = build(dev, 11, use_graph=True, overlap=True, force_collective=True, size=256)
     assert tc._stage_bb is not None
-    seen = []
-    orig = tc.allreduce.launch
-    tc.allreduce.launch = lambda start=0, end=None: (seen.append([start, tc.arena.count if end is None else end]), orig(start, end))[1]
     firsts = None
     for i in range(3):
-        del seen[:]
         c = tc.step()
         if i == 0:
             firsts = [float(c['class_loss']), float(c['regr_loss'])]
     torch.cuda.synchronize()
-    res["stage_cut"] = {"slices": [list(x) for x in seen], "first_step_losses": firsts, "first_step_losses_plain": first_plain,
+    res["stage_cut"] = {"slices": [list(x) for x in tc.schedule], "first_step_losses": firsts, "first_step_losses_plain": first_plain,
                         "max_abs_diff": float((wa - tc.arena.weights).abs().max()), "scale": float(wa.abs().max())}
     tc.check_device_errors()
     dist.barrier()
@@ -161,9 +172,10 @@ def rccl(out_dir):
     for _ in range(steps):
         out = tr.step()
     torch.cuda.synchronize()
-    launched = list(tr.allreduce.launched)
     np.save(os.path.join(out_dir, "w_%d.npy" % rank), tr.arena.weights.cpu().numpy())
-    json.dump({"rank": rank, "world": world, "launched": launched, "cut_offset": tr.cut_offset, "count": tr.arena.count,
+    json.dump({"rank": rank, "world": world, "schedule": [list(x) for x in tr.schedule], "cut_offset": tr.cut_offset, "count": tr.arena.count,
+               "heads_offset": tr.heads_offset, "capturable": bool(tr.allreduce.capturable), "whole": bool(tr._graphs[5]),
+               "defer_wgrad": bool(tr.defer_wgrad),
                "exposed_ms": tr.allreduce_exposed_ms(), "losses": [float(out['class_loss']), float(out['regr_loss'])],
                "graph": bool(tr._graphs is not None)}, open(os.path.join(out_dir, "r_%d.json" % rank), "w"))
     tr.check_device_errors()

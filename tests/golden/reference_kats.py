@@ -84,3 +84,66 @@ def pyramid_sizes(s):
         if i >= 2:
             out.append(c)
     return out          # P3..P7
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Known-answer vectors from TENSORFLOW's own published unit tests, for the ops the reference calls but holds no test
+# of (SURVEY section 8c "[TF-sem]" rows).  Transcribed from memory of the TF 1.x test sources (TF is
+# not installable here); each vector is also self-evidently consistent with the op's documented definition, which the
+# comments spell out.  Data only.
+#
+# tensorflow/core/kernels/non_max_suppression_op_test.cc, NonMaxSuppressionOpTest (and, first case, the same data in
+# tensorflow/python/ops/image_ops_test.py NonMaxSuppressionTest.testSelectFromThreeClusters) -- the op behind
+# reference utils.py:213-220.  Boxes [y1, x1, y2, x2]; three clusters at x ~ 0, ~ 10, ~ 100; IoU threshold 0.5.
+TF_NMS_THREE_CLUSTERS_BOXES = np.array([[0, 0, 1, 1], [0, 0.1, 1, 1.1], [0, -0.1, 1, 0.9],
+                                        [0, 10, 1, 11], [0, 10.1, 1, 11.1], [0, 100, 1, 101]], dtype=np.float32)
+TF_NMS_THREE_CLUSTERS_SCORES = np.array([0.9, 0.75, 0.6, 0.95, 0.5, 0.3], dtype=np.float32)
+# TestSelectFromThreeClustersFlippedCoordinates: the same boxes with some corner pairs swapped (the kernel min/max-normalises)
+TF_NMS_FLIPPED_BOXES = np.array([[1, 1, 0, 0], [0, 0.1, 1, 1.1], [0, 0.9, 1, -0.1],
+                                 [0, 10, 1, 11], [1, 10.1, 0, 11.1], [1, 101, 0, 100]], dtype=np.float32)
+TF_NMS_CASES = [
+    # (TF test name, boxes, scores, max_output_size, expected selected indices)
+    ("TestSelectFromThreeClusters", TF_NMS_THREE_CLUSTERS_BOXES, TF_NMS_THREE_CLUSTERS_SCORES, 3, [3, 0, 5]),
+    ("TestSelectFromThreeClustersFlippedCoordinates", TF_NMS_FLIPPED_BOXES, TF_NMS_THREE_CLUSTERS_SCORES, 3, [3, 0, 5]),
+    ("TestSelectAtMostTwoBoxesFromThreeClusters", TF_NMS_THREE_CLUSTERS_BOXES, TF_NMS_THREE_CLUSTERS_SCORES, 2, [3, 0]),
+    ("TestSelectAtMostThirtyBoxesFromThreeClusters", TF_NMS_THREE_CLUSTERS_BOXES, TF_NMS_THREE_CLUSTERS_SCORES, 30, [3, 0, 5]),
+    ("TestSelectWithNegativeScores", TF_NMS_THREE_CLUSTERS_BOXES, TF_NMS_THREE_CLUSTERS_SCORES - np.float32(10.0), 6, [3, 0, 5]),
+    ("TestSelectSingleBox", np.array([[0, 0, 1, 1]], dtype=np.float32), np.array([0.9], dtype=np.float32), 3, [0]),
+    ("TestSelectFromTenIdenticalBoxes", np.tile(np.array([[0, 0, 1, 1]], dtype=np.float32), (10, 1)),
+     np.full(10, 0.9, dtype=np.float32), 3, [0]),
+    ("TestEmptyInput", np.zeros((0, 4), dtype=np.float32), np.zeros((0,), dtype=np.float32), 30, []),
+]
+
+# tensorflow/python/ops/image_ops_test.py, ResizeImagesTest.testResizeUpAlignCornersTrue -- tf.image.resize_images(...,
+# align_corners=True), the op behind reference retinanet.py:153-155 (NEAREST_NEIGHBOR, Q12) and dataset.py:145-151 (BILINEAR):
+# a [1, 3, 2, 1] image resized to 5 x 4.  Source rows 0, 0.5, 1, 1.5, 2: the nearest-neighbour case pins the half-way
+# rounding (0.5 -> 1, 1.5 -> 2: roundf, not half-to-even); source columns 0, 1/3, 2/3, 1.
+TF_RESIZE_ALIGN_CORNERS_INPUT = np.array([6, 3, 3, 6, 6, 9], dtype=np.float32).reshape(1, 3, 2, 1)
+TF_RESIZE_ALIGN_CORNERS_SIZE = (5, 4)
+TF_RESIZE_ALIGN_CORNERS_NEAREST = np.array([6.0, 6.0, 3.0, 3.0, 3.0, 3.0, 6.0, 6.0, 3.0, 3.0, 6.0, 6.0, 6.0, 6.0,
+                                            9.0, 9.0, 6.0, 6.0, 9.0, 9.0], dtype=np.float32).reshape(1, 5, 4, 1)
+TF_RESIZE_ALIGN_CORNERS_BILINEAR = np.array([6.0, 5.0, 4.0, 3.0, 4.5, 4.5, 4.5, 4.5, 3.0, 4.0, 5.0, 6.0, 4.5, 5.5,
+                                             6.5, 7.5, 6.0, 7.0, 8.0, 9.0], dtype=np.float32).reshape(1, 5, 4, 1)
+
+# tensorflow/python/kernel_tests/losses_test.py, HuberLossTest (delta = 1, the reference's losses.py:146): mean over the elements
+# of 0.5 e^2 for |e| <= 1, |e| - 0.5 above.
+TF_HUBER_PREDICTIONS = np.array([1.5, -1.4, -1.0, 0.0], dtype=np.float32)
+TF_HUBER_CASES = [
+    # (TF test name, labels, predictions, expected loss)
+    ("testAllQuadratic", np.array([1.0, -1.0, 0.0, 0.5], dtype=np.float32), TF_HUBER_PREDICTIONS,
+     0.5 * (0.25 + 0.16 + 1.0 + 0.25) / 4.0),
+    ("testAllLinear", np.array([0.0, 1.0, 0.0, 1.5], dtype=np.float32), TF_HUBER_PREDICTIONS,
+     (1.5 + 2.4 + 1.0 + 1.5) / 4.0 - 0.5),
+    ("testMixedQuadraticLinear", np.array([[1.0, -1.0, 0.0, 0.5], [0.0, 1.0, 0.0, 1.5]], dtype=np.float32),
+     np.stack([TF_HUBER_PREDICTIONS, TF_HUBER_PREDICTIONS]),
+     (0.5 * (0.25 + 0.16 + 1.0 + 0.25) / 4.0 + (1.5 + 2.4 + 1.0 + 1.5) / 4.0 - 0.5) / 2.0),
+]
+
+# tensorflow/python/kernel_tests/losses_test.py, SigmoidCrossEntropyLossTest (mean of tf.nn.sigmoid_cross_entropy_with_logits,
+# the op of reference losses.py:124): saturated logits of +-100 -- a naive log(sigmoid) overflows, the stable form
+# max(x, 0) - x z + log(1 + exp(-|x|)) gives 0 per right entry and 100 per wrong one.
+TF_BCE_LOGITS = np.array([[100.0, -100.0, -100.0], [-100.0, 100.0, -100.0], [-100.0, -100.0, 100.0]], dtype=np.float32)
+TF_BCE_CASES = [
+    ("testAllCorrectSigmoid", np.eye(3, dtype=np.float32), 0.0),
+    ("testAllWrongSigmoid", np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], dtype=np.float32), 600.0 / 9.0),
+]

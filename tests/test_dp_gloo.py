@@ -80,10 +80,14 @@ def _trainer_worker(rank, world, port, out_dir):
             # what the real segment A plans when MobileNetV2's stage cut is installed (a collective is active): the chain's
             # backward pass in two parts, cut in front of bottleneck_4_1 (mobilenet_v2.STAGE_CUT_AFTER = bottleneck_3_3)
             self._parts = [(None, None, (stage_off[0], self.cut_offset)), (None, None, (0, stage_off[0]))]
+            # ... and, with the tower weight gradients deferred, the records segment B's first part launches
+            self._deferred_wgrads = ["tower weight gradients"] if self.defer_wgrad else []
             return torch.zeros(()), torch.zeros(())
 
-        def segment_b(self, part=None):
+        def segment_b(self, part=None, join_wgrads=True, after_wgrads=None):
             # the slices above this part's were launched before this runs; they may already have been summed
+            if self._deferred_wgrads:          # the real segment B forks them in front of its first part
+                self._fork_wgrads(after_wgrads)
             lo, hi = self._parts[part][2]
             g = torch.Generator().manual_seed(5000 + 1000 * self.steps_done + 100 * part + rank)
             self.arena.grads[lo:hi].copy_(torch.randn(hi - lo, generator=g))
@@ -137,6 +141,46 @@ def _trainer_worker(rank, world, port, out_dir):
         for r in range(world):
             g = torch.Generator().manual_seed(1000 * step + r)
             want[tr.cut_offset:] += torch.randn(tr.arena.count - tr.cut_offset, generator=g)
+            g = torch.Generator().manual_seed(5000 + 1000 * step + r)
+            want[stage_off[0]:tr.cut_offset] += torch.randn(tr.cut_offset - stage_off[0], generator=g)
+            g = torch.Generator().manual_seed(5000 + 1000 * step + 100 + r)
+            want[:stage_off[0]] += torch.randn(stage_off[0], generator=g)
+        assert torch.allclose(tr.arena.grads, want, atol=1e-6)
+        assert tr.schedule == [(tr.cut_offset, tr.arena.count), (stage_off[0], tr.cut_offset), (0, stage_off[0])]
+    # Round 6: the SAME step with the head towers' weight gradients deferred (what every rank runs on the GPU when the collectives
+    # are nodes of the step's graph): the FPN's slice goes out when segment A ends, the subnets' slice behind the deferred
+    # products -- which overwrite it AFTER segment A -- and before the backbone parts' slices
+    import ops
+    heads = offs[id(next(iter(net.base.classification_subnet.parameters())))]
+    assert tr.heads_offset == heads and tr.cut_offset < heads < tr.arena.count
+    assert all(offs[id(p)] < heads for p in net.base.fpn.parameters())
+    assert all(offs[id(p)] >= heads for m in (net.base.classification_subnet, net.base.regression_subnet) for p in m.parameters())
+
+    def fake_wgrads(records):
+        assert records == ["tower weight gradients"]
+        events.append("wgrads")
+        g = torch.Generator().manual_seed(9000 + 1000 * tr.steps_done + rank)
+        tr.arena.grads[heads:].copy_(torch.randn(tr.arena.count - heads, generator=g))
+    ops.run_deferred_wgrads = fake_wgrads
+    tr.defer_wgrad = True
+    for step in range(2, 4):
+        del tr.allreduce.launched[:]
+        del events[:]
+        tr.step({})
+        assert events == ["A", ("launch", tr.cut_offset, heads), "wgrads", ("launch", heads, tr.arena.count), "B0",
+                          ("launch", stage_off[0], tr.cut_offset), "B1", ("launch", 0, stage_off[0]), "opt"], events
+        assert tr.schedule == [(tr.cut_offset, heads), (heads, tr.arena.count), (stage_off[0], tr.cut_offset), (0, stage_off[0])]
+        cover = sorted(tr.allreduce.launched)
+        assert cover[0][0] == 0 and cover[-1][1] == tr.arena.count
+        assert all(a[1] == b[0] for a, b in zip(cover, cover[1:])) and all(s % train.OPT_BLOCK == 0 for s, _ in cover)
+        want = torch.zeros_like(tr.arena.grads)
+        for r in range(world):
+            g = torch.Generator().manual_seed(1000 * step + r)
+            want[tr.cut_offset:] += torch.randn(tr.arena.count - tr.cut_offset, generator=g)
+        want[heads:] = 0                                       # (segment A's values there were overwritten by the deferred products)
+        for r in range(world):
+            g = torch.Generator().manual_seed(9000 + 1000 * step + r)
+            want[heads:] += torch.randn(tr.arena.count - heads, generator=g)
             g = torch.Generator().manual_seed(5000 + 1000 * step + r)
             want[stage_off[0]:tr.cut_offset] += torch.randn(tr.cut_offset - stage_off[0], generator=g)
             g = torch.Generator().manual_seed(5000 + 1000 * step + 100 + r)

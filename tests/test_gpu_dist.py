@@ -31,11 +31,18 @@ def test_rccl_world1_forced_collectives_bit_equal_to_plain_step(tmp_path):
     r = subprocess.run([sys.executable, WORKER, "nccl1", out], env=_env(), timeout=600, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.load(open(out))
-    assert res["losses_plain"] == res["losses_dist"], res
-    assert res["bit_equal_weights"], res
-    assert 0 < res["cut_offset"] < res["count"]
-    # heads + FPN region first (issued under the backbone's backward pass), the backbone region after it
-    assert res["launched"][0][0] >= res["cut_offset"] and res["launched"][res["buckets_per_step"] - 1][1] <= res["cut_offset"]
+    assert res["losses_plain"] == res["losses_dist"] == res["losses_fallback"], res
+    assert res["bit_equal_weights"] and res["bit_equal_weights_fallback"], res
+    cut, heads, count = res["cut_offset"], res["heads_offset"], res["count"]
+    assert 0 < cut < heads < count
+    m = res["modes"]
+    # the step several ranks run is the step the headline times -- one graph, the collectives nodes of it,
+    # the tower weight gradients deferred; the fallback (collectives cannot be captured) is one graph per part without deferral
+    assert m["capturable"] and m["whole_step_graph"] and m["defer_wgrad"], m
+    assert not m["fallback_capturable"] and not m["fallback_whole_step_graph"] and not m["fallback_defer_wgrad"], m
+    # FPN slice when segment A ends, the subnets' slice behind their deferred products, the backbone's after its backward pass
+    assert res["schedule"] == [[cut, heads], [heads, count], [0, cut]], res["schedule"]
+    assert res["schedule_fallback"] == [[cut, count], [0, cut]], res["schedule_fallback"]
     # ... and with MobileNetV2's stage cut (the chain's backward pass in two parts, train.py:261-267): three slices per step,
     # tiling the arena from the top down; the identity pass-through at the cut is exact in the forward pass (same first-step
     # losses, bit for bit) and re-groups one GroupNorm's gradient sums in the backward pass (weights within 1e-6 of the range)
@@ -43,8 +50,8 @@ def test_rccl_world1_forced_collectives_bit_equal_to_plain_step(tmp_path):
     assert sc["first_step_losses"] == sc["first_step_losses_plain"], sc
     assert sc["max_abs_diff"] <= 1e-6 * sc["scale"], sc
     lo = sc["slices"]
-    assert len(lo) == 3 and lo[0] == [res["cut_offset"], res["count"]] and lo[1][1] == res["cut_offset"] and lo[2] == [0, lo[1][0]], lo
-    assert 4 * lo[2][1] <= 1 << 20, lo
+    assert len(lo) == 4 and lo[0] == [cut, heads] and lo[1] == [heads, count] and lo[2][1] == cut and lo[3] == [0, lo[2][0]], lo
+    assert 4 * lo[3][1] <= 1 << 20, lo
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
@@ -59,8 +66,12 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert res["n_gpus"] == 1 and res["steps"] == 4
     ar = res["config"]["allreduce"]
     assert ar["backend"] == "rccl" and ar["ranks"] == 1 and ar["collectives_issued"]
-    # heads + FPN, then the chain above the C3 tap, then the rest of the backbone (MobileNetV2's stage cut is on: a collective is active)
-    assert res["config"]["backward_segments"] == 3 and len(ar["slice_schedule_bytes"]) == 3
+    # FPN, the subnets (behind their deferred weight gradients), then the chain above the C3 tap, then the rest of the backbone
+    # (MobileNetV2's stage cut is on: a collective is active)
+    assert res["config"]["backward_segments"] == 3 and len(ar["slice_schedule_bytes"]) == 4
+    assert res["config"]["whole_step_in_one_graph"] and res["config"]["collectives_captured_in_graph"] and res["config"]["tower_weight_gradients_deferred"]
+    # ... and the fallback path (one graph per part, eager collectives) ran too: it is where the exposed time is measured
+    assert len(ar["one_graph_per_part_eager_collectives"]["slice_schedule_bytes"]) == 3
     assert ar["bytes_overlapped_with_backbone_backward"] > ar["bytes_after_backward"] > 0
     assert ar["bytes_after_backward"] <= 1 << 20, ar            # <= 1 MB left after the last backward kernel
     assert res["config"]["gn_barrier_timeouts"] == 0
@@ -68,7 +79,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     # be the first time this code executes)
     assert ar["rccl_ranks"] == 1 and len(ar["allreduce_exposed_ms_per_rank"]) == 1
     assert ar["allreduce_exposed_ms_max"] >= ar["allreduce_exposed_ms_mean"] >= 0.0
-    assert len(ar["slices"]) == 3 and all(sl["bytes"] > 0 and sl["ms_alone"] > 0 for sl in ar["slices"])
+    assert len(ar["slices"]) == 4 and all(sl["bytes"] > 0 and sl["ms_alone"] > 0 for sl in ar["slices"])
     assert sum(sl["bytes"] for sl in ar["slices"]) == ar["bytes_overlapped_with_backbone_backward"] + ar["bytes_after_backward"]
 
 
@@ -123,14 +134,14 @@ def test_rccl_world_n_replicas_identical_and_equal_to_accumulation(tmp_path):
     for i in range(world):
         res = json.load(open(tmp_path / ("r_%d.json" % i)))
         assert res["world"] == world and res["graph"]
-        cut, count, launched = res["cut_offset"], res["count"], [tuple(x) for x in res["launched"]]
-        per = len(launched) // 3
-        assert per >= 2 and len(launched) == 3 * per
-        for s in range(3):
-            step = launched[s * per:(s + 1) * per]
-            heads = [b for b in step if b[0] >= cut]
-            backbone = [b for b in step if b[1] <= cut]
-            assert len(heads) + len(backbone) == per                       # no bucket straddles the cut
-            assert step[:len(heads)] == heads                               # heads + FPN region first
-            assert sorted(heads) [0][0] == cut and max(e for _, e in heads) == count
-            assert min(b for b, _ in backbone) == 0 and max(e for _, e in backbone) == cut
+        cut, heads, count = res["cut_offset"], res["heads_offset"], res["count"]
+        sched = [tuple(x) for x in res["schedule"]]
+        # the slices tile the arena from the top down; only the last one (<= 1 MB) is reduced after the last backward kernel
+        if res["whole"]:
+            assert res["capturable"] and res["defer_wgrad"]
+            assert sched[:2] == [(cut, heads), (heads, count)], sched
+            rest = sched[2:]
+        else:
+            assert sched[0] == (cut, count), sched
+            rest = sched[1:]
+        assert rest[0][1] == cut and rest[-1][0] == 0 and all(a[0] == b[1] for a, b in zip(rest, rest[1:])), sched

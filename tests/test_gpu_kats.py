@@ -99,3 +99,54 @@ def test_classmap_decode_kat_through_product(dev):
     import utils
     got = utils.classmap_decode(_t(K.CLASSMAP, dev)).fg_mask.cpu().numpy()
     assert np.array_equal(got, K.CLASSMAP_FG_EXPECTED)
+
+
+# ---- TensorFlow's own published unit-test vectors (tests/golden/reference_kats.py "TF_*") through the kernels
+@pytest.mark.parametrize("case", range(len(K.TF_NMS_CASES)), ids=[c[0] for c in K.TF_NMS_CASES])
+def test_tf_published_nms_vectors_through_kernel(dev, case):
+    """NonMaxSuppressionOpTest.* through rn_nms_classwise (one class): the indices TF's own test expects (utils.py:213-220)."""
+    import utils
+    name, boxes, scores, max_out, want = K.TF_NMS_CASES[case]
+    cls = torch.zeros((boxes.shape[0],), dtype=torch.int64, device=dev)
+    _, _, _, idx = utils._nms_arrays(_t(boxes, dev), _t(scores, dev), cls, 1, max_out)
+    assert idx.cpu().tolist() == want, (name, idx.cpu().tolist())
+    if boxes.shape[0]:
+        got = utils.nms(utils.BoxesDecoded(_t(boxes, dev), _t(scores, dev), cls), max_output_size=max_out)
+        assert np.array_equal(got.boxes.cpu().numpy(), boxes[want]) and np.array_equal(got.scores.cpu().numpy(), scores[want])
+
+
+def test_tf_published_resize_vectors_through_kernels(dev):
+    """ResizeImagesTest.testResizeUpAlignCornersTrue: the FPN's nearest-neighbour up-sample (rn_upsample_add with a zero lateral,
+    retinanet.py:153-157) and the input pipeline's bilinear rescale (rn_resize_bilinear_normalize, dataset.py:145-151)."""
+    import dataset
+    import ops
+    oh, ow = K.TF_RESIZE_ALIGN_CORNERS_SIZE
+    for ch in (4, 8):
+        top = np.repeat(K.TF_RESIZE_ALIGN_CORNERS_INPUT, ch, axis=3)
+        got = ops.upsample_add(torch.zeros((1, oh, ow, ch), device=dev), _t(top, dev)).cpu().numpy()
+        assert np.array_equal(got, np.repeat(K.TF_RESIZE_ALIGN_CORNERS_NEAREST, ch, axis=3))
+    img = np.repeat(K.TF_RESIZE_ALIGN_CORNERS_INPUT, 3, axis=3)
+    got = dataset.rescale_image(_t(img, dev), size=(oh, ow)).cpu().numpy()
+    assert np.allclose(got, np.repeat(K.TF_RESIZE_ALIGN_CORNERS_BILINEAR, 3, axis=3), rtol=0, atol=1e-6)
+
+
+def test_tf_published_huber_and_sigmoid_cross_entropy_vectors_through_loss_kernel(dev):
+    """HuberLossTest.* (losses.py:144-152) and SigmoidCrossEntropyLossTest.testAllCorrect / testAllWrongSigmoid (losses.py:124)
+    through rn_detection_loss (ops.detection_loss, mode bce_dice = the reference's live loss)."""
+    import ops
+    for name, labels, preds, want in K.TF_HUBER_CASES:
+        lab, pre = np.atleast_2d(labels), np.atleast_2d(preds)
+        m = lab.shape[0]
+        one = np.ones((m, 1), np.float32)                      # one class, label 1 => every row is foreground
+        _, reg, _ = ops.detection_loss([_t(np.zeros((m, 1), np.float32), dev)], [_t(pre, dev)], [_t(one, dev)], [_t(lab, dev)],
+                                       [_t(np.ones(m, np.uint8), dev)], 1, "bce_dice")
+        assert abs(reg.item() - want) <= 1e-6, (name, reg.item(), want)
+    z = K.TF_BCE_LOGITS
+    zero4 = np.zeros((3, 4), np.float32)
+    for name, labels, want in K.TF_BCE_CASES:
+        cl, _, _ = ops.detection_loss([_t(z, dev)], [_t(zero4, dev)], [_t(labels, dev)], [_t(zero4, dev)],
+                                      [_t(np.ones(3, np.uint8), dev)], 3, "bce_dice")
+        # class loss = mean BCE + mean_c dice_c (losses.py:124-139); dice_c = 1 - 2 sum(l p) / (sum l + sum p) with p = sigmoid(+-100)
+        # in {0, 1}: 0 for every class when all are right, 1 when all are wrong
+        dice = 0.0 if name == "testAllCorrectSigmoid" else 1.0
+        assert abs(cl.item() - dice - want) <= 1e-3, (name, cl.item(), want)

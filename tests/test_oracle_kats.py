@@ -189,3 +189,41 @@ def test_dropout_mask_restatement_vector_equals_scalar_and_sites_cover_the_refer
     p = model_ref.init_params("mobilenet_v2", num_classes=3)
     model_ref.retinanet_forward(p, torch.zeros(1, 64, 64, 3), 3, dropout=hook)
     assert len(seen) == 53 and len(set(seen)) == 53 and all(s.startswith("backbone.") and s.endswith(".dropout") for s in seen)
+
+
+# ---- TensorFlow's own published unit-test vectors (tests/golden/reference_kats.py, "TF_*"): the [TF-sem] half of the oracle
+def test_tf_published_nms_vectors():
+    """NonMaxSuppressionOpTest.* -> utils_ref.nms_indices / nms_indices_vectorised (reference utils.py:213-220)."""
+    for name, boxes, scores, max_out, want in K.TF_NMS_CASES:
+        for fn in (utils_ref.nms_indices, utils_ref.nms_indices_vectorised):
+            got = fn(boxes, scores, max_output_size=max_out, iou_threshold=0.5)
+            assert list(got) == want, (name, fn.__name__, list(got))
+
+
+def test_tf_published_resize_align_corners_vectors():
+    """ResizeImagesTest.testResizeUpAlignCornersTrue -> the nearest-neighbour up-sample of the FPN (retinanet.py:153-155) and
+    the bilinear rescale of the input pipeline (dataset.py:145-151)."""
+    x = torch.from_numpy(K.TF_RESIZE_ALIGN_CORNERS_INPUT)
+    oh, ow = K.TF_RESIZE_ALIGN_CORNERS_SIZE
+    assert np.array_equal(tf_ops_ref.upsample_nearest_align_corners(x, oh, ow).numpy(), K.TF_RESIZE_ALIGN_CORNERS_NEAREST)
+    assert list(tf_ops_ref.nn_resize_index(5, 3)) == [0, 1, 1, 2, 2] and list(tf_ops_ref.nn_resize_index(4, 2)) == [0, 0, 1, 1]
+    got = dataset_ref.resize_bilinear_align_corners(K.TF_RESIZE_ALIGN_CORNERS_INPUT, oh, ow)
+    assert np.allclose(np.asarray(got), K.TF_RESIZE_ALIGN_CORNERS_BILINEAR, rtol=0, atol=1e-6)
+
+
+def test_tf_published_huber_vectors():
+    """HuberLossTest.* (delta 1) -> losses_ref.regression_loss with every row foreground (losses.py:144-152)."""
+    for name, labels, preds, want in K.TF_HUBER_CASES:
+        lab = torch.from_numpy(np.atleast_2d(labels))
+        pre = torch.from_numpy(np.atleast_2d(preds))
+        fg = torch.ones(lab.shape[0], dtype=torch.bool)
+        got = float(losses_ref.regression_loss(lab, pre, fg))
+        assert abs(got - want) <= 1e-6, (name, got, want)
+
+
+def test_tf_published_sigmoid_cross_entropy_vectors():
+    """SigmoidCrossEntropyLossTest.testAllCorrectSigmoid / testAllWrongSigmoid -> losses_ref.sigmoid_bce_with_logits (losses.py:124)."""
+    z = torch.from_numpy(K.TF_BCE_LOGITS)
+    for name, labels, want in K.TF_BCE_CASES:
+        got = float(losses_ref.sigmoid_bce_with_logits(torch.from_numpy(labels), z).mean())
+        assert abs(got - want) <= 1e-3, (name, got, want)

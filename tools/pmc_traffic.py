@@ -47,6 +47,11 @@ def main(fetch_dir, write_dir):
     # what tools/gemm_pmc.py launched: bench.py compares this with its own workload and drops `traffic` when they differ
     out["_shape"] = {"points": 36, "tiles": 2 * sum(((s + 3) // 4) ** 2 for s in (64, 32, 16, 8, 4)), "cin": 256, "cout": 256, "batch": 2, "image": 512}
     out["_product_mode"] = 1 if x3 else 0
+    # ... and the kernel sources it measured: a kernel edit that keeps the shape must not leave this figure in the driver's line
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from src_hash import kernel_source_hash, FILES
+    out["_kernel_source_sha"] = kernel_source_hash()
+    out["_kernel_source_files"] = list(FILES)
     out["_note"] = "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), averaged over the dispatches of tools/gemm_pmc.py"
     print(json.dumps(out, indent=1))
 
