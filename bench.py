@@ -707,6 +707,15 @@ def allreduce_slices(trainer, iters=20):
     return out
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def _free_port():
     import socket
     so = socket.socket()
@@ -946,10 +955,17 @@ def main():
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
+    # RCCL prints a version banner through C stdio when a communicator is created; on a pipe that buffer would be flushed at
+    # exit, AFTER the line below -- flush it now on every rank so that the JSON line is the last thing on stdout
+    _flush_c_stdio()
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        _flush_c_stdio()
 
 
 if __name__ == "__main__":

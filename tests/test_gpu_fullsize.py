@@ -244,14 +244,14 @@ def test_cfg3_cfg4_whole_net_forward_matches_oracle(dev, backbone, size, batch):
     print(backbone, "whole-net forward at %d px: worst max-norm relative error %.2e" % (size, worst))
 
 
-def _oracle_losses_and_grads(backbone, weights, image, lab_c, lab_r, masks, classes, dtype):
+def _oracle_losses_and_grads(backbone, weights, image, lab_c, lab_r, masks, classes, dtype, dropout=None):
     """(class loss, regression loss, {name: gradient}) of the composed oracle -- literal 32-split ResNeXt bottlenecks / concatenating
     DenseNet blocks (backbones_ref) + FPN + shared subnets (model_ref) + losses_ref, torch autograd on the host -- in `dtype`."""
     from oracle import losses_ref
     leaves = {k: v.detach().to(dtype).requires_grad_(True) for k, v in weights.items()}
     params = {to_oracle_name(k): v for k, v in leaves.items()}
     bparams = {k[len("base."):]: v for k, v in leaves.items() if k.startswith("base.backbone")}
-    fe = backbones_ref.backbone_forward(backbone, bparams, image.to(dtype))
+    fe = backbones_ref.backbone_forward(backbone, bparams, image.to(dtype), dropout=dropout)
     pyr = model_ref.fpn_forward(params, fe, "elu")
     ocls = {k: model_ref.subnet_forward(params, v, "classification_subnet", 9, classes, "elu") for k, v in pyr.items()}
     oreg = {k: model_ref.subnet_forward(params, v, "regression_subnet", 9, 4, "elu") for k, v in pyr.items()}
