@@ -996,6 +996,18 @@ int rn::launch_batched_gemm(const float* A, const float* B, float* C, int M, int
 }
 
 namespace {
+// Dense 1x1 / stride-1 convolutions of ONE tensor are plain products x [M x Cin] W [Cin x Cout]: in product mode 1 they run on
+// the split-bf16 kernels of gemm_x3.hip (round 6) where the grid is large enough to need no split-K (the tiny maps keep the
+// fp32 split-K path).  Returns the m-tile rows (64 / 128) or 0.
+int x3_conv1x1(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, long m, int x_ld, bool with_bias) {
+  if (nseg != 1 || bt.n != 1 || ngroups(g) != 1 || g->kh != 1 || g->kw != 1 || g->stride != 1 || with_bias) return 0;
+  if (g->cin % 4 || segs[0].cout % 4) return 0;
+  const int rows = rn::conv1x1_x3_tile(m, g->cin, segs[0].cout, x_ld);
+  if (!rows) return 0;
+  const long tiles = rn::ceil_div64(m, rows) * rn::ceil_div(segs[0].cout, rows);
+  return tiles >= 96 ? rows : 0;
+}
+
 int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
                   const Scratch& sc, const StatReq& sr) {
   if (int e = validate_geom(segs, nseg, g)) return e;
@@ -1043,6 +1055,33 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
       hipLaunchKernelGGL(stem_conv_fwd_kernel, dim3((unsigned)(d.m / STEM_PPB)), dim3(256), 0, (hipStream_t)stream, st_a);
       RN_LAUNCH_CHECK();
       return RN_OK;
+    }
+  }
+  if (const int xrows = x3_conv1x1(segs, nseg, g, bt, a.seg[0].m, a.seg[0].x_ld, a.seg[0].bias != nullptr)) {
+    const SegDev& d = a.seg[0];
+    const int ohw = d.oh * d.ow;
+    bool take = true;
+    float2* rows = nullptr;
+    if (sr.rows || sr.bytes_out) {
+      const int groups = sr.rows ? sr.rows->groups : sr.groups;
+      const bool ok = ohw % xrows == 0 && groups >= 1 && d.cout % groups == 0 && (double)ohw * (d.cout / groups) < 16777216.0 &&
+                      rn_group_norm_rows_ok(d.cout, groups, ohw / xrows, 0);
+      if (!ok) {
+        take = false;                       // (the fp32 kernels' tiles may still fit the map: fall through)
+      } else if (sr.bytes_out) {
+        *sr.bytes_out = (size_t)(d.m / xrows) * d.cout * 8;
+        if (sr.layout_out) { sr.layout_out->rows_per_sample = ohw / xrows; sr.layout_out->per_group = 0; sr.layout_out->groups = groups; }
+        return RN_OK;
+      } else {
+        RN_UNSUPPORTED(sr.rows->rows_per_sample != ohw / xrows || sr.rows->per_group != 0,
+                       "conv fwd stats: this shape / layout cannot produce GroupNorm rows (rn_conv2d_stats_rows)");
+        RN_CHECK_ARG(sr.rows->rows, "conv fwd stats: null rows");
+        rows = (float2*)sr.rows->rows;
+      }
+    }
+    if (take) {
+      if (sc.need_out) { *sc.need_out = 0; return RN_OK; }
+      return rn::launch_conv1x1_fwd_x3(d.a + d.x_coff, d.x_ld, d.b, d.out, d.m, g->cin, d.cout, rows, (hipStream_t)stream);
     }
   }
   const int c = (G > 1 && a.seg[0].cout / G <= 64)
@@ -1140,6 +1179,11 @@ int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, co
     rn::same_pad(d.w, g->kw, g->stride, &d.ow, &d.pad_l);
     d.m = d.n * d.h * d.w;
     set_x_view(d, segs[s], g->cin);
+  }
+  if (!plan && x3_conv1x1(segs, nseg, g, bt, a.seg[0].m, a.seg[0].x_ld, false)) {      // (a `plan` request = the merged kernel: see rn_conv2d_bwd)
+    if (sc.need_out) { *sc.need_out = 0; return RN_OK; }
+    const SegDev& d = a.seg[0];
+    return rn::launch_conv1x1_dgrad_x3(d.a, d.b, d.out + d.x_coff, d.x_ld, d.m, g->cin, d.cout, (hipStream_t)stream);
   }
   // stride 2: an input pixel only sees the taps of its own row / column parity -- the plain implicit GEMM multiplies
   // 3/4 structural zeros (ResNeXt's three 3x3/2 identity convs alone: 3 x 142 of 189 GFLOP per cfg-3 step).  Phase
@@ -1298,7 +1342,13 @@ extern "C" size_t rn_conv2d_wgrad_workspace(const rn_conv_seg* segs, int nseg, c
   if (validate_geom(segs, nseg, g)) return 0;
   WgradPlan p;
   if (plan_wgrad(segs, nseg, g, &p)) return 0;
-  return (size_t)p.nsplit * p.ktotal * p.cout * sizeof(float);
+  size_t need = (size_t)p.nsplit * p.ktotal * p.cout * sizeof(float);
+  if (nseg == 1 && g->kh == 1 && g->kw == 1 && g->stride == 1 && ngroups(g) == 1 && g->cin % 4 == 0 && segs[0].cout % 4 == 0) {
+    // (either product mode may run: the split-bf16 kernels have their own slab count)
+    const size_t x3 = rn::conv1x1_wgrad_workspace_x3(segs[0].n * segs[0].h * segs[0].w, g->cin, segs[0].cout);
+    if (x3 > need) need = x3;
+  }
+  return need;
 }
 
 namespace {
@@ -1342,6 +1392,19 @@ int conv_wgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, fl
   if (int e = validate_geom(segs, nseg, g)) return e;
   RN_CHECK_ARG((dw || nsplit_out) && workspace, "conv wgrad: null dw/workspace");
   RN_CHECK_ARG(bt.n == 1 || nseg == 1, "conv: batched mode takes one segment");
+  if (!plan && !nsplit_out && nseg == 1) {
+    SegDev v = {};
+    set_x_view(v, segs[0], g->cin);
+    const long m = (long)segs[0].n * segs[0].h * segs[0].w;
+    if (x3_conv1x1(segs, nseg, g, bt, m, v.x_ld, false)) {
+      RN_CHECK_ARG(segs[0].x && segs[0].dy, "conv wgrad: null pointer in segment 0");
+      int ns = 0;
+      if (int e = rn::launch_conv1x1_wgrad_x3(segs[0].x + v.x_coff, v.x_ld, segs[0].dy, (int)m, g->cin, segs[0].cout, workspace, workspace_bytes,
+                                              (hipStream_t)stream, &ns))
+        return e;
+      return rn::launch_reduce_rows((const float*)workspace, dw, (int64_t)g->cin * segs[0].cout, ns, accumulate, (hipStream_t)stream);
+    }
+  }
   WgradPlan p;
   if (int e = plan_wgrad(segs, nseg, g, &p, bt.n)) return e;
   const size_t need = (size_t)p.nsplit * bt.n * p.ktotal * p.cout * sizeof(float);
@@ -1415,6 +1478,11 @@ extern "C" int rn_conv2d_bwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
   static const bool enabled = getenv("RN_NO_MERGED_BWD") == nullptr;
   Planned pd, pw;
   bool merge = enabled && nseg <= 4;
+  if (merge && nseg == 1 && validate_geom(segs, nseg, g) == 0) {      // dense 1x1 in product mode 1: two split-bf16 launches instead
+    SegDev v = {};
+    set_x_view(v, segs[0], g->cin);
+    if (x3_conv1x1(segs, nseg, g, Batch{1, 0, 0, 0}, (long)segs[0].n * segs[0].h * segs[0].w, v.x_ld, false)) merge = false;
+  }
   if (merge) {
     if (int e = conv_dgrad_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream, Scratch{nullptr, 0, nullptr}, &pd)) return e;
     if (int e = conv_wgrad_impl(segs, nseg, g, dw, 0, workspace, workspace_bytes, Batch{1, 0, 0, 0}, stream, nullptr, &pw)) return e;

@@ -40,6 +40,8 @@ struct X3Args {
   X3Op a, b;
   float* c; long c_bstride, c_sstride; int ldc;
   int K, chunk, nsplit, nbatch, tiles_m, tiles_n;
+  float2* stat;       // dense 1x1 convs (rn::launch_conv1x1_fwd_x3): per (m-tile, column) sums (sum y, sum y^2) over the tile's rows -> stat[tile_m * ldc + col]
+                      // (the GroupNorm statistic rows of conv_gemm.hip's conv_stats_epilogue, same layout); nullptr: off
   int dbg;      // RN_X3_DBG (timing aid, wrong results): bit 0 no MFMAs, bit 1 no split / LDS stores, bit 2 no global loads after the first, bit 3 no fragment reads, bit 4 the dword epilogue
 };
 
@@ -142,8 +144,12 @@ __device__ __forceinline__ bf16x8 fragment(const unsigned short* tile, int p, in
 // the LDS traffic and the split's VALU work per matrix-core instruction (the 64 x 64 tile is bound by their SUM: 28 us for the
 // head-tower product against 8 us of matrix-core time); WT = 1 is for launches too small to fill the chip with 128 x 128 tiles.
 // NST register stages: the operand tiles of NST K-steps are in flight at once.
-template <bool A_KS, bool B_KS, int WT, int NST>
+// DBG: the leave-one-out timing aid (RN_X3_DBG, wrong results) as its own instantiation -- in the production kernel (DBG = false)
+// the K-step is ONE basic block: run-time tests between its phases would keep the scheduler from moving the next step's fragment
+// reads and the global loads in between the matrix-core instructions.
+template <bool A_KS, bool B_KS, int WT, int NST, bool DBG = false>
 __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Args a) {
+  const int dbg = DBG ? a.dbg : 0;
   constexpr int ROWS = 64 * WT;
   typedef TileGeom<ROWS> G;
   __shared__ __attribute__((aligned(16))) unsigned short lds[6 * G::PLANE];
@@ -179,19 +185,19 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
     for (int st = 0; st < NST; ++st) {
       const int it = it0 + st;
       if (it < nk) {                         // (block-uniform)
-        if (!(a.dbg & 2)) {
+        if (!(dbg & 2)) {
           la[st].store(At, t);
           lb[st].store(Bt, t);
         }
         __syncthreads();
-        if (it + NST < nk && !(a.dbg & 4)) {
+        if (it + NST < nk && !(dbg & 4)) {
           la[st].load(ra, a.a, m0, kbeg + (it + NST) * XK, kend, t);
           lb[st].load(rb, a.b, n0, kbeg + (it + NST) * XK, kend, t);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           bf16x8 fa[WT][3], fb[WT][3];
-          if (!(a.dbg & 8)) {
+          if (!(dbg & 8)) {
 #pragma unroll
             for (int i = 0; i < WT; ++i)
 #pragma unroll
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
 #pragma unroll
               for (int p = 0; p < 3; ++p) { fa[i][p] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)t, 1u, 2u, 3u}); fb[i][p] = fa[i][p]; }
           }
-          if (!(a.dbg & 1))
+          if (!(dbg & 1))
 #pragma unroll
           for (int i = 0; i < WT; ++i)
 #pragma unroll
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
     }
   }
   float* pc = a.c + (size_t)split * a.c_sstride + (size_t)batch * a.c_bstride;
-  if (WT == 2 && !(a.dbg & 16)) {
+  if (WT == 2 && !(dbg & 16)) {
     // 16-byte stores through LDS: the accumulator layout (lane = column, registers = rows) would go out as 64 dword stores per
     // lane in 128-byte pieces; staged per wave as [32 rows][64 columns] it leaves as 8 x 16-byte stores per lane and 32-row half,
     // every instruction writing four whole 256-byte row segments.  (The operand tiles are dead: the K loop ended with a barrier.)
@@ -250,6 +256,28 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
   } else {
     store_tile<ROWS, ROWS, 2, 2>(acc, pc, nullptr, m0, n0, a.a.rows, a.b.rows, a.ldc, wm, wn, lane);
   }
+  if (a.stat) {      // (block-uniform) GroupNorm partial sums of the tile: rows past the end were multiplied as zeros
+    __syncthreads();                                         // the staging area / operand tiles are dead
+    float* red = reinterpret_cast<float*>(lds);              // [2 wm][ROWS columns][2]
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const float v = acc[i][j][q]; s1 += v; s2 = fmaf(v, v, s2); }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lane < 32) {
+        const int col = (wn * WT + j) * 32 + r;
+        red[(wm * ROWS + col) * 2 + 0] = s1;
+        red[(wm * ROWS + col) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (t < ROWS && n0 + t < a.b.rows)
+      a.stat[(size_t)tile_m * a.ldc + n0 + t] = make_float2(red[t * 2] + red[(ROWS + t) * 2], red[t * 2 + 1] + red[(ROWS + t) * 2 + 1]);
+  }
 }
 
 // Measured and not kept (round 5): the same tiles as a "ping-pong" block of 512 threads -- two groups of 4 waves, each with its
@@ -259,6 +287,12 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
 // + 1.4 global loads) whatever the interleaving, as they would under a power-limited clock: what shortens it is less WORK
 // (operands split once by their producers instead of once per consuming block), not a different schedule.
 
+// Measured and not kept (round 6): the K loop software-pipelined inside every wave -- the split of tile it + 1 (registers -> packed
+// registers) issued in the matrix-core phase of tile it, in the shadow of its MFMAs (the compiler does interleave them: 5 - 8 VALU
+// per MFMA), only the 24 LDS stores of the packed values left between the barriers, no branch in the step: 28.0 us against 26.8 us
+// for the head-tower product, 54.5 against 52.1 for the backward pair, the step unchanged (499.9 vs 499.9 images/s).  What DID
+// help (round 6): the leave-one-out switches (RN_X3_DBG) are a template parameter now -- as run-time tests they split the K-step
+// into basic blocks the scheduler could not move fragment reads and global loads across.
 int g_mode = -1;
 int mode() {
   if (g_mode < 0) {
@@ -293,7 +327,12 @@ int launch(X3Args a, bool a_ks, bool b_ks, int rows, hipStream_t st, unsigned ld
     else if (!a_ks && !b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, false, WT_, NST_>), grid, dim3(XT), 0, st, a);     \
     else hipLaunchKernelGGL((gemm_x3_kernel<true, false, WT_, NST_>), grid, dim3(XT), 0, st, a);                          \
   } while (0)
-  if (rows == 128) {
+  if (rows == 128 && dbg) {     // (the timing aid measures the head-tower configuration)
+    if (a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<true, true, 2, 2, true>), grid, dim3(XT), lds_pad, st, a);
+    else if (!a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, true, 2, 2, true>), grid, dim3(XT), 0, st, a);
+    else if (!a_ks && !b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, false, 2, 2, true>), grid, dim3(XT), 0, st, a);
+    else hipLaunchKernelGGL((gemm_x3_kernel<true, false, 2, 2, true>), grid, dim3(XT), 0, st, a);
+  } else if (rows == 128) {
     if (nst_env == 1) RN_X3K(2, 1);
     else RN_X3K(2, 2);
   } else {
@@ -340,6 +379,52 @@ int launch_batched_gemm_x3(const float* A, const float* B, float* C, int M, int 
   a.c = C; a.c_bstride = (long)M * N; a.c_sstride = 0; a.ldc = N;
   a.K = K; a.chunk = rn::ceil_div(K, XK) * XK; a.nsplit = 1; a.nbatch = nbatch;
   return launch(a, false, b_nk == 0, tile_rows(M, N, nbatch), st);
+}
+
+// ---- dense 1x1 / stride-1 convolutions as plain products (round 6: the ResNeXt / DenseNet bottleneck 1x1 convs and the FPN laterals,
+// resnet.py:38-49,67-69, densenet.py:61-66,137-142, retinanet.py:127-133,195-201): y [M x Cout] = x [M x Cin] W [Cin x Cout], x a
+// channel slice (pixel stride x_ld) of a possibly wider buffer.  conv_gemm.hip routes them here in product mode 1.
+static const bool conv1x1_on = !(getenv("RN_X3_CONV1X1") && atoi(getenv("RN_X3_CONV1X1")) == 0);
+int conv1x1_x3_tile(long M, int Cin, int Cout, int x_ld) {
+  if (mode() != 1 || !conv1x1_on || M < 1 || M > 0x7fffffffL || !gemm_x3_ok((int)M, Cin, Cout) || !fits(M * (long)x_ld)) return 0;
+  return tile_rows(M, Cout, 1);
+}
+int launch_conv1x1_fwd_x3(const float* x, int x_ld, const float* w, float* y, int M, int Cin, int Cout, float2* stat_rows, hipStream_t st) {
+  X3Args a = {};
+  a.a = {x, 0, x_ld, M};
+  a.b = {w, 0, Cout, Cout};                 // W [Cin][Cout]: k-strided
+  a.c = y; a.c_bstride = 0; a.c_sstride = 0; a.ldc = Cout;
+  a.K = Cin; a.chunk = rn::ceil_div(Cin, XK) * XK; a.nsplit = 1; a.nbatch = 1;
+  a.stat = stat_rows;
+  return launch(a, false, true, tile_rows(M, Cout, 1), st);
+}
+// dx [M x Cin] (pixel stride dx_ld) = dy [M x Cout] W^T
+int launch_conv1x1_dgrad_x3(const float* dy, const float* w, float* dx, int dx_ld, int M, int Cin, int Cout, hipStream_t st) {
+  X3Args a = {};
+  a.a = {dy, 0, Cout, M};
+  a.b = {w, 0, Cout, Cin};                  // Op2(ci, co) = W[ci * Cout + co]: k-contiguous
+  a.c = dx; a.c_bstride = 0; a.c_sstride = 0; a.ldc = dx_ld;
+  a.K = Cout; a.chunk = rn::ceil_div(Cout, XK) * XK; a.nsplit = 1; a.nbatch = 1;
+  return launch(a, false, false, tile_rows(M, Cin, 1), st);
+}
+size_t conv1x1_wgrad_workspace_x3(int M, int Cin, int Cout) { return batched_gemm_tn_workspace_x3(M, Cin, Cout, 1); }
+// slabs [nsplit][Cin][Cout] of x^T dy in `workspace` (the caller sums them: rn::launch_reduce_rows)
+int launch_conv1x1_wgrad_x3(const float* x, int x_ld, const float* dy, int M, int Cin, int Cout, void* workspace, size_t workspace_bytes,
+                            hipStream_t st, int* nsplit_out) {
+  int ns, ck, tr;
+  tn_split(M, Cin, Cout, 1, &ns, &ck, &tr);
+  const size_t need = (size_t)ns * Cin * Cout * sizeof(float);
+  if (workspace_bytes < need) {
+    rn::set_error("conv 1x1 wgrad x3: workspace %zu < %zu bytes", workspace_bytes, need);
+    return RN_EWORKSPACE;
+  }
+  X3Args a = {};
+  a.a = {x, 0, x_ld, Cin};                  // rows = the Cin output rows, contraction index = the pixel
+  a.b = {dy, 0, Cout, Cout};
+  a.c = (float*)workspace; a.c_bstride = 0; a.c_sstride = (long)Cin * Cout; a.ldc = Cout;
+  a.K = M; a.chunk = ck; a.nsplit = ns; a.nbatch = 1;
+  *nsplit_out = ns;
+  return launch(a, true, true, tr, st);
 }
 
 size_t batched_gemm_tn_workspace_x3(int M, int K, int N, int nbatch) {

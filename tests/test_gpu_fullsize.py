@@ -244,7 +244,7 @@ def test_cfg3_cfg4_whole_net_forward_matches_oracle(dev, backbone, size, batch):
     print(backbone, "whole-net forward at %d px: worst max-norm relative error %.2e" % (size, worst))
 
 
-def _oracle_losses_and_grads(backbone, weights, image, lab_c, lab_r, masks, classes, dtype, dropout=None):
+def _oracle_losses_and_grads(backbone, weights, image, lab_c, lab_r, masks, classes, dtype, dropout=None, mode="focal"):
     """(class loss, regression loss, {name: gradient}) of the composed oracle -- literal 32-split ResNeXt bottlenecks / concatenating
     DenseNet blocks (backbones_ref) + FPN + shared subnets (model_ref) + losses_ref, torch autograd on the host -- in `dtype`."""
     from oracle import losses_ref
@@ -257,7 +257,7 @@ def _oracle_losses_and_grads(backbone, weights, image, lab_c, lab_r, masks, clas
     oreg = {k: model_ref.subnet_forward(params, v, "regression_subnet", 9, 4, "elu") for k, v in pyr.items()}
     ocl, orl = losses_ref.loss(train_ref.compact({k: v.to(dtype) for k, v in lab_c.items()}, masks),
                                train_ref.compact({k: v.to(dtype) for k, v in lab_r.items()}, masks),
-                               train_ref.compact(ocls, masks), train_ref.compact(oreg, masks), "focal")
+                               train_ref.compact(ocls, masks), train_ref.compact(oreg, masks), mode)
     names = list(leaves.keys())
     grads = dict(zip(names, torch.autograd.grad(ocl + orl, [leaves[n] for n in names])))
     return float(ocl.detach()), float(orl.detach()), {n: g.double().numpy() for n, g in grads.items()}

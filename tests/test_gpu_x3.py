@@ -122,3 +122,62 @@ def test_winograd_layer_both_product_modes_vs_oracle(dev, product_mode, mode):
         assert_close(yg[i].detach().cpu().numpy(), yc[i].detach().numpy(), 1e-4, "winograd fwd level %d (mode %d)" % (i, mode))
         assert_close(xg[i].grad.cpu().numpy(), xc[i].grad.numpy(), 1e-4, "winograd dx level %d (mode %d)" % (i, mode))
     assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), 1e-4, "winograd dw (mode %d)" % mode)
+
+
+# ---- round 6: the dense 1x1 / stride-1 convolutions on the same kernels (resnet.py:38-49,67-69, densenet.py:61-66,137-142)
+@pytest.mark.parametrize("n,hw,cin,cout", [(2, 64, 64, 256), (2, 64, 256, 64), (1, 96, 128, 512), (2, 32, 1024, 256), (2, 16, 2048, 512),
+                                           (2, 16, 512, 2048), (4, 40, 544, 128), (2, 40, 100, 36)])
+def test_conv1x1_split_bf16_fwd_bwd_as_accurate_as_fp32(dev, product_mode, n, hw, cin, cout):
+    """ops.conv2d of a 1x1 / stride-1 kernel (forward, data gradient, weight gradient) in both product modes against fp64, at the
+    K = 64 .. 2 048 / N = 36 .. 2 048 shapes of the ResNeXt / DenseNet bottlenecks: the split-bf16 path must be as accurate as the
+    fp32 matrix-core path (error relative to sum |a||b| within 2 x the fp32 kernel's own, and below 3e-7)."""
+    import ops
+    rng = np.random.default_rng(n * hw + cin + cout)
+    x = rng.standard_normal((n, hw, hw, cin)).astype(np.float32)
+    w = (rng.standard_normal((1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    dy = rng.standard_normal((n, hw, hw, cout)).astype(np.float32)
+    X, W2, DY = x.reshape(-1, cin).astype(np.float64), w.reshape(cin, cout).astype(np.float64), dy.reshape(-1, cout).astype(np.float64)
+    ref = {"y": X @ W2, "dx": DY @ W2.T, "dw": X.T @ DY}
+    mag = {"y": np.abs(X) @ np.abs(W2), "dx": np.abs(DY) @ np.abs(W2).T, "dw": np.abs(X).T @ np.abs(DY)}
+    errs = []
+    for mode in (0, 1):
+        product_mode(mode)
+        xg, wg = _t(x, dev).requires_grad_(True), _t(w, dev).requires_grad_(True)
+        y = ops.conv2d(xg, wg, None, 1)
+        y.backward(_t(dy, dev))
+        got = {"y": y.detach().cpu().numpy().reshape(-1, cout), "dx": xg.grad.cpu().numpy().reshape(-1, cin), "dw": wg.grad.cpu().numpy().reshape(cin, cout)}
+        assert all(np.isfinite(v).all() for v in got.values())
+        errs.append({k: float((np.abs(got[k].astype(np.float64) - ref[k]) / mag[k]).max()) for k in ref})
+    print("conv 1x1 %d x %d^2 x %d -> %d: error / sum|a||b| fp32 %s, split bf16 %s" % (
+        n, hw, cin, cout, {k: "%.1e" % v for k, v in errs[0].items()}, {k: "%.1e" % v for k, v in errs[1].items()}))
+    for k in ref:
+        assert errs[1][k] <= max(2.0 * errs[0][k], 3e-7), (k, errs)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_conv1x1_with_group_norm_statistics_both_modes(dev, product_mode, mode):
+    """conv 1x1 -> GroupNorm -> ReLU with the GroupNorm's statistics taken from the conv's epilogue (ops.conv2d(gn=...): the rows the
+    split-bf16 kernel writes have the layout of the fp32 kernel's), forward and all gradients vs the oracle, both modes."""
+    import ops
+    product_mode(mode)
+    rng = np.random.default_rng(17 + mode)
+    n, hw, cin, cout = 2, 64, 128, 256
+    x = rng.standard_normal((n, hw, hw, cin)).astype(np.float32)
+    w = (rng.standard_normal((1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    gamma, beta = (1 + 0.2 * rng.standard_normal(cout)).astype(np.float32), (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    dz = rng.standard_normal((n, hw, hw, cout)).astype(np.float32)
+    xc, wc = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(w).requires_grad_(True)
+    gc, bc = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
+    zc = T.activation(T.group_norm(T.conv2d_same(xc, wc, 1), gc, bc), "relu")
+    zc.backward(torch.from_numpy(dz))
+    xg, wg = _t(x, dev).requires_grad_(True), _t(w, dev).requires_grad_(True)
+    gg, bg = _t(gamma, dev).requires_grad_(True), _t(beta, dev).requires_grad_(True)
+    y = ops.conv2d(xg, wg, None, 1, gn=(32, 1e-5))
+    assert getattr(y, "_gn_rows", None) is not None, "the conv did not emit GroupNorm rows"
+    zg = ops.group_norm_act(y, gg, bg, groups=32, act="relu")
+    zg.backward(_t(dz, dev))
+    assert_close(zg.detach().cpu().numpy(), zc.detach().numpy(), 1e-4, "conv1x1 + GN + relu (mode %d)" % mode)
+    assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), 1e-4, "dx (mode %d)" % mode)
+    assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), 1e-4, "dw (mode %d)" % mode)
+    assert_close(gg.grad.cpu().numpy(), gc.grad.numpy(), 1e-4, "dgamma (mode %d)" % mode)
+    assert_close(bg.grad.cpu().numpy(), bc.grad.numpy(), 1e-4, "dbeta (mode %d)" % mode)
