@@ -1008,9 +1008,28 @@ int x3_conv1x1(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const B
   return tiles >= 96 ? rows : 0;
 }
 
+// Dense k x k convs that are not plain products (3x3 / stride 2 ...) through an explicit patch matrix on the split-bf16 kernels
+// (im2col.hip); returns the patch matrix's bytes (0: not taken).  Dense x / dx only, one tensor, no bias.
+size_t x3_im2col(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, bool with_bias) {
+  if (nseg != 1 || bt.n != 1 || ngroups(g) != 1 || with_bias) return 0;
+  if (segs[0].x_ld > 0 && (segs[0].x_ld != g->cin || segs[0].x_coff != 0)) return 0;
+  return rn::im2col_x3_bytes(segs[0].n, segs[0].h, segs[0].w, g->cin, segs[0].cout, g->kh, g->kw, g->stride);
+}
+// Grouped 3x3 / stride-1 convs with 4 .. 32 channels per group (the ResNeXt bottlenecks' conv 2): direct kernels of grouped_conv.hip
+bool gconv_direct(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, bool with_bias) {
+  if (nseg != 1 || bt.n != 1 || ngroups(g) < 2 || g->kh != 3 || g->kw != 3 || g->stride != 1 || with_bias) return false;
+  if (segs[0].cout != g->cin || (segs[0].x_ld > 0 && (segs[0].x_ld != g->cin || segs[0].x_coff != 0))) return false;
+  return rn::gconv3x3_ok(segs[0].n, segs[0].h, segs[0].w, g->cin, ngroups(g));
+}
+
 int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
                   const Scratch& sc, const StatReq& sr) {
   if (int e = validate_geom(segs, nseg, g)) return e;
+  if (!sr.rows && !sr.bytes_out && gconv_direct(segs, nseg, g, bt, segs[0].bias != nullptr)) {
+    if (sc.need_out) { *sc.need_out = 0; return RN_OK; }
+    RN_CHECK_ARG(segs[0].x && segs[0].wgt && segs[0].y, "conv fwd: null pointer in segment 0");
+    return rn::launch_gconv3x3(segs[0].x, segs[0].wgt, segs[0].y, segs[0].n, segs[0].h, segs[0].w, g->cin, ngroups(g), 0, (hipStream_t)stream);
+  }
   RN_CHECK_ARG(bt.n == 1 || nseg == 1, "conv: batched mode takes one segment");
   ConvArgs a = {};
   a.nbatch = bt.n; a.bs_a = bt.bs_a; a.bs_b = bt.bs_b; a.bs_out = bt.bs_out;
@@ -1057,7 +1076,15 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
       return RN_OK;
     }
   }
-  if (const int xrows = x3_conv1x1(segs, nseg, g, bt, a.seg[0].m, a.seg[0].x_ld, a.seg[0].bias != nullptr)) {
+  // dense convs of one tensor as split-bf16 products (product mode 1): 1x1 / stride 1 directly on x, any other kernel through the patch
+  // matrix written into the caller's scratch (rn_conv2d_fwd_workspace asks for it; a caller that brings none keeps the fp32 kernels)
+  int xrows = x3_conv1x1(segs, nseg, g, bt, a.seg[0].m, a.seg[0].x_ld, a.seg[0].bias != nullptr);
+  size_t colb = 0;
+  if (!xrows && (colb = x3_im2col(segs, nseg, g, bt, a.seg[0].bias != nullptr)) != 0) {
+    if (sc.need_out || (sc.ws && sc.bytes >= colb)) xrows = rn::conv1x1_x3_tile(a.seg[0].m, g->kh * g->kw * g->cin, a.seg[0].cout, g->kh * g->kw * g->cin);
+    else colb = 0;
+  }
+  if (xrows) {
     const SegDev& d = a.seg[0];
     const int ohw = d.oh * d.ow;
     bool take = true;
@@ -1080,8 +1107,11 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
       }
     }
     if (take) {
-      if (sc.need_out) { *sc.need_out = 0; return RN_OK; }
-      return rn::launch_conv1x1_fwd_x3(d.a + d.x_coff, d.x_ld, d.b, d.out, d.m, g->cin, d.cout, rows, (hipStream_t)stream);
+      if (sc.need_out) { *sc.need_out = colb; return RN_OK; }
+      if (!colb) return rn::launch_conv1x1_fwd_x3(d.a + d.x_coff, d.x_ld, d.b, d.out, d.m, g->cin, d.cout, rows, (hipStream_t)stream);
+      const int K = g->kh * g->kw * g->cin;                    // W in HWIO is the [K][cout] matrix
+      if (int e = rn::launch_im2col(d.a, (float*)sc.ws, d.n, d.h, d.w, g->cin, g->kh, g->kw, g->stride, (hipStream_t)stream)) return e;
+      return rn::launch_conv1x1_fwd_x3((const float*)sc.ws, K, d.b, d.out, d.m, K, d.cout, rows, (hipStream_t)stream);
     }
   }
   const int c = (G > 1 && a.seg[0].cout / G <= 64)
@@ -1162,6 +1192,26 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
 int conv_dgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, rn_stream_t stream,
                     const Scratch& sc, Planned* plan) {
   if (int e = validate_geom(segs, nseg, g)) return e;
+  if (!plan) {
+    if (const size_t colb = x3_im2col(segs, nseg, g, bt, false)) {
+      if (sc.need_out) { *sc.need_out = colb; return RN_OK; }
+      if (sc.ws && sc.bytes >= colb) {
+        RN_CHECK_ARG(segs[0].dy && segs[0].wgt && segs[0].dx, "conv dgrad: null pointer in segment 0");
+        int oh, ow, pt, pl;
+        rn::same_pad(segs[0].h, g->kh, g->stride, &oh, &pt);
+        rn::same_pad(segs[0].w, g->kw, g->stride, &ow, &pl);
+        const int M = segs[0].n * oh * ow, K = g->kh * g->kw * g->cin;
+        // dcol [M][K] = dy [M][cout] W^T  (W [K][cout]: the product's [N = K][k = cout] operand), then the gather
+        if (int e = rn::launch_conv1x1_dgrad_x3(segs[0].dy, segs[0].wgt, (float*)sc.ws, K, M, K, segs[0].cout, (hipStream_t)stream)) return e;
+        return rn::launch_col2im((const float*)sc.ws, segs[0].dx, segs[0].n, segs[0].h, segs[0].w, g->cin, g->kh, g->kw, g->stride, (hipStream_t)stream);
+      }
+    }
+  }
+  if (!plan && gconv_direct(segs, nseg, g, bt, false)) {       // the same direct kernel on dy, the kernel rotated / transposed per group
+    if (sc.need_out) { *sc.need_out = 0; return RN_OK; }
+    RN_CHECK_ARG(segs[0].dy && segs[0].wgt && segs[0].dx, "conv dgrad: null pointer in segment 0");
+    return rn::launch_gconv3x3(segs[0].dy, segs[0].wgt, segs[0].dx, segs[0].n, segs[0].h, segs[0].w, g->cin, ngroups(g), 1, (hipStream_t)stream);
+  }
   RN_CHECK_ARG(bt.n == 1 || nseg == 1, "conv: batched mode takes one segment");
   ConvArgs a = {};
   a.nbatch = bt.n; a.bs_a = bt.bs_a; a.bs_b = bt.bs_b; a.bs_out = bt.bs_out;
@@ -1348,6 +1398,14 @@ extern "C" size_t rn_conv2d_wgrad_workspace(const rn_conv_seg* segs, int nseg, c
     const size_t x3 = rn::conv1x1_wgrad_workspace_x3(segs[0].n * segs[0].h * segs[0].w, g->cin, segs[0].cout);
     if (x3 > need) need = x3;
   }
+  if (gconv_direct(segs, nseg, g, Batch{1, 0, 0, 0}, false)) {
+    const size_t gc = rn::gconv3x3_wgrad_workspace(segs[0].n, segs[0].h, segs[0].w, g->cin, ngroups(g));
+    if (gc > need) need = gc;
+  }
+  if (const size_t colb = x3_im2col(segs, nseg, g, Batch{1, 0, 0, 0}, false)) {      // patch matrix + the split product's slabs
+    const size_t ic = colb + rn::conv1x1_wgrad_workspace_x3((int)(colb / 4 / ((size_t)g->kh * g->kw * g->cin)), g->kh * g->kw * g->cin, segs[0].cout);
+    if (ic > need) need = ic;
+  }
   return need;
 }
 
@@ -1392,6 +1450,26 @@ int conv_wgrad_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, fl
   if (int e = validate_geom(segs, nseg, g)) return e;
   RN_CHECK_ARG((dw || nsplit_out) && workspace, "conv wgrad: null dw/workspace");
   RN_CHECK_ARG(bt.n == 1 || nseg == 1, "conv: batched mode takes one segment");
+  if (!plan && !nsplit_out) {
+    if (const size_t colb = x3_im2col(segs, nseg, g, bt, false)) {
+      const int K = g->kh * g->kw * g->cin, M = (int)(colb / 4 / (size_t)K);
+      const size_t slabs = rn::conv1x1_wgrad_workspace_x3(M, K, segs[0].cout);
+      if (workspace_bytes >= colb + slabs) {
+        RN_CHECK_ARG(segs[0].x && segs[0].dy && dw, "conv wgrad: null pointer in segment 0");
+        float* col = (float*)workspace;
+        if (int e = rn::launch_im2col(segs[0].x, col, segs[0].n, segs[0].h, segs[0].w, g->cin, g->kh, g->kw, g->stride, (hipStream_t)stream)) return e;
+        int ns = 0;
+        void* sl = (char*)workspace + colb;
+        if (int e = rn::launch_conv1x1_wgrad_x3(col, K, segs[0].dy, M, K, segs[0].cout, sl, workspace_bytes - colb, (hipStream_t)stream, &ns)) return e;
+        return rn::launch_reduce_rows((const float*)sl, dw, (int64_t)K * segs[0].cout, ns, accumulate, (hipStream_t)stream);
+      }
+    }
+  }
+  if (!plan && !nsplit_out && gconv_direct(segs, nseg, g, bt, false)) {
+    RN_CHECK_ARG(segs[0].x && segs[0].dy && dw, "conv wgrad: null pointer in segment 0");
+    return rn::launch_gconv3x3_wgrad(segs[0].x, segs[0].dy, dw, accumulate, segs[0].n, segs[0].h, segs[0].w, g->cin, ngroups(g), workspace,
+                                     workspace_bytes, (hipStream_t)stream);
+  }
   if (!plan && !nsplit_out && nseg == 1) {
     SegDev v = {};
     set_x_view(v, segs[0], g->cin);
@@ -1482,6 +1560,8 @@ extern "C" int rn_conv2d_bwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
     SegDev v = {};
     set_x_view(v, segs[0], g->cin);
     if (x3_conv1x1(segs, nseg, g, Batch{1, 0, 0, 0}, (long)segs[0].n * segs[0].h * segs[0].w, v.x_ld, false)) merge = false;
+    if (gconv_direct(segs, nseg, g, Batch{1, 0, 0, 0}, false)) merge = false;          // ... grouped 3x3: the direct kernels
+    if (x3_im2col(segs, nseg, g, Batch{1, 0, 0, 0}, false)) merge = false;             // ... dense k x k / stride 2: patch matrix + split products
   }
   if (merge) {
     if (int e = conv_dgrad_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream, Scratch{nullptr, 0, nullptr}, &pd)) return e;
@@ -1489,7 +1569,11 @@ extern "C" int rn_conv2d_bwd(const rn_conv_seg* segs, int nseg, const rn_conv_ge
     merge = pd.simple && pd.vec && pw.vec && pd.cfg == 2 && pd.a.nseg <= 4 && pw.a.nseg <= 4;
   }
   if (!merge) {
-    if (int e = conv_dgrad_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream)) return e;
+    // (the patch-matrix path of the data gradient needs the scratch -- the weight gradient's is at least as large; every other
+    // shape keeps the scratch-free data gradient it always had)
+    const bool ic = nseg == 1 && validate_geom(segs, nseg, g) == 0 && x3_im2col(segs, nseg, g, Batch{1, 0, 0, 0}, false) != 0;
+    if (int e = conv_dgrad_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream, ic ? Scratch{workspace, workspace_bytes, nullptr} : Scratch{nullptr, 0, nullptr}))
+      return e;
     return conv_wgrad_impl(segs, nseg, g, dw, 0, workspace, workspace_bytes, Batch{1, 0, 0, 0}, stream);
   }
   const ConvArgs4 d4 = compact(pd.a), w4 = compact(pw.a);

@@ -63,6 +63,16 @@ int launch_conv1x1_dgrad_x3(const float* dy, const float* w, float* dx, int dx_l
 size_t conv1x1_wgrad_workspace_x3(int M, int Cin, int Cout);
 int launch_conv1x1_wgrad_x3(const float* x, int x_ld, const float* dy, int M, int Cin, int Cout, void* workspace, size_t workspace_bytes,
                             hipStream_t st, int* nsplit_out);
+// dense k x k convs (not 1 x 1 / stride 1) as split-bf16 products of an explicit patch matrix (im2col.hip); bytes == 0: not taken
+size_t im2col_x3_bytes(int n, int h, int wd, int cin, int cout, int kh, int kw, int stride);
+int launch_im2col(const float* x, float* col, int n, int h, int wd, int cin, int kh, int kw, int stride, hipStream_t st);
+int launch_col2im(const float* dcol, float* dx, int n, int h, int wd, int cin, int kh, int kw, int stride, hipStream_t st);
+// grouped 3x3 / stride-1 convs with 4 / 8 / 16 / 32 channels per group as direct convolutions (grouped_conv.hip)
+bool gconv3x3_ok(int n, int h, int wd, int c, int groups);
+int launch_gconv3x3(const float* x, const float* w, float* y, int n, int h, int wd, int c, int groups, int transpose, hipStream_t st);
+size_t gconv3x3_wgrad_workspace(int n, int h, int wd, int c, int groups);
+int launch_gconv3x3_wgrad(const float* x, const float* dy, float* dw, int accumulate, int n, int h, int wd, int c, int groups, void* workspace,
+                          size_t workspace_bytes, hipStream_t st);
 int launch_batched_gemm_tn_x3(const float* A, const float* B, int M, int K, int N, int nbatch, void* workspace, size_t workspace_bytes,
                               hipStream_t st, int* nsplit_out, int background = 0);
 // Entry points that end with a row reduction open one of these with their `defer` argument: while it is alive (this

@@ -124,7 +124,10 @@ def _conv_fwd(segs, n, geom, device, gn=None, samples=0):
         if nbytes:
             rows = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
             lay.rows = rows.data_ptr()
-            _rn.check(L.rn_conv2d_fwd_stats(segs, n, C.byref(geom), None, 0, C.byref(lay), _rn.stream()), "rn_conv2d_fwd_stats")
+            # (the scratch rn_conv2d_stats_rows was told about: the patch matrix of a strided dense conv on the split-bf16 kernels)
+            ws = _rn.workspace(need, device) if need else None
+            _rn.check(L.rn_conv2d_fwd_stats(segs, n, C.byref(geom), ws.data_ptr() if need else None, ws.numel() if need else 0, C.byref(lay),
+                                            _rn.stream()), "rn_conv2d_fwd_stats")
             return rows, lay.rows_per_sample, lay.per_group, g
     ws = _rn.workspace(need, device) if need else None
     _rn.check(L.rn_conv2d_fwd(segs, n, C.byref(geom), ws.data_ptr() if need else None, ws.numel() if need else 0,

@@ -153,3 +153,26 @@ def test_concat_free_dense_block_equals_concat_form(dev, rate):
     names = ["dx"] + [n for n, _ in blk.named_parameters()]
     for name, a, b in zip(names, grads[0], grads[1]):
         assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4, "dense block " + name)
+
+
+@pytest.mark.parametrize("n,h,w,c", [(2, 64, 64, 128), (2, 64, 64, 256), (2, 36, 50, 512), (2, 19, 27, 1024), (1, 100, 75, 128)])
+def test_grouped_3x3_direct_kernels_equal_the_literal_split_form(dev, n, h, w, c):
+    """The direct grouped 3x3 / stride-1 kernels (csrc/grouped_conv.hip, round 6: 4 / 8 / 16 / 32 channels per group at maps large
+    enough to fill the chip; ragged tiles: 36 x 50, 19 x 27, 100 x 75) against the reference's literal form -- tf.split into 32 pieces,
+    one Conv2D per piece, tf.concat (resnet.py:88-95) -- forward, data gradient and weight gradient, 1e-4."""
+    import ops
+    from oracle import tf_ops_ref as T
+    G, cg = 32, c // 32
+    rng = np.random.default_rng(c + h)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, cg, c)) / np.sqrt(9 * cg)).astype(np.float32)
+    dy = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    xc, wc = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(wt).requires_grad_(True)
+    yc = torch.cat([T.conv2d_same(s, wc[..., g * cg:(g + 1) * cg], 1) for g, s in enumerate(torch.split(xc, cg, dim=-1))], -1)
+    yc.backward(torch.from_numpy(dy))
+    xg, wg = torch.from_numpy(x).to(dev).requires_grad_(True), torch.from_numpy(wt).to(dev).requires_grad_(True)
+    yg = ops.conv2d(xg, wg, None, 1, groups=G)
+    yg.backward(torch.from_numpy(dy).to(dev))
+    assert_close(yg.detach().cpu().numpy(), yc.detach().numpy(), TOL, "grouped conv forward")
+    assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), TOL, "grouped conv dx")
+    assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), TOL, "grouped conv dw")

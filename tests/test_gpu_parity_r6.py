@@ -6,9 +6,10 @@
       MobileNetV2-FPN and ResNeXt-50-FPN;
   (b) BASELINE configs[3] AS BENCHMARKED: DenseNet-121-FPN 640 x 640, batch 4, dropout 0.2 (densenet.py:44,67,77,143), the masks the
       kernels draw injected into the oracle at its 119 sites;
-  (c) the cfg-3 size (ResNeXt-50-FPN, 800 x 800, batch 2) on a CONDITIONED net -- trained by the product's own loop at that size -- where ReLU /
-      max-pool decisions that differ between two fp32 evaluations are rare: most tensors must hold 5e-4 against the fp32 oracle
-      DIRECTLY (the random-init variant in test_gpu_fullsize.py stays as the stress case).
+  (c) the cfg-3 size (ResNeXt-50-FPN, 800 x 800, batch 2) on a CONDITIONED net -- trained by the product's own loop at that size --
+      judged against the oracle in fp32 and fp64: measured, the trained net is MORE sensitive to ReLU / max-pool decisions than the
+      random-init one (the fp32 oracle is a median 1.2e-1 from its own fp64 evaluation), and the product is ~100 x closer to the
+      fp64 gradient than the fp32 oracle is (the random-init variant in test_gpu_fullsize.py stays as the stress case).
 Runs on the MI355X box; the oracle legs take tens of seconds each on its host cores."""
 import numpy as np
 import pytest
@@ -160,9 +161,10 @@ def test_cfg3_full_size_gradients_on_a_conditioned_net(dev):
     """(c): ResNeXt-50-FPN trained by the product's own loop AT the cfg-3 size -- DeviceFeed + one-graph step on the seeded shapes
     stream rendered at 800 x 800, batch [sample, hflip], BCE + dice + Huber (the reference's live loss, losses.py:124-152; focal
     collapses at this learning rate), momentum, lr 1e-2, 600 steps -- THEN one more 800 x 800 batch-2 step on a
-    held-out sample against the composed oracle (fp32 and fp64): losses 1e-4 against the fp32 oracle, or as close to the fp64 oracle
-    as the fp32 oracle is (x 3); >= 90 % of the 208 parameter tensors inside 5e-4 against the fp32 oracle directly; the rest by the
-    fp64 arbitration, at most 20 of them."""
+    held-out sample against the composed oracle evaluated in fp32 AND in fp64.  Asserted: losses within 1e-5 of the fp64 oracle's;
+    no gradient tensor further from the fp64 gradient than the fp32 oracle is, on geometric average >= 10 x closer; median / worst
+    distance to the fp64 gradient <= 6e-3 / 6e-2 (see the comment at the asserts for what was measured and why the 5e-4 bar against
+    the FP32 oracle cannot be the yardstick here)."""
     import dataset, layers, levels as levels_mod, retinanet, train
     from data_loaders.shapes import Shapes
     steps, hw, mode = 600, (800, 800), "bce_dice"
@@ -213,11 +215,24 @@ def test_cfg3_full_size_gradients_on_a_conditioned_net(dev):
     frac = 1.0 - len(loose) / len(errs)
     bad = [(n, e) for e, n in loose if err(grads_hip[n], g64[n]) > max(5e-4, 3.0 * err(g32[n], g64[n]))]
     worst64 = max(err(g32[n], g64[n]) for n in g32)
+    ratios = np.array([err(grads_hip[n], g64[n]) / max(err(g32[n], g64[n]), 1e-9) for n in g32])
+    geo = float(np.exp(np.log(np.maximum(ratios, 1e-9)).mean()))
+    e64 = sorted((err(grads_hip[n], g64[n]), n) for n in g64)
+    in64 = sum(1 for e, _ in e64 if e <= 5e-4)
+    med64, worst = e64[len(e64) // 2][0], e64[-1]
     print("cfg-3 size on a conditioned ResNeXt-50-FPN (600 steps at 800 x 800): class loss %.6f (oracle %.6f; distance to the fp32 / fp64 oracle "
-          "%s), regr loss %.6f (oracle %.6f; %s); %d of %d tensors (%.1f %%) inside 5e-4 against the fp32 oracle directly, %d by the fp64 "
-          "arbitration; largest: %s; fp32 vs fp64 oracle differ by up to %.1e"
-          % (cl, ocl, n1, rl, orl, n2, len(errs) - len(loose), len(errs), 100 * frac, len(loose),
-             ", ".join("%s %.1e" % (n, e) for e, n in errs[:3]), worst64))
+          "%s), regr loss %.6f (oracle %.6f; %s); against the fp32 oracle %d of %d tensors (%.1f %%) inside 5e-4 (fp32 vs fp64 ORACLE: median %.1e, "
+          "up to %.1e); against the fp64 oracle directly: %d inside 5e-4, median %.1e, 90th percentile %.1e, worst %.1e (%s); product / fp32-oracle "
+          "distance to the fp64 gradient: geometric mean %.3f, max %.2f"
+          % (cl, ocl, n1, rl, orl, n2, len(errs) - len(loose), len(errs), 100 * frac, float(np.median([err(g32[n], g64[n]) for n in g32])), worst64,
+             in64, med64, e64[int(0.9 * len(e64))][0], worst[0], worst[1], geo, float(ratios.max())))
+    # MEASURED (round 6, twice): the hypothesis behind this test -- "on a conditioned net two fp32 evaluations rarely take different ReLU /
+    # max-pool branches" -- is FALSE at this size: training sharpens the net, and the fp32 CPU oracle is then a median 1.2e-1 (up to
+    # 3.4e-1) away from its own fp64 evaluation, so "5e-4 against the fp32 oracle" holds for 4 of 208 tensors.  The product sits a
+    # median 2.1e-3 (90th percentile 4.7e-3, worst 2.1e-2) from the fp64 gradient -- 60 x closer than the fp32 oracle on median,
+    # 100 x on geometric average -- and its losses 5e-8 / 4e-7 from the fp64 losses (the fp32 oracle's: 9e-5 / 4e-4).  The bars
+    # below are those measurements x ~3; what they protect is "the product is far MORE accurate than an fp32 reference evaluation".
     assert not bad, bad
-    assert frac >= 0.90, "only %.1f %% of the tensors hold 5e-4 against the fp32 oracle" % (100 * frac)
-    assert len(loose) <= 20, "%d tensors needed the fp64 arbitration (cap 20)" % len(loose)
+    assert abs(cl - ocl64) <= 1e-5 * abs(ocl64) and abs(rl - orl64) <= 1e-5 * abs(orl64), (cl, ocl64, rl, orl64)
+    assert geo <= 0.1 and float(ratios.max()) <= 1.0, (geo, float(ratios.max()))
+    assert med64 <= 6e-3 and worst[0] <= 6e-2, (med64, worst)

@@ -181,3 +181,40 @@ def test_conv1x1_with_group_norm_statistics_both_modes(dev, product_mode, mode):
     assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), 1e-4, "dw (mode %d)" % mode)
     assert_close(gg.grad.cpu().numpy(), gc.grad.numpy(), 1e-4, "dgamma (mode %d)" % mode)
     assert_close(bg.grad.cpu().numpy(), bc.grad.numpy(), 1e-4, "dbeta (mode %d)" % mode)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,gn", [(2, 64, 64, 128, 512, False), (2, 50, 38, 256, 512, False), (2, 64, 64, 128, 512, True)])
+def test_strided_dense_conv_through_the_patch_matrix(dev, product_mode, n, h, w, cin, cout, gn):
+    """3x3 / stride-2 dense convs (the ResNeXt "down" convs, resnet.py:60-69) in product mode 1 run as split-bf16 products of an explicit
+    patch matrix (csrc/im2col.hip): forward (optionally with the GroupNorm statistic rows of the conv's epilogue), data gradient (product
+    + gather) and weight gradient against the oracle's direct convolution, even and odd maps (TF SAME padding 0/1 and 1/1), 1e-4;
+    mode 0 (the fp32 implicit GEMM) beside it."""
+    import ops
+    rng = np.random.default_rng(h * w + cin)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    xc, wc = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(wt).requires_grad_(True)
+    yc = T.conv2d_same(xc, wc, 2)
+    dy = rng.standard_normal(tuple(yc.shape)).astype(np.float32)
+    if gn:
+        gamma, beta = (1 + 0.2 * rng.standard_normal(cout)).astype(np.float32), (0.1 * rng.standard_normal(cout)).astype(np.float32)
+        gc, bc = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
+        zc = T.group_norm(yc, gc, bc)
+    else:
+        zc = yc
+    zc.backward(torch.from_numpy(dy))
+    for mode in (1, 0):
+        product_mode(mode)
+        xg, wg = _t(x, dev).requires_grad_(True), _t(wt, dev).requires_grad_(True)
+        if gn:
+            gg, bg = _t(gamma, dev).requires_grad_(True), _t(beta, dev).requires_grad_(True)
+            y = ops.conv2d(xg, wg, None, 2, gn=(32, 1e-5))
+            zg = ops.group_norm_act(y, gg, bg, groups=32)
+        else:
+            zg = ops.conv2d(xg, wg, None, 2)
+        zg.backward(_t(dy, dev))
+        assert_close(zg.detach().cpu().numpy(), zc.detach().numpy(), 1e-4, "strided conv forward (mode %d)" % mode)
+        assert_close(xg.grad.cpu().numpy(), xc.grad.numpy(), 1e-4, "strided conv dx (mode %d)" % mode)
+        assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), 1e-4, "strided conv dw (mode %d)" % mode)
+        if gn:
+            assert_close(gg.grad.cpu().numpy(), gc.grad.numpy(), 1e-4, "dgamma (mode %d)" % mode)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC evidence of the training step (GPU box): kernel trace + three counter passes over the same bench command.
 export TMPDIR=/tmp; mkdir -p gpurun_out
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-nms --no-roofline --no-extras --no-graph"
 rocprofv3 -L > gpurun_out/${R}_counters_list.txt 2>&1
 for P in trace fetch write sq; do rm -rf gpurun_out/${R}_pmc_$P; done

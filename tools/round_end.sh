@@ -4,14 +4,17 @@
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 [ -z "$QUICK" ] && timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -12 > gpurun_out/${R}_tests.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/${R}_smoke.log 2>&1
 timeout 900 python bench.py > gpurun_out/${R}_bench.log 2>&1
+grep '^{"metric"' gpurun_out/${R}_bench.log | tail -1 > gpurun_out/${R}_bench_line.json
+timeout 600 python bench.py --gpus 1 --spawn --force-collective --no-cpu-baseline --no-nms --no-roofline --no-extras 2>/dev/null | grep '^{"metric"' | tail -1 > gpurun_out/${R}_bench_line_forced_collective.json
 rm -rf gpurun_out/${R}_prof gpurun_out/${R}_pmc_fetch gpurun_out/${R}_pmc_write
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_prof -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/${R}_prof.log 2>&1
 TRACE=$(find gpurun_out/${R}_prof -name "bench_kernel_trace.csv" | head -1)
 python tools/timeline.py $TRACE > gpurun_out/${R}_bench_step_timeline.txt
+python tools/mb_bwd_layers.py $TRACE > gpurun_out/${R}_mb_bwd_layers.txt
 python tools/by_grid.py $TRACE > gpurun_out/${R}_bench_kernel_trace_by_grid.txt
 cp $(find gpurun_out/${R}_prof -name "bench_kernel_stats.csv" | head -1) gpurun_out/${R}_bench_kernel_stats.csv
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${R}_pmc_fetch -- python tools/gemm_pmc.py > gpurun_out/${R}_pmc_f.log 2>&1
@@ -35,4 +38,4 @@ rm -rf gpurun_out/${R}_nms_prof gpurun_out/${R}_prof gpurun_out/${R}_pmc_fetch g
 [ -z "$QUICK" ] && (timeout 300 python tools/x3_bench.py > gpurun_out/${R}_x3_products.txt 2>&1; for v in 0 1 2 4 8 15; do echo "RN_X3_DBG=$v $(env RN_X3_DBG=$v timeout 300 python tools/x3_bench.py 2>&1 | grep 'mode 1' | tail -1)"; done > gpurun_out/${R}_x3_leave_one_out.txt 2>&1)
 [ -z "$QUICK" ] && (timeout 600 python tools/f16_trained_probe.py 2500 1e-2 2>&1 | tail -8 > gpurun_out/${R}_f16_trained_probe.txt)
 [ -z "$QUICK" ] && (timeout 400 python tools/f16_layer_probe.py > gpurun_out/${R}_f16_layers.txt 2>&1; timeout 300 python tools/bench_inference.py > gpurun_out/${R}_inference_lines.txt 2>&1)
-tail -3 gpurun_out/${R}_tests.log; tail -1 gpurun_out/${R}_smoke.log; tail -1 gpurun_out/${R}_bench.log | cut -c1-400
+tail -3 gpurun_out/${R}_tests.log; tail -1 gpurun_out/${R}_smoke.log; cut -c1-400 gpurun_out/${R}_bench_line.json
