@@ -48,7 +48,7 @@ typedef struct rn_reduce_list rn_reduce_list;
 
 /* Version of this header's ABI: bumped whenever an entry point's arguments or a struct layout change.  rn_version() returns
  * the value the library was built with; a caller built against another value must not call anything else. */
-#define RN_API_VERSION 404
+#define RN_API_VERSION 405
 int rn_version(void);
 const char* rn_last_error(void);
 
@@ -118,6 +118,17 @@ size_t rn_conv2d_stats_rows(const rn_conv_seg* segs, int nseg, const rn_conv_geo
 /* rn_conv2d_fwd + the rows of y (one dense segment, no bias) */
 int rn_conv2d_fwd_stats(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, void* workspace, size_t workspace_bytes,
                         const rn_gn_rows* rows, rn_stream_t stream);
+
+/* Conv2D -> Dropout (-> the statistics of the GroupNorm behind it) as ONE launch: y = dropout(conv(x)), and `rows` (may be NULL) = the
+ * partial sums of the DROPPED y in the layout rn_conv2d_dropout_rows reports -- DenseNet's composite function runs
+ * 1x1 conv -> Dropout -> GroupNorm (densenet.py:61-67, 70-77, dropout: densenet.py:23): the conv's output is never stored un-dropped and
+ * the GroupNorm does not read it twice.  The mask is rn_dropout's (keep element i of y iff hash(seed + *seed_dev, i) >= rate, scaled by
+ * 1 / (1 - rate)): bit-identical to rn_conv2d_fwd followed by rn_dropout.  Dense 1x1 / stride-1 convs of one segment without bias, in
+ * product mode 1 (rn_set_product_mode): rn_conv2d_dropout_rows sets *fused_ok = 0 and the call returns RN_EUNSUPPORTED elsewhere -- the
+ * caller then runs rn_conv2d_fwd + rn_dropout.  rn_conv2d_dropout_rows returns the rows' bytes (0: no rows for this shape). */
+size_t rn_conv2d_dropout_rows(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int groups, rn_gn_rows* layout, int* fused_ok);
+int rn_conv2d_fwd_dropout(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float rate, uint64_t seed, const uint64_t* seed_dev,
+                          const rn_gn_rows* rows, rn_stream_t stream);
 
 /* dw[kh,kw,cin,cout] = sum over all segments (they share the kernel: shared heads);
  * split-K partial slabs go to `workspace`, reduced in fixed order (bitwise reproducible).

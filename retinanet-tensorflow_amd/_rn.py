@@ -19,7 +19,7 @@ LOSS_MODE = {"bce_dice": 0, "focal": 1}
 OPT = {"momentum": 0, "rmsprop": 1, "adam": 2}
 OPT_BLOCK = 1024
 LOSS_STATS_HEADER = 8
-API_VERSION = 404        # RN_API_VERSION of include/rn_hip.h these bindings were written against
+API_VERSION = 405        # RN_API_VERSION of include/rn_hip.h these bindings were written against
 
 
 class RnError(RuntimeError):
@@ -166,7 +166,7 @@ _lib = None
 SYMBOLS = [
     "rn_version", "rn_last_error", "rn_same_pad",
     "rn_conv2d_fwd_workspace", "rn_conv2d_dgrad_workspace",
-    "rn_zero", "rn_conv2d_fwd", "rn_conv2d_stats_rows", "rn_conv2d_fwd_stats", "rn_depthwise_stats_rows", "rn_depthwise_fwd_stats", "rn_group_norm_rows_ok",
+    "rn_zero", "rn_conv2d_fwd", "rn_conv2d_stats_rows", "rn_conv2d_fwd_stats", "rn_conv2d_dropout_rows", "rn_conv2d_fwd_dropout", "rn_depthwise_stats_rows", "rn_depthwise_fwd_stats", "rn_group_norm_rows_ok",
     "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad", "rn_conv2d_bwd",
     "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes",
@@ -207,7 +207,7 @@ def lib():
                      "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace", "rn_conv3x3_winograd_workspace", "rn_conv2d_fwd_workspace",
                      "rn_conv2d_dgrad_workspace",
                      "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_bwd_workspace", "rn_wino_gn_rows",
-                     "rn_winograd_bwd_products_workspace", "rn_conv2d_stats_rows", "rn_depthwise_stats_rows"):
+                     "rn_winograd_bwd_products_workspace", "rn_conv2d_stats_rows", "rn_depthwise_stats_rows", "rn_conv2d_dropout_rows"):
             getattr(L, name).restype = C.c_size_t
         L.rn_optimizer_workspace.argtypes = [C.c_int64]
         L.rn_dwgn_supported.argtypes = [C.c_void_p, C.c_int]
@@ -229,6 +229,8 @@ def lib():
         L.rn_debug_collective_standin.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]
         L.rn_conv2d_stats_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.rn_conv2d_fwd_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.rn_conv2d_dropout_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rn_conv2d_fwd_dropout.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rn_depthwise_stats_rows.argtypes = [C.c_int] * 7 + [C.c_void_p]
         L.rn_group_norm_rows_ok.argtypes = [C.c_int] * 4
         L.rn_depthwise_fwd_stats.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]

@@ -973,6 +973,42 @@ extern "C" int rn_conv2d_fwd_stats(const rn_conv_seg* segs, int nseg, const rn_c
   RN_CHECK_ARG(rows, "conv fwd stats: null rows");
   return conv_fwd_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream, Scratch{workspace, workspace_bytes, nullptr}, StatReq{rows, 0, nullptr, nullptr});
 }
+// conv -> Dropout (-> statistics of the dropped output) in one launch: dense 1x1 / stride-1 convs of one tensor on the split-bf16
+// kernels (product mode 1).  See include/rn_hip.h.
+namespace {
+int fused_dropout_rows(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int* ohw_out, long* m_out, int* x_ld, int* x_coff);
+}
+extern "C" size_t rn_conv2d_dropout_rows(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int groups, rn_gn_rows* layout, int* fused_ok) {
+  if (fused_ok) *fused_ok = 0;
+  int ohw, ld, coff; long m;
+  const int xrows = fused_dropout_rows(segs, nseg, g, &ohw, &m, &ld, &coff);
+  if (!xrows) return 0;
+  if (fused_ok) *fused_ok = 1;
+  const int cout = segs[0].cout;
+  const bool ok = ohw % xrows == 0 && groups >= 1 && cout % groups == 0 && (double)ohw * (cout / groups) < 16777216.0 &&
+                  rn_group_norm_rows_ok(cout, groups, ohw / xrows, 0);
+  if (!ok) return 0;
+  if (layout) { layout->rows_per_sample = ohw / xrows; layout->per_group = 0; layout->groups = groups; }
+  return (size_t)(m / xrows) * cout * 8;
+}
+extern "C" int rn_conv2d_fwd_dropout(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, float rate, uint64_t seed, const uint64_t* seed_dev,
+                                     const rn_gn_rows* rows, rn_stream_t stream) {
+  RN_CHECK_ARG(rate >= 0.f && rate < 1.f, "conv + dropout: rate %g outside [0, 1)", (double)rate);
+  int ohw, ld, coff; long m;
+  const int xrows = fused_dropout_rows(segs, nseg, g, &ohw, &m, &ld, &coff);
+  RN_UNSUPPORTED(!xrows, "conv + dropout: not a dense 1x1 / stride-1 conv the split-bf16 kernels take (rn_conv2d_dropout_rows: fused_ok == 0)");
+  RN_CHECK_ARG(segs[0].x && segs[0].wgt && segs[0].y, "conv + dropout: null pointer in segment 0");
+  float2* r = nullptr;
+  if (rows) {
+    rn_gn_rows want = {};
+    RN_UNSUPPORTED(!rn_conv2d_dropout_rows(segs, nseg, g, rows->groups, &want, nullptr) || want.rows_per_sample != rows->rows_per_sample ||
+                       rows->per_group != 0, "conv + dropout: this shape / layout cannot produce GroupNorm rows (rn_conv2d_dropout_rows)");
+    RN_CHECK_ARG(rows->rows, "conv + dropout: null rows");
+    r = (float2*)rows->rows;
+  }
+  return rn::launch_conv1x1_fwd_x3(segs[0].x + coff, ld, segs[0].wgt, segs[0].y, (int)m, g->cin, segs[0].cout, r, (hipStream_t)stream, rate, seed, seed_dev);
+}
+
 extern "C" int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, void* workspace, size_t workspace_bytes,
                                rn_stream_t stream) {
   return conv_dgrad_impl(segs, nseg, g, Batch{1, 0, 0, 0}, stream, Scratch{workspace, workspace_bytes, nullptr});
@@ -1006,6 +1042,16 @@ int x3_conv1x1(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const B
   if (!rows) return 0;
   const long tiles = rn::ceil_div64(m, rows) * rn::ceil_div(segs[0].cout, rows);
   return tiles >= 96 ? rows : 0;
+}
+
+// m-tile rows of the fused conv + dropout launch (0: the shape is not taken)
+int fused_dropout_rows(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int* ohw_out, long* m_out, int* x_ld, int* x_coff) {
+  if (validate_geom(segs, nseg, g)) return 0;
+  SegDev v = {};
+  set_x_view(v, segs[0], g->cin);
+  const long m = (long)segs[0].n * segs[0].h * segs[0].w;
+  *ohw_out = segs[0].h * segs[0].w; *m_out = m; *x_ld = v.x_ld; *x_coff = v.x_coff;
+  return x3_conv1x1(segs, nseg, g, Batch{1, 0, 0, 0}, m, v.x_ld, segs[0].bias != nullptr);
 }
 
 // Dense k x k convs that are not plain products (3x3 / stride 2 ...) through an explicit patch matrix on the split-bf16 kernels

@@ -42,6 +42,10 @@ struct X3Args {
   int K, chunk, nsplit, nbatch, tiles_m, tiles_n;
   float2* stat;       // dense 1x1 convs (rn::launch_conv1x1_fwd_x3): per (m-tile, column) sums (sum y, sum y^2) over the tile's rows -> stat[tile_m * ldc + col]
                       // (the GroupNorm statistic rows of conv_gemm.hip's conv_stats_epilogue, same layout); nullptr: off
+  // dense 1x1 convs followed by a Dropout (DenseNet's composite function, densenet.py:61-67): the mask of rn_dropout -- keep element i of the
+  // output tensor iff uniform01(seed + *seed_dev, i) >= rate, scaled by 1 / (1 - rate) -- applied to the accumulators before they are stored
+  // and summed: the conv's output never exists un-dropped, `stat` holds the sums of the DROPPED tensor.  rate == 0: off
+  float drop_rate, drop_keep; uint64_t drop_seed; const uint64_t* drop_seed_dev;
   int dbg;      // RN_X3_DBG (timing aid, wrong results): bit 0 no MFMAs, bit 1 no split / LDS stores, bit 2 no global loads after the first, bit 3 no fragment reads, bit 4 the dword epilogue
 };
 
@@ -229,6 +233,18 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
     }
   }
   float* pc = a.c + (size_t)split * a.c_sstride + (size_t)batch * a.c_bstride;
+  if (a.drop_rate > 0.f) {                                   // (block-uniform; only the 1x1-conv entry points set it)
+    const uint64_t sd = a.drop_seed + (a.drop_seed_dev ? *a.drop_seed_dev : 0ull);
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int j = 0; j < WT; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = m0 + (wm * WT + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h, col = n0 + (wn * WT + j) * 32 + r;
+          acc[i][j][q] = rn::uniform01(sd, (uint64_t)row * (uint64_t)a.ldc + (uint64_t)col) >= a.drop_rate ? acc[i][j][q] * a.drop_keep : 0.f;
+        }
+  }
   if (WT == 2 && !(dbg & 16)) {
     // 16-byte stores through LDS: the accumulator layout (lane = column, registers = rows) would go out as 64 dword stores per
     // lane in 128-byte pieces; staged per wave as [32 rows][64 columns] it leaves as 8 x 16-byte stores per lane and 32-row half,
@@ -389,8 +405,10 @@ int conv1x1_x3_tile(long M, int Cin, int Cout, int x_ld) {
   if (mode() != 1 || !conv1x1_on || M < 1 || M > 0x7fffffffL || !gemm_x3_ok((int)M, Cin, Cout) || !fits(M * (long)x_ld)) return 0;
   return tile_rows(M, Cout, 1);
 }
-int launch_conv1x1_fwd_x3(const float* x, int x_ld, const float* w, float* y, int M, int Cin, int Cout, float2* stat_rows, hipStream_t st) {
+int launch_conv1x1_fwd_x3(const float* x, int x_ld, const float* w, float* y, int M, int Cin, int Cout, float2* stat_rows, hipStream_t st,
+                          float drop_rate, uint64_t drop_seed, const uint64_t* drop_seed_dev) {
   X3Args a = {};
+  if (drop_rate > 0.f) { a.drop_rate = drop_rate; a.drop_keep = 1.f / (1.f - drop_rate); a.drop_seed = drop_seed; a.drop_seed_dev = drop_seed_dev; }
   a.a = {x, 0, x_ld, M};
   a.b = {w, 0, Cout, Cout};                 // W [Cin][Cout]: k-strided
   a.c = y; a.c_bstride = 0; a.c_sstride = 0; a.ldc = Cout;

@@ -58,7 +58,8 @@ int launch_batched_gemm_x3(const float* A, const float* B, float* C, int M, int 
 size_t batched_gemm_tn_workspace_x3(int M, int K, int N, int nbatch);
 // dense 1x1 / stride-1 convolutions on the same kernels (0: not taken -- product mode 0, RN_X3_CONV1X1=0, or the shape; else the m-tile rows)
 int conv1x1_x3_tile(long M, int Cin, int Cout, int x_ld);
-int launch_conv1x1_fwd_x3(const float* x, int x_ld, const float* w, float* y, int M, int Cin, int Cout, float2* stat_rows, hipStream_t st);
+int launch_conv1x1_fwd_x3(const float* x, int x_ld, const float* w, float* y, int M, int Cin, int Cout, float2* stat_rows, hipStream_t st,
+                          float drop_rate = 0.f, uint64_t drop_seed = 0, const uint64_t* drop_seed_dev = nullptr);
 int launch_conv1x1_dgrad_x3(const float* dy, const float* w, float* dx, int dx_ld, int M, int Cin, int Cout, hipStream_t st);
 size_t conv1x1_wgrad_workspace_x3(int M, int Cin, int Cout);
 int launch_conv1x1_wgrad_x3(const float* x, int x_ld, const float* dy, int M, int Cin, int Cout, void* workspace, size_t workspace_bytes,

@@ -1212,12 +1212,15 @@ def dropout(x, rate, seed=0, seed_dev=None):
 
 # ---------------------------------------------------------------------------------------- concat-free DenseNet block
 def _gn_raw(fwd, x, x_ld, c, n, hw, gamma, beta, groups, eps, act, mean, rstd, y=None, dy=None, dx=None, dx_ld=0, dx_acc=False,
-            dgamma=None, dbeta=None):
-    """One rn_group_norm_fwd / _bwd call on raw buffers (x may be the first c channels of a buffer with x_ld channels)."""
+            dgamma=None, dbeta=None, stat_rows=None):
+    """One rn_group_norm_fwd / _bwd call on raw buffers (x may be the first c channels of a buffer with x_ld channels).
+    stat_rows (forward, dense x): the _rn.GnRows its producer wrote (rn_conv2d_fwd_stats / rn_conv2d_fwd_dropout)."""
     L = _rn.lib()
     dev = gamma.device
     g = gn_groups(c, groups)
     params = _gn_params(c, g, eps, act, 0.0, 0, None, False, dev)
+    if stat_rows is not None and fwd:
+        params.stat_rows = C.addressof(stat_rows)
     segs = (_rn.GnSeg * 1)()
     sg = segs[0]
     sg.x, sg.mean, sg.rstd, sg.n, sg.hw, sg.x_ld = x.data_ptr(), _rn.f32(mean), _rn.f32(rstd), n, hw, x_ld
@@ -1253,6 +1256,9 @@ def _conv_bwd_raw(x, w, dy, stride=1):
     return dx, dw
 
 
+DENSE_FUSED_DROPOUT = os.environ.get("RN_DENSE_FUSED_DROPOUT", "1") == "1"     # (A/B aid: 0 = conv, rn_dropout and a statistics pass as three launches)
+
+
 class _DenseBlock(torch.autograd.Function):
     """A DenseNet-BC block (densenet.py:83-121) without the growth concat: ONE [n,h,w,c_total] buffer; layer i
     (GN-act-1x1(4k)-drop-GN-act-3x3(k)-drop, densenet.py:50-80) normalises the first c_i channels in place (rn_gn_seg.x_ld) and
@@ -1280,14 +1286,32 @@ class _DenseBlock(torch.autograd.Function):
             m1, r1 = torch.empty((n, gr1), device=dev), torch.empty((n, gr1), device=dev)
             _gn_raw(True, buf, ct, ci, n, hw, g1, b1, groups, eps, act, m1, r1, y=a)
             y1 = torch.empty((n, h, w, c4), dtype=torch.float32, device=dev)
-            _conv_fwd(_conv_segs([a], w1, None, [y1], None, None), 1, _rn.ConvGeom(1, 1, 1, ci, 1), dev)
-            d1 = y1
-            if rate > 0.0:
-                d1 = torch.empty_like(y1)
-                _rn.check(L.rn_dropout(_rn.f32(y1), _rn.f32(d1), y1.numel(), rate, seeds[i][0], sd, _rn.stream()), "rn_dropout")
+            segs1, geom1 = _conv_segs([a], w1, None, [y1], None, None), _rn.ConvGeom(1, 1, 1, ci, 1)
+            d1, lay2, rows2 = None, None, None
+            if rate > 0.0 and DENSE_FUSED_DROPOUT:
+                # conv -> Dropout -> the statistics of GroupNorm 2 in ONE launch (rn_conv2d_fwd_dropout): y1 is never stored un-dropped, the
+                # dropout pass (read + write of the 4k-channel tensor) and the GroupNorm's statistics pass (another read) are gone
+                ok, lay = C.c_int(0), _rn.GnRows(None, 0, 0, gr2)
+                nbytes = L.rn_conv2d_dropout_rows(segs1, 1, C.byref(geom1), gr2, C.byref(lay), C.byref(ok))
+                if ok.value:
+                    if nbytes:
+                        rows2 = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+                        lay.rows, lay2 = rows2.data_ptr(), lay
+                    _rn.check(L.rn_conv2d_fwd_dropout(segs1, 1, C.byref(geom1), rate, seeds[i][0], sd, C.byref(lay) if nbytes else None,
+                                                      _rn.stream()), "rn_conv2d_fwd_dropout")
+                    d1 = y1
+            if d1 is None:
+                got = _conv_fwd(segs1, 1, geom1, dev, gn=(groups, eps) if rate <= 0.0 else None)
+                d1 = y1
+                if got is not None:                   # (no dropout: the conv's own epilogue wrote the rows of y1)
+                    rows2 = got[0]
+                    lay2 = _rn.GnRows(rows2.data_ptr(), got[1], got[2], got[3])
+                if rate > 0.0:
+                    d1 = torch.empty_like(y1)
+                    _rn.check(L.rn_dropout(_rn.f32(y1), _rn.f32(d1), y1.numel(), rate, seeds[i][0], sd, _rn.stream()), "rn_dropout")
             a2 = torch.empty_like(d1)
             m2, r2 = torch.empty((n, gr2), device=dev), torch.empty((n, gr2), device=dev)
-            _gn_raw(True, d1, 0, c4, n, hw, g2, b2, groups, eps, act, m2, r2, y=a2)
+            _gn_raw(True, d1, 0, c4, n, hw, g2, b2, groups, eps, act, m2, r2, y=a2, stat_rows=lay2)
             y2 = torch.empty((n, h, w, k), dtype=torch.float32, device=dev)
             _conv_fwd(_conv_segs([a2], w2, None, [y2], None, None), 1, _rn.ConvGeom(3, 3, 1, c4, 1), dev)
             _rn.check(L.rn_dropout_strided(_rn.f32(y2), _rn.f32(buf), px, k, k, 0, ct, ci, rate, seeds[i][1], sd, _rn.stream()),

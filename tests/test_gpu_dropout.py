@@ -271,3 +271,44 @@ def test_densenet_with_dropout_matches_oracle(dev):
     bad = [e for e in errs if e[0] > 5e-4]
     assert not bad, "%d of %d gradients off: %s" % (len(bad), len(errs), ", ".join("%s %.2e" % (n, e) for e, n in bad[:12]))
     print("DenseNet-121-FPN dropout 0.2 vs oracle with injected masks: worst gradient error %.2e (%s)" % errs[0])
+
+
+@pytest.mark.parametrize("n,hw,cin,cout", [(2, 64, 96, 128), (4, 40, 544, 128), (1, 96, 64, 128)])
+def test_conv_dropout_statistics_in_one_launch_equals_the_three(dev, n, hw, cin, cout):
+    """rn_conv2d_fwd_dropout (round 6: DenseNet's 1x1 conv -> Dropout -> GroupNorm statistics as ONE launch of the split-bf16 kernel,
+    densenet.py:61-67) against the three launches it replaces: the dropped output bit-identical to rn_conv2d_fwd followed by rn_dropout
+    (the same mask AND the same conv values), and its statistic rows equal to the per-tile sums of that tensor; then the
+    restated mask (oracle/dropout_ref.py) on top of the oracle's conv, 1e-4."""
+    import _rn, ops
+    L = _rn.lib()
+    rng = np.random.default_rng(cin + hw)
+    rate, seed, counter = 0.2, 0x1234567, 3 * ops.DROPOUT_COUNTER_STEP
+    x = torch.from_numpy(rng.standard_normal((n, hw, hw, cin)).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rng.standard_normal((1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)).to(dev)
+    sd = torch.tensor([counter], dtype=torch.int64, device=dev)
+    geom = _rn.ConvGeom(1, 1, 1, cin, 1)
+    y = torch.empty((n, hw, hw, cout), dtype=torch.float32, device=dev)
+    segs = ops._conv_segs([x], w, None, [y], None, None)
+    ops._conv_fwd(segs, 1, geom, dev)
+    want = torch.empty_like(y)
+    _rn.check(L.rn_dropout(_rn.f32(y), _rn.f32(want), y.numel(), rate, seed, sd.data_ptr(), _rn.stream()), "rn_dropout")
+    ok, lay = C.c_int(0), _rn.GnRows(None, 0, 0, 32)
+    nbytes = L.rn_conv2d_dropout_rows(segs, 1, C.byref(geom), 32, C.byref(lay), C.byref(ok))
+    assert ok.value == 1 and nbytes > 0
+    rows = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device=dev)
+    lay.rows = rows.data_ptr()
+    got = torch.full_like(y, float("nan"))
+    segs2 = ops._conv_segs([x], w, None, [got], None, None)
+    _rn.check(L.rn_conv2d_fwd_dropout(segs2, 1, C.byref(geom), rate, seed, sd.data_ptr(), C.byref(lay), _rn.stream()), "rn_conv2d_fwd_dropout")
+    assert torch.equal(got, want)
+    kept = float((got != 0).float().mean())
+    assert abs(kept - (1 - rate)) < 0.01, kept
+    # the rows: (sum, sum of squares) per (tile of rows_per_sample-th of a sample's pixels, channel)
+    rps = lay.rows_per_sample
+    t = want.reshape(n, rps, (hw * hw) // rps, cout).double()
+    ref = torch.stack([t.sum(2), (t * t).sum(2)], -1).reshape(-1, cout, 2)
+    assert_close(rows.reshape(-1, cout, 2).cpu().numpy(), ref.cpu().numpy(), 1e-5, "statistic rows of the dropped output")
+    # ... and against the oracle: conv, then the restated mask
+    yc = T.conv2d_same(x.cpu(), w.cpu(), 1)
+    mask = dropout_ref.keep_mask(seed + counter, tuple(yc.shape), rate)
+    assert_close(got.cpu().numpy(), (yc * torch.from_numpy(mask.astype(np.float32)) / (1 - rate)).numpy(), 1e-4, "dropped conv output vs oracle")
