@@ -942,9 +942,13 @@ def main():
             del step
             torch.cuda.empty_cache()
             if not args.no_graph and not started:
-                cp = collective_path_n1(args, device, ips)
-                result["config"]["allreduce"]["n1_collective_path"] = cp
-                result["config"]["allreduce"]["n1_collective_path_images_per_sec"] = cp["images_per_sec"]
+                try:
+                    cp = collective_path_n1(args, device, ips)
+                    result["config"]["allreduce"]["n1_collective_path"] = cp
+                    result["config"]["allreduce"]["n1_collective_path_images_per_sec"] = cp["images_per_sec"]
+                except Exception as e:      # noqa: BLE001 -- an extra must not take the headline line down (no RCCL group on this box ...)
+                    result["config"]["allreduce"]["n1_collective_path"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    result["config"]["allreduce"]["n1_collective_path_images_per_sec"] = None
             result["config"]["fresh_data"] = fresh_data(device, ips)
             result["config"]["cfg1_gpu"] = cfg1_gpu(device)
             torch.cuda.empty_cache()

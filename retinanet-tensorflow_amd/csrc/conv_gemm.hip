@@ -1037,7 +1037,7 @@ namespace {
 // fp32 split-K path).  Returns the m-tile rows (64 / 128) or 0.
 int x3_conv1x1(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const Batch& bt, long m, int x_ld, bool with_bias) {
   if (nseg != 1 || bt.n != 1 || ngroups(g) != 1 || g->kh != 1 || g->kw != 1 || g->stride != 1 || with_bias) return 0;
-  if (g->cin % 4 || segs[0].cout % 4) return 0;
+  if (g->cin % 4 || segs[0].cout % 4 || x_ld % 4 || (segs[0].x_ld > 0 && segs[0].x_coff % 4)) return 0;     // 16-byte operand pieces and stores
   const int rows = rn::conv1x1_x3_tile(m, g->cin, segs[0].cout, x_ld);
   if (!rows) return 0;
   const long tiles = rn::ceil_div64(m, rows) * rn::ceil_div(segs[0].cout, rows);

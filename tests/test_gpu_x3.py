@@ -218,3 +218,40 @@ def test_strided_dense_conv_through_the_patch_matrix(dev, product_mode, n, h, w,
         assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), 1e-4, "strided conv dw (mode %d)" % mode)
         if gn:
             assert_close(gg.grad.cpu().numpy(), gc.grad.numpy(), 1e-4, "dgamma (mode %d)" % mode)
+
+
+def test_conv1x1_split_bf16_on_a_channel_slice(dev, product_mode):
+    """The 1x1 entry points on a channel SLICE of a wider buffer (rn_conv_seg.x_ld / x_coff: the concat-free DenseNet block reads and
+    writes slices of one [n, h, w, c_total] buffer, densenet.py:117-121): forward reads channels [coff, coff + cin) of x, the data
+    gradient writes them into dx and leaves the other channels alone, the weight gradient reads them -- product mode 1 vs fp64."""
+    import _rn, ops
+    L = _rn.lib()
+    product_mode(1)
+    rng = np.random.default_rng(5)
+    n, hw, ld, coff, cin, cout = 2, 64, 160, 32, 96, 128
+    xb = rng.standard_normal((n, hw, hw, ld)).astype(np.float32)
+    w = (rng.standard_normal((1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    dy = rng.standard_normal((n, hw, hw, cout)).astype(np.float32)
+    X = xb[..., coff:coff + cin].reshape(-1, cin).astype(np.float64)
+    W2, DY = w.reshape(cin, cout).astype(np.float64), dy.reshape(-1, cout).astype(np.float64)
+    xd, wd, dyd = _t(xb, dev), _t(w, dev), _t(dy, dev)
+    geom = _rn.ConvGeom(1, 1, 1, cin, 1)
+    y = torch.full((n, hw, hw, cout), float("nan"), device=dev)
+    segs = ops._conv_segs([xd], wd, None, [y], None, None, x_ld=ld, x_coff=coff)
+    assert L.rn_conv2d_fwd_workspace(segs, 1, C.byref(geom)) == 0
+    _rn.check(L.rn_conv2d_fwd(segs, 1, C.byref(geom), None, 0, _rn.stream()), "rn_conv2d_fwd")
+    mag = np.abs(X) @ np.abs(W2)
+    assert float((np.abs(y.cpu().numpy().reshape(-1, cout) - X @ W2) / mag).max()) <= 3e-7
+    dxb = torch.full((n, hw, hw, ld), 7.0, device=dev)
+    segs = ops._conv_segs([xd], wd, None, None, [dyd], [dxb], x_ld=ld, x_coff=coff)
+    _rn.check(L.rn_conv2d_dgrad(segs, 1, C.byref(geom), None, 0, _rn.stream()), "rn_conv2d_dgrad")
+    got = dxb.cpu().numpy()
+    assert np.all(got[..., :coff] == 7.0) and np.all(got[..., coff + cin:] == 7.0)            # the other channels are untouched
+    magd = np.abs(DY) @ np.abs(W2).T
+    assert float((np.abs(got[..., coff:coff + cin].reshape(-1, cin) - DY @ W2.T) / magd).max()) <= 3e-7
+    need = L.rn_conv2d_wgrad_workspace(segs, 1, C.byref(geom))
+    ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dev)
+    dw = torch.full((1, 1, cin, cout), float("nan"), device=dev)
+    _rn.check(L.rn_conv2d_wgrad(segs, 1, C.byref(geom), _rn.f32(dw), 0, ws.data_ptr(), ws.numel(), _rn.stream(), None), "rn_conv2d_wgrad")
+    magw = np.abs(X).T @ np.abs(DY)
+    assert float((np.abs(dw.cpu().numpy().reshape(cin, cout) - X.T @ DY) / magw).max()) <= 3e-7
