@@ -53,7 +53,7 @@ TRAIN_GFLOP_PER_IMAGE = 239.2       # BASELINE.md section 3 (3 x forward conv FL
 # whole number of tiles).  EXECUTED = (39.87 - 38.268) + 38.268 / 4 = 11.169 GMAC forward -> x 2 FLOP x 3 passes:
 EXECUTED_TRAIN_GFLOP_PER_IMAGE = 67.0
 # name prefix and grid of the forward product launch of a head-tower layer in a rocprofv3 trace (the `roofline` kernel)
-X3_FWD_KERNEL = "gemm_x3_kernel<false, true, 2, 2>"
+X3_FWD_KERNEL = "gemm_x3_kernel<false, true, 2, 2, false>"
 X3_FWD_GRID = lambda tiles: 36 * (-(-tiles // 128)) * 2       # noqa: E731
 PRODUCT_REPS = 8                    # back-to-back launches per graph when the product kernels are timed alone (_graph_time)
 FP16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
