@@ -112,22 +112,12 @@ int rn_conv2d_dgrad(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, vo
 typedef struct rn_gn_rows {
   void* rows;
   int32_t rows_per_sample, per_group, groups;
-  int32_t ld; /* pairs between consecutive rows; 0 = width.  > width: the GroupNorm reads a channel PREFIX of rows kept for a wider
-                 buffer (rn_channel_rows below) */
 } rn_gn_rows;
 size_t rn_conv2d_stats_rows(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, size_t workspace_bytes, int groups,
                             rn_gn_rows* layout);
 /* rn_conv2d_fwd + the rows of y (one dense segment, no bias) */
 int rn_conv2d_fwd_stats(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, void* workspace, size_t workspace_bytes,
                         const rn_gn_rows* rows, rn_stream_t stream);
-
-/* Per-channel partial sums of a channel SLICE of a wider buffer: rows [n][rows_per_sample][rows->ld] (sum, sum of squares) pairs, written
- * for the channels [coff, coff + c) of x [n][hw][x_ld]; row r of a sample covers its r-th run of ceil(hw / rows_per_sample) pixels.
- * The concat-free DenseNet block (densenet.py:83-121) keeps ONE such rows tensor for its [n, hw, c_total] buffer: the sums of the
- * channels already in the buffer never change, so every layer adds the rows of the k channels it appended and its first GroupNorm
- * (over the prefix [0, c_i), densenet.py:55-58) merges a prefix of the rows (rn_gn_rows.ld = c_total) instead of re-reading the
- * prefix: O(depth) statistics traffic instead of O(depth^2).  c, coff, x_ld multiples of 4; c <= 1024. */
-int rn_channel_rows(const float* x, int n, int hw, int x_ld, int coff, int c, const rn_gn_rows* rows, rn_stream_t stream);
 
 /* Conv2D -> Dropout (-> the statistics of the GroupNorm behind it) as ONE launch: y = dropout(conv(x)), and `rows` (may be NULL) = the
  * partial sums of the DROPPED y in the layout rn_conv2d_dropout_rows reports -- DenseNet's composite function runs

@@ -96,7 +96,7 @@ class GnParams(C.Structure):
 
 class GnRows(C.Structure):
     """rn_gn_rows: partial (sum, sum of squares) rows a conv / depthwise forward wrote for the GroupNorm that follows"""
-    _fields_ = [("rows", C.c_void_p), ("rows_per_sample", C.c_int32), ("per_group", C.c_int32), ("groups", C.c_int32), ("ld", C.c_int32)]
+    _fields_ = [("rows", C.c_void_p), ("rows_per_sample", C.c_int32), ("per_group", C.c_int32), ("groups", C.c_int32)]
 
 
 class GnResidualNorm(C.Structure):
@@ -166,7 +166,7 @@ _lib = None
 SYMBOLS = [
     "rn_version", "rn_last_error", "rn_same_pad",
     "rn_conv2d_fwd_workspace", "rn_conv2d_dgrad_workspace",
-    "rn_zero", "rn_conv2d_fwd", "rn_conv2d_stats_rows", "rn_conv2d_fwd_stats", "rn_conv2d_dropout_rows", "rn_conv2d_fwd_dropout", "rn_channel_rows", "rn_depthwise_stats_rows", "rn_depthwise_fwd_stats", "rn_group_norm_rows_ok",
+    "rn_zero", "rn_conv2d_fwd", "rn_conv2d_stats_rows", "rn_conv2d_fwd_stats", "rn_conv2d_dropout_rows", "rn_conv2d_fwd_dropout", "rn_depthwise_stats_rows", "rn_depthwise_fwd_stats", "rn_group_norm_rows_ok",
     "rn_conv2d_dgrad", "rn_conv2d_wgrad_workspace", "rn_conv2d_wgrad", "rn_conv2d_bwd",
     "rn_conv2d_bias_grad_workspace", "rn_conv2d_bias_grad", "rn_conv3x3_winograd_workspace", "rn_conv3x3_winograd",
     "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_wgrad", "rn_conv3x3_winograd_keep_bytes",
@@ -231,7 +231,6 @@ def lib():
         L.rn_conv2d_fwd_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_conv2d_dropout_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.rn_conv2d_fwd_dropout.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.rn_channel_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.rn_depthwise_stats_rows.argtypes = [C.c_int] * 7 + [C.c_void_p]
         L.rn_group_norm_rows_ok.argtypes = [C.c_int] * 4
         L.rn_depthwise_fwd_stats.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]

@@ -46,7 +46,6 @@ struct GnArgs {
   float* pgrad;    // slice-resident bwd: [2][total_samples][c] per-sample sum g (plane 0) and sum g*xhat (plane 1)
   // rows path: [chunk][per_group ? groups : c] pairs (the producer's, rn_gn_params.stat_rows, or rows_out below); slab width
   const float2* rows; int rows_per_group, rows_sw;   // (rows of a sample: seg.chunks, first row: seg.chunk_start)
-  int rows_ld;                                       // pairs between consecutive rows (0: the row width)
   float2* rows_out;                                  // gn_rows_partial_kernel: [total_chunks][groups]
   int nt_loads;    // fp16 apply: x and the residual are read for the last time here -- non-temporal loads (large inference batches)
   // fp16 apply: the residual is itself a RAW conv output whose (activation-free) GroupNorm is applied here (ResNeXt's projection branch)
@@ -421,14 +420,13 @@ __device__ __forceinline__ void rows_merge(const GnArgs& a, const GnSeg& sg, int
   const int e0 = per_group ? c0 / cpg : c0;
   const int RL = AT / gw;                             // row lanes
   const int el = tid % gw, rl = tid / gw;
-  const int WL = a.rows_ld ? a.rows_ld : W;           // (a channel prefix of rows kept for a wider buffer: rn_channel_rows)
-  const float2* __restrict__ rp = a.rows + (size_t)(sg.chunk_start + nl * sg.chunks) * WL + e0 + el;
+  const float2* __restrict__ rp = a.rows + (size_t)(sg.chunk_start + nl * sg.chunks) * W + e0 + el;
   double S = 0.0, Q = 0.0;
   if (rl < RL) {
     for (int r0 = rl; r0 < sg.chunks; r0 += 8 * RL) {
       float2 w[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = rp[(size_t)min(r0 + j * RL, sg.chunks - 1) * WL];
+      for (int j = 0; j < 8; ++j) w[j] = rp[(size_t)min(r0 + j * RL, sg.chunks - 1) * W];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         if (r0 + j * RL < sg.chunks) { S += (double)w[j].x; Q += (double)w[j].y; }
@@ -1554,52 +1552,6 @@ int rows_slab(int c, int cpg) {
 }
 }  // namespace
 
-// ---- per-channel (sum, sum of squares) rows of a channel slice (rn_channel_rows): grid (rows per sample, samples); a thread owns 4
-// channels of every (256 / (c / 4))-th pixel of the block's run, fp32 per thread, the pixel lanes summed in fp64 in a fixed order
-namespace {
-struct ChanRowsArgs { const float* x; float2* rows; int hw, x_ld, coff, c, R, ld; };
-__global__ __launch_bounds__(256) void gn_channel_rows_kernel(const ChanRowsArgs a) {
-  __shared__ double red[256][8];
-  const int r = blockIdx.x, nl = blockIdx.y, tid = threadIdx.x;
-  const int cq = a.c >> 2, lanes = 256 / cq;
-  const int q4 = tid % cq, pl = tid / cq;
-  const int per = (a.hw + a.R - 1) / a.R, p_lo = r * per, p_hi = min(p_lo + per, a.hw);
-  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-  if (pl < lanes) {
-    const float* __restrict__ x = a.x + (size_t)nl * a.hw * a.x_ld + a.coff + q4 * 4;
-    for (int p = p_lo + pl; p < p_hi; p += lanes) {
-      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * a.x_ld);
-      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-      q[0] = fmaf(v.x, v.x, q[0]); q[1] = fmaf(v.y, v.y, q[1]); q[2] = fmaf(v.z, v.z, q[2]); q[3] = fmaf(v.w, v.w, q[3]);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { red[tid][j] = (double)s[j]; red[tid][4 + j] = (double)q[j]; }
-  __syncthreads();
-  if (tid < a.c) {
-    const int qq = tid >> 2, j = tid & 3;
-    double S = 0.0, Q = 0.0;
-    for (int l = 0; l < lanes; ++l) { S += red[l * cq + qq][j]; Q += red[l * cq + qq][4 + j]; }
-    a.rows[((size_t)nl * a.R + r) * a.ld + a.coff + tid] = make_float2((float)S, (float)Q);
-  }
-}
-}  // namespace
-extern "C" int rn_channel_rows(const float* x, int n, int hw, int x_ld, int coff, int c, const rn_gn_rows* rows, rn_stream_t stream) {
-  RN_CHECK_ARG(x && rows && rows->rows && n >= 1 && hw >= 1, "channel rows: bad argument");
-  RN_CHECK_ARG(c >= 4 && c % 4 == 0 && coff >= 0 && coff % 4 == 0 && x_ld % 4 == 0 && coff + c <= x_ld, "channel rows: channels [%d, %d) of %d",
-               coff, coff + c, x_ld);
-  RN_UNSUPPORTED(c > 1024, "channel rows: %d channels per call (<= 1024)", c);
-  RN_CHECK_ARG(rows->rows_per_sample >= 1 && rows->per_group == 0 && rows->ld >= coff + c, "channel rows: rows layout (per channel, ld >= coff + c)");
-  // (c > 256: 256-channel pieces, so that a block's 256 threads cover a piece's channels in its final sum)
-  for (int c0 = 0; c0 < c; c0 += 256) {
-    const int cc = c - c0 < 256 ? c - c0 : 256;
-    ChanRowsArgs a = {x, (float2*)rows->rows, hw, x_ld, coff + c0, cc, rows->rows_per_sample, rows->ld};
-    hipLaunchKernelGGL(gn_channel_rows_kernel, dim3((unsigned)rows->rows_per_sample, (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
-  }
-  RN_LAUNCH_CHECK();
-  return RN_OK;
-}
-
 extern "C" int rn_group_norm_rows_ok(int c, int groups, int rows_per_sample, int per_group) {
   if (c < 4 || c % 4 || groups < 1 || c % groups || rows_per_sample < 1) return 0;
   const int cpg = c / groups, sw = rows_slab(c, cpg);
@@ -1681,13 +1633,10 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
   }
   a.gamma = gamma; a.beta = beta; a.partial = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  // (a channel-prefix view of x is fine here: the apply kernel reads x with its pixel stride; only a strided / accumulating dx is not --
-  // that is the backward pass)
-  if (p->stat_rows && p->stat_rows->rows && a.nseg == 1 && !a.in_half && !a.out_half && a.act != RN_ACT_SIGMOID &&
-      p->stat_rows->groups == a.groups && rn_group_norm_rows_ok(a.c, a.groups, p->stat_rows->rows_per_sample, p->stat_rows->per_group) &&
-      (p->stat_rows->ld == 0 || (!p->stat_rows->per_group && p->stat_rows->ld >= a.c))) {
+  if (p->stat_rows && p->stat_rows->rows && a.nseg == 1 && !a.in_half && !a.out_half && !a.strided && a.act != RN_ACT_SIGMOID &&
+      p->stat_rows->groups == a.groups && rn_group_norm_rows_ok(a.c, a.groups, p->stat_rows->rows_per_sample, p->stat_rows->per_group)) {
     // x came with partial-sum rows from its producer: merge them and apply in one pass
-    a.rows = (const float2*)p->stat_rows->rows; a.rows_per_group = p->stat_rows->per_group; a.rows_ld = p->stat_rows->ld;
+    a.rows = (const float2*)p->stat_rows->rows; a.rows_per_group = p->stat_rows->per_group;
     a.seg[0].chunks = p->stat_rows->rows_per_sample; a.seg[0].chunk_start = 0;
     a.rows_sw = rows_slab(a.c, a.cpg);
     launch_apply_rows<false>(a, st);

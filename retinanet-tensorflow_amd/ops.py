@@ -1256,7 +1256,6 @@ def _conv_bwd_raw(x, w, dy, stride=1):
     return dx, dw
 
 
-DENSE_CACHED_ROWS = os.environ.get("RN_DENSE_CACHED_ROWS", "1") == "1"        # (A/B aid: 0 = every layer's first GroupNorm re-reads its prefix)
 DENSE_FUSED_DROPOUT = os.environ.get("RN_DENSE_FUSED_DROPOUT", "1") == "1"     # (A/B aid: 0 = conv, rn_dropout and a statistics pass as three launches)
 
 
@@ -1278,15 +1277,6 @@ class _DenseBlock(torch.autograd.Function):
         sd = seed_dev.data_ptr() if seed_dev is not None else None
         buf = torch.empty((n, h, w, ct), dtype=torch.float32, device=dev)
         _rn.check(L.rn_dropout_strided(_rn.f32(x), _rn.f32(buf), px, c_in, c_in, 0, ct, 0, 0.0, 0, None, _rn.stream()), "rn_dropout_strided")
-        # per-channel (sum, sum of squares) rows of the buffer, kept for the whole block: a channel's sums never change once it is in the
-        # buffer, so every layer adds the rows of the k channels it appended (rn_channel_rows) and its first GroupNorm merges a PREFIX of
-        # them instead of re-reading the prefix [0, c_i) of the buffer -- O(depth) instead of O(depth^2) statistics traffic
-        crows = None
-        if DENSE_CACHED_ROWS and c_in % 4 == 0 and k % 4 == 0:
-            R = max(1, min(16, hw // 512))
-            cache = torch.empty((n, R, ct, 2), dtype=torch.float32, device=dev)
-            crows = _rn.GnRows(cache.data_ptr(), R, 0, 0, ct)
-            _rn.check(L.rn_channel_rows(_rn.f32(buf), n, hw, ct, 0, c_in, C.byref(crows), _rn.stream()), "rn_channel_rows")
         saved = []
         for i in range(depth):
             g1, b1, w1, g2, b2, w2 = params[6 * i:6 * i + 6]
@@ -1294,10 +1284,7 @@ class _DenseBlock(torch.autograd.Function):
             gr1, gr2 = gn_groups(ci, groups), gn_groups(c4, groups)
             a = torch.empty((n, h, w, ci), dtype=torch.float32, device=dev)
             m1, r1 = torch.empty((n, gr1), device=dev), torch.empty((n, gr1), device=dev)
-            lay1 = None
-            if crows is not None and L.rn_group_norm_rows_ok(ci, gr1, crows.rows_per_sample, 0):
-                lay1 = _rn.GnRows(crows.rows, crows.rows_per_sample, 0, gr1, ct)
-            _gn_raw(True, buf, ct, ci, n, hw, g1, b1, groups, eps, act, m1, r1, y=a, stat_rows=lay1)
+            _gn_raw(True, buf, ct, ci, n, hw, g1, b1, groups, eps, act, m1, r1, y=a)
             y1 = torch.empty((n, h, w, c4), dtype=torch.float32, device=dev)
             segs1, geom1 = _conv_segs([a], w1, None, [y1], None, None), _rn.ConvGeom(1, 1, 1, ci, 1)
             d1, lay2, rows2 = None, None, None
@@ -1329,8 +1316,6 @@ class _DenseBlock(torch.autograd.Function):
             _conv_fwd(_conv_segs([a2], w2, None, [y2], None, None), 1, _rn.ConvGeom(3, 3, 1, c4, 1), dev)
             _rn.check(L.rn_dropout_strided(_rn.f32(y2), _rn.f32(buf), px, k, k, 0, ct, ci, rate, seeds[i][1], sd, _rn.stream()),
                       "rn_dropout_strided")
-            if crows is not None and i + 1 < depth:
-                _rn.check(L.rn_channel_rows(_rn.f32(buf), n, hw, ct, ci, k, C.byref(crows), _rn.stream()), "rn_channel_rows")
             saved += [a, m1, r1, d1, a2, m2, r2]
         ctx.cfg = cfg
         ctx.nparams = len(params)
