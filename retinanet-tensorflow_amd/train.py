@@ -326,7 +326,8 @@ class Trainer(object):
         # [cut_offset, heads_offset) -- is all-reduced at once, the subnets' slice [heads_offset, count) BEHIND the deferred products
         # on their stream (the collective waits for that stream, not for the backbone's backward pass).  A forked stream must be
         # joined inside the graph that forked it, so with one graph PER PART and eager collectives between them (the fallback when
-        # the collectives cannot be captured) the deferral is off.  RN_DEFER_WGRAD=0: off everywhere.
+        # the collectives cannot be captured) the products are forked AND joined inside the first part's graph and the subnets'
+        # slice is reduced right behind that part, under the parts that follow.  RN_DEFER_WGRAD=0: off everywhere.
         self.heads_offset = self.arena.count
         if base is not None and hasattr(base, 'classification_subnet'):
             first = next(iter(base.classification_subnet.parameters()), None)
@@ -338,8 +339,7 @@ class Trainer(object):
             self.allreduce._capturable = False
         if self.allreduce.active and use_graph and self.whole_step_graph and self.device.type == 'cuda':
             self.allreduce.probe_capturable(self.device)
-        self.defer_wgrad = (os.environ.get("RN_DEFER_WGRAD", "1") == "1" and self.device.type == 'cuda' and self.direct_param_grads
-                            and (not self.allreduce.active or not use_graph or self._whole_step_ok()))
+        self.defer_wgrad = os.environ.get("RN_DEFER_WGRAD", "1") == "1" and self.device.type == 'cuda' and self.direct_param_grads
         self._deferred_wgrads = []
         self._deferred_running = []
         self._graphs = None
@@ -646,6 +646,7 @@ class Trainer(object):
             err = hip.hipGraphDebugDotPrint(ctypes.c_void_p(ga.raw_cuda_graph()), dot.encode(), 0)
             print("hipGraphDebugDotPrint ->", err, dot, flush=True)
             ga.instantiate()
+        had_deferred = bool(self._deferred_wgrads) and self.num_parts() > 0      # (forked and joined inside the first part's graph)
         gbs, ranges = [], []
         for j in range(self.num_parts()):          # one graph per part of segment B: the collectives go between the replays
             gb = torch.cuda.CUDAGraph()
@@ -653,7 +654,8 @@ class Trainer(object):
                 ranges.append(self.segment_b(j))   # (deferred weight gradients, if any, are forked AND joined inside the first part)
             gbs.append(gb)
         self._parts = []
-        self._graphs = (ga, gbs, ranges, self._graph_out, self._static, False)
+        # (index 6: were tower weight gradients deferred into the first part's graph?  Then the subnets' slice is complete after it)
+        self._graphs = (ga, gbs, ranges, self._graph_out, self._static, False, had_deferred)
 
     def _whole_step_ok(self):
         ar = self.allreduce
@@ -721,9 +723,13 @@ class Trainer(object):
                     if hi > lo:
                         self.schedule.append((lo, hi))
                         ar.launch(lo, hi)
-                reduce(self.cut_offset, self.arena.count)             # heads + FPN: under the backbone's backward pass
-                for gb, (lo, hi) in zip(self._graphs[1], self._graphs[2]):
+                deferred = bool(self._graphs[6]) and ar.active
+                top = self.heads_offset if deferred else self.arena.count
+                reduce(self.cut_offset, top)                          # heads + FPN (or the FPN alone): under the backbone's backward pass
+                for j, (gb, (lo, hi)) in enumerate(zip(self._graphs[1], self._graphs[2])):
                     gb.replay()
+                    if j == 0 and deferred:
+                        reduce(top, self.arena.count)                 # the subnets' slice: its deferred products ran (and joined) inside part 0
                     reduce(lo, hi)                                    # this part's slice: under the parts that follow
                 if self.timing is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

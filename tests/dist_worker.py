@@ -77,7 +77,7 @@ def nccl1(out_path):
     assert tr.cut_offset > 0 and tr.allreduce.active and tr.allreduce.world == 1 and tr._stage_bb is None
     # round 6: RCCL's all-reduce replays correctly from a captured graph here (probed with a known answer), so the step several
     # ranks run is ONE graph with the collectives as nodes and keeps the deferred tower weight gradients; `ts` is the fallback
-    # (one graph per part, eager collectives between them, no deferral)
+    # (one graph per part, eager collectives between them; the deferred products forked and joined inside the first part's graph)
     res_modes = {"capturable": bool(tr.allreduce.capturable), "defer_wgrad": bool(tr.defer_wgrad),
                  "fallback_capturable": bool(ts.allreduce.capturable), "fallback_defer_wgrad": bool(ts.defer_wgrad)}
     tr.timing = {}

@@ -39,10 +39,13 @@ def test_rccl_world1_forced_collectives_bit_equal_to_plain_step(tmp_path):
     # the step several ranks run is the step the headline times -- one graph, the collectives nodes of it,
     # the tower weight gradients deferred; the fallback (collectives cannot be captured) is one graph per part without deferral
     assert m["capturable"] and m["whole_step_graph"] and m["defer_wgrad"], m
-    assert not m["fallback_capturable"] and not m["fallback_whole_step_graph"] and not m["fallback_defer_wgrad"], m
+    assert not m["fallback_capturable"] and not m["fallback_whole_step_graph"] and m["fallback_defer_wgrad"], m
     # FPN slice when segment A ends, the subnets' slice behind their deferred products, the backbone's after its backward pass
     assert res["schedule"] == [[cut, heads], [heads, count], [0, cut]], res["schedule"]
-    assert res["schedule_fallback"] == [[cut, count], [0, cut]], res["schedule_fallback"]
+    # (the fallback keeps the deferral too: the products are forked and joined inside the first part's graph, the subnets' slice goes
+    # out behind that part -- here the only part: RN_STAGE_CUTS=0)
+    assert res["schedule_fallback"] == [[cut, heads], [0, cut]] or res["schedule_fallback"] == [[cut, heads], [heads, count], [0, cut]], res["schedule_fallback"]
+    assert sorted(res["schedule_fallback"]) == [[0, cut], [cut, heads], [heads, count]], res["schedule_fallback"]
     # ... and with MobileNetV2's stage cut (the chain's backward pass in two parts, train.py:261-267): three slices per step,
     # tiling the arena from the top down; the identity pass-through at the cut is exact in the forward pass (same first-step
     # losses, bit for bit) and re-groups one GroupNorm's gradient sums in the backward pass (weights within 1e-6 of the range)
@@ -71,7 +74,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert res["config"]["backward_segments"] == 3 and len(ar["slice_schedule_bytes"]) == 4
     assert res["config"]["whole_step_in_one_graph"] and res["config"]["collectives_captured_in_graph"] and res["config"]["tower_weight_gradients_deferred"]
     # ... and the fallback path (one graph per part, eager collectives) ran too: it is where the exposed time is measured
-    assert len(ar["one_graph_per_part_eager_collectives"]["slice_schedule_bytes"]) == 3
+    assert len(ar["one_graph_per_part_eager_collectives"]["slice_schedule_bytes"]) == 4
     assert ar["bytes_overlapped_with_backbone_backward"] > ar["bytes_after_backward"] > 0
     assert ar["bytes_after_backward"] <= 1 << 20, ar            # <= 1 MB left after the last backward kernel
     assert res["config"]["gn_barrier_timeouts"] == 0
