@@ -1126,8 +1126,11 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
   // matrix written into the caller's scratch (rn_conv2d_fwd_workspace asks for it; a caller that brings none keeps the fp32 kernels)
   int xrows = x3_conv1x1(segs, nseg, g, bt, a.seg[0].m, a.seg[0].x_ld, a.seg[0].bias != nullptr);
   size_t colb = 0;
-  if (!xrows && (colb = x3_im2col(segs, nseg, g, bt, a.seg[0].bias != nullptr)) != 0) {
-    if (sc.need_out || (sc.ws && sc.bytes >= colb)) xrows = rn::conv1x1_x3_tile(a.seg[0].m, g->kh * g->kw * g->cin, a.seg[0].cout, g->kh * g->kw * g->cin);
+  int n_piece = 0;                            // the patch-matrix path runs the batch in equal pieces of this many samples (<= 1 GiB each)
+  if (!xrows && nseg == 1 && bt.n == 1 && G == 1 && !a.seg[0].bias && a.seg[0].x_ld == g->cin && a.seg[0].x_coff == 0 &&
+      (colb = rn::im2col_x3_fwd_pieces(a.seg[0].n, a.seg[0].h, a.seg[0].w, g->cin, a.seg[0].cout, g->kh, g->kw, g->stride, &n_piece)) != 0) {
+    if (sc.need_out || (sc.ws && sc.bytes >= colb))
+      xrows = rn::conv1x1_x3_tile((long)n_piece * a.seg[0].oh * a.seg[0].ow, g->kh * g->kw * g->cin, a.seg[0].cout, g->kh * g->kw * g->cin);
     else colb = 0;
   }
   if (xrows) {
@@ -1156,8 +1159,16 @@ int conv_fwd_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, cons
       if (sc.need_out) { *sc.need_out = colb; return RN_OK; }
       if (!colb) return rn::launch_conv1x1_fwd_x3(d.a + d.x_coff, d.x_ld, d.b, d.out, d.m, g->cin, d.cout, rows, (hipStream_t)stream);
       const int K = g->kh * g->kw * g->cin;                    // W in HWIO is the [K][cout] matrix
-      if (int e = rn::launch_im2col(d.a, (float*)sc.ws, d.n, d.h, d.w, g->cin, g->kh, g->kw, g->stride, (hipStream_t)stream)) return e;
-      return rn::launch_conv1x1_fwd_x3((const float*)sc.ws, K, d.b, d.out, d.m, K, d.cout, rows, (hipStream_t)stream);
+      const int mp = n_piece * ohw;                            // rows of a piece (a whole number of m-tiles when rows are asked for)
+      for (int s0 = 0; s0 < d.n; s0 += n_piece) {
+        if (int e = rn::launch_im2col(d.a + (size_t)s0 * d.h * d.w * g->cin, (float*)sc.ws, n_piece, d.h, d.w, g->cin, g->kh, g->kw, g->stride,
+                                      (hipStream_t)stream))
+          return e;
+        if (int e = rn::launch_conv1x1_fwd_x3((const float*)sc.ws, K, d.b, d.out + (size_t)s0 * ohw * d.cout, mp, K, d.cout,
+                                              rows ? rows + (size_t)(s0 * (ohw / xrows)) * d.cout : nullptr, (hipStream_t)stream))
+          return e;
+      }
+      return RN_OK;
     }
   }
   const int c = (G > 1 && a.seg[0].cout / G <= 64)

@@ -73,8 +73,25 @@ const bool g_on = !(getenv("RN_X3_IM2COL") && atoi(getenv("RN_X3_IM2COL")) == 0)
 }  // namespace
 
 namespace rn {
+size_t im2col_x3_bytes(int n, int h, int wd, int cin, int cout, int kh, int kw, int stride);
 // patch-matrix bytes of the conv, or 0 when the path is not taken (product mode 0, RN_X3_IM2COL=0, channels not multiples of 4, 1 x 1 /
 // stride-1 kernels -- those are plain products already --, too few tiles, or > 2 GiB)
+// forward only: the batch in equal pieces of `*n_piece` samples whose patch matrix stays under 1 GiB (large inference batches: the first
+// "down" conv of a 1024^2 batch of 16 would need 2.4 GB at once) -- bytes of ONE piece, or 0 when the path is not taken
+size_t im2col_x3_fwd_pieces(int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int* n_piece) {
+  for (int np = n; np >= 1; --np) {
+    if (n % np) continue;
+    int oh, ow, pt, pl;
+    rn::same_pad(h, kh, stride, &oh, &pt);
+    rn::same_pad(wd, kw, stride, &ow, &pl);
+    static const double cap = (getenv("RN_X3_IM2COL_PIECE_MB") ? atof(getenv("RN_X3_IM2COL_PIECE_MB")) : 1024.0) * 1048576.0;   // (tests: a small cap)
+    if ((double)np * oh * ow * kh * kw * cin * 4.0 > cap && np > 1) continue;
+    *n_piece = np;
+    return im2col_x3_bytes(np, h, wd, cin, cout, kh, kw, stride);
+  }
+  return 0;
+}
+
 size_t im2col_x3_bytes(int n, int h, int wd, int cin, int cout, int kh, int kw, int stride) {
   if (!g_on || rn::product_mode() != 1 || cin % 4 || cout % 4 || (kh == 1 && kw == 1 && stride == 1)) return 0;
   int oh, ow, pt, pl;

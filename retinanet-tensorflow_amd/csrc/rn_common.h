@@ -66,6 +66,7 @@ int launch_conv1x1_wgrad_x3(const float* x, int x_ld, const float* dy, int M, in
                             hipStream_t st, int* nsplit_out);
 // dense k x k convs (not 1 x 1 / stride 1) as split-bf16 products of an explicit patch matrix (im2col.hip); bytes == 0: not taken
 size_t im2col_x3_bytes(int n, int h, int wd, int cin, int cout, int kh, int kw, int stride);
+size_t im2col_x3_fwd_pieces(int n, int h, int wd, int cin, int cout, int kh, int kw, int stride, int* n_piece);
 int launch_im2col(const float* x, float* col, int n, int h, int wd, int cin, int kh, int kw, int stride, hipStream_t st);
 int launch_col2im(const float* dcol, float* dx, int n, int h, int wd, int cin, int kh, int kw, int stride, hipStream_t st);
 // grouped 3x3 / stride-1 convs with 4 / 8 / 16 / 32 channels per group as direct convolutions (grouped_conv.hip)

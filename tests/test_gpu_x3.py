@@ -255,3 +255,38 @@ def test_conv1x1_split_bf16_on_a_channel_slice(dev, product_mode):
     _rn.check(L.rn_conv2d_wgrad(segs, 1, C.byref(geom), _rn.f32(dw), 0, ws.data_ptr(), ws.numel(), _rn.stream(), None), "rn_conv2d_wgrad")
     magw = np.abs(X).T @ np.abs(DY)
     assert float((np.abs(dw.cpu().numpy().reshape(cin, cout) - X.T @ DY) / magw).max()) <= 3e-7
+
+
+def test_strided_dense_conv_patch_matrix_in_pieces(dev, tmp_path):
+    """Forward of a 3x3 / stride-2 dense conv whose patch matrix is built in equal PIECES of the batch (large inference batches: <= 1 GiB per
+    piece; here RN_X3_IM2COL_PIECE_MB=40 forces 4 samples into 2 pieces of 2 in a fresh process), with the GroupNorm statistic rows of
+    every piece landing in their place: bit-identical to the one-piece run of the same kernels."""
+    import os, subprocess, sys
+    script = r'''
+import os, sys
+ROOT = sys.argv[1]
+for p in (ROOT, os.path.join(ROOT, "retinanet-tensorflow_amd")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import ops
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(9)
+x = torch.from_numpy(rng.standard_normal((4, 64, 64, 128)).astype(np.float32)).to(dev)
+w = torch.from_numpy((rng.standard_normal((3, 3, 128, 512)) / 34).astype(np.float32)).to(dev)
+g, b = torch.ones(512, device=dev), torch.zeros(512, device=dev)
+with torch.no_grad():
+    y = ops.conv2d(x, w, None, 2, gn=(32, 1e-5))
+    assert getattr(y, "_gn_rows", None) is not None
+    z = ops.group_norm_act(y, g, b, groups=32)
+np.save(sys.argv[2], np.stack([y.cpu().numpy(), z.cpu().numpy()]))
+'''
+    outs = []
+    for cap in ("4096", "40"):
+        out = str(tmp_path / ("y_%s.npy" % cap))
+        env = dict(os.environ, RN_X3_IM2COL_PIECE_MB=cap)
+        r = subprocess.run([sys.executable, "-c", script, os.path.dirname(os.path.dirname(os.path.abspath(__file__))), out], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0], outs[1])
+    assert np.isfinite(outs[0]).all() and abs(float(outs[0][1].mean())) < 1e-3       # (the normalised output: zero mean per group)
