@@ -355,6 +355,7 @@ class Trainer(object):
         # host-side scalars are constants of such a graph: momentum SGD without clipping only (no step-dependent scalar), and a
         # changed learning rate captures again (the rate is part of the cache key).  RN_WHOLE_STEP_GRAPH=0: one graph per part.
         self.schedule = []             # the gradient slices of the last recorded / eager step, in the order their all-reduce was issued
+        self._last_lr, self._lr_changes = None, 0
         self.recaptures = 0
         self._static = None
         # the device word every fused dropout hashes (bumped by the optimizer kernel); replicas start it at different values
@@ -683,6 +684,17 @@ class Trainer(object):
         feed = self.input_fn if (features is None and hasattr(self.input_fn, 'stage')) else None
         key = feed.stage() if feed is not None else None
         whole = self._whole_step_ok()
+        if whole:
+            # the one-graph step bakes the learning rate into the captured update: a rate that keeps changing (a schedule, a warm-up)
+            # would capture again every step -- two warm-up passes + a capture each time, churning the graph cache.  After the third
+            # distinct rate the trainer keeps to one graph per part with the update launched eagerly (its scalars are launch arguments).
+            if self.opt.lr != self._last_lr:
+                self._last_lr, self._lr_changes = self.opt.lr, self._lr_changes + 1
+                if self._lr_changes == 4:
+                    print("[trainer] the learning rate keeps changing: the update leaves the captured step (one graph per part from here on)",
+                          file=sys.stderr, flush=True)
+            if self._lr_changes > 3:
+                whole = False
         if whole:
             key = (key, 'whole', self.opt.lr, id(self.allreduce))
         if self.use_graph:

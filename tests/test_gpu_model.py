@@ -386,3 +386,20 @@ def test_whole_step_graph_equals_segments_and_eager(dev):
     assert torch.equal(tw.opt.state1, ts.opt.state1) and torch.equal(tw.opt.state1, te.opt.state1)
     assert tw.drop_counter.item() == ts.drop_counter.item() == te.drop_counter.item() == 4 * ops.DROPOUT_COUNTER_STEP
     assert tw.opt.step_count == ts.opt.step_count == te.opt.step_count == 4 and tw.steps_done == 4
+    # a learning-rate SCHEDULE (a new rate every step) must not capture a new graph set every step: after the third distinct rate the
+    # update leaves the captured step (one graph per part + the eagerly launched update, whose rate is a launch argument) -- and the
+    # results stay those of eager launches
+    for i in range(5):
+        for t in (tw, te):
+            t.opt.lr = 0.9 * t.opt.lr
+        ow, oe = tw.step(feats), te.step(feats)
+        assert ow["class_loss"].item() == oe["class_loss"].item(), (i, ow["class_loss"].item(), oe["class_loss"].item())
+    torch.cuda.synchronize()
+    assert not tw._graphs[5] and tw._lr_changes >= 5
+    caches = len(tw._graph_cache)
+    for t in (tw, te):
+        t.opt.lr = 0.9 * t.opt.lr
+    tw.step(feats); te.step(feats)
+    torch.cuda.synchronize()
+    assert len(tw._graph_cache) == caches                       # (no further capture: the rate is no longer part of the key)
+    assert torch.equal(tw.arena.weights, te.arena.weights)
