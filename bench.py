@@ -53,7 +53,8 @@ TRAIN_GFLOP_PER_IMAGE = 239.2       # BASELINE.md section 3 (3 x forward conv FL
 # whole number of tiles).  EXECUTED = (39.87 - 38.268) + 38.268 / 4 = 11.169 GMAC forward -> x 2 FLOP x 3 passes:
 EXECUTED_TRAIN_GFLOP_PER_IMAGE = 67.0
 # name prefix and grid of the forward product launch of a head-tower layer in a rocprofv3 trace (the `roofline` kernel)
-X3_FWD_KERNEL = "gemm_x3_kernel<false, true, 2, 2, false>"
+X3_FWD_KERNEL = "gemm_x3_kernel<false, true, 2, 2, false, false>"          # fp32 kernel operand, split inside the product kernel
+X3_FWD_KERNEL_BFRAG = "gemm_x3_kernel<false, true, 2, 2, false, true>"      # kernel operand pre-split in fragment order by the kernel transform
 X3_FWD_GRID = lambda tiles: 36 * (-(-tiles // 128)) * 2       # noqa: E731
 PRODUCT_REPS = 8                    # back-to-back launches per graph when the product kernels are timed alone (_graph_time)
 FP16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
@@ -174,12 +175,22 @@ def roofline_kernels(device):
     A = torch.randn(36, tiles, 256, device=device)
     B = torch.randn(36, 256, 256, device=device) * 0.01
     Cm = torch.empty(36, tiles, 256, device=device)
-    fwd_ms = _graph_time(lambda: _rn.check(L.rn_gemm_batched(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, 36, 0,
-                                                             _rn.stream()), "rn_gemm_batched"), reps=PRODUCT_REPS)
+    # product mode 1: the training step's tower layers hand the FORWARD product kernel its kernel operand U pre-split in fragment order
+    # (written that way by the Winograd kernel transform, csrc/winograd.hip wino_weight_frag_body); here rn_x3_pack_bfrag builds
+    # the same image from B once, outside the timed launches -- the timed kernel is the one the step runs
+    bfrag = bool(L.rn_get_product_mode()) and bool(L.rn_x3_bfrag_ok(tiles, 256, 256))
     dM = torch.randn(36, tiles, 256, device=device)
     need = L.rn_winograd_bwd_products_workspace(tiles, 256, 256, 36)
     ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=device)
     nsplit = C.c_int(0)
+    if bfrag:
+        Bf = torch.empty(L.rn_x3_bfrag_bytes(256, 256, 36), dtype=torch.uint8, device=device)
+        _rn.check(L.rn_x3_pack_bfrag(_rn.f32(B), Bf.data_ptr(), 256, 256, 36, 0, _rn.stream()), "rn_x3_pack_bfrag")
+        fwd_ms = _graph_time(lambda: _rn.check(L.rn_gemm_batched_bfrag(_rn.f32(A), Bf.data_ptr(), _rn.f32(Cm), tiles, 256, 256, 36, 1,
+                                                                       _rn.stream()), "rn_gemm_batched_bfrag"), reps=PRODUCT_REPS)
+    else:
+        fwd_ms = _graph_time(lambda: _rn.check(L.rn_gemm_batched(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, 36, 0,
+                                                                 _rn.stream()), "rn_gemm_batched"), reps=PRODUCT_REPS)
     bwd_ms = _graph_time(lambda: _rn.check(L.rn_winograd_bwd_products(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256,
                                                                       _rn.f32(A), _rn.f32(dM), 256, 256, 36, ws.data_ptr(),
                                                                       ws.numel(), C.byref(nsplit), _rn.stream()),
@@ -266,7 +277,9 @@ def roofline_kernels(device):
         fwd = x3_entry(entry("head-tower layer, forward products (largest in-step kernel: 17 launches per step)",
                              "gemm_x3_kernel: 36 x [682x256]x[256x256], fp32 operands split into 3 bf16, 6 bf16 MFMA products, fp32 accumulate",
                              "mfma", flops, fwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", fwd_bytes, "fwd_products",
-                             prof=(X3_FWD_KERNEL, X3_FWD_GRID(tiles))), flops, fwd_ms)
+                             prof=(X3_FWD_KERNEL_BFRAG if bfrag else X3_FWD_KERNEL, X3_FWD_GRID(tiles))), flops, fwd_ms)
+        fwd["kernel_operand"] = ("pre-split into 3 bf16 planes in MFMA-fragment order by the Winograd kernel transform (6 B / element, read straight "
+                                 "from global memory)") if bfrag else "fp32, split inside the product kernel"
         bwd = x3_entry(entry("head-tower layer, backward products: data-gradient launch + weight-gradient launch (8 pairs per step)",
                              "gemm_x3_kernel (dgrad) + gemm_x3_kernel (wgrad): 36 x ([682x256]x[256x256]^T + [256x682]x[682x256] in %d ranges)" % max(nsplit.value, 1),
                              "mfma", 2 * flops, bwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", bwd_bytes, "bwd_products"), 2 * flops, bwd_ms)

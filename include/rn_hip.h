@@ -48,7 +48,7 @@ typedef struct rn_reduce_list rn_reduce_list;
 
 /* Version of this header's ABI: bumped whenever an entry point's arguments or a struct layout change.  rn_version() returns
  * the value the library was built with; a caller built against another value must not call anything else. */
-#define RN_API_VERSION 405
+#define RN_API_VERSION 406
 int rn_version(void);
 const char* rn_last_error(void);
 
@@ -231,6 +231,22 @@ int rn_conv3x3_winograd_bwd(const rn_conv_seg* segs, int nseg, int cin, int cout
  * Shapes the split kernels do not take (K or N not a multiple of 4, matrices >= 2 GiB) use mode 0 regardless. */
 int rn_set_product_mode(int mode);
 int rn_get_product_mode(void);
+/* Product mode 1, the kernel operand of the head towers' FORWARD products (the reference's conv kernels of retinanet.py:37-62,85-106)
+ * pre-split by its PRODUCER: the Winograd kernel transform of rn_conv3x3_winograd_gn writes U as the three bf16 planes the product
+ * kernel needs, in the order its matrix-core instruction reads them -- [32-column block][16-k step][plane][lane][8 bf16], 6 bytes
+ * per element -- and the product kernel loads its B fragments straight from global memory (no split, no LDS for that operand).
+ * Same values, same order of operations: results are bit-identical to the fp32-operand kernel.  Process-wide switch (default on,
+ * RN_X3_BFRAG=0 at first use: off).
+ *   rn_x3_bfrag_ok     1 when [M x K] x [K x N] can take such an operand now (mode 1, switch on, K % 16 == 0, N % 4 == 0)
+ *   rn_x3_bfrag_bytes  bytes of the images of `nbatch` [K x N] operands (the columns padded to 32)
+ *   rn_x3_pack_bfrag   fp32 B_b ([K x N], or [N x K] when b_nk) -> images: for stand-alone products (tests, bench.py)
+ *   rn_gemm_batched_bfrag   rn_gemm_batched with B given as images (fwd_name: which of two identical kernel instantiations runs) */
+int rn_set_x3_bfrag(int on);
+int rn_get_x3_bfrag(void);
+int rn_x3_bfrag_ok(int M, int K, int N);
+size_t rn_x3_bfrag_bytes(int K, int N, int nbatch);
+int rn_x3_pack_bfrag(const float* B, void* out, int K, int N, int nbatch, int b_nk, rn_stream_t stream);
+int rn_gemm_batched_bfrag(const float* A, const void* Bfrag, float* C, int M, int K, int N, int nbatch, int fwd_name, rn_stream_t stream);
 
 /* ------------------------------------------------------------------ fp16 inference convolution
  * BASELINE configs[4] ("Inference-only ResNeXt-50-FPN 1024x1024 bs=16, fp16"): forward conv on the f16
@@ -515,8 +531,20 @@ typedef struct rn_wino_gn {
   /* output side: NULL out_rows = no statistics */
   float* out_rows;        /* [rows][out_groups][4] */
   int32_t out_groups;
+  /* the kernel transforms prepared ahead of the layer by rn_conv3x3_winograd_gn_weights (train.Trainer: all tower layers once per
+   * step on a side stream beside the backbone, off the layers' critical path): u_ready = its u_out (NULL: transformed inside this
+   * call, in the workspace); urot_ready != 0: urot_buf already holds its urot_out and is only read */
+  const void* u_ready;
+  int32_t urot_ready;
 } rn_wino_gn;
 size_t rn_wino_gn_rows(const rn_conv_seg* segs, int nseg, int tile);
+/* The kernel transforms of such a layer alone: U in the format the layer's forward product reads under the current switches
+ * (fp32 [P][cin][cout], or the fragment image of rn_x3_pack_bfrag) -> u_out (rn_conv3x3_winograd_gn_u_bytes bytes), and the rotated
+ * kernel's transform (fp32, the data gradient's operand) -> urot_out (urot_bytes of rn_conv3x3_winograd_keep_bytes; NULL: skipped).
+ * Same kernels, same values as inside rn_conv3x3_winograd_gn.  The reference's conv kernels: retinanet.py:37-62,85-106. */
+size_t rn_conv3x3_winograd_gn_u_bytes(int cin, int cout, int tile);
+int rn_conv3x3_winograd_gn_weights(const float* w, int cin, int cout, int tile, void* u_out, size_t u_out_bytes, float* urot_out,
+                                   rn_stream_t stream);
 /* y = conv3x3_same(act(GN(x)), w) (+ bias).  Workspace / v_buf / urot_buf as rn_conv3x3_winograd. */
 int rn_conv3x3_winograd_gn(const rn_conv_seg* segs, int nseg, int cin, int cout, const float* w, const float* bias, int tile,
                            const rn_wino_gn* gn, void* workspace, size_t workspace_bytes, float* v_buf, float* urot_buf,

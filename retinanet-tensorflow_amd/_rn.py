@@ -19,7 +19,7 @@ LOSS_MODE = {"bce_dice": 0, "focal": 1}
 OPT = {"momentum": 0, "rmsprop": 1, "adam": 2}
 OPT_BLOCK = 1024
 LOSS_STATS_HEADER = 8
-API_VERSION = 405        # RN_API_VERSION of include/rn_hip.h these bindings were written against
+API_VERSION = 406        # RN_API_VERSION of include/rn_hip.h these bindings were written against
 
 
 class RnError(RuntimeError):
@@ -45,7 +45,8 @@ class ConvGeom(C.Structure):
 
 class WinoGn(C.Structure):
     _fields_ = [("in_rows", C.c_void_p), ("in_gamma", C.c_void_p), ("in_beta", C.c_void_p), ("in_groups", C.c_int32),
-                ("in_act", C.c_int32), ("in_eps", C.c_float), ("out_rows", C.c_void_p), ("out_groups", C.c_int32)]
+                ("in_act", C.c_int32), ("in_eps", C.c_float), ("out_rows", C.c_void_p), ("out_groups", C.c_int32),
+                ("u_ready", C.c_void_p), ("urot_ready", C.c_int32)]
 
 
 class WinoGnBwd(C.Structure):
@@ -183,6 +184,7 @@ SYMBOLS = [
     "rn_optimizer_workspace", "rn_grad_norm_l2reg", "rn_optimizer_step", "rn_counter_add", "rn_add_segs",
     "rn_mb_rows_max", "rn_mb_compact_rows_layout", "rn_mb_compact_rows", "rn_mb_pointwise_rows", "rn_mb_pointwise_fwd", "rn_mb_depthwise_rows", "rn_mb_depthwise_fwd", "rn_mb_apply",
     "rn_mb_resident_sync_bytes", "rn_mb_resident_rows", "rn_mb_resident_fwd", "rn_set_product_mode", "rn_get_product_mode",
+    "rn_set_x3_bfrag", "rn_get_x3_bfrag", "rn_x3_bfrag_ok", "rn_x3_bfrag_bytes", "rn_x3_pack_bfrag", "rn_gemm_batched_bfrag", "rn_conv3x3_winograd_gn_u_bytes", "rn_conv3x3_winograd_gn_weights",
     "rn_mb_pointwise_bwd_rows", "rn_mb_pointwise_bwd_workspace", "rn_mb_pointwise_bwd",
     "rn_mb_depthwise_bwd_rows", "rn_mb_depthwise_bwd_workspace", "rn_mb_depthwise_bwd",
     "rn_debug_collective_standin", "rn_optimizer_norm_pairs", "rn_optimizer_step_norm", "rn_norm_reg_finalize",
@@ -207,7 +209,8 @@ def lib():
                      "rn_conv2d_bias_grad_workspace", "rn_nms_classwise_workspace", "rn_conv3x3_winograd_workspace", "rn_conv2d_fwd_workspace",
                      "rn_conv2d_dgrad_workspace",
                      "rn_conv3x3_winograd_wgrad_workspace", "rn_conv3x3_winograd_bwd_workspace", "rn_wino_gn_rows",
-                     "rn_winograd_bwd_products_workspace", "rn_conv2d_stats_rows", "rn_depthwise_stats_rows", "rn_conv2d_dropout_rows"):
+                     "rn_winograd_bwd_products_workspace", "rn_conv2d_stats_rows", "rn_depthwise_stats_rows", "rn_conv2d_dropout_rows",
+                     "rn_x3_bfrag_bytes", "rn_conv3x3_winograd_gn_u_bytes"):
             getattr(L, name).restype = C.c_size_t
         L.rn_optimizer_workspace.argtypes = [C.c_int64]
         L.rn_dwgn_supported.argtypes = [C.c_void_p, C.c_int]
@@ -259,6 +262,13 @@ def lib():
         L.rn_winograd_bwd_products_workspace.argtypes = [C.c_int] * 4
         L.rn_winograd_bwd_products.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_int] * 3 + \
                                               [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.rn_x3_bfrag_ok.argtypes = [C.c_int] * 3
+        L.rn_conv3x3_winograd_gn_u_bytes.argtypes = [C.c_int] * 3
+        L.rn_conv3x3_winograd_gn_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.rn_x3_bfrag_bytes.argtypes = [C.c_int] * 3
+        L.rn_x3_pack_bfrag.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
+        L.rn_gemm_batched_bfrag.argtypes = [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p]
+        L.rn_set_x3_bfrag.argtypes = [C.c_int]
         L.rn_conv3x3_winograd_gn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rn_conv3x3_winograd_gn_bwd_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,

@@ -46,6 +46,9 @@ struct X3Args {
   // output tensor iff uniform01(seed + *seed_dev, i) >= rate, scaled by 1 / (1 - rate) -- applied to the accumulators before they are stored
   // and summed: the conv's output never exists un-dropped, `stat` holds the sums of the DROPPED tensor.  rate == 0: off
   float drop_rate, drop_keep; uint64_t drop_seed; const uint64_t* drop_seed_dev;
+  // B_FRAG kernels: Op2 comes pre-split and in MFMA-fragment order (see `FragB` below) -- `bfrag` per batch `bfrag_bstride` bytes apart,
+  // `b_nblk` 32-row blocks x `b_ks16` 16-k steps; b.rows (the column bound of the epilogue) as ever, b.p / b.ld unused
+  const void* bfrag; long bfrag_bstride; int b_nblk, b_ks16;
   int dbg;      // RN_X3_DBG (timing aid, wrong results): bit 0 no MFMAs, bit 1 no split / LDS stores, bit 2 no global loads after the first, bit 3 no fragment reads, bit 4 the dword epilogue
 };
 
@@ -144,6 +147,37 @@ __device__ __forceinline__ bf16x8 fragment(const unsigned short* tile, int p, in
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tile + p * G::PLANE + row * LDR + s * 16 + h * 8));
 }
 
+// Op2 pre-split by its PRODUCER and laid out in MFMA-fragment order (the Winograd kernel transform writes U / Urot this way once per
+// layer and step, winograd.hip wino_weight_frag_body; rn_x3_pack_bfrag for stand-alone products): per batch matrix
+//     [n block nb = n / 32][k step kk = k / 16][plane p < 3][lane l < 64][8 bf16]       (6 bytes per element, K % 16 == 0, n padded to 32)
+// with lane l holding column n = 32 nb + (l & 31) at k = 16 kk + 8 (l >> 5) .. + 7 -- what lane l feeds v_mfma_f32_32x32x16_bf16 as
+// its B operand is ONE 16-byte global load (1 KB contiguous per wave and fragment; L2-resident: every m-tile of a batch re-reads
+// the same 48 KB per column block) straight into the registers the instruction reads.  Against the LDS route that removes, per
+// K-step of a 128 x 128 tile and thread: the split of 16 elements (~90 VALU operations), 6 ds_write_b128 and 48 ds_read_b32 (the
+// k-strided operand's fragments are dword gathers), and half of the block's LDS.  The fragments of K-step t + 1 are requested as
+// the matrix-core instructions of K-step t release their registers.
+struct FragB {
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned base[2];       // byte offset of (column block of this wave's tile j, k step 0, plane 0, this lane); OOB past the last block
+  int ks16;
+  template <int WT>
+  __device__ __forceinline__ void init(const X3Args& a, int batch, int n0, int wn, int lane) {
+    rs = make_rsrc(static_cast<const char*>(a.bfrag) + (size_t)batch * a.bfrag_bstride, (unsigned)a.b_nblk * (unsigned)a.b_ks16 * 3072u);
+    ks16 = a.b_ks16;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const int nb = (n0 >> 5) + wn * WT + j;
+      base[j] = nb < a.b_nblk ? ((unsigned)nb * (unsigned)a.b_ks16 * 192u + (unsigned)lane) * 16u : OOB;
+    }
+  }
+  // the three planes of (tile column block j, 16-k step kk); steps past K: zeros (out of the descriptor's range)
+  __device__ __forceinline__ void load(int j, int kk, bf16x8 (&f)[3]) const {
+    const unsigned vo = (kk < ks16 && base[j] != OOB) ? base[j] + (unsigned)kk * 3072u : OOB;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) f[p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, p * 1024, 0));
+  }
+};
+
 // Block tile (64 WT) x (64 WT) x 32, 4 waves as 2 x 2, each wave WT x WT MFMA tiles of 32 x 32.  WT = 2 (128 x 128) halves
 // the LDS traffic and the split's VALU work per matrix-core instruction (the 64 x 64 tile is bound by their SUM: 28 us for the
 // head-tower product against 8 us of matrix-core time); WT = 1 is for launches too small to fill the chip with 128 x 128 tiles.
@@ -151,14 +185,17 @@ __device__ __forceinline__ bf16x8 fragment(const unsigned short* tile, int p, in
 // DBG: the leave-one-out timing aid (RN_X3_DBG, wrong results) as its own instantiation -- in the production kernel (DBG = false)
 // the K-step is ONE basic block: run-time tests between its phases would keep the scheduler from moving the next step's fragment
 // reads and the global loads in between the matrix-core instructions.
-template <bool A_KS, bool B_KS, int WT, int NST, bool DBG = false>
+// B_FRAG: Op2 from the pre-split fragment-ordered image (FragB; B_KS then only names the instantiation: forward / data gradient).
+template <bool A_KS, bool B_KS, int WT, int NST, bool DBG = false, bool B_FRAG = false>
 __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Args a) {
   const int dbg = DBG ? a.dbg : 0;
   constexpr int ROWS = 64 * WT;
   typedef TileGeom<ROWS> G;
-  __shared__ __attribute__((aligned(16))) unsigned short lds[6 * G::PLANE];
+  // (B_FRAG: the A planes only -- or the epilogue's staging area, 4 waves x 32 rows x 68 floats, where that is larger)
+  constexpr int LDS_HALFS = B_FRAG ? (WT == 2 && 3 * G::PLANE < 4 * 32 * 68 * 2 ? 4 * 32 * 68 * 2 : 3 * G::PLANE) : 6 * G::PLANE;
+  __shared__ __attribute__((aligned(16))) unsigned short lds[LDS_HALFS];
   unsigned short* At = lds;
-  unsigned short* Bt = lds + 3 * G::PLANE;
+  unsigned short* Bt = lds + (B_FRAG ? 0 : 3 * G::PLANE);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
@@ -172,17 +209,27 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
   const float* pb = a.b.p + (size_t)batch * a.b.bstride;
   // (the descriptor covers the whole batch matrix: rows x ld for KC, K x ld for KS)
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(pa, (unsigned)(A_KS ? a.K : a.a.rows) * (unsigned)a.a.ld * 4u);
-  const __amdgpu_buffer_rsrc_t rb = make_rsrc(pb, (unsigned)(B_KS ? a.K : a.b.rows) * (unsigned)a.b.ld * 4u);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(pb, B_FRAG ? 0u : (unsigned)(B_KS ? a.K : a.b.rows) * (unsigned)a.b.ld * 4u);
   TileLoad<A_KS, ROWS> la[NST];
-  TileLoad<B_KS, ROWS> lb[NST];
+  TileLoad<B_KS, ROWS> lb[B_FRAG ? 1 : NST];
+  FragB fragb;
+  bf16x8 fbq[2][WT][3];                       // B_FRAG: the fragments of the K-step at hand (16-k halves s = 0, 1), refilled in place
   f32x16 acc[WT][WT];
   zero_acc<WT, WT>(acc);
   const int nk = (kend - kbeg + XK - 1) / XK;
+  const int kk0 = kbeg >> 4;                  // (B_FRAG launches have one k range: kbeg = 0)
+  if constexpr (B_FRAG) {
+    fragb.template init<WT>(a, batch, n0, wn, lane);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < WT; ++j) fragb.load(j, kk0 + s, fbq[s][j]);
+  }
 #pragma unroll
   for (int st = 0; st < NST; ++st)
     if (st < nk) {
       la[st].load(ra, a.a, m0, kbeg + st * XK, kend, t);
-      lb[st].load(rb, a.b, n0, kbeg + st * XK, kend, t);
+      if constexpr (!B_FRAG) lb[st].load(rb, a.b, n0, kbeg + st * XK, kend, t);
     }
   for (int it0 = 0; it0 < nk; it0 += NST) {
 #pragma unroll
@@ -191,12 +238,12 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
       if (it < nk) {                         // (block-uniform)
         if (!(dbg & 2)) {
           la[st].store(At, t);
-          lb[st].store(Bt, t);
+          if constexpr (!B_FRAG) lb[st].store(Bt, t);
         }
         __syncthreads();
         if (it + NST < nk && !(dbg & 4)) {
           la[st].load(ra, a.a, m0, kbeg + (it + NST) * XK, kend, t);
-          lb[st].load(rb, a.b, n0, kbeg + (it + NST) * XK, kend, t);
+          if constexpr (!B_FRAG) lb[st].load(rb, a.b, n0, kbeg + (it + NST) * XK, kend, t);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -207,7 +254,8 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
 #pragma unroll
               for (int p = 0; p < 3; ++p) {
                 fa[i][p] = fragment<A_KS, ROWS>(At, p, (wm * WT + i) * 32 + r, h, s);
-                fb[i][p] = fragment<B_KS, ROWS>(Bt, p, (wn * WT + i) * 32 + r, h, s);
+                if constexpr (B_FRAG) fb[i][p] = fbq[s][i][p];
+                else fb[i][p] = fragment<B_KS, ROWS>(Bt, p, (wn * WT + i) * 32 + r, h, s);
               }
           } else {
 #pragma unroll
@@ -227,6 +275,13 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
             }
+          // the same half of the NEXT K-step into the registers just read (past the last step: out of range, zeros, no traffic)
+          if constexpr (B_FRAG) {
+            if (!(dbg & 4)) {
+#pragma unroll
+              for (int j = 0; j < WT; ++j) fragb.load(j, it + 1 < nk ? kk0 + 2 * (it + 1) + s : 0x7fffffff, fbq[s][j]);
+            }
+          }
         }
         __syncthreads();
       }
@@ -309,6 +364,30 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
 // for the head-tower product, 54.5 against 52.1 for the backward pair, the step unchanged (499.9 vs 499.9 images/s).  What DID
 // help (round 6): the leave-one-out switches (RN_X3_DBG) are a template parameter now -- as run-time tests they split the K-step
 // into basic blocks the scheduler could not move fragment reads and global loads across.
+// fp32 B_b ([K][N], or [N][K] when b_nk) -> its fragment image (FragB): stand-alone products (tests, bench.py, tools); inside the
+// network the Winograd kernel transform writes the image itself.  One thread per dword (two consecutive k of one column).
+__global__ __launch_bounds__(256) void pack_bfrag_kernel(const float* __restrict__ B, unsigned* __restrict__ out, int K, int N, int b_nk,
+                                                         int ks16, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  const long blk = i >> 8;
+  const int kk = (int)(blk % ks16), nb = (int)(blk / ks16);
+  const int n = nb * 32 + (lane & 31), k = kk * 16 + (lane >> 5) * 8 + 2 * j;
+  const float* Bb = B + (size_t)blockIdx.y * K * N;
+  float v0 = 0.f, v1 = 0.f;
+  if (n < N) {
+    v0 = b_nk ? Bb[(size_t)n * K + k] : Bb[(size_t)k * N + n];
+    v1 = b_nk ? Bb[(size_t)n * K + k + 1] : Bb[(size_t)(k + 1) * N + n];
+  }
+  unsigned h0[3], h1[3];
+  split3(v0, h0[0], h0[1], h0[2]);
+  split3(v1, h1[0], h1[1], h1[2]);
+  unsigned* o = out + (size_t)blockIdx.y * (size_t)(total / 256) * 768 + (size_t)blk * 768 + lane * 4 + j;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) o[p * 256] = pack_hi(h0[p], h1[p]);
+}
+
 int g_mode = -1;
 int mode() {
   if (g_mode < 0) {
@@ -343,6 +422,20 @@ int launch(X3Args a, bool a_ks, bool b_ks, int rows, hipStream_t st, unsigned ld
     else if (!a_ks && !b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, false, WT_, NST_>), grid, dim3(XT), 0, st, a);     \
     else hipLaunchKernelGGL((gemm_x3_kernel<true, false, WT_, NST_>), grid, dim3(XT), 0, st, a);                          \
   } while (0)
+  if (a.bfrag) {                // Op2 pre-split in fragment order (launch_batched_gemm_x3_bfrag): Op1 k-contiguous, one k range
+    if (rows == 128 && dbg) {
+      if (b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, true, 2, 2, true, true>), grid, dim3(XT), 0, st, a);
+      else hipLaunchKernelGGL((gemm_x3_kernel<false, false, 2, 2, true, true>), grid, dim3(XT), 0, st, a);
+    } else if (rows == 128) {
+      if (b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, true, 2, 2, false, true>), grid, dim3(XT), 0, st, a);
+      else hipLaunchKernelGGL((gemm_x3_kernel<false, false, 2, 2, false, true>), grid, dim3(XT), 0, st, a);
+    } else {
+      if (b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, true, 1, 3, false, true>), grid, dim3(XT), 0, st, a);
+      else hipLaunchKernelGGL((gemm_x3_kernel<false, false, 1, 3, false, true>), grid, dim3(XT), 0, st, a);
+    }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+  }
   if (rows == 128 && dbg) {     // (the timing aid measures the head-tower configuration)
     if (a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<true, true, 2, 2, true>), grid, dim3(XT), lds_pad, st, a);
     else if (!a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, true, 2, 2, true>), grid, dim3(XT), 0, st, a);
@@ -395,6 +488,39 @@ int launch_batched_gemm_x3(const float* A, const float* B, float* C, int M, int 
   a.c = C; a.c_bstride = (long)M * N; a.c_sstride = 0; a.ldc = N;
   a.K = K; a.chunk = rn::ceil_div(K, XK) * XK; a.nsplit = 1; a.nbatch = nbatch;
   return launch(a, false, b_nk == 0, tile_rows(M, N, nbatch), st);
+}
+
+// ---- Op2 pre-split in fragment order (FragB above) ----
+static int g_bfrag = -1;
+int bfrag_on() {
+  if (g_bfrag < 0) g_bfrag = !(getenv("RN_X3_BFRAG") && atoi(getenv("RN_X3_BFRAG")) == 0);
+  return g_bfrag;
+}
+void set_bfrag(int on) { g_bfrag = on ? 1 : 0; }
+// (k in whole 16-steps; the columns are padded to whole 32-blocks inside the image)
+// (the M-independent half: which FORMAT a [K x N] kernel operand has under the current switches)
+bool x3_bfrag_format(int K, int N) { return mode() == 1 && bfrag_on() && K >= 16 && K % 16 == 0 && N >= 4 && N % 4 == 0 && fits(x3_bfrag_bytes(K, N) / 4); }
+bool x3_bfrag_ok(int M, int K, int N) { return x3_bfrag_format(K, N) && gemm_x3_ok(M, K, N); }
+size_t x3_bfrag_bytes(int K, int N) { return (size_t)rn::ceil_div(N, 32) * (size_t)(K / 16) * 3072u; }
+// C_b [M x N] = A_b [M x K] * B_b, B_b given as its fragment image (`fwd_name`: which of the two identical instantiations runs --
+// the profiler then tells forward products from data-gradient products by name)
+int launch_batched_gemm_x3_bfrag(const float* A, const void* Bfrag, float* C, int M, int K, int N, int nbatch, int fwd_name, hipStream_t st) {
+  X3Args a = {};
+  a.a = {A, (long)M * K, K, M};
+  a.b = {nullptr, 0, N, N};
+  a.bfrag = Bfrag; a.bfrag_bstride = (long)x3_bfrag_bytes(K, N); a.b_nblk = rn::ceil_div(N, 32); a.b_ks16 = K / 16;
+  a.c = C; a.c_bstride = (long)M * N; a.c_sstride = 0; a.ldc = N;
+  a.K = K; a.chunk = rn::ceil_div(K, XK) * XK; a.nsplit = 1; a.nbatch = nbatch;
+  return launch(a, false, fwd_name != 0, tile_rows(M, N, nbatch), st);
+}
+
+int launch_pack_bfrag(const float* B, void* out, int K, int N, int nbatch, int b_nk, hipStream_t st) {
+  const int ks16 = K / 16;
+  const long total = (long)rn::ceil_div(N, 32) * ks16 * 256;
+  hipLaunchKernelGGL(pack_bfrag_kernel, dim3((unsigned)rn::ceil_div64(total, 256), (unsigned)nbatch), dim3(256), 0, st, B, (unsigned*)out, K, N, b_nk,
+                     ks16, total);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
 }
 
 // ---- dense 1x1 / stride-1 convolutions as plain products (round 6: the ResNeXt / DenseNet bottleneck 1x1 convs and the FPN laterals,
@@ -490,3 +616,20 @@ extern "C" int rn_set_product_mode(int mode_) {
   return RN_OK;
 }
 extern "C" int rn_get_product_mode(void) { return rn::product_mode(); }
+
+extern "C" int rn_set_x3_bfrag(int on) {
+  rn::set_bfrag(on);
+  return RN_OK;
+}
+extern "C" int rn_get_x3_bfrag(void) { return rn::bfrag_on(); }
+extern "C" int rn_x3_bfrag_ok(int M, int K, int N) { return rn::x3_bfrag_ok(M, K, N) ? 1 : 0; }
+extern "C" size_t rn_x3_bfrag_bytes(int K, int N, int nbatch) { return (K > 0 && N > 0 && nbatch > 0 && K % 16 == 0) ? rn::x3_bfrag_bytes(K, N) * (size_t)nbatch : 0; }
+extern "C" int rn_x3_pack_bfrag(const float* B, void* out, int K, int N, int nbatch, int b_nk, rn_stream_t stream) {
+  RN_CHECK_ARG(B && out && K >= 16 && K % 16 == 0 && N >= 1 && nbatch >= 1 && nbatch <= 65535, "x3 pack: bad argument");
+  return rn::launch_pack_bfrag(B, out, K, N, nbatch, b_nk, (hipStream_t)stream);
+}
+extern "C" int rn_gemm_batched_bfrag(const float* A, const void* Bfrag, float* C, int M, int K, int N, int nbatch, int fwd_name, rn_stream_t stream) {
+  RN_CHECK_ARG(A && Bfrag && C && nbatch >= 1, "gemm bfrag: bad argument");
+  RN_UNSUPPORTED(!rn::x3_bfrag_ok(M, K, N), "gemm bfrag: [%d x %d] x [%d x %d] cannot take a fragment-ordered operand (mode / RN_X3_BFRAG / K %% 16)", M, K, K, N);
+  return rn::launch_batched_gemm_x3_bfrag(A, Bfrag, C, M, K, N, nbatch, fwd_name, (hipStream_t)stream);
+}

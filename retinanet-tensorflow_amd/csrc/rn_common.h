@@ -56,6 +56,15 @@ void set_product_mode(int m);
 bool gemm_x3_ok(int M, int K, int N);
 int launch_batched_gemm_x3(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, int b_nk, hipStream_t st);
 size_t batched_gemm_tn_workspace_x3(int M, int K, int N, int nbatch);
+// Op2 pre-split into three bf16 planes in MFMA-fragment order by its producer (gemm_x3.hip FragB; RN_X3_BFRAG=0 / rn_set_x3_bfrag(0): off):
+// the Winograd kernel transform writes U / Urot that way, the product kernel loads its B fragments straight from global memory
+bool x3_bfrag_ok(int M, int K, int N);
+bool x3_bfrag_format(int K, int N);             // the M-independent half of x3_bfrag_ok
+size_t x3_bfrag_bytes(int K, int N);            // per batch matrix
+int bfrag_on();
+void set_bfrag(int on);
+int launch_batched_gemm_x3_bfrag(const float* A, const void* Bfrag, float* C, int M, int K, int N, int nbatch, int fwd_name, hipStream_t st);
+int launch_pack_bfrag(const float* B, void* out, int K, int N, int nbatch, int b_nk, hipStream_t st);
 // dense 1x1 / stride-1 convolutions on the same kernels (0: not taken -- product mode 0, RN_X3_CONV1X1=0, or the shape; else the m-tile rows)
 int conv1x1_x3_tile(long M, int Cin, int Cout, int x_ld);
 int launch_conv1x1_fwd_x3(const float* x, int x_ld, const float* w, float* y, int M, int Cin, int Cout, float2* stat_rows, hipStream_t st,

@@ -56,7 +56,11 @@ struct Wino<2> {
     o[0] = (m[0] + m[1]) + m[2]; o[1] = (m[1] - m[2]) - m[3];
   }
   // G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+  // (contraction off: every rounding of the kernel transform is pinned, so that U has the same bits whichever kernel computes it --
+  // wino_weight_body and wino_weight_frag_body; left to itself the compiler fuses these products into adds of the NEXT call, and
+  // differently in the two: 30 % of the elements of some points came out one ulp apart, tools/dbg_u.py)
   static __device__ __forceinline__ void g(const float (&w)[3], float (&u)[4]) {
+#pragma clang fp contract(off)
     u[0] = w[0]; u[1] = 0.5f * (w[0] + w[1] + w[2]); u[2] = 0.5f * (w[0] - w[1] + w[2]); u[3] = w[2];
   }
   // A (4x2): the gradient of the output transform, dM = A dY A^T
@@ -93,6 +97,7 @@ struct Wino<4> {
   }
   // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
   static __device__ __forceinline__ void g(const float (&w)[3], float (&u)[6]) {
+#pragma clang fp contract(off)
     const float s = w[0] + w[2];
     u[0] = 0.25f * w[0];
     u[1] = (-1.f / 6.f) * (s + w[1]);
@@ -314,7 +319,7 @@ __device__ __forceinline__ void wino_weight_body(const float* __restrict__ w, fl
   for (int pass = 0; pass < 2; ++pass) {
     const bool r = pass ? true : (rot != 0);
     float* out = pass ? u2 : u;
-    if (pass && !u2) break;
+    if (!out) continue;
     float t[3][P];  // t[b][a] = (G g)[a][b]
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
@@ -334,6 +339,87 @@ __device__ __forceinline__ void wino_weight_body(const float* __restrict__ w, fl
   }
 }
 
+// The same transform written as the forward product kernel's pre-split B operand (gemm_x3.hip FragB: three bf16 planes in
+// MFMA-fragment order, [n block][16-k step][plane][lane][8 bf16]; B(k = ci, n = co)) instead of fp32 [xi][cin][cout].
+// One thread per dword = two consecutive k of one column n, for all (M+2)^2 points and the three planes; a wave covers 16 columns x
+// 4 k-pairs, so each of its stores fills sixteen whole 16-byte lane slots (256 contiguous bytes).  Threads of padding columns
+// (n >= cout, inside the last 32-block) write zeros.  The arithmetic is Wino<M>::g twice, as in wino_weight_body: the same bits
+// (g compiles without contraction).
+__device__ __forceinline__ void split3w(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
+  h1 = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h1);
+  h2 = __float_as_uint(r1) & 0xffff0000u;
+  h3 = __float_as_uint(r1 - __uint_as_float(h2));
+}
+template <int M>
+__device__ __forceinline__ void wino_weight_frag_body(const float* __restrict__ w, unsigned* __restrict__ out, int cin, int cout, int blk) {
+  constexpr int P = M + 2;
+  const int nb16 = ((cout + 31) / 32) * 2, ks16 = cin / 16;
+  const int64_t i = (int64_t)blk * NT + threadIdx.x;
+  if (i >= (int64_t)(cin / 2) * nb16 * 16) return;
+  const int nl = (int)(i & 15), q = (int)((i >> 4) & 3);
+  const int64_t rest = i >> 6;
+  const int n = (int)(rest % nb16) * 16 + nl, k = (int)(rest / nb16) * 8 + 2 * q;
+  const int64_t kn = (int64_t)cin * cout;
+  float g9[2][3][3];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) g9[e][a][b] = n < cout ? w[(size_t)(a * 3 + b) * kn + (int64_t)(k + e) * cout + n] : 0.f;      // w[tap][ci][co]
+  float t[2][3][P];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float col[3] = {g9[e][0][b], g9[e][1][b], g9[e][2][b]};
+      Wino<M>::g(col, t[e][b]);
+    }
+  // dword (n, k pair) of batch xi, plane p: ((((n / 32) ks16 + k / 16) 3 + p) 64 + (n % 32) + 32 ((k / 8) % 2)) 4 + (k % 8) / 2
+  const size_t bstride = (size_t)(nb16 / 2) * ks16 * 768;      // dwords per batch
+  unsigned* o = out + ((size_t)(n >> 5) * ks16 + (k >> 4)) * 768 + ((n & 31) + 32 * ((k >> 3) & 1)) * 4 + ((k & 7) >> 1);
+#pragma unroll
+  for (int a = 0; a < P; ++a) {
+    float oe[2][P];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float row[3] = {t[e][0][a], t[e][1][a], t[e][2][a]};
+      Wino<M>::g(row, oe[e]);
+    }
+#pragma unroll
+    for (int b = 0; b < P; ++b) {
+      unsigned h0[3], h1[3];
+      split3w(oe[0][b], h0[0], h0[1], h0[2]);
+      split3w(oe[1][b], h1[0], h1[1], h1[2]);
+      unsigned* ob = o + (size_t)(a * P + b) * bstride;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ob[p * 256] = __builtin_amdgcn_perm(h1[p], h0[p], 0x07060302u);      // (the lower k in the low half)
+    }
+  }
+}
+// blocks of a kernel-transform launch: [fp32 outputs (u and / or u2) | U as a fragment image], each part optional
+struct WeightArgs {
+  const float* w; float* u; float* u2; int64_t kn; int rot;
+  unsigned* uf; int cin, cout;      // fragment-ordered U (null: not wanted)
+};
+__host__ __device__ inline int weight_blocks_f32(const WeightArgs& wa) { return (wa.u || wa.u2) ? (int)((wa.kn + NT - 1) / NT) : 0; }
+__host__ __device__ inline int weight_blocks_frag(const WeightArgs& wa) {
+  return wa.uf ? (int)(((int64_t)(wa.cin / 2) * ((wa.cout + 31) / 32) * 32 + NT - 1) / NT) : 0;
+}
+__host__ __device__ inline int weight_blocks(const WeightArgs& wa) { return weight_blocks_f32(wa) + weight_blocks_frag(wa); }
+template <int M>
+__device__ __forceinline__ void wino_weight_any_body(const WeightArgs& wa, int blk) {
+  const int n0 = weight_blocks_f32(wa);
+  if (blk < n0) wino_weight_body<M>(wa.w, wa.u, wa.u2, wa.kn, wa.rot, blk);
+  else wino_weight_frag_body<M>(wa.w, wa.uf, wa.cin, wa.cout, blk - n0);
+}
+
+template <int M>
+__global__ __launch_bounds__(NT) void wino_weight_any_kernel(const WeightArgs wa) {
+  wino_weight_any_body<M>(wa, blockIdx.x);
+}
+
 template <int M>
 __global__ __launch_bounds__(NT) void wino_dw_kernel(const float* __restrict__ du, float* __restrict__ dw, int64_t kn, int nsplit,
                                                     int accumulate) {
@@ -350,7 +436,6 @@ __global__ __launch_bounds__(NT) void wino_weight_kernel(const float* __restrict
 //   forward  : input transform of x            | kernel transform (+ the rotated one kept for backward)
 //   backward : B^T dy B (for the data gradient) | A dy A^T (for the weight gradient)      -- both read dy
 //   backward : output transform -> dx           | G^T dU G -> dw
-struct WeightArgs { const float* w; float* u; float* u2; int64_t kn; int rot; };
 struct DwArgs2 { const float* du; float* dw; int64_t kn; int nsplit, accumulate; };
 
 template <int M, int W>
@@ -420,6 +505,15 @@ int width_for(int64_t tiles, int c) {
     else if (WIDTH == 2) hipLaunchKernelGGL((KERNEL<M, 2>), dim3(grid_for((TOTAL_C) / 2)), dim3(NT), 0, st, ARGS); \
     else hipLaunchKernelGGL((KERNEL<M, 1>), dim3(grid_for(TOTAL_C)), dim3(NT), 0, st, ARGS);                       \
   } while (0)
+
+// bytes of the forward pass's transformed kernel U (p2 points) in the workspace: fp32 [p2][cin][cout], or the forward product
+// kernel's pre-split fragment image (6 bytes per element, the columns padded to 32: gemm_x3.hip FragB) -- whichever the run-time
+// switches pick, the region holds either
+size_t u_bytes(size_t p2, int cin, int cout) {
+  size_t b = (size_t)cin * cout * 4;
+  if (cin % 16 == 0 && rn::x3_bfrag_bytes(cin, cout) > b) b = rn::x3_bfrag_bytes(cin, cout);
+  return p2 * b;
+}
 
 size_t tiles_of(const rn_conv_seg* segs, int nseg, int m) {
   size_t tiles = 0;
@@ -518,7 +612,7 @@ extern "C" int rn_conv3x3_winograd_wgrad(const rn_conv_seg* segs, int nseg, int 
 extern "C" size_t rn_conv3x3_winograd_workspace(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile) {
   if (!segs || nseg < 1 || nseg > RN_MAX_SEG || (tile != 2 && tile != 4)) return 0;
   const size_t tiles = tiles_of(segs, nseg, tile), p2 = (size_t)(tile + 2) * (tile + 2);
-  return rn::align_up(p2 * cin * cout * 4, 256) + rn::align_up(p2 * tiles * cin * 4, 256) + rn::align_up(p2 * tiles * cout * 4, 256);
+  return rn::align_up(u_bytes(p2, cin, cout), 256) + rn::align_up(p2 * tiles * cin * 4, 256) + rn::align_up(p2 * tiles * cout * 4, 256);
 }
 
 // dgrad == 0: y = conv3x3_same(x, w) + bias.   dgrad != 0: dx = conv3x3_same(dy, rot180(w)^T)  (w is always
@@ -536,7 +630,7 @@ extern "C" int rn_conv3x3_winograd(const rn_conv_seg* segs, int nseg, int cin, i
   }
   const size_t p2 = (size_t)(tile + 2) * (tile + 2);
   float* U = (float*)workspace;
-  float* V = (float*)((char*)workspace + rn::align_up(p2 * cin * cout * 4, 256));
+  float* V = (float*)((char*)workspace + rn::align_up(u_bytes(p2, cin, cout), 256));
   float* Mb = (float*)((char*)V + rn::align_up(p2 * ia.total_tiles * ia.c * 4, 256));
   hipStream_t st = (hipStream_t)stream;
   return tile == 2 ? run<2>(ia, oa, cin, cout, w, bias, dgrad != 0, U, V, Mb, v_buf, urot_buf, st)
@@ -1164,9 +1258,10 @@ constexpr int chunk_waves() { return W <= 2 ? 3 : 1; }
 template <int M, int W, template <int> class LT>
 __global__ __launch_bounds__(chunk_threads<W>()) void wino_gn_fwd_pre_kernel(const CArgs in, const Fold f, const WeightArgs wa,
                                                                                int nb_chunk, int slabs) {
-  const int b = blockIdx.x;
-  if (b < nb_chunk) chunk_input_body<M, W, LT>(in, f, b / slabs, b % slabs);
-  else wino_weight_body<M>(wa.w, wa.u, wa.u2, wa.kn, wa.rot, b - nb_chunk);
+  // (the kernel-transform blocks FIRST: they are the longer ones -- 100+ stores per thread -- and would otherwise be the launch's tail)
+  const int nb_w = (int)gridDim.x - nb_chunk, b = (int)blockIdx.x - nb_w;
+  if (b >= 0) chunk_input_body<M, W, LT>(in, f, b / slabs, b % slabs);
+  else wino_weight_any_body<M>(wa, (int)blockIdx.x);
 }
 template <int M, int W, template <int> class LT>
 __global__ __launch_bounds__(chunk_threads<W>()) void wino_gn_input_kernel(const CArgs in, const Fold f, int slabs) {
@@ -1254,7 +1349,20 @@ int run_gn_fwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float
   if (v_buf) V = v_buf;
   ia.buf = V;
   const int64_t kn = (int64_t)cin * cout;
-  const WeightArgs wa = {w, U, urot_buf, kn, 0};
+  // the kernel transform writes U as the forward product kernel's pre-split fragment-ordered operand where that kernel takes one
+  // (rn::x3_bfrag_ok: product mode 1, cin % 16 == 0): the same workspace region, 6 instead of 4 bytes per element.  Urot (kept for the
+  // backward pass) stays fp32: the data-gradient product reads its kernel operand k-contiguous, whole 16-byte fragments from LDS, and
+  // gains nothing from the image (measured: 25.9 vs 25.8 us; the forward product 25.7 vs 27.8 us)
+  const bool u_frag = rn::x3_bfrag_ok(ia.total_tiles, cin, cout);
+  WeightArgs wa = {w, u_frag ? nullptr : U, urot_buf, kn, 0, u_frag ? (unsigned*)U : nullptr, cin, cout};
+  // the caller transformed the kernel ahead of the layer (rn_conv3x3_winograd_gn_weights: once per step, off the layers' critical
+  // path): no kernel-transform blocks in this launch
+  if (gn->u_ready) {
+    RN_UNSUPPORTED(u_frag != rn::x3_bfrag_format(cin, cout), "winograd gn: the prepared kernel transform has another format than this launch needs");
+    U = (float*)gn->u_ready;
+    wa.u = nullptr; wa.uf = nullptr;
+  }
+  if (gn->urot_ready) wa.u2 = nullptr;
   Fold fi = {};
   const bool fold_in = gn->in_rows != nullptr;
   if (fold_in) {
@@ -1262,11 +1370,15 @@ int run_gn_fwd(const rn_conv_seg* segs, int nseg, int cin, int cout, const float
     fi.act = gn->in_act; fi.eps = gn->in_eps;
   }
   const int wi = chunk_width(ia.total_tiles, cin, fold_in ? fi.cpg : 0);
-  const int slabs_in = cin / (CK_LANES * wi), nb_chunk = ia.total_chunks * slabs_in, nb_w = (int)rn::ceil_div64(kn, NT);
+  const int slabs_in = cin / (CK_LANES * wi), nb_chunk = ia.total_chunks * slabs_in, nb_w = weight_blocks(wa);
   if (fold_in) RN_WGN(wi, hipLaunchKernelGGL((wino_gn_fwd_pre_kernel<M, W, LoadGnAct>), dim3(nb_chunk + nb_w), dim3(chunk_threads<W>()), 0, st, ia, fi, wa, nb_chunk, slabs_in));
   else RN_WGN(wi, hipLaunchKernelGGL((wino_gn_fwd_pre_kernel<M, W, LoadPlain>), dim3(nb_chunk + nb_w), dim3(chunk_threads<W>()), 0, st, ia, fi, wa, nb_chunk, slabs_in));
   RN_LAUNCH_CHECK();
-  if (int e = rn::launch_batched_gemm(V, U, Mb, ia.total_tiles, cin, cout, P2, 0, st)) return e;
+  if (u_frag) {
+    if (int e = rn::launch_batched_gemm_x3_bfrag(V, U, Mb, ia.total_tiles, cin, cout, P2, 1, st)) return e;
+  } else if (int e = rn::launch_batched_gemm(V, U, Mb, ia.total_tiles, cin, cout, P2, 0, st)) {
+    return e;
+  }
   if (!gn->out_rows) {  // no statistics wanted: the grid-stride output transform (any cout % 4 == 0, e.g. the 720 class maps)
     WArgs wia = {}, woa = {};
     if (int e = fill(segs, nseg, cin, cout, M, false, &wia, &woa)) return e;
@@ -1395,6 +1507,32 @@ int check_fold(const rn_conv_seg* segs, int nseg, int cin, int cout, int tile) {
 }
 }  // namespace
 
+// The kernel transforms of a folded layer ahead of the layer: U in the format its forward product reads (fp32 [P][cin][cout], or the
+// pre-split fragment image when rn_x3_bfrag_ok) -> u_out (rn_conv3x3_winograd_gn_u_bytes), the rotated kernel's transform (fp32, for
+// the data gradient) -> urot_out (rn_conv3x3_winograd_keep_bytes' urot_bytes; NULL: not wanted).  Pass them to
+// rn_conv3x3_winograd_gn as gn->u_ready / urot_buf + gn->urot_ready.
+extern "C" size_t rn_conv3x3_winograd_gn_u_bytes(int cin, int cout, int tile) {
+  if (cin < 1 || cout < 1 || (tile != 2 && tile != 4)) return 0;
+  return u_bytes((size_t)(tile + 2) * (tile + 2), cin, cout);
+}
+extern "C" int rn_conv3x3_winograd_gn_weights(const float* w, int cin, int cout, int tile, void* u_out, size_t u_out_bytes, float* urot_out,
+                                              rn_stream_t stream) {
+  RN_CHECK_ARG(w && u_out && (tile == 2 || tile == 4), "winograd gn weights: bad argument");
+  RN_UNSUPPORTED(cin % CK_MAXCH != 0 || cout % 4 != 0, "winograd gn weights: cin %d must be a multiple of %d, cout %d of 4", cin, CK_MAXCH, cout);
+  const size_t need = rn_conv3x3_winograd_gn_u_bytes(cin, cout, tile);
+  if (u_out_bytes < need) {
+    rn::set_error("winograd gn weights: u_out %zu < %zu bytes", u_out_bytes, need);
+    return RN_EWORKSPACE;
+  }
+  const bool u_frag = rn::x3_bfrag_format(cin, cout);
+  const WeightArgs wa = {w, u_frag ? nullptr : (float*)u_out, urot_out, (int64_t)cin * cout, 0, u_frag ? (unsigned*)u_out : nullptr, cin, cout};
+  hipStream_t st = (hipStream_t)stream;
+  if (tile == 2) hipLaunchKernelGGL(wino_weight_any_kernel<2>, dim3((unsigned)weight_blocks(wa)), dim3(NT), 0, st, wa);
+  else hipLaunchKernelGGL(wino_weight_any_kernel<4>, dim3((unsigned)weight_blocks(wa)), dim3(NT), 0, st, wa);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
 extern "C" int rn_conv3x3_winograd_gn_bwd_wgrad(const rn_conv_seg* segs, int nseg, int cin, int cout, float* dw, int accumulate, int tile,
                                                 void* workspace, size_t workspace_bytes, const float* v_buf, int urot_was_given,
                                                 rn_stream_t stream) {
@@ -1429,7 +1567,7 @@ extern "C" int rn_conv3x3_winograd_gn(const rn_conv_seg* segs, int nseg, int cin
   const size_t p2 = (size_t)(tile + 2) * (tile + 2), tiles = tiles_of(segs, nseg, tile);
   RN_UNSUPPORTED((double)tiles * (cin > cout ? cin : cout) * 4.0 >= 2147483648.0, "winograd gn: a transform plane is >= 2 GiB");
   float* U = (float*)workspace;
-  float* V = (float*)((char*)workspace + rn::align_up(p2 * cin * cout * 4, 256));
+  float* V = (float*)((char*)workspace + rn::align_up(u_bytes(p2, cin, cout), 256));
   float* Mb = (float*)((char*)V + rn::align_up(p2 * tiles * cin * 4, 256));
   hipStream_t st = (hipStream_t)stream;
   return tile == 2 ? run_gn_fwd<2>(segs, nseg, cin, cout, w, bias, gn, U, V, Mb, v_buf, urot_buf, st)

@@ -522,6 +522,36 @@ def wino_tower_ok(xs, tower, out_w, groups):
     return 4 * (m + 2) ** 2 * (tiles * 2 * widest + widest * widest) <= WINOGRAD_MAX_WORKSPACE
 
 
+# Kernel transforms prepared ahead of the layers (rn_conv3x3_winograd_gn_weights; train.Trainer with RN_WINO_PRE=1, opt-in: measured
+# slower than transforming inside the layers' first launch, see train.Trainer.wino_pre): the layers' own launches then carry no
+# kernel-transform blocks.  {w.data_ptr(): (u_buf, urot_buf, event)}; set for the duration of ONE forward pass.
+WINO_PRE = {}
+
+
+class WinoPretransform(object):
+    """Persistent U / Urot buffers of a list of conv kernels [3,3,cin,cout] and the launches that fill them."""
+
+    def __init__(self, weights):
+        L = _rn.lib()
+        self.items = []
+        for w in weights:
+            cin, cout = int(w.shape[2]), int(w.shape[3])
+            ub = int(L.rn_conv3x3_winograd_gn_u_bytes(cin, cout, WINOGRAD_TILE))
+            u = torch.empty((ub + 3) // 4, dtype=torch.float32, device=w.device)
+            urot = torch.empty((WINOGRAD_TILE + 2) ** 2 * cin * cout, dtype=torch.float32, device=w.device)
+            self.items.append((w, u, urot))
+
+    def launch(self):
+        """The transforms on the CURRENT stream; returns the registry for ops.WINO_PRE (the event: recorded behind them)."""
+        L = _rn.lib()
+        for w, u, urot in self.items:
+            _rn.check(L.rn_conv3x3_winograd_gn_weights(_rn.f32(w), int(w.shape[2]), int(w.shape[3]), WINOGRAD_TILE, u.data_ptr(), u.numel() * 4,
+                                                       _rn.f32(urot), _rn.stream()), "rn_conv3x3_winograd_gn_weights")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return {w.data_ptr(): (u, urot, ev) for w, u, urot in self.items}, ev
+
+
 class _WinoTower(torch.autograd.Function):
     """k x [conv3x3 (no bias) -> GroupNorm -> activation] (+ optionally a final conv3x3 with bias) on n tensors that share
     every parameter, as k (+1) folded Winograd layers: see rn_conv3x3_winograd_gn.  Without the final conv the last
@@ -559,7 +589,14 @@ class _WinoTower(torch.autograd.Function):
                 g_out = gn_groups(cout, groups)
                 rows = torch.empty((nrows, g_out, 4), dtype=torch.float32, device=dev)
                 gn.out_rows, gn.out_groups = rows.data_ptr(), g_out
-            v_buf, u_buf = _winograd_keep_buffers(segs, n, w, training and WINOGRAD_WGRAD, training)
+            pre = WINO_PRE.get(w.data_ptr()) if WINO_PRE else None
+            if pre is not None:                         # U / Urot transformed ahead of the layer: no kernel-transform blocks here
+                torch.cuda.current_stream().wait_event(pre[2])
+                v_buf, _ = _winograd_keep_buffers(segs, n, w, training and WINOGRAD_WGRAD, False)
+                u_buf = pre[1]
+                gn.u_ready, gn.urot_ready = pre[0].data_ptr(), 1
+            else:
+                v_buf, u_buf = _winograd_keep_buffers(segs, n, w, training and WINOGRAD_WGRAD, training)
             need = L.rn_conv3x3_winograd_workspace(segs, n, cin, cout, tile)
             ws = _rn.workspace(need, dev)
             _rn.check(L.rn_conv3x3_winograd_gn(segs, n, cin, cout, _rn.f32(w), _rn.f32(b) if b is not None else None, tile,

@@ -133,6 +133,17 @@ class _Subnet(Model):
             return self.out_conv(blocks[-1][1].fused(raw, training, act=act))
         return None
 
+    def tower_kernels(self):
+        """The 3 x 3 kernels the folded Winograd path transforms (the four tower convs and the output conv), or [] while the
+        layers are not built / the path is off: train.Trainer transforms them once per step ahead of the layers
+        (ops.WinoPretransform)."""
+        blocks = [blk.layers for blk in self.pre_conv.layers]
+        ws = [b[0].weight for b in blocks] + [self.out_conv.weight]
+        if any(w is None or not w.is_cuda or w.dtype != torch.float32 or w.shape[0] != 3 or w.shape[1] != 3 or w.shape[2] % 64 or w.shape[3] % 4
+               for w in ws):
+            return []
+        return ws
+
     def _f16_tower(self, maps):
         """fp16 inference: the four [conv, GroupNorm, act] blocks with the GroupNorm STATISTICS taken from the conv's epilogue
         (ops_f16.conv2d_norm: no statistics pass over the conv output) on the levels where that pass costs -- the large maps,

@@ -340,6 +340,14 @@ class Trainer(object):
         if self.allreduce.active and use_graph and self.whole_step_graph and self.device.type == 'cuda':
             self.allreduce.probe_capturable(self.device)
         self.defer_wgrad = os.environ.get("RN_DEFER_WGRAD", "1") == "1" and self.device.type == 'cuda' and self.direct_param_grads
+        # OPT-IN (RN_WINO_PRE=1; measured SLOWER, kept as the record of the experiment): the Winograd kernel transforms of the head
+        # towers' 10 convs once per step on a side stream beside the backbone's forward pass, instead of inside every layer's first
+        # launch (ops.WinoPretransform).  Same kernels, same values -- the weights do not change between the optimizer's update and
+        # the forward pass that follows -- and the layers' launches lose their kernel-transform blocks (upper bound with the
+        # transforms skipped altogether: 491 -> 497 - 502 images/s), but ten more launches beside the backbone's latency-bound
+        # chain cost more than that: 471 - 485 against 488 - 494 images/s (profiles/r06_ab_runs.txt).
+        self.wino_pre = os.environ.get("RN_WINO_PRE", "0") == "1" and self.device.type == 'cuda'
+        self._wino_pre = None
         self._deferred_wgrads = []
         self._deferred_running = []
         self._graphs = None
@@ -477,7 +485,13 @@ class Trainer(object):
             self._stage_cuts = []
             self._parts = []
             ops.begin_direct_grad_step()       # a parameter's gradient slot may be written once per step from here on
-            logits = {'detection': self.net(features['image'], training=True)}
+            pre_ev = self._fork_kernel_transforms()
+            try:
+                logits = {'detection': self.net(features['image'], training=True)}
+            finally:
+                ops.WINO_PRE = {}
+            if pre_ev is not None:             # (joined even if no layer read them: a captured side stream must rejoin)
+                torch.cuda.current_stream().wait_event(pre_ev)
             if label_stream is not None:
                 torch.cuda.current_stream().wait_stream(label_stream)
             inp, logits = utils.process_labels_and_logits(labels=features, logits=logits, levels=self.levels)
@@ -501,6 +515,28 @@ class Trainer(object):
                 ops.run_deferred_wgrads(self._deferred_wgrads)
                 self._deferred_wgrads = []
             return class_loss.detach(), regr_loss.detach()
+
+    PRE_STREAM = 8                     # _rn.side_stream index of the tower kernels' transforms
+
+    def _fork_kernel_transforms(self):
+        """Launch the head towers' kernel transforms on their side stream (behind everything queued so far: the optimizer's update of
+        the previous step) and publish the buffers for this forward pass (ops.WINO_PRE).  Returns the event behind them, or None."""
+        if not self.wino_pre or not (ops.WINO_GN_FOLD and ops.WINOGRAD):
+            return None
+        if self._wino_pre is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None                    # (built by the eager steps in front of a capture; never allocate inside one)
+            base = getattr(self.net, 'base', self.net)
+            subnets = [getattr(base, n, None) for n in ('classification_subnet', 'regression_subnet')]
+            kernels = [w for sn in subnets if sn is not None and hasattr(sn, 'tower_kernels') for w in sn.tower_kernels()]
+            if not kernels:
+                return None
+            self._wino_pre = ops.WinoPretransform(kernels)
+        side = _rn.side_stream(self.device, self.PRE_STREAM)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.WINO_PRE, ev = self._wino_pre.launch()
+        return ev
 
     def num_parts(self):
         """Parts of segment B planned by the last segment_a (1 without stage cuts, 0 without any cut)."""

@@ -349,6 +349,38 @@ def test_deferred_tower_weight_gradients_change_no_bit(dev, use_graph, monkeypat
     assert torch.equal(ta.arena.weights, tb.arena.weights)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_kernel_transforms_ahead_of_the_layers_change_no_bit(dev, use_graph, monkeypatch):
+    """RN_WINO_PRE=1 (opt-in: measured slower, DESIGN_EXPERIMENTS): the head towers' Winograd kernel transforms once per step on a side
+    stream in front of the forward pass (rn_conv3x3_winograd_gn_weights -> rn_wino_gn.u_ready / urot_ready) instead of inside every
+    layer's first launch: the same kernels on the same weights, so losses and weights after three steps are bit-identical."""
+    import dataset, layers, levels as levels_mod, retinanet, train
+    lv = levels_mod.build_levels()
+
+    def build(pre):
+        monkeypatch.setenv("RN_WINO_PRE", "1" if pre else "0")
+        layers.Dropout._next_seed[0] = 0x5EED
+        torch.manual_seed(4)
+        net = retinanet.RetinaNet('mobilenet_v2', lv, 4, layers.elu, 0.2).to(dev)
+        return train.Trainer(net, lv, loss_mode="focal", device=dev, use_graph=use_graph)
+
+    ta, tb = build(True), build(False)
+    assert ta.wino_pre and not tb.wino_pre
+    rng = np.random.default_rng(2)
+    size = 256
+    image = torch.from_numpy(rng.standard_normal((2, size, size, 3)).astype(np.float32)).to(dev)
+    boxes = torch.tensor([[[0.1, 0.2, 0.7, 0.8], [0.4, 0.1, 0.9, 0.5]]], device=dev)
+    cids = torch.tensor([[1, 3]], dtype=torch.int32, device=dev)
+    c, r, m = dataset.build_labels((size, size), cids, boxes, lv, 4, flip_pair=True)
+    feats = {"image": image, "detection": {"classifications": c, "regressions": r}, "trainable_masks": m}
+    for _ in range(3):
+        oa, ob = ta.step(feats), tb.step(feats)
+        assert oa["class_loss"].item() == ob["class_loss"].item() and oa["regr_loss"].item() == ob["regr_loss"].item()
+    torch.cuda.synchronize()
+    assert ta._wino_pre is not None and len(ta._wino_pre.items) == 10 and tb._wino_pre is None
+    assert torch.equal(ta.arena.weights, tb.arena.weights)
+
+
 def test_whole_step_graph_equals_segments_and_eager(dev):
     """One rank: segment A, segment B and the optimizer's update captured as ONE graph (Trainer.whole_step_graph) against the
     segments several ranks replay (two graphs + the eagerly launched update) and against eager launches: the same kernels on the

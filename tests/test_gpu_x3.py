@@ -290,3 +290,86 @@ np.save(sys.argv[2], np.stack([y.cpu().numpy(), z.cpu().numpy()]))
         outs.append(np.load(out))
     assert np.array_equal(outs[0], outs[1])
     assert np.isfinite(outs[0]).all() and abs(float(outs[0][1].mean())) < 1e-3       # (the normalised output: zero mean per group)
+
+
+# ---- the kernel operand pre-split in fragment order by its producer (gemm_x3.hip FragB, include/rn_hip.h rn_x3_*bfrag*) ----
+@pytest.fixture()
+def bfrag_switch():
+    import _rn
+    L = _rn.lib()
+    before = L.rn_get_x3_bfrag()
+    yield L.rn_set_x3_bfrag
+    L.rn_set_x3_bfrag(before)
+
+
+@pytest.mark.parametrize("M,K,N,nb,b_nk,wide", [(682, 256, 256, 4, 0, False), (682, 256, 256, 3, 1, False), (682, 256, 720, 2, 0, False),
+                                                (682, 720, 256, 2, 1, False), (682, 256, 36, 3, 0, False), (100, 32, 64, 5, 0, False),
+                                                (64, 1024, 128, 2, 1, False), (37, 48, 20, 3, 0, False), (300, 256, 256, 2, 0, True),
+                                                (300, 256, 256, 2, 1, True), (5000, 64, 256, 1, 0, False)])
+def test_products_with_a_fragment_ordered_operand_are_bit_identical(dev, product_mode, bfrag_switch, M, K, N, nb, b_nk, wide):
+    """rn_x3_pack_bfrag + rn_gemm_batched_bfrag against rn_gemm_batched on the same fp32 operands (product mode 1): the same three
+    bf16 planes and the same matrix-core instructions in the same order -- every output bit equal; K = 720 ends in a half K-step
+    (zeros past K), N = 720 / 36 / 20 end inside a 32-column block (zero padding columns)."""
+    import ctypes as C
+    import _rn
+    L = _rn.lib()
+    product_mode(1)
+    bfrag_switch(1)
+    assert L.rn_x3_bfrag_ok(M, K, N) == 1
+    rng = np.random.default_rng(M + K + N + b_nk)
+    Ad = _t(_operands(rng, (nb, M, K), wide), dev)
+    Bd = _t(_operands(rng, (nb, N, K) if b_nk else (nb, K, N), wide), dev)
+    want = torch.full((nb, M, N), float("nan"), device=dev)
+    _rn.check(L.rn_gemm_batched(_rn.f32(Ad), _rn.f32(Bd), _rn.f32(want), M, K, N, nb, b_nk, _rn.stream()), "rn_gemm_batched")
+    nbytes = L.rn_x3_bfrag_bytes(K, N, nb)
+    assert nbytes == nb * ((N + 31) // 32) * 32 * K * 6
+    img = torch.full((nbytes,), 0xff, dtype=torch.uint8, device=dev)          # (NaN patterns wherever the pack kernel does not write)
+    _rn.check(L.rn_x3_pack_bfrag(_rn.f32(Bd), img.data_ptr(), K, N, nb, b_nk, _rn.stream()), "rn_x3_pack_bfrag")
+    for fwd_name in (0, 1):
+        got = torch.full((nb, M, N), float("nan"), device=dev)
+        _rn.check(L.rn_gemm_batched_bfrag(_rn.f32(Ad), img.data_ptr(), _rn.f32(got), M, K, N, nb, fwd_name, _rn.stream()), "rn_gemm_batched_bfrag")
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), float((got - want).abs().max())
+    # switched off (or mode 0, or K % 16 != 0): the entry refuses instead of misreading the operand
+    bfrag_switch(0)
+    assert L.rn_x3_bfrag_ok(M, K, N) == 0
+    assert L.rn_gemm_batched_bfrag(_rn.f32(Ad), img.data_ptr(), _rn.f32(got), M, K, N, nb, 0, _rn.stream()) != 0
+    bfrag_switch(1)
+    assert L.rn_x3_bfrag_ok(M, 36, N) == 0 and L.rn_x3_bfrag_bytes(36, N, 1) == 0
+
+
+@pytest.mark.parametrize("shapes,cout", [([(2, 64, 64), (2, 32, 32), (2, 16, 16), (2, 8, 8), (2, 4, 4)], 256), ([(2, 24, 40), (2, 7, 5)], 720),
+                                         ([(1, 20, 12)], 36)])
+@pytest.mark.parametrize("keep", [True, False])
+def test_folded_winograd_layers_fragment_ordered_kernel_is_bit_identical(dev, product_mode, bfrag_switch, shapes, cout, keep, monkeypatch):
+    """GroupNorm-folded head-tower layers (ops.wino_tower: the kernel transform writes U as the forward product's fragment image)
+    with the switch on against off: outputs, input gradients and weight gradients bit-equal -- the two kernel-transform bodies
+    compute the same bits (Wino<M>::g compiles without contraction), the product is bit-identical on equal operands (above).
+    cout = 720 / 36: the class / box output convs (columns padded inside the last 32-block).  keep = False: the backward pass
+    rebuilds V and Urot itself."""
+    import _rn
+    import ops
+    L = _rn.lib()
+    product_mode(1)
+    monkeypatch.setattr(ops, "WINOGRAD_KEEP", keep)
+    torch.manual_seed(3)
+    cin = 256
+    xs0 = [torch.randn(n, h, w, cin, device=dev) for n, h, w in shapes]
+    tower = [(torch.randn(3, 3, cin, cin, device=dev) * 0.03, torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1) for _ in range(2)]
+    w_out = torch.randn(3, 3, cin, cout, device=dev) * 0.03
+    b_out = torch.randn(cout, device=dev) * 0.1
+    res = []
+    for on in (0, 1):
+        bfrag_switch(on)
+        assert L.rn_x3_bfrag_ok(100, cin, cin) == on
+        xs = [x.clone().requires_grad_(True) for x in xs0]
+        tw = [tuple(t.clone().requires_grad_(True) for t in layer) for layer in tower]
+        wo, bo = w_out.clone().requires_grad_(True), b_out.clone().requires_grad_(True)
+        assert ops.wino_tower_ok(xs, tw, wo, 32)
+        ys = ops.wino_tower(xs, tw, wo, bo, 32, 1e-5, "elu")
+        loss = sum((y * torch.cos(torch.arange(y.numel(), device=dev, dtype=torch.float32).reshape(y.shape) * 0.37)).sum() for y in ys)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append([y.detach() for y in ys] + [x.grad for x in xs] + [t.grad for layer in tw for t in layer] + [wo.grad, bo.grad])
+    for a, b in zip(*res):
+        assert a is not None and b is not None
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), float((a - b).abs().max())

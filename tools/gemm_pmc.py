@@ -31,12 +31,21 @@ nsplit = C.c_int(0)
 img = torch.randn(2, 512, 512, 3, device=dev)
 w_stem = torch.randn(3, 3, 3, 32, device=dev) * 0.1
 gamma, beta = torch.ones(32, device=dev), torch.zeros(32, device=dev)
+# product mode 1: the forward product with its kernel operand pre-split in fragment order (what the training step runs: the Winograd
+# kernel transform writes U that way; here rn_x3_pack_bfrag does, a kernel of another name)
+frag = bool(L.rn_get_product_mode()) and bool(L.rn_x3_bfrag_ok(tiles, 256, 256))
+if frag:
+    Bf = torch.empty(L.rn_x3_bfrag_bytes(256, 256, 36), dtype=torch.uint8, device=dev)
+    _rn.check(L.rn_x3_pack_bfrag(_rn.f32(B), Bf.data_ptr(), 256, 256, 36, 0, _rn.stream()), "rn_x3_pack_bfrag")
 for _ in range(30):
-    _rn.check(L.rn_gemm_batched(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, 36, 0, _rn.stream()), "rn_gemm_batched")
+    if frag:
+        _rn.check(L.rn_gemm_batched_bfrag(_rn.f32(A), Bf.data_ptr(), _rn.f32(Cm), tiles, 256, 256, 36, 1, _rn.stream()), "rn_gemm_batched_bfrag")
+    else:
+        _rn.check(L.rn_gemm_batched(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, 36, 0, _rn.stream()), "rn_gemm_batched")
     _rn.check(L.rn_winograd_bwd_products(_rn.f32(A), _rn.f32(B), _rn.f32(Cm), tiles, 256, 256, _rn.f32(A), _rn.f32(dM), 256, 256, 36,
                                          ws.data_ptr(), ws.numel(), C.byref(nsplit), _rn.stream()), "rn_winograd_bwd_products")
     with torch.no_grad():
         y = ops.conv2d(img, w_stem, None, 2, gn=(32, 1e-5))
         ops.group_norm_act(y, gamma, beta, groups=32, act="elu", drop_rate=0.2, seed=1)
 torch.cuda.synchronize()
-print("tiles", tiles, "nsplit", nsplit.value)
+print("tiles", tiles, "nsplit", nsplit.value, "fragment-ordered kernel operand", frag)

@@ -45,3 +45,18 @@ for mode in (0, 1, 0, 1):
     gf = 2.0 * P * M * K * N / 1e9
     print("mode %d: forward product %.1f us (%.1f TFLOP/s fp32-equivalent), dgrad %.1f us, backward products (dgrad + wgrad) %.1f us (%d slabs; %.1f TFLOP/s)"
           % (mode, f, gf / f * 1e3, d, b, ns.value, 2 * gf / b * 1e3))
+
+# the forward product's kernel operand pre-split in fragment order by its producer (rn_x3_pack_bfrag once, outside the timed launches:
+# inside the network the Winograd kernel transform writes it); for the data-gradient product (b_nk = 1) the same image layout is
+# measured too -- it gains nothing there (its fp32 operand is k-contiguous: whole 16-byte fragments from LDS), so the network keeps Urot fp32
+L.rn_set_product_mode(1)
+if L.rn_x3_bfrag_ok(M, K, N):
+    img0 = torch.empty(L.rn_x3_bfrag_bytes(K, N, P), dtype=torch.uint8, device=dev)
+    img1 = torch.empty_like(img0)
+    _rn.check(L.rn_x3_pack_bfrag(_rn.f32(B), img0.data_ptr(), K, N, P, 0, _rn.stream()), "pack")
+    _rn.check(L.rn_x3_pack_bfrag(_rn.f32(B), img1.data_ptr(), K, N, P, 1, _rn.stream()), "pack")
+    for _ in range(2):
+        f = timed(lambda: _rn.check(L.rn_gemm_batched_bfrag(_rn.f32(A), img0.data_ptr(), _rn.f32(Cc), M, K, N, P, 1, _rn.stream()), "fwd"))
+        d = timed(lambda: _rn.check(L.rn_gemm_batched_bfrag(_rn.f32(A), img1.data_ptr(), _rn.f32(Cc), M, K, N, P, 0, _rn.stream()), "dgrad"))
+        print("mode 1, kernel operand pre-split in fragment order: forward product %.1f us (%.1f TFLOP/s fp32-equivalent), dgrad %.1f us"
+              % (f, gf / f * 1e3, d))
