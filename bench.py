@@ -53,8 +53,8 @@ TRAIN_GFLOP_PER_IMAGE = 239.2       # BASELINE.md section 3 (3 x forward conv FL
 # whole number of tiles).  EXECUTED = (39.87 - 38.268) + 38.268 / 4 = 11.169 GMAC forward -> x 2 FLOP x 3 passes:
 EXECUTED_TRAIN_GFLOP_PER_IMAGE = 67.0
 # name prefix and grid of the forward product launch of a head-tower layer in a rocprofv3 trace (the `roofline` kernel)
-X3_FWD_KERNEL = "gemm_x3_kernel<false, true, 2, 2, false, false>"          # fp32 kernel operand, split inside the product kernel
-X3_FWD_KERNEL_BFRAG = "gemm_x3_kernel<false, true, 2, 2, false, true>"      # kernel operand pre-split in fragment order by the kernel transform
+X3_FWD_KERNEL = "gemm_x3_kernel<false, true, 2, 2, false>"                # fp32 kernel operand, split inside the product kernel (csrc/gemm_x3.hip)
+X3_FWD_KERNEL_BFRAG = "gemm_x3_bfrag_kernel<true, 2, 2, false>"             # kernel operand pre-split in fragment order by the kernel transform (csrc/gemm_x3_bfrag.hip)
 X3_FWD_GRID = lambda tiles: 36 * (-(-tiles // 128)) * 2       # noqa: E731
 PRODUCT_REPS = 8                    # back-to-back launches per graph when the product kernels are timed alone (_graph_time)
 FP16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak
@@ -275,7 +275,7 @@ def roofline_kernels(device):
             return e
 
         fwd = x3_entry(entry("head-tower layer, forward products (largest in-step kernel: 17 launches per step)",
-                             "gemm_x3_kernel: 36 x [682x256]x[256x256], fp32 operands split into 3 bf16, 6 bf16 MFMA products, fp32 accumulate",
+                             ("gemm_x3_bfrag_kernel" if bfrag else "gemm_x3_kernel") + ": 36 x [682x256]x[256x256], fp32 operands split into 3 bf16, 6 bf16 MFMA products, fp32 accumulate",
                              "mfma", flops, fwd_ms, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", fwd_bytes, "fwd_products",
                              prof=(X3_FWD_KERNEL_BFRAG if bfrag else X3_FWD_KERNEL, X3_FWD_GRID(tiles))), flops, fwd_ms)
         fwd["kernel_operand"] = ("pre-split into 3 bf16 planes in MFMA-fragment order by the Winograd kernel transform (6 B / element, read straight "

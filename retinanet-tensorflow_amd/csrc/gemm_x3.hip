@@ -28,155 +28,7 @@
 
 namespace {
 using namespace rn_tiles;
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
-
-constexpr int XK = 32, XT = 256;
-constexpr int LDR = 40;               // halfs per LDS row of a KC tile: 32 k + 8 pad = 80 bytes
-
-struct X3Op { const float* p; long bstride; int ld, rows; };
-struct X3Args {
-  X3Op a, b;
-  float* c; long c_bstride, c_sstride; int ldc;
-  int K, chunk, nsplit, nbatch, tiles_m, tiles_n;
-  float2* stat;       // dense 1x1 convs (rn::launch_conv1x1_fwd_x3): per (m-tile, column) sums (sum y, sum y^2) over the tile's rows -> stat[tile_m * ldc + col]
-                      // (the GroupNorm statistic rows of conv_gemm.hip's conv_stats_epilogue, same layout); nullptr: off
-  // dense 1x1 convs followed by a Dropout (DenseNet's composite function, densenet.py:61-67): the mask of rn_dropout -- keep element i of the
-  // output tensor iff uniform01(seed + *seed_dev, i) >= rate, scaled by 1 / (1 - rate) -- applied to the accumulators before they are stored
-  // and summed: the conv's output never exists un-dropped, `stat` holds the sums of the DROPPED tensor.  rate == 0: off
-  float drop_rate, drop_keep; uint64_t drop_seed; const uint64_t* drop_seed_dev;
-  // B_FRAG kernels: Op2 comes pre-split and in MFMA-fragment order (see `FragB` below) -- `bfrag` per batch `bfrag_bstride` bytes apart,
-  // `b_nblk` 32-row blocks x `b_ks16` 16-k steps; b.rows (the column bound of the epilogue) as ever, b.p / b.ld unused
-  const void* bfrag; long bfrag_bstride; int b_nblk, b_ks16;
-  int dbg;      // RN_X3_DBG (timing aid, wrong results): bit 0 no MFMAs, bit 1 no split / LDS stores, bit 2 no global loads after the first, bit 3 no fragment reads, bit 4 the dword epilogue
-};
-
-// x = h1 + h2 + h3 exactly, each with <= 8 significant bits (fp32 bit patterns whose low 16 bits are zero)
-__device__ __forceinline__ void split3(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
-  h1 = __float_as_uint(x) & 0xffff0000u;
-  const float r1 = x - __uint_as_float(h1);
-  h2 = __float_as_uint(r1) & 0xffff0000u;
-  h3 = __float_as_uint(r1 - __uint_as_float(h2));
-}
-// two bf16 (the high halves of lo and hi) in one dword, lo in the low half (the lower k)
-__device__ __forceinline__ unsigned pack_hi(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
-
-// One operand tile [ROWS rows][32 k] (ROWS = 64 or 128): ROWS / 32 float4 loads per thread either way.
-//   KC (k contiguous in memory): 4 consecutive k of rows t/8 + 32 i  -> LDS [row][k] bf16, 80-byte rows: a lane's MFMA fragment
-//      (8 consecutive k of one row) is ONE ds_read_b128
-//   KS (rows contiguous in memory): rows 4 (t%16) + 64 i2 .. +3 at k = 2 (t/16) and 2 (t/16) + 1 -> LDS [k pair][row] dwords (a
-//      dword = the bf16 pair (k, k + 1) of one row; rows of ROWS + 4 dwords): the thread's four rows of a plane are ONE
-//      ds_write_b128, a fragment is four ds_read_b32 a k-pair apart (lanes = consecutive rows: conflict-free) -- the transpose
-//      costs nothing
-template <int ROWS>
-struct TileGeom {
-  static constexpr int PLANE = ROWS * LDR;        // halfs per plane (the KS image, 16 x (ROWS + 4) dwords, is smaller)
-  static constexpr int KS_LD = ROWS + 4;          // dwords per k-pair row of a KS tile
-  static constexpr int NQ = ROWS / 32;            // float4 per thread
-};
-template <bool KS, int ROWS>
-struct TileLoad {
-  typedef TileGeom<ROWS> G;
-  float4 q[G::NQ];
-  __device__ __forceinline__ void load(const __amdgpu_buffer_rsrc_t rs, const X3Op& op, int row0, int k0, int k1, int t) {
-    if (KS) {
-      const int k = k0 + (t >> 4) * 2;
-#pragma unroll
-      for (int i2 = 0; i2 < G::NQ / 2; ++i2) {
-        const int row = row0 + (t & 15) * 4 + 64 * i2;
-        const bool rok = row < op.rows;               // (rows % 4 == 0: a quad is inside or outside)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          q[2 * i2 + i] = Vec<4>::load(rs, (rok && k + i < k1) ? ((unsigned)(k + i) * (unsigned)op.ld + (unsigned)row) * 4u : OOB);
-      }
-    } else {
-      const int k = k0 + (t & 7) * 4;
-#pragma unroll
-      for (int i = 0; i < G::NQ; ++i) {
-        const int row = row0 + (t >> 3) + 32 * i;
-        q[i] = Vec<4>::load(rs, (row < op.rows && k < k1) ? ((unsigned)row * (unsigned)op.ld + (unsigned)k) * 4u : OOB);
-      }
-    }
-  }
-  // the three planes of this thread's values -> LDS (`tile`: the operand's plane 0; planes PLANE halfs apart)
-  __device__ __forceinline__ void store(unsigned short* tile, int t) const {
-    if (KS) {       // q[2 i2] = rows r..r+3 at k, q[2 i2 + 1] = the same rows at k + 1
-#pragma unroll
-      for (int i2 = 0; i2 < G::NQ / 2; ++i2) {
-        const float v[8] = {q[2 * i2].x, q[2 * i2].y, q[2 * i2].z, q[2 * i2].w, q[2 * i2 + 1].x, q[2 * i2 + 1].y, q[2 * i2 + 1].z, q[2 * i2 + 1].w};
-        unsigned h[3][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) split3(v[j], h[0][j], h[1][j], h[2][j]);
-        unsigned* dst = reinterpret_cast<unsigned*>(tile) + (t >> 4) * G::KS_LD + (t & 15) * 4 + 64 * i2;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          u32x4 w;
-          w.x = pack_hi(h[p][0], h[p][4]); w.y = pack_hi(h[p][1], h[p][5]);
-          w.z = pack_hi(h[p][2], h[p][6]); w.w = pack_hi(h[p][3], h[p][7]);
-          *reinterpret_cast<u32x4*>(dst + p * (G::PLANE / 2)) = w;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < G::NQ; ++i) {
-        unsigned h[3][4];
-        split3(q[i].x, h[0][0], h[1][0], h[2][0]); split3(q[i].y, h[0][1], h[1][1], h[2][1]);
-        split3(q[i].z, h[0][2], h[1][2], h[2][2]); split3(q[i].w, h[0][3], h[1][3], h[2][3]);
-        unsigned short* dst = tile + ((t >> 3) + 32 * i) * LDR + (t & 7) * 4;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          u32x2v w;
-          w.x = pack_hi(h[p][0], h[p][1]); w.y = pack_hi(h[p][2], h[p][3]);
-          *reinterpret_cast<u32x2v*>(dst + p * G::PLANE) = w;
-        }
-      }
-    }
-  }
-};
-// a lane's fragment of k-step s (k = 16 s + 8 h .. + 7) of row `row` of the tile's plane p
-template <bool KS, int ROWS>
-__device__ __forceinline__ bf16x8 fragment(const unsigned short* tile, int p, int row, int h, int s) {
-  typedef TileGeom<ROWS> G;
-  if (KS) {
-    const unsigned* src = reinterpret_cast<const unsigned*>(tile) + p * (G::PLANE / 2) + (8 * s + 4 * h) * G::KS_LD + row;
-    u32x4 w;
-    w.x = src[0]; w.y = src[G::KS_LD]; w.z = src[2 * G::KS_LD]; w.w = src[3 * G::KS_LD];
-    return __builtin_bit_cast(bf16x8, w);
-  }
-  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tile + p * G::PLANE + row * LDR + s * 16 + h * 8));
-}
-
-// Op2 pre-split by its PRODUCER and laid out in MFMA-fragment order (the Winograd kernel transform writes U / Urot this way once per
-// layer and step, winograd.hip wino_weight_frag_body; rn_x3_pack_bfrag for stand-alone products): per batch matrix
-//     [n block nb = n / 32][k step kk = k / 16][plane p < 3][lane l < 64][8 bf16]       (6 bytes per element, K % 16 == 0, n padded to 32)
-// with lane l holding column n = 32 nb + (l & 31) at k = 16 kk + 8 (l >> 5) .. + 7 -- what lane l feeds v_mfma_f32_32x32x16_bf16 as
-// its B operand is ONE 16-byte global load (1 KB contiguous per wave and fragment; L2-resident: every m-tile of a batch re-reads
-// the same 48 KB per column block) straight into the registers the instruction reads.  Against the LDS route that removes, per
-// K-step of a 128 x 128 tile and thread: the split of 16 elements (~90 VALU operations), 6 ds_write_b128 and 48 ds_read_b32 (the
-// k-strided operand's fragments are dword gathers), and half of the block's LDS.  The fragments of K-step t + 1 are requested as
-// the matrix-core instructions of K-step t release their registers.
-struct FragB {
-  __amdgpu_buffer_rsrc_t rs;
-  unsigned base[2];       // byte offset of (column block of this wave's tile j, k step 0, plane 0, this lane); OOB past the last block
-  int ks16;
-  template <int WT>
-  __device__ __forceinline__ void init(const X3Args& a, int batch, int n0, int wn, int lane) {
-    rs = make_rsrc(static_cast<const char*>(a.bfrag) + (size_t)batch * a.bfrag_bstride, (unsigned)a.b_nblk * (unsigned)a.b_ks16 * 3072u);
-    ks16 = a.b_ks16;
-#pragma unroll
-    for (int j = 0; j < WT; ++j) {
-      const int nb = (n0 >> 5) + wn * WT + j;
-      base[j] = nb < a.b_nblk ? ((unsigned)nb * (unsigned)a.b_ks16 * 192u + (unsigned)lane) * 16u : OOB;
-    }
-  }
-  // the three planes of (tile column block j, 16-k step kk); steps past K: zeros (out of the descriptor's range)
-  __device__ __forceinline__ void load(int j, int kk, bf16x8 (&f)[3]) const {
-    const unsigned vo = (kk < ks16 && base[j] != OOB) ? base[j] + (unsigned)kk * 3072u : OOB;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) f[p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, p * 1024, 0));
-  }
-};
+#include "x3_tiles.h"
 
 // Block tile (64 WT) x (64 WT) x 32, 4 waves as 2 x 2, each wave WT x WT MFMA tiles of 32 x 32.  WT = 2 (128 x 128) halves
 // the LDS traffic and the split's VALU work per matrix-core instruction (the 64 x 64 tile is bound by their SUM: 28 us for the
@@ -185,17 +37,14 @@ struct FragB {
 // DBG: the leave-one-out timing aid (RN_X3_DBG, wrong results) as its own instantiation -- in the production kernel (DBG = false)
 // the K-step is ONE basic block: run-time tests between its phases would keep the scheduler from moving the next step's fragment
 // reads and the global loads in between the matrix-core instructions.
-// B_FRAG: Op2 from the pre-split fragment-ordered image (FragB; B_KS then only names the instantiation: forward / data gradient).
-template <bool A_KS, bool B_KS, int WT, int NST, bool DBG = false, bool B_FRAG = false>
+template <bool A_KS, bool B_KS, int WT, int NST, bool DBG = false>
 __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Args a) {
   const int dbg = DBG ? a.dbg : 0;
   constexpr int ROWS = 64 * WT;
   typedef TileGeom<ROWS> G;
-  // (B_FRAG: the A planes only -- or the epilogue's staging area, 4 waves x 32 rows x 68 floats, where that is larger)
-  constexpr int LDS_HALFS = B_FRAG ? (WT == 2 && 3 * G::PLANE < 4 * 32 * 68 * 2 ? 4 * 32 * 68 * 2 : 3 * G::PLANE) : 6 * G::PLANE;
-  __shared__ __attribute__((aligned(16))) unsigned short lds[LDS_HALFS];
+  __shared__ __attribute__((aligned(16))) unsigned short lds[6 * G::PLANE];
   unsigned short* At = lds;
-  unsigned short* Bt = lds + (B_FRAG ? 0 : 3 * G::PLANE);
+  unsigned short* Bt = lds + 3 * G::PLANE;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int bid = rn::xcd_remap(blockIdx.x, gridDim.x);
@@ -209,27 +58,17 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
   const float* pb = a.b.p + (size_t)batch * a.b.bstride;
   // (the descriptor covers the whole batch matrix: rows x ld for KC, K x ld for KS)
   const __amdgpu_buffer_rsrc_t ra = make_rsrc(pa, (unsigned)(A_KS ? a.K : a.a.rows) * (unsigned)a.a.ld * 4u);
-  const __amdgpu_buffer_rsrc_t rb = make_rsrc(pb, B_FRAG ? 0u : (unsigned)(B_KS ? a.K : a.b.rows) * (unsigned)a.b.ld * 4u);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(pb, (unsigned)(B_KS ? a.K : a.b.rows) * (unsigned)a.b.ld * 4u);
   TileLoad<A_KS, ROWS> la[NST];
-  TileLoad<B_KS, ROWS> lb[B_FRAG ? 1 : NST];
-  FragB fragb;
-  bf16x8 fbq[2][WT][3];                       // B_FRAG: the fragments of the K-step at hand (16-k halves s = 0, 1), refilled in place
+  TileLoad<B_KS, ROWS> lb[NST];
   f32x16 acc[WT][WT];
   zero_acc<WT, WT>(acc);
   const int nk = (kend - kbeg + XK - 1) / XK;
-  const int kk0 = kbeg >> 4;                  // (B_FRAG launches have one k range: kbeg = 0)
-  if constexpr (B_FRAG) {
-    fragb.template init<WT>(a, batch, n0, wn, lane);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int j = 0; j < WT; ++j) fragb.load(j, kk0 + s, fbq[s][j]);
-  }
 #pragma unroll
   for (int st = 0; st < NST; ++st)
     if (st < nk) {
       la[st].load(ra, a.a, m0, kbeg + st * XK, kend, t);
-      if constexpr (!B_FRAG) lb[st].load(rb, a.b, n0, kbeg + st * XK, kend, t);
+      lb[st].load(rb, a.b, n0, kbeg + st * XK, kend, t);
     }
   for (int it0 = 0; it0 < nk; it0 += NST) {
 #pragma unroll
@@ -238,12 +77,12 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
       if (it < nk) {                         // (block-uniform)
         if (!(dbg & 2)) {
           la[st].store(At, t);
-          if constexpr (!B_FRAG) lb[st].store(Bt, t);
+          lb[st].store(Bt, t);
         }
         __syncthreads();
         if (it + NST < nk && !(dbg & 4)) {
           la[st].load(ra, a.a, m0, kbeg + (it + NST) * XK, kend, t);
-          if constexpr (!B_FRAG) lb[st].load(rb, a.b, n0, kbeg + (it + NST) * XK, kend, t);
+          lb[st].load(rb, a.b, n0, kbeg + (it + NST) * XK, kend, t);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -254,8 +93,7 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
 #pragma unroll
               for (int p = 0; p < 3; ++p) {
                 fa[i][p] = fragment<A_KS, ROWS>(At, p, (wm * WT + i) * 32 + r, h, s);
-                if constexpr (B_FRAG) fb[i][p] = fbq[s][i][p];
-                else fb[i][p] = fragment<B_KS, ROWS>(Bt, p, (wn * WT + i) * 32 + r, h, s);
+                fb[i][p] = fragment<B_KS, ROWS>(Bt, p, (wn * WT + i) * 32 + r, h, s);
               }
           } else {
 #pragma unroll
@@ -275,13 +113,6 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
             }
-          // the same half of the NEXT K-step into the registers just read (past the last step: out of range, zeros, no traffic)
-          if constexpr (B_FRAG) {
-            if (!(dbg & 4)) {
-#pragma unroll
-              for (int j = 0; j < WT; ++j) fragb.load(j, it + 1 < nk ? kk0 + 2 * (it + 1) + s : 0x7fffffff, fbq[s][j]);
-            }
-          }
         }
         __syncthreads();
       }
@@ -364,30 +195,6 @@ __global__ __launch_bounds__(XT, WT == 2 ? 2 : 4) void gemm_x3_kernel(const X3Ar
 // for the head-tower product, 54.5 against 52.1 for the backward pair, the step unchanged (499.9 vs 499.9 images/s).  What DID
 // help (round 6): the leave-one-out switches (RN_X3_DBG) are a template parameter now -- as run-time tests they split the K-step
 // into basic blocks the scheduler could not move fragment reads and global loads across.
-// fp32 B_b ([K][N], or [N][K] when b_nk) -> its fragment image (FragB): stand-alone products (tests, bench.py, tools); inside the
-// network the Winograd kernel transform writes the image itself.  One thread per dword (two consecutive k of one column).
-__global__ __launch_bounds__(256) void pack_bfrag_kernel(const float* __restrict__ B, unsigned* __restrict__ out, int K, int N, int b_nk,
-                                                         int ks16, long total) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
-  const long blk = i >> 8;
-  const int kk = (int)(blk % ks16), nb = (int)(blk / ks16);
-  const int n = nb * 32 + (lane & 31), k = kk * 16 + (lane >> 5) * 8 + 2 * j;
-  const float* Bb = B + (size_t)blockIdx.y * K * N;
-  float v0 = 0.f, v1 = 0.f;
-  if (n < N) {
-    v0 = b_nk ? Bb[(size_t)n * K + k] : Bb[(size_t)k * N + n];
-    v1 = b_nk ? Bb[(size_t)n * K + k + 1] : Bb[(size_t)(k + 1) * N + n];
-  }
-  unsigned h0[3], h1[3];
-  split3(v0, h0[0], h0[1], h0[2]);
-  split3(v1, h1[0], h1[1], h1[2]);
-  unsigned* o = out + (size_t)blockIdx.y * (size_t)(total / 256) * 768 + (size_t)blk * 768 + lane * 4 + j;
-#pragma unroll
-  for (int p = 0; p < 3; ++p) o[p * 256] = pack_hi(h0[p], h1[p]);
-}
-
 int g_mode = -1;
 int mode() {
   if (g_mode < 0) {
@@ -422,20 +229,6 @@ int launch(X3Args a, bool a_ks, bool b_ks, int rows, hipStream_t st, unsigned ld
     else if (!a_ks && !b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, false, WT_, NST_>), grid, dim3(XT), 0, st, a);     \
     else hipLaunchKernelGGL((gemm_x3_kernel<true, false, WT_, NST_>), grid, dim3(XT), 0, st, a);                          \
   } while (0)
-  if (a.bfrag) {                // Op2 pre-split in fragment order (launch_batched_gemm_x3_bfrag): Op1 k-contiguous, one k range
-    if (rows == 128 && dbg) {
-      if (b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, true, 2, 2, true, true>), grid, dim3(XT), 0, st, a);
-      else hipLaunchKernelGGL((gemm_x3_kernel<false, false, 2, 2, true, true>), grid, dim3(XT), 0, st, a);
-    } else if (rows == 128) {
-      if (b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, true, 2, 2, false, true>), grid, dim3(XT), 0, st, a);
-      else hipLaunchKernelGGL((gemm_x3_kernel<false, false, 2, 2, false, true>), grid, dim3(XT), 0, st, a);
-    } else {
-      if (b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, true, 1, 3, false, true>), grid, dim3(XT), 0, st, a);
-      else hipLaunchKernelGGL((gemm_x3_kernel<false, false, 1, 3, false, true>), grid, dim3(XT), 0, st, a);
-    }
-    RN_LAUNCH_CHECK();
-    return RN_OK;
-  }
   if (rows == 128 && dbg) {     // (the timing aid measures the head-tower configuration)
     if (a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<true, true, 2, 2, true>), grid, dim3(XT), lds_pad, st, a);
     else if (!a_ks && b_ks) hipLaunchKernelGGL((gemm_x3_kernel<false, true, 2, 2, true>), grid, dim3(XT), 0, st, a);
@@ -490,38 +283,8 @@ int launch_batched_gemm_x3(const float* A, const float* B, float* C, int M, int 
   return launch(a, false, b_nk == 0, tile_rows(M, N, nbatch), st);
 }
 
-// ---- Op2 pre-split in fragment order (FragB above) ----
-static int g_bfrag = -1;
-int bfrag_on() {
-  if (g_bfrag < 0) g_bfrag = !(getenv("RN_X3_BFRAG") && atoi(getenv("RN_X3_BFRAG")) == 0);
-  return g_bfrag;
-}
-void set_bfrag(int on) { g_bfrag = on ? 1 : 0; }
-// (k in whole 16-steps; the columns are padded to whole 32-blocks inside the image)
-// (the M-independent half: which FORMAT a [K x N] kernel operand has under the current switches)
-bool x3_bfrag_format(int K, int N) { return mode() == 1 && bfrag_on() && K >= 16 && K % 16 == 0 && N >= 4 && N % 4 == 0 && fits(x3_bfrag_bytes(K, N) / 4); }
-bool x3_bfrag_ok(int M, int K, int N) { return x3_bfrag_format(K, N) && gemm_x3_ok(M, K, N); }
-size_t x3_bfrag_bytes(int K, int N) { return (size_t)rn::ceil_div(N, 32) * (size_t)(K / 16) * 3072u; }
-// C_b [M x N] = A_b [M x K] * B_b, B_b given as its fragment image (`fwd_name`: which of the two identical instantiations runs --
-// the profiler then tells forward products from data-gradient products by name)
-int launch_batched_gemm_x3_bfrag(const float* A, const void* Bfrag, float* C, int M, int K, int N, int nbatch, int fwd_name, hipStream_t st) {
-  X3Args a = {};
-  a.a = {A, (long)M * K, K, M};
-  a.b = {nullptr, 0, N, N};
-  a.bfrag = Bfrag; a.bfrag_bstride = (long)x3_bfrag_bytes(K, N); a.b_nblk = rn::ceil_div(N, 32); a.b_ks16 = K / 16;
-  a.c = C; a.c_bstride = (long)M * N; a.c_sstride = 0; a.ldc = N;
-  a.K = K; a.chunk = rn::ceil_div(K, XK) * XK; a.nsplit = 1; a.nbatch = nbatch;
-  return launch(a, false, fwd_name != 0, tile_rows(M, N, nbatch), st);
-}
-
-int launch_pack_bfrag(const float* B, void* out, int K, int N, int nbatch, int b_nk, hipStream_t st) {
-  const int ks16 = K / 16;
-  const long total = (long)rn::ceil_div(N, 32) * ks16 * 256;
-  hipLaunchKernelGGL(pack_bfrag_kernel, dim3((unsigned)rn::ceil_div64(total, 256), (unsigned)nbatch), dim3(256), 0, st, B, (unsigned*)out, K, N, b_nk,
-                     ks16, total);
-  RN_LAUNCH_CHECK();
-  return RN_OK;
-}
+int x3_tile_rows(long rows_a, long rows_b, long batches) { return tile_rows(rows_a, rows_b, batches); }
+bool x3_fits(long elems) { return fits(elems); }
 
 // ---- dense 1x1 / stride-1 convolutions as plain products (round 6: the ResNeXt / DenseNet bottleneck 1x1 convs and the FPN laterals,
 // resnet.py:38-49,67-69, densenet.py:61-66,137-142, retinanet.py:127-133,195-201): y [M x Cout] = x [M x Cin] W [Cin x Cout], x a
@@ -617,19 +380,3 @@ extern "C" int rn_set_product_mode(int mode_) {
 }
 extern "C" int rn_get_product_mode(void) { return rn::product_mode(); }
 
-extern "C" int rn_set_x3_bfrag(int on) {
-  rn::set_bfrag(on);
-  return RN_OK;
-}
-extern "C" int rn_get_x3_bfrag(void) { return rn::bfrag_on(); }
-extern "C" int rn_x3_bfrag_ok(int M, int K, int N) { return rn::x3_bfrag_ok(M, K, N) ? 1 : 0; }
-extern "C" size_t rn_x3_bfrag_bytes(int K, int N, int nbatch) { return (K > 0 && N > 0 && nbatch > 0 && K % 16 == 0) ? rn::x3_bfrag_bytes(K, N) * (size_t)nbatch : 0; }
-extern "C" int rn_x3_pack_bfrag(const float* B, void* out, int K, int N, int nbatch, int b_nk, rn_stream_t stream) {
-  RN_CHECK_ARG(B && out && K >= 16 && K % 16 == 0 && N >= 1 && nbatch >= 1 && nbatch <= 65535, "x3 pack: bad argument");
-  return rn::launch_pack_bfrag(B, out, K, N, nbatch, b_nk, (hipStream_t)stream);
-}
-extern "C" int rn_gemm_batched_bfrag(const float* A, const void* Bfrag, float* C, int M, int K, int N, int nbatch, int fwd_name, rn_stream_t stream) {
-  RN_CHECK_ARG(A && Bfrag && C && nbatch >= 1, "gemm bfrag: bad argument");
-  RN_UNSUPPORTED(!rn::x3_bfrag_ok(M, K, N), "gemm bfrag: [%d x %d] x [%d x %d] cannot take a fragment-ordered operand (mode / RN_X3_BFRAG / K %% 16)", M, K, K, N);
-  return rn::launch_batched_gemm_x3_bfrag(A, Bfrag, C, M, K, N, nbatch, fwd_name, (hipStream_t)stream);
-}

@@ -56,10 +56,12 @@ void set_product_mode(int m);
 bool gemm_x3_ok(int M, int K, int N);
 int launch_batched_gemm_x3(const float* A, const float* B, float* C, int M, int K, int N, int nbatch, int b_nk, hipStream_t st);
 size_t batched_gemm_tn_workspace_x3(int M, int K, int N, int nbatch);
-// Op2 pre-split into three bf16 planes in MFMA-fragment order by its producer (gemm_x3.hip FragB; RN_X3_BFRAG=0 / rn_set_x3_bfrag(0): off):
+// Op2 pre-split into three bf16 planes in MFMA-fragment order by its producer (gemm_x3_bfrag.hip FragB; RN_X3_BFRAG=0 / rn_set_x3_bfrag(0): off):
 // the Winograd kernel transform writes U / Urot that way, the product kernel loads its B fragments straight from global memory
 bool x3_bfrag_ok(int M, int K, int N);
 bool x3_bfrag_format(int K, int N);             // the M-independent half of x3_bfrag_ok
+int x3_tile_rows(long rows_a, long rows_b, long batches);      // (gemm_x3.hip's tile choice / size limit, for gemm_x3_bfrag.hip)
+bool x3_fits(long elems);
 size_t x3_bfrag_bytes(int K, int N);            // per batch matrix
 int bfrag_on();
 void set_bfrag(int on);

@@ -339,7 +339,7 @@ __device__ __forceinline__ void wino_weight_body(const float* __restrict__ w, fl
   }
 }
 
-// The same transform written as the forward product kernel's pre-split B operand (gemm_x3.hip FragB: three bf16 planes in
+// The same transform written as the forward product kernel's pre-split B operand (gemm_x3_bfrag.hip FragB: three bf16 planes in
 // MFMA-fragment order, [n block][16-k step][plane][lane][8 bf16]; B(k = ci, n = co)) instead of fp32 [xi][cin][cout].
 // One thread per dword = two consecutive k of one column n, for all (M+2)^2 points and the three planes; a wave covers 16 columns x
 // 4 k-pairs, so each of its stores fills sixteen whole 16-byte lane slots (256 contiguous bytes).  Threads of padding columns
@@ -507,7 +507,7 @@ int width_for(int64_t tiles, int c) {
   } while (0)
 
 // bytes of the forward pass's transformed kernel U (p2 points) in the workspace: fp32 [p2][cin][cout], or the forward product
-// kernel's pre-split fragment image (6 bytes per element, the columns padded to 32: gemm_x3.hip FragB) -- whichever the run-time
+// kernel's pre-split fragment image (6 bytes per element, the columns padded to 32: gemm_x3_bfrag.hip FragB) -- whichever the run-time
 // switches pick, the region holds either
 size_t u_bytes(size_t p2, int cin, int cout) {
   size_t b = (size_t)cin * cout * 4;

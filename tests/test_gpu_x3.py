@@ -292,7 +292,7 @@ np.save(sys.argv[2], np.stack([y.cpu().numpy(), z.cpu().numpy()]))
     assert np.isfinite(outs[0]).all() and abs(float(outs[0][1].mean())) < 1e-3       # (the normalised output: zero mean per group)
 
 
-# ---- the kernel operand pre-split in fragment order by its producer (gemm_x3.hip FragB, include/rn_hip.h rn_x3_*bfrag*) ----
+# ---- the kernel operand pre-split in fragment order by its producer (gemm_x3_bfrag.hip FragB, include/rn_hip.h rn_x3_*bfrag*) ----
 @pytest.fixture()
 def bfrag_switch():
     import _rn

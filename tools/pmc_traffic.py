@@ -9,9 +9,9 @@ import re
 import sys
 from collections import defaultdict
 
-# product mode 1 (split bf16, csrc/gemm_x3.hip): forward = <false, true, ...>, backward = data gradient <false, false, ...> +
+# product mode 1 (split bf16, csrc/gemm_x3.hip / gemm_x3_bfrag.hip): forward = gemm_x3_bfrag_kernel<true, ...> (or gemm_x3_kernel<false, true, ...> with RN_X3_BFRAG=0), backward = data gradient <false, false, ...> +
 # weight gradient <true, true, ...> (two launches); product mode 0: the fp32 matrix-core kernels
-KERNELS_X3 = {"fwd_products": ("gemm_x3_kernel<false, true",), "bwd_products": ("gemm_x3_kernel<false, false", "gemm_x3_kernel<true, true"),
+KERNELS_X3 = {"fwd_products": ("gemm_x3_kernel<false, true", "gemm_x3_bfrag_kernel<true"), "bwd_products": ("gemm_x3_kernel<false, false", "gemm_x3_kernel<true, true"),
               "group_norm": ("stem_conv_fwd_kernel", "gn_apply_rows_kernel")}
 KERNELS_F32 = {"fwd_products": ("conv_fwd_kernel",), "bwd_products": ("conv_bwd_kernel",),
                "group_norm": ("stem_conv_fwd_kernel", "gn_apply_rows_kernel")}

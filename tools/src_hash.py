@@ -6,7 +6,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the product kernels of the Winograd layers (gemm_x3: split-bf16, conv_gemm: fp32 matrix cores), their callers, the stem + apply pass
-FILES = ("gemm_x3.hip", "conv_gemm.hip", "conv_tiles.h", "winograd.hip", "group_norm.hip", "rn_common.h")
+FILES = ("gemm_x3.hip", "gemm_x3_bfrag.hip", "x3_tiles.h", "conv_gemm.hip", "conv_tiles.h", "winograd.hip", "group_norm.hip", "rn_common.h")
 
 
 def kernel_source_hash():
