@@ -48,7 +48,7 @@ typedef struct rn_reduce_list rn_reduce_list;
 
 /* Version of this header's ABI: bumped whenever an entry point's arguments or a struct layout change.  rn_version() returns
  * the value the library was built with; a caller built against another value must not call anything else. */
-#define RN_API_VERSION 406
+#define RN_API_VERSION 407
 int rn_version(void);
 const char* rn_last_error(void);
 
@@ -284,8 +284,15 @@ typedef struct rn_f16_fold {
   const float* in_mean; const float* in_rstd; const float* in_gamma; const float* in_beta;
   int in_groups; int in_act;
   float* partial;
+  /* several segments in one launch (the head towers' pyramid levels, retinanet.py:37-62,85-106; output side only): `partial` is ONE
+   * array [2][total_chunks][cout]; segment s writes its rows (n_s x tiles per sample, rn_conv2d_f16_stats_tiles) from row
+   * seg_chunk_start[s] on; a segment with 0 tiles per sample (its m-tiles straddle samples) writes none.  NULL: one segment, as above. */
+  const int32_t* seg_chunk_start;
+  int32_t total_chunks;
 } rn_f16_fold;
 int rn_conv2d_f16_fold_rows(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g);
+/* m-tiles per sample each segment of such a launch would write statistics rows for (0: none) */
+int rn_conv2d_f16_stats_tiles(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int32_t* tiles_per_sample);
 int rn_conv2d_fwd_f16_fold(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const rn_f16_fold* fold, rn_stream_t stream);
 /* mean / rstd [n][groups] from the partial sums above (fp64, fixed order); hw = oh * ow */
 int rn_group_norm_finalize(const float* partial, int n, int rows_per_sample, int hw, int c, int groups, float eps, float* mean,
@@ -406,6 +413,13 @@ int rn_group_norm_rows_ok(int c, int groups, int rows_per_sample, int per_group)
 size_t rn_group_norm_workspace(const rn_gn_seg* segs, int nseg, const rn_gn_params* p);
 int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, const float* gamma,
                       const float* beta, void* workspace, size_t workspace_bytes, rn_stream_t stream);
+/* fp16 inference, several segments (the head towers' pyramid levels: the GroupNorm + activation behind the tower convs of
+ * retinanet.py:37-62,85-106): y = act(GN(x)) with the statistics taken from the conv's epilogue rows (rn_conv2d_fwd_f16_fold with
+ * seg_chunk_start; `partial` and `tiles_per_sample` as there / as rn_conv2d_f16_stats_tiles returned them) instead of a pass over x;
+ * a segment with 0 tiles per sample (<= 4096 pixels per sample) is summed from x by the finalise blocks.  fp16 x and y, dense,
+ * c % 64 == 0, no dropout, no residual.  Two launches (finalise, apply). */
+int rn_group_norm_fwd_f16_tiles(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, const float* gamma, const float* beta,
+                                const float* partial, const int32_t* tiles_per_sample, rn_stream_t stream);
 /* dgamma/dbeta [c] are OVERWRITTEN with the sum over all segments. */
 int rn_group_norm_bwd(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, const float* gamma,
                       const float* beta, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,

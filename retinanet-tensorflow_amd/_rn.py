@@ -19,7 +19,7 @@ LOSS_MODE = {"bce_dice": 0, "focal": 1}
 OPT = {"momentum": 0, "rmsprop": 1, "adam": 2}
 OPT_BLOCK = 1024
 LOSS_STATS_HEADER = 8
-API_VERSION = 406        # RN_API_VERSION of include/rn_hip.h these bindings were written against
+API_VERSION = 407        # RN_API_VERSION of include/rn_hip.h these bindings were written against
 
 
 class RnError(RuntimeError):
@@ -107,7 +107,8 @@ class GnResidualNorm(C.Structure):
 class F16Fold(C.Structure):
     """rn_f16_fold"""
     _fields_ = [("in_mean", C.c_void_p), ("in_rstd", C.c_void_p), ("in_gamma", C.c_void_p), ("in_beta", C.c_void_p),
-                ("in_groups", C.c_int32), ("in_act", C.c_int32), ("partial", C.c_void_p)]
+                ("in_groups", C.c_int32), ("in_act", C.c_int32), ("partial", C.c_void_p),
+                ("seg_chunk_start", C.c_void_p), ("total_chunks", C.c_int32)]
 
 
 class MbRows(C.Structure):
@@ -185,6 +186,7 @@ SYMBOLS = [
     "rn_mb_rows_max", "rn_mb_compact_rows_layout", "rn_mb_compact_rows", "rn_mb_pointwise_rows", "rn_mb_pointwise_fwd", "rn_mb_depthwise_rows", "rn_mb_depthwise_fwd", "rn_mb_apply",
     "rn_mb_resident_sync_bytes", "rn_mb_resident_rows", "rn_mb_resident_fwd", "rn_set_product_mode", "rn_get_product_mode",
     "rn_set_x3_bfrag", "rn_get_x3_bfrag", "rn_x3_bfrag_ok", "rn_x3_bfrag_bytes", "rn_x3_pack_bfrag", "rn_gemm_batched_bfrag", "rn_conv3x3_winograd_gn_u_bytes", "rn_conv3x3_winograd_gn_weights",
+    "rn_conv2d_f16_stats_tiles", "rn_group_norm_fwd_f16_tiles",
     "rn_mb_pointwise_bwd_rows", "rn_mb_pointwise_bwd_workspace", "rn_mb_pointwise_bwd",
     "rn_mb_depthwise_bwd_rows", "rn_mb_depthwise_bwd_workspace", "rn_mb_depthwise_bwd",
     "rn_debug_collective_standin", "rn_optimizer_norm_pairs", "rn_optimizer_step_norm", "rn_norm_reg_finalize",
@@ -263,6 +265,8 @@ def lib():
         L.rn_winograd_bwd_products.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_int] * 3 + \
                                               [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_x3_bfrag_ok.argtypes = [C.c_int] * 3
+        L.rn_conv2d_f16_stats_tiles.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.rn_group_norm_fwd_f16_tiles.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rn_conv3x3_winograd_gn_u_bytes.argtypes = [C.c_int] * 3
         L.rn_conv3x3_winograd_gn_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.rn_x3_bfrag_bytes.argtypes = [C.c_int] * 3

@@ -30,6 +30,9 @@ struct SegH {
   const _Float16* x; const _Float16* wt; const float* bias; void* y;
   const _Float16* wf;   // the kernel once more in MFMA-fragment order (frag_offset_halfs behind wt), nullptr when K % 16 != 0
   int n, h, w, oh, ow, cout, pad_t, pad_l, m, tiles_n, start, x_ld, x_coff;
+  // FOUT kernels: this segment's (m-tile, channel) statistic rows -- row `tile_m` of [2][prows][cout] (the second half prows * cout
+  // floats behind the first); nullptr: the segment emits none (its tiles straddle samples: the caller takes them from the tensor)
+  float* partial; int prows;
 };
 // rn_f16_fold on the device: the GroupNorm in FRONT of the conv applied to the A operand between the global load and the LDS
 // store (x holds the raw output of the previous conv), and / or the statistics of the GroupNorm BEHIND the conv from the
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
       }
       if (ps + 1 < PASSES) __syncthreads();
     }
-    if (FOUT) {            // the two lane halves, then the WM wave rows -> one (sum, sum of squares) per column of the tile
+    if (FOUT && sg.partial != nullptr) {   // the two lane halves, then the WM wave rows -> one (sum, sum of squares) per column of the tile
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         st1[tn] += __shfl_xor(st1[tn], 32, 64);
@@ -589,9 +592,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_f16_kernel(const ArgsH args)
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int w_ = 0; w_ < WM; ++w_) { t1 += sred[(w_ * BN + tid) * 2 + 0]; t2 += sred[(w_ * BN + tid) * 2 + 1]; }
-        float* p1 = args.fold.partial + (size_t)tile_m * cout + n0 + tid;
+        float* p1 = sg.partial + (size_t)tile_m * cout + n0 + tid;
         p1[0] = t1;
-        p1[(size_t)args.fold.prows * cout] = t2;
+        p1[(size_t)sg.prows * cout] = t2;
       }
     }
     return;
@@ -923,7 +926,7 @@ namespace {
 // fold == nullptr: the plain convolution.  rows_out != nullptr: dry run -- *rows_out = m-tile rows per sample the statistics
 // would take (0: this shape cannot fold), nothing is launched.
 int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int out_f32, const rn_f16_fold* fold, int* rows_out,
-                  rn_stream_t stream) {
+                  rn_stream_t stream, int* tiles_out = nullptr) {
   RN_CHECK_ARG(segs && g && nseg >= 1 && nseg <= RN_MAX_SEG, "conv f16: bad segments");
   RN_CHECK_ARG(g->kh >= 1 && g->kw >= 1 && g->stride >= 1 && g->cin >= 1, "conv f16: bad geometry");
   const int G = g->groups > 1 ? g->groups : 1;
@@ -1041,7 +1044,23 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
     a.a_nt = once && (nt_mode >= 0 ? nt_mode != 0 : bytes >= 33554432.0);
   }
   int fbits = 0;
-  if (fold || rows_out) {
+  if (tiles_out || (fold && fold->seg_chunk_start)) {
+    // Several segments (the head towers' pyramid levels in one launch), output statistics only: every segment whose m-tiles lie
+    // inside one sample writes its rows into ONE array [2][total_chunks][cout] at its own first row (seg_chunk_start[s]; its
+    // rows: sample-major, tiles_out[s] per sample); a segment whose tiles straddle samples (P7: 64 pixels per sample) gets 0.
+    RN_UNSUPPORTED(out_f32 || (cout_g & 7) != 0 || G != 1, "conv f16 stats: fp16 output, cout %% 8 == 0, no groups");
+    RN_UNSUPPORTED(fold && fold->in_mean, "conv f16 stats: several segments fold the output side only");
+    for (int s = 0; s < nseg; ++s) {
+      SegH& d = a.seg[s];
+      const int ohw = d.oh * d.ow, t = ohw % kCfgs[c].bm == 0 ? ohw / kCfgs[c].bm : 0;
+      if (tiles_out) { tiles_out[s] = t; continue; }
+      RN_CHECK_ARG(d.bias == nullptr && fold->partial && fold->total_chunks >= 1, "conv f16 stats: bias-free conv, a partial array");
+      d.partial = t ? fold->partial + (size_t)fold->seg_chunk_start[s] * d.cout : nullptr;
+      d.prows = fold->total_chunks;
+    }
+    if (tiles_out) return RN_OK;
+    fbits = 2;
+  } else if (fold || rows_out) {
     // a tile's rows must lie inside one sample, the fp16 staged epilogue must be the one that runs, one segment
     const SegH& d = a.seg[0];
     const int ohw = d.oh * d.ow;
@@ -1063,6 +1082,7 @@ int conv_f16_impl(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int 
     if (fold->partial) {
       RN_CHECK_ARG(d.bias == nullptr, "conv f16 fold: the statistics are those of a bias-free conv (the GroupNorm behind it absorbs a bias)");
       a.fold.partial = fold->partial; a.fold.prows = d.n * (ohw / kCfgs[c].bm);
+      a.seg[0].partial = fold->partial; a.seg[0].prows = a.fold.prows;
       fbits |= 2;
     }
   }
@@ -1133,6 +1153,11 @@ extern "C" int rn_conv2d_f16_fold_rows(const rn_conv_seg* segs, int nseg, const 
   int rows = 0;
   if (conv_f16_impl(segs, nseg, g, 0, nullptr, &rows, nullptr) != RN_OK) return 0;
   return rows;
+}
+
+extern "C" int rn_conv2d_f16_stats_tiles(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, int32_t* tiles_per_sample) {
+  RN_CHECK_ARG(tiles_per_sample, "conv f16 stats tiles: null argument");
+  return conv_f16_impl(segs, nseg, g, 0, nullptr, nullptr, nullptr, tiles_per_sample);
 }
 
 extern "C" int rn_conv2d_fwd_f16_fold(const rn_conv_seg* segs, int nseg, const rn_conv_geom* g, const rn_f16_fold* fold, rn_stream_t stream) {

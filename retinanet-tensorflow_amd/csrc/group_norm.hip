@@ -204,6 +204,10 @@ __global__ __launch_bounds__(T) void gn_finalize_cols_segs_kernel(const GnArgs a
   const float* __restrict__ p1 = a.partial + (size_t)(sg.chunk_start + nl * rows) * a.c + slab * 64 + cl;
   const float* __restrict__ p2 = p1 + (size_t)a.total_chunks * a.c;
   double s1 = 0.0, s2 = 0.0;
+  if (rows == 0) {       // rn_group_norm_fwd_f16_tiles: a segment nobody wrote rows for (a small map): the sums straight from the fp16 tensor
+    const _Float16* __restrict__ x = reinterpret_cast<const _Float16*>(sg.x) + (size_t)nl * sg.hw * sg.x_ld + slab * 64 + cl;
+    for (int p = rl; p < sg.hw; p += 4) { const float f = (float)x[(size_t)p * sg.x_ld]; s1 += (double)f; s2 += (double)f * (double)f; }
+  }
   for (int r0 = rl; r0 < rows; r0 += 32) {
     float u[8], v[8];
 #pragma unroll
@@ -1703,6 +1707,42 @@ extern "C" int rn_group_norm_fwd(const rn_gn_seg* segs, int nseg, const rn_gn_pa
     }
   else
     hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(apply_blocks(a), a.total_samples), dim3(T), 0, st, a);
+  RN_LAUNCH_CHECK();
+  return RN_OK;
+}
+
+// fp16 inference, several segments: GroupNorm + activation of conv outputs whose statistics came out of the conv's epilogue
+// (rn_conv2d_fwd_f16_fold with seg_chunk_start: per (m-tile, channel) sums in `partial` [2][total rows][c], segment s at the rows
+// behind those of segments 0 .. s-1, n_s * tiles_per_sample[s] of them) -- the statistics pass over the tensors is not run; a
+// segment with tiles_per_sample[s] == 0 (a small map whose conv tiles straddle samples) is summed from its tensor by the finalise
+// blocks themselves.  Two launches: finalise, apply.
+extern "C" int rn_group_norm_fwd_f16_tiles(const rn_gn_seg* segs, int nseg, const rn_gn_params* p, const float* gamma, const float* beta,
+                                           const float* partial, const int32_t* tiles_per_sample, rn_stream_t stream) {
+  GnArgs a = {};
+  if (int e = build_args(segs, nseg, p, &a, false)) return e;
+  RN_CHECK_ARG(gamma && beta && partial && tiles_per_sample, "group_norm f16 tiles: null argument");
+  RN_UNSUPPORTED(!(a.in_half && a.out_half) || a.strided || a.c % 64 != 0 || a.cpg > 64 || 64 % a.cpg != 0 || a.drop_rate != 0.f,
+                 "group_norm f16 tiles: fp16 in and out, dense, c %% 64 == 0, whole groups per 64 channels, no dropout");
+  int chunks = 0;
+  for (int s = 0; s < nseg; ++s) {
+    GnSeg& d = a.seg[s];
+    const int t = tiles_per_sample[s];
+    RN_CHECK_ARG(t >= 0 && (t == 0 || d.hw % t == 0), "group_norm f16 tiles: segment %d: %d tiles for %d pixels", s, t, d.hw);
+    RN_UNSUPPORTED(t == 0 && d.hw > 4096, "group_norm f16 tiles: segment %d has no rows and %d pixels per sample", s, d.hw);
+    d.chunks = t; d.ppc = t ? d.hw / t : d.hw; d.chunk_start = chunks;
+    chunks += d.n * t;
+  }
+  a.total_chunks = chunks;
+  a.gamma = gamma; a.beta = beta; a.partial = const_cast<float*>(partial);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_finalize_cols_segs_kernel, dim3(a.total_samples * (a.c / 64)), dim3(T), 0, st, a);
+  switch (a.act) {
+    case RN_ACT_RELU: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_RELU>, dim3(apply_blocks(a, 8), a.total_samples), dim3(T), 0, st, a); break;
+    case RN_ACT_ELU: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_ELU>, dim3(apply_blocks(a, 8), a.total_samples), dim3(T), 0, st, a); break;
+    case RN_ACT_RELU6: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_RELU6>, dim3(apply_blocks(a, 8), a.total_samples), dim3(T), 0, st, a); break;
+    case RN_ACT_SIGMOID: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_SIGMOID>, dim3(apply_blocks(a, 8), a.total_samples), dim3(T), 0, st, a); break;
+    default: hipLaunchKernelGGL(gn_apply_f16x8_kernel<RN_ACT_NONE>, dim3(apply_blocks(a, 8), a.total_samples), dim3(T), 0, st, a); break;
+  }
   RN_LAUNCH_CHECK();
   return RN_OK;
 }

@@ -215,6 +215,73 @@ def conv2d_norm(x, w, norm, act=None, stride=1, groups=1):
     return Pending(y, mean, rstd, norm.gamma.detach(), norm.beta.detach(), gout, act)
 
 
+HEAD_EPILOGUE_STATS = os.environ.get("RN_F16_HEAD_EPILOGUE_STATS", "1") == "1"
+
+
+def conv_norm_act_levels(xs, w, norm, act=None):
+    """act(GroupNorm(conv3x3(x))) for every tensor of the list `xs` (shared kernel, no bias: the head towers' blocks on all pyramid
+    levels, retinanet.py:37-62,85-106) in THREE launches: the conv of all levels with the GroupNorm statistics of its output from its
+    epilogue (rn_conv2d_fwd_f16_fold, seg_chunk_start), finalise, apply (rn_group_norm_fwd_f16_tiles) -- the statistics pass over the
+    conv outputs (179 MB per GroupNorm at cfg 5) is not run.  A level whose conv tiles straddle samples (P7) is summed from its tensor by
+    the finalise blocks.  None: the shape does not qualify (the caller runs conv2d + group_norm_act)."""
+    if not (FOLD and HEAD_EPILOGUE_STATS):
+        return None
+    xs = [t.contiguous() for t in xs]
+    kh, kw, cin_g, cout = w.shape
+    if any(t.dtype != torch.float16 or t.shape[3] != cin_g for t in xs) or cout % 64 != 0:
+        return None
+    wt, g2, cin = packed_weight(w, 1, None)
+    L = _rn.lib()
+    n = len(xs)
+    dev = xs[0].device
+    geom = _rn.ConvGeom(kh, kw, 1, cin, g2)
+    segs = (_rn.ConvSeg * n)()
+    raws = []
+    for i, t in enumerate(xs):
+        y = torch.empty((t.shape[0], t.shape[1], t.shape[2], cout), dtype=torch.float16, device=dev)
+        raws.append(y)
+        s = segs[i]
+        s.x, s.wgt, s.y, s.bias = _rn.f16(t), _rn.f16(wt), _rn.f16(y), None
+        s.wgt_bytes = wt.numel() * 2
+        s.n, s.h, s.w, s.cout = t.shape[0], t.shape[1], t.shape[2], cout
+    tiles = (C.c_int32 * n)()
+    if L.rn_conv2d_f16_stats_tiles(segs, n, C.byref(geom), tiles) != 0 or not any(tiles[i] for i in range(n)):
+        return None
+    if any(tiles[i] == 0 and xs[i].shape[1] * xs[i].shape[2] > 4096 for i in range(n)):
+        return None
+    starts = (C.c_int32 * n)()
+    total = 0
+    for i in range(n):
+        starts[i] = total
+        total += xs[i].shape[0] * tiles[i]
+    partial = torch.empty((2, total, cout), dtype=torch.float32, device=dev)
+    fold = _rn.F16Fold()
+    fold.partial = partial.data_ptr()
+    fold.seg_chunk_start = C.cast(starts, C.c_void_p)
+    fold.total_chunks = total
+    _rn.check(L.rn_conv2d_fwd_f16_fold(segs, n, C.byref(geom), C.byref(fold), _rn.stream()), "rn_conv2d_fwd_f16_fold")
+    if norm.gamma is None:
+        norm.build(cout, dev)
+    g = gn_groups(cout, norm.groups)
+    gsegs = (_rn.GnSeg * n)()
+    ys, keep = [], []
+    for i, t in enumerate(raws):
+        y = torch.empty_like(t)
+        mean = torch.empty((t.shape[0], g), dtype=torch.float32, device=dev)
+        rstd = torch.empty((t.shape[0], g), dtype=torch.float32, device=dev)
+        keep += [mean, rstd]
+        ys.append(y)
+        s = gsegs[i]
+        s.x, s.y, s.residual = _rn.ptr(t), _rn.f16(y), None
+        s.mean, s.rstd = _rn.f32(mean), _rn.f32(rstd)
+        s.n, s.hw = t.shape[0], t.shape[1] * t.shape[2]
+    params = _rn.GnParams(c=cout, groups=g, act=_rn.ACT[act], act_after_residual=0, in_f16=1, out_f16=1, eps=float(norm.eps), drop_rate=0.0,
+                          drop_seed=0, drop_seed_dev=None)
+    _rn.check(L.rn_group_norm_fwd_f16_tiles(gsegs, n, C.byref(params), _rn.f32(norm.gamma.detach()), _rn.f32(norm.beta.detach()), partial.data_ptr(),
+                                            C.cast(tiles, C.c_void_p), _rn.stream()), "rn_group_norm_fwd_f16_tiles")
+    return ys
+
+
 def group_norm_act(x, gamma, beta, groups=32, eps=1e-5, act=None, residual=None, act_after_residual=False):
     """GroupNorm -> act (-> + residual) with fp32 or fp16 input and fp16 output/residual.  Lists allowed."""
     multi = isinstance(x, (list, tuple))

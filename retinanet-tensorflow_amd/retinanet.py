@@ -144,6 +144,21 @@ class _Subnet(Model):
             return []
         return ws
 
+    def _f16_tower_levels(self, maps):
+        """fp16 inference: the four [conv, GroupNorm, act] blocks on ALL levels, three launches per block -- the conv of every level
+        with the GroupNorm statistics from its epilogue, finalise, apply (ops_f16.conv_norm_act_levels): no statistics pass over the
+        conv outputs.  None when a block does not qualify (then the layers run one by one)."""
+        import ops_f16
+        blocks = [blk.layers for blk in self.pre_conv.layers]          # [conv, norm, act] each
+        if any(b[0].weight is None or b[0].bias is not None for b in blocks) or not all(m.dtype == torch.float16 for m in maps):
+            return None
+        cur = list(maps)
+        for conv, norm, act in blocks:
+            cur = ops_f16.conv_norm_act_levels(cur, conv.weight, norm, L.activation_name(act))
+            if cur is None:
+                return None
+        return cur
+
     def _f16_tower(self, maps):
         """fp16 inference: the four [conv, GroupNorm, act] blocks with the GroupNorm STATISTICS taken from the conv's epilogue
         (ops_f16.conv2d_norm: no statistics pass over the conv output) on the levels where that pass costs -- the large maps,
@@ -177,7 +192,9 @@ class _Subnet(Model):
         multi = isinstance(input, (list, tuple))
         out = self._folded(list(input) if multi else [input], training)
         if out is None and L.INFERENCE_F16 and not training and multi and all(torch.is_tensor(m) and m.is_cuda for m in input):
-            tower = self._f16_tower(list(input))
+            tower = self._f16_tower_levels(list(input))
+            if tower is None:
+                tower = self._f16_tower(list(input))
             if tower is not None:
                 out = list(self.out_conv(tower))
         if out is None:

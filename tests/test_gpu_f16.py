@@ -385,3 +385,48 @@ def test_apply_with_pending_residual_norm(dev, act, after):
     ref = f(gn(y, py) + gn(r, pr)) if after else f(gn(y, py)) + gn(r, pr)
     e_f = float((fused.float() - ref).abs().max()); e_t = float((two.float() - ref).abs().max())
     assert e_f <= e_t * 1.05 + 1e-6, (e_f, e_t)
+
+
+@pytest.mark.parametrize("act", ["elu", "relu"])
+@pytest.mark.parametrize("shapes", [[(3, 32, 32), (3, 16, 16), (3, 8, 8), (3, 4, 4)],        # P7-like last level: 16 pixels per sample, no rows
+                                    [(2, 64, 48), (2, 16, 16), (2, 2, 2)],
+                                    [(1, 16, 16)]])
+def test_head_tower_block_with_epilogue_statistics_on_all_levels(dev, monkeypatch, act, shapes):
+    """ops_f16.conv_norm_act_levels (round 6: the tower conv of every pyramid level in one launch with the GroupNorm statistics of its
+    output from the epilogue, finalise, apply; a level whose conv tiles straddle samples is summed from its tensor by the finalise
+    blocks) against conv2d + group_norm_act: the conv outputs are the same kernel's (bit-equal), the statistics are fp64 sums of
+    the same fp16 values in another order, so the normalised tensors agree to an fp16 rounding (1e-3 of the range); the statistics
+    themselves against fp64 sums of the conv output."""
+    import ops_f16
+    monkeypatch.setenv("RN_CONV_CFG", "5")          # the 256 x 256 tile (what the cfg-5 heads run) on these small maps
+    g = torch.Generator().manual_seed(len(shapes) * 7 + len(act))
+    c = 256
+    xs = [(torch.randn(n, h, w, c, generator=g) * 1.2 + 0.2).to(dev).half() for n, h, w in shapes]
+    wt = (torch.randn(3, 3, c, c, generator=g) / (9 * c) ** 0.5).to(dev)
+
+    class Norm(object):
+        def __init__(self):
+            self.groups, self.eps = 32, 1e-5
+            self.gamma = (1 + 0.2 * torch.randn(c, generator=g)).to(dev)
+            self.beta = (0.1 * torch.randn(c, generator=g)).to(dev)
+        def build(self, c_, d):
+            pass
+    norm = Norm()
+    got = ops_f16.conv_norm_act_levels(xs, wt, norm, act)
+    assert got is not None and len(got) == len(xs)
+    raw = ops_f16.conv2d(xs, wt)
+    want = ops_f16.group_norm_act(raw, norm.gamma, norm.beta, groups=32, eps=1e-5, act=act)
+    for i, (a, b, r) in enumerate(zip(got, want, raw)):
+        assert a.shape == b.shape and a.dtype == torch.float16
+        assert_close(a.float().cpu().numpy(), b.float().cpu().numpy(), 1e-3, "level %d" % i)
+        # ... and against an fp64 GroupNorm of the conv output itself
+        y = r.float().cpu().numpy().astype(np.float64)
+        n, h, w, _ = y.shape
+        yg = y.reshape(n, h * w, 32, c // 32)
+        mean, var = yg.mean(axis=(1, 3), keepdims=True), yg.var(axis=(1, 3), keepdims=True)
+        z = ((yg - mean) / np.sqrt(var + 1e-5)).reshape(n, h, w, c) * norm.gamma.cpu().numpy().astype(np.float64) + norm.beta.cpu().numpy().astype(np.float64)
+        z = np.where(z > 0, z, np.expm1(np.minimum(z, 0))) if act == "elu" else np.maximum(z, 0)
+        assert_close(a.float().cpu().numpy(), z.astype(np.float32), 2e-3, "level %d vs fp64" % i)
+    # switched off: the caller's fallback
+    monkeypatch.setattr(ops_f16, "HEAD_EPILOGUE_STATS", False)
+    assert ops_f16.conv_norm_act_levels(xs, wt, norm, act) is None
